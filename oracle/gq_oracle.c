@@ -1,0 +1,236 @@
+/*
+ * gq_oracle.c -- CPU restatement of the reference's HSQ / QSGD gradient
+ * quantisation hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle: a plain-C restatement of what the reference
+ * (xinyandai/gradient-quantization, Python/PyTorch) computes on this path.  It
+ * is NOT part of the product.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it; the product (gradient-quantization_amd/)
+ * never links, imports or calls anything in oracle/ and fails loudly when its
+ * HIP library is missing.
+ *
+ * Parity pin: every function here is checked against the golden vectors under
+ * tests/golden/, which were produced by importing the reference itself
+ * (tests/golden/make_golden.py) -- see tests/test_oracle_golden.py.
+ *
+ * Arithmetic contract (why this is bit-exact with torch.mm on CPU):
+ * the reference's inner products run in MKL sgemm with K = c_dim; that result
+ * is bit-identical to a single-accumulator ascending chain
+ *     acc = 0; for j = 0..d-1: acc = fmaf(c[j], v[j], acc)
+ * (re-verified by the golden tests).  Compile with
+ * -ffp-contract=off so that nothing else is fused.
+ *
+ * Build:  gcc -O2 -fPIC -shared -fopenmp -ffp-contract=off -o libgq_oracle.so gq_oracle.c -lm
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <limits.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define GQ_EXPORT __attribute__((visibility("default")))
+
+GQ_EXPORT int gq_oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+GQ_EXPORT void gq_oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/*
+ * HSQ encode.  Follows compressors/nearest_neighbor_compressor.py:63-73:
+ *   p     = mm(codewords, vec.view(-1,d).T).T         (:68)
+ *   codes = argmax(|p|, dim=1)   -- first maximum     (:69,:72)
+ *   u     = p.gather(1, codes)   -- SIGNED projection (:73)
+ * grad: [M*d] f32, codebook: [K*d] f32 row-major (already row-normalised),
+ * codes: [M] int32, u: [M] f32.
+ */
+GQ_EXPORT void gq_oracle_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, int K,
+                                    int32_t *codes, float *u) {
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        const float *v = grad + m * (int64_t)d;
+        float best_abs = -1.0f, best_p = 0.0f;
+        int32_t best_k = 0;
+        for (int k = 0; k < K; ++k) {
+            const float *c = codebook + (int64_t)k * d;
+            float acc = 0.0f;
+            for (int j = 0; j < d; ++j) acc = fmaf(c[j], v[j], acc);
+            float a = fabsf(acc);
+            /* torch.argmax: first index of the maximum; a NaN counts as the maximum */
+            if (a > best_abs || (isnan(a) && !isnan(best_abs))) {
+                best_abs = a;
+                best_p = acc;
+                best_k = k;
+            }
+        }
+        codes[m] = best_k;
+        u[m] = best_p;
+    }
+}
+
+/* torch.min / torch.max over the whole tensor
+ * (compressors/probabilistic_scalar_compressor.py:13-14).  lb_ub[0]=min, [1]=max. */
+GQ_EXPORT void gq_oracle_minmax(const float *u, int64_t M, float *lb_ub) {
+    float lo = INFINITY, hi = -INFINITY;
+    int has_nan = 0;
+    for (int64_t i = 0; i < M; ++i) {
+        float x = u[i];
+        if (isnan(x)) has_nan = 1;
+        if (x < lo) lo = x;
+        if (x > hi) hi = x;
+    }
+    if (has_nan) lo = hi = NAN;
+    lb_ub[0] = lo;
+    lb_ub[1] = hi;
+}
+
+/*
+ * Scalar (norm) quantiser.  Follows
+ * compressors/probabilistic_scalar_compressor.py:12-27:
+ *   if lb - ub == 0: levels = 0                                      (:15-16)
+ *   x = |(u - lb) / (ub - lb)| * s                                   (:17)
+ *   l = trunc(clamp(x, 0, s-1))                                      (:18)
+ *   if random: l += (x - float(l) > r)        r = torch.rand(M)      (:20-26)
+ * r may be NULL when random == 0.
+ */
+GQ_EXPORT void gq_oracle_scalar_levels(const float *u, int64_t M, int n_bit, int random, const float *r,
+                                       float lb, float ub, int32_t *levels) {
+    const float s = (float)(1 << n_bit);
+    if (lb - ub == 0.0f) {
+        memset(levels, 0, (size_t)M * sizeof(int32_t));
+        return;
+    }
+    const float range = ub - lb;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < M; ++i) {
+        float q = (u[i] - lb) / range;
+        float x = fabsf(q) * s;
+        float c = x < 0.0f ? 0.0f : (x > s - 1.0f ? s - 1.0f : x);
+        int32_t l = isnan(c) ? INT_MIN : (int32_t)c;
+        if (random) {
+            float prob = x - (float)l;
+            l += (prob > r[i]) ? 1 : 0;
+        }
+        levels[i] = l;
+    }
+}
+
+/* Scalar de-quantiser, probabilistic_scalar_compressor.py:29-33:
+ *   n = float(l) * (ub - lb) / s + lb      -- mul, then /s, then add; nothing fused */
+GQ_EXPORT void gq_oracle_scalar_decode(const int32_t *levels, int64_t M, int n_bit, float lb, float ub,
+                                       float *norms) {
+    const float s = (float)(1 << n_bit);
+    const float range = ub - lb;
+    for (int64_t i = 0; i < M; ++i) {
+        float t = (float)levels[i] * range;
+        t = t / s;
+        norms[i] = t + lb;
+    }
+}
+
+/* HSQ decode, nearest_neighbor_compressor.py:85-90:
+ *   out[m,:] = codewords[codes[m],:] * norms[m] */
+GQ_EXPORT void gq_oracle_hsq_decode(const int32_t *codes, const float *norms, const float *codebook, int64_t M,
+                                    int d, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        const float *c = codebook + (int64_t)codes[m] * d;
+        const float n = norms[m];
+        float *o = out + m * (int64_t)d;
+        for (int j = 0; j < d; ++j) o[j] = c[j] * n;
+    }
+}
+
+/*
+ * Full HSQ compress in one call (what bench.py's cpu_baseline times):
+ * encode + global min/max + levels.  Returns lb/ub through lb_ub[2].
+ */
+GQ_EXPORT void gq_oracle_hsq_compress(const float *grad, const float *codebook, int64_t M, int d, int K, int n_bit,
+                                      int random, const float *r, int32_t *codes, float *u, float *lb_ub,
+                                      int32_t *levels) {
+    gq_oracle_hsq_encode(grad, codebook, M, d, K, codes, u);
+    gq_oracle_minmax(u, M, lb_ub);
+    gq_oracle_scalar_levels(u, M, n_bit, random, r, lb_ub[0], lb_ub[1], levels);
+}
+
+/*
+ * Parameter-server aggregate, quantizers/ps_quantizer.py:48:
+ *   g = torch.stack(decoded_u, 0).mean(0)
+ * decoded: [U][n] contiguous.  Sum in user order, then divide by U.
+ */
+GQ_EXPORT void gq_oracle_mean_users(const float *decoded, int U, int64_t n, float *out) {
+    for (int64_t i = 0; i < n; ++i) {
+        float acc = decoded[i];
+        for (int k = 1; k < U; ++k) acc += decoded[(int64_t)k * n + i];
+        out[i] = acc / (float)U;
+    }
+}
+
+/*
+ * QSGD compress, compressors/qsgd_compressor.py:42-64 (bucket = `d` consecutive
+ * elements of the flattened tensor):
+ *   norm  = max |v| over the bucket                        (:49)
+ *   x     = |v / norm| * s                                 (:50,:52)
+ *   l     = trunc(clamp(x, 0, s-1))                        (:53)
+ *   l    += (x - float(l) > r)        if random            (:55-61)
+ *   signs = sign(v) > 0                                    (:63)
+ * A zero bucket gives 0/0 = NaN -> the int32 cast of NaN is INT_MIN on the
+ * reference's x86 CPU path; reproduced explicitly here.
+ */
+GQ_EXPORT void gq_oracle_qsgd_compress(const float *grad, int64_t Mb, int d, int n_bit, int random, const float *r,
+                                       float *norm, uint8_t *signs, int32_t *levels) {
+    const float s = (float)(1 << n_bit);
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < Mb; ++b) {
+        const float *v = grad + b * (int64_t)d;
+        float mx = 0.0f;
+        int has_nan = 0;
+        for (int j = 0; j < d; ++j) {
+            float a = fabsf(v[j]);
+            if (isnan(a)) has_nan = 1;
+            if (a > mx) mx = a;
+        }
+        if (has_nan) mx = NAN;
+        norm[b] = mx;
+        for (int j = 0; j < d; ++j) {
+            int64_t i = b * (int64_t)d + j;
+            float q = v[j] / mx;
+            float x = fabsf(q) * s;
+            float c = x < 0.0f ? 0.0f : (x > s - 1.0f ? s - 1.0f : x);
+            int32_t l = isnan(c) ? INT_MIN : (int32_t)c;
+            if (random) {
+                float prob = x - (float)l;
+                l += (prob > r[i]) ? 1 : 0;
+            }
+            levels[i] = l;
+            signs[i] = v[j] > 0.0f ? 1 : 0;
+        }
+    }
+}
+
+/* QSGD decompress, qsgd_compressor.py:66-71:
+ *   out = (float(l) * (2*signs - 1)) * norm / s */
+GQ_EXPORT void gq_oracle_qsgd_decompress(const float *norm, const uint8_t *signs, const int32_t *levels, int64_t Mb,
+                                         int d, int n_bit, float *out) {
+    const float s = (float)(1 << n_bit);
+    for (int64_t b = 0; b < Mb; ++b) {
+        for (int j = 0; j < d; ++j) {
+            int64_t i = b * (int64_t)d + j;
+            float sv = (float)levels[i] * (2.0f * (float)signs[i] - 1.0f);
+            float t = sv * norm[b];
+            out[i] = t / s;
+        }
+    }
+}

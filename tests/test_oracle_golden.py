@@ -1,0 +1,164 @@
+"""Pins the CPU oracle (oracle/gq_oracle.c) against golden vectors captured from
+the reference itself (tests/golden/make_golden.py imports /root/reference).
+
+Bit-exact for codes / levels / u / lb / ub / decoded; the user-mean aggregate is
+checked to 1e-6 relative L2 (north star tolerance: 1e-5)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def _cb(d, K):
+    return np.load(os.path.join(GOLDEN, "codebook_d%d_k%d_normalized.npy" % (d, K)))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+HSQ_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "hsq_*.npz")))
+QSGD_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "qsgd_*.npz")))
+PSQ_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "psq_*.npz")))
+
+
+def test_fixture_inventory():
+    assert len(HSQ_CASES) >= 20 and len(QSGD_CASES) >= 4 and len(PSQ_CASES) >= 5
+
+
+@pytest.mark.parametrize("name", HSQ_CASES)
+def test_hsq_compress_matches_reference(oracle, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d, K, n_bit, random = int(g["dim"]), int(g["K"]), int(g["n_bit"]), int(g["random"])
+    cb = _cb(d, K)
+    codes, u = oracle.hsq_encode(g["x"], cb)
+    assert np.array_equal(codes, g["codes"].astype(np.int32)), "codes differ from the reference"
+    if codes.size == 1:
+        # M == 1: torch.mm sees a [d,1] operand and dispatches to MKL *sgemv*, whose
+        # accumulation order is not the sgemm chain (measured: 69 % of products differ
+        # in the last ulp; every M >= 2 is bit-identical).  Documented deviation
+        # (DESIGN.md "Known deviations"): codes equal, u within 2 ulp.  Unreachable
+        # through PSQuantizer (tensors <= 1000 elements are identity-compressed).
+        assert abs(int(_bits(u)[0]) - int(_bits(g["u"])[0])) <= 2
+        return
+    assert np.array_equal(_bits(u), _bits(g["u"])), "projections u differ bitwise from the reference"
+    if n_bit == 32:
+        dec = oracle.hsq_decode(codes, u, cb)
+    else:
+        r = g["r"] if random else None
+        lb, ub, levels = oracle.scalar_levels(u, n_bit, random, r)
+        assert _bits(lb) == _bits(g["lb"]) and _bits(ub) == _bits(g["ub"])
+        assert np.array_equal(levels, g["levels"])
+        dec = oracle.hsq_decompress(codes, levels, lb, ub, cb, n_bit)
+    assert np.array_equal(_bits(dec), _bits(g["decoded"].reshape(-1))), "decoded tensor differs bitwise"
+
+
+def test_hsq_level_range_quirk():
+    """random=1 lets the top element reach level 2^n_bit."""
+    g = np.load(os.path.join(GOLDEN, "hsq_randn_s1_rand.npz"))
+    assert g["levels"].max() == 64 and g["levels"].min() == 0
+    g = np.load(os.path.join(GOLDEN, "hsq_randn_s1_det.npz"))
+    assert g["levels"].max() == 63
+
+
+@pytest.mark.parametrize("name", QSGD_CASES)
+def test_qsgd_matches_reference(oracle, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d, n_bit, random = int(g["dim"]), int(g["n_bit"]), int(g["random"])
+    r = g["r"] if random else None
+    norm, signs, levels = oracle.qsgd_compress(g["x"], d, n_bit, random, r)
+    assert np.array_equal(_bits(norm), _bits(g["norm"].reshape(-1)))
+    assert np.array_equal(signs.astype(bool), g["signs"].reshape(-1))
+    assert np.array_equal(levels, g["levels"].reshape(-1))
+    dec = oracle.qsgd_decompress(norm, signs, levels, d, n_bit)
+    ref = g["decoded"].reshape(-1)
+    # a zero bucket decodes to +-0 (INT_MIN * -1 * 0); compare values, not the sign of zero
+    assert np.array_equal(dec, ref)
+
+
+def _dim_for(size, c_dim):
+    """The reference's sub-dimension repair loop (nearest_neighbor_compressor.py:23-29)."""
+    if c_dim == 0 or size < c_dim:
+        return size
+    dim = c_dim
+    for _ in range(10):
+        if size % dim != 0:
+            dim = dim // 2 * 3
+    return dim
+
+
+@pytest.mark.parametrize("name", [n for n in PSQ_CASES if "qsgd" not in n])
+def test_psquantizer_matches_reference(oracle, name):
+    """Replays PSQuantizer.record/apply (quantizers/ps_quantizer.py:27-65) with the
+    oracle primitives and compares with what the reference produced."""
+    import math
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    U, epoch, steps, P = int(g["users"]), int(g["epoch"]), int(g["steps"]), int(g["n_params"])
+    ef = any(k.startswith("err_") for k in g.files)
+    two_phase = "twophase" in name
+    scale = 0.5 if "scale0.5" in name else (2 / (math.exp(-epoch) + 1) - 1)
+    cb = _cb(16, 256)
+
+    def roundtrip(x):
+        if x.size <= 1000:
+            return x.copy()
+        c = oracle.hsq_compress(x, cb, 6, 0)
+        return oracle.hsq_decompress(c["codes"], c["levels"], c["lb"], c["ub"], cb, 6).reshape(x.shape)
+
+    err = {(i, u): None for i in range(P) for u in range(U)}
+    serr = {i: None for i in range(P)}
+    for st in range(steps):
+        decoded = [[None] * U for _ in range(P)]
+        for u in range(U):
+            for i in range(P):
+                grad = g["grad_s%d_u%d_p%d" % (st, u, i)].copy()
+                if ef:
+                    e = err[(i, u)] if err[(i, u)] is not None else np.zeros_like(grad)
+                    grad = grad + np.float32(scale) * e
+                    dec = roundtrip(grad)
+                    err[(i, u)] = grad - dec
+                else:
+                    dec = roundtrip(grad)
+                decoded[i][u] = dec
+        for i in range(P):
+            agg = oracle.mean_users(np.stack(decoded[i], 0)).reshape(decoded[i][0].shape)
+            if two_phase:
+                if ef:
+                    se = serr[i] if serr[i] is not None else np.zeros_like(agg)
+                    agg = agg + se
+                    dec = roundtrip(agg)
+                    serr[i] = agg - dec
+                    agg = dec
+                else:
+                    agg = roundtrip(agg)
+            ref = g["agg_s%d_p%d" % (st, i)]
+            rel = np.linalg.norm((agg - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-30)
+            assert rel <= 1e-6, (name, st, i, rel)
+    if ef:
+        for i in range(P):
+            for u in range(U):
+                ref = g["err_p%d_u%d" % (i, u)]
+                rel = np.linalg.norm((err[(i, u)] - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-30)
+                assert rel <= 1e-5, (name, "err", i, u, rel)
+
+
+def test_mean_users_is_bit_exact_with_reference(oracle):
+    """For the non-EF single-phase case the whole aggregate is expected bit-exact."""
+    g = np.load(os.path.join(GOLDEN, "psq_fcn_u4_det.npz"))
+    cb = _cb(16, 256)
+    U, P = int(g["users"]), int(g["n_params"])
+    for i in range(P):
+        decs = []
+        for u in range(U):
+            x = g["grad_s0_u%d_p%d" % (u, i)]
+            if x.size <= 1000:
+                decs.append(x.copy())
+            else:
+                c = oracle.hsq_compress(x, cb, 6, 0)
+                decs.append(oracle.hsq_decompress(c["codes"], c["levels"], c["lb"], c["ub"], cb, 6).reshape(x.shape))
+        agg = oracle.mean_users(np.stack(decs, 0)).reshape(decs[0].shape)
+        assert np.array_equal(_bits(agg), _bits(g["agg_s0_p%d" % i]))
