@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Build libgq_hsq.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python gradient-quantization_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU
+box with the source snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libgq_hsq.so")
+SOURCES = ["gq_common.hip", "hsq_encode.hip", "hsq_levels.hip", "hsq_decode.hip", "qsgd.hip"]
+# -ffp-contract=off: the reference's elementwise ops are separately rounded; hipcc's
+# default ("fast") would fuse the decode's mul/add and the level quantiser's sub/div.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+         "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (ROCm toolchain required)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "gq_hsq.h"), __file__]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,95 @@
+// Library-level entry points and shared host helpers.
+#include <stdarg.h>
+#include <string.h>
+
+#include "gq_common.hpp"
+
+namespace gq {
+
+char *last_error_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int cu_count() {
+    static thread_local int cached_dev = -1;
+    static thread_local int cached_cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached_dev = dev;
+        cached_cus = n;
+    }
+    return cached_cus;
+}
+
+__global__ void axpy_inplace_kernel(float *__restrict__ y, const float *__restrict__ x, float a, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        // ps_quantizer.py:35  grad.add_(scale * error): the product is rounded, then added
+        float t = a * x[i];
+        y[i] = y[i] + t;
+    }
+}
+
+__global__ void sub_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ o,
+                           int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) o[i] = a[i] - b[i];
+}
+
+static inline int grid_for(int64_t n, int block) {
+    int64_t g = (n + block - 1) / block;
+    int64_t cap = (int64_t)cu_count() * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace gq
+
+GQ_API int gq_abi_version(void) { return 1; }
+
+GQ_API const char *gq_last_error(void) { return gq::last_error_buf(); }
+
+GQ_API int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return gq::fail(GQ_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (arch && arch_len) {
+        strncpy(arch, prop.gcnArchName, arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    return GQ_OK;
+}
+
+GQ_API int gq_axpy_inplace(float *grad, const float *err, float scale, int64_t n, void *stream) {
+    if (n < 0 || (n > 0 && (!grad || !err))) return gq::fail(GQ_ERR_INVALID_ARG, "gq_axpy_inplace: bad arguments");
+    if (n == 0) return GQ_OK;
+    hipLaunchKernelGGL(gq::axpy_inplace_kernel, dim3(gq::grid_for(n, 256)), dim3(256), 0, gq::as_stream(stream), grad,
+                       err, scale, n);
+    GQ_CHECK_LAUNCH("gq_axpy_inplace");
+    return GQ_OK;
+}
+
+GQ_API int gq_sub(const float *grad, const float *decoded, float *err, int64_t n, void *stream) {
+    if (n < 0 || (n > 0 && (!grad || !decoded || !err))) return gq::fail(GQ_ERR_INVALID_ARG, "gq_sub: bad arguments");
+    if (n == 0) return GQ_OK;
+    hipLaunchKernelGGL(gq::sub_kernel, dim3(gq::grid_for(n, 256)), dim3(256), 0, gq::as_stream(stream), grad, decoded,
+                       err, n);
+    GQ_CHECK_LAUNCH("gq_sub");
+    return GQ_OK;
+}

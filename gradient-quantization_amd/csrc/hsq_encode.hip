@@ -1,0 +1,356 @@
+// HSQ encode kernels for gfx950 (MI355X).
+//
+// Replaces nearest_neighbor_compressor.py:65-73 of the reference
+// (view(-1,d) -> torch.mm -> abs -> argmax -> gather).  The reference's inner
+// products are, bit for bit, the ascending chain acc = fmaf(c[j], v[j], acc) from
+// acc = 0.  gfx950's f32-input MFMA (v_mfma_f32_32x32x2_f32)
+// evaluates exactly that chain over its k index -- one rounding per product, no
+// wider internal accumulator -- so the scores come out of the matrix cores
+// bit-identical to the reference while running at the full f32 rate.
+//
+// Three implementations, all exact:
+//   d16k256  codebook (256x16) held in 64 VGPRs per lane as MFMA A fragments;
+//            gradient subvectors are the B operand (subvector = MFMA column = lane),
+//            so the 256-way argmax is lane-local plus ONE cross-half exchange.
+//   generic  same MFMA formulation for any (d, K); fragments come from L1/L2.
+//   valu     one subvector per lane, codebook broadcast from LDS, __fmaf_rn chain,
+//            wave-level min/max by shuffles; kept as the cross-check of the MFMA path.
+#include "gq_common.hpp"
+
+namespace gq {
+
+constexpr int ENC_THREADS = 256;
+constexpr int ENC_WAVES = ENC_THREADS / 64;
+
+__device__ __forceinline__ void swap32(float &x, float &y) {
+    // v_permlane32_swap: lanes 32..63 of x <-> lanes 0..31 of y.
+    // After it: x = (x.lo, y.lo), y = (x.hi, y.hi).
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]);
+    y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap32(int &x, int &y) {
+    auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)y, false, false);
+    x = (int)r[0];
+    y = (int)r[1];
+}
+
+// Strict '>' keeps the FIRST maximum when candidates are visited in ascending index.
+__device__ __forceinline__ void take_if_greater(float &bv, int &bi, float v, int idx) {
+    const bool gt = fabsf(v) > fabsf(bv);
+    bv = gt ? v : bv;
+    bi = gt ? idx : bi;
+}
+
+// Row of the 32x32 MFMA result held in accumulator register r of a lane in half h
+// is  (r&3) + 8*(r>>2) + 4*h ; this is the h-independent part.
+__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// Per-block (min,max) of u -> partials[2*blockIdx.x], and block 0 pads the unused slots.
+__device__ __forceinline__ void write_minmax_partials(float lmin, float lmax, float *__restrict__ partials) {
+    __shared__ float s_min[ENC_WAVES], s_max[ENC_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    lmin = wave_min(lmin);
+    lmax = wave_max(lmax);
+    if (lane == 0) {
+        s_min[wave] = lmin;
+        s_max[wave] = lmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = s_min[0], b = s_max[0];
+#pragma unroll
+        for (int w = 1; w < ENC_WAVES; ++w) {
+            a = fminf(a, s_min[w]);
+            b = fmaxf(b, s_max[w]);
+        }
+        partials[2 * blockIdx.x] = a;
+        partials[2 * blockIdx.x + 1] = b;
+    }
+    if (blockIdx.x == 0) {
+        for (int i = gridDim.x + threadIdx.x; i < GQ_MAX_PARTIALS; i += blockDim.x) {
+            partials[2 * i] = INFINITY;
+            partials[2 * i + 1] = -INFINITY;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// d = 16, K = 256: the BASELINE configuration.
+//
+// One wave handles a tile of 64 subvectors (4 KiB of gradient) per iteration as two
+// 32-column MFMA blocks.  Lane (j = lane&31, h = lane>>5) loads floats [8h, 8h+8) of
+// subvector j (two dwordx4; the wave covers the 2 KiB block exactly once), four
+// v_permlane32_swap turn that into the B fragments b[ks] = v[2ks + h].  For each of the
+// 8 row blocks of 32 codewords the 8 chained MFMAs produce, in every lane, 16 finished
+// scores of ITS subvector; the running best is updated in registers.
+// HBM traffic per subvector: 64 B read, 1 B code + 4 B u written.
+// ------------------------------------------------------------------------------------
+template <typename CodeT>
+__global__ __launch_bounds__(ENC_THREADS) void hsq_encode_d16k256_kernel(const float *__restrict__ grad,
+                                                                        const float *__restrict__ cb, int64_t M,
+                                                                        CodeT *__restrict__ codes,
+                                                                        float *__restrict__ u,
+                                                                        float *__restrict__ partials) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+
+    // A fragments: a[rb][ks] = codebook[rb*32 + j][2*ks + h]   (64 VGPRs)
+    float a[8][8];
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) a[rb][ks] = cb[(rb * 32 + j) * 16 + 2 * ks + h];
+    }
+
+    const int64_t ntiles = (M + 63) >> 6;
+    const int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
+    int64_t t = (int64_t)blockIdx.x * ENC_WAVES + wave;
+
+    float lmin = INFINITY, lmax = -INFINITY;
+    f32x4 cur[4], nxt[4];
+
+    auto load_tile = [&](int64_t tile, f32x4(&dst)[4]) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            int64_t sv = tile * 64 + blk * 32 + j;
+            sv = sv < M ? sv : M - 1;  // tail: re-read the last subvector, result is masked
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(grad + sv * 16 + 8 * h);
+            dst[2 * blk] = p[0];
+            dst[2 * blk + 1] = p[1];
+        }
+    };
+
+    if (t < ntiles) load_tile(t, cur);
+    for (; t < ntiles; t += nw) {
+        const int64_t tn = t + nw;
+        if (tn < ntiles) load_tile(tn, nxt);  // prefetch the next tile under this tile's MFMAs
+
+        float bv[2];
+        int bi[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            float r0 = cur[2 * blk][0], r1 = cur[2 * blk][1], r2 = cur[2 * blk][2], r3 = cur[2 * blk][3];
+            float r4 = cur[2 * blk + 1][0], r5 = cur[2 * blk + 1][1], r6 = cur[2 * blk + 1][2],
+                  r7 = cur[2 * blk + 1][3];
+            swap32(r0, r1);
+            swap32(r2, r3);
+            swap32(r4, r5);
+            swap32(r6, r7);
+            const float b[8] = {r0, r2, r4, r6, r1, r3, r5, r7};  // b[ks] = v[2*ks + h]
+
+            float best_v = 0.0f;
+            int best_i = 0;
+#pragma unroll
+            for (int rb = 0; rb < 8; ++rb) {
+                f32x16 acc = {0};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][ks], b[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) take_if_greater(best_v, best_i, acc[r], rb * 32 + acc_row(r));
+            }
+            bv[blk] = best_v;
+            bi[blk] = best_i + 4 * h;
+        }
+
+        // Cross-half exchange: afterwards lane L holds both half-candidates of subvector
+        // t*64 + L  (lanes 0..31: first block, lanes 32..63: second block).
+        swap32(bv[0], bv[1]);
+        swap32(bi[0], bi[1]);
+        const float a0 = fabsf(bv[0]), a1 = fabsf(bv[1]);
+        const bool take1 = (a1 > a0) || (a1 == a0 && bi[1] < bi[0]);
+        const float val = take1 ? bv[1] : bv[0];
+        const int idx = take1 ? bi[1] : bi[0];
+
+        const int64_t sv = t * 64 + lane;
+        if (sv < M) {
+            codes[sv] = (CodeT)idx;
+            u[sv] = val;
+            lmin = fminf(lmin, val);
+            lmax = fmaxf(lmax, val);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+    }
+    write_minmax_partials(lmin, lmax, partials);
+}
+
+// ------------------------------------------------------------------------------------
+// Generic (d, K): same MFMA formulation; A/B fragments are fetched per MFMA from
+// global memory (the codebook and the 64-subvector tile stay L1/L2 resident).
+// k beyond d and codewords beyond K are fed as zeros: fma(0,0,acc) == acc exactly
+// (acc is never -0 in this chain), and padded codewords are excluded from the argmax.
+// ------------------------------------------------------------------------------------
+template <typename CodeT>
+__global__ __launch_bounds__(ENC_THREADS) void hsq_encode_generic_kernel(const float *__restrict__ grad,
+                                                                        const float *__restrict__ cb, int64_t M,
+                                                                        int d, int K, CodeT *__restrict__ codes,
+                                                                        float *__restrict__ u,
+                                                                        float *__restrict__ partials) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int ksteps = (d + 1) >> 1;
+    const int rblocks = (K + 31) >> 5;
+
+    const int64_t ntiles = (M + 63) >> 6;
+    const int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
+    float lmin = INFINITY, lmax = -INFINITY;
+
+    for (int64_t t = (int64_t)blockIdx.x * ENC_WAVES + wave; t < ntiles; t += nw) {
+        float bv[2];
+        int bi[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            int64_t sv = t * 64 + blk * 32 + j;
+            sv = sv < M ? sv : M - 1;
+            const float *v = grad + sv * (int64_t)d;
+            float best_v = 0.0f;
+            int best_i = 0;
+            for (int rb = 0; rb < rblocks; ++rb) {
+                const int row = rb * 32 + j;
+                const float *c = cb + (int64_t)(row < K ? row : K - 1) * d;
+                const bool row_ok = row < K;
+                f32x16 acc = {0};
+                for (int ks = 0; ks < ksteps; ++ks) {
+                    const int k = 2 * ks + h;
+                    const bool k_ok = k < d;
+                    const float av = (row_ok && k_ok) ? c[k_ok ? k : 0] : 0.0f;
+                    const float bvv = k_ok ? v[k_ok ? k : 0] : 0.0f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int idx = rb * 32 + acc_row(r);
+                    if (idx + 4 * h < K) take_if_greater(best_v, best_i, acc[r], idx);
+                }
+            }
+            bv[blk] = best_v;
+            bi[blk] = best_i + 4 * h;
+        }
+        swap32(bv[0], bv[1]);
+        swap32(bi[0], bi[1]);
+        // a half whose candidate index is out of range (K < 8) never saw a valid codeword
+        const bool v0 = bi[0] < K, v1 = bi[1] < K;
+        const float a0 = fabsf(bv[0]), a1 = fabsf(bv[1]);
+        const bool take1 = v1 && (!v0 || (a1 > a0) || (a1 == a0 && bi[1] < bi[0]));
+        const float val = take1 ? bv[1] : bv[0];
+        const int idx = take1 ? bi[1] : bi[0];
+        const int64_t sv = t * 64 + lane;
+        if (sv < M) {
+            codes[sv] = (CodeT)idx;
+            u[sv] = val;
+            lmin = fminf(lmin, val);
+            lmax = fmaxf(lmax, val);
+        }
+    }
+    write_minmax_partials(lmin, lmax, partials);
+}
+
+// ------------------------------------------------------------------------------------
+// VALU cross-check: one subvector per lane, codebook staged in LDS (broadcast reads),
+// explicit __fmaf_rn chain.  d <= 64, K*d*4 bytes <= 64 KiB.
+// ------------------------------------------------------------------------------------
+template <typename CodeT, int D>
+__global__ __launch_bounds__(ENC_THREADS) void hsq_encode_valu_kernel(const float *__restrict__ grad,
+                                                                     const float *__restrict__ cb, int64_t M, int K,
+                                                                     CodeT *__restrict__ codes,
+                                                                     float *__restrict__ u,
+                                                                     float *__restrict__ partials) {
+    extern __shared__ float s_cb[];
+    for (int i = threadIdx.x; i < K * D; i += blockDim.x) s_cb[i] = cb[i];
+    __syncthreads();
+    float lmin = INFINITY, lmax = -INFINITY;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += stride) {
+        float v[D];
+#pragma unroll
+        for (int jj = 0; jj < D; ++jj) v[jj] = grad[m * D + jj];
+        float best_v = 0.0f;
+        int best_i = 0;
+        for (int k = 0; k < K; ++k) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < D; ++jj) acc = __fmaf_rn(s_cb[k * D + jj], v[jj], acc);
+            take_if_greater(best_v, best_i, acc, k);
+        }
+        codes[m] = (CodeT)best_i;
+        u[m] = best_v;
+        lmin = fminf(lmin, best_v);
+        lmax = fmaxf(lmax, best_v);
+    }
+    write_minmax_partials(lmin, lmax, partials);
+}
+
+template <typename CodeT>
+static int launch_encode(const float *grad, const float *codebook, int64_t M, int d, int K, CodeT *codes, float *u,
+                         float *partials, int impl, hipStream_t st) {
+    const int cus = cu_count();
+    const int64_t ntiles = (M + 63) / 64;
+    int64_t blocks = (ntiles + ENC_WAVES - 1) / ENC_WAVES;
+    int64_t cap = (int64_t)cus * 4;
+    if (cap > GQ_MAX_PARTIALS) cap = GQ_MAX_PARTIALS;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+
+    if (impl == 0) impl = (d == 16 && K == 256) ? 1 : 2;
+    if (impl == 1) {
+        if (d != 16 || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 1 needs d=16, K=256");
+        if ((reinterpret_cast<uintptr_t>(grad) & 15) != 0)
+            return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: grad must be 16-byte aligned");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_d16k256_kernel<CodeT>), dim3((unsigned)blocks),
+                           dim3(ENC_THREADS), 0, st, grad, codebook, M, codes, u, partials);
+    } else if (impl == 2) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_generic_kernel<CodeT>), dim3((unsigned)blocks),
+                           dim3(ENC_THREADS), 0, st, grad, codebook, M, d, K, codes, u, partials);
+    } else if (impl == 3) {
+        const size_t lds = (size_t)K * d * sizeof(float);
+        if (lds > 64 * 1024) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: valu impl needs K*d*4 <= 64 KiB");
+        int64_t vb = (M + ENC_THREADS - 1) / ENC_THREADS;
+        if (vb > cap) vb = cap;
+        if (vb < 1) vb = 1;
+#define GQ_VALU_CASE(DD)                                                                                        \
+    case DD:                                                                                                    \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_valu_kernel<CodeT, DD>), dim3((unsigned)vb),              \
+                           dim3(ENC_THREADS), lds, st, grad, codebook, M, K, codes, u, partials);               \
+        break;
+        switch (d) {
+            GQ_VALU_CASE(8)
+            GQ_VALU_CASE(12)
+            GQ_VALU_CASE(16)
+            GQ_VALU_CASE(24)
+            GQ_VALU_CASE(32)
+            default:
+                return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: valu impl is built for d in {8,12,16,24,32}");
+        }
+#undef GQ_VALU_CASE
+    } else {
+        return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: unknown impl %d", impl);
+    }
+    GQ_CHECK_LAUNCH("gq_hsq_encode");
+    return GQ_OK;
+}
+
+}  // namespace gq
+
+GQ_API int gq_hsq_encode_impl(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes,
+                              int code_bytes, float *u, float *minmax_partials, int impl, void *stream) {
+    if (M < 1 || d < 1 || d > 512 || K < 1 || K > 65536)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: bad sizes M=%lld d=%d K=%d", (long long)M, d, K);
+    if (!grad || !codebook || !codes || !u || !minmax_partials)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: null pointer");
+    if (code_bytes == 1) {
+        if (K > 256) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: uint8 codes need K <= 256");
+        return gq::launch_encode<uint8_t>(grad, codebook, M, d, K, static_cast<uint8_t *>(codes), u, minmax_partials,
+                                          impl, gq::as_stream(stream));
+    }
+    if (code_bytes == 4)
+        return gq::launch_encode<int32_t>(grad, codebook, M, d, K, static_cast<int32_t *>(codes), u, minmax_partials,
+                                          impl, gq::as_stream(stream));
+    return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: code_bytes must be 1 or 4");
+}
+
+GQ_API int gq_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes,
+                         int code_bytes, float *u, float *minmax_partials, void *stream) {
+    return gq_hsq_encode_impl(grad, codebook, M, d, K, codes, code_bytes, u, minmax_partials, 0, stream);
+}

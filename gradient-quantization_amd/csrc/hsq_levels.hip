@@ -1,0 +1,104 @@
+// Scalar (norm) level quantiser for gfx950.
+//
+// Replaces probabilistic_scalar_compressor.py:12-27 of the reference.  The global
+// min/max (a whole-tensor dependency) is finished here from the per-workgroup
+// partials the encode kernel left behind, so compress is two launches and `u` makes
+// one round trip through HBM/L2 (0.25 B per gradient element each way).
+// Built with -ffp-contract=off: sub, IEEE divide, exact *2^n_bit, truncation -- the
+// same roundings as the reference's separate elementwise ops.
+#include "gq_common.hpp"
+
+namespace gq {
+
+constexpr int LV_THREADS = 256;
+
+template <typename LevelT>
+__global__ __launch_bounds__(LV_THREADS) void hsq_levels_kernel(const float *__restrict__ u, int64_t M, int n_bit,
+                                                               int random_mode, const float *__restrict__ r,
+                                                               uint64_t seed, const float *__restrict__ partials,
+                                                               float *__restrict__ lb_ub,
+                                                               LevelT *__restrict__ levels) {
+    // ---- finish min/max: every block reduces the same GQ_MAX_PARTIALS pairs (8 KiB, L2) ----
+    __shared__ float s_min[LV_THREADS / 64], s_max[LV_THREADS / 64];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < GQ_MAX_PARTIALS; i += LV_THREADS) {
+        const float2 p = reinterpret_cast<const float2 *>(partials)[i];
+        lo = fminf(lo, p.x);
+        hi = fmaxf(hi, p.y);
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0) {
+        s_min[threadIdx.x >> 6] = lo;
+        s_max[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    lo = s_min[0];
+    hi = s_max[0];
+#pragma unroll
+    for (int w = 1; w < LV_THREADS / 64; ++w) {
+        lo = fminf(lo, s_min[w]);
+        hi = fmaxf(hi, s_max[w]);
+    }
+    const float lb = lo, ub = hi;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        lb_ub[0] = lb;
+        lb_ub[1] = ub;
+    }
+
+    const float s = (float)(1 << n_bit);
+    const float smax = s - 1.0f;
+    const float range = ub - lb;
+    const bool flat = (lb - ub) == 0.0f;  // prob_scalar:15-16 -> all zeros
+    const int64_t stride = (int64_t)gridDim.x * LV_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * LV_THREADS + threadIdx.x; i < M; i += stride) {
+        int l = 0;
+        if (!flat) {
+            const float q = (u[i] - lb) / range;
+            const float x = fabsf(q) * s;
+            const float c = fminf(fmaxf(x, 0.0f), smax);
+            l = (int)c;
+            if (random_mode != GQ_RANDOM_OFF) {
+                const float prob = x - (float)l;
+                const float rr = (random_mode == GQ_RANDOM_GIVEN) ? r[i] : uniform01(seed, (uint64_t)i);
+                l += (prob > rr) ? 1 : 0;
+            }
+        }
+        levels[i] = (LevelT)l;
+    }
+}
+
+}  // namespace gq
+
+GQ_API int gq_hsq_levels(const float *u, int64_t M, int n_bit, int random_mode, const float *r, uint64_t seed,
+                         const float *minmax_partials, float *lb_ub, void *levels, int level_bytes, void *stream) {
+    if (M < 1 || n_bit < 1 || n_bit > 30)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels: bad sizes M=%lld n_bit=%d", (long long)M, n_bit);
+    if (!u || !minmax_partials || !lb_ub || !levels) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels: null pointer");
+    if (random_mode < GQ_RANDOM_OFF || random_mode > GQ_RANDOM_DEVICE)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels: random_mode %d", random_mode);
+    if (random_mode == GQ_RANDOM_GIVEN && !r) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels: r is null");
+    const int64_t top = ((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0);
+    if ((level_bytes == 1 && top > 255) || (level_bytes == 2 && top > 65535))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels: level_bytes=%d cannot hold level %lld", level_bytes,
+                        (long long)top);
+    int64_t blocks = (M + gq::LV_THREADS * 4 - 1) / (gq::LV_THREADS * 4);
+    const int64_t cap = (int64_t)gq::cu_count() * 2;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipStream_t st = gq::as_stream(stream);
+#define GQ_LAUNCH_LEVELS(T)                                                                                      \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gq::hsq_levels_kernel<T>), dim3((unsigned)blocks), dim3(gq::LV_THREADS), 0, \
+                       st, u, M, n_bit, random_mode, r, seed, minmax_partials, lb_ub, static_cast<T *>(levels))
+    if (level_bytes == 1)
+        GQ_LAUNCH_LEVELS(uint8_t);
+    else if (level_bytes == 2)
+        GQ_LAUNCH_LEVELS(uint16_t);
+    else if (level_bytes == 4)
+        GQ_LAUNCH_LEVELS(int32_t);
+    else
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels: level_bytes must be 1, 2 or 4");
+#undef GQ_LAUNCH_LEVELS
+    GQ_CHECK_LAUNCH("gq_hsq_levels");
+    return GQ_OK;
+}

@@ -1,0 +1,164 @@
+"""ctypes binding of libgq_hsq.so (include/gq_hsq.h) for torch tensors.
+
+This is the ONLY compute backend of the package: there is no CPU or eager-PyTorch
+fallback.  If the library is missing, or a tensor is not on a HIP device, the calls
+raise.  Tensors are passed as raw device pointers; work is enqueued on torch's
+current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_DIR, "libgq_hsq.so")
+
+GQ_MAX_PARTIALS = 1024
+RANDOM_OFF, RANDOM_GIVEN, RANDOM_DEVICE = 0, 1, 2
+ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU = 0, 1, 2, 3
+
+EXPORTS = [
+    "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_encode", "gq_hsq_encode_impl", "gq_hsq_levels",
+    "gq_hsq_decode_sum", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
+]
+
+_lib = None
+
+
+class GQNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libgq_hsq.so; fail loudly if it was not built (python gradient-quantization_amd/build.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GQNativeError(
+                "libgq_hsq.so not found at %s -- build it with `python gradient-quantization_amd/build.py` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.gq_last_error.restype = ctypes.c_char_p
+        L.gq_abi_version.restype = ctypes.c_int
+        for name in EXPORTS:
+            getattr(L, name)  # AttributeError if the library is stale
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise GQNativeError("%s failed (%d): %s" % (what, rc, lib().gq_last_error().decode()))
+
+
+def _dev_ptr(t, dtype=None, name="tensor"):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if t.device.type != "cuda":
+        raise GQNativeError("%s is on %s: the HIP kernels need a tensor in MI355X HBM (no CPU fallback)"
+                            % (name, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_CODE_BYTES = {torch.uint8: 1, torch.int32: 4}
+_LEVEL_BYTES = {torch.uint8: 1, torch.int16: 2, torch.int32: 4, torch.float32: 0}
+
+
+def new_partials(device):
+    return torch.empty(2 * GQ_MAX_PARTIALS, dtype=torch.float32, device=device)
+
+
+def device_info(device=0):
+    cus = ctypes.c_int(0)
+    arch = ctypes.create_string_buffer(128)
+    _check(lib().gq_device_info(ctypes.c_int(device), ctypes.byref(cus), arch, ctypes.c_size_t(128)), "gq_device_info")
+    return cus.value, arch.value.decode()
+
+
+def hsq_encode(grad, codebook, codes, u, partials, impl=ENCODE_AUTO):
+    """grad f32 [M*d] -> codes (uint8|int32 [M]), u f32 [M], partials f32 [2*GQ_MAX_PARTIALS]."""
+    K, d = codebook.shape
+    M = grad.numel() // d
+    assert grad.numel() == M * d and codes.numel() == M and u.numel() == M
+    assert partials.numel() >= 2 * GQ_MAX_PARTIALS
+    rc = lib().gq_hsq_encode_impl(_dev_ptr(grad, torch.float32, "grad"), _dev_ptr(codebook, torch.float32, "codebook"),
+                                  ctypes.c_int64(M), ctypes.c_int(d), ctypes.c_int(K), _dev_ptr(codes, None, "codes"),
+                                  ctypes.c_int(_CODE_BYTES[codes.dtype]), _dev_ptr(u, torch.float32, "u"),
+                                  _dev_ptr(partials, torch.float32, "partials"), ctypes.c_int(impl), _stream())
+    _check(rc, "gq_hsq_encode")
+
+
+def hsq_levels(u, n_bit, random_mode, r, seed, partials, lb_ub, levels):
+    M = u.numel()
+    assert levels.numel() == M and lb_ub.numel() == 2
+    rp = _dev_ptr(r, torch.float32, "r") if r is not None else ctypes.c_void_p(0)
+    if r is not None:
+        assert r.numel() == M
+    rc = lib().gq_hsq_levels(_dev_ptr(u, torch.float32, "u"), ctypes.c_int64(M), ctypes.c_int(n_bit),
+                             ctypes.c_int(random_mode), rp, ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                             _dev_ptr(partials, torch.float32, "partials"), _dev_ptr(lb_ub, torch.float32, "lb_ub"),
+                             _dev_ptr(levels, None, "levels"), ctypes.c_int(_LEVEL_BYTES[levels.dtype]), _stream())
+    _check(rc, "gq_hsq_levels")
+
+
+def hsq_decode_sum(codes, levels, lb_ub, codebook, n_bit, out, R=1):
+    """codes [R,M], levels [R,M] (int) or f32 norms [R,M], lb_ub [R,2] -> out f32 [M*d] (mean over R)."""
+    K, d = codebook.shape
+    M = codes.numel() // R
+    assert codes.numel() == R * M and levels.numel() == R * M and out.numel() == M * d
+    lvl_bytes = _LEVEL_BYTES[levels.dtype]
+    if lvl_bytes:
+        assert lb_ub is not None and lb_ub.numel() == 2 * R
+        lp = _dev_ptr(lb_ub, torch.float32, "lb_ub")
+    else:
+        lp = ctypes.c_void_p(0)
+    rc = lib().gq_hsq_decode_sum(_dev_ptr(codes, None, "codes"), ctypes.c_int(_CODE_BYTES[codes.dtype]),
+                                 _dev_ptr(levels, None, "levels"), ctypes.c_int(lvl_bytes), lp,
+                                 _dev_ptr(codebook, torch.float32, "codebook"), ctypes.c_int(R), ctypes.c_int64(M),
+                                 ctypes.c_int(d), ctypes.c_int(K), ctypes.c_int(n_bit if lvl_bytes else 0),
+                                 _dev_ptr(out, torch.float32, "out"), _stream())
+    _check(rc, "gq_hsq_decode_sum")
+
+
+def axpy_inplace(grad, err, scale):
+    assert grad.numel() == err.numel()
+    _check(lib().gq_axpy_inplace(_dev_ptr(grad, torch.float32, "grad"), _dev_ptr(err, torch.float32, "err"),
+                                 ctypes.c_float(scale), ctypes.c_int64(grad.numel()), _stream()), "gq_axpy_inplace")
+
+
+def sub(grad, decoded, err):
+    assert grad.numel() == decoded.numel() == err.numel()
+    _check(lib().gq_sub(_dev_ptr(grad, torch.float32, "grad"), _dev_ptr(decoded, torch.float32, "decoded"),
+                        _dev_ptr(err, torch.float32, "err"), ctypes.c_int64(grad.numel()), _stream()), "gq_sub")
+
+
+def qsgd_compress(grad, d, n_bit, random_mode, r, seed, norm, signs, levels):
+    Mb = grad.numel() // d
+    assert grad.numel() == Mb * d and norm.numel() == Mb and signs.numel() == Mb * d and levels.numel() == Mb * d
+    rp = _dev_ptr(r, torch.float32, "r") if r is not None else ctypes.c_void_p(0)
+    sg = signs.view(torch.uint8) if signs.dtype == torch.bool else signs
+    rc = lib().gq_qsgd_compress(_dev_ptr(grad, torch.float32, "grad"), ctypes.c_int64(Mb), ctypes.c_int(d),
+                                ctypes.c_int(n_bit), ctypes.c_int(random_mode), rp,
+                                ctypes.c_uint64(seed & (2 ** 64 - 1)), _dev_ptr(norm, torch.float32, "norm"),
+                                _dev_ptr(sg, torch.uint8, "signs"), _dev_ptr(levels, None, "levels"),
+                                ctypes.c_int(_LEVEL_BYTES[levels.dtype]), _stream())
+    _check(rc, "gq_qsgd_compress")
+
+
+def qsgd_decode_sum(norm, signs, levels, d, n_bit, out, R=1):
+    Mb = norm.numel() // R
+    assert signs.numel() == R * Mb * d and levels.numel() == R * Mb * d and out.numel() == Mb * d
+    sg = signs.view(torch.uint8) if signs.dtype == torch.bool else signs
+    rc = lib().gq_qsgd_decode_sum(_dev_ptr(norm, torch.float32, "norm"), _dev_ptr(sg, torch.uint8, "signs"),
+                                  _dev_ptr(levels, None, "levels"), ctypes.c_int(_LEVEL_BYTES[levels.dtype]),
+                                  ctypes.c_int(R), ctypes.c_int64(Mb), ctypes.c_int(d), ctypes.c_int(n_bit),
+                                  _dev_ptr(out, torch.float32, "out"), _stream())
+    _check(rc, "gq_qsgd_decode_sum")

@@ -1,0 +1,133 @@
+/*
+ * gq_hsq.h -- C ABI of libgq_hsq.so, the MI355X (gfx950) implementation of the
+ * gradient vector-quantisation hot path of xinyandai/gradient-quantization.
+ *
+ * The reference has no FFI: its boundary is the duck-typed Python protocol
+ *     Compressor(size, shape, args).compress(vec) / .decompress(signature)
+ *     Quantizer(Compressor, parameters, args).record(user, epoch) / .apply()
+ * (compressors/nearest_neighbor_compressor.py:10,63,80; quantizers/ps_quantizer.py:7,27,46).
+ * Each entry point below replaces the PyTorch op sequence inside one of those
+ * methods; the citation on each says which.  The Python classes with the
+ * reference's names live in gradient-quantization_amd/ and call these through
+ * ctypes with raw device pointers (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name starts with `h_`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every
+ *     call only enqueues work on that stream: no allocation, no synchronisation,
+ *     graph-capturable;
+ *   - return value: GQ_OK (0) or a negative GQ_ERR_* code; gq_last_error() gives text;
+ *   - nothing here falls back to the CPU: without a gfx950 device the calls fail.
+ */
+#ifndef GQ_HSQ_H
+#define GQ_HSQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GQ_OK 0
+#define GQ_ERR_INVALID_ARG (-1)
+#define GQ_ERR_UNSUPPORTED (-2)
+#define GQ_ERR_HIP (-3)
+
+/* Number of (min,max) float pairs gq_hsq_encode writes into `minmax_partials`
+ * (the buffer must hold 2 * GQ_MAX_PARTIALS floats). */
+#define GQ_MAX_PARTIALS 1024
+
+/* random_mode of gq_hsq_levels / gq_qsgd_compress */
+#define GQ_RANDOM_OFF 0    /* args.random == 0: deterministic truncation                      */
+#define GQ_RANDOM_GIVEN 1  /* stochastic rounding against caller-supplied r[] (reference parity:
+                              r = torch.rand(M) from the CPU generator, prob_scalar:23-25)       */
+#define GQ_RANDOM_DEVICE 2 /* stochastic rounding against an on-device counter-based generator
+                              seeded by `seed` (same distribution, not the same draws)          */
+
+/* Library / device identification. */
+int gq_abi_version(void);
+const char *gq_last_error(void);
+/* Fills CU count and the gcnArchName (e.g. "gfx950:sramecc+:xnack-") of `device`. */
+int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
+
+/*
+ * HSQ encode -- replaces nearest_neighbor_compressor.py:65-73 (view(-1,d); mm;
+ * abs; argmax; gather).  For every d-float subvector v of `grad` (M of them,
+ * row-major, contiguous):
+ *     p_k   = <codebook[k,:], v>   exactly as  acc=0; for j: acc=fmaf(c[j],v[j],acc)
+ *     code  = first k maximising |p_k|
+ *     u     = p_code              (signed)
+ * Outputs: codes[M] (code_bytes = 1 -> uint8, 4 -> int32; 1 requires K <= 256),
+ * u[M] f32, and per-workgroup (min,max) of u in minmax_partials[2*GQ_MAX_PARTIALS]
+ * (unused slots are filled with (+inf,-inf)).
+ * Requirements: 1 <= d <= 512, 1 <= K <= 65536, grad 16-byte aligned when d == 16.
+ */
+int gq_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes, int code_bytes,
+                  float *u, float *minmax_partials, void *stream);
+
+/* Same, with the kernel chosen explicitly (diagnostics / cross-checks; results are
+ * identical for every impl):  0 = auto, 1 = MFMA d16/K256 register-resident codebook,
+ * 2 = MFMA generic (any d, K), 3 = VALU fmaf chain with the codebook in LDS. */
+#define GQ_ENCODE_AUTO 0
+#define GQ_ENCODE_MFMA_D16K256 1
+#define GQ_ENCODE_MFMA_GENERIC 2
+#define GQ_ENCODE_VALU 3
+int gq_hsq_encode_impl(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes,
+                       int code_bytes, float *u, float *minmax_partials, int impl, void *stream);
+
+/*
+ * Scalar level quantiser -- replaces probabilistic_scalar_compressor.py:12-27.
+ *     lb = min(u), ub = max(u)    (finished here from minmax_partials)
+ *     levels = 0                                   if lb - ub == 0
+ *     x = |(u-lb)/(ub-lb)| * 2^n_bit ;  l = trunc(clamp(x, 0, 2^n_bit - 1))
+ *     l += (x - l > r)                             if random_mode != GQ_RANDOM_OFF
+ * Outputs lb_ub[2] (f32) and levels[M] (level_bytes 1/2/4 -> uint8/uint16/int32;
+ * the value range is [0, 2^n_bit] with stochastic rounding, [0, 2^n_bit - 1] without).
+ */
+int gq_hsq_levels(const float *u, int64_t M, int n_bit, int random_mode, const float *r, uint64_t seed,
+                  const float *minmax_partials, float *lb_ub, void *levels, int level_bytes, void *stream);
+
+/*
+ * Decode + aggregate -- replaces probabilistic_scalar_compressor.py:29-33 and
+ * nearest_neighbor_compressor.py:80-90 for each of R payloads, then
+ * ps_quantizer.py:48 (torch.stack(...).mean(0)) across them:
+ *     n_r[m]   = float(levels_r[m]) * (ub_r - lb_r) / 2^n_bit + lb_r     (no fusion)
+ *     out[m,:] = ( sum_{r=0..R-1, ascending} codebook[codes_r[m],:] * n_r[m] ) / R
+ * codes: [R][M], levels: [R][M], lb_ub: [R][2].  level_bytes == 0 means `levels`
+ * holds f32 norms [R][M] (the n_bit == 32 signature) and lb_ub / n_bit are ignored.
+ * R == 1 is the plain decompress.
+ */
+int gq_hsq_decode_sum(const void *codes, int code_bytes, const void *levels, int level_bytes, const float *lb_ub,
+                      const float *codebook, int R, int64_t M, int d, int K, int n_bit, float *out, void *stream);
+
+/*
+ * Error-feedback helpers fused around the codec (ps_quantizer.py:35,39):
+ *     gq_axpy_inplace:   grad += scale * err
+ *     gq_sub:            err   = grad - decoded
+ */
+int gq_axpy_inplace(float *grad, const float *err, float scale, int64_t n, void *stream);
+int gq_sub(const float *grad, const float *decoded, float *err, int64_t n, void *stream);
+
+/*
+ * QSGD compress -- replaces qsgd_compressor.py:47-64.  `grad` is Mb buckets of d floats.
+ *     norm[b]  = max_j |v_j| ;  x = |v/norm| * 2^n_bit ;  l = trunc(clamp(x, 0, 2^n_bit-1))
+ *     l += (x - l > r)  if random_mode ;  signs = v > 0
+ * Outputs norm[Mb] f32, signs[Mb*d] uint8 (0/1), levels[Mb*d] (level_bytes 1 or 4).
+ * A zero bucket yields level INT_MIN (int32) / 0 (uint8) and decodes to 0, as in the reference.
+ */
+int gq_qsgd_compress(const float *grad, int64_t Mb, int d, int n_bit, int random_mode, const float *r, uint64_t seed,
+                     float *norm, uint8_t *signs, void *levels, int level_bytes, void *stream);
+
+/*
+ * QSGD decode + aggregate -- replaces qsgd_compressor.py:66-71 for R payloads and
+ * ps_quantizer.py:48:   out = ( sum_r (float(l_r) * (2*signs_r - 1)) * norm_r / 2^n_bit ) / R
+ * norm: [R][Mb], signs: [R][Mb*d], levels: [R][Mb*d].
+ */
+int gq_qsgd_decode_sum(const float *norm, const uint8_t *signs, const void *levels, int level_bytes, int R, int64_t Mb,
+                       int d, int n_bit, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GQ_HSQ_H */

@@ -1,0 +1,233 @@
+"""GPU parity tests: the HIP kernels (through the C ABI, include/gq_hsq.h) against
+(1) the golden vectors captured from the reference and (2) the CPU oracle on seeded
+inputs.  Bit-exact for codes / levels / u / lb / ub and for the single-payload decode;
+the R-payload mean is bit-exact too (same summation order), asserted at 0 ulp."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+HSQ_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "hsq_*.npz")))
+QSGD_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "qsgd_*.npz")))
+
+
+def _cb(d, K):
+    return np.load(os.path.join(GOLDEN, "codebook_d%d_k%d_normalized.npy" % (d, K)))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from gq_amd import native
+    native.lib()
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return native
+
+
+def gpu_compress(nat, x, cb, n_bit, random, r=None, impl=0, code_dtype=None, level_dtype=torch.int32, seed=0):
+    dev = torch.device("cuda:0")
+    K, d = cb.shape
+    g = torch.from_numpy(np.ascontiguousarray(x, np.float32).reshape(-1)).to(dev)
+    c = torch.from_numpy(cb).to(dev)
+    M = g.numel() // d
+    if code_dtype is None:
+        code_dtype = torch.uint8 if K <= 256 else torch.int32
+    codes = torch.empty(M, dtype=code_dtype, device=dev)
+    u = torch.empty(M, dtype=torch.float32, device=dev)
+    partials = nat.new_partials(dev)
+    nat.hsq_encode(g, c, codes, u, partials, impl=impl)
+    out = dict(codes=codes, u=u, cb=c, M=M)
+    if n_bit != 32:
+        lb_ub = torch.empty(2, dtype=torch.float32, device=dev)
+        levels = torch.empty(M, dtype=level_dtype, device=dev)
+        rt = torch.from_numpy(np.ascontiguousarray(r, np.float32)).to(dev) if random == 1 else None
+        nat.hsq_levels(u, n_bit, random, rt, seed, partials, lb_ub, levels)
+        out.update(lb_ub=lb_ub, levels=levels)
+    torch.cuda.synchronize()
+    return out
+
+
+def gpu_decode(nat, res, n_bit):
+    dev = res["codes"].device
+    K, d = res["cb"].shape
+    out = torch.empty(res["M"] * d, dtype=torch.float32, device=dev)
+    if n_bit == 32:
+        nat.hsq_decode_sum(res["codes"], res["u"], None, res["cb"], 32, out, R=1)
+    else:
+        nat.hsq_decode_sum(res["codes"], res["levels"], res["lb_ub"], res["cb"], n_bit, out, R=1)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+IMPLS = {"auto": 0, "mfma_generic": 2, "valu": 3}
+
+
+@pytest.mark.parametrize("impl", ["auto", "mfma_generic", "valu"])
+@pytest.mark.parametrize("name", HSQ_CASES)
+def test_hsq_matches_reference_golden(nat, name, impl):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d, K, n_bit, random = int(g["dim"]), int(g["K"]), int(g["n_bit"]), int(g["random"])
+    if impl == "valu" and (d not in (8, 12, 16, 24, 32) or K * d * 4 > 65536):
+        pytest.skip("valu cross-check kernel not built for this shape")
+    cb = _cb(d, K)
+    r = g["r"] if random else None
+    res = gpu_compress(nat, g["x"], cb, n_bit, random, r, impl=IMPLS[impl])
+    codes = res["codes"].cpu().numpy().astype(np.int32)
+    u = res["u"].cpu().numpy()
+    assert np.array_equal(codes, g["codes"].astype(np.int32)), "codes differ from the reference"
+    if codes.size == 1:  # M == 1: reference runs MKL sgemv (see test_oracle_golden.py)
+        assert abs(int(_bits(u)[0]) - int(_bits(g["u"])[0])) <= 2
+        return
+    assert np.array_equal(_bits(u), _bits(g["u"])), "u differs bitwise from the reference"
+    if n_bit != 32:
+        lb_ub = res["lb_ub"].cpu().numpy()
+        assert _bits(lb_ub[0]) == _bits(g["lb"]) and _bits(lb_ub[1]) == _bits(g["ub"])
+        assert np.array_equal(res["levels"].cpu().numpy(), g["levels"])
+    dec = gpu_decode(nat, res, n_bit)
+    assert np.array_equal(_bits(dec), _bits(g["decoded"].reshape(-1))), "decoded differs bitwise"
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-3])
+@pytest.mark.parametrize("M", [1, 2, 31, 32, 33, 63, 64, 65, 127, 4095, 4096, 4097, 100003])
+def test_hsq_encode_vs_oracle_ragged(nat, oracle, M, scale):
+    """Ragged subvector counts around the 64-subvector tile and the grid size."""
+    rng = np.random.RandomState(1000 + M)
+    cb = _cb(16, 256)
+    x = (rng.standard_normal(M * 16) * scale).astype(np.float32)
+    ref = oracle.hsq_compress(x, cb, 6, 0)
+    res = gpu_compress(nat, x, cb, 6, 0)
+    assert np.array_equal(res["codes"].cpu().numpy().astype(np.int32), ref["codes"])
+    assert np.array_equal(_bits(res["u"].cpu().numpy()), _bits(ref["u"]))
+    lb_ub = res["lb_ub"].cpu().numpy()
+    assert _bits(lb_ub[0]) == _bits(ref["lb"]) and _bits(lb_ub[1]) == _bits(ref["ub"])
+    assert np.array_equal(res["levels"].cpu().numpy(), ref["levels"])
+
+
+@pytest.mark.parametrize("level_dtype", [torch.uint8, torch.int16, torch.int32])
+def test_hsq_level_widths_and_given_r(nat, oracle, level_dtype):
+    rng = np.random.RandomState(5)
+    cb = _cb(16, 256)
+    x = rng.standard_normal(16 * 5000).astype(np.float32)
+    r = rng.random_sample(5000).astype(np.float32)
+    ref = oracle.hsq_compress(x, cb, 6, 1, r)
+    res = gpu_compress(nat, x, cb, 6, 1, r, level_dtype=level_dtype)
+    assert np.array_equal(res["levels"].cpu().numpy().astype(np.int32), ref["levels"])
+    assert ref["levels"].max() == 64  # the top element always rounds up
+    dec = gpu_decode(nat, res, 6)
+    assert np.array_equal(_bits(dec), _bits(oracle.hsq_decompress(ref["codes"], ref["levels"], ref["lb"], ref["ub"], cb, 6)))
+
+
+def test_hsq_device_rng_is_stochastic_rounding(nat, oracle):
+    """GQ_RANDOM_DEVICE: levels are floor or floor+1 of x, and unbiased on average."""
+    rng = np.random.RandomState(6)
+    cb = _cb(16, 256)
+    M = 200000
+    x = rng.standard_normal(16 * M).astype(np.float32)
+    det = oracle.hsq_compress(x, cb, 6, 0)
+    res = gpu_compress(nat, x, cb, 6, 2, seed=1234)
+    lv = res["levels"].cpu().numpy().astype(np.int64)
+    diff = lv - det["levels"]
+    assert diff.min() >= 0 and diff.max() <= 1
+    xs = np.abs((det["u"].astype(np.float64) - det["lb"]) / (np.float64(det["ub"]) - det["lb"])) * 64
+    frac = xs - np.floor(np.minimum(xs, 63))
+    assert abs(diff.mean() - frac.mean()) < 5e-3
+    res2 = gpu_compress(nat, x, cb, 6, 2, seed=1234)
+    assert torch.equal(res["levels"], res2["levels"])          # reproducible per seed
+    res3 = gpu_compress(nat, x, cb, 6, 2, seed=99)
+    assert not torch.equal(res["levels"], res3["levels"])
+
+
+@pytest.mark.parametrize("R", [1, 2, 3, 8])
+def test_hsq_decode_sum_matches_oracle_mean(nat, oracle, R):
+    rng = np.random.RandomState(40 + R)
+    cb = _cb(16, 256)
+    M = 3000
+    dev = torch.device("cuda:0")
+    codes, levels, lbub, decs = [], [], [], []
+    for r in range(R):
+        x = (rng.standard_normal(16 * M) * (0.5 + r)).astype(np.float32)
+        c = oracle.hsq_compress(x, cb, 6, 0)
+        codes.append(c["codes"].astype(np.uint8))
+        levels.append(c["levels"].astype(np.uint8))
+        lbub.append([c["lb"], c["ub"]])
+        decs.append(oracle.hsq_decompress(c["codes"], c["levels"], c["lb"], c["ub"], cb, 6))
+    ref = oracle.mean_users(np.stack(decs, 0))
+    out = torch.empty(M * 16, dtype=torch.float32, device=dev)
+    nat.hsq_decode_sum(torch.from_numpy(np.stack(codes)).to(dev), torch.from_numpy(np.stack(levels)).to(dev),
+                       torch.tensor(lbub, dtype=torch.float32, device=dev), torch.from_numpy(cb).to(dev), 6, out, R=R)
+    got = out.cpu().numpy()
+    assert np.array_equal(_bits(got), _bits(ref))
+
+
+@pytest.mark.parametrize("name", QSGD_CASES)
+def test_qsgd_matches_reference_golden(nat, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d, n_bit, random = int(g["dim"]), int(g["n_bit"]), int(g["random"])
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(g["x"].reshape(-1)).to(dev)
+    Mb = x.numel() // d
+    norm = torch.empty(Mb, dtype=torch.float32, device=dev)
+    signs = torch.empty(Mb * d, dtype=torch.uint8, device=dev)
+    levels = torch.empty(Mb * d, dtype=torch.int32, device=dev)
+    r = torch.from_numpy(g["r"].reshape(-1)).to(dev) if random else None
+    nat.qsgd_compress(x, d, n_bit, 1 if random else 0, r, 0, norm, signs, levels)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(norm.cpu().numpy()), _bits(g["norm"].reshape(-1)))
+    assert np.array_equal(signs.cpu().numpy().astype(bool), g["signs"].reshape(-1))
+    assert np.array_equal(levels.cpu().numpy(), g["levels"].reshape(-1))
+    out = torch.empty(Mb * d, dtype=torch.float32, device=dev)
+    nat.qsgd_decode_sum(norm, signs, levels, d, n_bit, out, R=1)
+    assert np.array_equal(out.cpu().numpy(), g["decoded"].reshape(-1))
+
+
+def test_full_size_properties(nat, oracle):
+    """BASELINE size (25M floats): size-independent properties + a sampled oracle check."""
+    dev = torch.device("cuda:0")
+    cb_np = _cb(16, 256)
+    cb = torch.from_numpy(cb_np).to(dev)
+    torch.manual_seed(1234)
+    g = torch.randn(25_000_000, device=dev)
+    M = g.numel() // 16
+    codes = torch.empty(M, dtype=torch.uint8, device=dev)
+    u = torch.empty(M, dtype=torch.float32, device=dev)
+    partials = nat.new_partials(dev)
+    lb_ub = torch.empty(2, dtype=torch.float32, device=dev)
+    levels = torch.empty(M, dtype=torch.uint8, device=dev)
+    nat.hsq_encode(g, cb, codes, u, partials)
+    nat.hsq_levels(u, 6, 0, None, 0, partials, lb_ub, levels)
+    out = torch.empty_like(g)
+    nat.hsq_decode_sum(codes, levels, lb_ub, cb, 6, out, R=1)
+    torch.cuda.synchronize()
+    # lb/ub are the exact extrema of u
+    assert lb_ub[0].item() == u.min().item() and lb_ub[1].item() == u.max().item()
+    assert int(levels.max()) == 63 and int(levels.min()) == 0
+    # u is the projection on the chosen codeword, and no codeword projects larger (fp32 matmul check)
+    V = g.view(-1, 16)
+    sel = cb[codes.long()]
+    proj = (V * sel).sum(1)
+    assert torch.allclose(proj, u, rtol=1e-4, atol=1e-5)
+    idx = torch.arange(0, M, 97, device=dev)
+    best = (V[idx] @ cb.t()).abs().max(1).values
+    assert torch.all(u[idx].abs() >= best * (1 - 1e-5))
+    # decoded = codeword * dequantised level; the residual is smaller than the input
+    assert (g - out).norm() < g.norm()
+    # idempotence of the decode and linearity in R: mean of two identical payloads == one payload
+    out2 = torch.empty_like(g)
+    nat.hsq_decode_sum(torch.cat([codes, codes]), torch.cat([levels, levels]), torch.cat([lb_ub, lb_ub]), cb, 6,
+                       out2, R=2)
+    assert torch.equal(out, out2)
+    # sampled bit-exact check against the oracle on a 1M-element window (offset not tile aligned)
+    off = 16 * 123457
+    win = g[off:off + 16 * 65536].cpu().numpy()
+    rc, ru = oracle.hsq_encode(win, cb_np)
+    assert np.array_equal(codes[123457:123457 + 65536].cpu().numpy().astype(np.int32), rc)
+    assert np.array_equal(_bits(u[123457:123457 + 65536].cpu().numpy()), _bits(ru))
