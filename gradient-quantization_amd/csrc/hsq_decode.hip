@@ -28,7 +28,8 @@ __device__ __forceinline__ float level_to_norm<float>(float l, float, float, flo
 template <typename CodeT, typename LevelT, bool LDS_CB>
 __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_v4_kernel(
     const CodeT *__restrict__ codes, const LevelT *__restrict__ levels, const float *__restrict__ lb_ub,
-    const float *__restrict__ cb, int R, int64_t M, int d, int K, int n_bit, float *__restrict__ out) {
+    int64_t code_stride, int64_t level_stride, int64_t lbub_stride, const float *__restrict__ cb, int R, int64_t M,
+    int d, int K, int n_bit, float *__restrict__ out) {
     extern __shared__ float s_cb[];
     if (LDS_CB) {
         for (int i = threadIdx.x; i < K * d; i += DEC_THREADS) s_cb[i] = cb[i];
@@ -44,10 +45,10 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_v4_kernel(
         const int q = (int)(i - m * q_per);
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int r = 0; r < R; ++r) {
-            const int code = (int)codes[(int64_t)r * M + m];
-            const float lb = lb_ub ? lb_ub[2 * r] : 0.0f;
-            const float range = lb_ub ? (lb_ub[2 * r + 1] - lb) : 0.0f;
-            const float n = level_to_norm<LevelT>(levels[(int64_t)r * M + m], lb, range, s);
+            const int code = (int)codes[(int64_t)r * code_stride + m];
+            const float lb = lb_ub ? lb_ub[r * lbub_stride] : 0.0f;
+            const float range = lb_ub ? (lb_ub[r * lbub_stride + 1] - lb) : 0.0f;
+            const float n = level_to_norm<LevelT>(levels[(int64_t)r * level_stride + m], lb, range, s);
             const float *row = (LDS_CB ? s_cb : cb) + (int64_t)code * d + 4 * q;
             const f32x4 c = *reinterpret_cast<const f32x4 *>(row);
             f32x4 dec;
@@ -78,7 +79,8 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_v4_kernel(
 template <typename CodeT, typename LevelT>
 __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_scalar_kernel(
     const CodeT *__restrict__ codes, const LevelT *__restrict__ levels, const float *__restrict__ lb_ub,
-    const float *__restrict__ cb, int R, int64_t M, int d, int n_bit, float *__restrict__ out) {
+    int64_t code_stride, int64_t level_stride, int64_t lbub_stride, const float *__restrict__ cb, int R, int64_t M,
+    int d, int n_bit, float *__restrict__ out) {
     const int64_t total = M * d;
     const float s = (float)(1 << (n_bit & 31));
     const float fR = (float)R;
@@ -88,10 +90,10 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_scalar_kernel(
         const int jj = (int)(i - m * d);
         float acc = 0.0f;
         for (int r = 0; r < R; ++r) {
-            const int code = (int)codes[(int64_t)r * M + m];
-            const float lb = lb_ub ? lb_ub[2 * r] : 0.0f;
-            const float range = lb_ub ? (lb_ub[2 * r + 1] - lb) : 0.0f;
-            const float n = level_to_norm<LevelT>(levels[(int64_t)r * M + m], lb, range, s);
+            const int code = (int)codes[(int64_t)r * code_stride + m];
+            const float lb = lb_ub ? lb_ub[r * lbub_stride] : 0.0f;
+            const float range = lb_ub ? (lb_ub[r * lbub_stride + 1] - lb) : 0.0f;
+            const float n = level_to_norm<LevelT>(levels[(int64_t)r * level_stride + m], lb, range, s);
             const float dec = cb[(int64_t)code * d + jj] * n;
             acc = (r == 0) ? dec : acc + dec;
         }
@@ -101,8 +103,9 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_scalar_kernel(
 }
 
 template <typename CodeT, typename LevelT>
-static int launch_decode(const CodeT *codes, const LevelT *levels, const float *lb_ub, const float *cb, int R,
-                         int64_t M, int d, int K, int n_bit, float *out, hipStream_t st) {
+static int launch_decode(const CodeT *codes, const LevelT *levels, const float *lb_ub, int64_t cs, int64_t ls,
+                         int64_t bs, const float *cb, int R, int64_t M, int d, int K, int n_bit, float *out,
+                         hipStream_t st) {
     const int64_t cap = (int64_t)cu_count() * 8;
     if ((d & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(cb) & 15) == 0) {
         const int64_t total = M * (d >> 2);
@@ -113,10 +116,10 @@ static int launch_decode(const CodeT *codes, const LevelT *levels, const float *
         // stage the codebook in LDS when it fits and the launch is big enough to amortise it
         if (lds <= 64 * 1024 && total >= (int64_t)K * d) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_v4_kernel<CodeT, LevelT, true>), dim3((unsigned)blocks),
-                               dim3(DEC_THREADS), lds, st, codes, levels, lb_ub, cb, R, M, d, K, n_bit, out);
+                               dim3(DEC_THREADS), lds, st, codes, levels, lb_ub, cs, ls, bs, cb, R, M, d, K, n_bit, out);
         } else {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_v4_kernel<CodeT, LevelT, false>), dim3((unsigned)blocks),
-                               dim3(DEC_THREADS), 0, st, codes, levels, lb_ub, cb, R, M, d, K, n_bit, out);
+                               dim3(DEC_THREADS), 0, st, codes, levels, lb_ub, cs, ls, bs, cb, R, M, d, K, n_bit, out);
         }
     } else {
         const int64_t total = M * d;
@@ -124,28 +127,29 @@ static int launch_decode(const CodeT *codes, const LevelT *levels, const float *
         if (blocks > cap) blocks = cap;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_scalar_kernel<CodeT, LevelT>), dim3((unsigned)blocks),
-                           dim3(DEC_THREADS), 0, st, codes, levels, lb_ub, cb, R, M, d, n_bit, out);
+                           dim3(DEC_THREADS), 0, st, codes, levels, lb_ub, cs, ls, bs, cb, R, M, d, n_bit, out);
     }
     GQ_CHECK_LAUNCH("gq_hsq_decode_sum");
     return GQ_OK;
 }
 
 template <typename CodeT>
-static int dispatch_levels(const CodeT *codes, const void *levels, int level_bytes, const float *lb_ub,
-                           const float *cb, int R, int64_t M, int d, int K, int n_bit, float *out, hipStream_t st) {
+static int dispatch_levels(const CodeT *codes, int64_t cs, const void *levels, int level_bytes, int64_t ls,
+                           const float *lb_ub, int64_t bs, const float *cb, int R, int64_t M, int d, int K, int n_bit,
+                           float *out, hipStream_t st) {
     switch (level_bytes) {
         case 0:
-            return launch_decode<CodeT, float>(codes, static_cast<const float *>(levels), nullptr, cb, R, M, d, K, 0,
-                                               out, st);
+            return launch_decode<CodeT, float>(codes, static_cast<const float *>(levels), nullptr, cs, ls, 0, cb, R, M,
+                                               d, K, 0, out, st);
         case 1:
-            return launch_decode<CodeT, uint8_t>(codes, static_cast<const uint8_t *>(levels), lb_ub, cb, R, M, d, K,
-                                                 n_bit, out, st);
+            return launch_decode<CodeT, uint8_t>(codes, static_cast<const uint8_t *>(levels), lb_ub, cs, ls, bs, cb, R,
+                                                 M, d, K, n_bit, out, st);
         case 2:
-            return launch_decode<CodeT, uint16_t>(codes, static_cast<const uint16_t *>(levels), lb_ub, cb, R, M, d, K,
-                                                  n_bit, out, st);
+            return launch_decode<CodeT, uint16_t>(codes, static_cast<const uint16_t *>(levels), lb_ub, cs, ls, bs, cb,
+                                                  R, M, d, K, n_bit, out, st);
         case 4:
-            return launch_decode<CodeT, int32_t>(codes, static_cast<const int32_t *>(levels), lb_ub, cb, R, M, d, K,
-                                                 n_bit, out, st);
+            return launch_decode<CodeT, int32_t>(codes, static_cast<const int32_t *>(levels), lb_ub, cs, ls, bs, cb, R,
+                                                 M, d, K, n_bit, out, st);
         default:
             return fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: level_bytes must be 0, 1, 2 or 4");
     }
@@ -153,20 +157,32 @@ static int dispatch_levels(const CodeT *codes, const void *levels, int level_byt
 
 }  // namespace gq
 
-GQ_API int gq_hsq_decode_sum(const void *codes, int code_bytes, const void *levels, int level_bytes,
-                             const float *lb_ub, const float *codebook, int R, int64_t M, int d, int K, int n_bit,
-                             float *out, void *stream) {
+GQ_API int gq_hsq_decode_sum_strided(const void *codes, int code_bytes, int64_t code_stride_bytes, const void *levels,
+                                     int level_bytes, int64_t level_stride_bytes, const float *lb_ub,
+                                     int64_t lbub_stride_bytes, const float *codebook, int R, int64_t M, int d, int K,
+                                     int n_bit, float *out, void *stream) {
     if (M < 1 || d < 1 || K < 1 || R < 1)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: bad sizes R=%d M=%lld d=%d K=%d", R, (long long)M, d, K);
     if (!codes || !levels || !codebook || !out) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: null pointer");
     if (level_bytes != 0 && (!lb_ub || n_bit < 1 || n_bit > 30))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: lb_ub / n_bit required with integer levels");
+    const int lsz = level_bytes == 0 ? 4 : level_bytes;
+    if ((code_bytes != 1 && code_bytes != 4) || code_stride_bytes % code_bytes || level_stride_bytes % lsz ||
+        lbub_stride_bytes % 4)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: strides must be multiples of the element size");
     hipStream_t st = gq::as_stream(stream);
+    const int64_t cs = code_stride_bytes / code_bytes, ls = level_stride_bytes / lsz, bs = lbub_stride_bytes / 4;
     if (code_bytes == 1)
-        return gq::dispatch_levels<uint8_t>(static_cast<const uint8_t *>(codes), levels, level_bytes, lb_ub, codebook,
-                                            R, M, d, K, n_bit, out, st);
-    if (code_bytes == 4)
-        return gq::dispatch_levels<int32_t>(static_cast<const int32_t *>(codes), levels, level_bytes, lb_ub, codebook,
-                                            R, M, d, K, n_bit, out, st);
-    return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: code_bytes must be 1 or 4");
+        return gq::dispatch_levels<uint8_t>(static_cast<const uint8_t *>(codes), cs, levels, level_bytes, ls, lb_ub, bs,
+                                            codebook, R, M, d, K, n_bit, out, st);
+    return gq::dispatch_levels<int32_t>(static_cast<const int32_t *>(codes), cs, levels, level_bytes, ls, lb_ub, bs,
+                                        codebook, R, M, d, K, n_bit, out, st);
+}
+
+GQ_API int gq_hsq_decode_sum(const void *codes, int code_bytes, const void *levels, int level_bytes,
+                             const float *lb_ub, const float *codebook, int R, int64_t M, int d, int K, int n_bit,
+                             float *out, void *stream) {
+    const int lsz = level_bytes == 0 ? 4 : level_bytes;
+    return gq_hsq_decode_sum_strided(codes, code_bytes, M * (int64_t)code_bytes, levels, level_bytes, M * (int64_t)lsz,
+                                     lb_ub, 8, codebook, R, M, d, K, n_bit, out, stream);
 }

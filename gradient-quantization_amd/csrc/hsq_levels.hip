@@ -102,3 +102,49 @@ GQ_API int gq_hsq_levels(const float *u, int64_t M, int n_bit, int random_mode, 
     GQ_CHECK_LAUNCH("gq_hsq_levels");
     return GQ_OK;
 }
+
+// ---- standalone min/max partials (ProbabilisticScalarCompressor used on its own) -------
+namespace gq {
+__global__ __launch_bounds__(LV_THREADS) void minmax_partials_kernel(const float *__restrict__ v, int64_t n,
+                                                                    float *__restrict__ partials) {
+    __shared__ float s_min[LV_THREADS / 64], s_max[LV_THREADS / 64];
+    float lo = INFINITY, hi = -INFINITY;
+    const int64_t stride = (int64_t)gridDim.x * LV_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * LV_THREADS + threadIdx.x; i < n; i += stride) {
+        const float x = v[i];
+        lo = fminf(lo, x);
+        hi = fmaxf(hi, x);
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0) {
+        s_min[threadIdx.x >> 6] = lo;
+        s_max[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < LV_THREADS / 64; ++w) {
+            lo = fminf(lo, s_min[w]);
+            hi = fmaxf(hi, s_max[w]);
+        }
+        partials[2 * blockIdx.x] = lo;
+        partials[2 * blockIdx.x + 1] = hi;
+    }
+    if (blockIdx.x == 0)
+        for (int i = gridDim.x + threadIdx.x; i < GQ_MAX_PARTIALS; i += LV_THREADS) {
+            partials[2 * i] = INFINITY;
+            partials[2 * i + 1] = -INFINITY;
+        }
+}
+}  // namespace gq
+
+GQ_API int gq_minmax_partials(const float *v, int64_t n, float *minmax_partials, void *stream) {
+    if (n < 1 || !v || !minmax_partials) return gq::fail(GQ_ERR_INVALID_ARG, "gq_minmax_partials: bad arguments");
+    int64_t blocks = (n + gq::LV_THREADS * 8 - 1) / (gq::LV_THREADS * 8);
+    if (blocks > GQ_MAX_PARTIALS) blocks = GQ_MAX_PARTIALS;
+    hipLaunchKernelGGL(gq::minmax_partials_kernel, dim3((unsigned)blocks), dim3(gq::LV_THREADS), 0,
+                       gq::as_stream(stream), v, n, minmax_partials);
+    GQ_CHECK_LAUNCH("gq_minmax_partials");
+    return GQ_OK;
+}

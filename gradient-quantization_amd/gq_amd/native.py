@@ -19,7 +19,7 @@ ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU = 0, 1, 2, 3
 
 EXPORTS = [
     "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_encode", "gq_hsq_encode_impl", "gq_hsq_levels",
-    "gq_hsq_decode_sum", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
+    "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
 
 _lib = None
@@ -109,6 +109,11 @@ def hsq_levels(u, n_bit, random_mode, r, seed, partials, lb_ub, levels):
     _check(rc, "gq_hsq_levels")
 
 
+def minmax_partials(v, partials):
+    _check(lib().gq_minmax_partials(_dev_ptr(v, torch.float32, "v"), ctypes.c_int64(v.numel()),
+                                    _dev_ptr(partials, torch.float32, "partials"), _stream()), "gq_minmax_partials")
+
+
 def hsq_decode_sum(codes, levels, lb_ub, codebook, n_bit, out, R=1):
     """codes [R,M], levels [R,M] (int) or f32 norms [R,M], lb_ub [R,2] -> out f32 [M*d] (mean over R)."""
     K, d = codebook.shape
@@ -126,6 +131,26 @@ def hsq_decode_sum(codes, levels, lb_ub, codebook, n_bit, out, R=1):
                                  ctypes.c_int(d), ctypes.c_int(K), ctypes.c_int(n_bit if lvl_bytes else 0),
                                  _dev_ptr(out, torch.float32, "out"), _stream())
     _check(rc, "gq_hsq_decode_sum")
+
+
+def hsq_decode_sum_packed(wire, M, codebook, n_bit, out, R, codes_off=0, levels_off=None, lbub_off=None,
+                          code_dtype=torch.uint8, level_dtype=torch.uint8):
+    """Decode the all-gathered wire buffer `wire` (uint8 [R, P]; per rank: codes at codes_off,
+    levels at levels_off, (lb, ub) f32 at lbub_off) and average over the R ranks -- no repack."""
+    K, d = codebook.shape
+    assert wire.dtype == torch.uint8 and wire.dim() == 2 and wire.shape[0] == R and wire.is_contiguous()
+    P = wire.shape[1]
+    cb_, lb_ = _CODE_BYTES[code_dtype], _LEVEL_BYTES[level_dtype]
+    assert out.numel() == M * d
+    base = wire.data_ptr()
+    _dev_ptr(wire, torch.uint8, "wire")
+    rc = lib().gq_hsq_decode_sum_strided(
+        ctypes.c_void_p(base + codes_off), ctypes.c_int(cb_), ctypes.c_int64(P),
+        ctypes.c_void_p(base + levels_off), ctypes.c_int(lb_), ctypes.c_int64(P),
+        ctypes.c_void_p(base + lbub_off), ctypes.c_int64(P),
+        _dev_ptr(codebook, torch.float32, "codebook"), ctypes.c_int(R), ctypes.c_int64(M), ctypes.c_int(d),
+        ctypes.c_int(K), ctypes.c_int(n_bit), _dev_ptr(out, torch.float32, "out"), _stream())
+    _check(rc, "gq_hsq_decode_sum_strided")
 
 
 def axpy_inplace(grad, err, scale):

@@ -1,0 +1,39 @@
+"""Wire format of one rank's compressed gradient (what RCCL all-gathers over xGMI).
+
+The reference never ships compressed bytes (ps_quantizer.py:41-43 decodes in place);
+this layout is what makes the (codes, levels) payload real.  For one HSQ tensor of M
+subvectors with k_bit <= 8 and levels that fit a byte:
+
+    [ codes u8[M] | pad to 16 | levels u8[M] | pad to 16 | lb f32 | ub f32 | pad to 16 ]
+
+All sections are 16-byte aligned so the kernels can write them in place (the encode
+and level kernels write straight into views of this buffer; nothing is repacked).
+"""
+import torch
+
+
+def _up(x, a=16):
+    return (x + a - 1) // a * a
+
+
+class HSQWire:
+    """Offsets of the sections of one rank's payload."""
+
+    def __init__(self, M):
+        self.M = M
+        self.codes_off = 0
+        self.levels_off = _up(M)
+        self.lbub_off = self.levels_off + _up(M)
+        self.nbytes = self.lbub_off + 16
+
+    def alloc(self, device, ranks=None):
+        shape = (self.nbytes,) if ranks is None else (ranks, self.nbytes)
+        return torch.empty(shape, dtype=torch.uint8, device=device)
+
+    def views(self, buf):
+        """(codes u8[M], levels u8[M], lb_ub f32[2]) views into a 1-D payload buffer."""
+        assert buf.dim() == 1 and buf.numel() == self.nbytes
+        codes = buf[self.codes_off:self.codes_off + self.M]
+        levels = buf[self.levels_off:self.levels_off + self.M]
+        lb_ub = buf[self.lbub_off:self.lbub_off + 8].view(torch.float32)
+        return codes, levels, lb_ub

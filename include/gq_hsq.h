@@ -88,6 +88,11 @@ int gq_hsq_encode_impl(const float *grad, const float *codebook, int64_t M, int 
 int gq_hsq_levels(const float *u, int64_t M, int n_bit, int random_mode, const float *r, uint64_t seed,
                   const float *minmax_partials, float *lb_ub, void *levels, int level_bytes, void *stream);
 
+/* Per-workgroup (min,max) of an arbitrary f32 vector in the minmax_partials format, for
+ * running gq_hsq_levels on a vector that did not come out of gq_hsq_encode
+ * (ProbabilisticScalarCompressor used on its own; torch.min/torch.max at prob_scalar:13-14). */
+int gq_minmax_partials(const float *v, int64_t n, float *minmax_partials, void *stream);
+
 /*
  * Decode + aggregate -- replaces probabilistic_scalar_compressor.py:29-33 and
  * nearest_neighbor_compressor.py:80-90 for each of R payloads, then
@@ -100,6 +105,14 @@ int gq_hsq_levels(const float *u, int64_t M, int n_bit, int random_mode, const f
  */
 int gq_hsq_decode_sum(const void *codes, int code_bytes, const void *levels, int level_bytes, const float *lb_ub,
                       const float *codebook, int R, int64_t M, int d, int K, int n_bit, float *out, void *stream);
+
+/* Same with explicit per-payload strides (bytes): payload r starts at codes + r*code_stride_bytes,
+ * levels + r*level_stride_bytes, lb_ub + r*lbub_stride_bytes.  This is what the all-gathered
+ * wire buffer [R][codes | levels | lb,ub] is decoded from without a repack. */
+int gq_hsq_decode_sum_strided(const void *codes, int code_bytes, int64_t code_stride_bytes, const void *levels,
+                              int level_bytes, int64_t level_stride_bytes, const float *lb_ub,
+                              int64_t lbub_stride_bytes, const float *codebook, int R, int64_t M, int d, int K,
+                              int n_bit, float *out, void *stream);
 
 /*
  * Error-feedback helpers fused around the codec (ps_quantizer.py:35,39):
