@@ -1,0 +1,421 @@
+"""Quantizer layer with the reference's contract:
+
+    q = Quantizer(Compressor, model.parameters(), args)      # args.mode in {'ps','ring'}
+    for user in ...: loss.backward(); q.record(user, epoch=epoch)
+    q.apply(); optimizer.step()
+
+PSQuantizer mirrors quantizers/ps_quantizer.py:6-65, re-designed around a real wire:
+
+* `record` compresses every gradient straight into this user's slot of ONE wire buffer
+  (codes | levels | lb,ub per tensor; raw f32 for the <=1000-element tensors).  Nothing is
+  decoded unless error feedback needs the residual.
+* `apply` (alias `aggregate`) all-gathers the wire buffers of all ranks with ONE RCCL
+  collective when torch.distributed is initialised (world_size > 1: every rank is one or
+  more of the reference's `num_users`), then runs decode+mean on the GPU: payloads are
+  summed in (rank, user) order and divided by their count -- the same arithmetic as the
+  reference's torch.stack(decoded).mean(0) -- and `param.grad.data` is rebound to it.
+
+The single-process case (no process group) is the reference's simulated-users loop with
+identical results; the wire simply never leaves the GPU.
+
+Codecs are the only objects that touch device memory; the product codecs call the HIP
+library (gq_amd.native).  `codec_factory` exists so that the host logic above can be
+exercised without a GPU by the tests (with the CPU oracle as the checker codec).
+"""
+import math
+
+import torch
+
+from . import native
+from .compressors import (IdenticalCompressor, NearestNeighborCompressor, QSGDCompressor, _next_seed,
+                          _require_device)
+
+
+def _up(x, a=16):
+    return (x + a - 1) // a * a
+
+
+# --------------------------------------------------------------------------------------
+# Codecs: how one parameter tensor is written to / read from the wire
+# --------------------------------------------------------------------------------------
+class DenseCodec(object):
+    """IdenticalCompressor tensors (<=1000 elements, ps_quantizer.py:18-19): raw f32 on the wire."""
+
+    def __init__(self, compressor, numel, shape):
+        self.numel, self.shape = numel, shape
+        self.nbytes = _up(numel * 4)
+
+    def encode_into(self, grad, wire_user, off, salt):
+        wire_user[off:off + self.numel * 4].view(torch.float32).copy_(grad.reshape(-1))
+
+    def roundtrip(self, grad, salt):
+        return grad.clone()
+
+    def decode_mean(self, gathered, off, R):
+        # [R, numel] view of the gathered wire; stack().mean(0) of the reference
+        rows = gathered[:, off:off + self.numel * 4].view(torch.float32)
+        return rows.mean(dim=0).view(self.shape)
+
+
+class GenericCodec(object):
+    """Any other compressor class (sign, top-k, user supplied): ships the DECODED tensor.
+    Keeps the reference semantics (mean of decompress(compress(g))) without a compact format."""
+
+    def __init__(self, compressor, numel, shape):
+        self.c, self.numel, self.shape = compressor, numel, shape
+        self.nbytes = _up(numel * 4)
+
+    def roundtrip(self, grad, salt):
+        return self.c.decompress(self.c.compress(grad)).reshape(self.shape)
+
+    def encode_into(self, grad, wire_user, off, salt):
+        wire_user[off:off + self.numel * 4].view(torch.float32).copy_(self.roundtrip(grad, salt).reshape(-1))
+
+    def decode_mean(self, gathered, off, R):
+        rows = gathered[:, off:off + self.numel * 4].view(torch.float32)
+        return rows.mean(dim=0).view(self.shape)
+
+
+class HSQCodec(object):
+    """NearestNeighborCompressor on the HIP kernels.  Wire per user:
+    codes[M] (uint8 | int32) | levels[M] (uint8/int16/int32, or f32 u when n_bit == 32) | lb, ub."""
+
+    def __init__(self, compressor, numel, shape):
+        self.c, self.numel, self.shape = compressor, numel, shape
+        M = compressor.M
+        self.M = M
+        self.code_dtype = compressor.code_dtype
+        self.level_dtype = compressor.wire_level_dtype() if compressor.compressed_norm else torch.float32
+        cb = torch.empty(0, dtype=self.code_dtype).element_size()
+        lb = torch.empty(0, dtype=self.level_dtype).element_size()
+        self.codes_off = 0
+        self.levels_off = _up(M * cb)
+        self.lbub_off = self.levels_off + _up(M * lb)
+        self.nbytes = self.lbub_off + 16
+        self._u = None
+        self._partials = None
+
+    def _views(self, wire_user, off):
+        M = self.M
+        cb = torch.empty(0, dtype=self.code_dtype).element_size()
+        lb = torch.empty(0, dtype=self.level_dtype).element_size()
+        codes = wire_user[off + self.codes_off:off + self.codes_off + M * cb].view(self.code_dtype)
+        levels = wire_user[off + self.levels_off:off + self.levels_off + M * lb].view(self.level_dtype)
+        lb_ub = wire_user[off + self.lbub_off:off + self.lbub_off + 8].view(torch.float32)
+        return codes, levels, lb_ub
+
+    def _scratch(self, dev):
+        if self._u is None or self._u.device != dev:
+            self._u = torch.empty(self.M, dtype=torch.float32, device=dev)
+            self._partials = native.new_partials(dev)
+        return self._u, self._partials
+
+    def _levels(self, u, partials, levels, lb_ub, salt):
+        nc = self.c.norm_compressor
+        if not nc.random:
+            native.hsq_levels(u, nc.n_bit, native.RANDOM_OFF, None, 0, partials, lb_ub, levels)
+        elif nc._rng == "reference":
+            r = torch.rand(self.M)
+            native.hsq_levels(u, nc.n_bit, native.RANDOM_GIVEN, r.to(u.device), 0, partials, lb_ub, levels)
+        else:
+            native.hsq_levels(u, nc.n_bit, native.RANDOM_DEVICE, None, _next_seed() ^ salt, partials, lb_ub, levels)
+
+    def encode_into(self, grad, wire_user, off, salt):
+        _require_device(grad, "HSQCodec.encode_into")
+        dev = grad.device
+        flat = grad.contiguous().view(-1)
+        codes, levels, lb_ub = self._views(wire_user, off)
+        cbk = self.c._codebook_on(dev)
+        if self.c.compressed_norm:
+            u, partials = self._scratch(dev)
+            native.hsq_encode(flat, cbk, codes, u, partials)
+            self._levels(u, partials, levels, lb_ub, salt)
+        else:
+            _, partials = self._scratch(dev)
+            native.hsq_encode(flat, cbk, codes, levels, partials)  # `levels` section holds f32 u
+
+    def decode_wire(self, wire_user, off, out):
+        """Decode this user's own payload (error feedback residual)."""
+        self._decode(wire_user.view(1, -1), off, 1, out)
+
+    def _decode(self, gathered, off, R, out):
+        P = gathered.shape[1]
+        cbk = self.c._codebook_on(gathered.device)
+        native.hsq_decode_sum_packed(gathered, self.M, cbk, self.c.n_bit if self.c.compressed_norm else 32, out, R,
+                                     codes_off=off + self.codes_off, levels_off=off + self.levels_off,
+                                     lbub_off=off + self.lbub_off, code_dtype=self.code_dtype,
+                                     level_dtype=self.level_dtype)
+        assert P == gathered.stride(0)
+
+    def roundtrip(self, grad, salt):
+        dev = grad.device
+        tmp = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
+        self.encode_into(grad, tmp, 0, salt)
+        out = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        self.decode_wire(tmp, 0, out)
+        return out.view(self.shape)
+
+    def decode_mean(self, gathered, off, R):
+        out = torch.empty(self.numel, dtype=torch.float32, device=gathered.device)
+        self._decode(gathered, off, R, out)
+        return out.view(self.shape)
+
+
+class QSGDCodec(object):
+    """QSGDCompressor on the HIP kernels.  Wire per user: norm f32[Mb] | signs u8[n] | levels u8|i32 [n]."""
+
+    def __init__(self, compressor, numel, shape):
+        self.c, self.numel, self.shape = compressor, numel, shape
+        self.Mb, self.d = compressor.M, compressor.dim
+        top = 2 ** compressor.bit
+        self.level_dtype = torch.uint8 if top <= 127 else torch.int32
+        lb = torch.empty(0, dtype=self.level_dtype).element_size()
+        self.norm_off = 0
+        self.signs_off = _up(self.Mb * 4)
+        self.levels_off = self.signs_off + _up(numel)
+        self.nbytes = self.levels_off + _up(numel * lb)
+
+    def _views(self, wire_user, off):
+        lb = torch.empty(0, dtype=self.level_dtype).element_size()
+        norm = wire_user[off + self.norm_off:off + self.norm_off + self.Mb * 4].view(torch.float32)
+        signs = wire_user[off + self.signs_off:off + self.signs_off + self.numel]
+        levels = wire_user[off + self.levels_off:off + self.levels_off + self.numel * lb].view(self.level_dtype)
+        return norm, signs, levels
+
+    def encode_into(self, grad, wire_user, off, salt):
+        _require_device(grad, "QSGDCodec.encode_into")
+        flat = grad.contiguous().view(-1)
+        norm, signs, levels = self._views(wire_user, off)
+        c = self.c
+        if not c.random:
+            native.qsgd_compress(flat, self.d, c.bit, native.RANDOM_OFF, None, 0, norm, signs, levels)
+        elif c._rng == "reference":
+            r = torch.rand(self.Mb, self.d)
+            native.qsgd_compress(flat, self.d, c.bit, native.RANDOM_GIVEN, r.to(flat.device).view(-1), 0, norm, signs,
+                                 levels)
+        else:
+            native.qsgd_compress(flat, self.d, c.bit, native.RANDOM_DEVICE, None, _next_seed() ^ salt, norm, signs,
+                                 levels)
+
+    def _decode_rows(self, gathered, off, R, out):
+        # the QSGD entry point takes dense [R][...] arrays: gather the three sections
+        # (strided views -> contiguous; QSGD payloads are 2 B/element so this is a small copy)
+        lb = torch.empty(0, dtype=self.level_dtype).element_size()
+        norm = gathered[:, off + self.norm_off:off + self.norm_off + self.Mb * 4].contiguous().view(torch.float32)
+        signs = gathered[:, off + self.signs_off:off + self.signs_off + self.numel].contiguous()
+        levels = gathered[:, off + self.levels_off:off + self.levels_off + self.numel * lb].contiguous() \
+            .view(self.level_dtype)
+        native.qsgd_decode_sum(norm.view(-1), signs.view(-1), levels.view(-1), self.d, self.c.bit, out, R=R)
+
+    def roundtrip(self, grad, salt):
+        tmp = torch.empty(self.nbytes, dtype=torch.uint8, device=grad.device)
+        self.encode_into(grad, tmp, 0, salt)
+        out = torch.empty(self.numel, dtype=torch.float32, device=grad.device)
+        self._decode_rows(tmp.view(1, -1), 0, 1, out)
+        return out.view(self.shape)
+
+    def decode_wire(self, wire_user, off, out):
+        self._decode_rows(wire_user.view(1, -1), off, 1, out)
+
+    def decode_mean(self, gathered, off, R):
+        out = torch.empty(self.numel, dtype=torch.float32, device=gathered.device)
+        self._decode_rows(gathered, off, R, out)
+        return out.view(self.shape)
+
+
+def default_codec_factory(compressor, numel, shape):
+    if isinstance(compressor, IdenticalCompressor):
+        return DenseCodec(compressor, numel, shape)
+    if isinstance(compressor, NearestNeighborCompressor):
+        return HSQCodec(compressor, numel, shape)
+    if isinstance(compressor, QSGDCompressor):
+        return QSGDCodec(compressor, numel, shape)
+    return GenericCodec(compressor, numel, shape)
+
+
+# --------------------------------------------------------------------------------------
+# Parameter-server quantizer
+# --------------------------------------------------------------------------------------
+def _ef_scale(args, epoch):
+    # ps_quantizer.py:28-31
+    if args.scale == 'exp':
+        return 2 / (math.exp(-epoch) + 1) - 1
+    return float(args.scale)
+
+
+def _dist_world(process_group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(process_group), dist.get_rank(process_group)
+    return 1, 0
+
+
+class PSQuantizer(object):
+    def __init__(self, Compressor, parameters, args, process_group=None, codec_factory=None):
+        self.parameters = list(parameters)
+        self.num_layers = len(self.parameters)
+        self.args = args
+        self.error_feedback = args.ef
+        self.two_phase = args.two_phase
+        self.process_group = process_group
+        factory = codec_factory or default_codec_factory
+        self.compressors = []
+        self.codecs = []
+        self.offsets = []
+        off = 0
+        for param in self.parameters:
+            param_size = param.flatten().shape[0]
+            comp = Compressor(param_size, param.shape, args) if param_size > 1000 else IdenticalCompressor()
+            codec = factory(comp, param_size, param.shape)
+            self.compressors.append(comp)
+            self.codecs.append(codec)
+            self.offsets.append(off)
+            off += codec.nbytes
+            if self.error_feedback:
+                param.error = [torch.zeros_like(param) for _ in range(args.num_users)]
+            if self.error_feedback and self.two_phase:
+                param.server_error = torch.zeros_like(param)
+        self.user_bytes = _up(off)          # one user's payload (all tensors)
+        self.capacity = max(1, int(args.num_users))
+        self.recorded = 0                   # record() calls since the last apply()
+        self._wire = None
+        self._gathered = None
+
+    # ---- buffers -------------------------------------------------------------------------
+    def _ensure_wire(self, device, slots):
+        if self._wire is None or self._wire.device != device or self._wire.shape[0] < slots:
+            cap = max(self.capacity, slots)
+            new = torch.zeros((cap, self.user_bytes), dtype=torch.uint8, device=device)
+            if self._wire is not None and self._wire.device == device:
+                new[:self._wire.shape[0]].copy_(self._wire)
+            self._wire = new
+            self.capacity = cap
+        return self._wire
+
+    def wire_bytes_per_user(self):
+        return self.user_bytes
+
+    # ---- reference protocol -------------------------------------------------------------
+    def record(self, user, epoch):
+        scale = _ef_scale(self.args, epoch)
+        dev = self.parameters[0].grad.device
+        slot = self.recorded
+        wire = self._ensure_wire(dev, slot + 1)[slot]
+        world, rank = _dist_world(self.process_group)
+        salt = ((rank * 1000003 + user) * 0x9E3779B1) & (2 ** 62 - 1)
+        for i, param in enumerate(self.parameters):
+            codec, off = self.codecs[i], self.offsets[i]
+            grad = param.grad.data
+            if self.error_feedback:
+                # ps_quantizer.py:35-39:  grad += scale*error ; error = grad - decoded
+                if grad.device.type == "cuda" and grad.is_contiguous() and grad.dtype == torch.float32:
+                    native.axpy_inplace(grad, param.error[user].contiguous(), scale)
+                else:
+                    grad.add_(scale * param.error[user])
+                codec.encode_into(grad, wire, off, salt)
+                if hasattr(codec, "decode_wire"):
+                    decoded = torch.empty(grad.numel(), dtype=torch.float32, device=grad.device)
+                    codec.decode_wire(wire, off, decoded)
+                    decoded = decoded.view(param.shape)
+                else:
+                    decoded = codec.roundtrip(grad, salt)
+                if grad.device.type == "cuda" and grad.is_contiguous():
+                    err = torch.empty_like(grad)
+                    native.sub(grad, decoded.contiguous(), err)
+                    param.error[user].data = err
+                else:
+                    param.error[user].data = grad - decoded
+            else:
+                codec.encode_into(grad, wire, off, salt)
+        self.recorded += 1
+
+    def apply(self):
+        if self.recorded == 0:
+            return
+        world, rank = _dist_world(self.process_group)
+        local = self._wire[:self.recorded]
+        if world > 1:
+            import torch.distributed as dist
+            need = (world * self.recorded, self.user_bytes)
+            if self._gathered is None or tuple(self._gathered.shape) != need or self._gathered.device != local.device:
+                self._gathered = torch.empty(need, dtype=torch.uint8, device=local.device)
+            # ONE collective per step: every rank's [users, bytes] block, rank-major
+            dist.all_gather_into_tensor(self._gathered.view(-1), local.contiguous().view(-1),
+                                        group=self.process_group)
+            gathered = self._gathered
+        else:
+            gathered = local
+        R = gathered.shape[0]
+        for i, param in enumerate(self.parameters):
+            codec, off = self.codecs[i], self.offsets[i]
+            g = codec.decode_mean(gathered, off, R)
+            if self.two_phase:
+                # ps_quantizer.py:52-61 -- identical on every rank (salt 0, same call count)
+                if self.error_feedback:
+                    g = g + param.server_error
+                    decoded = codec.roundtrip(g, 0)
+                    param.server_error = g - decoded
+                    g = decoded
+                else:
+                    g = codec.roundtrip(g, 0)
+            param.grad.data = g
+        self.recorded = 0
+
+    aggregate = apply
+
+
+# --------------------------------------------------------------------------------------
+# Ring quantizer (the reference's other --mode; sequential by construction)
+# --------------------------------------------------------------------------------------
+class RingQuantizer(object):
+    """quantizers/ring_quantizer.py:7-49: user k adds user k-1's decoded running sum to its
+    own gradient and re-compresses; the result is the LAST user's decode (a sum, not a mean)."""
+
+    def __init__(self, Compressor, parameters, args, codec_factory=None):
+        self.parameters = list(parameters)
+        self.args = args
+        self.error_feedback = args.ef
+        factory = codec_factory or default_codec_factory
+        self.compressors, self.codecs = [], []
+        for param in self.parameters:
+            n = param.flatten().shape[0]
+            comp = Compressor(n, param.shape, args) if n > 1000 else IdenticalCompressor()
+            self.compressors.append(comp)
+            self.codecs.append(factory(comp, n, param.shape))
+            if self.error_feedback:
+                param.error = [torch.zeros_like(param) for _ in range(args.num_users)]
+        self.running = [None] * len(self.parameters)
+
+    def record(self, user, epoch):
+        scale = _ef_scale(self.args, epoch)
+        for i, param in enumerate(self.parameters):
+            grad = param.grad.data
+            if user != 0 and self.running[i] is not None:
+                grad.add_(self.running[i])
+            if self.error_feedback:
+                grad.add_(scale * param.error[user])
+                decoded = self.codecs[i].roundtrip(grad, user)
+                param.error[user].data = grad - decoded
+            else:
+                decoded = self.codecs[i].roundtrip(grad, user)
+            self.running[i] = decoded
+
+    def apply(self):
+        for i, param in enumerate(self.parameters):
+            if self.running[i] is not None:
+                param.grad.data = self.running[i]
+        self.running = [None] * len(self.parameters)
+
+    aggregate = apply
+
+
+def Quantizer(Compressor, parameters, args, **kw):
+    """quantizers/base_quantizer.py:5-10."""
+    if args.mode == 'ps':
+        return PSQuantizer(Compressor, parameters, args, **kw)
+    elif args.mode == 'ring':
+        return RingQuantizer(Compressor, parameters, args, **{k: v for k, v in kw.items() if k == "codec_factory"})
+    assert False, "mode {} not recognized".format(args.mode)
+
+
+__all__ = ["Quantizer", "PSQuantizer", "RingQuantizer"]

@@ -1,0 +1,66 @@
+"""Worker for the gloo world_size-2 test (tests/test_host_logic.py).  TEST-ONLY."""
+import os
+import sys
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT, os.path.join(ROOT, "gradient-quantization_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+SHAPES = [(96, 112), (96,), (12, 96), (12,), (40, 128)]
+
+
+def make_args(users, **kw):
+    base = dict(c_dim=16, k_bit=8, n_bit=6, no_cuda=True, random=0, ef=True, two_phase=False, scale="exp",
+                num_users=users, mode="ps", cr=256)
+    base.update(kw)
+    return Namespace(**base)
+
+
+def grads_for(global_user, step):
+    g = torch.Generator().manual_seed(1000 * step + global_user)
+    return [torch.randn(s, generator=g) * 1e-2 for s in SHAPES]
+
+
+def run(quantizer, params, local_users, first_global_user, steps=2):
+    out = {}
+    for st in range(steps):
+        for u in range(local_users):
+            for p, gr in zip(params, grads_for(first_global_user + u, st)):
+                p.grad = gr.clone()
+            quantizer.record(u, epoch=1)
+        quantizer.apply()
+        for i, p in enumerate(params):
+            out["s%d_p%d" % (st, i)] = p.grad.data.numpy().copy()
+    return out
+
+
+def build(users):
+    from oracle_codec import oracle_codec_factory
+    from gq_amd.compressors import NearestNeighborCompressor
+    from gq_amd.quantizers import Quantizer
+    params = [torch.nn.Parameter(torch.zeros(*s)) for s in SHAPES]
+    q = Quantizer(NearestNeighborCompressor, params, make_args(users), codec_factory=oracle_codec_factory)
+    return q, params
+
+
+def run_single_process(total_users):
+    q, params = build(total_users)
+    return run(q, params, total_users, 0)
+
+
+if __name__ == "__main__":
+    rank, world, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = 2
+    q, params = build(local)
+    res = run(q, params, local, rank * local)
+    np.savez(out + "_rank%d.npz" % rank, **res)
+    dist.barrier()
+    dist.destroy_process_group()
