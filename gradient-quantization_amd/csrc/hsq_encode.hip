@@ -86,12 +86,41 @@ __device__ __forceinline__ void write_minmax_partials(float lmin, float lmax, fl
 // scores of ITS subvector; the running best is updated in registers.
 // HBM traffic per subvector: 64 B read, 1 B code + 4 B u written.
 // ------------------------------------------------------------------------------------
+// 8 chained MFMAs = the 32 scores x 32 subvectors of one row block (ascending k: the fmaf chain).
+__device__ __forceinline__ f32x16 score_chain(const float (&a)[8], const float (&b)[8]) {
+    f32x16 acc = {0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], b[ks], acc, 0, 0, 0);
+    return acc;
+}
+
+// First-max over the 16 finished scores of one row block, then into the running best.
+// Inside a row block the candidates carry their ROW (0..27: inline constants, no VGPRs for
+// index literals); the block base rb*32 is added once per block.  Two independent chains
+// (registers 0-7 / 8-15; every index of the first is below every index of the second) keep
+// the compare -> select dependency from serialising the VALU.
+struct Best {
+    float v;
+    int i;
+};
+__device__ __forceinline__ void argmax_block(Best &best, const f32x16 &acc, int rb) {
+    float lv = acc[0], hv = acc[8];
+    int li = acc_row(0), hi = acc_row(8);
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+        take_if_greater(lv, li, acc[r], acc_row(r));
+        take_if_greater(hv, hi, acc[r + 8], acc_row(r + 8));
+    }
+    take_if_greater(lv, li, hv, hi);            // strict: ties stay with the lower rows
+    take_if_greater(best.v, best.i, lv, li + rb * 32);  // strict: ties stay with earlier blocks
+}
+
 template <typename CodeT>
-__global__ __launch_bounds__(ENC_THREADS) void hsq_encode_d16k256_kernel(const float *__restrict__ grad,
-                                                                        const float *__restrict__ cb, int64_t M,
-                                                                        CodeT *__restrict__ codes,
-                                                                        float *__restrict__ u,
-                                                                        float *__restrict__ partials) {
+__global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_d16k256_kernel(const float *__restrict__ grad,
+                                                                           const float *__restrict__ cb, int64_t M,
+                                                                           CodeT *__restrict__ codes,
+                                                                           float *__restrict__ u,
+                                                                           float *__restrict__ partials) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
 
@@ -126,8 +155,8 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_d16k256_kernel(const f
         const int64_t tn = t + nw;
         if (tn < ntiles) load_tile(tn, nxt);  // prefetch the next tile under this tile's MFMAs
 
-        float bv[2];
-        int bi[2];
+        // B fragments of both 32-subvector blocks: b[blk][ks] = v[2*ks + h]
+        float b[2][8];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             float r0 = cur[2 * blk][0], r1 = cur[2 * blk][1], r2 = cur[2 * blk][2], r3 = cur[2 * blk][3];
@@ -137,21 +166,35 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_d16k256_kernel(const f
             swap32(r2, r3);
             swap32(r4, r5);
             swap32(r6, r7);
-            const float b[8] = {r0, r2, r4, r6, r1, r3, r5, r7};  // b[ks] = v[2*ks + h]
+            b[blk][0] = r0; b[blk][1] = r2; b[blk][2] = r4; b[blk][3] = r6;
+            b[blk][4] = r1; b[blk][5] = r3; b[blk][6] = r5; b[blk][7] = r7;
+        }
 
-            float best_v = 0.0f;
-            int best_i = 0;
+        // Software pipeline over the 16 (block, row block) chains: the MFMAs of chain c+1 are
+        // issued between the VALU argmax instructions of chain c (two accumulator sets).
+        Best best[2] = {{0.0f, 0}, {0.0f, 0}};
+        f32x16 acc = score_chain(a[0], b[0]);
 #pragma unroll
-            for (int rb = 0; rb < 8; ++rb) {
-                f32x16 acc = {0};
+        for (int c = 0; c < 16; ++c) {
+            f32x16 nacc;
+            if (c + 1 < 16) nacc = score_chain(a[(c + 1) & 7], b[(c + 1) >> 3]);
+            argmax_block(best[c >> 3], acc, c & 7);
+            if (c + 1 < 16) {
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][ks], b[ks], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) take_if_greater(best_v, best_i, acc[r], rb * 32 + acc_row(r));
+                for (int k = 0; k < 8; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // six VALU (2 scores)
+                }
+                acc = nacc;
             }
-            bv[blk] = best_v;
-            bi[blk] = best_i + 4 * h;
+        }
+
+        float bv[2];
+        int bi[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            bv[blk] = best[blk].v;
+            bi[blk] = best[blk].i + 4 * h;
         }
 
         // Cross-half exchange: afterwards lane L holds both half-candidates of subvector
@@ -282,26 +325,40 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_valu_kernel(const floa
     write_minmax_partials(lmin, lmax, partials);
 }
 
+// Resident workgroups per CU of a kernel (occupancy API, cached): the persistent grids are
+// sized to exactly one resident wave of workgroups so that no workgroup queues behind another.
+template <typename KernelT>
+static int resident_blocks_per_cu(KernelT kernel, int threads, size_t lds) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) n = 1;
+    return n;
+}
+
 template <typename CodeT>
 static int launch_encode(const float *grad, const float *codebook, int64_t M, int d, int K, CodeT *codes, float *u,
                          float *partials, int impl, hipStream_t st) {
     const int cus = cu_count();
     const int64_t ntiles = (M + 63) / 64;
-    int64_t blocks = (ntiles + ENC_WAVES - 1) / ENC_WAVES;
-    int64_t cap = (int64_t)cus * 4;
-    if (cap > GQ_MAX_PARTIALS) cap = GQ_MAX_PARTIALS;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
+    static const int bpc_d16 = resident_blocks_per_cu(hsq_encode_d16k256_kernel<CodeT>, ENC_THREADS, 0);
+    static const int bpc_gen = resident_blocks_per_cu(hsq_encode_generic_kernel<CodeT>, ENC_THREADS, 0);
+    auto grid_for = [&](int bpc) {
+        int64_t blocks = (ntiles + ENC_WAVES - 1) / ENC_WAVES;
+        int64_t cap = (int64_t)cus * bpc;
+        if (cap > GQ_MAX_PARTIALS) cap = GQ_MAX_PARTIALS;
+        if (blocks > cap) blocks = cap;
+        return blocks < 1 ? (int64_t)1 : blocks;
+    };
+    const int64_t cap = (int64_t)cus * 4 > GQ_MAX_PARTIALS ? GQ_MAX_PARTIALS : (int64_t)cus * 4;
 
     if (impl == 0) impl = (d == 16 && K == 256) ? 1 : 2;
     if (impl == 1) {
         if (d != 16 || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 1 needs d=16, K=256");
         if ((reinterpret_cast<uintptr_t>(grad) & 15) != 0)
             return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: grad must be 16-byte aligned");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_d16k256_kernel<CodeT>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_d16k256_kernel<CodeT>), dim3((unsigned)grid_for(bpc_d16)),
                            dim3(ENC_THREADS), 0, st, grad, codebook, M, codes, u, partials);
     } else if (impl == 2) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_generic_kernel<CodeT>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_generic_kernel<CodeT>), dim3((unsigned)grid_for(bpc_gen)),
                            dim3(ENC_THREADS), 0, st, grad, codebook, M, d, K, codes, u, partials);
     } else if (impl == 3) {
         const size_t lds = (size_t)K * d * sizeof(float);
