@@ -103,7 +103,7 @@ def main():
     codes, levels, lb_ub = wire.views(payload)
     gathered = wire.alloc(dev, ranks=world) if world > 1 else payload.view(1, -1)
     u = torch.empty(M, dtype=torch.float32, device=dev)
-    partials = native.new_partials(dev)
+    partials = native.new_workspace(dev, M)
     out = torch.empty(SIZE, dtype=torch.float32, device=dev)
 
     def compress():

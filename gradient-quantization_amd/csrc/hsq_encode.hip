@@ -15,65 +15,9 @@
 //   generic  same MFMA formulation for any (d, K); fragments come from L1/L2.
 //   valu     one subvector per lane, codebook broadcast from LDS, __fmaf_rn chain,
 //            wave-level min/max by shuffles; kept as the cross-check of the MFMA path.
-#include "gq_common.hpp"
+#include "hsq_encode_common.hpp"
 
 namespace gq {
-
-constexpr int ENC_THREADS = 256;
-constexpr int ENC_WAVES = ENC_THREADS / 64;
-
-__device__ __forceinline__ void swap32(float &x, float &y) {
-    // v_permlane32_swap: lanes 32..63 of x <-> lanes 0..31 of y.
-    // After it: x = (x.lo, y.lo), y = (x.hi, y.hi).
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    x = __uint_as_float(r[0]);
-    y = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void swap32(int &x, int &y) {
-    auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)y, false, false);
-    x = (int)r[0];
-    y = (int)r[1];
-}
-
-// Strict '>' keeps the FIRST maximum when candidates are visited in ascending index.
-__device__ __forceinline__ void take_if_greater(float &bv, int &bi, float v, int idx) {
-    const bool gt = fabsf(v) > fabsf(bv);
-    bv = gt ? v : bv;
-    bi = gt ? idx : bi;
-}
-
-// Row of the 32x32 MFMA result held in accumulator register r of a lane in half h
-// is  (r&3) + 8*(r>>2) + 4*h ; this is the h-independent part.
-__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
-
-// Per-block (min,max) of u -> partials[2*blockIdx.x], and block 0 pads the unused slots.
-__device__ __forceinline__ void write_minmax_partials(float lmin, float lmax, float *__restrict__ partials) {
-    __shared__ float s_min[ENC_WAVES], s_max[ENC_WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    lmin = wave_min(lmin);
-    lmax = wave_max(lmax);
-    if (lane == 0) {
-        s_min[wave] = lmin;
-        s_max[wave] = lmax;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float a = s_min[0], b = s_max[0];
-#pragma unroll
-        for (int w = 1; w < ENC_WAVES; ++w) {
-            a = fminf(a, s_min[w]);
-            b = fmaxf(b, s_max[w]);
-        }
-        partials[2 * blockIdx.x] = a;
-        partials[2 * blockIdx.x + 1] = b;
-    }
-    if (blockIdx.x == 0) {
-        for (int i = gridDim.x + threadIdx.x; i < GQ_MAX_PARTIALS; i += blockDim.x) {
-            partials[2 * i] = INFINITY;
-            partials[2 * i + 1] = -INFINITY;
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------
 // d = 16, K = 256: the BASELINE configuration.
@@ -325,15 +269,6 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_valu_kernel(const floa
     write_minmax_partials(lmin, lmax, partials);
 }
 
-// Resident workgroups per CU of a kernel (occupancy API, cached): the persistent grids are
-// sized to exactly one resident wave of workgroups so that no workgroup queues behind another.
-template <typename KernelT>
-static int resident_blocks_per_cu(KernelT kernel, int threads, size_t lds) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) n = 1;
-    return n;
-}
-
 template <typename CodeT>
 static int launch_encode(const float *grad, const float *codebook, int64_t M, int d, int K, CodeT *codes, float *u,
                          float *partials, int impl, hipStream_t st) {
@@ -344,13 +279,19 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
     auto grid_for = [&](int bpc) {
         int64_t blocks = (ntiles + ENC_WAVES - 1) / ENC_WAVES;
         int64_t cap = (int64_t)cus * bpc;
-        if (cap > GQ_MAX_PARTIALS) cap = GQ_MAX_PARTIALS;
+        if (cap > GQ_MAIN_PARTIALS) cap = GQ_MAIN_PARTIALS;
         if (blocks > cap) blocks = cap;
         return blocks < 1 ? (int64_t)1 : blocks;
     };
-    const int64_t cap = (int64_t)cus * 4 > GQ_MAX_PARTIALS ? GQ_MAX_PARTIALS : (int64_t)cus * 4;
+    const int64_t cap = (int64_t)cus * 4 > GQ_MAIN_PARTIALS ? GQ_MAIN_PARTIALS : (int64_t)cus * 4;
 
-    if (impl == 0) impl = (d == 16 && K == 256) ? 1 : 2;
+    if (impl == 0) impl = (d == 16 && K == 256) ? 4 : 2;
+    if (impl == 4) {
+        if (d != 16 || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 4 needs d=16, K=256");
+        if ((reinterpret_cast<uintptr_t>(grad) & 15) != 0)
+            return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: grad must be 16-byte aligned");
+        return launch_encode_pf<CodeT>(grad, codebook, M, codes, u, partials, st);
+    }
     if (impl == 1) {
         if (d != 16 || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 1 needs d=16, K=256");
         if ((reinterpret_cast<uintptr_t>(grad) & 15) != 0)
@@ -389,6 +330,11 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
 }
 
 }  // namespace gq
+
+GQ_API size_t gq_hsq_workspace_bytes(int64_t M) {
+    if (M < 0) M = 0;
+    return (size_t)(2 * GQ_MAX_PARTIALS) * sizeof(float) + 16 + (size_t)M * sizeof(int32_t);
+}
 
 GQ_API int gq_hsq_encode_impl(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes,
                               int code_bytes, float *u, float *minmax_partials, int impl, void *stream) {

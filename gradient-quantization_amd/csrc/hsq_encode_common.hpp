@@ -1,0 +1,84 @@
+// Device helpers shared by the HSQ encode kernels (hsq_encode.hip, hsq_encode_pf.hip).
+#pragma once
+#include "gq_common.hpp"
+
+namespace gq {
+
+constexpr int ENC_THREADS = 256;
+constexpr int ENC_WAVES = ENC_THREADS / 64;
+
+__device__ __forceinline__ void swap32(float &x, float &y) {
+    // v_permlane32_swap: lanes 32..63 of x <-> lanes 0..31 of y.
+    // After it: x = (x.lo, y.lo), y = (x.hi, y.hi).
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]);
+    y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap32(int &x, int &y) {
+    auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)y, false, false);
+    x = (int)r[0];
+    y = (int)r[1];
+}
+
+// Strict '>' keeps the FIRST maximum when candidates are visited in ascending index.
+__device__ __forceinline__ void take_if_greater(float &bv, int &bi, float v, int idx) {
+    const bool gt = fabsf(v) > fabsf(bv);
+    bv = gt ? v : bv;
+    bi = gt ? idx : bi;
+}
+
+// Row of the 32x32 MFMA result held in accumulator register r of a lane in half h
+// is  (r&3) + 8*(r>>2) + 4*h ; this is the h-independent part.
+__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// Per-block (min,max) of u -> partials[2*blockIdx.x], and block 0 pads the unused slots.
+__device__ __forceinline__ void write_minmax_partials(float lmin, float lmax, float *__restrict__ partials) {
+    __shared__ float s_min[ENC_WAVES], s_max[ENC_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    lmin = wave_min(lmin);
+    lmax = wave_max(lmax);
+    if (lane == 0) {
+        s_min[wave] = lmin;
+        s_max[wave] = lmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = s_min[0], b = s_max[0];
+#pragma unroll
+        for (int w = 1; w < ENC_WAVES; ++w) {
+            a = fminf(a, s_min[w]);
+            b = fmaxf(b, s_max[w]);
+        }
+        partials[2 * blockIdx.x] = a;
+        partials[2 * blockIdx.x + 1] = b;
+    }
+    if (blockIdx.x == 0) {
+        for (int i = gridDim.x + threadIdx.x; i < GQ_MAX_PARTIALS; i += blockDim.x) {
+            partials[2 * i] = INFINITY;
+            partials[2 * i + 1] = -INFINITY;
+        }
+    }
+}
+
+
+// Workspace layout (gq_hsq_workspace_bytes): [ (min,max) x GQ_MAX_PARTIALS | counter (16 B) | worklist int32[M] ]
+// The last GQ_FIXUP_PARTIALS (min,max) slots belong to the fix-up kernel of the prefilter path.
+constexpr int GQ_MAIN_PARTIALS = GQ_MAX_PARTIALS - GQ_FIXUP_PARTIALS;
+__host__ __device__ inline int *ws_counter(float *ws) { return reinterpret_cast<int *>(ws + 2 * GQ_MAX_PARTIALS); }
+__host__ __device__ inline int *ws_worklist(float *ws) { return reinterpret_cast<int *>(ws + 2 * GQ_MAX_PARTIALS) + 4; }
+
+// Resident workgroups per CU of a kernel (occupancy API): the persistent grids are sized to
+// exactly one resident wave of workgroups so that no workgroup queues behind another.
+template <typename KernelT>
+static int resident_blocks_per_cu(KernelT kernel, int threads, size_t lds) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) n = 1;
+    return n;
+}
+
+// hsq_encode_pf.hip: bf16x3 MFMA prefilter + exact f32 rescoring + fix-up kernel (d=16, K=256).
+template <typename CodeT>
+int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *workspace,
+                     hipStream_t st);
+
+}  // namespace gq

@@ -1,0 +1,350 @@
+// HSQ encode, d = 16, K = 256: bf16x3 matrix-core prefilter + exact f32 rescoring.
+//
+// The exact f32 MFMA kernel (hsq_encode.hip) is bound by the f32 matrix rate, and on gfx950
+// the f32 MFMA shares its datapath with the VALU (measured, tools/enc_probe.hip: their times
+// ADD), so the 256-way argmax cannot hide behind it.  This kernel gets the same bits out
+// with ~4x less time:
+//
+//  1. APPROXIMATE scores on the bf16 matrix pipe (which does overlap with the VALU):
+//       c = ch + cl + O(2^-18 c),  v = vh + vl + O(2^-18 v)      (bf16 hi/lo splits)
+//       s~_k = ch.vh + ch.vl + cl.vh     (3 x v_mfma_f32_32x32x16_bf16, f32 accumulate)
+//     |s~_k - p_k| <= E := 2^-15 * max_k||c_k||_1 * max_j |v_j|   for the reference's p_k (fmaf chain):
+//     dropped terms 3*2^-18, chain/accumulate roundings ~2^-20, all relative to
+//     sum_j |c_kj||v_j| <= ||c_k||_1 max|v_j| <= 4 (1+eps) max|v_j|  (rows are unit L2 norm).
+//  2. Per lane (= half of a subvector's 256 candidates) the VALU keeps the TOP-2 of the keys
+//       key = (bits(s~) & 0x7FFFFFC0) | candidate_id        (|.| for free: the mask drops the sign)
+//     with v_and_or / v_med3_u32 / v_max_u32 / v_max3_u32: 2.5 ops per score.
+//  3. EXACT rescoring: the best candidate of each half (2 per subvector) is recomputed with the
+//     reference's arithmetic, acc = fmaf(c[j], v[j], acc) for j ascending, codebook row from LDS.
+//     The larger |p| (lower index on a tie) is the answer IF every other candidate is provably
+//     smaller:  upper(second-best key of either half) + E < |u|.  Then no candidate that was not
+//     rescored can reach |u| even after the approximation error, so code and u are exactly the
+//     reference's first-max argmax and projection.
+//  4. Otherwise (top-2 gap below ~2e-4 relative, ~1e-3 of random subvectors; tiny / huge / non-finite
+//     inputs) the subvector goes to a worklist and a small fix-up kernel recomputes it exactly
+//     against all 256 codewords (one wave per subvector).  Correctness never depends on E being
+//     tight -- only on it being an upper bound.
+#include "hsq_encode_common.hpp"
+
+namespace gq {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr unsigned KEY_MASK = 0x7FFFFFC0u;  // drop sign + 6 low mantissa bits (2^-17 relative)
+constexpr float ERR_SCALE = 1.0025f * 3.0517578125e-05f;  // 2^-15 (x ||c||_1 x max|v_j|), analytic bound ~0.44 of it
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// two f32 -> packed bf16 pair (round to nearest even), one VALU op on gfx950
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// x = hi + lo + O(2^-18 x): hi = bf16(x), lo = bf16(x - hi)   (x - hi is exact in f32)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, unsigned &lo) {
+    hi = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(hi << 16);
+    const float r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
+    lo = cvt_pk_bf16(r0, r1);
+}
+// 8 consecutive floats -> the hi and lo bf16x8 MFMA fragments
+__device__ __forceinline__ void split8(const f32x4 &q0, const f32x4 &q1, bf16x8 &hi, bf16x8 &lo) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split_pair(q0[0], q0[1], h0, l0);
+    split_pair(q0[2], q0[3], h1, l1);
+    split_pair(q1[0], q1[1], h2, l2);
+    split_pair(q1[2], q1[3], h3, l3);
+    const u32x4 H = {h0, h1, h2, h3}, L = {l0, l1, l2, l3};
+    hi = __builtin_bit_cast(bf16x8, H);
+    lo = __builtin_bit_cast(bf16x8, L);
+}
+
+__device__ __forceinline__ unsigned and_or(unsigned x, unsigned mask, unsigned c) { return (x & mask) | c; }
+// one VALU op each (hipcc does not reliably form these from min/max compositions)
+__device__ __forceinline__ unsigned max3u(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned med3u(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// Exact reference arithmetic: p = fmaf chain over j ascending, from +0.
+__device__ __forceinline__ float exact_score(const float *__restrict__ row, const float (&v)[16]) {
+    const f32x4 c0 = *reinterpret_cast<const f32x4 *>(row);
+    const f32x4 c1 = *reinterpret_cast<const f32x4 *>(row + 4);
+    const f32x4 c2 = *reinterpret_cast<const f32x4 *>(row + 8);
+    const f32x4 c3 = *reinterpret_cast<const f32x4 *>(row + 12);
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __fmaf_rn(c0[j], v[j], acc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __fmaf_rn(c1[j], v[4 + j], acc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __fmaf_rn(c2[j], v[8 + j], acc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __fmaf_rn(c3[j], v[12 + j], acc);
+    return acc;
+}
+
+template <typename CodeT>
+__global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const float *__restrict__ grad,
+                                                                      const float *__restrict__ cb, int64_t M,
+                                                                      CodeT *__restrict__ codes,
+                                                                      float *__restrict__ u,
+                                                                      float *__restrict__ ws) {
+    __shared__ __attribute__((aligned(16))) float s_cb[256 * 16];  // f32 codebook for the exact rescoring
+    for (int i = threadIdx.x; i < 256 * 16 / 4; i += ENC_THREADS)
+        reinterpret_cast<f32x4 *>(s_cb)[i] = reinterpret_cast<const f32x4 *>(cb)[i];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+
+    // A fragments of v_mfma_f32_32x32x16_bf16: lane (row j, half h) holds c[rb*32+j][8h .. 8h+7]
+    bf16x8 ch[8], cl[8];
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) {
+        const f32x4 q0 = *reinterpret_cast<const f32x4 *>(cb + (rb * 32 + j) * 16 + 8 * h);
+        const f32x4 q1 = *reinterpret_cast<const f32x4 *>(cb + (rb * 32 + j) * 16 + 8 * h + 4);
+        split8(q0, q1, ch[rb], cl[rb]);
+    }
+    __syncthreads();
+    // The error bound scales with max_k ||c_k||_1 (<= 4 for unit-L2 rows); measure it instead of
+    // trusting the caller's codebook to be normalised.
+    __shared__ float s_c1[ENC_WAVES];
+    {
+        float l1 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) l1 += fabsf(s_cb[threadIdx.x * 16 + e]);
+        l1 = wave_max(l1);
+        if ((threadIdx.x & 63) == 0) s_c1[threadIdx.x >> 6] = l1;
+    }
+    __syncthreads();
+    float c1 = s_c1[0];
+#pragma unroll
+    for (int w = 1; w < ENC_WAVES; ++w) c1 = fmaxf(c1, s_c1[w]);
+    const float err_scale = c1 * ERR_SCALE;  // E = max|v_j| * err_scale
+
+    const int64_t ntiles = (M + 63) >> 6;
+    const int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
+    int64_t t = (int64_t)blockIdx.x * ENC_WAVES + wave;
+    int *const counter = ws_counter(ws);
+    int *const worklist = ws_worklist(ws);
+
+    float lmin = INFINITY, lmax = -INFINITY;
+    f32x4 cur[4], nxt[4];
+
+    auto load_tile = [&](int64_t tile, f32x4(&dst)[4]) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            int64_t sv = tile * 64 + blk * 32 + j;
+            sv = sv < M ? sv : M - 1;  // tail: re-read the last subvector, result is masked
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(grad + sv * 16 + 8 * h);
+            dst[2 * blk] = p[0];
+            dst[2 * blk + 1] = p[1];
+        }
+    };
+
+    if (t < ntiles) load_tile(t, cur);
+    for (; t < ntiles; t += nw) {
+        const int64_t tn = t + nw;
+        if (tn < ntiles) load_tile(tn, nxt);  // prefetch the next tile
+
+        // B fragments: lane (col j, half h) holds v[8h .. 8h+7] of subvector j of each block
+        bf16x8 vh[2], vl[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) split8(cur[2 * blk], cur[2 * blk + 1], vh[blk], vl[blk]);
+
+        // ---- prefilter: 16 (block, row block) chains, top-2 keys per (block, row-block half) ----
+        unsigned best[4] = {0, 0, 0, 0}, second[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int blk = c >> 3, rb = c & 7, trk = c >> 2;
+            f32x16 acc = {0};
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[rb], vh[blk], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[rb], vl[blk], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[rb], vh[blk], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const unsigned k0 = and_or(__float_as_uint(acc[r]), KEY_MASK, (unsigned)((rb & 3) * 16 + r));
+                const unsigned k1 = and_or(__float_as_uint(acc[r + 1]), KEY_MASK, (unsigned)((rb & 3) * 16 + r + 1));
+                second[trk] = max(second[trk], med3u(best[trk], k0, k1));
+                best[trk] = max3u(best[trk], k0, k1);
+            }
+        }
+
+        // ---- per block: merge the two trackers; candidate row and the bound on everything else ----
+        int k1[2];
+        unsigned s2[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const unsigned bA = best[2 * blk], bB = best[2 * blk + 1];
+            const bool useB = (bB & KEY_MASK) > (bA & KEY_MASK);
+            const unsigned bw = useB ? bB : bA, bl = useB ? bA : bB;
+            const int li = (int)(bw & 63u);
+            const int r = li & 15;
+            k1[blk] = ((li >> 4) + (useB ? 4 : 0)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            s2[blk] = max3u(second[2 * blk], second[2 * blk + 1], bl) | 63u;  // upper end of its bucket
+        }
+
+        // ---- this lane's own full subvector (tile subvector `lane`): 8 swaps of the B loads ----
+        float vf[16];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = cur[e >> 2][e & 3];        // block 0: floats 8h+e of subvector j
+            float y = cur[2 + (e >> 2)][e & 3];  // block 1
+            swap32(x, y);                        // x = floats e (0..7), y = floats 8+e of subvector `lane`
+            vf[e] = x;
+            vf[8 + e] = y;
+        }
+        // cross-half exchange of the candidates: [0] = lower-half rows, [1] = upper-half rows
+        swap32(k1[0], k1[1]);
+        {
+            int a0 = (int)s2[0], a1 = (int)s2[1];
+            swap32(a0, a1);
+            s2[0] = (unsigned)a0;
+            s2[1] = (unsigned)a1;
+        }
+
+        // ---- exact rescoring of the two candidates (the reference's fmaf chain) ----
+        const float pa = exact_score(s_cb + k1[0] * 16, vf);
+        const float pb = exact_score(s_cb + k1[1] * 16, vf);
+        const float aa = fabsf(pa), ab = fabsf(pb);
+        const bool takeb = (ab > aa) || (ab == aa && k1[1] < k1[0]);
+        float val = takeb ? pb : pa;
+        int idx = takeb ? k1[1] : k1[0];
+
+        float vmax = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) vmax = fmaxf(fmaxf(fabsf(vf[e]), fabsf(vf[e + 1])), vmax);
+        const float E = vmax * err_scale;
+        const float others = __uint_as_float(max(s2[0], s2[1]));  // >= every s~ that was not rescored
+        bool safe = (others + E < fabsf(val)) && (vmax >= 8.27e-25f) && (vmax <= 1.0e30f);
+        if (vmax == 0.0f) {  // all-zero subvector: every score is +0 -> first index, u = +0
+            safe = true;
+            val = 0.0f;
+            idx = 0;
+        }
+        // NaN anywhere makes vmax/others comparisons false -> not safe -> exact fix-up path
+
+        const int64_t sv = t * 64 + lane;
+        if (sv < M) {
+            if (safe) {
+                codes[sv] = (CodeT)idx;
+                u[sv] = val;
+                lmin = fminf(lmin, val);
+                lmax = fmaxf(lmax, val);
+            } else {
+                const int pos = atomicAdd(counter, 1);
+                worklist[pos] = (int)sv;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+    }
+    write_minmax_partials(lmin, lmax, ws);
+}
+
+// ---------------------------------------------------------------------------------------
+// Fix-up: exact recomputation of the worklist.  One wave per subvector; lane k owns codewords
+// k, k+64, k+128, k+192 (rows kept in registers), exact fmaf chains, then a wave-wide
+// first-max reduction on (|p|, index).  Writes codes/u and the last GQ_FIXUP_PARTIALS
+// (min,max) slots.
+// ---------------------------------------------------------------------------------------
+template <typename CodeT>
+__global__ __launch_bounds__(256) void hsq_encode_fixup_kernel(const float *__restrict__ grad,
+                                                              const float *__restrict__ cb,
+                                                              CodeT *__restrict__ codes, float *__restrict__ u,
+                                                              float *__restrict__ ws) {
+    __shared__ float s_min[4], s_max[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int count = *ws_counter(ws);
+    const int *worklist = ws_worklist(ws);
+    float lmin = INFINITY, lmax = -INFINITY;
+    const int nw = gridDim.x * 4;
+    if (count > 0) {
+        float c[4][16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) c[q][e] = cb[(q * 64 + lane) * 16 + e];
+        for (int w = blockIdx.x * 4 + wave; w < count; w += nw) {
+            const int64_t sv = worklist[w];
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = grad[sv * 16 + e];
+            float bv = 0.0f;
+            int bi = lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc = __fmaf_rn(c[q][e], v[e], acc);
+                if (q == 0) {
+                    bv = acc;
+                } else {
+                    take_if_greater(bv, bi, acc, q * 64 + lane);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                const float a0 = fabsf(bv), a1 = fabsf(ov);
+                const bool take = (a1 > a0) || (a1 == a0 && oi < bi);
+                bv = take ? ov : bv;
+                bi = take ? oi : bi;
+            }
+            if (lane == 0) {
+                codes[sv] = (CodeT)bi;
+                u[sv] = bv;
+            }
+            lmin = fminf(lmin, bv);
+            lmax = fmaxf(lmax, bv);
+        }
+    }
+    if (lane == 0) {
+        s_min[wave] = lmin;
+        s_max[wave] = lmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = s_min[0], b = s_max[0];
+        for (int w = 1; w < 4; ++w) {
+            a = fminf(a, s_min[w]);
+            b = fmaxf(b, s_max[w]);
+        }
+        ws[2 * (GQ_MAIN_PARTIALS + blockIdx.x)] = a;
+        ws[2 * (GQ_MAIN_PARTIALS + blockIdx.x) + 1] = b;
+    }
+}
+
+template <typename CodeT>
+int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *ws,
+                     hipStream_t st) {
+    if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<CodeT>, ENC_THREADS, 0);
+    const int64_t ntiles = (M + 63) / 64;
+    int64_t blocks = (ntiles + ENC_WAVES - 1) / ENC_WAVES;
+    int64_t cap = (int64_t)cu_count() * bpc;
+    if (cap > GQ_MAIN_PARTIALS) cap = GQ_MAIN_PARTIALS;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipError_t e = hipMemsetAsync(ws_counter(ws), 0, 16, st);
+    if (e != hipSuccess) return fail(GQ_ERR_HIP, "gq_hsq_encode: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, st,
+                       grad, codebook, M, codes, u, ws);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_fixup_kernel<CodeT>), dim3(GQ_FIXUP_PARTIALS), dim3(256), 0, st,
+                       grad, codebook, codes, u, ws);
+    GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter)");
+    return GQ_OK;
+}
+
+template int launch_encode_pf<uint8_t>(const float *, const float *, int64_t, uint8_t *, float *, float *, hipStream_t);
+template int launch_encode_pf<int32_t>(const float *, const float *, int64_t, int32_t *, float *, float *, hipStream_t);
+
+}  // namespace gq

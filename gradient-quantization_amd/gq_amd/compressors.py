@@ -93,7 +93,7 @@ class ProbabilisticScalarCompressor(object):
     def compress(self, vec):
         _require_device(vec, "ProbabilisticScalarCompressor.compress")
         flat = vec.contiguous().view(-1)
-        partials = native.new_partials(flat.device)
+        partials = native.new_workspace(flat.device, 0)
         native.minmax_partials(flat, partials)
         lb_ub = torch.empty(2, dtype=torch.float32, device=flat.device)
         levels = torch.empty(flat.numel(), dtype=self.code_dtype, device=flat.device)
@@ -160,7 +160,7 @@ class NearestNeighborCompressor(object):
         M = self.M
         codes = torch.empty(M, dtype=self.code_dtype, device=dev)
         u = torch.empty(M, dtype=torch.float32, device=dev)
-        partials = native.new_partials(dev)
+        partials = native.new_workspace(dev, M)
         native.hsq_encode(flat, cb, codes, u, partials)
         if not self.compressed_norm:
             return [u, codes]
@@ -205,7 +205,7 @@ class NearestNeighborCompressor(object):
         if u is None:
             u = torch.empty(self.M, dtype=torch.float32, device=dev)
         if partials is None:
-            partials = native.new_partials(dev)
+            partials = native.new_workspace(dev, self.M)
         native.hsq_encode(flat, cb, codes, u, partials)
         self.norm_compressor._levels_from_partials(u, partials, levels, lb_ub)
 

@@ -14,11 +14,12 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_DIR, "libgq_hsq.so")
 
 GQ_MAX_PARTIALS = 1024
+GQ_FIXUP_PARTIALS = 64
 RANDOM_OFF, RANDOM_GIVEN, RANDOM_DEVICE = 0, 1, 2
-ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU = 0, 1, 2, 3
+ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFILTER_D16K256 = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_encode", "gq_hsq_encode_impl", "gq_hsq_levels",
+    "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_workspace_bytes", "gq_hsq_encode", "gq_hsq_encode_impl", "gq_hsq_levels",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
 
@@ -40,6 +41,7 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.gq_last_error.restype = ctypes.c_char_p
         L.gq_abi_version.restype = ctypes.c_int
+        L.gq_hsq_workspace_bytes.restype = ctypes.c_size_t
         for name in EXPORTS:
             getattr(L, name)  # AttributeError if the library is stale
         _lib = L
@@ -72,8 +74,19 @@ _CODE_BYTES = {torch.uint8: 1, torch.int32: 4}
 _LEVEL_BYTES = {torch.uint8: 1, torch.int16: 2, torch.int32: 4, torch.float32: 0}
 
 
-def new_partials(device):
-    return torch.empty(2 * GQ_MAX_PARTIALS, dtype=torch.float32, device=device)
+def workspace_floats(M):
+    nbytes = int(lib().gq_hsq_workspace_bytes(ctypes.c_int64(int(M))))
+    return (nbytes + 3) // 4
+
+
+def new_workspace(device, M=0):
+    """Encode workspace for M subvectors: (min,max) partials | counter | worklist (f32-typed storage)."""
+    return torch.empty(workspace_floats(M), dtype=torch.float32, device=device)
+
+
+def fixup_count(workspace):
+    """Number of subvectors the last prefilter encode sent to the exact fix-up kernel (syncs)."""
+    return int(workspace[2 * GQ_MAX_PARTIALS:2 * GQ_MAX_PARTIALS + 1].view(torch.int32).item())
 
 
 def device_info(device=0):
@@ -84,11 +97,11 @@ def device_info(device=0):
 
 
 def hsq_encode(grad, codebook, codes, u, partials, impl=ENCODE_AUTO):
-    """grad f32 [M*d] -> codes (uint8|int32 [M]), u f32 [M], partials f32 [2*GQ_MAX_PARTIALS]."""
+    """grad f32 [M*d] -> codes (uint8|int32 [M]), u f32 [M]; `partials` = new_workspace(device, M)."""
     K, d = codebook.shape
     M = grad.numel() // d
     assert grad.numel() == M * d and codes.numel() == M and u.numel() == M
-    assert partials.numel() >= 2 * GQ_MAX_PARTIALS
+    assert partials.numel() >= workspace_floats(M), "encode workspace too small: use native.new_workspace(device, M)"
     rc = lib().gq_hsq_encode_impl(_dev_ptr(grad, torch.float32, "grad"), _dev_ptr(codebook, torch.float32, "codebook"),
                                   ctypes.c_int64(M), ctypes.c_int(d), ctypes.c_int(K), _dev_ptr(codes, None, "codes"),
                                   ctypes.c_int(_CODE_BYTES[codes.dtype]), _dev_ptr(u, torch.float32, "u"),

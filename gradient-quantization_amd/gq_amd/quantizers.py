@@ -107,7 +107,7 @@ class HSQCodec(object):
     def _scratch(self, dev):
         if self._u is None or self._u.device != dev:
             self._u = torch.empty(self.M, dtype=torch.float32, device=dev)
-            self._partials = native.new_partials(dev)
+            self._partials = native.new_workspace(dev, self.M)
         return self._u, self._partials
 
     def _levels(self, u, partials, levels, lb_ub, salt):

@@ -34,9 +34,15 @@ extern "C" {
 #define GQ_ERR_UNSUPPORTED (-2)
 #define GQ_ERR_HIP (-3)
 
-/* Number of (min,max) float pairs gq_hsq_encode writes into `minmax_partials`
- * (the buffer must hold 2 * GQ_MAX_PARTIALS floats). */
+/* Encode workspace (caller-allocated device memory, gq_hsq_workspace_bytes(M) bytes, 16-byte
+ * aligned, no initialisation needed):
+ *   [ (min,max) f32 pairs x GQ_MAX_PARTIALS | counter (16 B) | worklist int32[M] ]
+ * gq_hsq_encode leaves the per-workgroup (min,max) of u in the pairs (unused slots hold
+ * (+inf,-inf); the last GQ_FIXUP_PARTIALS slots belong to the exact fix-up kernel of the
+ * prefilter path, which also owns the counter and the worklist); gq_hsq_levels reads the pairs. */
 #define GQ_MAX_PARTIALS 1024
+#define GQ_FIXUP_PARTIALS 64
+size_t gq_hsq_workspace_bytes(int64_t M);
 
 /* random_mode of gq_hsq_levels / gq_qsgd_compress */
 #define GQ_RANDOM_OFF 0    /* args.random == 0: deterministic truncation                      */
@@ -59,26 +65,28 @@ int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
  *     code  = first k maximising |p_k|
  *     u     = p_code              (signed)
  * Outputs: codes[M] (code_bytes = 1 -> uint8, 4 -> int32; 1 requires K <= 256),
- * u[M] f32, and per-workgroup (min,max) of u in minmax_partials[2*GQ_MAX_PARTIALS]
- * (unused slots are filled with (+inf,-inf)).
- * Requirements: 1 <= d <= 512, 1 <= K <= 65536, grad 16-byte aligned when d == 16.
+ * u[M] f32, and per-workgroup (min,max) of u at the head of `workspace` (see above).
+ * Requirements: 1 <= d <= 512, 1 <= K <= 65536, M < 2^31, grad 16-byte aligned when d == 16.
  */
 int gq_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes, int code_bytes,
-                  float *u, float *minmax_partials, void *stream);
+                  float *u, float *workspace, void *stream);
 
 /* Same, with the kernel chosen explicitly (diagnostics / cross-checks; results are
- * identical for every impl):  0 = auto, 1 = MFMA d16/K256 register-resident codebook,
- * 2 = MFMA generic (any d, K), 3 = VALU fmaf chain with the codebook in LDS. */
+ * identical for every impl):  0 = auto, 1 = exact f32 MFMA, d16/K256, register-resident
+ * codebook, 2 = exact f32 MFMA generic (any d, K), 3 = VALU fmaf chain with the codebook in
+ * LDS, 4 = d16/K256 bf16x3 MFMA prefilter + exact f32 rescoring + exact fix-up (the default
+ * for d16/K256; bit-identical output). */
 #define GQ_ENCODE_AUTO 0
 #define GQ_ENCODE_MFMA_D16K256 1
 #define GQ_ENCODE_MFMA_GENERIC 2
 #define GQ_ENCODE_VALU 3
+#define GQ_ENCODE_PREFILTER_D16K256 4
 int gq_hsq_encode_impl(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes,
-                       int code_bytes, float *u, float *minmax_partials, int impl, void *stream);
+                       int code_bytes, float *u, float *workspace, int impl, void *stream);
 
 /*
  * Scalar level quantiser -- replaces probabilistic_scalar_compressor.py:12-27.
- *     lb = min(u), ub = max(u)    (finished here from minmax_partials)
+ *     lb = min(u), ub = max(u)    (finished here from the (min,max) pairs at the head of `workspace`)
  *     levels = 0                                   if lb - ub == 0
  *     x = |(u-lb)/(ub-lb)| * 2^n_bit ;  l = trunc(clamp(x, 0, 2^n_bit - 1))
  *     l += (x - l > r)                             if random_mode != GQ_RANDOM_OFF
@@ -86,12 +94,13 @@ int gq_hsq_encode_impl(const float *grad, const float *codebook, int64_t M, int 
  * the value range is [0, 2^n_bit] with stochastic rounding, [0, 2^n_bit - 1] without).
  */
 int gq_hsq_levels(const float *u, int64_t M, int n_bit, int random_mode, const float *r, uint64_t seed,
-                  const float *minmax_partials, float *lb_ub, void *levels, int level_bytes, void *stream);
+                  const float *workspace, float *lb_ub, void *levels, int level_bytes, void *stream);
 
-/* Per-workgroup (min,max) of an arbitrary f32 vector in the minmax_partials format, for
- * running gq_hsq_levels on a vector that did not come out of gq_hsq_encode
- * (ProbabilisticScalarCompressor used on its own; torch.min/torch.max at prob_scalar:13-14). */
-int gq_minmax_partials(const float *v, int64_t n, float *minmax_partials, void *stream);
+/* Per-workgroup (min,max) of an arbitrary f32 vector into the head of a workspace
+ * (gq_hsq_workspace_bytes(0) bytes suffice), for running gq_hsq_levels on a vector that did not
+ * come out of gq_hsq_encode (ProbabilisticScalarCompressor used on its own; torch.min/torch.max
+ * at prob_scalar:13-14). */
+int gq_minmax_partials(const float *v, int64_t n, float *workspace, void *stream);
 
 /*
  * Decode + aggregate -- replaces probabilistic_scalar_compressor.py:29-33 and

@@ -43,9 +43,9 @@ def gpu_compress(nat, x, cb, n_bit, random, r=None, impl=0, code_dtype=None, lev
         code_dtype = torch.uint8 if K <= 256 else torch.int32
     codes = torch.empty(M, dtype=code_dtype, device=dev)
     u = torch.empty(M, dtype=torch.float32, device=dev)
-    partials = nat.new_partials(dev)
+    partials = nat.new_workspace(dev, M)
     nat.hsq_encode(g, c, codes, u, partials, impl=impl)
-    out = dict(codes=codes, u=u, cb=c, M=M)
+    out = dict(codes=codes, u=u, cb=c, M=M, ws=partials)
     if n_bit != 32:
         lb_ub = torch.empty(2, dtype=torch.float32, device=dev)
         levels = torch.empty(M, dtype=level_dtype, device=dev)
@@ -68,16 +68,18 @@ def gpu_decode(nat, res, n_bit):
     return out.cpu().numpy()
 
 
-IMPLS = {"auto": 0, "mfma_generic": 2, "valu": 3}
+IMPLS = {"auto": 0, "mfma_exact_d16k256": 1, "mfma_generic": 2, "valu": 3, "prefilter_d16k256": 4}
 
 
-@pytest.mark.parametrize("impl", ["auto", "mfma_generic", "valu"])
+@pytest.mark.parametrize("impl", ["auto", "mfma_exact_d16k256", "mfma_generic", "valu", "prefilter_d16k256"])
 @pytest.mark.parametrize("name", HSQ_CASES)
 def test_hsq_matches_reference_golden(nat, name, impl):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     d, K, n_bit, random = int(g["dim"]), int(g["K"]), int(g["n_bit"]), int(g["random"])
     if impl == "valu" and (d not in (8, 12, 16, 24, 32) or K * d * 4 > 65536):
         pytest.skip("valu cross-check kernel not built for this shape")
+    if impl in ("mfma_exact_d16k256", "prefilter_d16k256") and (d, K) != (16, 256):
+        pytest.skip("d16/K256 specialisation")
     cb = _cb(d, K)
     r = g["r"] if random else None
     res = gpu_compress(nat, g["x"], cb, n_bit, random, r, impl=IMPLS[impl])
@@ -199,7 +201,7 @@ def test_full_size_properties(nat, oracle):
     M = g.numel() // 16
     codes = torch.empty(M, dtype=torch.uint8, device=dev)
     u = torch.empty(M, dtype=torch.float32, device=dev)
-    partials = nat.new_partials(dev)
+    partials = nat.new_workspace(dev, M)
     lb_ub = torch.empty(2, dtype=torch.float32, device=dev)
     levels = torch.empty(M, dtype=torch.uint8, device=dev)
     nat.hsq_encode(g, cb, codes, u, partials)
@@ -231,3 +233,76 @@ def test_full_size_properties(nat, oracle):
     rc, ru = oracle.hsq_encode(win, cb_np)
     assert np.array_equal(codes[123457:123457 + 65536].cpu().numpy().astype(np.int32), rc)
     assert np.array_equal(_bits(u[123457:123457 + 65536].cpu().numpy()), _bits(ru))
+
+
+def test_prefilter_equals_exact_mfma_at_full_size_and_fixup_rate(nat):
+    """The bf16x3 prefilter path must reproduce the exact f32 MFMA kernel bit for bit on 25M
+    elements (randn and randn*1e-3), and only a small fraction may need the exact fix-up."""
+    dev = torch.device("cuda:0")
+    cb = torch.from_numpy(_cb(16, 256)).to(dev)
+    for seed, scale in [(1234, 1.0), (77, 1e-3)]:
+        torch.manual_seed(seed)
+        g = torch.randn(25_000_000, device=dev) * scale
+        M = g.numel() // 16
+        res = {}
+        for impl in (1, 4):
+            codes = torch.empty(M, dtype=torch.uint8, device=dev)
+            u = torch.empty(M, dtype=torch.float32, device=dev)
+            ws = nat.new_workspace(dev, M)
+            lb_ub = torch.empty(2, dtype=torch.float32, device=dev)
+            nat.hsq_encode(g, cb, codes, u, ws, impl=impl)
+            levels = torch.empty(M, dtype=torch.uint8, device=dev)
+            nat.hsq_levels(u, 6, 0, None, 0, ws, lb_ub, levels)
+            torch.cuda.synchronize()
+            res[impl] = (codes, u, lb_ub, levels, ws)
+        assert torch.equal(res[1][0], res[4][0]), "codes differ between exact and prefilter kernels"
+        assert torch.equal(res[1][1].view(torch.int32), res[4][1].view(torch.int32)), "u differs bitwise"
+        assert torch.equal(res[1][2].view(torch.int32), res[4][2].view(torch.int32))
+        assert torch.equal(res[1][3], res[4][3])
+        n_fix = nat.fixup_count(res[4][4])
+        assert 0 < n_fix < M * 0.01, n_fix
+        print("scale %g: fix-up worklist %d of %d subvectors (%.4f%%)" % (scale, n_fix, M, 100.0 * n_fix / M))
+
+
+@pytest.mark.parametrize("case", ["zeros", "constant", "ties", "huge", "tiny", "mixed_scales"])
+def test_prefilter_degenerate_inputs_match_exact(nat, oracle, case):
+    rng = np.random.RandomState(11)
+    cbn = _cb(16, 256)
+    M = 5000
+    if case == "zeros":
+        x = np.zeros(M * 16, np.float32)
+        x[16 * 7:16 * 8] = -0.0
+    elif case == "constant":
+        x = np.tile(rng.standard_normal(16).astype(np.float32), M)
+    elif case == "ties":
+        a = rng.randint(0, 256, M)
+        b = (a + 1 + rng.randint(0, 255, M)) % 256
+        x = (cbn[a] + rng.choice([-1.0, 1.0], M)[:, None].astype(np.float32) * cbn[b]).reshape(-1)
+    elif case == "huge":
+        x = (rng.standard_normal(M * 16) * 1e32).astype(np.float32)
+    elif case == "tiny":
+        x = (rng.standard_normal(M * 16) * 1e-30).astype(np.float32)
+        x[:16 * 100] *= 1e-12   # subnormal products
+    else:
+        x = (rng.standard_normal(M * 16) * np.exp(rng.standard_normal(M * 16) * 8)).astype(np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    ref_codes, ref_u = oracle.hsq_encode(x, cbn)
+    res = gpu_compress(nat, x, cbn, 32, 0, impl=4)
+    assert np.array_equal(res["codes"].cpu().numpy().astype(np.int32), ref_codes)
+    assert np.array_equal(_bits(res["u"].cpu().numpy()), _bits(ref_u))
+    n_fix = nat.fixup_count(res["ws"])
+    if case == "zeros":
+        assert n_fix == 0            # handled inline, never sent to the fix-up kernel
+    if case in ("huge", "tiny"):
+        assert n_fix > 0             # outside the proven range of the error bound -> exact path
+
+
+def test_prefilter_respects_unnormalised_codebooks(nat, oracle):
+    """The error bound scales with the measured max ||c_k||_1, not an assumed unit norm."""
+    rng = np.random.RandomState(12)
+    cbn = (_cb(16, 256) * rng.uniform(0.2, 30.0, (256, 1))).astype(np.float32)
+    x = rng.standard_normal(16 * 20000).astype(np.float32)
+    ref_codes, ref_u = oracle.hsq_encode(x, cbn)
+    res = gpu_compress(nat, x, cbn, 32, 0, impl=4)
+    assert np.array_equal(res["codes"].cpu().numpy().astype(np.int32), ref_codes)
+    assert np.array_equal(_bits(res["u"].cpu().numpy()), _bits(ref_u))

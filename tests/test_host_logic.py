@@ -81,7 +81,7 @@ def test_compute_fails_loudly_without_gpu():
         ProbabilisticScalarCompressor(6, a).compress(torch.randn(10))
     with pytest.raises(native.GQNativeError):
         native.hsq_encode(torch.zeros(16), torch.zeros(256, 16), torch.zeros(1, dtype=torch.uint8), torch.zeros(1),
-                          torch.zeros(2048))
+                          torch.zeros(4096))
 
 
 # ---- codebook / constructor logic ----------------------------------------------------

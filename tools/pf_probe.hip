@@ -1,0 +1,115 @@
+// Probe: bf16x3 MFMA chains + packed-key top-2 tracking (registers only): what does the
+// prefilter inner loop cost per 64-subvector tile?
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s\n", hipGetErrorString(e_)); return; } } while (0)
+
+__device__ __forceinline__ unsigned and_or(unsigned x, unsigned m, unsigned c) {
+    unsigned d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(m), "n"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned max3u(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned med3u(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// MODE 0: MFMA only; 1: MFMA + keys top-2 (2.5 ops/score); 2: MFMA + keys top-1 (1.5 ops/score); 3: VALU top-2 only
+template <int MODE, int NMFMA>
+__global__ __launch_bounds__(256, 2) void probe(const float *in, float *out, int iters) {
+    bf16x8 ch[8], cl[8], vh[2], vl[2];
+    for (int i = 0; i < 8; ++i)
+        for (int k = 0; k < 8; ++k) {
+            ch[i][k] = (short)(__float_as_uint(in[(threadIdx.x + 64 * i + 7 * k) & 1023]) >> 16);
+            cl[i][k] = (short)(__float_as_uint(in[(threadIdx.x + 64 * i + 11 * k) & 1023]) >> 16);
+        }
+    for (int i = 0; i < 2; ++i)
+        for (int k = 0; k < 8; ++k) {
+            vh[i][k] = (short)(__float_as_uint(in[(threadIdx.x * 3 + 64 * i + 5 * k) & 1023]) >> 16);
+            vl[i][k] = (short)(__float_as_uint(in[(threadIdx.x * 5 + 64 * i + 3 * k) & 1023]) >> 16);
+        }
+    unsigned best[4] = {0, 0, 0, 0}, second[4] = {0, 0, 0, 0};
+    const unsigned mask = 0x7FFFFFC0u;
+    f32x16 fake;
+    for (int r = 0; r < 16; ++r) fake[r] = in[(threadIdx.x + r) & 1023];
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            f32x16 acc = {0};
+            if (MODE == 3) {
+                acc = fake;
+                fake[c] += __uint_as_float(best[0] & 0x3f800000);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[c & 7], vh[c >> 3], acc, 0, 0, 0);
+                if (NMFMA >= 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[c & 7], vl[c >> 3], acc, 0, 0, 0);
+                if (NMFMA >= 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[c & 7], vh[c >> 3], acc, 0, 0, 0);
+            }
+            const int t = (c >> 2);  // tracker set: (block, rb<4 | rb>=4)
+            if (MODE == 0) {
+                asm volatile("" ::"v"(acc));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const unsigned k0 = and_or(__float_as_uint(acc[r]), mask, (unsigned)(((c & 3) * 16 + r) & 63));
+                    const unsigned k1 = and_or(__float_as_uint(acc[r + 1]), mask, (unsigned)(((c & 3) * 16 + r + 1) & 63));
+                    if (MODE == 1 || MODE == 3) {
+                        const unsigned m = med3u(best[t], k0, k1);
+                        second[t] = max(second[t], m);
+                    }
+                    best[t] = max3u(best[t], k0, k1);
+                }
+            }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] =
+        __uint_as_float(best[0] ^ best[1] ^ best[2] ^ best[3] ^ second[0] ^ second[1] ^ second[2] ^ second[3]);
+}
+
+template <int MODE, int NMFMA>
+void run(const char *name, int blocks) {
+    float *in, *out;
+    CK(hipMalloc(&in, 4096 * 4));
+    CK(hipMalloc(&out, (size_t)blocks * 256 * 4));
+    float h[1024];
+    for (int i = 0; i < 1024; ++i) h[i] = (float)((i * 2654435761u) >> 8) * 1e-7f - 0.8f;
+    CK(hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice));
+    const int iters = 2000;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    probe<MODE, NMFMA><<<blocks, 256>>>(in, out, 20);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    probe<MODE, NMFMA><<<blocks, 256>>>(in, out, iters);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    // tiles of 64 subvectors processed per second -> projected time for 25M elements (24414 tiles)
+    double tiles = (double)blocks * 4 * iters;
+    printf("%-34s blocks=%4d  %.3f ms  -> 25M-element encode projection %.1f us\n", name, blocks, ms,
+           ms * 1e3 * 24414.0 / tiles);
+    CK(hipFree(in));
+    CK(hipFree(out));
+}
+
+int main() {
+    for (int bpc = 1; bpc <= 3; ++bpc) {
+        int blocks = 256 * bpc;
+        run<0, 3>("3 bf16 MFMA only", blocks);
+        run<0, 1>("1 bf16 MFMA only", blocks);
+        run<1, 3>("3 MFMA + top-2 keys", blocks);
+        run<2, 3>("3 MFMA + top-1 keys", blocks);
+        run<1, 1>("1 MFMA + top-2 keys", blocks);
+        run<3, 3>("VALU top-2 keys only", blocks);
+    }
+    return 0;
+}
