@@ -26,6 +26,10 @@
 //     tight -- only on it being an upper bound.
 #include "hsq_encode_common.hpp"
 
+#ifndef GQ_PF_EXP
+#define GQ_PF_EXP 0  // timing experiments only (tools/exp_time.py); 0 = product
+#endif
+
 namespace gq {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -104,7 +108,10 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
 
-    // A fragments of v_mfma_f32_32x32x16_bf16: lane (row j, half h) holds c[rb*32+j][8h .. 8h+7]
+    // A fragments of v_mfma_f32_32x32x16_bf16: lane (row j, half h) holds c[rb*32+j][8h .. 8h+7];
+    // hi and lo bf16 parts, 64 VGPRs, resident for the kernel's lifetime.  (Keeping them in LDS
+    // instead and running 4 waves/SIMD measured slower: the kernel is bound by VALU issue, not
+    // by latency.)
     bf16x8 ch[8], cl[8];
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb) {
@@ -149,31 +156,60 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
         }
     };
 
-    if (t < ntiles) load_tile(t, cur);
+    // B fragments: lane (col j, half h) holds v[8h .. 8h+7] of subvector j of each block
+    bf16x8 vh[2], vl[2];
+    if (t < ntiles) {
+        load_tile(t, cur);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) split8(cur[2 * blk], cur[2 * blk + 1], vh[blk], vl[blk]);
+    }
     for (; t < ntiles; t += nw) {
         const int64_t tn = t + nw;
         if (tn < ntiles) load_tile(tn, nxt);  // prefetch the next tile
 
-        // B fragments: lane (col j, half h) holds v[8h .. 8h+7] of subvector j of each block
-        bf16x8 vh[2], vl[2];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) split8(cur[2 * blk], cur[2 * blk + 1], vh[blk], vl[blk]);
-
         // ---- prefilter: 16 (block, row block) chains, top-2 keys per (block, row-block half) ----
+        // One wave issues a VALU op every ~4 cycles and a 32x32x16 bf16 MFMA occupies the matrix
+        // pipe for 32; the three MFMAs of a chain depend on each other, and issue is in order, so
+        // they are placed one by one BETWEEN the key operations of the previous chain
+        // (sched_barrier pins the order): the matrix pipe then runs entirely under the VALU stream.
         unsigned best[4] = {0, 0, 0, 0}, second[4] = {0, 0, 0, 0};
+        unsigned vmask = KEY_MASK;
+        asm volatile("" : "+v"(vmask));  // keep the mask in a VGPR: v_and_or with an SGPR operand issues slower
+        auto keys = [&](const f32x16 &a, int rb, int trk, int r0, int r1) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int blk = c >> 3, rb = c & 7, trk = c >> 2;
-            f32x16 acc = {0};
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[rb], vh[blk], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[rb], vl[blk], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[rb], vh[blk], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const unsigned k0 = and_or(__float_as_uint(acc[r]), KEY_MASK, (unsigned)((rb & 3) * 16 + r));
-                const unsigned k1 = and_or(__float_as_uint(acc[r + 1]), KEY_MASK, (unsigned)((rb & 3) * 16 + r + 1));
+            for (int r = r0; r < r1; r += 2) {
+                const unsigned k0 = and_or(__float_as_uint(a[r]), vmask, (unsigned)((rb & 3) * 16 + r));
+                const unsigned k1 = and_or(__float_as_uint(a[r + 1]), vmask, (unsigned)((rb & 3) * 16 + r + 1));
                 second[trk] = max(second[trk], med3u(best[trk], k0, k1));
                 best[trk] = max3u(best[trk], k0, k1);
+            }
+        };
+        f32x16 acc = {0};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[0], vh[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[0], vl[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[0], vh[0], acc, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int rb = c & 7, trk = c >> 2;
+            if (c + 1 < 16) {
+                const int nb = (c + 1) >> 3, nr = (c + 1) & 7;
+                f32x16 nacc = {0};
+                __builtin_amdgcn_sched_barrier(0);
+                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[nr], vh[nb], nacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                keys(acc, rb, trk, 0, 4);
+                __builtin_amdgcn_sched_barrier(0);
+                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vl[nb], nacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                keys(acc, rb, trk, 4, 10);
+                __builtin_amdgcn_sched_barrier(0);
+                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vh[nb], nacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                keys(acc, rb, trk, 10, 16);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = nacc;
+            } else {
+                keys(acc, rb, trk, 0, 16);
             }
         }
 
@@ -211,8 +247,12 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
         }
 
         // ---- exact rescoring of the two candidates (the reference's fmaf chain) ----
+#if GQ_PF_EXP == 1 || GQ_PF_EXP == 5
+        const float pa = __uint_as_float(s2[0]) + vf[0] + vf[15], pb = __uint_as_float(s2[1]) + vf[3] + vf[9];
+#else
         const float pa = exact_score(s_cb + k1[0] * 16, vf);
         const float pb = exact_score(s_cb + k1[1] * 16, vf);
+#endif
         const float aa = fabsf(pa), ab = fabsf(pb);
         const bool takeb = (ab > aa) || (ab == aa && k1[1] < k1[0]);
         float val = takeb ? pb : pa;
@@ -230,21 +270,51 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
             idx = 0;
         }
         // NaN anywhere makes vmax/others comparisons false -> not safe -> exact fix-up path
+#if GQ_PF_EXP != 0 && GQ_PF_EXP != 6 && GQ_PF_EXP < 7
+        safe = true;
+#endif
 
         const int64_t sv = t * 64 + lane;
-        if (sv < M) {
+        const bool valid = sv < M;
+
+        // Consume the prefetched tile (convert it to the next B fragments) BEFORE this tile's
+        // stores are issued: the wait for the prefetch then sees only long-finished memory ops.
+        // Done the other way round, the compiler's vmcnt wait at the first use of `nxt` sits right
+        // behind the just-issued stores and every tile eats a store round trip.
+        bf16x8 nvh[2], nvl[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) split8(nxt[2 * blk], nxt[2 * blk + 1], nvh[blk], nvl[blk]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            vh[blk] = nvh[blk];
+            vl[blk] = nvl[blk];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+#if GQ_PF_EXP == 4
+        if (valid && idx == 12345 && val == 3.0f) {
+#else
+        if (valid) {
+#endif
+            // provisional values for flagged subvectors are overwritten by the fix-up kernel
+#if GQ_PF_EXP != 7
+            codes[sv] = (CodeT)idx;
+#endif
+#if GQ_PF_EXP != 8
+            u[sv] = val;
+#endif
             if (safe) {
-                codes[sv] = (CodeT)idx;
-                u[sv] = val;
                 lmin = fminf(lmin, val);
                 lmax = fmaxf(lmax, val);
             } else {
+#if GQ_PF_EXP < 6
                 const int pos = atomicAdd(counter, 1);
                 worklist[pos] = (int)sv;
+#endif
             }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
     }
     write_minmax_partials(lmin, lmax, ws);
 }

@@ -11,7 +11,7 @@ import os
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "libgq_hsq.so")
+LIB_PATH = os.environ.get("GQ_LIB_PATH") or os.path.join(_PKG_DIR, "libgq_hsq.so")
 
 GQ_MAX_PARTIALS = 1024
 GQ_FIXUP_PARTIALS = 64
