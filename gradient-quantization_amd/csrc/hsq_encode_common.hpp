@@ -31,6 +31,17 @@ __device__ __forceinline__ void take_if_greater(float &bv, int &bi, float v, int
 // is  (r&3) + 8*(r>>2) + 4*h ; this is the h-independent part.
 __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
 
+// Workspace layout (gq_hsq_workspace_bytes):
+//   [ (min,max) x GQ_MAX_PARTIALS | int32 x4: worklist count, finish ticket, `final` flag, - | worklist int32[M] ]
+// The last GQ_FIXUP_PARTIALS (min,max) slots belong to the finish kernel of the prefilter path.
+// The int32 block must be zero before the first use (the finish kernel re-zeroes what it uses).
+constexpr int GQ_MAIN_PARTIALS = GQ_MAX_PARTIALS - GQ_FIXUP_PARTIALS;
+__host__ __device__ inline int *ws_counter(float *ws) { return reinterpret_cast<int *>(ws + 2 * GQ_MAX_PARTIALS); }
+__host__ __device__ inline const int *ws_counter(const float *ws) {
+    return reinterpret_cast<const int *>(ws + 2 * GQ_MAX_PARTIALS);
+}
+__host__ __device__ inline int *ws_worklist(float *ws) { return reinterpret_cast<int *>(ws + 2 * GQ_MAX_PARTIALS) + 4; }
+
 // Per-block (min,max) of u -> partials[2*blockIdx.x], and block 0 pads the unused slots.
 __device__ __forceinline__ void write_minmax_partials(float lmin, float lmax, float *__restrict__ partials) {
     __shared__ float s_min[ENC_WAVES], s_max[ENC_WAVES];
@@ -51,6 +62,7 @@ __device__ __forceinline__ void write_minmax_partials(float lmin, float lmax, fl
         }
         partials[2 * blockIdx.x] = a;
         partials[2 * blockIdx.x + 1] = b;
+        if (blockIdx.x == 0) ws_counter(partials)[2] = 0;  // pairs are partials, not yet the final (lb, ub)
     }
     if (blockIdx.x == 0) {
         for (int i = gridDim.x + threadIdx.x; i < GQ_MAX_PARTIALS; i += blockDim.x) {
@@ -60,12 +72,6 @@ __device__ __forceinline__ void write_minmax_partials(float lmin, float lmax, fl
     }
 }
 
-
-// Workspace layout (gq_hsq_workspace_bytes): [ (min,max) x GQ_MAX_PARTIALS | counter (16 B) | worklist int32[M] ]
-// The last GQ_FIXUP_PARTIALS (min,max) slots belong to the fix-up kernel of the prefilter path.
-constexpr int GQ_MAIN_PARTIALS = GQ_MAX_PARTIALS - GQ_FIXUP_PARTIALS;
-__host__ __device__ inline int *ws_counter(float *ws) { return reinterpret_cast<int *>(ws + 2 * GQ_MAX_PARTIALS); }
-__host__ __device__ inline int *ws_worklist(float *ws) { return reinterpret_cast<int *>(ws + 2 * GQ_MAX_PARTIALS) + 4; }
 
 // Resident workgroups per CU of a kernel (occupancy API): the persistent grids are sized to
 // exactly one resident wave of workgroups so that no workgroup queues behind another.

@@ -320,62 +320,79 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
 }
 
 // ---------------------------------------------------------------------------------------
-// Fix-up: exact recomputation of the worklist.  One wave per subvector; lane k owns codewords
-// k, k+64, k+128, k+192 (rows kept in registers), exact fmaf chains, then a wave-wide
-// first-max reduction on (|p|, index).  Writes codes/u and the last GQ_FIXUP_PARTIALS
-// (min,max) slots.
+// Finish kernel (GQ_FIXUP_PARTIALS workgroups, always launched behind the main kernel):
+//  1. exact recomputation of the worklist: one wave per subvector; lane k owns codewords
+//     k, k+64, k+128, k+192 (rows in registers), the reference's fmaf chains, then a wave-wide
+//     first-max reduction on (|p|, index); writes codes / u;
+//  2. the LAST workgroup to finish (ticket counter; partials published with agent-scope
+//     atomic stores, read back with agent-scope atomic loads -- cdna_hip_programming.md G16)
+//     folds all (min,max) pairs into the final (lb, ub) at pair 0, raises the `final` flag the
+//     level kernel looks at, and zeroes the worklist counter for the next call (no memset node).
+// The first worklist entry of every wave is fetched speculatively, before the count is known,
+// so the dependent-load chain is count || entry -> subvector -> compute.
 // ---------------------------------------------------------------------------------------
 template <typename CodeT>
-__global__ __launch_bounds__(256) void hsq_encode_fixup_kernel(const float *__restrict__ grad,
-                                                              const float *__restrict__ cb,
-                                                              CodeT *__restrict__ codes, float *__restrict__ u,
-                                                              float *__restrict__ ws) {
+__global__ __launch_bounds__(256) void hsq_encode_finish_kernel(const float *__restrict__ grad,
+                                                               const float *__restrict__ cb, int64_t M,
+                                                               CodeT *__restrict__ codes, float *__restrict__ u,
+                                                               float *__restrict__ ws) {
     __shared__ float s_min[4], s_max[4];
+    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int count = *ws_counter(ws);
+    int *const ctr = ws_counter(ws);
     const int *worklist = ws_worklist(ws);
-    float lmin = INFINITY, lmax = -INFINITY;
     const int nw = gridDim.x * 4;
-    if (count > 0) {
-        float c[4][16];
+    const int w0 = blockIdx.x * 4 + wave;
+
+    // issue everything that does not depend on the count
+    const int count = __hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int sv_spec = worklist[(int64_t)w0 < M ? w0 : 0];
+    f32x4 c[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) c[q][e] = cb[(q * 64 + lane) * 16 + e];
-        for (int w = blockIdx.x * 4 + wave; w < count; w += nw) {
-            const int64_t sv = worklist[w];
-            float v[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = grad[sv * 16 + e];
-            float bv = 0.0f;
-            int bi = lane;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc = __fmaf_rn(c[q][e], v[e], acc);
-                if (q == 0) {
-                    bv = acc;
-                } else {
-                    take_if_greater(bv, bi, acc, q * 64 + lane);
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                const float a0 = fabsf(bv), a1 = fabsf(ov);
-                const bool take = (a1 > a0) || (a1 == a0 && oi < bi);
-                bv = take ? ov : bv;
-                bi = take ? oi : bi;
-            }
-            if (lane == 0) {
-                codes[sv] = (CodeT)bi;
-                u[sv] = bv;
-            }
-            lmin = fminf(lmin, bv);
-            lmax = fmaxf(lmax, bv);
+        for (int e = 0; e < 4; ++e) c[q][e] = *reinterpret_cast<const f32x4 *>(cb + (q * 64 + lane) * 16 + 4 * e);
+    sv_spec = ((unsigned)sv_spec < (uint64_t)M) ? sv_spec : 0;
+    float vlane = grad[(int64_t)sv_spec * 16 + (lane & 15)];
+
+    float lmin = INFINITY, lmax = -INFINITY;
+    for (int w = w0; w < count; w += nw) {
+        int64_t sv = sv_spec;
+        if (w != w0) {
+            sv = worklist[w];
+            vlane = grad[sv * 16 + (lane & 15)];
         }
+        float bv = 0.0f;
+        int bi = lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float ve = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vlane), e));
+                acc = __fmaf_rn(c[q][e >> 2][e & 3], ve, acc);
+            }
+            if (q == 0) {
+                bv = acc;
+            } else {
+                take_if_greater(bv, bi, acc, q * 64 + lane);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            const float a0 = fabsf(bv), a1 = fabsf(ov);
+            const bool take = (a1 > a0) || (a1 == a0 && oi < bi);
+            bv = take ? ov : bv;
+            bi = take ? oi : bi;
+        }
+        if (lane == 0) {
+            codes[sv] = (CodeT)bi;
+            u[sv] = bv;
+        }
+        lmin = fminf(lmin, bv);
+        lmax = fmaxf(lmax, bv);
     }
     if (lane == 0) {
         s_min[wave] = lmin;
@@ -388,8 +405,49 @@ __global__ __launch_bounds__(256) void hsq_encode_fixup_kernel(const float *__re
             a = fminf(a, s_min[w]);
             b = fmaxf(b, s_max[w]);
         }
-        ws[2 * (GQ_MAIN_PARTIALS + blockIdx.x)] = a;
-        ws[2 * (GQ_MAIN_PARTIALS + blockIdx.x) + 1] = b;
+        float *slot = ws + 2 * (GQ_MAIN_PARTIALS + blockIdx.x);
+        __hip_atomic_store(slot, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left before the ticket is drawn
+        const int ticket = __hip_atomic_fetch_add(&ctr[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (ticket == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (s_last) {
+        // pairs [0, GQ_MAIN_PARTIALS) come from the previous kernel (plain loads); the rest from the
+        // other workgroups of this launch (agent-scope loads, never L1-served)
+        float lo = INFINITY, hi = -INFINITY;
+        for (int i = threadIdx.x; i < GQ_MAX_PARTIALS; i += 256) {
+            float a, b;
+            if (i < GQ_MAIN_PARTIALS) {
+                a = ws[2 * i];
+                b = ws[2 * i + 1];
+            } else {
+                a = __hip_atomic_load(ws + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b = __hip_atomic_load(ws + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            lo = fminf(lo, a);
+            hi = fmaxf(hi, b);
+        }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        __syncthreads();  // everyone has read pair 0 and the LDS scratch is free again
+        if (lane == 0) {
+            s_min[wave] = lo;
+            s_max[wave] = hi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) {
+                lo = fminf(lo, s_min[w]);
+                hi = fmaxf(hi, s_max[w]);
+            }
+            ws[0] = lo;
+            ws[1] = hi;
+            ctr[2] = 1;  // pair 0 holds the final (lb, ub)
+            ctr[0] = 0;  // worklist empty for the next call
+            ctr[1] = 0;
+        }
     }
 }
 
@@ -404,12 +462,10 @@ int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT 
     if (cap > GQ_MAIN_PARTIALS) cap = GQ_MAIN_PARTIALS;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipError_t e = hipMemsetAsync(ws_counter(ws), 0, 16, st);
-    if (e != hipSuccess) return fail(GQ_ERR_HIP, "gq_hsq_encode: memset: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, st,
                        grad, codebook, M, codes, u, ws);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_fixup_kernel<CodeT>), dim3(GQ_FIXUP_PARTIALS), dim3(256), 0, st,
-                       grad, codebook, codes, u, ws);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_finish_kernel<CodeT>), dim3(GQ_FIXUP_PARTIALS), dim3(256), 0, st,
+                       grad, codebook, M, codes, u, ws);
     GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter)");
     return GQ_OK;
 }

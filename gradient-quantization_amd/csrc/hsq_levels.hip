@@ -6,7 +6,7 @@
 // one round trip through HBM/L2 (0.25 B per gradient element each way).
 // Built with -ffp-contract=off: sub, IEEE divide, exact *2^n_bit, truncation -- the
 // same roundings as the reference's separate elementwise ops.
-#include "gq_common.hpp"
+#include "hsq_encode_common.hpp"
 
 namespace gq {
 
@@ -18,27 +18,35 @@ __global__ __launch_bounds__(LV_THREADS) void hsq_levels_kernel(const float *__r
                                                                uint64_t seed, const float *__restrict__ partials,
                                                                float *__restrict__ lb_ub,
                                                                LevelT *__restrict__ levels) {
-    // ---- finish min/max: every block reduces the same GQ_MAX_PARTIALS pairs (8 KiB, L2) ----
+    // ---- lb / ub: already final at pair 0 (prefilter encode's finish kernel), or finished here by
+    // every block from the GQ_MAX_PARTIALS pairs (8 KiB from L2) ----
     __shared__ float s_min[LV_THREADS / 64], s_max[LV_THREADS / 64];
-    float lo = INFINITY, hi = -INFINITY;
-    for (int i = threadIdx.x; i < GQ_MAX_PARTIALS; i += LV_THREADS) {
-        const float2 p = reinterpret_cast<const float2 *>(partials)[i];
-        lo = fminf(lo, p.x);
-        hi = fmaxf(hi, p.y);
-    }
-    lo = wave_min(lo);
-    hi = wave_max(hi);
-    if ((threadIdx.x & 63) == 0) {
-        s_min[threadIdx.x >> 6] = lo;
-        s_max[threadIdx.x >> 6] = hi;
-    }
-    __syncthreads();
-    lo = s_min[0];
-    hi = s_max[0];
+    float lo, hi;
+    if (ws_counter(partials)[2] != 0) {
+        lo = partials[0];
+        hi = partials[1];
+    } else {
+        lo = INFINITY;
+        hi = -INFINITY;
+        for (int i = threadIdx.x; i < GQ_MAX_PARTIALS; i += LV_THREADS) {
+            const float2 p = reinterpret_cast<const float2 *>(partials)[i];
+            lo = fminf(lo, p.x);
+            hi = fmaxf(hi, p.y);
+        }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        if ((threadIdx.x & 63) == 0) {
+            s_min[threadIdx.x >> 6] = lo;
+            s_max[threadIdx.x >> 6] = hi;
+        }
+        __syncthreads();
+        lo = s_min[0];
+        hi = s_max[0];
 #pragma unroll
-    for (int w = 1; w < LV_THREADS / 64; ++w) {
-        lo = fminf(lo, s_min[w]);
-        hi = fmaxf(hi, s_max[w]);
+        for (int w = 1; w < LV_THREADS / 64; ++w) {
+            lo = fminf(lo, s_min[w]);
+            hi = fmaxf(hi, s_max[w]);
+        }
     }
     const float lb = lo, ub = hi;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -50,22 +58,37 @@ __global__ __launch_bounds__(LV_THREADS) void hsq_levels_kernel(const float *__r
     const float smax = s - 1.0f;
     const float range = ub - lb;
     const bool flat = (lb - ub) == 0.0f;  // prob_scalar:15-16 -> all zeros
-    const int64_t stride = (int64_t)gridDim.x * LV_THREADS;
-    for (int64_t i = (int64_t)blockIdx.x * LV_THREADS + threadIdx.x; i < M; i += stride) {
-        int l = 0;
-        if (!flat) {
-            const float q = (u[i] - lb) / range;
-            const float x = fabsf(q) * s;
-            const float c = fminf(fmaxf(x, 0.0f), smax);
-            l = (int)c;
-            if (random_mode != GQ_RANDOM_OFF) {
-                const float prob = x - (float)l;
-                const float rr = (random_mode == GQ_RANDOM_GIVEN) ? r[i] : uniform01(seed, (uint64_t)i);
-                l += (prob > rr) ? 1 : 0;
-            }
+    auto level_of = [&](float uu, int64_t i) -> int {
+        if (flat) return 0;
+        const float q = (uu - lb) / range;
+        const float x = fabsf(q) * s;
+        const float c = fminf(fmaxf(x, 0.0f), smax);
+        int l = (int)c;
+        if (random_mode != GQ_RANDOM_OFF) {
+            const float prob = x - (float)l;
+            const float rr = (random_mode == GQ_RANDOM_GIVEN) ? r[i] : uniform01(seed, (uint64_t)i);
+            l += (prob > rr) ? 1 : 0;
         }
-        levels[i] = (LevelT)l;
+        return l;
+    };
+    // four levels per thread and iteration: one dwordx4 load, one packed store
+    const int64_t M4 = ((reinterpret_cast<uintptr_t>(u) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(levels) & (4 * sizeof(LevelT) - 1)) == 0)
+                           ? (M >> 2)
+                           : 0;
+    const int64_t stride = (int64_t)gridDim.x * LV_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * LV_THREADS + threadIdx.x; i < M4; i += stride) {
+        const f32x4 uu = reinterpret_cast<const f32x4 *>(u)[i];
+        LevelT out[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = (LevelT)level_of(uu[e], 4 * i + e);
+        struct alignas(4 * sizeof(LevelT)) Pack {
+            LevelT v[4];
+        } pk = {{out[0], out[1], out[2], out[3]}};
+        reinterpret_cast<Pack *>(levels)[i] = pk;
     }
+    for (int64_t i = 4 * M4 + (int64_t)blockIdx.x * LV_THREADS + threadIdx.x; i < M; i += stride)
+        levels[i] = (LevelT)level_of(u[i], i);
 }
 
 }  // namespace gq
@@ -82,8 +105,8 @@ GQ_API int gq_hsq_levels(const float *u, int64_t M, int n_bit, int random_mode, 
     if ((level_bytes == 1 && top > 255) || (level_bytes == 2 && top > 65535))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels: level_bytes=%d cannot hold level %lld", level_bytes,
                         (long long)top);
-    int64_t blocks = (M + gq::LV_THREADS * 4 - 1) / (gq::LV_THREADS * 4);
-    const int64_t cap = (int64_t)gq::cu_count() * 2;
+    int64_t blocks = (M + gq::LV_THREADS * 8 - 1) / (gq::LV_THREADS * 8);
+    const int64_t cap = (int64_t)gq::cu_count() * 4;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipStream_t st = gq::as_stream(stream);
@@ -130,6 +153,7 @@ __global__ __launch_bounds__(LV_THREADS) void minmax_partials_kernel(const float
         }
         partials[2 * blockIdx.x] = lo;
         partials[2 * blockIdx.x + 1] = hi;
+        if (blockIdx.x == 0) ws_counter(partials)[2] = 0;
     }
     if (blockIdx.x == 0)
         for (int i = gridDim.x + threadIdx.x; i < GQ_MAX_PARTIALS; i += LV_THREADS) {

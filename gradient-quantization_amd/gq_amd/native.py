@@ -14,7 +14,7 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("GQ_LIB_PATH") or os.path.join(_PKG_DIR, "libgq_hsq.so")
 
 GQ_MAX_PARTIALS = 1024
-GQ_FIXUP_PARTIALS = 64
+GQ_FIXUP_PARTIALS = 256
 RANDOM_OFF, RANDOM_GIVEN, RANDOM_DEVICE = 0, 1, 2
 ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFILTER_D16K256 = 0, 1, 2, 3, 4
 
@@ -80,13 +80,21 @@ def workspace_floats(M):
 
 
 def new_workspace(device, M=0):
-    """Encode workspace for M subvectors: (min,max) partials | counter | worklist (f32-typed storage)."""
-    return torch.empty(workspace_floats(M), dtype=torch.float32, device=device)
+    """Encode workspace for M subvectors: (min,max) partials | counters | worklist (f32-typed storage).
+    Zero-initialised: the counter block must be zero before the first use (include/gq_hsq.h)."""
+    return torch.zeros(workspace_floats(M), dtype=torch.float32, device=device)
 
 
-def fixup_count(workspace):
-    """Number of subvectors the last prefilter encode sent to the exact fix-up kernel (syncs)."""
-    return int(workspace[2 * GQ_MAX_PARTIALS:2 * GQ_MAX_PARTIALS + 1].view(torch.int32).item())
+def fixup_count(workspace, M):
+    """Number of subvectors the last prefilter encode sent to the exact fix-up path (syncs).
+    The finish kernel zeroes the counter, so this counts the entries it left in the worklist:
+    call it on a workspace whose worklist was filled with -1 beforehand (tests do)."""
+    wl = workspace[2 * GQ_MAX_PARTIALS + 4:2 * GQ_MAX_PARTIALS + 4 + M].view(torch.int32)
+    return int((wl >= 0).sum().item())
+
+
+def mark_worklist(workspace, M):
+    workspace[2 * GQ_MAX_PARTIALS + 4:2 * GQ_MAX_PARTIALS + 4 + M].view(torch.int32).fill_(-1)
 
 
 def device_info(device=0):

@@ -35,13 +35,15 @@ extern "C" {
 #define GQ_ERR_HIP (-3)
 
 /* Encode workspace (caller-allocated device memory, gq_hsq_workspace_bytes(M) bytes, 16-byte
- * aligned, no initialisation needed):
- *   [ (min,max) f32 pairs x GQ_MAX_PARTIALS | counter (16 B) | worklist int32[M] ]
- * gq_hsq_encode leaves the per-workgroup (min,max) of u in the pairs (unused slots hold
- * (+inf,-inf); the last GQ_FIXUP_PARTIALS slots belong to the exact fix-up kernel of the
- * prefilter path, which also owns the counter and the worklist); gq_hsq_levels reads the pairs. */
+ * aligned):
+ *   [ (min,max) f32 pairs x GQ_MAX_PARTIALS | int32 x4: worklist count, ticket, final flag, - | worklist int32[M] ]
+ * The int32 x4 block (bytes [8*GQ_MAX_PARTIALS, +16)) must be ZERO before the first use; the
+ * library keeps it consistent afterwards (no memset per call).  gq_hsq_encode leaves the
+ * per-workgroup (min,max) of u in the pairs (unused slots hold (+inf,-inf); the last
+ * GQ_FIXUP_PARTIALS slots belong to the prefilter path's finish kernel, which also folds all
+ * pairs into the final (lb, ub) at pair 0 and raises the final flag); gq_hsq_levels reads them. */
 #define GQ_MAX_PARTIALS 1024
-#define GQ_FIXUP_PARTIALS 64
+#define GQ_FIXUP_PARTIALS 256
 size_t gq_hsq_workspace_bytes(int64_t M);
 
 /* random_mode of gq_hsq_levels / gq_qsgd_compress */

@@ -44,6 +44,7 @@ def gpu_compress(nat, x, cb, n_bit, random, r=None, impl=0, code_dtype=None, lev
     codes = torch.empty(M, dtype=code_dtype, device=dev)
     u = torch.empty(M, dtype=torch.float32, device=dev)
     partials = nat.new_workspace(dev, M)
+    nat.mark_worklist(partials, M)
     nat.hsq_encode(g, c, codes, u, partials, impl=impl)
     out = dict(codes=codes, u=u, cb=c, M=M, ws=partials)
     if n_bit != 32:
@@ -249,6 +250,7 @@ def test_prefilter_equals_exact_mfma_at_full_size_and_fixup_rate(nat):
             codes = torch.empty(M, dtype=torch.uint8, device=dev)
             u = torch.empty(M, dtype=torch.float32, device=dev)
             ws = nat.new_workspace(dev, M)
+            nat.mark_worklist(ws, M)
             lb_ub = torch.empty(2, dtype=torch.float32, device=dev)
             nat.hsq_encode(g, cb, codes, u, ws, impl=impl)
             levels = torch.empty(M, dtype=torch.uint8, device=dev)
@@ -259,7 +261,7 @@ def test_prefilter_equals_exact_mfma_at_full_size_and_fixup_rate(nat):
         assert torch.equal(res[1][1].view(torch.int32), res[4][1].view(torch.int32)), "u differs bitwise"
         assert torch.equal(res[1][2].view(torch.int32), res[4][2].view(torch.int32))
         assert torch.equal(res[1][3], res[4][3])
-        n_fix = nat.fixup_count(res[4][4])
+        n_fix = nat.fixup_count(res[4][4], M)
         assert 0 < n_fix < M * 0.01, n_fix
         print("scale %g: fix-up worklist %d of %d subvectors (%.4f%%)" % (scale, n_fix, M, 100.0 * n_fix / M))
 
@@ -290,7 +292,7 @@ def test_prefilter_degenerate_inputs_match_exact(nat, oracle, case):
     res = gpu_compress(nat, x, cbn, 32, 0, impl=4)
     assert np.array_equal(res["codes"].cpu().numpy().astype(np.int32), ref_codes)
     assert np.array_equal(_bits(res["u"].cpu().numpy()), _bits(ref_u))
-    n_fix = nat.fixup_count(res["ws"])
+    n_fix = nat.fixup_count(res["ws"], M)
     if case == "zeros":
         assert n_fix == 0            # handled inline, never sent to the fix-up kernel
     if case in ("huge", "tiny"):

@@ -13,6 +13,7 @@ M = g.numel() // 16
 codes = torch.empty(M, dtype=torch.uint8, device=dev)
 u = torch.empty(M, dtype=torch.float32, device=dev)
 ws = native.new_workspace(dev, M)
+native.mark_worklist(ws, M)
 impl = int(os.environ.get("IMPL", "4"))
 for _ in range(5):
     native.hsq_encode(g, cb, codes, u, ws, impl=impl)
@@ -24,4 +25,4 @@ for _ in range(30):
 e.record()
 torch.cuda.synchronize()
 print("%s impl=%d: %.1f us per encode (incl. fix-up launch), fixups=%d" % (
-    os.path.basename(os.environ.get("GQ_LIB_PATH", "product")), impl, s.elapsed_time(e) / 30 * 1e3, native.fixup_count(ws)))
+    os.path.basename(os.environ.get("GQ_LIB_PATH", "product")), impl, s.elapsed_time(e) / 30 * 1e3, native.fixup_count(ws, M)))
