@@ -37,13 +37,35 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# per-file extra flags
+EXTRA = {
+    # lets fmaxf on MFMA outputs lower to v_max3_f32 without canonicalising v_max x,x,x (see the file)
+    "hsq_encode_pf.hip": ["-fno-honor-nans"],
+}
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    compile_flags = [f for f in FLAGS if f != "-shared"]
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc()] + compile_flags + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd), obj))
+    objs = []
+    for cmd, p, obj in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+        objs.append(obj)
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB
 
 

@@ -11,14 +11,19 @@
 //     |s~_k - p_k| <= E := 2^-15 * max_k||c_k||_1 * max_j |v_j|   for the reference's p_k (fmaf chain):
 //     dropped terms 3*2^-18, chain/accumulate roundings ~2^-20, all relative to
 //     sum_j |c_kj||v_j| <= ||c_k||_1 max|v_j| <= 4 (1+eps) max|v_j|  (rows are unit L2 norm).
-//  2. Per lane (= half of a subvector's 256 candidates) the VALU keeps the TOP-2 of the keys
-//       key = (bits(s~) & 0x7FFFFFC0) | candidate_id        (|.| for free: the mask drops the sign)
-//     with v_and_or / v_med3_u32 / v_max_u32 / v_max3_u32: 2.5 ops per score.
-//  3. EXACT rescoring: the best candidate of each half (2 per subvector) is recomputed with the
-//     reference's arithmetic, acc = fmaf(c[j], v[j], acc) for j ascending, codebook row from LDS.
-//     The larger |p| (lower index on a tie) is the answer IF every other candidate is provably
-//     smaller:  upper(second-best key of either half) + E < |u|.  Then no candidate that was not
-//     rescored can reach |u| even after the approximation error, so code and u are exactly the
+//  2. The 16 scores a lane gets per row block are 8 GROUPS of 2 consecutive codewords
+//     (accumulator registers 2p, 2p+1).  Per group the VALU takes g = max |s~| (one v_max_f32
+//     with |.| modifiers) and forms ONE key
+//       key = (bits(g) & 0x7FFFFFE0) | group_id ,
+//     and keeps the TOP-2 group keys per lane (v_med3_u32 / v_max3_u32): ~1.6 VALU ops per
+//     score instead of ~3 for a compare/select argmax.  (On gfx950 min/max/med3 and v_and_or
+//     issue ~1.6x slower than add/fma -- tools/valu_probe.hip -- so op COUNT is what matters.)
+//  3. EXACT rescoring: both codewords of the best group of each half (4 per subvector) are
+//     recomputed with the reference's arithmetic, acc = fmaf(c[j], v[j], acc) for j ascending,
+//     codebook rows from LDS.  The largest |p| (lowest index on a tie) is the answer IF every
+//     other candidate is provably smaller:  upper(second-best group key of either half) + E < |u|.
+//     Every candidate that was not rescored lies in a group whose key is <= that bound, so it
+//     cannot reach |u| even after the approximation error: code and u are exactly the
 //     reference's first-max argmax and projection.
 //  4. Otherwise (top-2 gap below ~2e-4 relative, ~1e-3 of random subvectors; tiny / huge / non-finite
 //     inputs) the subvector goes to a worklist and a small fix-up kernel recomputes it exactly
@@ -26,15 +31,12 @@
 //     tight -- only on it being an upper bound.
 #include "hsq_encode_common.hpp"
 
-#ifndef GQ_PF_EXP
-#define GQ_PF_EXP 0  // timing experiments only (tools/exp_time.py); 0 = product
-#endif
-
 namespace gq {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr unsigned KEY_MASK = 0x7FFFFFC0u;  // drop sign + 6 low mantissa bits (2^-17 relative)
+constexpr unsigned KEY_MASK = 0x7FFFFFE0u;  // sign + 5 low mantissa bits make room for the group id (2^-18 relative)
+constexpr int PAIR_STRIDE = 36;             // LDS floats per codeword PAIR (32 used, 144 B): spreads random pairs over the banks
 constexpr float ERR_SCALE = 1.0025f * 3.0517578125e-05f;  // 2^-15 (x ||c||_1 x max|v_j|), analytic bound ~0.44 of it
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -77,6 +79,31 @@ __device__ __forceinline__ unsigned med3u(unsigned a, unsigned b, unsigned c) {
     return d;
 }
 
+// max(|a|,|b|,|c|,|d|) straight on MFMA results.  Plain C so that hipcc inserts the MFMA -> VALU
+// wait states itself (it pads nothing around inline asm: reading an accumulator from an asm
+// statement returned stale scores).  This file is compiled with -fno-honor-nans (build.py):
+// without it every fmaxf on an MFMA output gets a NaN-canonicalising v_max_f32 x,x,x in front
+// (6 VALU ops per group instead of 2).  NaN gradients are undefined input either way.
+__device__ __forceinline__ float absmax2(float a, float b) { return fmaxf(fabsf(a), fabsf(b)); }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Exact reference arithmetic for TWO consecutive codewords at once: p = fmaf chain over j
+// ascending, from +0, as packed f32 FMAs (v_pk_fma_f32 rounds each half like v_fma_f32).
+// `pair` points at the pair-interleaved LDS image: (c_even[j], c_odd[j]) for j = 0..15.
+__device__ __forceinline__ f32x2 exact_score_pair(const float *__restrict__ pair, const float (&v)[16]) {
+    f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(pair + 4 * q);   // (e[2q], o[2q], e[2q+1], o[2q+1])
+        const f32x2 c0 = {c[0], c[1]}, c1 = {c[2], c[3]};
+        const f32x2 v0 = {v[2 * q], v[2 * q]}, v1 = {v[2 * q + 1], v[2 * q + 1]};
+        acc = __builtin_elementwise_fma(c0, v0, acc);
+        acc = __builtin_elementwise_fma(c1, v1, acc);
+    }
+    return acc;
+}
+
 // Exact reference arithmetic: p = fmaf chain over j ascending, from +0.
 __device__ __forceinline__ float exact_score(const float *__restrict__ row, const float (&v)[16]) {
     const f32x4 c0 = *reinterpret_cast<const f32x4 *>(row);
@@ -101,9 +128,13 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
                                                                       CodeT *__restrict__ codes,
                                                                       float *__restrict__ u,
                                                                       float *__restrict__ ws) {
-    __shared__ __attribute__((aligned(16))) float s_cb[256 * 16];  // f32 codebook for the exact rescoring
-    for (int i = threadIdx.x; i < 256 * 16 / 4; i += ENC_THREADS)
-        reinterpret_cast<f32x4 *>(s_cb)[i] = reinterpret_cast<const f32x4 *>(cb)[i];
+    // f32 codebook for the exact rescoring, codeword pairs interleaved element by element:
+    // s_cb[(k>>1)*PAIR_STRIDE + 2*j + (k&1)] = c[k][j]
+    __shared__ __attribute__((aligned(16))) float s_cb[128 * PAIR_STRIDE];
+    for (int i = threadIdx.x; i < 256 * 16; i += ENC_THREADS) {
+        const int k = i >> 4, jj = i & 15;
+        s_cb[(k >> 1) * PAIR_STRIDE + 2 * jj + (k & 1)] = cb[i];
+    }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -126,7 +157,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
     {
         float l1 = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) l1 += fabsf(s_cb[threadIdx.x * 16 + e]);
+        for (int e = 0; e < 16; ++e) l1 += fabsf(s_cb[(threadIdx.x >> 1) * PAIR_STRIDE + 2 * e + (threadIdx.x & 1)]);
         l1 = wave_max(l1);
         if ((threadIdx.x & 63) == 0) s_c1[threadIdx.x >> 6] = l1;
     }
@@ -167,22 +198,19 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
         const int64_t tn = t + nw;
         if (tn < ntiles) load_tile(tn, nxt);  // prefetch the next tile
 
-        // ---- prefilter: 16 (block, row block) chains, top-2 keys per (block, row-block half) ----
-        // One wave issues a VALU op every ~4 cycles and a 32x32x16 bf16 MFMA occupies the matrix
-        // pipe for 32; the three MFMAs of a chain depend on each other, and issue is in order, so
-        // they are placed one by one BETWEEN the key operations of the previous chain
-        // (sched_barrier pins the order): the matrix pipe then runs entirely under the VALU stream.
+        // ---- prefilter: 16 (block, row block) chains; top-2 GROUP keys per (block, row-block half) ----
+        // The three MFMAs of chain c+1 depend on each other and issue is in order, so they are
+        // placed one by one BETWEEN the key operations of chain c (sched_barrier pins the order):
+        // the matrix pipe runs under the VALU stream.
         unsigned best[4] = {0, 0, 0, 0}, second[4] = {0, 0, 0, 0};
         unsigned vmask = KEY_MASK;
         asm volatile("" : "+v"(vmask));  // keep the mask in a VGPR: v_and_or with an SGPR operand issues slower
-        auto keys = [&](const f32x16 &a, int rb, int trk, int r0, int r1) {
-#pragma unroll
-            for (int r = r0; r < r1; r += 2) {
-                const unsigned k0 = and_or(__float_as_uint(a[r]), vmask, (unsigned)((rb & 3) * 16 + r));
-                const unsigned k1 = and_or(__float_as_uint(a[r + 1]), vmask, (unsigned)((rb & 3) * 16 + r + 1));
-                second[trk] = max(second[trk], med3u(best[trk], k0, k1));
-                best[trk] = max3u(best[trk], k0, k1);
-            }
+        auto group_key = [&](const f32x16 &a, int rb, int p) {   // group p = registers 2p, 2p+1 = two consecutive rows
+            return and_or(__float_as_uint(absmax2(a[2 * p], a[2 * p + 1])), vmask, (unsigned)((rb & 3) * 8 + p));
+        };
+        auto track = [&](int trk, unsigned k0, unsigned k1) {
+            second[trk] = max(second[trk], med3u(best[trk], k0, k1));
+            best[trk] = max3u(best[trk], k0, k1);
         };
         f32x16 acc = {0};
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[0], vh[0], acc, 0, 0, 0);
@@ -197,23 +225,25 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
                 __builtin_amdgcn_sched_barrier(0);
                 nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[nr], vh[nb], nacc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                keys(acc, rb, trk, 0, 4);
+                track(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
+                track(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
                 __builtin_amdgcn_sched_barrier(0);
                 nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vl[nb], nacc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                keys(acc, rb, trk, 4, 10);
+                track(trk, group_key(acc, rb, 4), group_key(acc, rb, 5));
                 __builtin_amdgcn_sched_barrier(0);
                 nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vh[nb], nacc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                keys(acc, rb, trk, 10, 16);
+                track(trk, group_key(acc, rb, 6), group_key(acc, rb, 7));
                 __builtin_amdgcn_sched_barrier(0);
                 acc = nacc;
             } else {
-                keys(acc, rb, trk, 0, 16);
+#pragma unroll
+                for (int p2 = 0; p2 < 8; p2 += 2) track(trk, group_key(acc, rb, p2), group_key(acc, rb, p2 + 1));
             }
         }
 
-        // ---- per block: merge the two trackers; candidate row and the bound on everything else ----
+        // ---- per block: merge the two trackers; best group's first codeword and the bound on the rest ----
         int k1[2];
         unsigned s2[2];
 #pragma unroll
@@ -221,10 +251,10 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
             const unsigned bA = best[2 * blk], bB = best[2 * blk + 1];
             const bool useB = (bB & KEY_MASK) > (bA & KEY_MASK);
             const unsigned bw = useB ? bB : bA, bl = useB ? bA : bB;
-            const int li = (int)(bw & 63u);
-            const int r = li & 15;
-            k1[blk] = ((li >> 4) + (useB ? 4 : 0)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            s2[blk] = max3u(second[2 * blk], second[2 * blk + 1], bl) | 63u;  // upper end of its bucket
+            const int gid = (int)(bw & 31u);
+            const int r = 2 * (gid & 7);                                              // first register of the group
+            k1[blk] = ((gid >> 3) + (useB ? 4 : 0)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // rows k1, k1+1
+            s2[blk] = max3u(second[2 * blk], second[2 * blk + 1], bl) | 31u;         // upper end of its bucket
         }
 
         // ---- this lane's own full subvector (tile subvector `lane`): 8 swaps of the B loads ----
@@ -246,33 +276,35 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
             s2[1] = (unsigned)a1;
         }
 
-        // ---- exact rescoring of the two candidates (the reference's fmaf chain) ----
-#if GQ_PF_EXP == 1 || GQ_PF_EXP == 5
-        const float pa = __uint_as_float(s2[0]) + vf[0] + vf[15], pb = __uint_as_float(s2[1]) + vf[3] + vf[9];
-#else
-        const float pa = exact_score(s_cb + k1[0] * 16, vf);
-        const float pb = exact_score(s_cb + k1[1] * 16, vf);
-#endif
-        const float aa = fabsf(pa), ab = fabsf(pb);
-        const bool takeb = (ab > aa) || (ab == aa && k1[1] < k1[0]);
-        float val = takeb ? pb : pa;
-        int idx = takeb ? k1[1] : k1[0];
+        // ---- exact rescoring of both groups (8 codewords; the reference's fmaf chain) ----
+        float gv[2];
+        int gi[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const f32x2 p01 = exact_score_pair(s_cb + (k1[g] >> 1) * PAIR_STRIDE, vf);   // k1 is even: one pair
+            float bv = p01[0];
+            int bi = k1[g];
+            take_if_greater(bv, bi, p01[1], k1[g] + 1);
+            gv[g] = bv;
+            gi[g] = bi;
+        }
+        const float aa = fabsf(gv[0]), ab = fabsf(gv[1]);
+        const bool takeb = (ab > aa) || (ab == aa && gi[1] < gi[0]);
+        float val = takeb ? gv[1] : gv[0];
+        int idx = takeb ? gi[1] : gi[0];
 
         float vmax = 0.0f;
 #pragma unroll
         for (int e = 0; e < 16; e += 2) vmax = fmaxf(fmaxf(fabsf(vf[e]), fabsf(vf[e + 1])), vmax);
         const float E = vmax * err_scale;
-        const float others = __uint_as_float(max(s2[0], s2[1]));  // >= every s~ that was not rescored
+        const float others = __uint_as_float(max(s2[0], s2[1]));  // >= every s~ outside the rescored groups
         bool safe = (others + E < fabsf(val)) && (vmax >= 8.27e-25f) && (vmax <= 1.0e30f);
         if (vmax == 0.0f) {  // all-zero subvector: every score is +0 -> first index, u = +0
             safe = true;
             val = 0.0f;
             idx = 0;
         }
-        // NaN anywhere makes vmax/others comparisons false -> not safe -> exact fix-up path
-#if GQ_PF_EXP != 0 && GQ_PF_EXP != 6 && GQ_PF_EXP < 7
-        safe = true;
-#endif
+        // NaN anywhere makes the comparisons false -> not safe -> exact fix-up path
 
         const int64_t sv = t * 64 + lane;
         const bool valid = sv < M;
@@ -293,26 +325,16 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
         }
         __builtin_amdgcn_sched_barrier(0);
 
-#if GQ_PF_EXP == 4
-        if (valid && idx == 12345 && val == 3.0f) {
-#else
         if (valid) {
-#endif
-            // provisional values for flagged subvectors are overwritten by the fix-up kernel
-#if GQ_PF_EXP != 7
+            // provisional values for flagged subvectors are overwritten by the finish kernel
             codes[sv] = (CodeT)idx;
-#endif
-#if GQ_PF_EXP != 8
             u[sv] = val;
-#endif
             if (safe) {
                 lmin = fminf(lmin, val);
                 lmax = fmaxf(lmax, val);
             } else {
-#if GQ_PF_EXP < 6
                 const int pos = atomicAdd(counter, 1);
                 worklist[pos] = (int)sv;
-#endif
             }
         }
     }
