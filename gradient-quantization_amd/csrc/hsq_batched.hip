@@ -1,0 +1,165 @@
+// Multi-tensor (segment table) level quantiser and decode-mean: one launch for all the
+// tensors of a model that share the (d = 16, K = 256) codebook -- ResNet-50 has 76 of them
+// between 1,024 and 2.4 M elements, and per-tensor launches would be launch-bound
+// (SURVEY.md 7.3-5).  Same arithmetic as hsq_levels.hip / hsq_decode.hip (which replace
+// probabilistic_scalar_compressor.py:12-33, nearest_neighbor_compressor.py:80-90 and
+// ps_quantizer.py:48); lb / ub stay PER TENSOR exactly as in the reference.
+//
+// Index space: every tensor is padded to whole 64-subvector tiles; tile_seg[tile] names its
+// tensor, seg_table[seg] = { grad ptr, M, first tile, codes off, levels off, lb/ub off,
+// out off (floats), - } (include/gq_hsq.h).  The matching encode is gq_hsq_encode_batched
+// (hsq_encode_pf.hip).
+#include "hsq_encode_common.hpp"
+
+namespace gq {
+
+constexpr int BT_THREADS = 256;
+
+__device__ __forceinline__ float order_unmap_f(unsigned m) {
+    return __uint_as_float(m ^ ((m >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+// 4 consecutive padded subvectors (one tile quarter-row) per thread and iteration.
+__global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
+    const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
+    uint64_t seed, uint8_t *__restrict__ wire) {
+    const float s = (float)(1 << n_bit), smax = s - 1.0f;
+    const int64_t total4 = ntiles * 16;
+    const int64_t stride = (int64_t)gridDim.x * BT_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * BT_THREADS + threadIdx.x; i < total4; i += stride) {
+        const int64_t tile = i >> 4;
+        const int seg = tile_seg[tile];
+        const int64_t *rec = seg_table + 8 * (int64_t)seg;
+        const int64_t m = rec[1];
+        const int64_t local = (tile - rec[2]) * 64 + 4 * (i & 15);
+        if (local >= m) continue;
+        const float lb = order_unmap_f(seg_minmax[2 * seg]), ub = order_unmap_f(seg_minmax[2 * seg + 1]);
+        if (local == 0) {
+            float *lbub = reinterpret_cast<float *>(wire + rec[5]);
+            lbub[0] = lb;
+            lbub[1] = ub;
+        }
+        const float range = ub - lb;
+        const bool flat = (lb - ub) == 0.0f;
+        const f32x4 uu = *reinterpret_cast<const f32x4 *>(u_flat + 4 * i);
+        uint8_t out[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int l = 0;
+            if (!flat) {
+                const float q = (uu[e] - lb) / range;
+                const float x = fabsf(q) * s;
+                const float c = fminf(fmaxf(x, 0.0f), smax);
+                l = (int)c;
+                if (random_mode == GQ_RANDOM_DEVICE) {
+                    const float prob = x - (float)l;
+                    l += (prob > uniform01(seed, (uint64_t)(4 * i + e))) ? 1 : 0;
+                }
+            }
+            out[e] = (uint8_t)l;
+        }
+        uint8_t *dst = wire + rec[4] + local;
+        if (local + 3 < m) {
+            *reinterpret_cast<uchar4 *>(dst) = make_uchar4(out[0], out[1], out[2], out[3]);
+        } else {
+            for (int e = 0; e < 4 && local + e < m; ++e) dst[e] = out[e];
+        }
+    }
+}
+
+// One thread per 4 output floats of the padded space; payload r starts at gathered + r*user_stride.
+__global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
+    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
+    float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float s_cb[256 * 16];
+    for (int i = threadIdx.x; i < 256 * 16 / 4; i += BT_THREADS)
+        reinterpret_cast<f32x4 *>(s_cb)[i] = reinterpret_cast<const f32x4 *>(cb)[i];
+    __syncthreads();
+    const float s = (float)(1 << n_bit);
+    const float fR = (float)R;
+    const int64_t total = ntiles * 64 * 4;
+    const int64_t stride = (int64_t)gridDim.x * BT_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * BT_THREADS + threadIdx.x; i < total; i += stride) {
+        const int64_t g = i >> 2;
+        const int q = (int)(i & 3);
+        const int64_t tile = g >> 6;
+        const int seg = tile_seg[tile];
+        const int64_t *rec = seg_table + 8 * (int64_t)seg;
+        const int64_t local = (tile - rec[2]) * 64 + (g & 63);
+        if (local >= rec[1]) continue;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int r = 0; r < R; ++r) {
+            const uint8_t *p = gathered + (int64_t)r * user_stride;
+            const int code = p[rec[3] + local];
+            const float *lbub = reinterpret_cast<const float *>(p + rec[5]);
+            const float lb = lbub[0], range = lbub[1] - lb;
+            float n = (float)p[rec[4] + local] * range;   // prob_scalar:31-32, unfused
+            n = n / s;
+            n = n + lb;
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(s_cb + code * 16 + 4 * q);
+            f32x4 dec;
+            dec[0] = c[0] * n;
+            dec[1] = c[1] * n;
+            dec[2] = c[2] * n;
+            dec[3] = c[3] * n;
+            if (r == 0) {
+                acc = dec;
+            } else {
+                acc[0] = acc[0] + dec[0];
+                acc[1] = acc[1] + dec[1];
+                acc[2] = acc[2] + dec[2];
+                acc[3] = acc[3] + dec[3];
+            }
+        }
+        if (R > 1) {
+            acc[0] = acc[0] / fR;
+            acc[1] = acc[1] / fR;
+            acc[2] = acc[2] / fR;
+            acc[3] = acc[3] / fR;
+        }
+        *reinterpret_cast<f32x4 *>(out + rec[6] + local * 16 + 4 * q) = acc;
+    }
+}
+
+static inline int64_t bt_grid(int64_t items) {
+    int64_t blocks = (items + BT_THREADS - 1) / BT_THREADS;
+    const int64_t cap = (int64_t)cu_count() * 8;
+    if (blocks > cap) blocks = cap;
+    return blocks < 1 ? 1 : blocks;
+}
+
+}  // namespace gq
+
+GQ_API int gq_hsq_levels_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                 const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
+                                 uint64_t seed, uint8_t *wire, void *stream) {
+    if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > 8)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: bad sizes");
+    if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !wire)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: null pointer");
+    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched: random_mode must be OFF or DEVICE");
+    if (((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > 255)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: levels do not fit uint8");
+    hipLaunchKernelGGL(gq::hsq_levels_batched_kernel, dim3((unsigned)gq::bt_grid(ntiles * 16)), dim3(gq::BT_THREADS), 0,
+                       gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed,
+                       wire);
+    GQ_CHECK_LAUNCH("gq_hsq_levels_batched");
+    return GQ_OK;
+}
+
+GQ_API int gq_hsq_decode_sum_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                     const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                     const float *codebook, int n_bit, float *out, void *stream) {
+    if (nseg < 1 || ntiles < 1 || R < 1 || n_bit < 1 || n_bit > 8)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: bad sizes");
+    if (!seg_table || !tile_seg || !gathered || !codebook || !out)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: null pointer");
+    hipLaunchKernelGGL(gq::hsq_decode_sum_batched_kernel, dim3((unsigned)gq::bt_grid(ntiles * 256)),
+                       dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
+                       user_stride_bytes, R, codebook, n_bit, out);
+    GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched");
+    return GQ_OK;
+}

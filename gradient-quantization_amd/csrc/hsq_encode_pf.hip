@@ -122,12 +122,39 @@ __device__ __forceinline__ float exact_score(const float *__restrict__ row, cons
     return acc;
 }
 
-template <typename CodeT>
-__global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const float *__restrict__ grad,
-                                                                      const float *__restrict__ cb, int64_t M,
-                                                                      CodeT *__restrict__ codes,
-                                                                      float *__restrict__ u,
-                                                                      float *__restrict__ ws) {
+// Arguments of the prefilter kernels.  Single-tensor form: grad/M/codes/u.  Batched form
+// (gq_hsq_encode_batched): a segment table describes many tensors that share the codebook; tiles
+// never straddle tensors (every tensor starts on a 64-subvector tile boundary of the padded
+// index space), so one launch serves all of them with per-tensor (min,max).
+struct PfArgs {
+    const float *grad;        // single
+    int64_t M;                // single: subvectors; batched: ntiles * 64 (padded index space)
+    void *codes;              // single
+    float *u;                 // single: u[M]; batched: u_flat[ntiles*64]
+    const float *cb;
+    float *ws;
+    const int64_t *seg_table; // batched: int64[8] per segment (include/gq_hsq.h)
+    const int32_t *tile_seg;  // batched
+    uint8_t *wire;            // batched
+    unsigned *seg_minmax;     // batched: order-mapped (min, max) per segment
+    int64_t ntiles;
+};
+
+// order-preserving float -> uint32 map for integer atomic min/max
+__device__ __forceinline__ unsigned order_map(float f) {
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float order_unmap(unsigned m) {
+    return __uint_as_float(m ^ ((m >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+template <typename CodeT, bool BATCHED>
+__global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfArgs a) {
+    const float *__restrict__ cb = a.cb;
+    float *__restrict__ ws = a.ws;
+    float *__restrict__ u = a.u;
+    const int64_t M = a.M;
     // f32 codebook for the exact rescoring, codeword pairs interleaved element by element:
     // s_cb[(k>>1)*PAIR_STRIDE + 2*j + (k&1)] = c[k][j]
     __shared__ __attribute__((aligned(16))) float s_cb[128 * PAIR_STRIDE];
@@ -167,36 +194,81 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
     for (int w = 1; w < ENC_WAVES; ++w) c1 = fmaxf(c1, s_c1[w]);
     const float err_scale = c1 * ERR_SCALE;  // E = max|v_j| * err_scale
 
-    const int64_t ntiles = (M + 63) >> 6;
+    const int64_t ntiles = BATCHED ? a.ntiles : ((M + 63) >> 6);
     const int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
     int64_t t = (int64_t)blockIdx.x * ENC_WAVES + wave;
     int *const counter = ws_counter(ws);
     int *const worklist = ws_worklist(ws);
 
     float lmin = INFINITY, lmax = -INFINITY;
+    int cur_seg = -1;  // batched: segment the running (lmin, lmax) belongs to
     f32x4 cur[4], nxt[4];
 
-    auto load_tile = [&](int64_t tile, f32x4(&dst)[4]) {
+    // where tile `tile` lives: base pointer, subvector count of its tensor, local index of its first subvector
+    struct Tile {
+        const float *base;
+        int64_t m, sv0;
+        int seg;
+        CodeT *codes;
+    };
+    auto tile_info = [&](int64_t tile) {
+        Tile ti;
+        if (BATCHED) {
+            ti.seg = __builtin_amdgcn_readfirstlane(a.tile_seg[tile]);
+            const int64_t *rec = a.seg_table + 8 * (int64_t)ti.seg;
+            ti.base = reinterpret_cast<const float *>(rec[0]);
+            ti.m = rec[1];
+            ti.sv0 = (tile - rec[2]) * 64;
+            ti.codes = reinterpret_cast<CodeT *>(a.wire + rec[3]);
+        } else {
+            ti.seg = 0;
+            ti.base = a.grad;
+            ti.m = M;
+            ti.sv0 = tile * 64;
+            ti.codes = static_cast<CodeT *>(a.codes);
+        }
+        return ti;
+    };
+    auto load_tile = [&](const Tile &ti, f32x4(&dst)[4]) {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
-            int64_t sv = tile * 64 + blk * 32 + j;
-            sv = sv < M ? sv : M - 1;  // tail: re-read the last subvector, result is masked
-            const f32x4 *p = reinterpret_cast<const f32x4 *>(grad + sv * 16 + 8 * h);
+            int64_t sv = ti.sv0 + blk * 32 + j;
+            sv = sv < ti.m ? sv : ti.m - 1;  // tail: re-read the last subvector, result is masked
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(ti.base + sv * 16 + 8 * h);
             dst[2 * blk] = p[0];
             dst[2 * blk + 1] = p[1];
         }
     };
+    auto flush_minmax = [&]() {  // batched: fold this wave's running (min,max) into its segment
+        const float lo = wave_min(lmin), hi = wave_max(lmax);
+        if (lane == 0 && cur_seg >= 0 && lo <= hi) {
+            atomicMin(&a.seg_minmax[2 * cur_seg], order_map(lo));
+            atomicMax(&a.seg_minmax[2 * cur_seg + 1], order_map(hi));
+        }
+        lmin = INFINITY;
+        lmax = -INFINITY;
+    };
 
     // B fragments: lane (col j, half h) holds v[8h .. 8h+7] of subvector j of each block
     bf16x8 vh[2], vl[2];
+    Tile ti = {};
     if (t < ntiles) {
-        load_tile(t, cur);
+        ti = tile_info(t);
+        load_tile(ti, cur);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) split8(cur[2 * blk], cur[2 * blk + 1], vh[blk], vl[blk]);
     }
     for (; t < ntiles; t += nw) {
         const int64_t tn = t + nw;
-        if (tn < ntiles) load_tile(tn, nxt);  // prefetch the next tile
+        Tile tin = ti;
+        if (tn < ntiles) {
+            tin = tile_info(tn);
+            load_tile(tin, nxt);  // prefetch the next tile
+        }
+        if (BATCHED && ti.seg != cur_seg) {
+            flush_minmax();
+            cur_seg = ti.seg;
+        }
 
         // ---- prefilter: 16 (block, row block) chains; top-2 GROUP keys per (block, row-block half) ----
         // The three MFMAs of chain c+1 depend on each other and issue is in order, so they are
@@ -306,8 +378,9 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
         }
         // NaN anywhere makes the comparisons false -> not safe -> exact fix-up path
 
-        const int64_t sv = t * 64 + lane;
-        const bool valid = sv < M;
+        const int64_t sv = ti.sv0 + lane;          // index inside this tile's tensor
+        const bool valid = sv < ti.m;
+        const int64_t gsv = BATCHED ? t * 64 + lane : sv;   // index into u / the worklist
 
         // Consume the prefetched tile (convert it to the next B fragments) BEFORE this tile's
         // stores are issued: the wait for the prefetch then sees only long-finished memory ops.
@@ -327,18 +400,23 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
 
         if (valid) {
             // provisional values for flagged subvectors are overwritten by the finish kernel
-            codes[sv] = (CodeT)idx;
-            u[sv] = val;
+            ti.codes[sv] = (CodeT)idx;
+            u[gsv] = val;
             if (safe) {
                 lmin = fminf(lmin, val);
                 lmax = fmaxf(lmax, val);
             } else {
                 const int pos = atomicAdd(counter, 1);
-                worklist[pos] = (int)sv;
+                worklist[pos] = (int)gsv;
             }
         }
+        ti = tin;
     }
-    write_minmax_partials(lmin, lmax, ws);
+    if (BATCHED) {
+        flush_minmax();
+    } else {
+        write_minmax_partials(lmin, lmax, ws);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -353,11 +431,12 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const flo
 // The first worklist entry of every wave is fetched speculatively, before the count is known,
 // so the dependent-load chain is count || entry -> subvector -> compute.
 // ---------------------------------------------------------------------------------------
-template <typename CodeT>
-__global__ __launch_bounds__(256) void hsq_encode_finish_kernel(const float *__restrict__ grad,
-                                                               const float *__restrict__ cb, int64_t M,
-                                                               CodeT *__restrict__ codes, float *__restrict__ u,
-                                                               float *__restrict__ ws) {
+template <typename CodeT, bool BATCHED>
+__global__ __launch_bounds__(256) void hsq_encode_finish_kernel(const PfArgs a) {
+    const float *__restrict__ cb = a.cb;
+    float *__restrict__ ws = a.ws;
+    float *__restrict__ u = a.u;
+    const int64_t M = a.M;  // size of the index space the worklist entries live in
     __shared__ float s_min[4], s_max[4];
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -365,6 +444,30 @@ __global__ __launch_bounds__(256) void hsq_encode_finish_kernel(const float *__r
     const int *worklist = ws_worklist(ws);
     const int nw = gridDim.x * 4;
     const int w0 = blockIdx.x * 4 + wave;
+
+    // where worklist entry `g` lives: its subvector's floats, its code slot, its segment
+    struct Item {
+        const float *v;
+        CodeT *code;
+        int seg;
+    };
+    auto item_of = [&](int64_t g) {
+        Item it;
+        if (BATCHED) {
+            const int64_t tile = g >> 6;
+            it.seg = a.tile_seg[tile];
+            const int64_t *rec = a.seg_table + 8 * (int64_t)it.seg;
+            int64_t sv = (tile - rec[2]) * 64 + (g & 63);
+            sv = sv < rec[1] ? sv : rec[1] - 1;   // (speculative entries may point into padding)
+            it.v = reinterpret_cast<const float *>(rec[0]) + sv * 16;
+            it.code = reinterpret_cast<CodeT *>(a.wire + rec[3]) + sv;
+        } else {
+            it.seg = 0;
+            it.v = a.grad + g * 16;
+            it.code = static_cast<CodeT *>(a.codes) + g;
+        }
+        return it;
+    };
 
     // issue everything that does not depend on the count
     const int count = __hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -375,14 +478,16 @@ __global__ __launch_bounds__(256) void hsq_encode_finish_kernel(const float *__r
 #pragma unroll
         for (int e = 0; e < 4; ++e) c[q][e] = *reinterpret_cast<const f32x4 *>(cb + (q * 64 + lane) * 16 + 4 * e);
     sv_spec = ((unsigned)sv_spec < (uint64_t)M) ? sv_spec : 0;
-    float vlane = grad[(int64_t)sv_spec * 16 + (lane & 15)];
+    Item it = item_of(sv_spec);
+    float vlane = it.v[lane & 15];
 
     float lmin = INFINITY, lmax = -INFINITY;
     for (int w = w0; w < count; w += nw) {
         int64_t sv = sv_spec;
         if (w != w0) {
             sv = worklist[w];
-            vlane = grad[sv * 16 + (lane & 15)];
+            it = item_of(sv);
+            vlane = it.v[lane & 15];
         }
         float bv = 0.0f;
         int bi = lane;
@@ -410,8 +515,12 @@ __global__ __launch_bounds__(256) void hsq_encode_finish_kernel(const float *__r
             bi = take ? oi : bi;
         }
         if (lane == 0) {
-            codes[sv] = (CodeT)bi;
+            *it.code = (CodeT)bi;
             u[sv] = bv;
+            if (BATCHED) {
+                atomicMin(&a.seg_minmax[2 * it.seg], order_map(bv));
+                atomicMax(&a.seg_minmax[2 * it.seg + 1], order_map(bv));
+            }
         }
         lmin = fminf(lmin, bv);
         lmax = fmaxf(lmax, bv);
@@ -435,7 +544,12 @@ __global__ __launch_bounds__(256) void hsq_encode_finish_kernel(const float *__r
         s_last = (ticket == (int)gridDim.x - 1);
     }
     __syncthreads();
-    if (s_last) {
+    if (s_last && BATCHED) {
+        if (threadIdx.x == 0) {
+            ctr[0] = 0;
+            ctr[1] = 0;
+        }
+    } else if (s_last) {
         // pairs [0, GQ_MAIN_PARTIALS) come from the previous kernel (plain loads); the rest from the
         // other workgroups of this launch (agent-scope loads, never L1-served)
         float lo = INFINITY, hi = -INFINITY;
@@ -473,21 +587,30 @@ __global__ __launch_bounds__(256) void hsq_encode_finish_kernel(const float *__r
     }
 }
 
-template <typename CodeT>
-int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *ws,
-                     hipStream_t st) {
-    if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
-    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<CodeT>, ENC_THREADS, 0);
-    const int64_t ntiles = (M + 63) / 64;
+static int64_t pf_grid(int64_t ntiles, int bpc) {
     int64_t blocks = (ntiles + ENC_WAVES - 1) / ENC_WAVES;
     int64_t cap = (int64_t)cu_count() * bpc;
     if (cap > GQ_MAIN_PARTIALS) cap = GQ_MAIN_PARTIALS;
     if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, st,
-                       grad, codebook, M, codes, u, ws);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_finish_kernel<CodeT>), dim3(GQ_FIXUP_PARTIALS), dim3(256), 0, st,
-                       grad, codebook, M, codes, u, ws);
+    return blocks < 1 ? 1 : blocks;
+}
+
+template <typename CodeT>
+int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *ws,
+                     hipStream_t st) {
+    if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<CodeT, false>, ENC_THREADS, 0);
+    PfArgs a = {};
+    a.grad = grad;
+    a.M = M;
+    a.codes = codes;
+    a.u = u;
+    a.cb = codebook;
+    a.ws = ws;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, false>), dim3((unsigned)pf_grid((M + 63) / 64, bpc)),
+                       dim3(ENC_THREADS), 0, st, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_finish_kernel<CodeT, false>), dim3(GQ_FIXUP_PARTIALS), dim3(256), 0,
+                       st, a);
     GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter)");
     return GQ_OK;
 }
@@ -496,3 +619,30 @@ template int launch_encode_pf<uint8_t>(const float *, const float *, int64_t, ui
 template int launch_encode_pf<int32_t>(const float *, const float *, int64_t, int32_t *, float *, float *, hipStream_t);
 
 }  // namespace gq
+
+GQ_API int gq_hsq_encode_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                 const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax,
+                                 float *workspace, void *stream) {
+    if (nseg < 1 || ntiles < 1 || ntiles * 64 > 0x7FFFFFFFLL)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched: bad sizes nseg=%d ntiles=%lld", nseg, (long long)ntiles);
+    if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched: null pointer");
+    static const int bpc = gq::resident_blocks_per_cu(gq::hsq_encode_pf_kernel<uint8_t, true>, gq::ENC_THREADS, 0);
+    gq::PfArgs a = {};
+    a.M = ntiles * 64;
+    a.u = u_flat;
+    a.cb = codebook;
+    a.ws = workspace;
+    a.seg_table = seg_table;
+    a.tile_seg = tile_seg;
+    a.wire = wire;
+    a.seg_minmax = seg_minmax;
+    a.ntiles = ntiles;
+    hipStream_t st = gq::as_stream(stream);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gq::hsq_encode_pf_kernel<uint8_t, true>), dim3((unsigned)gq::pf_grid(ntiles, bpc)),
+                       dim3(gq::ENC_THREADS), 0, st, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gq::hsq_encode_finish_kernel<uint8_t, true>), dim3(GQ_FIXUP_PARTIALS), dim3(256),
+                       0, st, a);
+    GQ_CHECK_LAUNCH("gq_hsq_encode_batched");
+    return GQ_OK;
+}

@@ -20,6 +20,7 @@ ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFI
 
 EXPORTS = [
     "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_workspace_bytes", "gq_hsq_encode", "gq_hsq_encode_impl", "gq_hsq_levels",
+    "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
 
@@ -172,6 +173,38 @@ def hsq_decode_sum_packed(wire, M, codebook, n_bit, out, R, codes_off=0, levels_
         _dev_ptr(codebook, torch.float32, "codebook"), ctypes.c_int(R), ctypes.c_int64(M), ctypes.c_int(d),
         ctypes.c_int(K), ctypes.c_int(n_bit), _dev_ptr(out, torch.float32, "out"), _stream())
     _check(rc, "gq_hsq_decode_sum_strided")
+
+
+def hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace):
+    assert workspace.numel() >= workspace_floats(ntiles * 64)
+    rc = lib().gq_hsq_encode_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                     _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                     ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
+                                     _dev_ptr(wire, torch.uint8, "wire"), _dev_ptr(u_flat, torch.float32, "u_flat"),
+                                     _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
+                                     _dev_ptr(workspace, torch.float32, "workspace"), _stream())
+    _check(rc, "gq_hsq_encode_batched")
+
+
+def hsq_levels_batched(seg_table, tile_seg, nseg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, wire):
+    rc = lib().gq_hsq_levels_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                     _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                     ctypes.c_int64(ntiles), _dev_ptr(u_flat, torch.float32, "u_flat"),
+                                     _dev_ptr(seg_minmax, torch.int32, "seg_minmax"), ctypes.c_int(n_bit),
+                                     ctypes.c_int(random_mode), ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                                     _dev_ptr(wire, torch.uint8, "wire"), _stream())
+    _check(rc, "gq_hsq_levels_batched")
+
+
+def hsq_decode_sum_batched(seg_table, tile_seg, nseg, ntiles, gathered, codebook, n_bit, out, R):
+    assert gathered.dtype == torch.uint8 and gathered.dim() == 2 and gathered.shape[0] == R and gathered.is_contiguous()
+    rc = lib().gq_hsq_decode_sum_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                         _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                         ctypes.c_int64(ntiles), _dev_ptr(gathered, torch.uint8, "gathered"),
+                                         ctypes.c_int64(gathered.shape[1]), ctypes.c_int(R),
+                                         _dev_ptr(codebook, torch.float32, "codebook"), ctypes.c_int(n_bit),
+                                         _dev_ptr(out, torch.float32, "out"), _stream())
+    _check(rc, "gq_hsq_decode_sum_batched")
 
 
 def axpy_inplace(grad, err, scale):

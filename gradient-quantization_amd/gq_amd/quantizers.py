@@ -41,9 +41,11 @@ def _up(x, a=16):
 class DenseCodec(object):
     """IdenticalCompressor tensors (<=1000 elements, ps_quantizer.py:18-19): raw f32 on the wire."""
 
+    align = 4       # dense sections are packed back to back so that ONE cat / ONE mean serves them all
+
     def __init__(self, compressor, numel, shape):
         self.numel, self.shape = numel, shape
-        self.nbytes = _up(numel * 4)
+        self.nbytes = numel * 4
 
     def encode_into(self, grad, wire_user, off, salt):
         wire_user[off:off + self.numel * 4].view(torch.float32).copy_(grad.reshape(-1))
@@ -223,6 +225,90 @@ class QSGDCodec(object):
         return out.view(self.shape)
 
 
+class BatchedHSQ(object):
+    """All NearestNeighborCompressor tensors with d = 16, K = 256 and byte-sized codes / levels are
+    encoded by ONE gq_hsq_encode_batched + ONE gq_hsq_levels_batched launch and decoded by ONE
+    gq_hsq_decode_sum_batched launch (per-tensor lb / ub, identical results).  The reference walks
+    the parameter list in Python (ps_quantizer.py:33,47); ResNet-50 has 76 such tensors."""
+
+    @staticmethod
+    def eligible(codec):
+        c = getattr(codec, "c", None)
+        return (type(codec) is HSQCodec and c.dim == 16 and c.K == 256 and c.compressed_norm
+                and codec.code_dtype == torch.uint8 and codec.level_dtype == torch.uint8
+                and (not c.norm_compressor.random or c.norm_compressor._rng == "device"))
+
+    def __init__(self, codecs, offsets, idxs, device, slots):
+        self.idxs = list(idxs)
+        self.codecs = [codecs[i] for i in self.idxs]
+        c0 = self.codecs[0].c
+        self.n_bit, self.random = c0.n_bit, bool(c0.norm_compressor.random)
+        self.codebook = c0._codebook_on(device)
+        self.nseg = len(self.idxs)
+        table = torch.zeros((self.nseg, 8), dtype=torch.int64)
+        tile_seg = []
+        tile, out_off = 0, 0
+        self.out_off = []
+        for s, (i, cd) in enumerate(zip(self.idxs, self.codecs)):
+            ntile = (cd.M + 63) // 64
+            table[s, 1], table[s, 2] = cd.M, tile
+            table[s, 3] = offsets[i] + cd.codes_off
+            table[s, 4] = offsets[i] + cd.levels_off
+            table[s, 5] = offsets[i] + cd.lbub_off
+            table[s, 6] = out_off
+            tile_seg += [s] * ntile
+            tile += ntile
+            self.out_off.append(out_off)
+            out_off += cd.numel
+        self.ntiles, self.out_floats = tile, out_off
+        self.tile_seg = torch.tensor(tile_seg, dtype=torch.int32, device=device)
+        # per-step header, one H2D copy: [segment table | (min,max) reset values]
+        init = torch.empty((self.nseg, 2), dtype=torch.int32)
+        init[:, 0], init[:, 1] = -1, 0            # 0xFFFFFFFF / 0: identities of the mapped min / max
+        self._host = [torch.cat([table.view(-1), init.view(torch.int64).view(-1)]).pin_memory() for _ in range(slots)]
+        self._events = [None] * slots
+        self._dev = torch.empty_like(self._host[0], device=device)
+        self.u_flat = torch.empty(self.ntiles * 64, dtype=torch.float32, device=device)
+        self.ws = native.new_workspace(device, self.ntiles * 64)
+        self.device = device
+        self.ready = False      # the device header has been written at least once
+
+    def encode(self, params, wire_user, slot, salt):
+        """Returns False (nothing launched) when a gradient is not a contiguous, 16-byte aligned f32
+        tensor on this device: the caller then takes the per-tensor path for this step."""
+        ptrs = []
+        for i in self.idxs:
+            g = params[i].grad.data
+            ptr = g.data_ptr()
+            if g.device != self.device or g.dtype != torch.float32 or not g.is_contiguous() or ptr % 16:
+                return False
+            ptrs.append(ptr)
+        slot %= len(self._host)
+        if self._events[slot] is not None:
+            self._events[slot].synchronize()       # the previous step's copy out of this pinned buffer
+        host = self._host[slot]
+        host[:self.nseg * 8].view(self.nseg, 8)[:, 0] = torch.tensor(ptrs, dtype=torch.int64)
+        self._dev.copy_(host, non_blocking=True)
+        self.ready = True
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[slot] = ev
+        seg_table = self._dev[:self.nseg * 8]
+        minmax = self._dev[self.nseg * 8:].view(torch.int32)
+        native.hsq_encode_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.codebook, wire_user,
+                                  self.u_flat, minmax, self.ws)
+        mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
+        native.hsq_levels_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.u_flat, minmax, self.n_bit,
+                                  mode, (_next_seed() ^ salt) if self.random else 0, wire_user)
+        return True
+
+    def decode_mean(self, gathered, R):
+        out = torch.empty(self.out_floats, dtype=torch.float32, device=gathered.device)
+        native.hsq_decode_sum_batched(self._dev[:self.nseg * 8], self.tile_seg, self.nseg, self.ntiles, gathered,
+                                      self.codebook, self.n_bit, out, R)
+        return [out[o:o + cd.numel].view(cd.shape) for o, cd in zip(self.out_off, self.codecs)]
+
+
 def default_codec_factory(compressor, numel, shape):
     if isinstance(compressor, IdenticalCompressor):
         return DenseCodec(compressor, numel, shape)
@@ -261,21 +347,32 @@ class PSQuantizer(object):
         factory = codec_factory or default_codec_factory
         self.compressors = []
         self.codecs = []
-        self.offsets = []
-        off = 0
         for param in self.parameters:
             param_size = param.flatten().shape[0]
             comp = Compressor(param_size, param.shape, args) if param_size > 1000 else IdenticalCompressor()
-            codec = factory(comp, param_size, param.shape)
             self.compressors.append(comp)
-            self.codecs.append(codec)
-            self.offsets.append(off)
-            off += codec.nbytes
+            self.codecs.append(factory(comp, param_size, param.shape))
             if self.error_feedback:
                 param.error = [torch.zeros_like(param) for _ in range(args.num_users)]
             if self.error_feedback and self.two_phase:
                 param.server_error = torch.zeros_like(param)
+        # wire layout of one user: 16-byte aligned sections for the compressed tensors first, then ONE
+        # packed region with the raw f32 of all identity-compressed (<= 1000 element) tensors
+        self.offsets = [0] * self.num_layers
+        off = 0
+        self.dense_idx = [i for i, c in enumerate(self.codecs) if type(c) is DenseCodec]
+        for i, c in enumerate(self.codecs):
+            if i not in self.dense_idx:
+                self.offsets[i] = off
+                off = _up(off + c.nbytes)
+        self.dense_off = off
+        for i in self.dense_idx:
+            self.offsets[i] = off
+            off += self.codecs[i].nbytes
+        self.dense_bytes = off - self.dense_off
         self.user_bytes = _up(off)          # one user's payload (all tensors)
+        self.batch_idx = [i for i, c in enumerate(self.codecs) if BatchedHSQ.eligible(c)]
+        self._batched = None                # built at the first record() on a HIP device
         self.capacity = max(1, int(args.num_users))
         self.recorded = 0                   # record() calls since the last apply()
         self._wire = None
@@ -303,7 +400,21 @@ class PSQuantizer(object):
         wire = self._ensure_wire(dev, slot + 1)[slot]
         world, rank = _dist_world(self.process_group)
         salt = ((rank * 1000003 + user) * 0x9E3779B1) & (2 ** 62 - 1)
+        skip = set()
+        if (not self.error_feedback and dev.type == "cuda" and len(self.batch_idx) >= 2
+                and not getattr(self.args, "gq_no_batch", False)):
+            if self._batched is None:
+                self._batched = BatchedHSQ(self.codecs, self.offsets, self.batch_idx, dev, self.capacity)
+            if self._batched.encode(self.parameters, wire, slot, salt):
+                skip.update(self.batch_idx)
+        if not self.error_feedback and len(self.dense_idx) >= 2:
+            # all small tensors with one concatenation straight into the packed wire region
+            torch.cat([self.parameters[i].grad.data.reshape(-1) for i in self.dense_idx],
+                      out=wire[self.dense_off:self.dense_off + self.dense_bytes].view(torch.float32))
+            skip.update(self.dense_idx)
         for i, param in enumerate(self.parameters):
+            if i in skip:
+                continue
             codec, off = self.codecs[i], self.offsets[i]
             grad = param.grad.data
             if self.error_feedback:
@@ -346,7 +457,23 @@ class PSQuantizer(object):
         else:
             gathered = local
         R = gathered.shape[0]
+        done = {}
+        if (self._batched is not None and self._batched.ready and not self.two_phase and not self.error_feedback
+                and gathered.device.type == "cuda"):
+            for i, g in zip(self.batch_idx, self._batched.decode_mean(gathered, R)):
+                done[i] = g
+        if len(self.dense_idx) >= 2 and not self.two_phase and not self.error_feedback:
+            rows = gathered[:, self.dense_off:self.dense_off + self.dense_bytes].view(torch.float32)
+            mean = rows.mean(dim=0)                      # stack().mean(0) of the reference, all at once
+            o = 0
+            for i in self.dense_idx:
+                n = self.codecs[i].numel
+                done[i] = mean[o:o + n].view(self.codecs[i].shape)
+                o += n
         for i, param in enumerate(self.parameters):
+            if i in done:
+                param.grad.data = done[i]
+                continue
             codec, off = self.codecs[i], self.offsets[i]
             g = codec.decode_mean(gathered, off, R)
             if self.two_phase:

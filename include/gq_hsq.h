@@ -126,6 +126,34 @@ int gq_hsq_decode_sum_strided(const void *codes, int code_bytes, int64_t code_st
                               int n_bit, float *out, void *stream);
 
 /*
+ * Multi-tensor (batched) forms for d = 16, K = 256, uint8 codes and levels: ONE launch serves every
+ * tensor of a model that shares the codebook (the reference loops over parameters in Python,
+ * ps_quantizer.py:33,47).  lb / ub stay per tensor.  Every tensor is padded to whole
+ * 64-subvector tiles in a common index space of `ntiles` tiles:
+ *   tile_seg   int32[ntiles]       tensor ("segment") of each tile, ascending
+ *   seg_table  int64[nseg][8]      { grad pointer (16-byte aligned), M subvectors, first tile,
+ *                                    byte offset of codes / of levels / of (lb,ub) inside ONE
+ *                                    user's wire, float offset of the tensor in `out`, reserved }
+ *   seg_minmax uint32[nseg][2]     order-mapped (min,max) of u; the caller resets it before each
+ *                                  encode to { 0xFFFFFFFF, 0 }
+ *   u_flat     float[ntiles*64]    projection spill, padded index space
+ *   workspace  gq_hsq_workspace_bytes(ntiles*64) bytes (same contract as gq_hsq_encode)
+ * gq_hsq_encode_batched writes codes into `wire`, u into u_flat and folds (min,max) into
+ * seg_minmax; gq_hsq_levels_batched writes levels and (lb,ub) into `wire`;
+ * gq_hsq_decode_sum_batched averages R users' wires (`gathered` + r*user_stride_bytes) into `out`.
+ * Results are identical to the per-tensor entry points.
+ */
+int gq_hsq_encode_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                          const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax,
+                          float *workspace, void *stream);
+int gq_hsq_levels_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                          const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
+                          uint64_t seed, uint8_t *wire, void *stream);
+int gq_hsq_decode_sum_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                              const uint8_t *gathered, int64_t user_stride_bytes, int R, const float *codebook,
+                              int n_bit, float *out, void *stream);
+
+/*
  * Error-feedback helpers fused around the codec (ps_quantizer.py:35,39):
  *     gq_axpy_inplace:   grad += scale * err
  *     gq_sub:            err   = grad - decoded

@@ -197,3 +197,65 @@ def test_nccl_single_rank_group_path():
         assert torch.equal(p.grad.data, comp.roundtrip(gr))
     finally:
         dist.destroy_process_group()
+
+
+RESNET50_COMPRESSED = ([(64, 3, 3, 3)] + [(64, 64, 1, 1), (64, 64, 3, 3), (256, 64, 1, 1)] * 2 + [(1024,)] * 4
+                       + [(128, 256, 1, 1), (128, 128, 3, 3), (512, 128, 1, 1), (512, 256, 1, 1)]
+                       + [(256, 512, 1, 1), (256, 256, 3, 3), (1024, 256, 1, 1), (2048,)]
+                       + [(512, 1024, 1, 1), (512, 512, 3, 3), (2048, 512, 1, 1), (2048, 1024, 1, 1)])
+RESNET50_SMALL = [(64,), (64,), (256,), (256,), (128,), (512,), (10, 64), (10,)]
+
+
+def _run_quantizer(shapes, users, seed, **argkw):
+    from gq_amd.compressors import NearestNeighborCompressor
+    from gq_amd.quantizers import Quantizer
+    params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in shapes]
+    q = Quantizer(NearestNeighborCompressor, params, make_args(num_users=users, **argkw))
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    for st in range(2):
+        for u in range(users):
+            for p in params:
+                p.grad = torch.randn(p.shape, device="cuda", generator=g) * 1e-2
+            q.record(u, epoch=1)
+        q.apply()
+    return q, [p.grad.data.clone() for p in params]
+
+
+def test_batched_quantizer_equals_per_tensor_path():
+    """One launch for all tensors (segment table) == the per-tensor kernels, bit for bit."""
+    shapes = RESNET50_COMPRESSED + RESNET50_SMALL
+    qb, gb = _run_quantizer(shapes, 3, 7)
+    qp, gp = _run_quantizer(shapes, 3, 7, gq_no_batch=True)
+    assert qb._batched is not None and qb._batched.ready and qp._batched is None
+    assert len(qb.batch_idx) == len(RESNET50_COMPRESSED)
+    for a, b, s in zip(gb, gp, shapes):
+        assert a.shape == torch.Size(s)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), s
+    # and the wire itself is identical (codes, levels, lb/ub, dense region)
+    assert torch.equal(qb._wire, qp._wire)
+
+
+def test_batched_quantizer_device_rng_and_misaligned_fallback():
+    shapes = RESNET50_COMPRESSED[:6] + RESNET50_SMALL[:3]
+    q, g = _run_quantizer(shapes, 2, 9, random=1)
+    det, gd = _run_quantizer(shapes, 2, 9, random=0)
+    for a, b in zip(g, gd):
+        # stochastic rounding moves every level by at most one step
+        assert (a - b).abs().max() <= (b.abs().max() * 2.5 + 1e-12)
+    # a non-contiguous gradient makes the step fall back to the per-tensor path
+    from gq_amd.compressors import NearestNeighborCompressor
+    from gq_amd.quantizers import Quantizer
+    params = [torch.nn.Parameter(torch.zeros(64, 64, device="cuda")) for _ in range(3)]
+    q = Quantizer(NearestNeighborCompressor, params, make_args(num_users=1))
+    ref = Quantizer(NearestNeighborCompressor, [torch.nn.Parameter(torch.zeros(64, 64, device="cuda")) for _ in range(3)],
+                    make_args(num_users=1, gq_no_batch=True))
+    grads = [torch.randn(64, 64, device="cuda") for _ in range(3)]
+    for p, pr, gr in zip(params, ref.parameters, grads):
+        p.grad = gr.t().contiguous().t()          # same values, column-major storage
+        pr.grad = gr.clone()
+    q.record(0, epoch=1)
+    ref.record(0, epoch=1)
+    q.apply()
+    ref.apply()
+    for p, pr in zip(params, ref.parameters):
+        assert torch.equal(p.grad.data, pr.grad.data)

@@ -1,0 +1,45 @@
+"""BASELINE config 3 shape: ResNet-50/CIFAR parameter list (161 tensors, 23.5 M parameters),
+HSQ c_dim=16 k_bit=8 n_bit=6, one record() + apply() per step on one MI355X.
+Times the quantizer with the batched (segment table) kernels and with per-tensor launches."""
+import json, os, sys, time
+from argparse import Namespace
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gradient-quantization_amd"))
+import torch
+from gq_amd.compressors import NearestNeighborCompressor, QSGDCompressor
+from gq_amd.quantizers import Quantizer
+
+shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "resnet50_cifar_shapes.json")))["parameter_shapes"]
+n = sum(int(torch.Size(s).numel()) for s in shapes)
+
+
+def run(tag, comp, users=1, steps=20, **kw):
+    base = dict(c_dim=16, k_bit=8, n_bit=6, no_cuda=False, random=1, ef=False, two_phase=False, scale="exp",
+                num_users=users, mode="ps", cr=256)
+    base.update(kw)
+    params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in shapes]
+    q = Quantizer(comp, params, Namespace(**base))
+    grads = [torch.randn(p.shape, device="cuda") * 1e-3 for p in params]
+
+    def step():
+        for u in range(users):
+            for p, g in zip(params, grads):
+                p.grad = g
+            q.record(u, epoch=1)
+        q.apply()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print("%-34s users=%d  %.3f ms/step  %.1f M elements/s (record+apply, %d tensors, wire %.2f MB/user)"
+          % (tag, users, dt * 1e3, users * n / dt / 1e6, len(shapes), q.wire_bytes_per_user() / 1e6))
+
+
+run("HSQ batched (segment table)", NearestNeighborCompressor)
+run("HSQ per-tensor launches", NearestNeighborCompressor, gq_no_batch=True)
+run("HSQ batched, 8 simulated users", NearestNeighborCompressor, users=8, steps=5)
+run("QSGD d128 n2 per-tensor", QSGDCompressor, c_dim=128, n_bit=2)
