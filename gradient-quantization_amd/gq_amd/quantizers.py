@@ -238,8 +238,10 @@ class BatchedHSQ(object):
                 and codec.code_dtype == torch.uint8 and codec.level_dtype == torch.uint8
                 and (not c.norm_compressor.random or c.norm_compressor._rng == "device"))
 
-    def __init__(self, codecs, offsets, idxs, device, slots):
+    def __init__(self, codecs, offsets, idxs, device, slots, user_bytes):
         self.idxs = list(idxs)
+        self.user_bytes = user_bytes
+        self._tmp_wire = None
         self.codecs = [codecs[i] for i in self.idxs]
         c0 = self.codecs[0].c
         self.n_bit, self.random = c0.n_bit, bool(c0.norm_compressor.random)
@@ -265,20 +267,21 @@ class BatchedHSQ(object):
         # per-step header, one H2D copy: [segment table | (min,max) reset values]
         init = torch.empty((self.nseg, 2), dtype=torch.int32)
         init[:, 0], init[:, 1] = -1, 0            # 0xFFFFFFFF / 0: identities of the mapped min / max
-        self._host = [torch.cat([table.view(-1), init.view(torch.int64).view(-1)]).pin_memory() for _ in range(slots)]
-        self._events = [None] * slots
+        self._host = [torch.cat([table.view(-1), init.view(torch.int64).view(-1)]).pin_memory()
+                      for _ in range(slots + 1)]          # one per user slot + one for the two-phase re-compress
+        self._events = [None] * (slots + 1)
         self._dev = torch.empty_like(self._host[0], device=device)
         self.u_flat = torch.empty(self.ntiles * 64, dtype=torch.float32, device=device)
         self.ws = native.new_workspace(device, self.ntiles * 64)
         self.device = device
         self.ready = False      # the device header has been written at least once
 
-    def encode(self, params, wire_user, slot, salt):
-        """Returns False (nothing launched) when a gradient is not a contiguous, 16-byte aligned f32
+    def encode(self, tensors, wire_user, slot, salt):
+        """Compress `tensors` (one per batched parameter, in order) into one user's wire.
+        Returns False (nothing launched) when a tensor is not a contiguous, 16-byte aligned f32
         tensor on this device: the caller then takes the per-tensor path for this step."""
         ptrs = []
-        for i in self.idxs:
-            g = params[i].grad.data
+        for g in tensors:
             ptr = g.data_ptr()
             if g.device != self.device or g.dtype != torch.float32 or not g.is_contiguous() or ptr % 16:
                 return False
@@ -301,6 +304,14 @@ class BatchedHSQ(object):
         native.hsq_levels_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.u_flat, minmax, self.n_bit,
                                   mode, (_next_seed() ^ salt) if self.random else 0, wire_user)
         return True
+
+    def roundtrip(self, tensors, slot, salt):
+        """decompress(compress(t)) for every batched tensor: 3 launches; None if not batchable."""
+        if self._tmp_wire is None:
+            self._tmp_wire = torch.zeros((1, self.user_bytes), dtype=torch.uint8, device=self.device)
+        if not self.encode(tensors, self._tmp_wire[0], slot, salt):
+            return None
+        return self.decode_mean(self._tmp_wire, 1)
 
     def decode_mean(self, gathered, R):
         out = torch.empty(self.out_floats, dtype=torch.float32, device=gathered.device)
@@ -401,14 +412,26 @@ class PSQuantizer(object):
         world, rank = _dist_world(self.process_group)
         salt = ((rank * 1000003 + user) * 0x9E3779B1) & (2 ** 62 - 1)
         skip = set()
-        if (not self.error_feedback and dev.type == "cuda" and len(self.batch_idx) >= 2
-                and not getattr(self.args, "gq_no_batch", False)):
+        if dev.type == "cuda" and len(self.batch_idx) >= 2 and not getattr(self.args, "gq_no_batch", False):
             if self._batched is None:
-                self._batched = BatchedHSQ(self.codecs, self.offsets, self.batch_idx, dev, self.capacity)
-            if self._batched.encode(self.parameters, wire, slot, salt):
+                self._batched = BatchedHSQ(self.codecs, self.offsets, self.batch_idx, dev, self.capacity, self.user_bytes)
+            grads = [self.parameters[i].grad.data for i in self.batch_idx]
+            if self.error_feedback:
+                # ps_quantizer.py:35: grad += scale*error -- the product is rounded before the add
+                errs = [self.parameters[i].error[user] for i in self.batch_idx]
+                torch._foreach_add_(grads, torch._foreach_mul(errs, scale))
+            if self._batched.encode(grads, wire, slot, salt):
                 skip.update(self.batch_idx)
-        if not self.error_feedback and len(self.dense_idx) >= 2:
-            # all small tensors with one concatenation straight into the packed wire region
+                if self.error_feedback:
+                    # ps_quantizer.py:39: error = grad - decoded (decoded from this user's own wire slot)
+                    decoded = self._batched.decode_mean(wire.view(1, -1), 1)
+                    for i, e in zip(self.batch_idx, torch._foreach_sub(grads, decoded)):
+                        self.parameters[i].error[user].data = e
+            elif self.error_feedback:
+                torch._foreach_sub_(grads, torch._foreach_mul(errs, scale))   # undo; the per-tensor path redoes it
+        if len(self.dense_idx) >= 2:
+            # all small tensors with one concatenation straight into the packed wire region.  Under
+            # error feedback their residual is identically zero (decoded == grad), so nothing else to do.
             torch.cat([self.parameters[i].grad.data.reshape(-1) for i in self.dense_idx],
                       out=wire[self.dense_off:self.dense_off + self.dense_bytes].view(torch.float32))
             skip.update(self.dense_idx)
@@ -458,11 +481,26 @@ class PSQuantizer(object):
             gathered = local
         R = gathered.shape[0]
         done = {}
-        if (self._batched is not None and self._batched.ready and not self.two_phase and not self.error_feedback
-                and gathered.device.type == "cuda"):
-            for i, g in zip(self.batch_idx, self._batched.decode_mean(gathered, R)):
-                done[i] = g
-        if len(self.dense_idx) >= 2 and not self.two_phase and not self.error_feedback:
+        if self._batched is not None and self._batched.ready and gathered.device.type == "cuda":
+            gs = self._batched.decode_mean(gathered, R)
+            if self.two_phase:
+                # ps_quantizer.py:52-61, replicated on every rank (salt 0, same call count)
+                if self.error_feedback:
+                    gs = torch._foreach_add(gs, [self.parameters[i].server_error for i in self.batch_idx])
+                dec = self._batched.roundtrip(list(gs), self.capacity, 0)
+                if dec is not None:
+                    if self.error_feedback:
+                        for i, e in zip(self.batch_idx, torch._foreach_sub(gs, dec)):
+                            self.parameters[i].server_error = e
+                    gs = dec
+                    for i, g in zip(self.batch_idx, gs):
+                        done[i] = g
+                # (dec is None: not batchable -> the per-tensor loop below handles these tensors)
+            else:
+                for i, g in zip(self.batch_idx, gs):
+                    done[i] = g
+        if len(self.dense_idx) >= 2:
+            # identity tensors: two-phase / error feedback leave them unchanged (roundtrip == clone)
             rows = gathered[:, self.dense_off:self.dense_off + self.dense_bytes].view(torch.float32)
             mean = rows.mean(dim=0)                      # stack().mean(0) of the reference, all at once
             o = 0

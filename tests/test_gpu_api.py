@@ -259,3 +259,21 @@ def test_batched_quantizer_device_rng_and_misaligned_fallback():
     ref.apply()
     for p, pr in zip(params, ref.parameters):
         assert torch.equal(p.grad.data, pr.grad.data)
+
+
+@pytest.mark.parametrize("kw", [dict(ef=True), dict(two_phase=True), dict(ef=True, two_phase=True, scale="0.5")])
+def test_batched_error_feedback_and_two_phase_equal_per_tensor_path(kw):
+    """Error feedback / two-phase on the batched kernels == the per-tensor path, bit for bit
+    (aggregates, per-user residuals and the server residual)."""
+    shapes = RESNET50_COMPRESSED[:9] + RESNET50_SMALL[:4]
+    qb, gb = _run_quantizer(shapes, 2, 21, **kw)
+    qp, gp = _run_quantizer(shapes, 2, 21, gq_no_batch=True, **kw)
+    assert qb._batched is not None and qb._batched.ready
+    for a, b in zip(gb, gp):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    if kw.get("ef"):
+        for pb, pp in zip(qb.parameters, qp.parameters):
+            for eb, ep in zip(pb.error, pp.error):
+                assert torch.equal(eb, ep)
+            if kw.get("two_phase"):
+                assert torch.equal(pb.server_error, pp.server_error)
