@@ -1,0 +1,167 @@
+// QSGD on a packed wire, multi-tensor (segment table) form -- BASELINE config 5.
+//
+// Same arithmetic as qsgd.hip (which mirrors the reference's signature: f32 norm per bucket,
+// bool signs, int32 levels -- qsgd_compressor.py:42-71), but what is WRITTEN is a real wire format:
+//     norm f32[buckets] | one code per element = sign<<(bits-1) | level ,  bits = 4 (n_bit <= 2) or 8 (n_bit <= 6)
+// 4-bit codes are packed two per byte (element 2i in the low nibble).  ResNet-50 with c_dim=128,
+// n_bit=2: 0.53 B per gradient element instead of the 2 B of separate sign / level arrays.
+// One launch serves every tensor of a model: bucket_seg[bucket] names its tensor and
+// seg_table[seg] = { grad ptr, d, first bucket, norm off, codes off (bytes, inside ONE user's wire),
+// out off (floats), buckets, - }.  A zero bucket (0/0 = NaN level in the reference, decodes to 0)
+// is written as level 0.  HBM-bound: 4 B read + 0.5..1 B written per element; one wave per bucket.
+#include "gq_common.hpp"
+
+namespace gq {
+
+constexpr int QB_THREADS = 256;
+
+__device__ __forceinline__ unsigned qsgd_code(float v, float norm, float s, float smax, int random_mode,
+                                              uint64_t seed, uint64_t gidx, int bits) {
+    const float q = v / norm;
+    const float x = fabsf(q) * s;
+    unsigned l = 0;
+    if (x == x) {  // NaN (zero bucket) -> level 0
+        const float c = fminf(fmaxf(x, 0.0f), smax);
+        l = (unsigned)(int)c;
+        if (random_mode == GQ_RANDOM_DEVICE) {
+            const float prob = x - (float)l;
+            l += (prob > uniform01(seed, gidx)) ? 1u : 0u;
+        }
+    }
+    return l | ((v > 0.0f ? 1u : 0u) << (bits - 1));
+}
+
+// one wave per bucket; lane handles element pairs (2*lane, 2*lane+1), strided by 128
+__global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int n_bit,
+    int bits, int random_mode, uint64_t seed, uint8_t *__restrict__ wire) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
+    const float s = (float)(1 << n_bit), smax = s - 1.0f;
+    for (int64_t b = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); b < nbuckets; b += nw) {
+        const int seg = __builtin_amdgcn_readfirstlane(bucket_seg[b]);
+        const int64_t *rec = seg_table + 8 * (int64_t)seg;
+        const int d = (int)rec[1];
+        const int64_t lb = b - rec[2];
+        const float *v = reinterpret_cast<const float *>(rec[0]) + lb * d;
+        float mx = 0.0f;
+        for (int e = 2 * lane; e < d; e += 128) {
+            const float2 p = *reinterpret_cast<const float2 *>(v + e);
+            mx = fmaxf(mx, fmaxf(fabsf(p.x), fabsf(p.y)));
+        }
+        mx = wave_max(mx);
+        if (lane == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = mx;
+        const uint64_t g0 = (uint64_t)b << 20;  // RNG stream index: unique per (bucket, element)
+        if (bits == 4) {
+            uint8_t *dst = wire + rec[4] + ((lb * d) >> 1);
+            for (int e = 2 * lane; e < d; e += 128) {
+                const float2 p = *reinterpret_cast<const float2 *>(v + e);
+                const unsigned c0 = qsgd_code(p.x, mx, s, smax, random_mode, seed, g0 + e, 4);
+                const unsigned c1 = qsgd_code(p.y, mx, s, smax, random_mode, seed, g0 + e + 1, 4);
+                dst[e >> 1] = (uint8_t)(c0 | (c1 << 4));
+            }
+        } else {
+            uint8_t *dst = wire + rec[4] + lb * d;
+            for (int e = 2 * lane; e < d; e += 128) {
+                const float2 p = *reinterpret_cast<const float2 *>(v + e);
+                const unsigned c0 = qsgd_code(p.x, mx, s, smax, random_mode, seed, g0 + e, 8);
+                const unsigned c1 = qsgd_code(p.y, mx, s, smax, random_mode, seed, g0 + e + 1, 8);
+                *reinterpret_cast<uchar2 *>(dst + e) = make_uchar2((uint8_t)c0, (uint8_t)c1);
+            }
+        }
+    }
+}
+
+// decode + mean over R users: one wave per bucket, out = ( sum_r (l * (2*sign-1)) * norm / 2^n_bit ) / R
+__global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int n_bit,
+    int bits, const uint8_t *__restrict__ gathered, int64_t user_stride, int R, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
+    const float s = (float)(1 << n_bit);
+    const float fR = (float)R;
+    const unsigned lmask = (1u << (bits - 1)) - 1u;
+    for (int64_t b = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); b < nbuckets; b += nw) {
+        const int seg = __builtin_amdgcn_readfirstlane(bucket_seg[b]);
+        const int64_t *rec = seg_table + 8 * (int64_t)seg;
+        const int d = (int)rec[1];
+        const int64_t lb = b - rec[2];
+        float *o = out + rec[5] + lb * d;
+        for (int e = 2 * lane; e < d; e += 128) {
+            float a0 = 0.0f, a1 = 0.0f;
+            for (int r = 0; r < R; ++r) {
+                const uint8_t *p = gathered + (int64_t)r * user_stride;
+                const float norm = reinterpret_cast<const float *>(p + rec[3])[lb];
+                unsigned c0, c1;
+                if (bits == 4) {
+                    const unsigned byte = p[rec[4] + ((lb * d + e) >> 1)];
+                    c0 = byte & 15u;
+                    c1 = byte >> 4;
+                } else {
+                    const uchar2 cc = *reinterpret_cast<const uchar2 *>(p + rec[4] + lb * d + e);
+                    c0 = cc.x;
+                    c1 = cc.y;
+                }
+                // qsgd_compressor.py:69-70: (l * (2*signs - 1)) * norm / s
+                float t0 = (float)(c0 & lmask) * (2.0f * (float)(c0 >> (bits - 1)) - 1.0f);
+                float t1 = (float)(c1 & lmask) * (2.0f * (float)(c1 >> (bits - 1)) - 1.0f);
+                t0 = t0 * norm;
+                t1 = t1 * norm;
+                t0 = t0 / s;
+                t1 = t1 / s;
+                a0 = (r == 0) ? t0 : a0 + t0;
+                a1 = (r == 0) ? t1 : a1 + t1;
+            }
+            if (R > 1) {
+                a0 = a0 / fR;
+                a1 = a1 / fR;
+            }
+            *reinterpret_cast<float2 *>(o + e) = make_float2(a0, a1);
+        }
+    }
+}
+
+static inline int64_t qb_grid(int64_t nbuckets) {
+    int64_t blocks = (nbuckets + (QB_THREADS / 64) - 1) / (QB_THREADS / 64);
+    const int64_t cap = (int64_t)cu_count() * 8;
+    if (blocks > cap) blocks = cap;
+    return blocks < 1 ? 1 : blocks;
+}
+
+}  // namespace gq
+
+GQ_API int gq_qsgd_code_bits(int n_bit, int random_mode) {
+    // levels reach 2^n_bit with stochastic rounding, 2^n_bit - 1 without; one more bit for the sign
+    const int top = (1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0);
+    if (top <= 7) return 4;
+    if (top <= 127) return 8;
+    return 0;  // no packed format: use gq_qsgd_compress / gq_qsgd_decode_sum
+}
+
+GQ_API int gq_qsgd_compress_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
+                                    int n_bit, int random_mode, uint64_t seed, uint8_t *wire, void *stream) {
+    if (nseg < 1 || nbuckets < 1 || n_bit < 1) return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched: bad sizes");
+    if (!seg_table || !bucket_seg || !wire) return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched: null pointer");
+    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched: random_mode must be OFF or DEVICE");
+    const int bits = gq_qsgd_code_bits(n_bit, random_mode);
+    if (!bits) return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched: n_bit %d has no packed format", n_bit);
+    hipLaunchKernelGGL(gq::qsgd_compress_batched_kernel, dim3((unsigned)gq::qb_grid(nbuckets)), dim3(gq::QB_THREADS), 0,
+                       gq::as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, bits, random_mode, seed, wire);
+    GQ_CHECK_LAUNCH("gq_qsgd_compress_batched");
+    return GQ_OK;
+}
+
+GQ_API int gq_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
+                                      int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                      float *out, void *stream) {
+    if (nseg < 1 || nbuckets < 1 || n_bit < 1 || R < 1 || (bits != 4 && bits != 8))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: bad sizes");
+    if (!seg_table || !bucket_seg || !gathered || !out)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: null pointer");
+    hipLaunchKernelGGL(gq::qsgd_decode_sum_batched_kernel, dim3((unsigned)gq::qb_grid(nbuckets)), dim3(gq::QB_THREADS),
+                       0, gq::as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, bits, gathered,
+                       user_stride_bytes, R, out);
+    GQ_CHECK_LAUNCH("gq_qsgd_decode_sum_batched");
+    return GQ_OK;
+}

@@ -21,6 +21,7 @@ ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFI
 EXPORTS = [
     "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_workspace_bytes", "gq_hsq_encode", "gq_hsq_encode_impl", "gq_hsq_levels",
     "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched",
+    "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
 
@@ -205,6 +206,30 @@ def hsq_decode_sum_batched(seg_table, tile_seg, nseg, ntiles, gathered, codebook
                                          _dev_ptr(codebook, torch.float32, "codebook"), ctypes.c_int(n_bit),
                                          _dev_ptr(out, torch.float32, "out"), _stream())
     _check(rc, "gq_hsq_decode_sum_batched")
+
+
+def qsgd_code_bits(n_bit, random_mode):
+    return int(lib().gq_qsgd_code_bits(ctypes.c_int(n_bit), ctypes.c_int(random_mode)))
+
+
+def qsgd_compress_batched(seg_table, bucket_seg, nseg, nbuckets, n_bit, random_mode, seed, wire):
+    rc = lib().gq_qsgd_compress_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                        _dev_ptr(bucket_seg, torch.int32, "bucket_seg"), ctypes.c_int(nseg),
+                                        ctypes.c_int64(nbuckets), ctypes.c_int(n_bit), ctypes.c_int(random_mode),
+                                        ctypes.c_uint64(seed & (2 ** 64 - 1)), _dev_ptr(wire, torch.uint8, "wire"),
+                                        _stream())
+    _check(rc, "gq_qsgd_compress_batched")
+
+
+def qsgd_decode_sum_batched(seg_table, bucket_seg, nseg, nbuckets, n_bit, bits, gathered, out, R):
+    assert gathered.dtype == torch.uint8 and gathered.dim() == 2 and gathered.shape[0] == R and gathered.is_contiguous()
+    rc = lib().gq_qsgd_decode_sum_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                          _dev_ptr(bucket_seg, torch.int32, "bucket_seg"), ctypes.c_int(nseg),
+                                          ctypes.c_int64(nbuckets), ctypes.c_int(n_bit), ctypes.c_int(bits),
+                                          _dev_ptr(gathered, torch.uint8, "gathered"),
+                                          ctypes.c_int64(gathered.shape[1]), ctypes.c_int(R),
+                                          _dev_ptr(out, torch.float32, "out"), _stream())
+    _check(rc, "gq_qsgd_decode_sum_batched")
 
 
 def axpy_inplace(grad, err, scale):

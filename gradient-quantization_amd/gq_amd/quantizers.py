@@ -164,19 +164,39 @@ class HSQCodec(object):
 
 
 class QSGDCodec(object):
-    """QSGDCompressor on the HIP kernels.  Wire per user: norm f32[Mb] | signs u8[n] | levels u8|i32 [n]."""
+    """QSGDCompressor on the HIP kernels.  Wire per user, packed form (even bucket size <= 65536 and a
+    top level that fits 3 or 7 bits):  norm f32[Mb] | one code per element = sign<<(bits-1) | level,
+    4-bit codes two per byte.  Otherwise the plain form  norm f32[Mb] | signs u8[n] | levels u8|i32 [n]."""
 
     def __init__(self, compressor, numel, shape):
         self.c, self.numel, self.shape = compressor, numel, shape
         self.Mb, self.d = compressor.M, compressor.dim
-        top = 2 ** compressor.bit
-        self.level_dtype = torch.uint8 if top <= 127 else torch.int32
-        lb = torch.empty(0, dtype=self.level_dtype).element_size()
+        mode = native.RANDOM_DEVICE if compressor.random else native.RANDOM_OFF
+        self.bits = 0
+        if self.d % 2 == 0 and self.d <= 65536 and (not compressor.random or compressor._rng == "device"):
+            top = 2 ** compressor.bit - (0 if compressor.random else 1)
+            self.bits = 4 if top <= 7 else (8 if top <= 127 else 0)
         self.norm_off = 0
-        self.signs_off = _up(self.Mb * 4)
-        self.levels_off = self.signs_off + _up(numel)
-        self.nbytes = self.levels_off + _up(numel * lb)
+        if self.bits:
+            self.codes_off = _up(self.Mb * 4)
+            self.nbytes = self.codes_off + _up(numel * self.bits // 8)
+            self._single = None     # a one-tensor BatchedQSGD, built on first use
+        else:
+            top = 2 ** compressor.bit
+            self.level_dtype = torch.uint8 if top <= 127 else torch.int32
+            lb = torch.empty(0, dtype=self.level_dtype).element_size()
+            self.signs_off = _up(self.Mb * 4)
+            self.levels_off = self.signs_off + _up(numel)
+            self.nbytes = self.levels_off + _up(numel * lb)
+        self._mode = mode
 
+    # ---- packed form: a single-segment instance of the batched kernels ----------------------
+    def _batched1(self, dev):
+        if self._single is None or self._single.device != dev:
+            self._single = BatchedQSGD([self], [0], [0], dev, 1, self.nbytes)
+        return self._single
+
+    # ---- plain form --------------------------------------------------------------------------
     def _views(self, wire_user, off):
         lb = torch.empty(0, dtype=self.level_dtype).element_size()
         norm = wire_user[off + self.norm_off:off + self.norm_off + self.Mb * 4].view(torch.float32)
@@ -187,8 +207,12 @@ class QSGDCodec(object):
     def encode_into(self, grad, wire_user, off, salt):
         _require_device(grad, "QSGDCodec.encode_into")
         flat = grad.contiguous().view(-1)
-        norm, signs, levels = self._views(wire_user, off)
         c = self.c
+        if self.bits:
+            ok = self._batched1(flat.device).encode([flat], wire_user[off:off + self.nbytes], 0, salt)
+            assert ok, "QSGDCodec: gradient storage must be 8-byte aligned"
+            return
+        norm, signs, levels = self._views(wire_user, off)
         if not c.random:
             native.qsgd_compress(flat, self.d, c.bit, native.RANDOM_OFF, None, 0, norm, signs, levels)
         elif c._rng == "reference":
@@ -200,8 +224,13 @@ class QSGDCodec(object):
                                  levels)
 
     def _decode_rows(self, gathered, off, R, out):
-        # the QSGD entry point takes dense [R][...] arrays: gather the three sections
-        # (strided views -> contiguous; QSGD payloads are 2 B/element so this is a small copy)
+        if self.bits:
+            rows = gathered[:, off:off + self.nbytes]
+            if not rows.is_contiguous():
+                rows = rows.contiguous()
+            out.copy_(self._batched1(gathered.device).decode_mean(rows, R)[0].view(-1))
+            return
+        # the plain entry point takes dense [R][...] arrays: gather the three sections
         lb = torch.empty(0, dtype=self.level_dtype).element_size()
         norm = gathered[:, off + self.norm_off:off + self.norm_off + self.Mb * 4].contiguous().view(torch.float32)
         signs = gathered[:, off + self.signs_off:off + self.signs_off + self.numel].contiguous()
@@ -225,7 +254,53 @@ class QSGDCodec(object):
         return out.view(self.shape)
 
 
-class BatchedHSQ(object):
+class _BatchedBase(object):
+    """Shared plumbing of the multi-tensor kernels: a per-step header (segment table with the
+    tensors' current device pointers, plus kernel-specific reset values) goes to the device in ONE
+    pinned H2D copy; a ring of pinned buffers (one per user slot + one) keeps a copy in flight from
+    being overwritten."""
+
+    def _setup(self, table, extra, device, slots, user_bytes):
+        self.nseg = table.shape[0]
+        self.device = device
+        self.user_bytes = user_bytes
+        self._table_words = self.nseg * 8
+        host = torch.cat([table.view(-1), extra.view(-1)]) if extra is not None else table.view(-1).clone()
+        self._host = [host.clone().pin_memory() for _ in range(slots + 1)]
+        self._events = [None] * (slots + 1)
+        self._dev = torch.empty_like(host, device=device)
+        self._tmp_wire = None
+        self.ready = False      # the device header has been written at least once
+
+    def _upload(self, tensors, slot, align):
+        ptrs = []
+        for g in tensors:
+            ptr = g.data_ptr()
+            if g.device != self.device or g.dtype != torch.float32 or not g.is_contiguous() or ptr % align:
+                return False
+            ptrs.append(ptr)
+        slot %= len(self._host)
+        if self._events[slot] is not None:
+            self._events[slot].synchronize()       # the previous copy out of this pinned buffer
+        host = self._host[slot]
+        host[:self._table_words].view(self.nseg, 8)[:, 0] = torch.tensor(ptrs, dtype=torch.int64)
+        self._dev.copy_(host, non_blocking=True)
+        self.ready = True
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[slot] = ev
+        return True
+
+    def roundtrip(self, tensors, slot, salt):
+        """decompress(compress(t)) for every batched tensor in a few launches; None if not batchable."""
+        if self._tmp_wire is None:
+            self._tmp_wire = torch.zeros((1, self.user_bytes), dtype=torch.uint8, device=self.device)
+        if not self.encode(tensors, self._tmp_wire[0], slot, salt):
+            return None
+        return self.decode_mean(self._tmp_wire, 1)
+
+
+class BatchedHSQ(_BatchedBase):
     """All NearestNeighborCompressor tensors with d = 16, K = 256 and byte-sized codes / levels are
     encoded by ONE gq_hsq_encode_batched + ONE gq_hsq_levels_batched launch and decoded by ONE
     gq_hsq_decode_sum_batched launch (per-tensor lb / ub, identical results).  The reference walks
@@ -240,14 +315,12 @@ class BatchedHSQ(object):
 
     def __init__(self, codecs, offsets, idxs, device, slots, user_bytes):
         self.idxs = list(idxs)
-        self.user_bytes = user_bytes
-        self._tmp_wire = None
         self.codecs = [codecs[i] for i in self.idxs]
         c0 = self.codecs[0].c
         self.n_bit, self.random = c0.n_bit, bool(c0.norm_compressor.random)
         self.codebook = c0._codebook_on(device)
-        self.nseg = len(self.idxs)
-        table = torch.zeros((self.nseg, 8), dtype=torch.int64)
+        nseg = len(self.idxs)
+        table = torch.zeros((nseg, 8), dtype=torch.int64)
         tile_seg = []
         tile, out_off = 0, 0
         self.out_off = []
@@ -264,40 +337,20 @@ class BatchedHSQ(object):
             out_off += cd.numel
         self.ntiles, self.out_floats = tile, out_off
         self.tile_seg = torch.tensor(tile_seg, dtype=torch.int32, device=device)
-        # per-step header, one H2D copy: [segment table | (min,max) reset values]
-        init = torch.empty((self.nseg, 2), dtype=torch.int32)
+        init = torch.empty((nseg, 2), dtype=torch.int32)
         init[:, 0], init[:, 1] = -1, 0            # 0xFFFFFFFF / 0: identities of the mapped min / max
-        self._host = [torch.cat([table.view(-1), init.view(torch.int64).view(-1)]).pin_memory()
-                      for _ in range(slots + 1)]          # one per user slot + one for the two-phase re-compress
-        self._events = [None] * (slots + 1)
-        self._dev = torch.empty_like(self._host[0], device=device)
+        self._setup(table, init.view(torch.int64), device, slots, user_bytes)
         self.u_flat = torch.empty(self.ntiles * 64, dtype=torch.float32, device=device)
         self.ws = native.new_workspace(device, self.ntiles * 64)
-        self.device = device
-        self.ready = False      # the device header has been written at least once
 
     def encode(self, tensors, wire_user, slot, salt):
         """Compress `tensors` (one per batched parameter, in order) into one user's wire.
         Returns False (nothing launched) when a tensor is not a contiguous, 16-byte aligned f32
         tensor on this device: the caller then takes the per-tensor path for this step."""
-        ptrs = []
-        for g in tensors:
-            ptr = g.data_ptr()
-            if g.device != self.device or g.dtype != torch.float32 or not g.is_contiguous() or ptr % 16:
-                return False
-            ptrs.append(ptr)
-        slot %= len(self._host)
-        if self._events[slot] is not None:
-            self._events[slot].synchronize()       # the previous step's copy out of this pinned buffer
-        host = self._host[slot]
-        host[:self.nseg * 8].view(self.nseg, 8)[:, 0] = torch.tensor(ptrs, dtype=torch.int64)
-        self._dev.copy_(host, non_blocking=True)
-        self.ready = True
-        ev = torch.cuda.Event()
-        ev.record()
-        self._events[slot] = ev
-        seg_table = self._dev[:self.nseg * 8]
-        minmax = self._dev[self.nseg * 8:].view(torch.int32)
+        if not self._upload(tensors, slot, 16):
+            return False
+        seg_table = self._dev[:self._table_words]
+        minmax = self._dev[self._table_words:].view(torch.int32)
         native.hsq_encode_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.codebook, wire_user,
                                   self.u_flat, minmax, self.ws)
         mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
@@ -305,18 +358,57 @@ class BatchedHSQ(object):
                                   mode, (_next_seed() ^ salt) if self.random else 0, wire_user)
         return True
 
-    def roundtrip(self, tensors, slot, salt):
-        """decompress(compress(t)) for every batched tensor: 3 launches; None if not batchable."""
-        if self._tmp_wire is None:
-            self._tmp_wire = torch.zeros((1, self.user_bytes), dtype=torch.uint8, device=self.device)
-        if not self.encode(tensors, self._tmp_wire[0], slot, salt):
-            return None
-        return self.decode_mean(self._tmp_wire, 1)
+    def decode_mean(self, gathered, R):
+        out = torch.empty(self.out_floats, dtype=torch.float32, device=gathered.device)
+        native.hsq_decode_sum_batched(self._dev[:self._table_words], self.tile_seg, self.nseg, self.ntiles, gathered,
+                                      self.codebook, self.n_bit, out, R)
+        return [out[o:o + cd.numel].view(cd.shape) for o, cd in zip(self.out_off, self.codecs)]
+
+
+class BatchedQSGD(_BatchedBase):
+    """All packed-form QSGD tensors in ONE gq_qsgd_compress_batched / gq_qsgd_decode_sum_batched launch."""
+
+    @staticmethod
+    def eligible(codec):
+        return type(codec) is QSGDCodec and codec.bits != 0
+
+    def __init__(self, codecs, offsets, idxs, device, slots, user_bytes):
+        self.idxs = list(idxs)
+        self.codecs = [codecs[i] for i in self.idxs]
+        c0 = self.codecs[0]
+        self.n_bit, self.bits, self.random = c0.c.bit, c0.bits, bool(c0.c.random)
+        assert all(cd.bits == self.bits and cd.c.bit == self.n_bit for cd in self.codecs)
+        nseg = len(self.idxs)
+        table = torch.zeros((nseg, 8), dtype=torch.int64)
+        bucket_seg = []
+        bucket, out_off = 0, 0
+        self.out_off = []
+        for s, (i, cd) in enumerate(zip(self.idxs, self.codecs)):
+            table[s, 1], table[s, 2] = cd.d, bucket
+            table[s, 3] = offsets[i] + cd.norm_off
+            table[s, 4] = offsets[i] + cd.codes_off
+            table[s, 5] = out_off
+            table[s, 6] = cd.Mb
+            bucket_seg += [s] * cd.Mb
+            bucket += cd.Mb
+            self.out_off.append(out_off)
+            out_off += cd.numel + (cd.numel & 1)
+        self.nbuckets, self.out_floats = bucket, out_off
+        self.bucket_seg = torch.tensor(bucket_seg, dtype=torch.int32, device=device)
+        self._setup(table, None, device, slots, user_bytes)
+
+    def encode(self, tensors, wire_user, slot, salt):
+        if not self._upload(tensors, slot, 8):
+            return False
+        mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
+        native.qsgd_compress_batched(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets,
+                                     self.n_bit, mode, (_next_seed() ^ salt) if self.random else 0, wire_user)
+        return True
 
     def decode_mean(self, gathered, R):
         out = torch.empty(self.out_floats, dtype=torch.float32, device=gathered.device)
-        native.hsq_decode_sum_batched(self._dev[:self.nseg * 8], self.tile_seg, self.nseg, self.ntiles, gathered,
-                                      self.codebook, self.n_bit, out, R)
+        native.qsgd_decode_sum_batched(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets,
+                                       self.n_bit, self.bits, gathered, out, R)
         return [out[o:o + cd.numel].view(cd.shape) for o, cd in zip(self.out_off, self.codecs)]
 
 
@@ -382,8 +474,13 @@ class PSQuantizer(object):
             off += self.codecs[i].nbytes
         self.dense_bytes = off - self.dense_off
         self.user_bytes = _up(off)          # one user's payload (all tensors)
-        self.batch_idx = [i for i, c in enumerate(self.codecs) if BatchedHSQ.eligible(c)]
-        self._batched = None                # built at the first record() on a HIP device
+        # tensors served by multi-tensor kernels: (class, parameter indices), built at the first record()
+        self._groups = []
+        for cls in (BatchedHSQ, BatchedQSGD):
+            idx = [i for i, c in enumerate(self.codecs) if cls.eligible(c)]
+            if len(idx) >= 2 and not getattr(args, "gq_no_batch", False):
+                self._groups.append([cls, idx, None])
+        self.batch_idx = [i for g in self._groups for i in g[1]]
         self.capacity = max(1, int(args.num_users))
         self.recorded = 0                   # record() calls since the last apply()
         self._wire = None
@@ -412,20 +509,21 @@ class PSQuantizer(object):
         world, rank = _dist_world(self.process_group)
         salt = ((rank * 1000003 + user) * 0x9E3779B1) & (2 ** 62 - 1)
         skip = set()
-        if dev.type == "cuda" and len(self.batch_idx) >= 2 and not getattr(self.args, "gq_no_batch", False):
-            if self._batched is None:
-                self._batched = BatchedHSQ(self.codecs, self.offsets, self.batch_idx, dev, self.capacity, self.user_bytes)
-            grads = [self.parameters[i].grad.data for i in self.batch_idx]
+        for grp in (self._groups if dev.type == "cuda" else []):
+            cls, idxs, obj = grp
+            if obj is None:
+                obj = grp[2] = cls(self.codecs, self.offsets, idxs, dev, self.capacity, self.user_bytes)
+            grads = [self.parameters[i].grad.data for i in idxs]
             if self.error_feedback:
                 # ps_quantizer.py:35: grad += scale*error -- the product is rounded before the add
-                errs = [self.parameters[i].error[user] for i in self.batch_idx]
+                errs = [self.parameters[i].error[user] for i in idxs]
                 torch._foreach_add_(grads, torch._foreach_mul(errs, scale))
-            if self._batched.encode(grads, wire, slot, salt):
-                skip.update(self.batch_idx)
+            if obj.encode(grads, wire, slot, salt):
+                skip.update(idxs)
                 if self.error_feedback:
                     # ps_quantizer.py:39: error = grad - decoded (decoded from this user's own wire slot)
-                    decoded = self._batched.decode_mean(wire.view(1, -1), 1)
-                    for i, e in zip(self.batch_idx, torch._foreach_sub(grads, decoded)):
+                    decoded = obj.decode_mean(wire.view(1, -1), 1)
+                    for i, e in zip(idxs, torch._foreach_sub(grads, decoded)):
                         self.parameters[i].error[user].data = e
             elif self.error_feedback:
                 torch._foreach_sub_(grads, torch._foreach_mul(errs, scale))   # undo; the per-tensor path redoes it
@@ -481,24 +579,23 @@ class PSQuantizer(object):
             gathered = local
         R = gathered.shape[0]
         done = {}
-        if self._batched is not None and self._batched.ready and gathered.device.type == "cuda":
-            gs = self._batched.decode_mean(gathered, R)
+        for cls, idxs, obj in (self._groups if gathered.device.type == "cuda" else []):
+            if obj is None or not obj.ready:
+                continue
+            gs = obj.decode_mean(gathered, R)
             if self.two_phase:
                 # ps_quantizer.py:52-61, replicated on every rank (salt 0, same call count)
                 if self.error_feedback:
-                    gs = torch._foreach_add(gs, [self.parameters[i].server_error for i in self.batch_idx])
-                dec = self._batched.roundtrip(list(gs), self.capacity, 0)
-                if dec is not None:
-                    if self.error_feedback:
-                        for i, e in zip(self.batch_idx, torch._foreach_sub(gs, dec)):
-                            self.parameters[i].server_error = e
-                    gs = dec
-                    for i, g in zip(self.batch_idx, gs):
-                        done[i] = g
-                # (dec is None: not batchable -> the per-tensor loop below handles these tensors)
-            else:
-                for i, g in zip(self.batch_idx, gs):
-                    done[i] = g
+                    gs = torch._foreach_add(gs, [self.parameters[i].server_error for i in idxs])
+                dec = obj.roundtrip(list(gs), self.capacity, 0)
+                if dec is None:
+                    continue     # not batchable: the per-tensor loop below handles these tensors
+                if self.error_feedback:
+                    for i, e in zip(idxs, torch._foreach_sub(gs, dec)):
+                        self.parameters[i].server_error = e
+                gs = dec
+            for i, g in zip(idxs, gs):
+                done[i] = g
         if len(self.dense_idx) >= 2:
             # identity tensors: two-phase / error feedback leave them unchanged (roundtrip == clone)
             rows = gathered[:, self.dense_off:self.dense_off + self.dense_bytes].view(torch.float32)

@@ -179,6 +179,23 @@ int gq_qsgd_compress(const float *grad, int64_t Mb, int d, int n_bit, int random
 int gq_qsgd_decode_sum(const float *norm, const uint8_t *signs, const void *levels, int level_bytes, int R, int64_t Mb,
                        int d, int n_bit, float *out, void *stream);
 
+/*
+ * QSGD on a packed wire, multi-tensor form (one launch for all tensors; same arithmetic as
+ * gq_qsgd_compress / gq_qsgd_decode_sum).  Per element one code = sign<<(bits-1) | level with
+ * bits = gq_qsgd_code_bits(n_bit, random_mode): 4 (two codes per byte, element 2i in the low nibble)
+ * when the top level is <= 7, 8 when it is <= 127, 0 = no packed format.  Buckets are numbered across
+ * tensors: bucket_seg int32[nbuckets]; seg_table int64[nseg][8] = { grad pointer (8-byte aligned),
+ * d (even, <= 65536), first bucket, byte offset of the f32 norms / of the codes inside ONE user's wire,
+ * float offset of the tensor in `out`, buckets, reserved }.  A zero bucket is written as level 0
+ * (the reference's NaN level also decodes to 0).
+ */
+int gq_qsgd_code_bits(int n_bit, int random_mode);
+int gq_qsgd_compress_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
+                             int n_bit, int random_mode, uint64_t seed, uint8_t *wire, void *stream);
+int gq_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
+                               int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                               float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

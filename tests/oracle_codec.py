@@ -33,22 +33,35 @@ class OracleHSQCodec(HSQCodec):
 
 
 class OracleQSGDCodec(QSGDCodec):
+    """Packed QSGD wire (norm | 4- or 8-bit codes = sign<<(bits-1) | level) filled by the oracle."""
+
     def encode_into(self, grad, wire_user, off, salt):
         c = self.c
-        assert not c.random
+        assert not c.random and self.bits in (4, 8)
         norm, signs, levels = oracle.qsgd_compress(grad.detach().cpu().numpy().reshape(-1), self.d, c.bit, 0)
-        n, s, l = self._views(wire_user, off)
-        n.copy_(torch.from_numpy(norm))
-        s.copy_(torch.from_numpy(signs))
         lv = levels.copy()
-        lv[lv < 0] = 0  # INT_MIN (zero bucket) -> 0 in the uint8 wire, as the HIP kernel does
-        l.copy_(torch.from_numpy(lv).to(self.level_dtype))
+        lv[lv < 0] = 0  # INT_MIN (zero bucket) -> level 0 on the wire, as the HIP kernel does
+        codes = (lv.astype(np.uint8) | (signs.astype(np.uint8) << (self.bits - 1))).astype(np.uint8)
+        if self.bits == 4:
+            codes = (codes[0::2] | (codes[1::2] << 4)).astype(np.uint8)
+        wire_user[off + self.norm_off:off + self.norm_off + self.Mb * 4].view(torch.float32).copy_(torch.from_numpy(norm))
+        wire_user[off + self.codes_off:off + self.codes_off + codes.size].copy_(torch.from_numpy(codes))
 
     def _decode_rows(self, gathered, off, R, out):
         decs = []
+        nb = self.numel * self.bits // 8
         for r in range(R):
-            n, s, l = self._views(gathered[r], off)
-            decs.append(oracle.qsgd_decompress(n.numpy(), s.numpy(), l.numpy().astype(np.int32), self.d, self.c.bit))
+            norm = gathered[r, off + self.norm_off:off + self.norm_off + self.Mb * 4].view(torch.float32).numpy()
+            raw = gathered[r, off + self.codes_off:off + self.codes_off + nb].numpy()
+            if self.bits == 4:
+                codes = np.empty(self.numel, np.uint8)
+                codes[0::2] = raw & 15
+                codes[1::2] = raw >> 4
+            else:
+                codes = raw
+            signs = codes >> (self.bits - 1)
+            levels = (codes & ((1 << (self.bits - 1)) - 1)).astype(np.int32)
+            decs.append(oracle.qsgd_decompress(norm, signs, levels, self.d, self.c.bit))
         out.copy_(torch.from_numpy(oracle.mean_users(np.stack(decs, 0))))
 
 

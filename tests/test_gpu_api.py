@@ -226,7 +226,7 @@ def test_batched_quantizer_equals_per_tensor_path():
     shapes = RESNET50_COMPRESSED + RESNET50_SMALL
     qb, gb = _run_quantizer(shapes, 3, 7)
     qp, gp = _run_quantizer(shapes, 3, 7, gq_no_batch=True)
-    assert qb._batched is not None and qb._batched.ready and qp._batched is None
+    assert qb._groups and qb._groups[0][2] is not None and qb._groups[0][2].ready and not qp._groups
     assert len(qb.batch_idx) == len(RESNET50_COMPRESSED)
     for a, b, s in zip(gb, gp, shapes):
         assert a.shape == torch.Size(s)
@@ -268,7 +268,7 @@ def test_batched_error_feedback_and_two_phase_equal_per_tensor_path(kw):
     shapes = RESNET50_COMPRESSED[:9] + RESNET50_SMALL[:4]
     qb, gb = _run_quantizer(shapes, 2, 21, **kw)
     qp, gp = _run_quantizer(shapes, 2, 21, gq_no_batch=True, **kw)
-    assert qb._batched is not None and qb._batched.ready
+    assert qb._groups and qb._groups[0][2].ready
     for a, b in zip(gb, gp):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     if kw.get("ef"):
@@ -277,3 +277,43 @@ def test_batched_error_feedback_and_two_phase_equal_per_tensor_path(kw):
                 assert torch.equal(eb, ep)
             if kw.get("two_phase"):
                 assert torch.equal(pb.server_error, pp.server_error)
+
+
+def _run_qsgd(shapes, users, seed, **argkw):
+    from gq_amd.compressors import QSGDCompressor
+    from gq_amd.quantizers import Quantizer
+    params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in shapes]
+    q = Quantizer(QSGDCompressor, params, make_args(num_users=users, c_dim=128, n_bit=2, **argkw))
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    for st in range(2):
+        for u in range(users):
+            for p in params:
+                p.grad = torch.randn(p.shape, device="cuda", generator=g) * 1e-2
+            q.record(u, epoch=1)
+        q.apply()
+    return q, [p.grad.data.clone() for p in params]
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(ef=True), dict(two_phase=True)])
+def test_batched_packed_qsgd_equals_per_tensor_and_reference_arithmetic(kw, oracle):
+    """QSGD on the packed 4-bit wire: batched launch == per-tensor path, and the single-user decode
+    equals the oracle's decompress(compress(g)) (the reference's arithmetic)."""
+    shapes = RESNET50_COMPRESSED[:10] + RESNET50_SMALL[:3]
+    qb, gb = _run_qsgd(shapes, 2, 5, **kw)
+    qp, gp = _run_qsgd(shapes, 2, 5, gq_no_batch=True, **kw)
+    assert qb._groups and qb._groups[0][0].__name__ == "BatchedQSGD" and qb._groups[0][2].ready
+    for a, b in zip(gb, gp):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert qb.codecs[0].bits == 4
+    # 0.5 B per element + one f32 per 128-element bucket
+    n = sum(p.numel() for p in qb.parameters if p.numel() > 1000)
+    assert qb.wire_bytes_per_user() < n * 0.56 + 4 * 4096
+    if not kw:
+        from gq_amd.compressors import QSGDCompressor
+        x = torch.randn(256, 128, device="cuda") * 3
+        x[5] = 0.0   # a zero bucket
+        codec = qb.codecs[0].__class__(QSGDCompressor(x.numel(), x.shape, make_args(c_dim=128, n_bit=2)), x.numel(), x.shape)
+        got = codec.roundtrip(x, 0).cpu().numpy()
+        norm, signs, levels = oracle.qsgd_compress(x.cpu().numpy(), 128, 2, 0)
+        want = oracle.qsgd_decompress(norm, signs, levels, 128, 2).reshape(256, 128)
+        assert np.array_equal(got, want)

@@ -42,4 +42,5 @@ def run(tag, comp, users=1, steps=20, **kw):
 run("HSQ batched (segment table)", NearestNeighborCompressor)
 run("HSQ per-tensor launches", NearestNeighborCompressor, gq_no_batch=True)
 run("HSQ batched, 8 simulated users", NearestNeighborCompressor, users=8, steps=5)
-run("QSGD d128 n2 per-tensor", QSGDCompressor, c_dim=128, n_bit=2)
+run("QSGD d128 n2 batched, packed wire", QSGDCompressor, c_dim=128, n_bit=2)
+run("QSGD d128 n2 per-tensor launches", QSGDCompressor, c_dim=128, n_bit=2, gq_no_batch=True)
