@@ -2,8 +2,8 @@
 (gradient-quantization_amd/) ahead of the reference tree on PYTHONPATH and
 `from compressors import *` in main.py resolves to the MI355X implementations."""
 from gq_amd.compressors import (IdenticalCompressor, QSGDCompressor, NearestNeighborCompressor,  # noqa: F401
-                                ProbabilisticScalarCompressor, SignSGDCompressor,
-                                TopKSparsificationCompressor)
+                                ProbabilisticScalarCompressor, ProbabilisticVectorCompressor,
+                                ResidualCompressor, SignSGDCompressor, TopKSparsificationCompressor)
 
 __all__ = ["IdenticalCompressor", "QSGDCompressor", "NearestNeighborCompressor", "ProbabilisticScalarCompressor",
-           "SignSGDCompressor", "TopKSparsificationCompressor"]
+           "ProbabilisticVectorCompressor", "ResidualCompressor", "SignSGDCompressor", "TopKSparsificationCompressor"]

@@ -279,6 +279,108 @@ class QSGDCompressor(object):
         return self.decompress(self.compress(vec))
 
 
+class ProbabilisticVectorCompressor(object):
+    """Unbiased vector quantiser (probabilistic_vector_compressor.py:8-77), INTENDED semantics:
+    sample the codeword with probability |p_k| / ||p||_1, p = pinv(C^T) v, magnitude sign(p_k)*||p||_1,
+    so that E[decode] = v.  The reference's own class cannot run: it opens
+    ./codebook/... (the tree has ./codebooks/learned_codebook/..., which is what is used here) and
+    takes argmin of a bool tensor; its inverse-CDF intent -- first index whose cumulative
+    probability reaches r - 1e-5 -- is what gq_pvq_encode implements."""
+
+    def __init__(self, size, shape, args):
+        c_dim, k_bit, n_bit = args.c_dim, args.k_bit, args.n_bit
+        assert c_dim > 0
+        assert k_bit > 0
+        assert n_bit > 0
+        self.cuda = not args.no_cuda
+        self.size, self.shape = size, shape
+        self.dim = c_dim if c_dim < size else size
+        assert size % self.dim == 0, "not divisible size {} dim {}".format(size, self.dim)
+        self.K = 2 ** k_bit
+        if self.K == self.dim:
+            from scipy import stats
+            codewords = stats.ortho_group.rvs(self.dim).astype(np.float32)
+        else:
+            codewords = load_codebook(self.dim, self.K)
+        self.codewords = torch.from_numpy(np.ascontiguousarray(codewords))
+        self.c_dagger = torch.from_numpy(np.ascontiguousarray(np.linalg.pinv(codewords.T).astype(np.float32)))
+        self.code_dtype = torch.uint8 if k_bit <= 8 else torch.int32
+        self.n_bit = n_bit
+        self.compressed_norm = n_bit != 32
+        if self.compressed_norm:
+            self.norm_compressor = ProbabilisticScalarCompressor(n_bit, args)
+        self.M = size // self.dim
+        self._rng = _rng_mode(args)
+
+    def _on(self, device):
+        if self.codewords.device != device:
+            self.codewords = self.codewords.to(device)
+            self.c_dagger = self.c_dagger.to(device)
+        return self.codewords, self.c_dagger
+
+    def compress(self, vec):
+        _require_device(vec, "ProbabilisticVectorCompressor.compress")
+        dev = vec.device
+        flat = vec.contiguous().view(-1)
+        _, cdag = self._on(dev)
+        codes = torch.empty(self.M, dtype=self.code_dtype, device=dev)
+        u = torch.empty(self.M, dtype=torch.float32, device=dev)
+        ws = native.new_workspace(dev, 0)
+        if self._rng == "reference":
+            r = torch.rand(self.M)       # CPU generator, as :52
+            native.pvq_encode(flat, cdag, codes, u, ws, native.RANDOM_GIVEN, r.to(dev), 0)
+        else:
+            native.pvq_encode(flat, cdag, codes, u, ws, native.RANDOM_DEVICE, None, _next_seed())
+        if not self.compressed_norm:
+            return [u, codes]
+        lb_ub = torch.empty(2, dtype=torch.float32, device=dev)
+        levels = torch.empty(self.M, dtype=torch.int32, device=dev)
+        self.norm_compressor._levels_from_partials(u, ws, levels, lb_ub)
+        return [(lb_ub[0], lb_ub[1], levels), codes]
+
+    def decompress(self, signature):
+        norms, codes = signature
+        _require_device(codes, "ProbabilisticVectorCompressor.decompress")
+        dev = codes.device
+        cb, _ = self._on(dev)
+        codes = codes.contiguous().view(-1)
+        if codes.dtype not in (torch.uint8, torch.int32):
+            codes = codes.to(torch.int32)
+        out = torch.empty(self.size, dtype=torch.float32, device=dev)
+        if self.compressed_norm:
+            lb, ub, levels = norms
+            lb_ub = torch.stack([lb.reshape(()), ub.reshape(())]).to(device=dev, dtype=torch.float32)
+            native.hsq_decode_sum(codes, levels.contiguous().view(-1), lb_ub, cb, self.n_bit, out, R=1)
+        else:
+            native.hsq_decode_sum(codes, norms.contiguous().view(-1).float(), None, cb, 32, out, R=1)
+        return out.view(self.shape)
+
+
+class ResidualCompressor(object):
+    """Two stages (residual_compressor.py:7-32): NearestNeighbor on the gradient, then the
+    probabilistic vector compressor on what is left; decode = sum of the stage decodes."""
+
+    def __init__(self, size, shape, args):
+        self.compressors = [
+            NearestNeighborCompressor(size, shape, args),
+            ProbabilisticVectorCompressor(size, shape, args),
+        ]
+
+    def compress(self, vec):
+        residuals = vec.clone()
+        signatures = []
+        for compressor in self.compressors:
+            signature = compressor.compress(residuals)
+            decompressed = compressor.decompress(signature)
+            residuals -= decompressed
+            signatures.append(signature)
+        return signatures
+
+    def decompress(self, signatures):
+        decoded = [c.decompress(s) for s, c in zip(signatures, self.compressors)]
+        return torch.stack(decoded, dim=0).sum(dim=0)
+
+
 # ---- exported for `from compressors import *` in the reference's main.py ----------------
 # Not on the accelerated path (SURVEY.md section 2, rows 13): plain tensor ops, kept only so
 # that main.py's `quantizer_choices` table resolves.
@@ -318,4 +420,4 @@ class TopKSparsificationCompressor(object):
 
 
 __all__ = ["IdenticalCompressor", "QSGDCompressor", "NearestNeighborCompressor", "ProbabilisticScalarCompressor",
-           "SignSGDCompressor", "TopKSparsificationCompressor"]
+           "ProbabilisticVectorCompressor", "ResidualCompressor", "SignSGDCompressor", "TopKSparsificationCompressor"]

@@ -21,7 +21,7 @@ ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFI
 EXPORTS = [
     "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_workspace_bytes", "gq_hsq_encode", "gq_hsq_encode_impl", "gq_hsq_levels",
     "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched",
-    "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
+    "gq_pvq_encode", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
 
@@ -206,6 +206,19 @@ def hsq_decode_sum_batched(seg_table, tile_seg, nseg, ntiles, gathered, codebook
                                          _dev_ptr(codebook, torch.float32, "codebook"), ctypes.c_int(n_bit),
                                          _dev_ptr(out, torch.float32, "out"), _stream())
     _check(rc, "gq_hsq_decode_sum_batched")
+
+
+def pvq_encode(grad, c_dagger, codes, u, workspace, random_mode, r, seed):
+    K, d = c_dagger.shape
+    M = grad.numel() // d
+    assert grad.numel() == M * d and codes.numel() == M and u.numel() == M
+    rp = _dev_ptr(r, torch.float32, "r") if r is not None else ctypes.c_void_p(0)
+    rc = lib().gq_pvq_encode(_dev_ptr(grad, torch.float32, "grad"), _dev_ptr(c_dagger, torch.float32, "c_dagger"),
+                             ctypes.c_int64(M), ctypes.c_int(d), ctypes.c_int(K), ctypes.c_int(random_mode), rp,
+                             ctypes.c_uint64(seed & (2 ** 64 - 1)), _dev_ptr(codes, None, "codes"),
+                             ctypes.c_int(_CODE_BYTES[codes.dtype]), _dev_ptr(u, torch.float32, "u"),
+                             _dev_ptr(workspace, torch.float32, "workspace"), _stream())
+    _check(rc, "gq_pvq_encode")
 
 
 def qsgd_code_bits(n_bit, random_mode):

@@ -180,6 +180,19 @@ int gq_qsgd_decode_sum(const float *norm, const uint8_t *signs, const void *leve
                        int d, int n_bit, float *out, void *stream);
 
 /*
+ * ProbabilisticVectorCompressor encode -- the INTENDED semantics of
+ * probabilistic_vector_compressor.py:42-63 (the reference's own code cannot run):
+ *     p = c_dagger . v   (c_dagger = pinv(codewords^T), [K,d]) ;  l1 = sum_k |p_k|
+ *     code = first k with cumsum_k(|p|/l1) >= r - 1e-5 ;  u = sign(p_code) * l1
+ * r: one uniform draw per subvector (GQ_RANDOM_GIVEN: caller-supplied r[M]; GQ_RANDOM_DEVICE: in-kernel).
+ * Outputs codes[M], u[M] and the (min,max) partials of u in `workspace` (gq_hsq_workspace_bytes(0)
+ * bytes suffice) so that gq_hsq_levels / gq_hsq_decode_sum finish the compress / decompress
+ * exactly as for the NearestNeighbor compressor.  d in {4,8,12,16,24,32,64}.
+ */
+int gq_pvq_encode(const float *grad, const float *c_dagger, int64_t M, int d, int K, int random_mode, const float *r,
+                  uint64_t seed, void *codes, int code_bytes, float *u, float *workspace, void *stream);
+
+/*
  * QSGD on a packed wire, multi-tensor form (one launch for all tensors; same arithmetic as
  * gq_qsgd_compress / gq_qsgd_decode_sum).  Per element one code = sign<<(bits-1) | level with
  * bits = gq_qsgd_code_bits(n_bit, random_mode): 4 (two codes per byte, element 2i in the low nibble)

@@ -234,3 +234,42 @@ GQ_EXPORT void gq_oracle_qsgd_decompress(const float *norm, const uint8_t *signs
         }
     }
 }
+
+/*
+ * ProbabilisticVectorCompressor encode -- INTENDED semantics of
+ * compressors/probabilistic_vector_compressor.py:42-63.  PARITY UNPINNED: the reference's own
+ * implementation cannot run in this environment (it opens ./codebook/..., which does not exist, and
+ * calls torch.argmin on a bool tensor), so there are no golden vectors; the tests pin
+ * self-consistency (unbiasedness, inverse-CDF property) instead.
+ *   p = c_dagger . v (:47); l1 = sum|p| (:48); code = first k with cumsum(|p|/l1) >= r - 1e-5 (:52-58);
+ *   u = sign(p_code) * l1 (:60-61)
+ */
+GQ_EXPORT void gq_oracle_pvq_encode(const float *grad, const float *cdag, int64_t M, int d, int K, const float *r,
+                                    int32_t *codes, float *u) {
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        const float *v = grad + m * (int64_t)d;
+        float l1 = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            float acc = 0.0f;
+            for (int j = 0; j < d; ++j) acc = fmaf(cdag[(int64_t)k * d + j], v[j], acc);
+            l1 = l1 + fabsf(acc);
+        }
+        const float thr = r[m] - 1e-5f;
+        float cum = 0.0f, sel = 0.0f;
+        int code = K - 1, found = 0;
+        for (int k = 0; k < K; ++k) {
+            float acc = 0.0f;
+            for (int j = 0; j < d; ++j) acc = fmaf(cdag[(int64_t)k * d + j], v[j], acc);
+            cum = cum + fabsf(acc) / l1;
+            int hit = !found && (cum >= thr);
+            if (hit || (!found && k == K - 1)) {
+                code = k;
+                sel = acc;
+            }
+            found = found || hit;
+        }
+        codes[m] = code;
+        u[m] = (sel > 0.0f ? 1.0f : (sel < 0.0f ? -1.0f : 0.0f)) * l1;
+    }
+}

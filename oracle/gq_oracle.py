@@ -169,3 +169,18 @@ def qsgd_decompress(norm, signs, levels, d, n_bit):
                                     ctypes.c_int64(norm.size), ctypes.c_int(d), ctypes.c_int(n_bit),
                                     _p(out, _f32p))
     return out
+
+
+def pvq_encode(grad, c_dagger, r):
+    """ProbabilisticVectorCompressor encode (intended semantics; parity unpinned) -> (codes, u)."""
+    cd = _f32(c_dagger)
+    K, d = cd.shape
+    g = _f32(grad).reshape(-1)
+    M = g.size // d
+    r = _f32(r).reshape(-1)
+    assert r.size == M
+    codes = np.empty(M, np.int32)
+    u = np.empty(M, np.float32)
+    lib().gq_oracle_pvq_encode(_p(g, _f32p), _p(cd, _f32p), ctypes.c_int64(M), ctypes.c_int(d), ctypes.c_int(K),
+                               _p(r, _f32p), _p(codes, _i32p), _p(u, _f32p))
+    return codes, u

@@ -317,3 +317,61 @@ def test_batched_packed_qsgd_equals_per_tensor_and_reference_arithmetic(kw, orac
         norm, signs, levels = oracle.qsgd_compress(x.cpu().numpy(), 128, 2, 0)
         want = oracle.qsgd_decompress(norm, signs, levels, 128, 2).reshape(256, 128)
         assert np.array_equal(got, want)
+
+
+def test_probabilistic_vector_compressor_matches_oracle_and_is_unbiased(oracle):
+    """a12 (intended semantics, parity unpinned vs the reference -- its class cannot run):
+    GPU == CPU restatement bit for bit for the same draws r; the decode is unbiased."""
+    from gq_amd.compressors import ProbabilisticVectorCompressor
+    rng = np.random.RandomState(4)
+    M = 20000
+    x = rng.standard_normal(16 * M).astype(np.float32)
+    args = make_args(n_bit=32, gq_rng="reference")
+    comp = ProbabilisticVectorCompressor(x.size, torch.Size([x.size]), args)
+    assert comp.c_dagger.shape == (256, 16)
+    torch.manual_seed(123)
+    r = torch.rand(M).numpy()
+    torch.manual_seed(123)
+    u, codes = comp.compress(torch.from_numpy(x).cuda())
+    rc, ru = oracle.pvq_encode(x, comp.c_dagger.cpu().numpy(), r)
+    assert np.array_equal(codes.cpu().numpy().astype(np.int32), rc)
+    assert np.array_equal(_bits(u.cpu().numpy()), _bits(ru))
+    dec = comp.decompress([u, codes])
+    assert np.array_equal(dec.cpu().numpy().reshape(-1, 16),
+                          comp.codewords.cpu().numpy()[rc] * ru[:, None])
+    # unbiasedness with the in-kernel generator: mean decode of one repeated subvector -> that subvector
+    v = rng.standard_normal(16).astype(np.float32)
+    rep = 100000
+    c2 = ProbabilisticVectorCompressor(16 * rep, torch.Size([16 * rep]), make_args(n_bit=32))
+    out = c2.decompress(c2.compress(torch.from_numpy(np.tile(v, rep)).cuda())).view(rep, 16).double().mean(0).cpu().numpy()
+    assert np.linalg.norm(out - v) / np.linalg.norm(v) < 3e-2
+    # quantised norms (n_bit=6) go through the same level quantiser as HSQ
+    c3 = ProbabilisticVectorCompressor(x.size, torch.Size([M, 16]), make_args(n_bit=6, random=0))
+    sig = c3.compress(torch.from_numpy(x).cuda().view(M, 16))
+    (lb, ub, l), cds = sig
+    assert l.dtype == torch.int32 and int(l.max()) == 63 and c3.decompress(sig).shape == (M, 16)
+    # K == dim: random orthogonal codebook, c_dagger == codewords
+    c4 = ProbabilisticVectorCompressor(16 * 100, torch.Size([1600]), make_args(k_bit=4, n_bit=32))
+    assert torch.allclose(c4.c_dagger, c4.codewords, atol=1e-5)
+
+
+def test_residual_compressor_two_stages():
+    """a11: stage 1 (nearest neighbour) + stage 2 (probabilistic vector) on the residual."""
+    from gq_amd.compressors import ResidualCompressor, NearestNeighborCompressor
+    x = torch.randn(4096, 16, device="cuda")
+    args = make_args(n_bit=32)
+    rc = ResidualCompressor(x.numel(), x.shape, args)
+    sigs = rc.compress(x)
+    assert len(sigs) == 2
+    dec = rc.decompress(sigs)
+    s1 = rc.compressors[0].decompress(sigs[0])
+    assert torch.equal(s1, NearestNeighborCompressor(x.numel(), x.shape, args).decompress(
+        NearestNeighborCompressor(x.numel(), x.shape, args).compress(x)))
+    # stage 1 removes energy; the two-stage decode is the sum of the stage decodes
+    assert (x - s1).norm() < x.norm()
+    assert torch.allclose(dec, s1 + rc.compressors[1].decompress(sigs[1]))
+    # averaged over draws the second stage is unbiased on the residual, so the mean error shrinks
+    acc = torch.zeros_like(x)
+    for _ in range(40):
+        acc += rc.decompress(rc.compress(x))
+    assert (acc / 40 - x).norm() < 0.5 * (x - s1).norm()

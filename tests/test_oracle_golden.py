@@ -162,3 +162,32 @@ def test_mean_users_is_bit_exact_with_reference(oracle):
                 decs.append(oracle.hsq_decompress(c["codes"], c["levels"], c["lb"], c["ub"], cb, 6).reshape(x.shape))
         agg = oracle.mean_users(np.stack(decs, 0)).reshape(decs[0].shape)
         assert np.array_equal(_bits(agg), _bits(g["agg_s0_p%d" % i]))
+
+
+def test_pvq_oracle_is_an_unbiased_inverse_cdf_sampler(oracle):
+    """ProbabilisticVectorCompressor has NO reference fixtures (the reference's class cannot run,
+    SURVEY 8c: parity unpinned).  The restatement is pinned by its defining properties instead:
+    the chosen code is the inverse-CDF sample of |p|/||p||_1, u = sign(p_code)*||p||_1, and
+    E_r[decode] = v for a full-rank codebook."""
+    rng = np.random.RandomState(3)
+    cb = _cb(16, 256)
+    cdag = np.linalg.pinv(cb.T).astype(np.float32)
+    v = rng.standard_normal(16).astype(np.float32)
+    p = cdag.astype(np.float64) @ v.astype(np.float64)
+    prob = np.abs(p) / np.abs(p).sum()
+    draws = 200000
+    r = rng.random_sample(draws).astype(np.float32)
+    codes, u = oracle.pvq_encode(np.tile(v, draws), cdag, r)
+    # inverse CDF: code == first k with cumsum >= r - 1e-5 (float64 check away from bucket edges)
+    cum = np.cumsum(prob)
+    want = np.searchsorted(cum, r.astype(np.float64) - 1e-5, side="left").clip(0, 255)
+    edge = np.abs(cum[want] - (r - 1e-5)) < 1e-5
+    edge |= np.abs(np.concatenate([[0.0], cum])[want] - (r - 1e-5)) < 1e-5
+    assert np.array_equal(codes[~edge], want[~edge])
+    assert np.allclose(np.abs(u), np.abs(p).sum(), rtol=1e-5)
+    assert np.array_equal(np.sign(u), np.sign(p[codes]))
+    # unbiased: mean over draws of codeword*u == v
+    mean = (cb[codes].astype(np.float64) * u[:, None].astype(np.float64)).mean(0)
+    assert np.linalg.norm(mean - v) / np.linalg.norm(v) < 2e-2
+    freq = np.bincount(codes, minlength=256) / draws
+    assert np.abs(freq - prob).max() < 5e-3
