@@ -1,0 +1,226 @@
+"""Training driver: the counterpart of the reference's main.py loop (main.py:79-233) for boxes
+without torchvision / TensorFlow / network access.
+
+Same flag names and defaults as main.py:83-122, same iteration order as one_iter (main.py:216-233):
+    for user in range(num_users): zero_grad -> forward -> backward -> quantizer.record(user, epoch)
+    quantizer.apply() -> optimizer.step()
+and the same user split of each batch (main.py:189-193).  Differences, all host-side plumbing:
+  * data: a synthetic, learnable classification set with the named dataset's shapes
+    (`--dataset mnist|cifar10`), labels from a fixed random teacher -- no downloads;
+  * models: `fcn` (784-256-10, models/fcn.py:12-13) and a CIFAR bottleneck `resnet50` with the
+    reference's parameter-shape list (tests/golden/resnet50_cifar_shapes.json), plain torch.nn;
+  * logging: one JSON object per log point on stdout / --logfile instead of TF1 summaries;
+  * real data parallelism: launched under torch.distributed.run every rank is one (or
+    --num-users) of the reference's users; the quantizer all-gathers the wire once per step.
+The quantization itself is the HIP path (gq_amd.compressors / gq_amd.quantizers): no CPU fallback.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.optim as optim
+
+from .compressors import (IdenticalCompressor, NearestNeighborCompressor, QSGDCompressor, SignSGDCompressor,
+                          TopKSparsificationCompressor)
+from .quantizers import Quantizer
+
+quantizer_choices = {          # main.py:20-26
+    'sgd': IdenticalCompressor,
+    'qsgd': QSGDCompressor,
+    'hsq': NearestNeighborCompressor,
+    'sign': SignSGDCompressor,
+    'topk': TopKSparsificationCompressor,
+}
+
+
+class FCN(nn.Module):
+    """784-256-10 (models/fcn.py)."""
+
+    def __init__(self, num_classes=10):
+        super().__init__()
+        self.fc1 = nn.Linear(784, 256)
+        self.fc2 = nn.Linear(256, num_classes)
+
+    def forward(self, x):
+        return self.fc2(F.relu(self.fc1(x.view(x.shape[0], -1))))
+
+
+class _Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, in_planes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, self.expansion * planes, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(self.expansion * planes)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_planes != self.expansion * planes:
+            self.shortcut = nn.Sequential(nn.Conv2d(in_planes, self.expansion * planes, 1, stride=stride, bias=False),
+                                          nn.BatchNorm2d(self.expansion * planes))
+
+    def forward(self, x):
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = F.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return F.relu(out + self.shortcut(x))
+
+
+class ResNet50(nn.Module):
+    """CIFAR-style ResNet-50: 3x3 stem, stages [3,4,6,3] of bottleneck blocks, 23.5 M parameters."""
+
+    def __init__(self, num_classes=10):
+        super().__init__()
+        self.in_planes = 64
+        self.conv1 = nn.Conv2d(3, 64, 3, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.layer1 = self._stage(64, 3, 1)
+        self.layer2 = self._stage(128, 4, 2)
+        self.layer3 = self._stage(256, 6, 2)
+        self.layer4 = self._stage(512, 3, 2)
+        self.linear = nn.Linear(512 * _Bottleneck.expansion, num_classes)
+
+    def _stage(self, planes, blocks, stride):
+        layers = []
+        for s in [stride] + [1] * (blocks - 1):
+            layers.append(_Bottleneck(self.in_planes, planes, s))
+            self.in_planes = planes * _Bottleneck.expansion
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = self.layer4(self.layer3(self.layer2(self.layer1(out))))
+        out = F.adaptive_avg_pool2d(out, 1).flatten(1)
+        return self.linear(out)
+
+
+network_choices = {'fcn': FCN, 'resnet50': ResNet50}
+dataset_shapes = {'mnist': (1, 28, 28), 'cifar10': (3, 32, 32)}
+
+
+class SyntheticClassification(object):
+    """Fixed random inputs with labels from a random linear teacher: learnable, no files."""
+
+    def __init__(self, dataset, n, num_classes, device, seed):
+        g = torch.Generator().manual_seed(seed)
+        shape = dataset_shapes[dataset]
+        self.x = torch.randn((n,) + shape, generator=g)
+        teacher = torch.randn(self.x[0].numel(), num_classes, generator=g)
+        self.y = (self.x.view(n, -1) @ teacher).argmax(1)
+        self.x, self.y = self.x.to(device), self.y.to(device)
+        self.n = n
+
+    def batches(self, batch, epoch_seed, rank=0, world=1):
+        g = torch.Generator().manual_seed(epoch_seed)
+        perm = torch.randperm(self.n, generator=g).to(self.x.device)
+        per = batch * world
+        for i in range(0, self.n - per + 1, per):
+            idx = perm[i + rank * batch:i + (rank + 1) * batch]
+            yield self.x[idx], self.y[idx]
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description='Gradient quantization on MI355X (driver)')
+    p.add_argument('--network', type=str, default='fcn', choices=sorted(network_choices))
+    p.add_argument('--dataset', type=str, default='mnist', choices=sorted(dataset_shapes))
+    p.add_argument('--quantizer', type=str, default='hsq', choices=sorted(quantizer_choices))
+    p.add_argument('--mode', type=str, default='ps', choices=['ps', 'ring'])
+    p.add_argument('--scale', type=str, default="exp")
+    p.add_argument('--c-dim', type=int, default=32)
+    p.add_argument('--k-bit', type=int, default=8)
+    p.add_argument('--n-bit', type=int, default=8)
+    p.add_argument('--cr', type=int, default=256)
+    p.add_argument('--random', type=int, default=True)
+    p.add_argument('--num-users', type=int, default=8)
+    p.add_argument('--batch-size', type=int, default=32)
+    p.add_argument('--epochs', type=int, default=2)
+    p.add_argument('--momentum', type=float, default=0.9)
+    p.add_argument('--weight-decay', type=float, default=5e-4)
+    p.add_argument('--lr', type=float, default=0.1)
+    p.add_argument('--no-cuda', action='store_true', default=False)
+    p.add_argument('--ef', action='store_true', default=False)
+    p.add_argument('--two-phase', action='store_true', default=False)
+    p.add_argument('--seed', type=int, default=1)
+    p.add_argument('--train-size', type=int, default=4096, help='synthetic samples per epoch')
+    p.add_argument('--log-interval', type=int, default=8, help='iterations between JSON log lines')
+    p.add_argument('--logfile', type=str, default=None)
+    p.add_argument('--gq-rng', type=str, default=None, choices=[None, 'device', 'reference'])
+    return p
+
+
+def one_iter(model, loss_func, optimizer, quantizer, train_data, epoch):
+    """main.py:216-233."""
+    model.train()
+    losses = []
+    for user_id, (data, target) in enumerate(train_data):
+        optimizer.zero_grad()
+        loss = loss_func(model(data), target)
+        losses.append(loss.detach())
+        loss.backward()
+        quantizer.record(user_id, epoch=epoch)
+    quantizer.apply()
+    optimizer.step()
+    return torch.stack(losses).mean()
+
+
+def train(args, log=None):
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if args.no_cuda or not torch.cuda.is_available():
+        raise RuntimeError("gq_amd runs on MI355X only: there is no CPU path (drop --no-cuda)")
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.manual_seed(args.seed)
+    num_classes = 10
+    model = network_choices[args.network](num_classes=num_classes).to(device)
+    quantizer = Quantizer(quantizer_choices[args.quantizer], model.parameters(), args)
+    optimizer = optim.SGD(model.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+    loss_func = nn.CrossEntropyLoss()
+    data = SyntheticClassification(args.dataset, args.train_size, num_classes, device, args.seed)
+    out = open(args.logfile, "a") if (args.logfile and rank == 0) else None
+    history = []
+    it = 0
+    for epoch in range(1, args.epochs + 1):
+        # the loader yields num_users*batch_size samples per rank; split across users as main.py:189-193
+        for x, y in data.batches(args.batch_size * args.num_users, 1000 * args.seed + epoch, rank, world):
+            ub = x.shape[0] // args.num_users
+            users = [(x[u * ub:(u + 1) * ub], y[u * ub:(u + 1) * ub]) for u in range(args.num_users - 1)]
+            users.append((x[(args.num_users - 1) * ub:], y[(args.num_users - 1) * ub:]))
+            t0 = time.perf_counter()
+            loss = one_iter(model, loss_func, optimizer, quantizer, users, epoch)
+            it += 1
+            if it % args.log_interval == 0 or it == 1:
+                rec = {"iter": it, "epoch": epoch, "loss": float(loss), "ms_per_iter": (time.perf_counter() - t0) * 1e3,
+                       "ranks": world, "users_per_rank": args.num_users}
+                history.append(rec)
+                if rank == 0:
+                    line = json.dumps(rec)
+                    print(line)
+                    if out:
+                        out.write(line + "\n")
+                if log is not None:
+                    log.append(rec)
+    if out:
+        out.close()
+    return model, quantizer, history
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    train(args)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
