@@ -264,3 +264,40 @@ def test_psquantizer_two_ranks_gloo(tmp_path, oracle):
     single = w.run_single_process(4)
     for k in single:
         assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
+
+
+def test_run_reference_launcher_shadows_the_reference_packages(tmp_path):
+    """the launcher puts this implementation's `compressors` / `quantizers`
+    ahead of the ones that sit next to the reference's main.py, keeps the script's other local
+    imports working, and the codebook is found relative to the cwd like in the reference."""
+    ref = tmp_path / "ref"
+    for pkg in ("compressors", "quantizers"):
+        (ref / pkg).mkdir(parents=True)
+        (ref / pkg / "__init__.py").write_text("raise ImportError('the checkout\'s own package was imported')\n")
+    (ref / "helpers.py").write_text("VALUE = 42\n")
+    cbdir = ref / "codebooks" / "learned_codebook"
+    cbdir.mkdir(parents=True)
+    import shutil
+    shutil.copy(os.path.join(GOLDEN, "codebooks", "learned_codebook", "angular_dim_32_Ks_256.fvecs"), cbdir)
+    (ref / "main.py").write_text(
+        "import argparse\n"
+        "from compressors import *\n"
+        "from quantizers import *\n"
+        "import compressors, quantizers, helpers, torch\n"
+        "from argparse import Namespace\n"
+        "assert 'gradient-quantization_amd' in compressors.__file__ and 'gradient-quantization_amd' in quantizers.__file__\n"
+        "table = {'sgd': IdenticalCompressor, 'qsgd': QSGDCompressor, 'hsq': NearestNeighborCompressor,\n"
+        "         'sign': SignSGDCompressor, 'topk': TopKSparsificationCompressor}\n"
+        "p = argparse.ArgumentParser(); p.add_argument('--quantizer', default='hsq'); a0 = p.parse_args()\n"
+        "a = Namespace(c_dim=32, k_bit=8, n_bit=8, no_cuda=False, random=True, ef=False, two_phase=False,\n"
+        "              scale='exp', num_users=8, mode='ps', cr=256)\n"
+        "ps = [torch.nn.Parameter(torch.zeros(64, 64)), torch.nn.Parameter(torch.zeros(64))]\n"
+        "q = Quantizer(table[a0.quantizer], ps, a)\n"
+        "assert q.compressors[0].codewords.shape == (256, 32) and helpers.VALUE == 42 and __name__ == '__main__'\n"
+        "print('ok')\n")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    env.pop("GQ_CODEBOOK_DIR", None)
+    env.pop("PYTHONPATH", None)
+    out = subprocess.run([sys.executable, "-B", os.path.join(PKG, "run_reference.py"), "main.py", "--quantizer", "hsq"],
+                         cwd=str(ref), env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
