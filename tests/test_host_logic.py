@@ -301,3 +301,23 @@ def test_run_reference_launcher_shadows_the_reference_packages(tmp_path):
     out = subprocess.run([sys.executable, "-B", os.path.join(PKG, "run_reference.py"), "main.py", "--quantizer", "hsq"],
                          cwd=str(ref), env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/codebooks"), reason="reference checkout not present")
+def test_codebooks_are_found_in_a_reference_checkout_cwd(tmp_path):
+    """Run from the reference checkout (build container only): `./codebooks/learned_codebook/...`
+    relative to the cwd is what gets opened, as in nearest_neighbor_compressor.py:50-51."""
+    script = tmp_path / "probe.py"
+    script.write_text(
+        "from compressors import *\n"
+        "import torch, gq_amd.codebook as cbk\n"
+        "from argparse import Namespace\n"
+        "a = Namespace(c_dim=40, k_bit=10, n_bit=8, no_cuda=False, random=True)\n"
+        "c = NearestNeighborCompressor(40 * 50, torch.Size([50, 40]), a)\n"     # d=40, K=1024: only in the reference tree
+        "assert c.codewords.shape == (1024, 40) and cbk.codebook_path(40, 1024).startswith('./codebooks')\n"
+        "print('ok')\n")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    env.pop("GQ_CODEBOOK_DIR", None)
+    out = subprocess.run([sys.executable, "-B", os.path.join(PKG, "run_reference.py"), str(script)],
+                         cwd="/root/reference", env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
