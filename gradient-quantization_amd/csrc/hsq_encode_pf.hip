@@ -138,6 +138,7 @@ struct PfArgs {
     uint8_t *wire;            // batched
     unsigned *seg_minmax;     // batched: order-mapped (min, max) per segment
     int64_t ntiles;
+    int64_t split_tile;       // >= 0: first half of the grid shares tiles [0, split_tile), second half the rest
 };
 
 // order-preserving float -> uint32 map for integer atomic min/max
@@ -195,8 +196,23 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     const float err_scale = c1 * ERR_SCALE;  // E = max|v_j| * err_scale
 
     const int64_t ntiles = BATCHED ? a.ntiles : ((M + 63) >> 6);
-    const int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
+    // Static split of the tiles.  With two workgroups per CU the one dispatched first wins VALU
+    // arbitration on its SIMDs and runs ~1.55x faster than its partner, which then finishes the tail
+    // alone (tools/stamp_read.py: first half of the grid done after 37 us, second half after 50 us with
+    // an even split).  The launcher therefore gives the first half 63 % of the tiles (swept: 55..66 %).  A speed
+    // heuristic only: any dispatch order produces the same output.
+    int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
     int64_t t = (int64_t)blockIdx.x * ENC_WAVES + wave;
+    int64_t tile_end = ntiles;
+    if (a.split_tile >= 0) {
+        const int64_t half = gridDim.x / 2;
+        nw = half * ENC_WAVES;
+        if ((int64_t)blockIdx.x < half) {
+            tile_end = a.split_tile;
+        } else {
+            t = a.split_tile + ((int64_t)blockIdx.x - half) * ENC_WAVES + wave;
+        }
+    }
     int *const counter = ws_counter(ws);
     int *const worklist = ws_worklist(ws);
 
@@ -252,16 +268,16 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     // B fragments: lane (col j, half h) holds v[8h .. 8h+7] of subvector j of each block
     bf16x8 vh[2], vl[2];
     Tile ti = {};
-    if (t < ntiles) {
+    if (t < tile_end) {
         ti = tile_info(t);
         load_tile(ti, cur);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) split8(cur[2 * blk], cur[2 * blk + 1], vh[blk], vl[blk]);
     }
-    for (; t < ntiles; t += nw) {
+    for (; t < tile_end; t += nw) {
         const int64_t tn = t + nw;
         Tile tin = ti;
-        if (tn < ntiles) {
+        if (tn < tile_end) {
             tin = tile_info(tn);
             load_tile(tin, nxt);  // prefetch the next tile
         }
@@ -587,6 +603,16 @@ __global__ __launch_bounds__(256) void hsq_encode_finish_kernel(const PfArgs a) 
     }
 }
 
+// tiles for the first half of the grid (PfArgs::split_tile), or -1 for an even split
+static int64_t pf_split(int64_t ntiles, int64_t blocks, int bpc) {
+    static const int permille = [] {
+        const char *e = getenv("GQ_PF_SPLIT");
+        return e ? atoi(e) : 630;
+    }();
+    if (permille <= 0 || bpc != 2 || blocks != (int64_t)cu_count() * 2 || ntiles < blocks * ENC_WAVES * 4) return -1;
+    return (ntiles * permille) / 1000;
+}
+
 static int64_t pf_grid(int64_t ntiles, int bpc) {
     int64_t blocks = (ntiles + ENC_WAVES - 1) / ENC_WAVES;
     int64_t cap = (int64_t)cu_count() * bpc;
@@ -607,8 +633,10 @@ int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT 
     a.u = u;
     a.cb = codebook;
     a.ws = ws;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, false>), dim3((unsigned)pf_grid((M + 63) / 64, bpc)),
-                       dim3(ENC_THREADS), 0, st, a);
+    const int64_t blocks = pf_grid((M + 63) / 64, bpc);
+    a.split_tile = pf_split((M + 63) / 64, blocks, bpc);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, false>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0,
+                       st, a);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_finish_kernel<CodeT, false>), dim3(GQ_FIXUP_PARTIALS), dim3(256), 0,
                        st, a);
     GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter)");
@@ -639,7 +667,9 @@ GQ_API int gq_hsq_encode_batched(const int64_t *seg_table, const int32_t *tile_s
     a.seg_minmax = seg_minmax;
     a.ntiles = ntiles;
     hipStream_t st = gq::as_stream(stream);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gq::hsq_encode_pf_kernel<uint8_t, true>), dim3((unsigned)gq::pf_grid(ntiles, bpc)),
+    const int64_t blocks = gq::pf_grid(ntiles, bpc);
+    a.split_tile = gq::pf_split(ntiles, blocks, bpc);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gq::hsq_encode_pf_kernel<uint8_t, true>), dim3((unsigned)blocks),
                        dim3(gq::ENC_THREADS), 0, st, a);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gq::hsq_encode_finish_kernel<uint8_t, true>), dim3(GQ_FIXUP_PARTIALS), dim3(256),
                        0, st, a);

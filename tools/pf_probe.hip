@@ -23,6 +23,7 @@ __device__ __forceinline__ unsigned med3u(unsigned a, unsigned b, unsigned c) {
 }
 
 // MODE 0: MFMA only; 1: MFMA + keys top-2 (2.5 ops/score); 2: MFMA + keys top-1 (1.5 ops/score); 3: VALU top-2 only
+// MODE 5: product-like pair keys (1.6 ops/score), ONE chain at a time; MODE 6: same, TWO independent chains in flight
 template <int MODE, int NMFMA>
 __global__ __launch_bounds__(256, 2) void probe(const float *in, float *out, int iters) {
     bf16x8 ch[8], cl[8], vh[2], vl[2];
@@ -40,6 +41,45 @@ __global__ __launch_bounds__(256, 2) void probe(const float *in, float *out, int
     const unsigned mask = 0x7FFFFFC0u;
     f32x16 fake;
     for (int r = 0; r < 16; ++r) fake[r] = in[(threadIdx.x + r) & 1023];
+    if (MODE == 5 || MODE == 6) {
+        for (int it = 0; it < iters; ++it) {
+            auto pairkeys = [&](const f32x16 &acc, int c) {
+                const int t = c >> 2;
+#pragma unroll
+                for (int p = 0; p < 8; p += 2) {
+                    const float g0 = fmaxf(fabsf(acc[2 * p]), fabsf(acc[2 * p + 1]));
+                    const float g1 = fmaxf(fabsf(acc[2 * p + 2]), fabsf(acc[2 * p + 3]));
+                    const unsigned k0 = and_or(__float_as_uint(g0), mask, (unsigned)(((c & 3) * 8 + p) & 31));
+                    const unsigned k1 = and_or(__float_as_uint(g1), mask, (unsigned)(((c & 3) * 8 + p + 1) & 31));
+                    second[t] = max(second[t], med3u(best[t], k0, k1));
+                    best[t] = max3u(best[t], k0, k1);
+                }
+            };
+            if (MODE == 5) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    f32x16 acc = {0};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[c & 7], vh[c >> 3], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[c & 7], vl[c >> 3], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[c & 7], vh[c >> 3], acc, 0, 0, 0);
+                    pairkeys(acc, c);
+                }
+            } else {
+#pragma unroll
+                for (int rb = 0; rb < 8; ++rb) {
+                    f32x16 a0 = {0}, a1 = {0};
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[rb], vh[0], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[rb], vh[1], a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[rb], vl[0], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[rb], vl[1], a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[rb], vh[0], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[rb], vh[1], a1, 0, 0, 0);
+                    pairkeys(a0, rb);
+                    pairkeys(a1, rb + 8);
+                }
+            }
+        }
+    } else
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -102,7 +142,7 @@ void run(const char *name, int blocks) {
 }
 
 int main() {
-    for (int bpc = 1; bpc <= 3; ++bpc) {
+    for (int bpc = 2; bpc <= 3; ++bpc) {
         int blocks = 256 * bpc;
         run<0, 3>("3 bf16 MFMA only", blocks);
         run<0, 1>("1 bf16 MFMA only", blocks);
@@ -110,6 +150,8 @@ int main() {
         run<2, 3>("3 MFMA + top-1 keys", blocks);
         run<1, 1>("1 MFMA + top-2 keys", blocks);
         run<3, 3>("VALU top-2 keys only", blocks);
+        run<5, 3>("pair keys, one chain at a time", blocks);
+        run<6, 3>("pair keys, two chains in flight", blocks);
     }
     return 0;
 }

@@ -1,0 +1,45 @@
+"""Diagnostic build of the prefilter kernel with s_memtime / s_memrealtime stamps around the phases
+of a tile (cdna_hip_programming.md section 7, in-kernel stamps).  Never shipped, never timed:
+    python tools/stamp_build.py           # -> tools/exp/libgq_stamp.so
+    GQ_LIB_PATH=tools/exp/libgq_stamp.so python tools/stamp_read.py      (on the GPU box)
+The stamps are written behind the worklist, which no other code of the kernel reads."""
+import glob, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gradient-quantization_amd", "csrc")
+TMP = "/tmp/gq_stamp_src"
+shutil.rmtree(TMP, ignore_errors=True)
+shutil.copytree(SRC, TMP)
+p = os.path.join(TMP, "hsq_encode_pf.hip")
+s = open(p).read()
+stamp = ('        __builtin_amdgcn_sched_barrier(0);\n'
+         '        { unsigned long long ts_; asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) :: "memory"); '
+         '__builtin_amdgcn_sched_barrier(0); stamp_acc[ID] += (ts_ - ts_prev); ts_prev = ts_; }\n')
+def rep(old, new):
+    global s
+    assert old in s, old
+    s = s.replace(old, new, 1)
+rep("    const float *__restrict__ cb = a.cb;\n    float *__restrict__ ws = a.ws;\n    float *__restrict__ u = a.u;\n    const int64_t M = a.M;\n    // f32 codebook",
+    "    const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();\n    const float *__restrict__ cb = a.cb;\n    float *__restrict__ ws = a.ws;\n    float *__restrict__ u = a.u;\n    const int64_t M = a.M;\n    // f32 codebook")
+rep("    for (; t < tile_end; t += nw) {\n        const int64_t tn = t + nw;",
+    "    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();\n    unsigned long long stamp_acc[6] = {0,0,0,0,0,0}; unsigned long long ts_prev; "
+    "asm volatile(\"s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(ts_prev) :: \"memory\");\n    for (; t < tile_end; t += nw) {\n        const int64_t tn = t + nw;")
+for i, marker in enumerate(["        // ---- prefilter: 16 (block, row block) chains",
+                            "        // ---- per block: merge the two trackers",
+                            "        // ---- exact rescoring of both groups",
+                            "        // Consume the prefetched tile (convert it to the next B fragments)",
+                            "        if (valid) {\n            // provisional values"]):
+    rep(marker, stamp.replace("ID", str(i)) + marker)
+rep("        ti = tin;\n    }\n    if (BATCHED) {\n        flush_minmax();",
+    "        ti = tin;\n" + stamp.replace("ID", "5") + "    }\n"
+    "    { const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();\n"
+    "      if (!BATCHED && lane == 0 && blockIdx.x < 512) {\n"
+    "          unsigned long long *o = reinterpret_cast<unsigned long long *>(ws_worklist(ws) + (M - 65536)) + (blockIdx.x * 4 + wave) * 10;\n"
+    "          for (int i = 0; i < 6; ++i) o[i] = stamp_acc[i];\n"
+    "          o[6] = rt_entry; o[7] = rt0; o[8] = rt1; o[9] = 0; } }\n    if (BATCHED) {\n        flush_minmax();")
+open(p, "w").write(s)
+out = os.path.join(ROOT, "tools", "exp")
+os.makedirs(out, exist_ok=True)
+cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-honor-nans", "-fPIC", "-shared", "-std=c++17",
+       "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"), "-I" + TMP, "-o", os.path.join(out, "libgq_stamp.so")] + sorted(glob.glob(TMP + "/*.hip"))
+subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+print(os.path.join(out, "libgq_stamp.so"))

@@ -1,0 +1,41 @@
+"""Read the stamps of tools/exp/libgq_stamp.so (tools/stamp_build.py): where a tile's cycles go,
+the in-kernel clock, prologue length and how far apart the waves finish."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gradient-quantization_amd"))
+import torch, numpy as np
+from gq_amd import native
+from gq_amd.codebook import load_codebook
+dev = torch.device("cuda:0")
+cb = torch.from_numpy(load_codebook(16, 256)).to(dev)
+torch.manual_seed(1234)
+g = torch.randn(25_000_000, device=dev)
+M = g.numel() // 16
+codes = torch.empty(M, dtype=torch.uint8, device=dev); u = torch.empty(M, dtype=torch.float32, device=dev)
+ws = native.new_workspace(dev, M)
+for _ in range(3):
+    native.hsq_encode(g, cb, codes, u, ws, impl=4)
+torch.cuda.synchronize()
+wl = ws[2 * native.GQ_MAX_PARTIALS + 4:2 * native.GQ_MAX_PARTIALS + 4 + M]
+raw = wl[M - 65536:M - 65536 + 512 * 4 * 10 * 2].contiguous().view(torch.int64).view(-1, 10).cpu().numpy().astype(np.float64)
+seg, entry, rt0, rt1 = raw[:, :6], raw[:, 6], raw[:, 7], raw[:, 8]
+names = ["prefetch issue / loop top", "16 chains (MFMA + keys)", "tracker merge + swaps", "exact rescoring (LDS gather)",
+         "next-tile bf16 split", "stores + flags"]
+ntiles = (M + 63) // 64
+split = int(os.environ.get("GQ_PF_SPLIT", "630"))
+first = np.arange(len(raw)) < len(raw) // 2          # waves of the first half of the grid
+tiles_w = np.where(first, ntiles * split / 1000 / (len(raw) / 2), ntiles * (1000 - split) / 1000 / (len(raw) / 2)) if split > 0 else np.full(len(raw), ntiles / len(raw))
+tiles = tiles_w.mean()
+cyc = seg.sum(1).mean()
+loop_us = (rt1 - rt0).mean() / 100
+print("loop: %.0f shader cycles per wave in %.1f us -> in-kernel clock %.2f GHz; %.0f cycles per tile per wave" % (cyc, loop_us, cyc / loop_us / 1e3, cyc / tiles))
+for n, v in zip(names, seg.mean(0)):
+    print("  %-30s %6.0f cycles/tile  %5.1f %%" % (n, v / tiles, 100 * v / cyc))
+print("prologue per wave %.1f us (min %.1f, max %.1f); first entry -> last loop end %.1f us; loop-end skew %.1f us"
+      % ((rt0 - entry).mean() / 100, (rt0 - entry).min() / 100, (rt0 - entry).max() / 100, (rt1.max() - entry.min()) / 100, (rt1.max() - rt1.min()) / 100))
+end = (rt1 - entry.min()) / 100
+blk = np.arange(len(end)) // 4
+for lo, hi in [(0, 128), (128, 256), (256, 384), (384, 512)]:
+    m = (blk >= lo) & (blk < hi)
+    print("blocks %3d-%3d: loop ends at %.1f us on average (min %.1f, max %.1f), loop length %.1f us, %.1f tiles per wave, %.0f cycles per tile"
+          % (lo, hi - 1, end[m].mean(), end[m].min(), end[m].max(), ((rt1 - rt0)[m] / 100).mean(), tiles_w[m].mean(), (seg.sum(1)[m] / tiles_w[m]).mean()))
