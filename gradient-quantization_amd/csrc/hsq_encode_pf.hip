@@ -139,6 +139,7 @@ struct PfArgs {
     unsigned *seg_minmax;     // batched: order-mapped (min, max) per segment
     int64_t ntiles;
     int64_t split_tile;       // >= 0: first half of the grid shares tiles [0, split_tile), second half the rest
+    float ef_scale;           // EF kernels: grad <- grad + ef_scale * error (error pointer = seg_table[seg][7], 0 = none)
 };
 
 // order-preserving float -> uint32 map for integer atomic min/max
@@ -150,7 +151,10 @@ __device__ __forceinline__ float order_unmap(unsigned m) {
     return __uint_as_float(m ^ ((m >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
-template <typename CodeT, bool BATCHED>
+// EF (batched only): error feedback folded into the load -- the tile is read as
+// v = grad + ef_scale * error (product rounded, then the add: ps_quantizer.py:35) and v is written back
+// over grad, as the reference's in-place add_ does; the level kernel later writes error = v - decoded.
+template <typename CodeT, bool BATCHED, bool EF = false>
 __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfArgs a) {
     const float *__restrict__ cb = a.cb;
     float *__restrict__ ws = a.ws;
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     float lmin = INFINITY, lmax = -INFINITY;
     int cur_seg = -1;  // batched: segment the running (lmin, lmax) belongs to
     f32x4 cur[4], nxt[4];
+    f32x4 nxte[4];   // EF: the error tile that goes with nxt (dead otherwise)
 
     // where tile `tile` lives: base pointer, subvector count of its tensor, local index of its first subvector
     struct Tile {
@@ -226,6 +231,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
         int64_t m, sv0;
         int seg;
         CodeT *codes;
+        const float *err;   // EF: this tensor's error buffer or nullptr
     };
     auto tile_info = [&](int64_t tile) {
         Tile ti;
@@ -236,12 +242,14 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
             ti.m = rec[1];
             ti.sv0 = (tile - rec[2]) * 64;
             ti.codes = reinterpret_cast<CodeT *>(a.wire + rec[3]);
+            ti.err = EF ? reinterpret_cast<const float *>(rec[7]) : nullptr;
         } else {
             ti.seg = 0;
             ti.base = a.grad;
             ti.m = M;
             ti.sv0 = tile * 64;
             ti.codes = static_cast<CodeT *>(a.codes);
+            ti.err = nullptr;
         }
         return ti;
     };
@@ -253,6 +261,42 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
             const f32x4 *p = reinterpret_cast<const f32x4 *>(ti.base + sv * 16 + 8 * h);
             dst[2 * blk] = p[0];
             dst[2 * blk + 1] = p[1];
+        }
+    };
+    auto load_err = [&](const Tile &ti, f32x4(&dst)[4]) {
+        if (EF && ti.err) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                int64_t sv = ti.sv0 + blk * 32 + j;
+                sv = sv < ti.m ? sv : ti.m - 1;
+                const f32x4 *p = reinterpret_cast<const f32x4 *>(ti.err + sv * 16 + 8 * h);
+                dst[2 * blk] = p[0];
+                dst[2 * blk + 1] = p[1];
+            }
+        }
+    };
+    // v = grad + scale*error, written back over grad (valid subvectors only)
+    auto fold_err = [&](const Tile &ti, f32x4(&g)[4], const f32x4(&e)[4]) {
+        if (EF && ti.err) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    f32x4 &x = g[2 * blk + q];
+                    const f32x4 &y = e[2 * blk + q];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float prod = a.ef_scale * y[c];
+                        x[c] = x[c] + prod;
+                    }
+                }
+                const int64_t sv = ti.sv0 + blk * 32 + j;
+                if (sv < ti.m) {
+                    f32x4 *p = reinterpret_cast<f32x4 *>(const_cast<float *>(ti.base) + sv * 16 + 8 * h);
+                    p[0] = g[2 * blk];
+                    p[1] = g[2 * blk + 1];
+                }
+            }
         }
     };
     auto flush_minmax = [&]() {  // batched: fold this wave's running (min,max) into its segment
@@ -271,6 +315,8 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     if (t < tile_end) {
         ti = tile_info(t);
         load_tile(ti, cur);
+        load_err(ti, nxte);
+        fold_err(ti, cur, nxte);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) split8(cur[2 * blk], cur[2 * blk + 1], vh[blk], vl[blk]);
     }
@@ -280,6 +326,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
         if (tn < tile_end) {
             tin = tile_info(tn);
             load_tile(tin, nxt);  // prefetch the next tile
+            load_err(tin, nxte);
         }
         if (BATCHED && ti.seg != cur_seg) {
             flush_minmax();
@@ -403,6 +450,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
         // Done the other way round, the compiler's vmcnt wait at the first use of `nxt` sits right
         // behind the just-issued stores and every tile eats a store round trip.
         bf16x8 nvh[2], nvl[2];
+        if (EF && tn < tile_end) fold_err(tin, nxt, nxte);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) split8(nxt[2 * blk], nxt[2 * blk + 1], nvh[blk], nvl[blk]);
 #pragma unroll
@@ -648,15 +696,17 @@ template int launch_encode_pf<int32_t>(const float *, const float *, int64_t, in
 
 }  // namespace gq
 
-GQ_API int gq_hsq_encode_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                 const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax,
-                                 float *workspace, void *stream) {
+namespace gq {
+template <bool EF>
+static int encode_batched(const char *what, const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                          const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax, float *workspace,
+                          float ef_scale, void *stream) {
     if (nseg < 1 || ntiles < 1 || ntiles * 64 > 0x7FFFFFFFLL)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched: bad sizes nseg=%d ntiles=%lld", nseg, (long long)ntiles);
+        return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes nseg=%d ntiles=%lld", what, nseg, (long long)ntiles);
     if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched: null pointer");
-    static const int bpc = gq::resident_blocks_per_cu(gq::hsq_encode_pf_kernel<uint8_t, true>, gq::ENC_THREADS, 0);
-    gq::PfArgs a = {};
+        return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<uint8_t, true, EF>, ENC_THREADS, 0);
+    PfArgs a = {};
     a.M = ntiles * 64;
     a.u = u_flat;
     a.cb = codebook;
@@ -666,13 +716,29 @@ GQ_API int gq_hsq_encode_batched(const int64_t *seg_table, const int32_t *tile_s
     a.wire = wire;
     a.seg_minmax = seg_minmax;
     a.ntiles = ntiles;
-    hipStream_t st = gq::as_stream(stream);
-    const int64_t blocks = gq::pf_grid(ntiles, bpc);
-    a.split_tile = gq::pf_split(ntiles, blocks, bpc);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gq::hsq_encode_pf_kernel<uint8_t, true>), dim3((unsigned)blocks),
-                       dim3(gq::ENC_THREADS), 0, st, a);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gq::hsq_encode_finish_kernel<uint8_t, true>), dim3(GQ_FIXUP_PARTIALS), dim3(256),
-                       0, st, a);
-    GQ_CHECK_LAUNCH("gq_hsq_encode_batched");
+    a.ef_scale = ef_scale;
+    hipStream_t st = as_stream(stream);
+    const int64_t blocks = pf_grid(ntiles, bpc);
+    a.split_tile = pf_split(ntiles, blocks, bpc);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, true, EF>), dim3((unsigned)blocks),
+                       dim3(ENC_THREADS), 0, st, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_finish_kernel<uint8_t, true>), dim3(GQ_FIXUP_PARTIALS), dim3(256), 0,
+                       st, a);
+    GQ_CHECK_LAUNCH(what);
     return GQ_OK;
+}
+}  // namespace gq
+
+GQ_API int gq_hsq_encode_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                 const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax,
+                                 float *workspace, void *stream) {
+    return gq::encode_batched<false>("gq_hsq_encode_batched", seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat,
+                                     seg_minmax, workspace, 0.0f, stream);
+}
+
+GQ_API int gq_hsq_encode_batched_ef(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                    const float *codebook, float ef_scale, uint8_t *wire, float *u_flat,
+                                    uint32_t *seg_minmax, float *workspace, void *stream) {
+    return gq::encode_batched<true>("gq_hsq_encode_batched_ef", seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat,
+                                    seg_minmax, workspace, ef_scale, stream);
 }

@@ -31,42 +31,64 @@ __device__ __forceinline__ unsigned qsgd_code(float v, float norm, float s, floa
     return l | ((v > 0.0f ? 1u : 0u) << (bits - 1));
 }
 
-// one wave per bucket; lane handles element pairs (2*lane, 2*lane+1), strided by 128
+// one wave per bucket; lane handles element pairs (2*lane, 2*lane+1), strided by 128.
+// EF: error feedback fused around the codec (ps_quantizer.py:35-39): the bucket is read as
+// v = grad + ef_scale*error (product rounded, then the add), v is written back over grad, and
+// error = v - decode(code) replaces the old error -- all in this one pass.  seg_table[seg][7] is the
+// tensor's error buffer (0 = none).
+template <bool EF>
 __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int n_bit,
-    int bits, int random_mode, uint64_t seed, uint8_t *__restrict__ wire) {
+    int bits, int random_mode, uint64_t seed, float ef_scale, uint8_t *__restrict__ wire) {
     const int lane = threadIdx.x & 63;
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float s = (float)(1 << n_bit), smax = s - 1.0f;
+    const unsigned lmask = (1u << (bits - 1)) - 1u;
     for (int64_t b = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); b < nbuckets; b += nw) {
         const int seg = __builtin_amdgcn_readfirstlane(bucket_seg[b]);
         const int64_t *rec = seg_table + 8 * (int64_t)seg;
         const int d = (int)rec[1];
         const int64_t lb = b - rec[2];
-        const float *v = reinterpret_cast<const float *>(rec[0]) + lb * d;
+        float *v = reinterpret_cast<float *>(rec[0]) + lb * d;
+        float *err = (EF && rec[7]) ? reinterpret_cast<float *>(rec[7]) + lb * d : nullptr;
+        auto load = [&](int e) {
+            float2 p = *reinterpret_cast<const float2 *>(v + e);
+            if (EF && err) {
+                const float2 q = *reinterpret_cast<const float2 *>(err + e);
+                const float p0 = ef_scale * q.x, p1 = ef_scale * q.y;
+                p.x = p.x + p0;
+                p.y = p.y + p1;
+            }
+            return p;
+        };
         float mx = 0.0f;
         for (int e = 2 * lane; e < d; e += 128) {
-            const float2 p = *reinterpret_cast<const float2 *>(v + e);
+            const float2 p = load(e);
             mx = fmaxf(mx, fmaxf(fabsf(p.x), fabsf(p.y)));
         }
         mx = wave_max(mx);
         if (lane == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = mx;
         const uint64_t g0 = (uint64_t)b << 20;  // RNG stream index: unique per (bucket, element)
-        if (bits == 4) {
-            uint8_t *dst = wire + rec[4] + ((lb * d) >> 1);
-            for (int e = 2 * lane; e < d; e += 128) {
-                const float2 p = *reinterpret_cast<const float2 *>(v + e);
-                const unsigned c0 = qsgd_code(p.x, mx, s, smax, random_mode, seed, g0 + e, 4);
-                const unsigned c1 = qsgd_code(p.y, mx, s, smax, random_mode, seed, g0 + e + 1, 4);
+        uint8_t *dst = wire + rec[4] + (bits == 4 ? ((lb * d) >> 1) : lb * d);
+        for (int e = 2 * lane; e < d; e += 128) {
+            const float2 p = load(e);
+            const unsigned c0 = qsgd_code(p.x, mx, s, smax, random_mode, seed, g0 + e, bits);
+            const unsigned c1 = qsgd_code(p.y, mx, s, smax, random_mode, seed, g0 + e + 1, bits);
+            if (bits == 4) {
                 dst[e >> 1] = (uint8_t)(c0 | (c1 << 4));
-            }
-        } else {
-            uint8_t *dst = wire + rec[4] + lb * d;
-            for (int e = 2 * lane; e < d; e += 128) {
-                const float2 p = *reinterpret_cast<const float2 *>(v + e);
-                const unsigned c0 = qsgd_code(p.x, mx, s, smax, random_mode, seed, g0 + e, 8);
-                const unsigned c1 = qsgd_code(p.y, mx, s, smax, random_mode, seed, g0 + e + 1, 8);
+            } else {
                 *reinterpret_cast<uchar2 *>(dst + e) = make_uchar2((uint8_t)c0, (uint8_t)c1);
+            }
+            if (EF && err) {
+                // qsgd_compressor.py:69-70 on this element's own code, then ps_quantizer.py:39
+                float t0 = (float)(c0 & lmask) * (2.0f * (float)(c0 >> (bits - 1)) - 1.0f);
+                float t1 = (float)(c1 & lmask) * (2.0f * (float)(c1 >> (bits - 1)) - 1.0f);
+                t0 = t0 * mx;
+                t1 = t1 * mx;
+                t0 = t0 / s;
+                t1 = t1 / s;
+                *reinterpret_cast<float2 *>(v + e) = p;
+                *reinterpret_cast<float2 *>(err + e) = make_float2(p.x - t0, p.y - t1);
             }
         }
     }
@@ -138,18 +160,36 @@ GQ_API int gq_qsgd_code_bits(int n_bit, int random_mode) {
     return 0;  // no packed format: use gq_qsgd_compress / gq_qsgd_decode_sum
 }
 
+namespace gq {
+template <bool EF>
+static int qsgd_compress_batched(const char *what, const int64_t *seg_table, const int32_t *bucket_seg, int nseg,
+                                 int64_t nbuckets, int n_bit, int random_mode, uint64_t seed, float ef_scale,
+                                 uint8_t *wire, void *stream) {
+    if (nseg < 1 || nbuckets < 1 || n_bit < 1) return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes", what);
+    if (!seg_table || !bucket_seg || !wire) return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
+    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
+        return fail(GQ_ERR_UNSUPPORTED, "%s: random_mode must be OFF or DEVICE", what);
+    const int bits = gq_qsgd_code_bits(n_bit, random_mode);
+    if (!bits) return fail(GQ_ERR_UNSUPPORTED, "%s: n_bit %d has no packed format", what, n_bit);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched_kernel<EF>), dim3((unsigned)qb_grid(nbuckets)),
+                       dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, bits, random_mode,
+                       seed, ef_scale, wire);
+    GQ_CHECK_LAUNCH(what);
+    return GQ_OK;
+}
+}  // namespace gq
+
 GQ_API int gq_qsgd_compress_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
                                     int n_bit, int random_mode, uint64_t seed, uint8_t *wire, void *stream) {
-    if (nseg < 1 || nbuckets < 1 || n_bit < 1) return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched: bad sizes");
-    if (!seg_table || !bucket_seg || !wire) return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched: null pointer");
-    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched: random_mode must be OFF or DEVICE");
-    const int bits = gq_qsgd_code_bits(n_bit, random_mode);
-    if (!bits) return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched: n_bit %d has no packed format", n_bit);
-    hipLaunchKernelGGL(gq::qsgd_compress_batched_kernel, dim3((unsigned)gq::qb_grid(nbuckets)), dim3(gq::QB_THREADS), 0,
-                       gq::as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, bits, random_mode, seed, wire);
-    GQ_CHECK_LAUNCH("gq_qsgd_compress_batched");
-    return GQ_OK;
+    return gq::qsgd_compress_batched<false>("gq_qsgd_compress_batched", seg_table, bucket_seg, nseg, nbuckets, n_bit,
+                                            random_mode, seed, 0.0f, wire, stream);
+}
+
+GQ_API int gq_qsgd_compress_batched_ef(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
+                                       int n_bit, int random_mode, uint64_t seed, float ef_scale, uint8_t *wire,
+                                       void *stream) {
+    return gq::qsgd_compress_batched<true>("gq_qsgd_compress_batched_ef", seg_table, bucket_seg, nseg, nbuckets, n_bit,
+                                           random_mode, seed, ef_scale, wire, stream);
 }
 
 GQ_API int gq_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,

@@ -176,8 +176,19 @@ def hsq_decode_sum_packed(wire, M, codebook, n_bit, out, R, codes_off=0, levels_
     _check(rc, "gq_hsq_decode_sum_strided")
 
 
-def hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace):
+def hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace, ef_scale=None):
+    """ef_scale given: the error-feedback form (seg_table[:, 7] = error buffers, grads updated in place)."""
     assert workspace.numel() >= workspace_floats(ntiles * 64)
+    if ef_scale is not None:
+        rc = lib().gq_hsq_encode_batched_ef(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                            _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                            ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
+                                            ctypes.c_float(ef_scale), _dev_ptr(wire, torch.uint8, "wire"),
+                                            _dev_ptr(u_flat, torch.float32, "u_flat"),
+                                            _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
+                                            _dev_ptr(workspace, torch.float32, "workspace"), _stream())
+        _check(rc, "gq_hsq_encode_batched_ef")
+        return
     rc = lib().gq_hsq_encode_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
                                      _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
                                      ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
@@ -187,7 +198,19 @@ def hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat
     _check(rc, "gq_hsq_encode_batched")
 
 
-def hsq_levels_batched(seg_table, tile_seg, nseg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, wire):
+def hsq_levels_batched(seg_table, tile_seg, nseg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, wire,
+                       ef_codebook=None):
+    """ef_codebook given: also writes error = grad - decoded into the buffers of seg_table[:, 7]."""
+    if ef_codebook is not None:
+        rc = lib().gq_hsq_levels_batched_ef(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                            _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                            ctypes.c_int64(ntiles), _dev_ptr(u_flat, torch.float32, "u_flat"),
+                                            _dev_ptr(seg_minmax, torch.int32, "seg_minmax"), ctypes.c_int(n_bit),
+                                            ctypes.c_int(random_mode), ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                                            _dev_ptr(ef_codebook, torch.float32, "codebook"),
+                                            _dev_ptr(wire, torch.uint8, "wire"), _stream())
+        _check(rc, "gq_hsq_levels_batched_ef")
+        return
     rc = lib().gq_hsq_levels_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
                                      _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
                                      ctypes.c_int64(ntiles), _dev_ptr(u_flat, torch.float32, "u_flat"),
@@ -225,7 +248,16 @@ def qsgd_code_bits(n_bit, random_mode):
     return int(lib().gq_qsgd_code_bits(ctypes.c_int(n_bit), ctypes.c_int(random_mode)))
 
 
-def qsgd_compress_batched(seg_table, bucket_seg, nseg, nbuckets, n_bit, random_mode, seed, wire):
+def qsgd_compress_batched(seg_table, bucket_seg, nseg, nbuckets, n_bit, random_mode, seed, wire, ef_scale=None):
+    """ef_scale given: error feedback in the same pass (seg_table[:, 7] = error buffers)."""
+    if ef_scale is not None:
+        rc = lib().gq_qsgd_compress_batched_ef(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                               _dev_ptr(bucket_seg, torch.int32, "bucket_seg"), ctypes.c_int(nseg),
+                                               ctypes.c_int64(nbuckets), ctypes.c_int(n_bit), ctypes.c_int(random_mode),
+                                               ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_float(ef_scale),
+                                               _dev_ptr(wire, torch.uint8, "wire"), _stream())
+        _check(rc, "gq_qsgd_compress_batched_ef")
+        return
     rc = lib().gq_qsgd_compress_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
                                         _dev_ptr(bucket_seg, torch.int32, "bucket_seg"), ctypes.c_int(nseg),
                                         ctypes.c_int64(nbuckets), ctypes.c_int(n_bit), ctypes.c_int(random_mode),

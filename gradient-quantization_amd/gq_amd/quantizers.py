@@ -271,19 +271,42 @@ class _BatchedBase(object):
         self._dev = torch.empty_like(host, device=device)
         self._tmp_wire = None
         self.ready = False      # the device header has been written at least once
+        self._outs, self._out_views, self._out_turn = [None, None], [None, None], 0
 
-    def _upload(self, tensors, slot, align):
-        ptrs = []
-        for g in tensors:
-            ptr = g.data_ptr()
-            if g.device != self.device or g.dtype != torch.float32 or not g.is_contiguous() or ptr % align:
-                return False
-            ptrs.append(ptr)
+    def _out_buffer(self, device):
+        """Decode target + its per-tensor views.  Two buffers used in turn (the mean and its two-phase
+        re-decode never alias; last step's gradients stay intact for one more apply) and the 76+
+        slice/view objects of a model are built once instead of every step."""
+        k = self._out_turn
+        self._out_turn ^= 1
+        if self._outs[k] is None or self._outs[k].device != device:
+            out = torch.empty(self.out_floats, dtype=torch.float32, device=device)
+            self._outs[k] = out
+            self._out_views[k] = [out[o:o + cd.numel].view(cd.shape) for o, cd in zip(self.out_off, self.codecs)]
+        return self._outs[k], self._out_views[k]
+
+    def _upload(self, tensors, slot, align, errs=None):
+        """Column 0 of the segment table <- the tensors' device pointers; column 7 <- the error
+        buffers' (error-feedback kernels) or 0.  False if any tensor cannot be addressed that way."""
+        def pointers(ts):
+            out = []
+            for g in ts:
+                ptr = g.data_ptr()
+                if g.device != self.device or g.dtype != torch.float32 or not g.is_contiguous() or ptr % align:
+                    return None
+                out.append(ptr)
+            return out
+        ptrs = pointers(tensors)
+        eptrs = pointers(errs) if errs is not None else [0] * len(tensors)
+        if ptrs is None or eptrs is None or len(eptrs) != len(ptrs):
+            return False
         slot %= len(self._host)
         if self._events[slot] is not None:
             self._events[slot].synchronize()       # the previous copy out of this pinned buffer
         host = self._host[slot]
-        host[:self._table_words].view(self.nseg, 8)[:, 0] = torch.tensor(ptrs, dtype=torch.int64)
+        tab = host[:self._table_words].view(self.nseg, 8)
+        tab[:, 0] = torch.tensor(ptrs, dtype=torch.int64)
+        tab[:, 7] = torch.tensor(eptrs, dtype=torch.int64)
         self._dev.copy_(host, non_blocking=True)
         self.ready = True
         ev = torch.cuda.Event()
@@ -291,11 +314,12 @@ class _BatchedBase(object):
         self._events[slot] = ev
         return True
 
-    def roundtrip(self, tensors, slot, salt):
-        """decompress(compress(t)) for every batched tensor in a few launches; None if not batchable."""
+    def roundtrip(self, tensors, slot, salt, errs=None, ef_scale=None):
+        """decompress(compress(t)) for every batched tensor in a few launches; None if not batchable.
+        With `errs`: t <- t + ef_scale*err in place first and err <- t - decoded afterwards."""
         if self._tmp_wire is None:
             self._tmp_wire = torch.zeros((1, self.user_bytes), dtype=torch.uint8, device=self.device)
-        if not self.encode(tensors, self._tmp_wire[0], slot, salt):
+        if not self.encode(tensors, self._tmp_wire[0], slot, salt, errs, ef_scale):
             return None
         return self.decode_mean(self._tmp_wire, 1)
 
@@ -343,26 +367,29 @@ class BatchedHSQ(_BatchedBase):
         self.u_flat = torch.empty(self.ntiles * 64, dtype=torch.float32, device=device)
         self.ws = native.new_workspace(device, self.ntiles * 64)
 
-    def encode(self, tensors, wire_user, slot, salt):
+    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None):
         """Compress `tensors` (one per batched parameter, in order) into one user's wire.
         Returns False (nothing launched) when a tensor is not a contiguous, 16-byte aligned f32
-        tensor on this device: the caller then takes the per-tensor path for this step."""
-        if not self._upload(tensors, slot, 16):
+        tensor on this device: the caller then takes the per-tensor path for this step.
+        With `errs` (error feedback, ps_quantizer.py:34-39) the same two launches also do
+        t += ef_scale*err (in place, before encoding) and err = t - decoded (in place, after)."""
+        if not self._upload(tensors, slot, 16, errs):
             return False
         seg_table = self._dev[:self._table_words]
         minmax = self._dev[self._table_words:].view(torch.int32)
         native.hsq_encode_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.codebook, wire_user,
-                                  self.u_flat, minmax, self.ws)
+                                  self.u_flat, minmax, self.ws, ef_scale=ef_scale if errs is not None else None)
         mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
         native.hsq_levels_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.u_flat, minmax, self.n_bit,
-                                  mode, (_next_seed() ^ salt) if self.random else 0, wire_user)
+                                  mode, (_next_seed() ^ salt) if self.random else 0, wire_user,
+                                  ef_codebook=self.codebook if errs is not None else None)
         return True
 
     def decode_mean(self, gathered, R):
-        out = torch.empty(self.out_floats, dtype=torch.float32, device=gathered.device)
+        out, views = self._out_buffer(gathered.device)
         native.hsq_decode_sum_batched(self._dev[:self._table_words], self.tile_seg, self.nseg, self.ntiles, gathered,
                                       self.codebook, self.n_bit, out, R)
-        return [out[o:o + cd.numel].view(cd.shape) for o, cd in zip(self.out_off, self.codecs)]
+        return views
 
 
 class BatchedQSGD(_BatchedBase):
@@ -397,19 +424,21 @@ class BatchedQSGD(_BatchedBase):
         self.bucket_seg = torch.tensor(bucket_seg, dtype=torch.int32, device=device)
         self._setup(table, None, device, slots, user_bytes)
 
-    def encode(self, tensors, wire_user, slot, salt):
-        if not self._upload(tensors, slot, 8):
+    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None):
+        """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place)."""
+        if not self._upload(tensors, slot, 8, errs):
             return False
         mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
         native.qsgd_compress_batched(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets,
-                                     self.n_bit, mode, (_next_seed() ^ salt) if self.random else 0, wire_user)
+                                     self.n_bit, mode, (_next_seed() ^ salt) if self.random else 0, wire_user,
+                                     ef_scale=ef_scale if errs is not None else None)
         return True
 
     def decode_mean(self, gathered, R):
-        out = torch.empty(self.out_floats, dtype=torch.float32, device=gathered.device)
+        out, views = self._out_buffer(gathered.device)
         native.qsgd_decode_sum_batched(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets,
                                        self.n_bit, self.bits, gathered, out, R)
-        return [out[o:o + cd.numel].view(cd.shape) for o, cd in zip(self.out_off, self.codecs)]
+        return views
 
 
 def default_codec_factory(compressor, numel, shape):
@@ -473,6 +502,7 @@ class PSQuantizer(object):
             self.offsets[i] = off
             off += self.codecs[i].nbytes
         self.dense_bytes = off - self.dense_off
+        self._dense_mean, self._dense_views, self._dense_turn = [None, None], [None, None], 0
         self.user_bytes = _up(off)          # one user's payload (all tensors)
         # tensors served by multi-tensor kernels: (class, parameter indices), built at the first record()
         self._groups = []
@@ -514,19 +544,11 @@ class PSQuantizer(object):
             if obj is None:
                 obj = grp[2] = cls(self.codecs, self.offsets, idxs, dev, self.capacity, self.user_bytes)
             grads = [self.parameters[i].grad.data for i in idxs]
-            if self.error_feedback:
-                # ps_quantizer.py:35: grad += scale*error -- the product is rounded before the add
-                errs = [self.parameters[i].error[user] for i in idxs]
-                torch._foreach_add_(grads, torch._foreach_mul(errs, scale))
-            if obj.encode(grads, wire, slot, salt):
+            # error feedback (ps_quantizer.py:35,39) rides in the same launches: grad += scale*error
+            # before the encode, error = grad - decoded after it, both in place
+            errs = [self.parameters[i].error[user] for i in idxs] if self.error_feedback else None
+            if obj.encode(grads, wire, slot, salt, errs, scale):
                 skip.update(idxs)
-                if self.error_feedback:
-                    # ps_quantizer.py:39: error = grad - decoded (decoded from this user's own wire slot)
-                    decoded = obj.decode_mean(wire.view(1, -1), 1)
-                    for i, e in zip(idxs, torch._foreach_sub(grads, decoded)):
-                        self.parameters[i].error[user].data = e
-            elif self.error_feedback:
-                torch._foreach_sub_(grads, torch._foreach_mul(errs, scale))   # undo; the per-tensor path redoes it
         if len(self.dense_idx) >= 2:
             # all small tensors with one concatenation straight into the packed wire region.  Under
             # error feedback their residual is identically zero (decoded == grad), so nothing else to do.
@@ -584,27 +606,31 @@ class PSQuantizer(object):
                 continue
             gs = obj.decode_mean(gathered, R)
             if self.two_phase:
-                # ps_quantizer.py:52-61, replicated on every rank (salt 0, same call count)
-                if self.error_feedback:
-                    gs = torch._foreach_add(gs, [self.parameters[i].server_error for i in idxs])
-                dec = obj.roundtrip(list(gs), self.capacity, 0)
+                # ps_quantizer.py:52-61, replicated on every rank (salt 0, same call count); with error
+                # feedback g += server_error and server_error = g - decoded happen inside the launches
+                serr = [self.parameters[i].server_error for i in idxs] if self.error_feedback else None
+                dec = obj.roundtrip(list(gs), self.capacity, 0, serr, 1.0)
                 if dec is None:
                     continue     # not batchable: the per-tensor loop below handles these tensors
-                if self.error_feedback:
-                    for i, e in zip(idxs, torch._foreach_sub(gs, dec)):
-                        self.parameters[i].server_error = e
                 gs = dec
             for i, g in zip(idxs, gs):
                 done[i] = g
         if len(self.dense_idx) >= 2:
             # identity tensors: two-phase / error feedback leave them unchanged (roundtrip == clone)
             rows = gathered[:, self.dense_off:self.dense_off + self.dense_bytes].view(torch.float32)
-            mean = rows.mean(dim=0)                      # stack().mean(0) of the reference, all at once
-            o = 0
-            for i in self.dense_idx:
-                n = self.codecs[i].numel
-                done[i] = mean[o:o + n].view(self.codecs[i].shape)
-                o += n
+            k = self._dense_turn
+            self._dense_turn ^= 1
+            if self._dense_mean[k] is None or self._dense_mean[k].device != rows.device:
+                mean = torch.empty(rows.shape[1], dtype=torch.float32, device=rows.device)
+                views, o = [], 0
+                for i in self.dense_idx:
+                    n = self.codecs[i].numel
+                    views.append(mean[o:o + n].view(self.codecs[i].shape))
+                    o += n
+                self._dense_mean[k], self._dense_views[k] = mean, views
+            torch.mean(rows, dim=0, out=self._dense_mean[k])   # stack().mean(0) of the reference, all at once
+            for i, v in zip(self.dense_idx, self._dense_views[k]):
+                done[i] = v
         for i, param in enumerate(self.parameters):
             if i in done:
                 param.grad.data = done[i]

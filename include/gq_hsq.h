@@ -142,6 +142,13 @@ int gq_hsq_decode_sum_strided(const void *codes, int code_bytes, int64_t code_st
  * seg_minmax; gq_hsq_levels_batched writes levels and (lb,ub) into `wire`;
  * gq_hsq_decode_sum_batched averages R users' wires (`gathered` + r*user_stride_bytes) into `out`.
  * Results are identical to the per-tensor entry points.
+ *
+ * Error-feedback forms (ps_quantizer.py:34-39 for all tensors at once): seg_table[seg][7] is the
+ * tensor's error buffer (float*, 16-byte aligned; 0 = no feedback for this tensor).
+ * gq_hsq_encode_batched_ef reads every tile as v = grad + ef_scale*error (product rounded, then the
+ * add), writes v back over grad like the reference's in-place add_, and encodes v;
+ * gq_hsq_levels_batched_ef additionally writes error = v - decoded (the decode of the wire it has just
+ * completed) over the old error.  Same results as gq_axpy_inplace + encode + levels + decode + gq_sub.
  */
 int gq_hsq_encode_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                           const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax,
@@ -149,6 +156,12 @@ int gq_hsq_encode_batched(const int64_t *seg_table, const int32_t *tile_seg, int
 int gq_hsq_levels_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                           const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
                           uint64_t seed, uint8_t *wire, void *stream);
+int gq_hsq_encode_batched_ef(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                             const float *codebook, float ef_scale, uint8_t *wire, float *u_flat,
+                             uint32_t *seg_minmax, float *workspace, void *stream);
+int gq_hsq_levels_batched_ef(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                             const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
+                             uint64_t seed, const float *codebook, uint8_t *wire, void *stream);
 int gq_hsq_decode_sum_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                               const uint8_t *gathered, int64_t user_stride_bytes, int R, const float *codebook,
                               int n_bit, float *out, void *stream);
@@ -201,10 +214,16 @@ int gq_pvq_encode(const float *grad, const float *c_dagger, int64_t M, int d, in
  * d (even, <= 65536), first bucket, byte offset of the f32 norms / of the codes inside ONE user's wire,
  * float offset of the tensor in `out`, buckets, reserved }.  A zero bucket is written as level 0
  * (the reference's NaN level also decodes to 0).
+ * gq_qsgd_compress_batched_ef: error feedback in the same pass (ps_quantizer.py:35-39):
+ * seg_table[seg][7] = the tensor's error buffer (float*, 8-byte aligned; 0 = none); the bucket is read
+ * as v = grad + ef_scale*error, v is written back over grad and error = v - decode(code) over error.
  */
 int gq_qsgd_code_bits(int n_bit, int random_mode);
 int gq_qsgd_compress_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
                              int n_bit, int random_mode, uint64_t seed, uint8_t *wire, void *stream);
+int gq_qsgd_compress_batched_ef(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
+                                int n_bit, int random_mode, uint64_t seed, float ef_scale, uint8_t *wire,
+                                void *stream);
 int gq_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
                                int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                float *out, void *stream);

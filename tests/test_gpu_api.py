@@ -279,6 +279,35 @@ def test_batched_error_feedback_and_two_phase_equal_per_tensor_path(kw):
                 assert torch.equal(pb.server_error, pp.server_error)
 
 
+@pytest.mark.parametrize("which", ["hsq", "qsgd"])
+def test_fused_error_feedback_updates_grad_and_error_in_place(which):
+    """ps_quantizer.py:35,39 inside the batched launches: after record() the gradient tensor holds
+    grad + scale*error_old (the reference's in-place add_) and error holds grad_new - decoded, where
+    decoded is what a single-user apply() returns."""
+    from gq_amd.compressors import NearestNeighborCompressor, QSGDCompressor
+    from gq_amd.quantizers import Quantizer
+    shapes = [(1024,), (64, 3, 3, 3), (72, 16), (128, 128, 3, 3)]
+    params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in shapes]
+    kw = dict(c_dim=128, n_bit=2) if which == "qsgd" else {}
+    q = Quantizer(QSGDCompressor if which == "qsgd" else NearestNeighborCompressor, params,
+                  make_args(num_users=1, ef=True, scale="0.75", random=1, **kw))
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for p in params:
+        p.error[0] = torch.randn(p.shape, device="cuda", generator=gen) * 1e-3
+    grads = [torch.randn(p.shape, device="cuda", generator=gen) * 1e-2 for p in params]
+    old_err = [p.error[0].clone() for p in params]
+    for p, g in zip(params, grads):
+        p.grad = g.clone()
+    q.record(0, epoch=1)
+    assert q._groups and q._groups[0][2].ready
+    folded = [p.grad.data.clone() for p in params]
+    for f, g, e in zip(folded, grads, old_err):
+        assert torch.equal(f, g + 0.75 * e)
+    q.apply()
+    for p, f in zip(params, folded):
+        assert torch.equal(p.error[0], f - p.grad.data)
+
+
 def _run_qsgd(shapes, users, seed, **argkw):
     from gq_amd.compressors import QSGDCompressor
     from gq_amd.quantizers import Quantizer
@@ -304,6 +333,10 @@ def test_batched_packed_qsgd_equals_per_tensor_and_reference_arithmetic(kw, orac
     assert qb._groups and qb._groups[0][0].__name__ == "BatchedQSGD" and qb._groups[0][2].ready
     for a, b in zip(gb, gp):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    if kw.get("ef"):
+        for pb, pp in zip(qb.parameters, qp.parameters):
+            for eb, ep in zip(pb.error, pp.error):
+                assert torch.equal(eb, ep)
     assert qb.codecs[0].bits == 4
     # 0.5 B per element + one f32 per 128-element bucket
     n = sum(p.numel() for p in qb.parameters if p.numel() > 1000)

@@ -44,3 +44,6 @@ run("HSQ per-tensor launches", NearestNeighborCompressor, gq_no_batch=True)
 run("HSQ batched, 8 simulated users", NearestNeighborCompressor, users=8, steps=5)
 run("QSGD d128 n2 batched, packed wire", QSGDCompressor, c_dim=128, n_bit=2)
 run("QSGD d128 n2 per-tensor launches", QSGDCompressor, c_dim=128, n_bit=2, gq_no_batch=True)
+run("HSQ batched, error feedback", NearestNeighborCompressor, ef=True)
+run("HSQ batched, EF + two-phase", NearestNeighborCompressor, ef=True, two_phase=True)
+run("QSGD d128 n2 batched, error feedback", QSGDCompressor, c_dim=128, n_bit=2, ef=True)
