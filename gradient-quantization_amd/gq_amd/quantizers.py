@@ -314,6 +314,15 @@ class _BatchedBase(object):
         self._events[slot] = ev
         return True
 
+    def upload_layout(self):
+        """Device header with the layout columns only (no tensor pointers): enough for decode_mean,
+        which a ring rank may need before it has encoded anything."""
+        self._dev.copy_(self._host[0], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[0] = ev
+        self.ready = True
+
     def roundtrip(self, tensors, slot, salt, errs=None, ef_scale=None):
         """decompress(compress(t)) for every batched tensor in a few launches; None if not batchable.
         With `errs`: t <- t + ef_scale*err in place first and err <- t - decoded afterwards."""
@@ -583,29 +592,16 @@ class PSQuantizer(object):
                 codec.encode_into(grad, wire, off, salt)
         self.recorded += 1
 
-    def apply(self):
-        if self.recorded == 0:
-            return
-        world, rank = _dist_world(self.process_group)
-        local = self._wire[:self.recorded]
-        if world > 1:
-            import torch.distributed as dist
-            need = (world * self.recorded, self.user_bytes)
-            if self._gathered is None or tuple(self._gathered.shape) != need or self._gathered.device != local.device:
-                self._gathered = torch.empty(need, dtype=torch.uint8, device=local.device)
-            # ONE collective per step: every rank's [users, bytes] block, rank-major
-            dist.all_gather_into_tensor(self._gathered.view(-1), local.contiguous().view(-1),
-                                        group=self.process_group)
-            gathered = self._gathered
-        else:
-            gathered = local
+    def _decode_all(self, gathered, two_phase):
+        """Mean of the R = gathered.shape[0] user payloads for every parameter (ps_quantizer.py:47-61),
+        as a list of tensors in parameter order."""
         R = gathered.shape[0]
         done = {}
         for cls, idxs, obj in (self._groups if gathered.device.type == "cuda" else []):
             if obj is None or not obj.ready:
                 continue
             gs = obj.decode_mean(gathered, R)
-            if self.two_phase:
+            if two_phase:
                 # ps_quantizer.py:52-61, replicated on every rank (salt 0, same call count); with error
                 # feedback g += server_error and server_error = g - decoded happen inside the launches
                 serr = [self.parameters[i].server_error for i in idxs] if self.error_feedback else None
@@ -631,13 +627,14 @@ class PSQuantizer(object):
             torch.mean(rows, dim=0, out=self._dense_mean[k])   # stack().mean(0) of the reference, all at once
             for i, v in zip(self.dense_idx, self._dense_views[k]):
                 done[i] = v
+        out = []
         for i, param in enumerate(self.parameters):
             if i in done:
-                param.grad.data = done[i]
+                out.append(done[i])
                 continue
             codec, off = self.codecs[i], self.offsets[i]
             g = codec.decode_mean(gathered, off, R)
-            if self.two_phase:
+            if two_phase:
                 # ps_quantizer.py:52-61 -- identical on every rank (salt 0, same call count)
                 if self.error_feedback:
                     g = g + param.server_error
@@ -646,6 +643,26 @@ class PSQuantizer(object):
                     g = decoded
                 else:
                     g = codec.roundtrip(g, 0)
+            out.append(g)
+        return out
+
+    def apply(self):
+        if self.recorded == 0:
+            return
+        world, rank = _dist_world(self.process_group)
+        local = self._wire[:self.recorded]
+        if world > 1:
+            import torch.distributed as dist
+            need = (world * self.recorded, self.user_bytes)
+            if self._gathered is None or tuple(self._gathered.shape) != need or self._gathered.device != local.device:
+                self._gathered = torch.empty(need, dtype=torch.uint8, device=local.device)
+            # ONE collective per step: every rank's [users, bytes] block, rank-major
+            dist.all_gather_into_tensor(self._gathered.view(-1), local.contiguous().view(-1),
+                                        group=self.process_group)
+            gathered = self._gathered
+        else:
+            gathered = local
+        for param, g in zip(self.parameters, self._decode_all(gathered, self.two_phase)):
             param.grad.data = g
         self.recorded = 0
 
@@ -655,44 +672,82 @@ class PSQuantizer(object):
 # --------------------------------------------------------------------------------------
 # Ring quantizer (the reference's other --mode; sequential by construction)
 # --------------------------------------------------------------------------------------
-class RingQuantizer(object):
-    """quantizers/ring_quantizer.py:7-49: user k adds user k-1's decoded running sum to its
-    own gradient and re-compresses; the result is the LAST user's decode (a sum, not a mean)."""
+class RingQuantizer(PSQuantizer):
+    """quantizers/ring_quantizer.py:7-49: user k adds user k-1's decoded running sum to its own
+    gradient and re-compresses; the result is the LAST user's decode (a sum, not a mean).
 
-    def __init__(self, Compressor, parameters, args, codec_factory=None):
-        self.parameters = list(parameters)
-        self.args = args
-        self.error_feedback = args.ef
-        factory = codec_factory or default_codec_factory
-        self.compressors, self.codecs = [], []
-        for param in self.parameters:
-            n = param.flatten().shape[0]
-            comp = Compressor(n, param.shape, args) if n > 1000 else IdenticalCompressor()
-            self.compressors.append(comp)
-            self.codecs.append(factory(comp, n, param.shape))
-            if self.error_feedback:
-                param.error = [torch.zeros_like(param) for _ in range(args.num_users)]
-        self.running = [None] * len(self.parameters)
+    Built on PSQuantizer's wire and multi-tensor kernels: one record() is [grad += running] + the
+    parameter-server record (error feedback included, ring_quantizer.py:33-40 == ps_quantizer.py:34-39)
+    + a decode of the wire just written.  Under torch.distributed the ring is real: the users are
+    numbered rank-major, the compressed wire (not the decoded sum) travels rank -> rank+1 as ONE
+    point-to-point message over xGMI when a rank's users are done, and the last rank broadcasts the
+    final wire, which every rank decodes.  The chain is sequential by construction (each hop
+    re-compresses the sum of everything before it), so it costs `world` encode latencies."""
+
+    def __init__(self, Compressor, parameters, args, process_group=None, codec_factory=None):
+        two_phase = args.two_phase
+        args.two_phase = False           # ring_quantizer.py has no second phase and no server residual
+        try:
+            super().__init__(Compressor, parameters, args, process_group, codec_factory)
+        finally:
+            args.two_phase = two_phase
+        self.two_phase = False
+        self.running = None              # decoded running sum, one tensor per parameter
+        self._inbox = None
 
     def record(self, user, epoch):
-        scale = _ef_scale(self.args, epoch)
-        for i, param in enumerate(self.parameters):
-            grad = param.grad.data
-            if user != 0 and self.running[i] is not None:
-                grad.add_(self.running[i])
-            if self.error_feedback:
-                grad.add_(scale * param.error[user])
-                decoded = self.codecs[i].roundtrip(grad, user)
-                param.error[user].data = grad - decoded
-            else:
-                decoded = self.codecs[i].roundtrip(grad, user)
-            self.running[i] = decoded
+        world, rank = _dist_world(self.process_group)
+        dev = self.parameters[0].grad.device
+        if self.running is None and rank > 0:
+            # first local user of a rank > 0: the running sum arrives compressed from the previous rank
+            import torch.distributed as dist
+            if self._inbox is None or self._inbox.device != dev:
+                self._inbox = torch.empty((1, self.user_bytes), dtype=torch.uint8, device=dev)
+            dist.recv(self._inbox.view(-1), src=self._peer(rank - 1), group=self.process_group)
+            self._ready_for_wire(dev)
+            self.running = self._decode_all(self._inbox, False)
+        if self.running is not None:     # ring_quantizer.py:31-32 (user != 0)
+            torch._foreach_add_([p.grad.data for p in self.parameters], list(self.running))
+        self.recorded = 0                # every user re-uses wire slot 0
+        super().record(user, epoch)
+        self.running = self._decode_all(self._wire[:1], False)
+
+    def _peer(self, group_rank):
+        import torch.distributed as dist
+        return group_rank if self.process_group is None else dist.get_global_rank(self.process_group, group_rank)
+
+    def _ready_for_wire(self, dev):
+        """A rank may have to decode a wire before it has encoded anything: the multi-tensor kernels'
+        segment tables (the layout part; pointers are not needed for a decode) must exist."""
+        for grp in (self._groups if dev.type == "cuda" else []):
+            if grp[2] is None:
+                grp[2] = grp[0](self.codecs, self.offsets, grp[1], dev, self.capacity, self.user_bytes)
+            if not grp[2].ready:
+                grp[2].upload_layout()
 
     def apply(self):
-        for i, param in enumerate(self.parameters):
-            if self.running[i] is not None:
-                param.grad.data = self.running[i]
-        self.running = [None] * len(self.parameters)
+        world, rank = _dist_world(self.process_group)
+        if world > 1:
+            import torch.distributed as dist
+            if self.recorded == 0 and self.running is None:
+                return
+            dev = self._wire.device
+            if rank < world - 1:
+                dist.send(self._wire[0], dst=self._peer(rank + 1), group=self.process_group)
+            final = self._wire[:1] if rank == world - 1 else self._inbox_for(dev)
+            dist.broadcast(final.view(-1), src=self._peer(world - 1), group=self.process_group)
+            if rank != world - 1:
+                self.running = self._decode_all(final, False)
+        if self.running is not None:     # ring_quantizer.py:45-46
+            for param, g in zip(self.parameters, self.running):
+                param.grad.data = g
+        self.running = None
+        self.recorded = 0
+
+    def _inbox_for(self, dev):
+        if self._inbox is None or self._inbox.device != dev:
+            self._inbox = torch.empty((1, self.user_bytes), dtype=torch.uint8, device=dev)
+        return self._inbox
 
     aggregate = apply
 
@@ -702,7 +757,7 @@ def Quantizer(Compressor, parameters, args, **kw):
     if args.mode == 'ps':
         return PSQuantizer(Compressor, parameters, args, **kw)
     elif args.mode == 'ring':
-        return RingQuantizer(Compressor, parameters, args, **{k: v for k, v in kw.items() if k == "codec_factory"})
+        return RingQuantizer(Compressor, parameters, args, **kw)
     assert False, "mode {} not recognized".format(args.mode)
 
 

@@ -40,26 +40,27 @@ def run(quantizer, params, local_users, first_global_user, steps=2):
     return out
 
 
-def build(users):
+def build(users, mode="ps"):
     from oracle_codec import oracle_codec_factory
     from gq_amd.compressors import NearestNeighborCompressor
     from gq_amd.quantizers import Quantizer
     params = [torch.nn.Parameter(torch.zeros(*s)) for s in SHAPES]
-    q = Quantizer(NearestNeighborCompressor, params, make_args(users), codec_factory=oracle_codec_factory)
+    q = Quantizer(NearestNeighborCompressor, params, make_args(users, mode=mode), codec_factory=oracle_codec_factory)
     return q, params
 
 
-def run_single_process(total_users):
-    q, params = build(total_users)
+def run_single_process(total_users, mode="ps"):
+    q, params = build(total_users, mode)
     return run(q, params, total_users, 0)
 
 
 if __name__ == "__main__":
     rank, world, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    mode = sys.argv[4] if len(sys.argv) > 4 else "ps"
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     local = 2
-    q, params = build(local)
+    q, params = build(local, mode)
     res = run(q, params, local, rank * local)
     np.savez(out + "_rank%d.npz" % rank, **res)
     dist.barrier()

@@ -3,7 +3,10 @@
 
 Run in the build container only (the reference does not travel to the GPU box):
 
-    cd /root/reference && python -B /root/repo/tests/golden/make_golden.py
+    cd /root/reference && python -B /root/repo/tests/golden/make_golden.py [name-prefix ...]
+
+With name prefixes only the matching fixtures are (re)written and the other MANIFEST entries are
+kept (npz archives carry timestamps, so rewriting everything would churn every file).
 
 The reference's compressors read ``./codebooks/...`` relative to the cwd
 (compressors/nearest_neighbor_compressor.py:50), hence the cwd requirement.
@@ -16,6 +19,7 @@ source text):
 * ``codebook_d{d}_k{K}_normalized.npy`` the reference's post-``normalize`` codebook
 * ``hsq_*.npz``                       NearestNeighborCompressor.compress/decompress vectors
 * ``psq_*.npz``                       PSQuantizer.record/apply vectors (FCN-like grads)
+* ``ring_*.npz``                      RingQuantizer.record/apply vectors (same layout as psq_*)
 * ``qsgd_*.npz``                      QSGDCompressor vectors
 * ``MANIFEST.json``                   sha256 of every fixture + versions
 """
@@ -43,6 +47,11 @@ from compressors.probabilistic_scalar_compressor import ProbabilisticScalarCompr
 from quantizers import Quantizer  # noqa: E402
 
 torch.set_num_threads(8)
+ONLY = sys.argv[1:]
+
+
+def want(name):
+    return not ONLY or any(name.startswith(o) for o in ONLY)
 
 
 def make_args(**kw):
@@ -66,6 +75,8 @@ def f64_top2_gap(cb, x, d):
 
 def hsq_case(name, x, shape=None, seed_r=None, **argkw):
     """One NearestNeighborCompressor fixture: input, signature, decoded."""
+    if not want(name):
+        return
     args = make_args(**argkw)
     x = np.ascontiguousarray(x, dtype=np.float32)
     shape = tuple(shape) if shape is not None else x.shape
@@ -106,6 +117,8 @@ def hsq_case(name, x, shape=None, seed_r=None, **argkw):
 
 
 def qsgd_case(name, x, shape=None, seed_r=None, **argkw):
+    if not want(name):
+        return
     args = make_args(**argkw)
     x = np.ascontiguousarray(x, dtype=np.float32)
     shape = tuple(shape) if shape is not None else x.shape
@@ -127,6 +140,8 @@ def qsgd_case(name, x, shape=None, seed_r=None, **argkw):
 
 def psq_case(name, shapes, users, epoch, seed, scale_in=1e-2, steps=1, **argkw):
     """PSQuantizer.record x users + apply, `steps` times, on given parameter shapes."""
+    if not want(name):
+        return
     args = make_args(num_users=users, **argkw)
     g = torch.Generator().manual_seed(seed)
     params = [torch.nn.Parameter(torch.zeros(*s)) for s in shapes]
@@ -161,7 +176,7 @@ def main():
     os.makedirs(os.path.join(OUT, "codebooks", "learned_codebook"), exist_ok=True)
     from utils.vecs_io import fvecs_read
     from utils.vec_np import normalize
-    for d, K in [(16, 256), (8, 32), (24, 64), (12, 512), (32, 256), (8, 256)]:
+    for d, K in ([] if ONLY else [(16, 256), (8, 32), (24, 64), (12, 512), (32, 256), (8, 256)]):
         fn = "angular_dim_%d_Ks_%d.fvecs" % (d, K)
         src = os.path.join(REF, "codebooks", "learned_codebook", fn)
         dst = os.path.join(OUT, "codebooks", "learned_codebook", fn)
@@ -261,11 +276,19 @@ def main():
     psq_case("psq_fcn_u3_qsgd", fcn, users=3, epoch=1, seed=106, random=0, quantizer="qsgd",
              c_dim=128, n_bit=2)
 
+    # ---- RingQuantizer (quantizers/ring_quantizer.py): same record/apply protocol, sum semantics
+    psq_case("ring_fcn_u3_det", fcn, users=3, epoch=1, seed=107, random=0, mode="ring")
+    psq_case("ring_fcn_u3_ef", fcn, users=3, epoch=2, seed=108, random=0, mode="ring", ef=True, steps=2)
+    psq_case("ring_fcn_u2_qsgd_ef", fcn, users=2, epoch=1, seed=109, random=0, mode="ring", ef=True,
+             quantizer="qsgd", c_dim=128, n_bit=2, steps=2)
+
     # ---- manifest ---------------------------------------------------------------
     man = {"torch": torch.__version__, "numpy": np.__version__, "files": {}}
+    if ONLY:
+        man = json.load(open(os.path.join(OUT, "MANIFEST.json")))
     for root, _, files in os.walk(OUT):
         for fn in sorted(files):
-            if fn.endswith((".npz", ".npy", ".fvecs")):
+            if fn.endswith((".npz", ".npy", ".fvecs")) and (want(fn) or os.path.relpath(os.path.join(root, fn), OUT) not in man["files"]):
                 p = os.path.join(root, fn)
                 man["files"][os.path.relpath(p, OUT)] = hashlib.sha256(open(p, "rb").read()).hexdigest()
     json.dump(man, open(os.path.join(OUT, "MANIFEST.json"), "w"), indent=1, sort_keys=True)

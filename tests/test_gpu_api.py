@@ -15,6 +15,7 @@ GOLDEN = os.path.join(HERE, "golden")
 HSQ_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "hsq_*.npz")))
 QSGD_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "qsgd_*.npz")))
 PSQ = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "psq_*.npz")))
+RING = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ring_*.npz")))
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -136,6 +137,14 @@ def test_psquantizer_on_gpu_matches_reference(name):
     from test_host_logic import run_psq_fixture
     q = run_psq_fixture(name, None, device="cuda", tol=1e-6)
     assert q.codecs[0].__class__.__name__ in ("HSQCodec", "QSGDCodec")
+
+
+@pytest.mark.parametrize("name", RING)
+def test_ring_quantizer_on_gpu_matches_reference(name):
+    """quantizers/ring_quantizer.py on the HIP path (batched kernels, fused error feedback)."""
+    from test_host_logic import run_psq_fixture
+    q = run_psq_fixture(name, None, device="cuda", tol=1e-6)
+    assert type(q).__name__ == "RingQuantizer" and q._groups and q._groups[0][2].ready
 
 
 def test_psquantizer_bit_exact_single_phase():

@@ -168,6 +168,7 @@ def test_drop_in_module_names():
 
 # ---- quantizer host logic against the reference's captured record/apply outputs ------------
 PSQ = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "psq_*.npz")))
+RING = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ring_*.npz")))
 
 
 def _psq_args(name, users):
@@ -180,6 +181,8 @@ def _psq_args(name, users):
         kw["scale"] = "0.5"
     if "qsgd" in name:
         kw.update(c_dim=128, n_bit=2)
+    if name.startswith("ring_"):
+        kw["mode"] = "ring"
     return make_args(**kw)
 
 
@@ -221,6 +224,15 @@ def test_psquantizer_host_logic_matches_reference(name, oracle):
     run_psq_fixture(name, oracle_codec_factory)
 
 
+@pytest.mark.parametrize("name", RING)
+def test_ring_quantizer_host_logic_matches_reference(name, oracle):
+    """RingQuantizer.record x users + apply against the reference's captured outputs
+    (quantizers/ring_quantizer.py run by tests/golden/make_golden.py)."""
+    from oracle_codec import oracle_codec_factory
+    q = run_psq_fixture(name, oracle_codec_factory)
+    assert type(q).__name__ == "RingQuantizer"
+
+
 def test_ring_quantizer_semantics(oracle):
     """Ring mode: result is the last user's decode of the running sum (ring_quantizer.py:30-47)."""
     from oracle_codec import oracle_codec_factory
@@ -244,14 +256,17 @@ def test_ring_quantizer_semantics(oracle):
 
 
 # ---- world_size 2 over gloo -----------------------------------------------------------
-def test_psquantizer_two_ranks_gloo(tmp_path, oracle):
-    """2 ranks x 2 local users over gloo == 4 simulated users in one process (bitwise: the
-    payloads are summed in (rank, user) order either way)."""
+@pytest.mark.parametrize("mode", ["ps", "ring"])
+def test_quantizer_two_ranks_gloo(tmp_path, oracle, mode):
+    """2 ranks x 2 local users over gloo == 4 simulated users in one process, bitwise.  ps: the
+    payloads are summed in (rank, user) order either way.  ring: the compressed running sum hops
+    rank 0 -> rank 1 and the last rank's wire is broadcast (ring_quantizer.py semantics with the users
+    numbered rank-major)."""
     script = os.path.join(HERE, "_dist_worker.py")
     out = str(tmp_path / "res")
-    port = 29500 + (os.getpid() % 2000)
+    port = 29500 + (os.getpid() % 2000) + (7 if mode == "ring" else 0)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GQ_CODEBOOK_DIR=os.path.join(GOLDEN, "codebooks"))
-    procs = [subprocess.Popen([sys.executable, script, str(r), "2", out], env=env) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", out, mode], env=env) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     r0 = np.load(out + "_rank0.npz")
@@ -261,7 +276,7 @@ def test_psquantizer_two_ranks_gloo(tmp_path, oracle):
     # single-process reference run with 4 users
     sys.path.insert(0, HERE)
     import _dist_worker as w
-    single = w.run_single_process(4)
+    single = w.run_single_process(4, mode)
     for k in single:
         assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
 
