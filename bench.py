@@ -177,7 +177,7 @@ def main():
                                    + ("+RCCL all-gather" if world > 1 else "") + "+decode-mean",
                        "elements_per_rank": SIZE, "random": args.random, "ranks": world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "gq_hsq_encode = hsq_encode_pf_kernel + hsq_encode_finish_kernel",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "gq_hsq_encode = hsq_encode_pf_kernel (one launch: prefilter, exact rescoring, in-place exact fix-up, final lb/ub)",
                          "kernel_ms": enc_ms,
                          "note": "exact f32 scoring would need 512 flop/element (81 us at 157.3 TFLOP/s); the "
                                  "bf16x3 prefilter + exact rescoring path is bound by VALU issue, not by HBM"},

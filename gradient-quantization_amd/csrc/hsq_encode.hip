@@ -8,11 +8,12 @@
 // wider internal accumulator -- so the scores come out of the matrix cores
 // bit-identical to the reference while running at the full f32 rate.
 //
-// Three implementations, all exact:
+// Implementations, all exact (hsq_encode_pf.hip adds the bf16 prefilter path for d16/K256):
 //   d16k256  codebook (256x16) held in 64 VGPRs per lane as MFMA A fragments;
 //            gradient subvectors are the B operand (subvector = MFMA column = lane),
 //            so the 256-way argmax is lane-local plus ONE cross-half exchange.
-//   generic  same MFMA formulation for any (d, K); fragments come from L1/L2.
+//   lds      same MFMA formulation for any (d <= 128, K); codebook (chunked if need be) and tiles in LDS.
+//   generic  same MFMA formulation for any (d, K); fragments come from L1/L2 (fallback for d > 128).
 //   valu     one subvector per lane, codebook broadcast from LDS, __fmaf_rn chain,
 //            wave-level min/max by shuffles; kept as the cross-check of the MFMA path.
 #include "hsq_encode_common.hpp"
@@ -235,6 +236,159 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_generic_kernel(const f
 }
 
 // ------------------------------------------------------------------------------------
+// Any (d <= 128, K): exact f32 MFMA with BOTH operands staged in LDS.
+//
+// The codebook (or a chunk of `chunk_rows` rows of it when K*d*4 does not fit) and each wave's
+// 64-subvector tile are written to LDS once, de-interleaved -- a row is stored as
+// [ even k | odd k ], each run padded with zeros to dpad/2 floats (dpad = d rounded up to 8) --
+// so that lane (j, h) of v_mfma_f32_32x32x2_f32 finds its operands a[ks] = row[2ks + h] as ONE
+// contiguous run and fetches four k-steps per ds_read_b128.  Rows are dpad + 4 floats apart:
+// (dpad+4)/4 is odd, so the 16 lanes of a b128 phase hit 16 different bank groups.
+// Zero padding is exact: fma(0, 0, acc) == acc (acc is never -0 in this chain); padded codewords
+// are excluded from the argmax.  Two independent accumulator chains (the tile's two 32-column
+// blocks) share every A fragment.  When the codebook is chunked the workgroup re-stages the next
+// chunk between barriers and each wave carries its tile's running (best, index) in registers.
+// ------------------------------------------------------------------------------------
+constexpr int LDS_ROW_PAD = 4;
+
+template <typename CodeT>
+__global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float *__restrict__ grad,
+                                                                    const float *__restrict__ cb, int64_t M, int d,
+                                                                    int K, CodeT *__restrict__ codes,
+                                                                    float *__restrict__ u,
+                                                                    float *__restrict__ partials, int dpad,
+                                                                    int chunk_rows) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int stride = dpad + LDS_ROW_PAD, half = dpad >> 1;
+    float *const s_cb = lds;
+    float *const s_v = lds + (size_t)chunk_rows * stride + (size_t)wave * 64 * stride;
+    const int kpad = (K + 31) & ~31;
+    const int nchunks = (kpad + chunk_rows - 1) / chunk_rows;
+    const float inv_dpad = 1.0f / (float)dpad;
+
+    // rows [row0, row0 + chunk_rows) of the codebook -> s_cb (all threads)
+    auto stage_codebook = [&](int row0) {
+        const int total = chunk_rows * dpad;
+        for (int i = threadIdx.x; i < total; i += ENC_THREADS) {
+            const int r = (int)(((float)i + 0.5f) * inv_dpad);   // exact for these ranges (i < 2^20, dpad <= 128)
+            const int e = i - r * dpad;
+            const int row = row0 + r;
+            const float val = (row < K && e < d) ? cb[(int64_t)row * d + e] : 0.0f;
+            s_cb[r * stride + (e & 1) * half + (e >> 1)] = val;
+        }
+    };
+    // this wave's tile (64 subvectors) -> s_v; subvectors beyond M are zeros (masked at the store)
+    auto stage_tile = [&](int64_t t) {
+        const int total = 64 * dpad;
+        const int64_t sv0 = t * 64;
+        for (int i = lane; i < total; i += 64) {
+            const int r = (int)(((float)i + 0.5f) * inv_dpad);
+            const int e = i - r * dpad;
+            const float val = (sv0 + r < M && e < d) ? grad[(sv0 + r) * (int64_t)d + e] : 0.0f;
+            s_v[r * stride + (e & 1) * half + (e >> 1)] = val;
+        }
+    };
+
+    const int64_t ntiles = (M + 63) >> 6;
+    const int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
+    const int64_t rounds = (ntiles + nw - 1) / nw;   // the same for every wave of the grid: barriers stay uniform
+    float lmin = INFINITY, lmax = -INFINITY;
+    if (nchunks == 1) {
+        stage_codebook(0);
+        __syncthreads();
+    }
+    for (int64_t round = 0; round < rounds; ++round) {
+        const int64_t t = round * nw + (int64_t)blockIdx.x * ENC_WAVES + wave;
+        const bool active = t < ntiles;
+        if (active) stage_tile(t);
+        Best best[2] = {{0.0f, 0}, {0.0f, 0}};
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int row0 = chunk * chunk_rows;
+            if (nchunks > 1) {
+                __syncthreads();   // everyone is done with the previous chunk
+                stage_codebook(row0);
+                __syncthreads();   // chunk visible
+            } else {
+                // the tile is private to the wave and LDS operations of one wave complete in order:
+                // only the compiler has to be kept from moving the reads above the staging writes
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (!active) continue;
+            const int rblocks = min(chunk_rows, kpad - row0) >> 5;
+            for (int rb = 0; rb < rblocks; ++rb) {
+                const float *arow = s_cb + (rb * 32 + j) * stride + h * half;
+                const float *b0 = s_v + j * stride + h * half;
+                const float *b1 = s_v + (32 + j) * stride + h * half;
+                f32x16 acc0 = {0}, acc1 = {0};
+                for (int k4 = 0; k4 < half; k4 += 4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + k4);
+                    const f32x4 x0 = *reinterpret_cast<const f32x4 *>(b0 + k4);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4 *>(b1 + k4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], x0[q], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], x1[q], acc1, 0, 0, 0);
+                    }
+                }
+                // Padded codewords (rows >= K) score exactly +0 and never win a strict '>' against the
+                // running best (which starts at |0|), so no per-score validity test is needed.
+                argmax_block(best[0], acc0, (row0 >> 5) + rb);
+                argmax_block(best[1], acc1, (row0 >> 5) + rb);
+            }
+        }
+        if (!active) continue;
+        float bv[2] = {best[0].v, best[1].v};
+        int bi[2] = {best[0].i + 4 * h, best[1].i + 4 * h};
+        swap32(bv[0], bv[1]);
+        swap32(bi[0], bi[1]);
+        // a half whose candidate index is out of range (K < 8) never saw a valid codeword
+        const bool v0 = bi[0] < K, v1 = bi[1] < K;
+        const float a0 = fabsf(bv[0]), a1 = fabsf(bv[1]);
+        const bool take1 = v1 && (!v0 || (a1 > a0) || (a1 == a0 && bi[1] < bi[0]));
+        const float val = take1 ? bv[1] : bv[0];
+        const int idx = take1 ? bi[1] : bi[0];
+        const int64_t sv = t * 64 + lane;
+        if (sv < M) {
+            codes[sv] = (CodeT)idx;
+            u[sv] = val;
+            lmin = fminf(lmin, val);
+            lmax = fmaxf(lmax, val);
+        }
+    }
+    write_minmax_partials(lmin, lmax, partials);
+}
+
+// LDS plan of hsq_encode_lds_kernel: false if (d, K) does not fit
+static bool lds_plan(int d, int K, int *dpad, int *chunk_rows, size_t *bytes) {
+    static const int limit = [] {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, 0) != hipSuccess || v < 65536) v = 65536;
+        // a dynamic allocation of the full 160 KiB is refused at dispatch (HSA_STATUS_ERROR_INVALID_ALLOCATION,
+        // measured); 128 KiB leaves room and costs the chunked shapes next to nothing
+        if (v > 128 * 1024) v = 128 * 1024;
+        const char *e = getenv("GQ_LDS_LIMIT");   // tests: force the chunked path on small codebooks
+        if (e && atoi(e) >= 16384 && atoi(e) < v) v = atoi(e);
+        return v;
+    }();
+    if (d > 128) return false;
+    const int dp = (d + 7) & ~7, stride = dp + LDS_ROW_PAD;
+    const size_t tile = (size_t)ENC_WAVES * 64 * stride * sizeof(float);
+    const size_t row = (size_t)stride * sizeof(float);
+    if (tile + 32 * row > (size_t)limit) return false;
+    const int kpad = (K + 31) & ~31;
+    int rows = (int)(((size_t)limit - tile) / row) & ~31;
+    // the whole codebook when it fits in half the LDS (two workgroups per CU); otherwise the largest chunk
+    if ((size_t)kpad * row + tile <= (size_t)limit / 2 || rows >= kpad) rows = kpad < rows ? kpad : rows;
+    *dpad = dp;
+    *chunk_rows = rows;
+    *bytes = tile + (size_t)rows * row;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------
 // VALU cross-check: one subvector per lane, codebook staged in LDS (broadcast reads),
 // explicit __fmaf_rn chain.  d <= 64, K*d*4 bytes <= 64 KiB.
 // ------------------------------------------------------------------------------------
@@ -285,7 +439,26 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
     };
     const int64_t cap = (int64_t)cus * 4 > GQ_MAIN_PARTIALS ? GQ_MAIN_PARTIALS : (int64_t)cus * 4;
 
-    if (impl == 0) impl = (d == 16 && K == 256) ? 4 : 2;
+    int dpad = 0, chunk_rows = 0;
+    size_t lds_bytes = 0;
+    const bool lds_ok = lds_plan(d, K, &dpad, &chunk_rows, &lds_bytes);
+    if (impl == 0) impl = (d == 16 && K == 256) ? 4 : (lds_ok ? 5 : 2);
+    if (impl == 5) {
+        if (!lds_ok) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: impl 5 needs d <= 128 (d=%d K=%d)", d, K);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_lds_kernel<CodeT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipGetLastError();
+            attr_set = true;
+        }
+        const int bpc = resident_blocks_per_cu(hsq_encode_lds_kernel<CodeT>, ENC_THREADS, lds_bytes);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_lds_kernel<CodeT>), dim3((unsigned)grid_for(bpc)),
+                           dim3(ENC_THREADS), lds_bytes, st, grad, codebook, M, d, K, codes, u, partials, dpad,
+                           chunk_rows);
+        GQ_CHECK_LAUNCH("gq_hsq_encode (lds)");
+        return GQ_OK;
+    }
     if (impl == 4) {
         if (d != 16 || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 4 needs d=16, K=256");
         if ((reinterpret_cast<uintptr_t>(grad) & 15) != 0)

@@ -32,9 +32,9 @@ __device__ __forceinline__ void take_if_greater(float &bv, int &bi, float v, int
 __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
 
 // Workspace layout (gq_hsq_workspace_bytes):
-//   [ (min,max) x GQ_MAX_PARTIALS | int32 x4: worklist count, finish ticket, `final` flag, - | worklist int32[M] ]
-// The last GQ_FIXUP_PARTIALS (min,max) slots belong to the finish kernel of the prefilter path.
-// The int32 block must be zero before the first use (the finish kernel re-zeroes what it uses).
+//   [ (min,max) x GQ_MAX_PARTIALS | int32 x4: fix-up count, ticket, `final` flag, - | fix-up log int32[M] ]
+// The int32 block must be zero before the first use (the prefilter kernel's last workgroup re-zeroes
+// what it uses).  GQ_MAIN_PARTIALS caps the persistent grids.
 constexpr int GQ_MAIN_PARTIALS = GQ_MAX_PARTIALS - GQ_FIXUP_PARTIALS;
 __host__ __device__ inline int *ws_counter(float *ws) { return reinterpret_cast<int *>(ws + 2 * GQ_MAX_PARTIALS); }
 __host__ __device__ inline const int *ws_counter(const float *ws) {

@@ -25,10 +25,12 @@
 //     Every candidate that was not rescored lies in a group whose key is <= that bound, so it
 //     cannot reach |u| even after the approximation error: code and u are exactly the
 //     reference's first-max argmax and projection.
-//  4. Otherwise (top-2 gap below ~2e-4 relative, ~1e-3 of random subvectors; tiny / huge / non-finite
-//     inputs) the subvector goes to a worklist and a small fix-up kernel recomputes it exactly
-//     against all 256 codewords (one wave per subvector).  Correctness never depends on E being
-//     tight -- only on it being an upper bound.
+//  4. Otherwise (top-2 gap below ~2e-4 relative, ~5e-4 of random subvectors; tiny / huge / non-finite
+//     inputs) the wave stops for a moment and recomputes that subvector exactly against all 256
+//     codewords (lane k takes codewords k, k+64, k+128, k+192; wave-wide first-max reduction).
+//     Correctness never depends on E being tight -- only on it being an upper bound.
+//  5. The last workgroup to finish folds the per-workgroup (min,max) of u into the final (lb, ub):
+//     the whole encode is ONE launch.
 #include "hsq_encode_common.hpp"
 
 namespace gq {
@@ -462,172 +464,98 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
         }
         __builtin_amdgcn_sched_barrier(0);
 
+        // ---- exact fix-up, in place and wave-wide, for the few subvectors the bound could not settle
+        // (~5e-4 of random ones: a wave meets one every ~30 tiles).  The flagged lane's subvector is
+        // broadcast through SGPRs; lane k scores codewords k, k+64, k+128, k+192 with the reference's
+        // fmaf chain from the LDS codebook; a wave-wide first-max reduction picks the winner.
+        uint64_t todo = __ballot(valid && !safe);
+        while (todo) {
+            const int fl = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            float w[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                w[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vf[e]), fl));
+            float bv = 0.0f;
+            int bi = lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = q * 64 + lane;
+                const float *row = s_cb + (k >> 1) * PAIR_STRIDE + (k & 1);
+                float acc = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc = __fmaf_rn(row[2 * e], w[e], acc);
+                if (q == 0) {
+                    bv = acc;
+                } else {
+                    take_if_greater(bv, bi, acc, k);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                const float a0 = fabsf(bv), a1 = fabsf(ov);
+                const bool take = (a1 > a0) || (a1 == a0 && oi < bi);
+                bv = take ? ov : bv;
+                bi = take ? oi : bi;
+            }
+            if (lane == fl) {
+                val = bv;
+                idx = bi;
+            }
+            if (!BATCHED && lane == 0) {   // diagnostics only: which subvectors took this path
+                const int pos = atomicAdd(counter, 1);
+                worklist[pos] = (int)(ti.sv0 + fl);
+            }
+        }
+
         if (valid) {
-            // provisional values for flagged subvectors are overwritten by the finish kernel
             ti.codes[sv] = (CodeT)idx;
             u[gsv] = val;
-            if (safe) {
-                lmin = fminf(lmin, val);
-                lmax = fmaxf(lmax, val);
-            } else {
-                const int pos = atomicAdd(counter, 1);
-                worklist[pos] = (int)gsv;
-            }
+            lmin = fminf(lmin, val);
+            lmax = fmaxf(lmax, val);
         }
         ti = tin;
     }
     if (BATCHED) {
         flush_minmax();
-    } else {
-        write_minmax_partials(lmin, lmax, ws);
+        return;
     }
-}
-
-// ---------------------------------------------------------------------------------------
-// Finish kernel (GQ_FIXUP_PARTIALS workgroups, always launched behind the main kernel):
-//  1. exact recomputation of the worklist: one wave per subvector; lane k owns codewords
-//     k, k+64, k+128, k+192 (rows in registers), the reference's fmaf chains, then a wave-wide
-//     first-max reduction on (|p|, index); writes codes / u;
-//  2. the LAST workgroup to finish (ticket counter; partials published with agent-scope
-//     atomic stores, read back with agent-scope atomic loads -- cdna_hip_programming.md G16)
-//     folds all (min,max) pairs into the final (lb, ub) at pair 0, raises the `final` flag the
-//     level kernel looks at, and zeroes the worklist counter for the next call (no memset node).
-// The first worklist entry of every wave is fetched speculatively, before the count is known,
-// so the dependent-load chain is count || entry -> subvector -> compute.
-// ---------------------------------------------------------------------------------------
-template <typename CodeT, bool BATCHED>
-__global__ __launch_bounds__(256) void hsq_encode_finish_kernel(const PfArgs a) {
-    const float *__restrict__ cb = a.cb;
-    float *__restrict__ ws = a.ws;
-    float *__restrict__ u = a.u;
-    const int64_t M = a.M;  // size of the index space the worklist entries live in
-    __shared__ float s_min[4], s_max[4];
+    // ---- (lb, ub): per-workgroup pair -> workspace; the LAST workgroup to arrive (ticket counter;
+    // pairs published with agent-scope atomic stores and read back with agent-scope atomic loads --
+    // cdna_hip_programming.md G16) folds them into the final pair at slot 0, raises the `final` flag
+    // the level kernel looks at and re-zeroes the counters: no second launch, no memset node.
+    __shared__ float s_min[ENC_WAVES], s_max[ENC_WAVES];
     __shared__ int s_last;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int *const ctr = ws_counter(ws);
-    const int *worklist = ws_worklist(ws);
-    const int nw = gridDim.x * 4;
-    const int w0 = blockIdx.x * 4 + wave;
-
-    // where worklist entry `g` lives: its subvector's floats, its code slot, its segment
-    struct Item {
-        const float *v;
-        CodeT *code;
-        int seg;
-    };
-    auto item_of = [&](int64_t g) {
-        Item it;
-        if (BATCHED) {
-            const int64_t tile = g >> 6;
-            it.seg = a.tile_seg[tile];
-            const int64_t *rec = a.seg_table + 8 * (int64_t)it.seg;
-            int64_t sv = (tile - rec[2]) * 64 + (g & 63);
-            sv = sv < rec[1] ? sv : rec[1] - 1;   // (speculative entries may point into padding)
-            it.v = reinterpret_cast<const float *>(rec[0]) + sv * 16;
-            it.code = reinterpret_cast<CodeT *>(a.wire + rec[3]) + sv;
-        } else {
-            it.seg = 0;
-            it.v = a.grad + g * 16;
-            it.code = static_cast<CodeT *>(a.codes) + g;
-        }
-        return it;
-    };
-
-    // issue everything that does not depend on the count
-    const int count = __hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int sv_spec = worklist[(int64_t)w0 < M ? w0 : 0];
-    f32x4 c[4][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) c[q][e] = *reinterpret_cast<const f32x4 *>(cb + (q * 64 + lane) * 16 + 4 * e);
-    sv_spec = ((unsigned)sv_spec < (uint64_t)M) ? sv_spec : 0;
-    Item it = item_of(sv_spec);
-    float vlane = it.v[lane & 15];
-
-    float lmin = INFINITY, lmax = -INFINITY;
-    for (int w = w0; w < count; w += nw) {
-        int64_t sv = sv_spec;
-        if (w != w0) {
-            sv = worklist[w];
-            it = item_of(sv);
-            vlane = it.v[lane & 15];
-        }
-        float bv = 0.0f;
-        int bi = lane;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float ve = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vlane), e));
-                acc = __fmaf_rn(c[q][e >> 2][e & 3], ve, acc);
-            }
-            if (q == 0) {
-                bv = acc;
-            } else {
-                take_if_greater(bv, bi, acc, q * 64 + lane);
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            const float a0 = fabsf(bv), a1 = fabsf(ov);
-            const bool take = (a1 > a0) || (a1 == a0 && oi < bi);
-            bv = take ? ov : bv;
-            bi = take ? oi : bi;
-        }
+    {
+        const float lo = wave_min(lmin), hi = wave_max(lmax);
         if (lane == 0) {
-            *it.code = (CodeT)bi;
-            u[sv] = bv;
-            if (BATCHED) {
-                atomicMin(&a.seg_minmax[2 * it.seg], order_map(bv));
-                atomicMax(&a.seg_minmax[2 * it.seg + 1], order_map(bv));
-            }
+            s_min[wave] = lo;
+            s_max[wave] = hi;
         }
-        lmin = fminf(lmin, bv);
-        lmax = fmaxf(lmax, bv);
-    }
-    if (lane == 0) {
-        s_min[wave] = lmin;
-        s_max[wave] = lmax;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float a = s_min[0], b = s_max[0];
-        for (int w = 1; w < 4; ++w) {
-            a = fminf(a, s_min[w]);
-            b = fmaxf(b, s_max[w]);
+        float lo = s_min[0], hi = s_max[0];
+#pragma unroll
+        for (int w = 1; w < ENC_WAVES; ++w) {
+            lo = fminf(lo, s_min[w]);
+            hi = fmaxf(hi, s_max[w]);
         }
-        float *slot = ws + 2 * (GQ_MAIN_PARTIALS + blockIdx.x);
-        __hip_atomic_store(slot, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float *slot = ws + 2 * blockIdx.x;
+        __hip_atomic_store(slot, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left before the ticket is drawn
-        const int ticket = __hip_atomic_fetch_add(&ctr[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ticket = __hip_atomic_fetch_add(&counter[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (ticket == (int)gridDim.x - 1);
     }
     __syncthreads();
-    if (s_last && BATCHED) {
-        if (threadIdx.x == 0) {
-            ctr[0] = 0;
-            ctr[1] = 0;
-        }
-    } else if (s_last) {
-        // pairs [0, GQ_MAIN_PARTIALS) come from the previous kernel (plain loads); the rest from the
-        // other workgroups of this launch (agent-scope loads, never L1-served)
+    if (s_last) {
         float lo = INFINITY, hi = -INFINITY;
-        for (int i = threadIdx.x; i < GQ_MAX_PARTIALS; i += 256) {
-            float a, b;
-            if (i < GQ_MAIN_PARTIALS) {
-                a = ws[2 * i];
-                b = ws[2 * i + 1];
-            } else {
-                a = __hip_atomic_load(ws + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                b = __hip_atomic_load(ws + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            lo = fminf(lo, a);
-            hi = fmaxf(hi, b);
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += ENC_THREADS) {
+            lo = fminf(lo, __hip_atomic_load(ws + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            hi = fmaxf(hi, __hip_atomic_load(ws + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
         lo = wave_min(lo);
         hi = wave_max(hi);
@@ -638,15 +566,16 @@ __global__ __launch_bounds__(256) void hsq_encode_finish_kernel(const PfArgs a) 
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int w = 1; w < 4; ++w) {
+#pragma unroll
+            for (int w = 1; w < ENC_WAVES; ++w) {
                 lo = fminf(lo, s_min[w]);
                 hi = fmaxf(hi, s_max[w]);
             }
             ws[0] = lo;
             ws[1] = hi;
-            ctr[2] = 1;  // pair 0 holds the final (lb, ub)
-            ctr[0] = 0;  // worklist empty for the next call
-            ctr[1] = 0;
+            counter[2] = 1;  // pair 0 holds the final (lb, ub)
+            counter[0] = 0;  // fix-up log empty for the next call
+            counter[1] = 0;
         }
     }
 }
@@ -685,8 +614,6 @@ int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT 
     a.split_tile = pf_split((M + 63) / 64, blocks, bpc);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, false>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0,
                        st, a);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_finish_kernel<CodeT, false>), dim3(GQ_FIXUP_PARTIALS), dim3(256), 0,
-                       st, a);
     GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter)");
     return GQ_OK;
 }
@@ -722,8 +649,6 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
     a.split_tile = pf_split(ntiles, blocks, bpc);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, true, EF>), dim3((unsigned)blocks),
                        dim3(ENC_THREADS), 0, st, a);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_finish_kernel<uint8_t, true>), dim3(GQ_FIXUP_PARTIALS), dim3(256), 0,
-                       st, a);
     GQ_CHECK_LAUNCH(what);
     return GQ_OK;
 }

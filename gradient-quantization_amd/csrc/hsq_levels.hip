@@ -18,7 +18,7 @@ __global__ __launch_bounds__(LV_THREADS) void hsq_levels_kernel(const float *__r
                                                                uint64_t seed, const float *__restrict__ partials,
                                                                float *__restrict__ lb_ub,
                                                                LevelT *__restrict__ levels) {
-    // ---- lb / ub: already final at pair 0 (prefilter encode's finish kernel), or finished here by
+    // ---- lb / ub: already final at pair 0 (prefilter encode: its last workgroup), or finished here by
     // every block from the GQ_MAX_PARTIALS pairs (8 KiB from L2) ----
     __shared__ float s_min[LV_THREADS / 64], s_max[LV_THREADS / 64];
     float lo, hi;

@@ -88,9 +88,9 @@ def new_workspace(device, M=0):
 
 
 def fixup_count(workspace, M):
-    """Number of subvectors the last prefilter encode sent to the exact fix-up path (syncs).
-    The finish kernel zeroes the counter, so this counts the entries it left in the worklist:
-    call it on a workspace whose worklist was filled with -1 beforehand (tests do)."""
+    """Number of subvectors the last prefilter encode recomputed exactly (syncs).  The kernel
+    zeroes its counter when it ends, so this counts the entries it left in the log: call it on a
+    workspace whose log was filled with -1 beforehand (tests do)."""
     wl = workspace[2 * GQ_MAX_PARTIALS + 4:2 * GQ_MAX_PARTIALS + 4 + M].view(torch.int32)
     return int((wl >= 0).sum().item())
 

@@ -36,12 +36,13 @@ extern "C" {
 
 /* Encode workspace (caller-allocated device memory, gq_hsq_workspace_bytes(M) bytes, 16-byte
  * aligned):
- *   [ (min,max) f32 pairs x GQ_MAX_PARTIALS | int32 x4: worklist count, ticket, final flag, - | worklist int32[M] ]
+ *   [ (min,max) f32 pairs x GQ_MAX_PARTIALS | int32 x4: fix-up count, ticket, final flag, - | fix-up log int32[M] ]
  * The int32 x4 block (bytes [8*GQ_MAX_PARTIALS, +16)) must be ZERO before the first use; the
- * library keeps it consistent afterwards (no memset per call).  gq_hsq_encode leaves the
- * per-workgroup (min,max) of u in the pairs (unused slots hold (+inf,-inf); the last
- * GQ_FIXUP_PARTIALS slots belong to the prefilter path's finish kernel, which also folds all
- * pairs into the final (lb, ub) at pair 0 and raises the final flag); gq_hsq_levels reads them. */
+ * library keeps it consistent afterwards (no memset per call).  gq_hsq_encode leaves either the
+ * per-workgroup (min,max) of u in the pairs (unused slots hold (+inf,-inf), final flag 0) or -- the
+ * d16/K256 prefilter path, whose last workgroup folds them itself -- the final (lb, ub) at pair 0
+ * with the final flag raised; gq_hsq_levels reads them.  The log lists the subvectors the prefilter
+ * path recomputed exactly (diagnostics; valid until the next call). */
 #define GQ_MAX_PARTIALS 1024
 #define GQ_FIXUP_PARTIALS 256
 size_t gq_hsq_workspace_bytes(int64_t M);
@@ -77,12 +78,15 @@ int gq_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, in
  * identical for every impl):  0 = auto, 1 = exact f32 MFMA, d16/K256, register-resident
  * codebook, 2 = exact f32 MFMA generic (any d, K), 3 = VALU fmaf chain with the codebook in
  * LDS, 4 = d16/K256 bf16x3 MFMA prefilter + exact f32 rescoring + exact fix-up (the default
- * for d16/K256; bit-identical output). */
+ * for d16/K256; bit-identical output), 5 = exact f32 MFMA with the codebook (chunked when it
+ * does not fit) and the subvector tiles staged in LDS, any d <= 128 and any K (the default for
+ * everything but d16/K256; 2 remains the fallback for d > 128). */
 #define GQ_ENCODE_AUTO 0
 #define GQ_ENCODE_MFMA_D16K256 1
 #define GQ_ENCODE_MFMA_GENERIC 2
 #define GQ_ENCODE_VALU 3
 #define GQ_ENCODE_PREFILTER_D16K256 4
+#define GQ_ENCODE_MFMA_LDS 5
 int gq_hsq_encode_impl(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes,
                        int code_bytes, float *u, float *workspace, int impl, void *stream);
 

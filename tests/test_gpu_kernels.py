@@ -69,10 +69,10 @@ def gpu_decode(nat, res, n_bit):
     return out.cpu().numpy()
 
 
-IMPLS = {"auto": 0, "mfma_exact_d16k256": 1, "mfma_generic": 2, "valu": 3, "prefilter_d16k256": 4}
+IMPLS = {"auto": 0, "mfma_exact_d16k256": 1, "mfma_generic": 2, "valu": 3, "prefilter_d16k256": 4, "mfma_lds": 5}
 
 
-@pytest.mark.parametrize("impl", ["auto", "mfma_exact_d16k256", "mfma_generic", "valu", "prefilter_d16k256"])
+@pytest.mark.parametrize("impl", ["auto", "mfma_exact_d16k256", "mfma_generic", "valu", "prefilter_d16k256", "mfma_lds"])
 @pytest.mark.parametrize("name", HSQ_CASES)
 def test_hsq_matches_reference_golden(nat, name, impl):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
@@ -97,6 +97,28 @@ def test_hsq_matches_reference_golden(nat, name, impl):
         assert np.array_equal(res["levels"].cpu().numpy(), g["levels"])
     dec = gpu_decode(nat, res, n_bit)
     assert np.array_equal(_bits(dec), _bits(g["decoded"].reshape(-1))), "decoded differs bitwise"
+
+
+@pytest.mark.parametrize("d,K,M", [(16, 4096, 5000), (64, 1024, 1000), (100, 512, 777), (96, 256, 300), (5, 5, 1234),
+                                   (3, 32, 64), (33, 2048, 129), (1, 64, 4097), (65, 4096, 200)])
+def test_lds_staged_encode_any_shape_matches_generic_and_oracle(nat, oracle, d, K, M):
+    """The LDS-staged exact MFMA kernel (the default for everything but d16/K256): whole and chunked
+    codebooks, ragged tiles, K that is no multiple of 32, odd d -- bit-identical to the generic kernel
+    and to the oracle's fmaf chain (the reference's torch.mm arithmetic)."""
+    rng = np.random.RandomState(d * 1000 + K)
+    cb = rng.standard_normal((K, d)).astype(np.float32)
+    cb /= np.maximum(np.linalg.norm(cb, axis=1, keepdims=True), 1e-20)
+    x = (rng.standard_normal(M * d) * 0.1).astype(np.float32)
+    x[:d] = 0.0                       # an all-zero subvector -> code 0, u = +0
+    got = gpu_compress(nat, x, cb, 32, 0, impl=5)
+    gen = gpu_compress(nat, x, cb, 32, 0, impl=2)
+    auto = gpu_compress(nat, x, cb, 32, 0, impl=0)
+    for other in (gen, auto):
+        assert torch.equal(got["codes"], other["codes"])
+        assert torch.equal(got["u"].view(torch.int32), other["u"].view(torch.int32))
+    codes, u = oracle.hsq_encode(x, cb)
+    assert np.array_equal(got["codes"].cpu().numpy().astype(np.int64), codes.astype(np.int64))
+    assert np.array_equal(_bits(got["u"].cpu().numpy()), _bits(u))
 
 
 @pytest.mark.parametrize("scale", [1.0, 1e-3])

@@ -27,7 +27,7 @@ for i, marker in enumerate(["        // ---- prefilter: 16 (block, row block) ch
                             "        // ---- per block: merge the two trackers",
                             "        // ---- exact rescoring of both groups",
                             "        // Consume the prefetched tile (convert it to the next B fragments)",
-                            "        if (valid) {\n            // provisional values"]):
+                            "        // ---- exact fix-up, in place and wave-wide"]):
     rep(marker, stamp.replace("ID", str(i)) + marker)
 rep("        ti = tin;\n    }\n    if (BATCHED) {\n        flush_minmax();",
     "        ti = tin;\n" + stamp.replace("ID", "5") + "    }\n"

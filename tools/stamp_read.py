@@ -20,7 +20,7 @@ wl = ws[2 * native.GQ_MAX_PARTIALS + 4:2 * native.GQ_MAX_PARTIALS + 4 + M]
 raw = wl[M - 65536:M - 65536 + 512 * 4 * 10 * 2].contiguous().view(torch.int64).view(-1, 10).cpu().numpy().astype(np.float64)
 seg, entry, rt0, rt1 = raw[:, :6], raw[:, 6], raw[:, 7], raw[:, 8]
 names = ["prefetch issue / loop top", "16 chains (MFMA + keys)", "tracker merge + swaps", "exact rescoring (LDS gather)",
-         "next-tile bf16 split", "stores + flags"]
+         "next-tile bf16 split", "exact fix-up (rare) + stores"]
 ntiles = (M + 63) // 64
 split = int(os.environ.get("GQ_PF_SPLIT", "630"))
 first = np.arange(len(raw)) < len(raw) // 2          # waves of the first half of the grid
