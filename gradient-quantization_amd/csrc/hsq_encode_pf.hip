@@ -382,7 +382,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
 
         // ---- per block: merge the two trackers; best group's first codeword and the bound on the rest ----
         int k1[2];
-        unsigned s2[2];
+        unsigned s2[2], bk[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             const unsigned bA = best[2 * blk], bB = best[2 * blk + 1];
@@ -392,6 +392,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
             const int r = 2 * (gid & 7);                                              // first register of the group
             k1[blk] = ((gid >> 3) + (useB ? 4 : 0)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // rows k1, k1+1
             s2[blk] = max3u(second[2 * blk], second[2 * blk + 1], bl) | 31u;         // upper end of its bucket
+            bk[blk] = bw;
         }
 
         // ---- this lane's own full subvector (tile subvector `lane`): 8 swaps of the B loads ----
@@ -411,30 +412,28 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
             swap32(a0, a1);
             s2[0] = (unsigned)a0;
             s2[1] = (unsigned)a1;
+            int b0 = (int)bk[0], b1 = (int)bk[1];
+            swap32(b0, b1);
+            bk[0] = (unsigned)b0;
+            bk[1] = (unsigned)b1;
         }
 
-        // ---- exact rescoring of both groups (8 codewords; the reference's fmaf chain) ----
-        float gv[2];
-        int gi[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const f32x2 p01 = exact_score_pair(s_cb + (k1[g] >> 1) * PAIR_STRIDE, vf);   // k1 is even: one pair
-            float bv = p01[0];
-            int bi = k1[g];
-            take_if_greater(bv, bi, p01[1], k1[g] + 1);
-            gv[g] = bv;
-            gi[g] = bi;
-        }
-        const float aa = fabsf(gv[0]), ab = fabsf(gv[1]);
-        const bool takeb = (ab > aa) || (ab == aa && gi[1] < gi[0]);
-        float val = takeb ? gv[1] : gv[0];
-        int idx = takeb ? gi[1] : gi[0];
+        // ---- exact rescoring of the better of the two halves' best groups (2 codewords; the
+        // reference's fmaf chain).  The other half's best group joins the bound on everything that
+        // was not rescored.
+        const bool pick1 = (bk[1] & KEY_MASK) > (bk[0] & KEY_MASK);
+        const int kc = pick1 ? k1[1] : k1[0];
+        const unsigned rest = max3u(s2[0], s2[1], (pick1 ? bk[0] : bk[1]) | 31u);
+        const f32x2 p01 = exact_score_pair(s_cb + (kc >> 1) * PAIR_STRIDE, vf);   // kc is even: one pair
+        float val = p01[0];
+        int idx = kc;
+        take_if_greater(val, idx, p01[1], kc + 1);
 
         float vmax = 0.0f;
 #pragma unroll
         for (int e = 0; e < 16; e += 2) vmax = fmaxf(fmaxf(fabsf(vf[e]), fabsf(vf[e + 1])), vmax);
         const float E = vmax * err_scale;
-        const float others = __uint_as_float(max(s2[0], s2[1]));  // >= every s~ outside the rescored groups
+        const float others = __uint_as_float(rest);  // >= every s~ outside the rescored group
         bool safe = (others + E < fabsf(val)) && (vmax >= 8.27e-25f) && (vmax <= 1.0e30f);
         if (vmax == 0.0f) {  // all-zero subvector: every score is +0 -> first index, u = +0
             safe = true;

@@ -99,6 +99,20 @@ def test_hsq_matches_reference_golden(nat, name, impl):
     assert np.array_equal(_bits(dec), _bits(g["decoded"].reshape(-1))), "decoded differs bitwise"
 
 
+def test_lds_staged_encode_chunked_codebook_in_a_small_lds_budget():
+    """The same shapes with the kernel's LDS budget forced down to 56 KiB (GQ_LDS_LIMIT is read once
+    per process, hence the child process): every codebook is staged in several chunks and the results
+    still equal the generic kernel's and the oracle's."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GQ_LDS_LIMIT="57344")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", __file__, "-k",
+                        "any_shape and not 100-512 and not 96-256 and not 65-4096 and not 64-1024"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 @pytest.mark.parametrize("d,K,M", [(16, 4096, 5000), (64, 1024, 1000), (100, 512, 777), (96, 256, 300), (5, 5, 1234),
                                    (3, 32, 64), (33, 2048, 129), (1, 64, 4097), (65, 4096, 200)])
 def test_lds_staged_encode_any_shape_matches_generic_and_oracle(nat, oracle, d, K, M):

@@ -21,10 +21,8 @@ raw = wl[M - 65536:M - 65536 + 512 * 4 * 10 * 2].contiguous().view(torch.int64).
 seg, entry, rt0, rt1 = raw[:, :6], raw[:, 6], raw[:, 7], raw[:, 8]
 names = ["prefetch issue / loop top", "16 chains (MFMA + keys)", "tracker merge + swaps", "exact rescoring (LDS gather)",
          "next-tile bf16 split", "exact fix-up (rare) + stores"]
-ntiles = (M + 63) // 64
-split = int(os.environ.get("GQ_PF_SPLIT", "630"))
-first = np.arange(len(raw)) < len(raw) // 2          # waves of the first half of the grid
-tiles_w = np.where(first, ntiles * split / 1000 / (len(raw) / 2), ntiles * (1000 - split) / 1000 / (len(raw) / 2)) if split > 0 else np.full(len(raw), ntiles / len(raw))
+tiles_w = raw[:, 9]                                   # tiles each wave actually processed (dynamic scheduling)
+first = np.arange(len(raw)) < len(raw) // 2
 tiles = tiles_w.mean()
 cyc = seg.sum(1).mean()
 loop_us = (rt1 - rt0).mean() / 100
@@ -39,3 +37,13 @@ for lo, hi in [(0, 128), (128, 256), (256, 384), (384, 512)]:
     m = (blk >= lo) & (blk < hi)
     print("blocks %3d-%3d: loop ends at %.1f us on average (min %.1f, max %.1f), loop length %.1f us, %.1f tiles per wave, %.0f cycles per tile"
           % (lo, hi - 1, end[m].mean(), end[m].min(), end[m].max(), ((rt1 - rt0)[m] / 100).mean(), tiles_w[m].mean(), (seg.sum(1)[m] / tiles_w[m]).mean()))
+xcd = blk % 8
+print("per XCD (workgroup index % 8), first-dispatched half of the grid: tiles per wave / cycles per tile / loop end us")
+for x in range(8):
+    m = (xcd == x) & first
+    print("  xcd %d: %.2f tiles, %.0f cycles/tile, ends %.1f us (max %.1f) | second half: %.2f tiles, ends %.1f us (max %.1f)"
+          % (x, tiles_w[m].mean(), (seg.sum(1)[m] / np.maximum(tiles_w[m], 1)).mean(), end[m].mean(), end[m].max(),
+             tiles_w[(xcd == x) & ~first].mean(), end[(xcd == x) & ~first].mean(), end[(xcd == x) & ~first].max()))
+cu = blk % 256
+slow = np.argsort([end[cu == c].max() for c in range(256)])[-8:]
+print("slowest CUs-slots (workgroup index % 256):", slow, [round(float(end[cu == c].max()), 1) for c in slow])
