@@ -38,7 +38,7 @@ namespace gq {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr unsigned KEY_MASK = 0x7FFFFFE0u;  // sign + 5 low mantissa bits make room for the group id (2^-18 relative)
-constexpr int PAIR_STRIDE = 36;             // LDS floats per codeword PAIR (32 used, 144 B): spreads random pairs over the banks
+constexpr int QUAD_STRIDE = 68;             // LDS floats per GROUP of 4 codewords (64 used, 272 B = 17 x 16 B: random groups spread over the banks)
 constexpr float ERR_SCALE = 1.0025f * 3.0517578125e-05f;  // 2^-15 (x ||c||_1 x max|v_j|), analytic bound ~0.44 of it
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -86,24 +86,27 @@ __device__ __forceinline__ unsigned med3u(unsigned a, unsigned b, unsigned c) {
 // statement returned stale scores).  This file is compiled with -fno-honor-nans (build.py):
 // without it every fmaxf on an MFMA output gets a NaN-canonicalising v_max_f32 x,x,x in front
 // (6 VALU ops per group instead of 2).  NaN gradients are undefined input either way.
-__device__ __forceinline__ float absmax2(float a, float b) { return fmaxf(fabsf(a), fabsf(b)); }
+__device__ __forceinline__ float absmax4(float a, float b, float c, float d) {
+    return fmaxf(fmaxf(fmaxf(fabsf(a), fabsf(b)), fabsf(c)), fabsf(d));   // v_max3_f32 + v_max_f32
+}
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Exact reference arithmetic for TWO consecutive codewords at once: p = fmaf chain over j
+// Exact reference arithmetic for FOUR consecutive codewords at once: p = fmaf chain over j
 // ascending, from +0, as packed f32 FMAs (v_pk_fma_f32 rounds each half like v_fma_f32).
-// `pair` points at the pair-interleaved LDS image: (c_even[j], c_odd[j]) for j = 0..15.
-__device__ __forceinline__ f32x2 exact_score_pair(const float *__restrict__ pair, const float (&v)[16]) {
-    f32x2 acc = {0.0f, 0.0f};
+// `quad` points at the group-interleaved LDS image: (c0[j], c1[j], c2[j], c3[j]) for j = 0..15.
+__device__ __forceinline__ f32x4 exact_score_quad(const float *__restrict__ quad, const float (&v)[16]) {
+    f32x2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const f32x4 c = *reinterpret_cast<const f32x4 *>(pair + 4 * q);   // (e[2q], o[2q], e[2q+1], o[2q+1])
-        const f32x2 c0 = {c[0], c[1]}, c1 = {c[2], c[3]};
-        const f32x2 v0 = {v[2 * q], v[2 * q]}, v1 = {v[2 * q + 1], v[2 * q + 1]};
-        acc = __builtin_elementwise_fma(c0, v0, acc);
-        acc = __builtin_elementwise_fma(c1, v1, acc);
+    for (int jj = 0; jj < 16; ++jj) {
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(quad + 4 * jj);
+        const f32x2 c01 = {c[0], c[1]}, c23 = {c[2], c[3]};
+        const f32x2 vv = {v[jj], v[jj]};
+        a01 = __builtin_elementwise_fma(c01, vv, a01);
+        a23 = __builtin_elementwise_fma(c23, vv, a23);
     }
-    return acc;
+    const f32x4 r = {a01[0], a01[1], a23[0], a23[1]};
+    return r;
 }
 
 // Exact reference arithmetic: p = fmaf chain over j ascending, from +0.
@@ -163,11 +166,11 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     float *__restrict__ u = a.u;
     const int64_t M = a.M;
     // f32 codebook for the exact rescoring, codeword pairs interleaved element by element:
-    // s_cb[(k>>1)*PAIR_STRIDE + 2*j + (k&1)] = c[k][j]
-    __shared__ __attribute__((aligned(16))) float s_cb[128 * PAIR_STRIDE];
+    // s_cb[(k>>2)*QUAD_STRIDE + 4*j + (k&3)] = c[k][j]
+    __shared__ __attribute__((aligned(16))) float s_cb[64 * QUAD_STRIDE];
     for (int i = threadIdx.x; i < 256 * 16; i += ENC_THREADS) {
         const int k = i >> 4, jj = i & 15;
-        s_cb[(k >> 1) * PAIR_STRIDE + 2 * jj + (k & 1)] = cb[i];
+        s_cb[(k >> 2) * QUAD_STRIDE + 4 * jj + (k & 3)] = cb[i];
     }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     {
         float l1 = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) l1 += fabsf(s_cb[(threadIdx.x >> 1) * PAIR_STRIDE + 2 * e + (threadIdx.x & 1)]);
+        for (int e = 0; e < 16; ++e) l1 += fabsf(s_cb[(threadIdx.x >> 2) * QUAD_STRIDE + 4 * e + (threadIdx.x & 3)]);
         l1 = wave_max(l1);
         if ((threadIdx.x & 63) == 0) s_c1[threadIdx.x >> 6] = l1;
     }
@@ -342,8 +345,9 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
         unsigned best[4] = {0, 0, 0, 0}, second[4] = {0, 0, 0, 0};
         unsigned vmask = KEY_MASK;
         asm volatile("" : "+v"(vmask));  // keep the mask in a VGPR: v_and_or with an SGPR operand issues slower
-        auto group_key = [&](const f32x16 &a, int rb, int p) {   // group p = registers 2p, 2p+1 = two consecutive rows
-            return and_or(__float_as_uint(absmax2(a[2 * p], a[2 * p + 1])), vmask, (unsigned)((rb & 3) * 8 + p));
+        auto group_key = [&](const f32x16 &a, int rb, int q) {   // group q = registers 4q..4q+3 = four consecutive rows
+            return and_or(__float_as_uint(absmax4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3])), vmask,
+                          (unsigned)((rb & 3) * 4 + q));
         };
         auto track = [&](int trk, unsigned k0, unsigned k1) {
             second[trk] = max(second[trk], med3u(best[trk], k0, k1));
@@ -363,20 +367,17 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
                 nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[nr], vh[nb], nacc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 track(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
-                track(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
                 __builtin_amdgcn_sched_barrier(0);
                 nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vl[nb], nacc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                track(trk, group_key(acc, rb, 4), group_key(acc, rb, 5));
+                track(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
                 __builtin_amdgcn_sched_barrier(0);
                 nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vh[nb], nacc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                track(trk, group_key(acc, rb, 6), group_key(acc, rb, 7));
                 __builtin_amdgcn_sched_barrier(0);
                 acc = nacc;
             } else {
 #pragma unroll
-                for (int p2 = 0; p2 < 8; p2 += 2) track(trk, group_key(acc, rb, p2), group_key(acc, rb, p2 + 1));
+                for (int p2 = 0; p2 < 4; p2 += 2) track(trk, group_key(acc, rb, p2), group_key(acc, rb, p2 + 1));
             }
         }
 
@@ -389,8 +390,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
             const bool useB = (bB & KEY_MASK) > (bA & KEY_MASK);
             const unsigned bw = useB ? bB : bA, bl = useB ? bA : bB;
             const int gid = (int)(bw & 31u);
-            const int r = 2 * (gid & 7);                                              // first register of the group
-            k1[blk] = ((gid >> 3) + (useB ? 4 : 0)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // rows k1, k1+1
+            k1[blk] = ((gid >> 2) + (useB ? 4 : 0)) * 32 + 8 * (gid & 3) + 4 * h;   // rows k1 .. k1+3 (registers 4q..4q+3)
             s2[blk] = max3u(second[2 * blk], second[2 * blk + 1], bl) | 31u;         // upper end of its bucket
             bk[blk] = bw;
         }
@@ -424,10 +424,12 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
         const bool pick1 = (bk[1] & KEY_MASK) > (bk[0] & KEY_MASK);
         const int kc = pick1 ? k1[1] : k1[0];
         const unsigned rest = max3u(s2[0], s2[1], (pick1 ? bk[0] : bk[1]) | 31u);
-        const f32x2 p01 = exact_score_pair(s_cb + (kc >> 1) * PAIR_STRIDE, vf);   // kc is even: one pair
-        float val = p01[0];
+        const f32x4 p4 = exact_score_quad(s_cb + (kc >> 2) * QUAD_STRIDE, vf);   // kc is a multiple of 4: one group
+        float val = p4[0];
         int idx = kc;
-        take_if_greater(val, idx, p01[1], kc + 1);
+        take_if_greater(val, idx, p4[1], kc + 1);
+        take_if_greater(val, idx, p4[2], kc + 2);
+        take_if_greater(val, idx, p4[3], kc + 3);
 
         float vmax = 0.0f;
 #pragma unroll
@@ -480,10 +482,10 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int k = q * 64 + lane;
-                const float *row = s_cb + (k >> 1) * PAIR_STRIDE + (k & 1);
+                const float *row = s_cb + (k >> 2) * QUAD_STRIDE + (k & 3);
                 float acc = 0.0f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc = __fmaf_rn(row[2 * e], w[e], acc);
+                for (int e = 0; e < 16; ++e) acc = __fmaf_rn(row[4 * e], w[e], acc);
                 if (q == 0) {
                     bv = acc;
                 } else {
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
 static int64_t pf_split(int64_t ntiles, int64_t blocks, int bpc) {
     static const int permille = [] {
         const char *e = getenv("GQ_PF_SPLIT");
-        return e ? atoi(e) : 630;
+        return e ? atoi(e) : 625;
     }();
     if (permille <= 0 || bpc != 2 || blocks != (int64_t)cu_count() * 2 || ntiles < blocks * ENC_WAVES * 4) return -1;
     return (ntiles * permille) / 1000;
