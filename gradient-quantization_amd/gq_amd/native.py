@@ -21,6 +21,7 @@ ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFI
 EXPORTS = [
     "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_workspace_bytes", "gq_hsq_encode", "gq_hsq_encode_impl", "gq_hsq_levels",
     "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched",
+    "gq_hsq_encode_batched_ef", "gq_hsq_levels_batched_ef", "gq_qsgd_compress_batched_ef",
     "gq_pvq_encode", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
