@@ -6,7 +6,7 @@
 
 One step = one pass of the hot path over one synthetic 25,000,000-float32 gradient per
 rank, inputs resident in HBM:
-    encode (f32 MFMA) -> level quantiser -> [RCCL all-gather of (codes, levels, lb, ub)]
+    encode (bf16x3 MFMA prefilter + exact f32 rescoring, one launch) -> level quantiser -> [RCCL all-gather of (codes, levels, lb, ub)]
     -> decode + mean over ranks.
 `value` = ranks * 25e6 * K / (max-over-ranks time of K steps).  Weak scaling: every rank
 owns a full-size gradient (it is one of the reference's `num_users`).

@@ -44,7 +44,7 @@ extern "C" {
  * with the final flag raised; gq_hsq_levels reads them.  The log lists the subvectors the prefilter
  * path recomputed exactly (diagnostics; valid until the next call). */
 #define GQ_MAX_PARTIALS 1024
-#define GQ_FIXUP_PARTIALS 256
+#define GQ_FIXUP_PARTIALS 256 /* slots no grid writes: gq_hsq_encode fills them with (+inf,-inf) */
 size_t gq_hsq_workspace_bytes(int64_t M);
 
 /* random_mode of gq_hsq_levels / gq_qsgd_compress */

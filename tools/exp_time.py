@@ -24,5 +24,5 @@ for _ in range(30):
     native.hsq_encode(g, cb, codes, u, ws, impl=impl)
 e.record()
 torch.cuda.synchronize()
-print("%s impl=%d: %.1f us per encode (incl. fix-up launch), fixups=%d" % (
+print("%s impl=%d: %.1f us per encode (one launch), fixups=%d" % (
     os.path.basename(os.environ.get("GQ_LIB_PATH", "product")), impl, s.elapsed_time(e) / 30 * 1e3, native.fixup_count(ws, M)))
