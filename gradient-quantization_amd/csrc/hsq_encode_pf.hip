@@ -38,6 +38,7 @@ namespace gq {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr unsigned KEY_MASK = 0x7FFFFFE0u;  // sign + 5 low mantissa bits make room for the group id (2^-18 relative)
+constexpr int PF_LDS_SEGS = 384;            // batched form: tensors whose segment records are kept in LDS (24 KiB)
 constexpr int QUAD_STRIDE = 68;             // LDS floats per GROUP of 4 codewords (64 used, 272 B = 17 x 16 B: random groups spread over the banks)
 constexpr float ERR_SCALE = 1.0025f * 3.0517578125e-05f;  // 2^-15 (x ||c||_1 x max|v_j|), analytic bound ~0.44 of it
 
@@ -143,6 +144,7 @@ struct PfArgs {
     uint8_t *wire;            // batched
     unsigned *seg_minmax;     // batched: order-mapped (min, max) per segment
     int64_t ntiles;
+    int nseg;                 // batched: segments in seg_table
     int64_t split_tile;       // >= 0: first half of the grid shares tiles [0, split_tile), second half the rest
     float ef_scale;           // EF kernels: grad <- grad + ef_scale * error (error pointer = seg_table[seg][7], 0 = none)
 };
@@ -171,6 +173,15 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     for (int i = threadIdx.x; i < 256 * 16; i += ENC_THREADS) {
         const int k = i >> 4, jj = i & 15;
         s_cb[(k >> 2) * QUAD_STRIDE + 4 * jj + (k & 3)] = cb[i];
+    }
+    // Batched form: the segment table (64 B per tensor) goes to LDS once.  Looking a tile's tensor up in
+    // global memory costs two dependent round trips at the top of every tile (tile -> segment -> record),
+    // which made this form 3x slower than the single-tensor one; from LDS the record is ~100 cycles away,
+    // and the tile -> segment word is fetched one tile ahead.
+    __shared__ int64_t s_seg[BATCHED ? PF_LDS_SEGS * 8 : 1];
+    if (BATCHED) {
+        const int n = (a.nseg < PF_LDS_SEGS ? a.nseg : PF_LDS_SEGS) * 8;
+        for (int i = threadIdx.x; i < n; i += ENC_THREADS) s_seg[i] = a.seg_table[i];
     }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -222,6 +233,19 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
             t = a.split_tile + ((int64_t)blockIdx.x - half) * ENC_WAVES + wave;
         }
     }
+    // Single tensor: the waves interleave (tile t, t + nw, ...: the grid streams the gradient front to
+    // back).  Batched: every wave takes ONE CONTIGUOUS run of tiles instead, so that its running (min,max)
+    // stays with one tensor for many tiles -- interleaved, nearly every tile changes tensor and costs two
+    // atomics on that tensor's (min,max) words, and with ~2000 waves queueing on the few hot words of the
+    // big tensors (the next vmcnt wait covers them) the kernel ran 3x slower than the single-tensor one.
+    int64_t tstep = nw;
+    if (BATCHED) {
+        const int64_t lo = (a.split_tile >= 0 && (int64_t)blockIdx.x >= (int64_t)gridDim.x / 2) ? a.split_tile : 0;
+        const int64_t chunk = (tile_end - lo + nw - 1) / nw;
+        t = lo + (t - lo) * chunk;
+        tile_end = tile_end < t + chunk ? tile_end : t + chunk;
+        tstep = 1;
+    }
     int *const counter = ws_counter(ws);
     int *const worklist = ws_worklist(ws);
 
@@ -238,16 +262,21 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
         CodeT *codes;
         const float *err;   // EF: this tensor's error buffer or nullptr
     };
-    auto tile_info = [&](int64_t tile) {
+    auto uniform64 = [](int64_t v) {   // a wave-uniform value read through a vector path -> SGPRs
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    auto tile_info = [&](int64_t tile, int seg) {   // seg: the tile's tensor (batched; fetched ahead by the caller)
         Tile ti;
         if (BATCHED) {
-            ti.seg = __builtin_amdgcn_readfirstlane(a.tile_seg[tile]);
-            const int64_t *rec = a.seg_table + 8 * (int64_t)ti.seg;
-            ti.base = reinterpret_cast<const float *>(rec[0]);
-            ti.m = rec[1];
-            ti.sv0 = (tile - rec[2]) * 64;
-            ti.codes = reinterpret_cast<CodeT *>(a.wire + rec[3]);
-            ti.err = EF ? reinterpret_cast<const float *>(rec[7]) : nullptr;
+            ti.seg = seg;
+            const int64_t *rec = seg < PF_LDS_SEGS ? s_seg + 8 * seg : a.seg_table + 8 * (int64_t)seg;
+            ti.base = reinterpret_cast<const float *>(uniform64(rec[0]));
+            ti.m = uniform64(rec[1]);
+            ti.sv0 = (tile - uniform64(rec[2])) * 64;
+            ti.codes = reinterpret_cast<CodeT *>(a.wire + uniform64(rec[3]));
+            ti.err = EF ? reinterpret_cast<const float *>(uniform64(rec[7])) : nullptr;
         } else {
             ti.seg = 0;
             ti.base = a.grad;
@@ -317,22 +346,27 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     // B fragments: lane (col j, half h) holds v[8h .. 8h+7] of subvector j of each block
     bf16x8 vh[2], vl[2];
     Tile ti = {};
+    auto seg_of = [&](int64_t tile) {   // batched: tile -> tensor, one global word (0 beyond the end)
+        return (BATCHED && tile < tile_end) ? a.tile_seg[tile] : 0;
+    };
+    int seg_n = seg_of(t + tstep);      // in flight while the first tile is set up
     if (t < tile_end) {
-        ti = tile_info(t);
+        ti = tile_info(t, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[t]) : 0);
         load_tile(ti, cur);
         load_err(ti, nxte);
         fold_err(ti, cur, nxte);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) split8(cur[2 * blk], cur[2 * blk + 1], vh[blk], vl[blk]);
     }
-    for (; t < tile_end; t += nw) {
-        const int64_t tn = t + nw;
+    for (; t < tile_end; t += tstep) {
+        const int64_t tn = t + tstep;
         Tile tin = ti;
         if (tn < tile_end) {
-            tin = tile_info(tn);
+            tin = tile_info(tn, __builtin_amdgcn_readfirstlane(seg_n));   // seg_n was requested a tile ago
             load_tile(tin, nxt);  // prefetch the next tile
             load_err(tin, nxte);
         }
+        seg_n = seg_of(tn + tstep);
         if (BATCHED && ti.seg != cur_seg) {
             flush_minmax();
             cur_seg = ti.seg;
@@ -644,6 +678,7 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
     a.wire = wire;
     a.seg_minmax = seg_minmax;
     a.ntiles = ntiles;
+    a.nseg = nseg;
     a.ef_scale = ef_scale;
     hipStream_t st = as_stream(stream);
     const int64_t blocks = pf_grid(ntiles, bpc);
