@@ -78,9 +78,10 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
     uint64_t seed, const float *__restrict__ cb, uint8_t *__restrict__ wire) {
-    __shared__ __attribute__((aligned(16))) float s_cb[256 * 16];
+    // rows 20 floats apart: an odd number of 16-byte units spreads the random-row gathers over the banks
+    __shared__ __attribute__((aligned(16))) float s_cb[256 * 20];
     for (int i = threadIdx.x; i < 256 * 16 / 4; i += BT_THREADS)
-        reinterpret_cast<f32x4 *>(s_cb)[i] = reinterpret_cast<const f32x4 *>(cb)[i];
+        *reinterpret_cast<f32x4 *>(s_cb + (i >> 2) * 20 + 4 * (i & 3)) = reinterpret_cast<const f32x4 *>(cb)[i];
     __syncthreads();
     const float s = (float)(1 << n_bit), smax = s - 1.0f;
     const int64_t total = ntiles * 64 * 4;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_kernel(
         n = n / s;
         n = n + lb;
         const int code = wire[rec[3] + local];
-        const f32x4 c = *reinterpret_cast<const f32x4 *>(s_cb + code * 16 + 4 * q);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(s_cb + code * 20 + 4 * q);
         const f32x4 v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(rec[0]) + local * 16 + 4 * q);
         f32x4 e;
         e[0] = v[0] - c[0] * n;
@@ -135,9 +136,10 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
     float *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float s_cb[256 * 16];
+    // rows 20 floats apart: an odd number of 16-byte units spreads the random-row gathers over the banks
+    __shared__ __attribute__((aligned(16))) float s_cb[256 * 20];
     for (int i = threadIdx.x; i < 256 * 16 / 4; i += BT_THREADS)
-        reinterpret_cast<f32x4 *>(s_cb)[i] = reinterpret_cast<const f32x4 *>(cb)[i];
+        *reinterpret_cast<f32x4 *>(s_cb + (i >> 2) * 20 + 4 * (i & 3)) = reinterpret_cast<const f32x4 *>(cb)[i];
     __syncthreads();
     const float s = (float)(1 << n_bit);
     const float fR = (float)R;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_kernel(
             float n = (float)p[rec[4] + local] * range;   // prob_scalar:31-32, unfused
             n = n / s;
             n = n + lb;
-            const f32x4 c = *reinterpret_cast<const f32x4 *>(s_cb + code * 16 + 4 * q);
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(s_cb + code * 20 + 4 * q);
             f32x4 dec;
             dec[0] = c[0] * n;
             dec[1] = c[1] * n;

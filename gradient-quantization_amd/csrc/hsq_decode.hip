@@ -8,15 +8,24 @@
 // Write-bound: 4 B per output element + 2R/d B of payload reads; the codebook is
 // staged in LDS once per workgroup.  -ffp-contract=off keeps mul / div / add unfused.
 #include "gq_common.hpp"
+#include <type_traits>
 
 namespace gq {
 
 constexpr int DEC_THREADS = 256;
 
+// LDS row stride (floats) of a staged codebook.  Rows of d floats laid end to end start on very few
+// bank positions (d = 16: 64 B rows, the 128 B bank window has TWO), and a gather of 16 random rows
+// per ds_read_b128 then serialises ~8 ways (PMC: 16 conflict cycles per LDS instruction, LDS stalled 61 %
+// of an R = 8 decode).  An odd number of 16-byte units per row spreads the row starts over all positions.
+__host__ __device__ inline int cb_row_stride(int d) { return ((d >> 2) & 1) ? d : d + 4; }
+
+// s = 2^n_bit, so the reference's division by s is an exact scaling: multiplying by inv_s = 2^-n_bit
+// gives the same bits for every input and saves the IEEE division sequence per payload.
 template <typename LevelT>
-__device__ __forceinline__ float level_to_norm(LevelT l, float lb, float range, float s) {
+__device__ __forceinline__ float level_to_norm(LevelT l, float lb, float range, float inv_s) {
     float t = (float)l * range;
-    t = t / s;
+    t = t * inv_s;
     return t + lb;
 }
 template <>
@@ -32,12 +41,13 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_v4_kernel(
     int d, int K, int n_bit, float *__restrict__ out) {
     extern __shared__ float s_cb[];
     if (LDS_CB) {
-        for (int i = threadIdx.x; i < K * d; i += DEC_THREADS) s_cb[i] = cb[i];
+        const int rs = cb_row_stride(d);
+        for (int i = threadIdx.x; i < K * d; i += DEC_THREADS) s_cb[(i / d) * rs + (i % d)] = cb[i];
         __syncthreads();
     }
     const int q_per = d >> 2;
     const int64_t total = M * q_per;
-    const float s = (float)(1 << (n_bit & 31));
+    const float s = 1.0f / (float)(1 << (n_bit & 31));   // inv_s, see level_to_norm
     const float fR = (float)R;
     const int64_t stride = (int64_t)gridDim.x * DEC_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * DEC_THREADS + threadIdx.x; i < total; i += stride) {
@@ -49,7 +59,7 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_v4_kernel(
             const float lb = lb_ub ? lb_ub[r * lbub_stride] : 0.0f;
             const float range = lb_ub ? (lb_ub[r * lbub_stride + 1] - lb) : 0.0f;
             const float n = level_to_norm<LevelT>(levels[(int64_t)r * level_stride + m], lb, range, s);
-            const float *row = (LDS_CB ? s_cb : cb) + (int64_t)code * d + 4 * q;
+            const float *row = LDS_CB ? s_cb + code * cb_row_stride(d) + 4 * q : cb + (int64_t)code * d + 4 * q;
             const f32x4 c = *reinterpret_cast<const f32x4 *>(row);
             f32x4 dec;
             dec[0] = c[0] * n;
@@ -75,6 +85,86 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_v4_kernel(
     }
 }
 
+// d = 16 with byte codes and byte levels (the BASELINE wire).  With R payloads the decode is a gather
+// of R codebook rows per subvector, and from a plain LDS image that gather runs at a sixth of the LDS
+// rate (PMC: 16 conflict cycles per ds_read_b128; R = 8 took 69-80 us for 100 MB).  Here
+//  * one thread produces the same quarter (4 floats) of FOUR consecutive subvectors: two dword loads
+//    per payload bring its 4 codes and 4 levels;
+//  * the codebook is staged FOUR times, row r copy c at byte r*256 + c*64.  A ds_read_b128 is served in
+//    four fixed groups of 16 lanes (MI355X_MICROARCH.md, LDS): the four 4-lane teams of a group
+//    (one subvector each, 64 contiguous bytes) read copies 0..3, so every group covers the 64 banks
+//    exactly once whatever the codes are: conflict-free, 256 B/clk;
+//  * packed f32 multiplies / adds (separate roundings, as the reference).
+// Same arithmetic and summation order as the kernels above.
+constexpr int DEC16_THREADS = 1024;
+
+__global__ __launch_bounds__(DEC16_THREADS) void hsq_decode_sum_d16u8_kernel(
+    const uint8_t *__restrict__ codes, const uint8_t *__restrict__ levels, const float *__restrict__ lb_ub,
+    int64_t code_stride, int64_t level_stride, int64_t lbub_stride, const float *__restrict__ cb, int R, int64_t M,
+    int K, int n_bit, float *__restrict__ out) {
+    extern __shared__ float s_cb[];   // [K][4 copies][16]
+    for (int i = threadIdx.x; i < K * 16; i += DEC16_THREADS) {   // (row, copy, quarter)
+        const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
+        *reinterpret_cast<f32x4 *>(s_cb + row * 64 + c * 16 + 4 * q) = *reinterpret_cast<const f32x4 *>(cb + row * 16 + 4 * q);
+    }
+    __syncthreads();
+    const float inv_s = 1.0f / (float)(1 << (n_bit & 31));
+    const float fR = (float)R;
+    const int q = threadIdx.x & 3;
+    const float *const my_cb = s_cb + ((threadIdx.x >> 3) & 3) * 16 + 4 * q;   // this lane's copy and quarter
+    const int64_t total = ((M + 3) >> 2) * 4;   // (group of 4 subvectors, quarter) items
+    const int64_t stride = (int64_t)gridDim.x * DEC16_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * DEC16_THREADS + threadIdx.x; i < total; i += stride) {
+        const int64_t m0 = (i >> 2) * 4;
+        const int nv = (M - m0) < 4 ? (int)(M - m0) : 4;
+        f32x4 acc[4];
+        auto payload = [&](int r, auto first) {   // first: payload 0 initialises, the others accumulate
+            const uint8_t *cp = codes + (int64_t)r * code_stride + m0;
+            const uint8_t *lp = levels + (int64_t)r * level_stride + m0;
+            unsigned c4, l4;
+            if (nv == 4) {
+                c4 = *reinterpret_cast<const unsigned *>(cp);
+                l4 = *reinterpret_cast<const unsigned *>(lp);
+            } else {
+                c4 = l4 = 0;
+                for (int k = 0; k < nv; ++k) {
+                    c4 |= (unsigned)cp[k] << (8 * k);
+                    l4 |= (unsigned)lp[k] << (8 * k);
+                }
+            }
+            const float lb = lb_ub[r * lbub_stride];
+            const float range = lb_ub[r * lbub_stride + 1] - lb;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float n = level_to_norm<unsigned>((l4 >> (8 * k)) & 255u, lb, range, inv_s);
+                const f32x4 c = *reinterpret_cast<const f32x4 *>(my_cb + ((c4 >> (8 * k)) & 255u) * 64);
+                const f32x4 n4 = {n, n, n, n};
+                const f32x4 dec = c * n4;
+                if constexpr (decltype(first)::value) {
+                    acc[k] = dec;
+                } else {
+                    acc[k] = acc[k] + dec;
+                }
+            }
+        };
+        payload(0, std::true_type{});
+        for (int r = 1; r < R; ++r) payload(r, std::false_type{});
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < nv) {
+                f32x4 a = acc[k];
+                if (R > 1) {
+                    a[0] = a[0] / fR;
+                    a[1] = a[1] / fR;
+                    a[2] = a[2] / fR;
+                    a[3] = a[3] / fR;
+                }
+                *reinterpret_cast<f32x4 *>(out + (m0 + k) * 16 + 4 * q) = a;
+            }
+        }
+    }
+}
+
 // any d: one thread per output float.
 template <typename CodeT, typename LevelT>
 __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_scalar_kernel(
@@ -82,7 +172,7 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_scalar_kernel(
     int64_t code_stride, int64_t level_stride, int64_t lbub_stride, const float *__restrict__ cb, int R, int64_t M,
     int d, int n_bit, float *__restrict__ out) {
     const int64_t total = M * d;
-    const float s = (float)(1 << (n_bit & 31));
+    const float s = 1.0f / (float)(1 << (n_bit & 31));   // inv_s, see level_to_norm
     const float fR = (float)R;
     const int64_t stride = (int64_t)gridDim.x * DEC_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * DEC_THREADS + threadIdx.x; i < total; i += stride) {
@@ -107,12 +197,38 @@ static int launch_decode(const CodeT *codes, const LevelT *levels, const float *
                          int64_t bs, const float *cb, int R, int64_t M, int d, int K, int n_bit, float *out,
                          hipStream_t st) {
     const int64_t cap = (int64_t)cu_count() * 8;
+    if constexpr (sizeof(CodeT) == 1 && sizeof(LevelT) == 1) {
+        const uintptr_t align = reinterpret_cast<uintptr_t>(codes) | reinterpret_cast<uintptr_t>(levels) |
+                                (uintptr_t)cs | (uintptr_t)ls;
+        if (d == 16 && K <= 256 && lb_ub && (align & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(cb) & 15) == 0 && M >= (int64_t)K) {
+            const int64_t total = ((M + 3) >> 2) * 4;
+            const size_t lds = (size_t)K * 64 * sizeof(float);   // four copies of every row
+            static const int bpc = [] {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_d16u8_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                (void)hipGetLastError();
+                int n = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hsq_decode_sum_d16u8_kernel, DEC16_THREADS,
+                                                                 (size_t)256 * 64 * sizeof(float)) != hipSuccess || n < 1)
+                    n = 1;
+                return n;
+            }();
+            int64_t blocks = (total + DEC16_THREADS - 1) / DEC16_THREADS;
+            if (blocks > (int64_t)cu_count() * bpc) blocks = (int64_t)cu_count() * bpc;
+            hipLaunchKernelGGL(hsq_decode_sum_d16u8_kernel, dim3((unsigned)blocks), dim3(DEC16_THREADS), lds, st,
+                               reinterpret_cast<const uint8_t *>(codes), reinterpret_cast<const uint8_t *>(levels),
+                               lb_ub, cs, ls, bs, cb, R, M, K, n_bit, out);
+            GQ_CHECK_LAUNCH("gq_hsq_decode_sum");
+            return GQ_OK;
+        }
+    }
     if ((d & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(cb) & 15) == 0) {
         const int64_t total = M * (d >> 2);
         int64_t blocks = (total + DEC_THREADS - 1) / DEC_THREADS;
         if (blocks > cap) blocks = cap;
         if (blocks < 1) blocks = 1;
-        const size_t lds = (size_t)K * d * sizeof(float);
+        const size_t lds = (size_t)K * cb_row_stride(d) * sizeof(float);
         // stage the codebook in LDS when it fits and the launch is big enough to amortise it
         if (lds <= 64 * 1024 && total >= (int64_t)K * d) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_v4_kernel<CodeT, LevelT, true>), dim3((unsigned)blocks),
