@@ -442,7 +442,12 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
     int dpad = 0, chunk_rows = 0;
     size_t lds_bytes = 0;
     const bool lds_ok = lds_plan(d, K, &dpad, &chunk_rows, &lds_bytes);
-    if (impl == 0) impl = (d == 16 && K == 256) ? 4 : (lds_ok ? 5 : 2);
+    const bool pf_ok = K == 256 && (d == 8 || d == 16 || d == 32) && (reinterpret_cast<uintptr_t>(grad) & 15) == 0;
+    if (impl == 0) impl = pf_ok ? 4 : (lds_ok ? 5 : 2);
+    if (impl == 4 && K == 256 && (d == 8 || d == 32)) {
+        if (!pf_ok) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: grad must be 16-byte aligned");
+        return launch_encode_pfd<CodeT>(grad, codebook, M, d, codes, u, partials, st);
+    }
     if (impl == 5) {
         if (!lds_ok) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: impl 5 needs d <= 128 (d=%d K=%d)", d, K);
         static bool attr_set = false;
@@ -460,7 +465,7 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
         return GQ_OK;
     }
     if (impl == 4) {
-        if (d != 16 || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 4 needs d=16, K=256");
+        if (d != 16 || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 4 needs K=256 and d in {8, 16, 32}");
         if ((reinterpret_cast<uintptr_t>(grad) & 15) != 0)
             return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: grad must be 16-byte aligned");
         return launch_encode_pf<CodeT>(grad, codebook, M, codes, u, partials, st);

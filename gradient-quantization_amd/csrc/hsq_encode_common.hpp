@@ -86,5 +86,9 @@ static int resident_blocks_per_cu(KernelT kernel, int threads, size_t lds) {
 template <typename CodeT>
 int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *workspace,
                      hipStream_t st);
+// hsq_encode_pfd.hip: the same for d = 8 and d = 32 (K = 256).
+template <typename CodeT>
+int launch_encode_pfd(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u,
+                      float *workspace, hipStream_t st);
 
 }  // namespace gq

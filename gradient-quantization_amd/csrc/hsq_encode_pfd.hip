@@ -1,0 +1,371 @@
+// HSQ encode, K = 256, sub-dimension D = 8 or 32: the bf16x3 matrix-core prefilter + exact f32 rescoring
+// of hsq_encode_pf.hip (read its header first: same error bound, same keys, same exactness argument) for
+// the other sub-dimensions the reference's CLI reaches with 256 codewords (main.py's default is
+// --c-dim 32).  Single tensor only.  What differs from the d = 16 kernel:
+//   * a chain is 3 * KS v_mfma_f32_32x32x16_bf16 with KS = ceil(D / 16) k-steps; D = 8 feeds zeros for the
+//     upper half of the one k-step;
+//   * the A fragments (codebook hi / lo bf16 parts) do not fit the register file next to everything else
+//     for D = 32, so they live in LDS as ready-made fragments -- s_a[(rb * KS + s) * 2 + part][lane], one
+//     conflict-free ds_read_b128 each -- and are fetched one row block ahead; the chains run
+//     (rb, block 0), (rb, block 1) so that both blocks share them;
+//   * the error bound E = 2^-15 max||c||_1 max|v_j| still holds: dropped terms 3 * 2^-18 and, for the 96
+//     accumulated products of D = 32, accumulate roundings <= ~2^-17.4, both relative to sum |c_j||v_j|.
+// A tile is 64 subvectors (64 * D floats); scores per gradient element are 256 / D, so D = 32 costs half of
+// D = 16 per element and D = 8 twice as much.
+#include "hsq_pf_common.hpp"
+
+namespace gq {
+
+struct PfdArgs {
+    const float *grad;
+    int64_t M;
+    void *codes;
+    float *u;
+    const float *cb;
+    float *ws;
+    int64_t split_tile;   // pf_split()
+};
+
+// D = 32 wants ~360 registers per lane (two tiles of 64 x 32 floats in flight, fragments of both, two
+// accumulators): at two waves per SIMD it spilled 112 VGPRs and ran 101 us per 25 M elements; at one wave
+// per SIMD (512 registers) nothing spills and the in-wave MFMA / key-operation pipeline carries it: 68 us.
+template <typename CodeT, int D>
+__global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_kernel(const PfdArgs a) {
+    static_assert(D == 8 || D == 32, "built for D = 8 and D = 32 (D = 16: hsq_encode_pf.hip)");
+    constexpr int KS = D > 16 ? D / 16 : 1;    // MFMA k-steps per chain
+    constexpr int QS = 4 * D + 4;              // LDS floats per group of 4 codewords: an odd number of 16-byte units
+    const float *__restrict__ cb = a.cb;
+    float *__restrict__ ws = a.ws;
+    float *__restrict__ u = a.u;
+    const float *__restrict__ grad = a.grad;
+    CodeT *__restrict__ codes = static_cast<CodeT *>(a.codes);
+    const int64_t M = a.M;
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *const s_cb = lds;                                                         // [64 groups][QS]
+    bf16x8 *const s_a = reinterpret_cast<bf16x8 *>(lds + 64 * QS);                   // [8 * KS * 2][64 lanes]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+
+    // exact f32 codebook, groups of 4 codewords interleaved: s_cb[(k>>2)*QS + 4*e + (k&3)] = c[k][e]
+    for (int i = threadIdx.x; i < 256 * D; i += ENC_THREADS) {
+        const int k = i / D, e = i % D;
+        s_cb[(k >> 2) * QS + 4 * e + (k & 3)] = cb[i];
+    }
+    // A fragments of v_mfma_f32_32x32x16_bf16: lane (row j, half h) of k-step s holds
+    // c[rb*32 + j][16 s + 8 h .. + 7] (zeros beyond D), split into bf16 hi and lo
+    for (int i = threadIdx.x; i < 8 * KS * 64; i += ENC_THREADS) {
+        const int l = i & 63, s = (i >> 6) % KS, rb = i / (64 * KS);
+        const int row = rb * 32 + (l & 31), e0 = 16 * s + 8 * (l >> 5);
+        f32x4 q0 = {0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0;
+        if (e0 < D) {
+            q0 = *reinterpret_cast<const f32x4 *>(cb + row * D + e0);
+            q1 = *reinterpret_cast<const f32x4 *>(cb + row * D + e0 + 4);
+        }
+        bf16x8 hi, lo;
+        split8(q0, q1, hi, lo);
+        s_a[((rb * KS + s) * 2 + 0) * 64 + l] = hi;
+        s_a[((rb * KS + s) * 2 + 1) * 64 + l] = lo;
+    }
+    __syncthreads();
+    // the error bound scales with max_k ||c_k||_1: measured, not assumed
+    __shared__ float s_c1[ENC_WAVES];
+    {
+        float l1 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < D; ++e) l1 += fabsf(s_cb[(threadIdx.x >> 2) * QS + 4 * e + (threadIdx.x & 3)]);
+        l1 = wave_max(l1);
+        if (lane == 0) s_c1[wave] = l1;
+    }
+    __syncthreads();
+    float c1 = s_c1[0];
+#pragma unroll
+    for (int w = 1; w < ENC_WAVES; ++w) c1 = fmaxf(c1, s_c1[w]);
+    const float err_scale = c1 * ERR_SCALE;  // E = max|v_j| * err_scale
+
+    // static split of the tiles between the two halves of the grid (pf_split)
+    const int64_t ntiles = (M + 63) >> 6;
+    int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
+    int64_t t = (int64_t)blockIdx.x * ENC_WAVES + wave;
+    int64_t tile_end = ntiles;
+    if (a.split_tile >= 0) {
+        const int64_t half = gridDim.x / 2;
+        nw = half * ENC_WAVES;
+        if ((int64_t)blockIdx.x < half) {
+            tile_end = a.split_tile;
+        } else {
+            t = a.split_tile + ((int64_t)blockIdx.x - half) * ENC_WAVES + wave;
+        }
+    }
+    int *const counter = ws_counter(ws);
+    int *const worklist = ws_worklist(ws);
+
+    // tile data: lane (j, h) holds, for block b and k-step s, floats [16 s + 8 h, + 8) of subvector 32 b + j
+    auto load_tile = [&](int64_t tile, f32x4 (&dst)[2][KS][2]) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            int64_t sv = tile * 64 + b * 32 + j;
+            sv = sv < M ? sv : M - 1;  // tail: re-read the last subvector, result is masked
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (16 * s + 8 * h < D) {
+                    const f32x4 *p = reinterpret_cast<const f32x4 *>(grad + sv * D + 16 * s + 8 * h);
+                    dst[b][s][0] = p[0];
+                    dst[b][s][1] = p[1];
+                } else {
+                    dst[b][s][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    dst[b][s][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            }
+        }
+    };
+    auto load_a = [&](int rb, bf16x8 (&hi)[KS], bf16x8 (&lo)[KS]) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            hi[s] = s_a[((rb * KS + s) * 2 + 0) * 64 + lane];
+            lo[s] = s_a[((rb * KS + s) * 2 + 1) * 64 + lane];
+        }
+    };
+
+    float lmin = INFINITY, lmax = -INFINITY;
+    f32x4 cur[2][KS][2], nxt[2][KS][2];
+    bf16x8 vh[2][KS], vl[2][KS];
+    if (t < tile_end) {
+        load_tile(t, cur);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) split8(cur[b][s][0], cur[b][s][1], vh[b][s], vl[b][s]);
+    }
+    for (; t < tile_end; t += nw) {
+        const int64_t tn = t + nw;
+        if (tn < tile_end) load_tile(tn, nxt);  // prefetch the next tile
+
+        // ---- prefilter: 16 chains in the order (rb, block 0), (rb, block 1); top-2 GROUP keys per
+        // (block, row-block half).  The MFMAs of chain c+1 sit between the key operations of chain c.
+        unsigned best[4] = {0, 0, 0, 0}, second[4] = {0, 0, 0, 0};
+        unsigned vmask = KEY_MASK;
+        asm volatile("" : "+v"(vmask));  // keep the mask in a VGPR: v_and_or with an SGPR operand issues slower
+        auto group_key = [&](const f32x16 &x, int rb, int q) {   // group q = registers 4q..4q+3 = four consecutive rows
+            return and_or(__float_as_uint(absmax4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3])), vmask,
+                          (unsigned)((rb & 3) * 4 + q));
+        };
+        auto track = [&](int trk, unsigned k0, unsigned k1) {
+            second[trk] = max(second[trk], med3u(best[trk], k0, k1));
+            best[trk] = max3u(best[trk], k0, k1);
+        };
+        bf16x8 ahi[2][KS], alo[2][KS];   // A fragments, double-buffered by row-block parity
+        load_a(0, ahi[0], alo[0]);
+        f32x16 acc = {0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[0][s], vh[0][s], acc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[0][s], vl[0][s], acc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[0][s], vh[0][s], acc, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int rb = c >> 1, blk = c & 1, trk = blk * 2 + (rb >> 2);
+            if (blk == 0 && rb + 1 < 8) load_a(rb + 1, ahi[(rb + 1) & 1], alo[(rb + 1) & 1]);   // a row block ahead
+            if (c + 1 < 16) {
+                const int nr = (c + 1) >> 1, nb = (c + 1) & 1, ab = nr & 1;
+                f32x16 nacc = {0};
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[ab][s], vh[nb][s], nacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                track(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ab][s], vl[nb][s], nacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                track(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ab][s], vh[nb][s], nacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = nacc;
+            } else {
+                track(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
+                track(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
+            }
+        }
+
+        // ---- per block: merge the two trackers; best group's first codeword and the bound on the rest ----
+        int k1[2];
+        unsigned s2[2], bk[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const unsigned bA = best[2 * blk], bB = best[2 * blk + 1];
+            const bool useB = (bB & KEY_MASK) > (bA & KEY_MASK);
+            const unsigned bw = useB ? bB : bA, bl = useB ? bA : bB;
+            const int gid = (int)(bw & 31u);
+            k1[blk] = ((gid >> 2) + (useB ? 4 : 0)) * 32 + 8 * (gid & 3) + 4 * h;   // rows k1 .. k1+3 (registers 4q..4q+3)
+            s2[blk] = max3u(second[2 * blk], second[2 * blk + 1], bl) | 31u;         // upper end of its bucket
+            bk[blk] = bw;
+        }
+
+        // ---- this lane's own full subvector (tile subvector `lane`): swaps of the B loads ----
+        float vf[D];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = cur[0][s][e >> 2][e & 3];   // block 0: floats 16 s + 8 h + e of subvector j
+                float y = cur[1][s][e >> 2][e & 3];   // block 1
+                swap32(x, y);                          // x = floats 16 s + e, y = floats 16 s + 8 + e of subvector `lane`
+                vf[(16 * s + e) % D] = x;
+                if (16 * s + 8 + e < D) vf[(16 * s + 8 + e) % D] = y;
+            }
+        }
+        // cross-half exchange of the candidates: [0] = lower-half rows, [1] = upper-half rows
+        swap32(k1[0], k1[1]);
+        {
+            int a0 = (int)s2[0], a1 = (int)s2[1];
+            swap32(a0, a1);
+            s2[0] = (unsigned)a0;
+            s2[1] = (unsigned)a1;
+            int b0 = (int)bk[0], b1 = (int)bk[1];
+            swap32(b0, b1);
+            bk[0] = (unsigned)b0;
+            bk[1] = (unsigned)b1;
+        }
+
+        // ---- exact rescoring of the better of the two halves' best groups (4 codewords; the
+        // reference's fmaf chain); the other half's best group joins the bound on the rest
+        const bool pick1 = (bk[1] & KEY_MASK) > (bk[0] & KEY_MASK);
+        const int kc = pick1 ? k1[1] : k1[0];
+        const unsigned rest = max3u(s2[0], s2[1], (pick1 ? bk[0] : bk[1]) | 31u);
+        const f32x4 p4 = exact_score_quad<D>(s_cb + (kc >> 2) * QS, vf);   // kc is a multiple of 4: one group
+        float val = p4[0];
+        int idx = kc;
+        take_if_greater(val, idx, p4[1], kc + 1);
+        take_if_greater(val, idx, p4[2], kc + 2);
+        take_if_greater(val, idx, p4[3], kc + 3);
+
+        float vmax = 0.0f;
+#pragma unroll
+        for (int e = 0; e < D; e += 2) vmax = fmaxf(fmaxf(fabsf(vf[e]), fabsf(vf[e + 1])), vmax);
+        const float E = vmax * err_scale;
+        const float others = __uint_as_float(rest);  // >= every s~ outside the rescored group
+        bool safe = (others + E < fabsf(val)) && (vmax >= 8.27e-25f) && (vmax <= 1.0e30f);
+        if (vmax == 0.0f) {  // all-zero subvector: every score is +0 -> first index, u = +0
+            safe = true;
+            val = 0.0f;
+            idx = 0;
+        }
+        // NaN anywhere makes the comparisons false -> not safe -> exact path
+
+        const int64_t sv = t * 64 + lane;
+        const bool valid = sv < M;
+
+        // consume the prefetched tile BEFORE this tile's stores are issued (hsq_encode_pf.hip)
+        if (tn < tile_end) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    split8(nxt[b][s][0], nxt[b][s][1], vh[b][s], vl[b][s]);
+                    cur[b][s][0] = nxt[b][s][0];
+                    cur[b][s][1] = nxt[b][s][1];
+                    if (KS > 1) __builtin_amdgcn_sched_barrier(0);   // one fragment's temporaries at a time (register pressure)
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- exact fix-up, in place and wave-wide, for the few subvectors the bound could not settle
+        uint64_t todo = __ballot(valid && !safe);
+        while (todo) {
+            const int fl = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            float bv = 0.0f;
+            int bi = lane;
+            // rare path: keep it light on registers (one codeword at a time, 8 LDS reads in flight)
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                const int k = q * 64 + lane;
+                const float *row = s_cb + (k >> 2) * QS + (k & 3);
+                float sc = 0.0f;
+#pragma unroll
+                for (int e = 0; e < D; ++e) {
+                    if (e % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+                    const float we = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vf[e]), fl));
+                    sc = __fmaf_rn(row[4 * e], we, sc);
+                }
+                if (q == 0) {
+                    bv = sc;
+                } else {
+                    take_if_greater(bv, bi, sc, k);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                const float a0 = fabsf(bv), a1 = fabsf(ov);
+                const bool take = (a1 > a0) || (a1 == a0 && oi < bi);
+                bv = take ? ov : bv;
+                bi = take ? oi : bi;
+            }
+            if (lane == fl) {
+                val = bv;
+                idx = bi;
+            }
+            if (lane == 0) {   // diagnostics only: which subvectors took this path
+                const int pos = atomicAdd(counter, 1);
+                worklist[pos] = (int)(t * 64 + fl);
+            }
+        }
+
+        if (valid) {
+            codes[sv] = (CodeT)idx;
+            u[sv] = val;
+            lmin = fminf(lmin, val);
+            lmax = fmaxf(lmax, val);
+        }
+    }
+    pf_finish_minmax<true>(lmin, lmax, ws);
+}
+
+template <typename CodeT, int D>
+static int launch_pfd(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *ws,
+                      hipStream_t st) {
+    constexpr int KS = D > 16 ? D / 16 : 1;
+    constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
+    static const int bpc = [] {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<CodeT, D>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipGetLastError();
+        return resident_blocks_per_cu(hsq_encode_pfd_kernel<CodeT, D>, ENC_THREADS, lds);
+    }();
+    PfdArgs a = {};
+    a.grad = grad;
+    a.M = M;
+    a.codes = codes;
+    a.u = u;
+    a.cb = codebook;
+    a.ws = ws;
+    const int64_t ntiles = (M + 63) / 64;
+    const int64_t blocks = pf_grid(ntiles, bpc);
+    a.split_tile = pf_split(ntiles, blocks, bpc);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<CodeT, D>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds,
+                       st, a);
+    GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter, d = 8 / 32)");
+    return GQ_OK;
+}
+
+template <typename CodeT>
+int launch_encode_pfd(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u, float *ws,
+                      hipStream_t st) {
+    if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
+    if (d == 8) return launch_pfd<CodeT, 8>(grad, codebook, M, codes, u, ws, st);
+    if (d == 32) return launch_pfd<CodeT, 32>(grad, codebook, M, codes, u, ws, st);
+    return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: the d = 8 / 32 prefilter kernel was asked for d = %d", d);
+}
+
+template int launch_encode_pfd<uint8_t>(const float *, const float *, int64_t, int, uint8_t *, float *, float *,
+                                        hipStream_t);
+template int launch_encode_pfd<int32_t>(const float *, const float *, int64_t, int, int32_t *, float *, float *,
+                                        hipStream_t);
+
+}  // namespace gq

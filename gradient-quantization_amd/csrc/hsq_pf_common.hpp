@@ -1,0 +1,173 @@
+// Shared pieces of the bf16x3-prefilter encode kernels (hsq_encode_pf.hip: d = 16; hsq_encode_pfd.hip:
+// d = 8 and d = 32): bf16 hi/lo splitting, key operations, the exact rescoring of a codeword group and the
+// end-of-kernel (lb, ub) fold.  Files that include this are compiled with -fno-honor-nans (build.py).
+#pragma once
+#include "hsq_encode_common.hpp"
+
+namespace gq {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr unsigned KEY_MASK = 0x7FFFFFE0u;  // sign + 5 low mantissa bits make room for the group id (2^-18 relative)
+constexpr float ERR_SCALE = 1.0025f * 3.0517578125e-05f;  // 2^-15 (x ||c||_1 x max|v_j|), analytic bound ~0.44 of it
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// two f32 -> packed bf16 pair (round to nearest even), one VALU op on gfx950
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// x = hi + lo + O(2^-18 x): hi = bf16(x), lo = bf16(x - hi)   (x - hi is exact in f32)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, unsigned &lo) {
+    hi = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(hi << 16);
+    const float r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
+    lo = cvt_pk_bf16(r0, r1);
+}
+// 8 consecutive floats -> the hi and lo bf16x8 MFMA fragments
+__device__ __forceinline__ void split8(const f32x4 &q0, const f32x4 &q1, bf16x8 &hi, bf16x8 &lo) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split_pair(q0[0], q0[1], h0, l0);
+    split_pair(q0[2], q0[3], h1, l1);
+    split_pair(q1[0], q1[1], h2, l2);
+    split_pair(q1[2], q1[3], h3, l3);
+    const u32x4 H = {h0, h1, h2, h3}, L = {l0, l1, l2, l3};
+    hi = __builtin_bit_cast(bf16x8, H);
+    lo = __builtin_bit_cast(bf16x8, L);
+}
+
+__device__ __forceinline__ unsigned and_or(unsigned x, unsigned mask, unsigned c) { return (x & mask) | c; }
+// one VALU op each (hipcc does not reliably form these from min/max compositions)
+__device__ __forceinline__ unsigned max3u(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned med3u(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// max(|a|,|b|,|c|,|d|) straight on MFMA results.  Plain C so that hipcc inserts the MFMA -> VALU
+// wait states itself (it pads nothing around inline asm: reading an accumulator from an asm
+// statement returned stale scores).  This file is compiled with -fno-honor-nans (build.py):
+// without it every fmaxf on an MFMA output gets a NaN-canonicalising v_max_f32 x,x,x in front
+// (6 VALU ops per group instead of 2).  NaN gradients are undefined input either way.
+__device__ __forceinline__ float absmax4(float a, float b, float c, float d) {
+    return fmaxf(fmaxf(fmaxf(fabsf(a), fabsf(b)), fabsf(c)), fabsf(d));   // v_max3_f32 + v_max_f32
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Exact reference arithmetic for FOUR consecutive codewords at once: p = fmaf chain over j
+// ascending, from +0, as packed f32 FMAs (v_pk_fma_f32 rounds each half like v_fma_f32).
+// `quad` points at the group-interleaved LDS image: (c0[j], c1[j], c2[j], c3[j]) for j = 0..D-1.
+template <int D>
+__device__ __forceinline__ f32x4 exact_score_quad(const float *__restrict__ quad, const float (&v)[D]) {
+    f32x2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
+#pragma unroll
+    for (int jj = 0; jj < D; ++jj) {
+        // at most 16 row reads (64 VGPRs) in flight: left alone, the scheduler hoists all D of them
+        if (jj > 0 && jj % 16 == 0) __builtin_amdgcn_sched_barrier(0);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(quad + 4 * jj);
+        const f32x2 c01 = {c[0], c[1]}, c23 = {c[2], c[3]};
+        const f32x2 vv = {v[jj], v[jj]};
+        a01 = __builtin_elementwise_fma(c01, vv, a01);
+        a23 = __builtin_elementwise_fma(c23, vv, a23);
+    }
+    const f32x4 r = {a01[0], a01[1], a23[0], a23[1]};
+    return r;
+}
+
+// End of a single-tensor prefilter kernel: per-workgroup (min,max) of u -> workspace; the LAST workgroup
+// to arrive (ticket counter; pairs published with agent-scope atomic stores and read back with
+// agent-scope atomic loads -- cdna_hip_programming.md G16) folds them into the final pair at slot 0,
+// raises the `final` flag the level kernel looks at and re-zeroes the counters: no second launch, no
+// memset node.  `fold` = false (batched form: the per-tensor (min,max) went out by atomics) only resets
+// the counters.  Called by all threads of the workgroup.
+template <bool FOLD>
+__device__ __forceinline__ void pf_finish_minmax(float lmin, float lmax, float *__restrict__ ws) {
+    __shared__ float s_min[ENC_WAVES], s_max[ENC_WAVES];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int *const counter = ws_counter(ws);
+    {
+        const float lo = wave_min(lmin), hi = wave_max(lmax);
+        if (lane == 0) {
+            s_min[wave] = lo;
+            s_max[wave] = hi;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (FOLD) {
+            float lo = s_min[0], hi = s_max[0];
+#pragma unroll
+            for (int w = 1; w < ENC_WAVES; ++w) {
+                lo = fminf(lo, s_min[w]);
+                hi = fmaxf(hi, s_max[w]);
+            }
+            float *slot = ws + 2 * blockIdx.x;
+            __hip_atomic_store(slot, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left before the ticket is drawn
+        }
+        const int ticket = __hip_atomic_fetch_add(&counter[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (ticket == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    float lo = INFINITY, hi = -INFINITY;
+    if (FOLD) {
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += ENC_THREADS) {
+            lo = fminf(lo, __hip_atomic_load(ws + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            hi = fmaxf(hi, __hip_atomic_load(ws + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+    }
+    __syncthreads();  // everyone has read pair 0 and the LDS scratch is free again
+    if (lane == 0) {
+        s_min[wave] = lo;
+        s_max[wave] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (FOLD) {
+#pragma unroll
+            for (int w = 1; w < ENC_WAVES; ++w) {
+                lo = fminf(lo, s_min[w]);
+                hi = fmaxf(hi, s_max[w]);
+            }
+            ws[0] = lo;
+            ws[1] = hi;
+            counter[2] = 1;  // pair 0 holds the final (lb, ub)
+        }
+        counter[0] = 0;  // fix-up log empty for the next call
+        counter[1] = 0;
+    }
+}
+
+// Persistent grid of a prefilter kernel and the static split of its tiles: the first-dispatched half of
+// the grid gets `permille` of the tiles when exactly two workgroups share every CU (of the two, the older
+// one wins VALU arbitration and runs ~1.6x faster; profiles/r01_e_pf_kernel_stamps.txt); -1 = even split.
+static inline int64_t pf_grid(int64_t ntiles, int bpc) {
+    int64_t blocks = (ntiles + ENC_WAVES - 1) / ENC_WAVES;
+    int64_t cap = (int64_t)cu_count() * bpc;
+    if (cap > GQ_MAIN_PARTIALS) cap = GQ_MAIN_PARTIALS;
+    if (blocks > cap) blocks = cap;
+    return blocks < 1 ? 1 : blocks;
+}
+static inline int64_t pf_split(int64_t ntiles, int64_t blocks, int bpc) {
+    static const int permille = [] {
+        const char *e = getenv("GQ_PF_SPLIT");
+        return e ? atoi(e) : 625;
+    }();
+    if (permille <= 0 || bpc != 2 || blocks != (int64_t)cu_count() * 2 || ntiles < blocks * ENC_WAVES * 4) return -1;
+    return (ntiles * permille) / 1000;
+}
+
+}  // namespace gq

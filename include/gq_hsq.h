@@ -77,10 +77,10 @@ int gq_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, in
 /* Same, with the kernel chosen explicitly (diagnostics / cross-checks; results are
  * identical for every impl):  0 = auto, 1 = exact f32 MFMA, d16/K256, register-resident
  * codebook, 2 = exact f32 MFMA generic (any d, K), 3 = VALU fmaf chain with the codebook in
- * LDS, 4 = d16/K256 bf16x3 MFMA prefilter + exact f32 rescoring + exact fix-up (the default
- * for d16/K256; bit-identical output), 5 = exact f32 MFMA with the codebook (chunked when it
+ * LDS, 4 = bf16x3 MFMA prefilter + exact f32 rescoring + exact fix-up for K = 256 and d in
+ * {8, 16, 32} (the default for those shapes; bit-identical output), 5 = exact f32 MFMA with the codebook (chunked when it
  * does not fit) and the subvector tiles staged in LDS, any d <= 128 and any K (the default for
- * everything but d16/K256; 2 remains the fallback for d > 128). */
+ * every other shape; 2 remains the fallback for d > 128). */
 #define GQ_ENCODE_AUTO 0
 #define GQ_ENCODE_MFMA_D16K256 1
 #define GQ_ENCODE_MFMA_GENERIC 2

@@ -79,8 +79,10 @@ def test_hsq_matches_reference_golden(nat, name, impl):
     d, K, n_bit, random = int(g["dim"]), int(g["K"]), int(g["n_bit"]), int(g["random"])
     if impl == "valu" and (d not in (8, 12, 16, 24, 32) or K * d * 4 > 65536):
         pytest.skip("valu cross-check kernel not built for this shape")
-    if impl in ("mfma_exact_d16k256", "prefilter_d16k256") and (d, K) != (16, 256):
+    if impl == "mfma_exact_d16k256" and (d, K) != (16, 256):
         pytest.skip("d16/K256 specialisation")
+    if impl == "prefilter_d16k256" and not (K == 256 and d in (8, 16, 32)):
+        pytest.skip("the prefilter kernels are built for K = 256 and d in {8, 16, 32}")
     cb = _cb(d, K)
     r = g["r"] if random else None
     res = gpu_compress(nat, g["x"], cb, n_bit, random, r, impl=IMPLS[impl])
@@ -272,17 +274,20 @@ def test_full_size_properties(nat, oracle):
     assert np.array_equal(_bits(u[123457:123457 + 65536].cpu().numpy()), _bits(ru))
 
 
-def test_prefilter_equals_exact_mfma_at_full_size_and_fixup_rate(nat):
-    """The bf16x3 prefilter path must reproduce the exact f32 MFMA kernel bit for bit on 25M
-    elements (randn and randn*1e-3), and only a small fraction may need the exact fix-up."""
+@pytest.mark.parametrize("d", [16, 8, 32])
+def test_prefilter_equals_exact_mfma_at_full_size_and_fixup_rate(nat, d):
+    """The bf16x3 prefilter path (d = 16, and its d = 8 / d = 32 form) must reproduce the exact f32 MFMA
+    kernel bit for bit on 25M elements (randn and randn*1e-3), and only a small fraction may need the
+    exact fix-up."""
     dev = torch.device("cuda:0")
-    cb = torch.from_numpy(_cb(16, 256)).to(dev)
+    cb = torch.from_numpy(_cb(d, 256)).to(dev)
+    exact = 1 if d == 16 else 5
     for seed, scale in [(1234, 1.0), (77, 1e-3)]:
         torch.manual_seed(seed)
-        g = torch.randn(25_000_000, device=dev) * scale
-        M = g.numel() // 16
+        g = torch.randn(25_000_000 // d * d, device=dev) * scale
+        M = g.numel() // d
         res = {}
-        for impl in (1, 4):
+        for impl in (exact, 4):
             codes = torch.empty(M, dtype=torch.uint8, device=dev)
             u = torch.empty(M, dtype=torch.float32, device=dev)
             ws = nat.new_workspace(dev, M)
@@ -293,36 +298,37 @@ def test_prefilter_equals_exact_mfma_at_full_size_and_fixup_rate(nat):
             nat.hsq_levels(u, 6, 0, None, 0, ws, lb_ub, levels)
             torch.cuda.synchronize()
             res[impl] = (codes, u, lb_ub, levels, ws)
-        assert torch.equal(res[1][0], res[4][0]), "codes differ between exact and prefilter kernels"
-        assert torch.equal(res[1][1].view(torch.int32), res[4][1].view(torch.int32)), "u differs bitwise"
-        assert torch.equal(res[1][2].view(torch.int32), res[4][2].view(torch.int32))
-        assert torch.equal(res[1][3], res[4][3])
+        assert torch.equal(res[exact][0], res[4][0]), "codes differ between exact and prefilter kernels"
+        assert torch.equal(res[exact][1].view(torch.int32), res[4][1].view(torch.int32)), "u differs bitwise"
+        assert torch.equal(res[exact][2].view(torch.int32), res[4][2].view(torch.int32))
+        assert torch.equal(res[exact][3], res[4][3])
         n_fix = nat.fixup_count(res[4][4], M)
         assert 0 < n_fix < M * 0.01, n_fix
         print("scale %g: fix-up worklist %d of %d subvectors (%.4f%%)" % (scale, n_fix, M, 100.0 * n_fix / M))
 
 
+@pytest.mark.parametrize("d", [16, 8, 32])
 @pytest.mark.parametrize("case", ["zeros", "constant", "ties", "huge", "tiny", "mixed_scales"])
-def test_prefilter_degenerate_inputs_match_exact(nat, oracle, case):
+def test_prefilter_degenerate_inputs_match_exact(nat, oracle, case, d):
     rng = np.random.RandomState(11)
-    cbn = _cb(16, 256)
+    cbn = _cb(d, 256)
     M = 5000
     if case == "zeros":
-        x = np.zeros(M * 16, np.float32)
-        x[16 * 7:16 * 8] = -0.0
+        x = np.zeros(M * d, np.float32)
+        x[d * 7:d * 8] = -0.0
     elif case == "constant":
-        x = np.tile(rng.standard_normal(16).astype(np.float32), M)
+        x = np.tile(rng.standard_normal(d).astype(np.float32), M)
     elif case == "ties":
         a = rng.randint(0, 256, M)
         b = (a + 1 + rng.randint(0, 255, M)) % 256
         x = (cbn[a] + rng.choice([-1.0, 1.0], M)[:, None].astype(np.float32) * cbn[b]).reshape(-1)
     elif case == "huge":
-        x = (rng.standard_normal(M * 16) * 1e32).astype(np.float32)
+        x = (rng.standard_normal(M * d) * 1e32).astype(np.float32)
     elif case == "tiny":
-        x = (rng.standard_normal(M * 16) * 1e-30).astype(np.float32)
-        x[:16 * 100] *= 1e-12   # subnormal products
+        x = (rng.standard_normal(M * d) * 1e-30).astype(np.float32)
+        x[:d * 100] *= 1e-12   # subnormal products
     else:
-        x = (rng.standard_normal(M * 16) * np.exp(rng.standard_normal(M * 16) * 8)).astype(np.float32)
+        x = (rng.standard_normal(M * d) * np.exp(rng.standard_normal(M * d) * 8)).astype(np.float32)
     x = np.ascontiguousarray(x, np.float32)
     ref_codes, ref_u = oracle.hsq_encode(x, cbn)
     res = gpu_compress(nat, x, cbn, 32, 0, impl=4)
@@ -335,11 +341,12 @@ def test_prefilter_degenerate_inputs_match_exact(nat, oracle, case):
         assert n_fix > 0             # outside the proven range of the error bound -> exact path
 
 
-def test_prefilter_respects_unnormalised_codebooks(nat, oracle):
+@pytest.mark.parametrize("d", [16, 8, 32])
+def test_prefilter_respects_unnormalised_codebooks(nat, oracle, d):
     """The error bound scales with the measured max ||c_k||_1, not an assumed unit norm."""
     rng = np.random.RandomState(12)
-    cbn = (_cb(16, 256) * rng.uniform(0.2, 30.0, (256, 1))).astype(np.float32)
-    x = rng.standard_normal(16 * 20000).astype(np.float32)
+    cbn = (_cb(d, 256) * rng.uniform(0.2, 30.0, (256, 1))).astype(np.float32)
+    x = rng.standard_normal(d * 20000).astype(np.float32)
     ref_codes, ref_u = oracle.hsq_encode(x, cbn)
     res = gpu_compress(nat, x, cbn, 32, 0, impl=4)
     assert np.array_equal(res["codes"].cpu().numpy().astype(np.int32), ref_codes)
