@@ -40,15 +40,21 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// Counter-based uniform [0,1) generator for GQ_RANDOM_DEVICE: a 64-bit mix of
-// (seed, index) (splitmix64 finaliser), top 24 bits -> k * 2^-24, the same grid of
-// values torch.rand produces for float32.
+// Counter-based uniform [0,1) generator for GQ_RANDOM_DEVICE: a 32-bit avalanche hash (two
+// multiply-xorshift rounds, then a third round that folds in the upper halves) of (seed, index); the top
+// 24 bits -> k * 2^-24, the same grid of values torch.rand produces for float32.  ~12 VALU operations --
+// the 64-bit splitmix64 it replaces cost ~40 and was most of the QSGD compress kernel's time.
 __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f;  // 2^-24
+    uint32_t h = (uint32_t)idx + (uint32_t)seed * 0x9E3779B1u;
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    h += (uint32_t)(seed >> 32) ^ ((uint32_t)(idx >> 32) * 0x85EBCA77u);
+    h *= 0xC2B2AE3Du;
+    h ^= h >> 15;
+    return (float)(h >> 8) * 5.9604644775390625e-08f;  // 2^-24
 }
 
 }  // namespace gq

@@ -10,6 +10,7 @@
 // out off (floats), buckets, - }.  A zero bucket (0/0 = NaN level in the reference, decodes to 0)
 // is written as level 0.  HBM-bound: 4 B read + 0.5..1 B written per element; one wave per bucket.
 #include "gq_common.hpp"
+#include <type_traits>
 
 namespace gq {
 
@@ -94,6 +95,122 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
     }
 }
 
+// 4-bit wire, buckets of up to 256 elements (d % 8 == 0): 16 lanes per bucket (a wave takes four
+// buckets), a lane holds 8 (16 for d > 128) consecutive elements in registers -- the bucket is read from
+// HBM ONCE: max-abs over the lane's values, a 16-lane butterfly, then the codes straight from the
+// registers as one dword per 8 elements.  EF as in the kernel above.  (The wave-per-bucket form read
+// every bucket twice with 8-byte loads and spent most of its time in the 64-bit RNG: 71 us for the
+// 23.5 M-element ResNet-50 list.)
+template <bool EF>
+__global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int n_bit,
+    int random_mode, uint64_t seed, float ef_scale, uint8_t *__restrict__ wire) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, c0 = lane & 15;
+    const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
+    const float s = (float)(1 << n_bit), smax = s - 1.0f, inv_s = 1.0f / s;
+    const int64_t nquads = (nbuckets + 3) >> 2;
+    for (int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); qd < nquads; qd += nw) {
+        const int64_t b = 4 * qd + sub;
+        const bool live = b < nbuckets;
+        const int seg = live ? bucket_seg[b] : 0;
+        const int64_t *rec = seg_table + 8 * (int64_t)seg;
+        const int d = live ? (int)rec[1] : 0;
+        const int64_t lb = b - rec[2];
+        float *v = reinterpret_cast<float *>(rec[0]) + lb * d;
+        float *err = (EF && rec[7]) ? reinterpret_cast<float *>(rec[7]) + lb * d : nullptr;
+        if (live && (d > 256 || (d & 7) != 0)) {
+            // other bucket widths: the 16 lanes walk the bucket twice, an element pair at a time
+            auto load = [&](int e) {
+                float2 p = *reinterpret_cast<const float2 *>(v + e);
+                if (EF && err) {
+                    const float2 q = *reinterpret_cast<const float2 *>(err + e);
+                    const float p0 = ef_scale * q.x, p1 = ef_scale * q.y;
+                    p.x = p.x + p0;
+                    p.y = p.y + p1;
+                }
+                return p;
+            };
+            float m2 = 0.0f;
+            for (int e = 2 * c0; e < d; e += 32) {
+                const float2 p = load(e);
+                m2 = fmaxf(m2, fmaxf(fabsf(p.x), fabsf(p.y)));
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o, 64));
+            if (c0 == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = m2;
+            uint8_t *dst2 = wire + rec[4] + ((lb * d) >> 1);
+            for (int e = 2 * c0; e < d; e += 32) {
+                const float2 p = load(e);
+                const unsigned k0 = qsgd_code(p.x, m2, s, smax, random_mode, seed, ((uint64_t)b << 20) + e, 4);
+                const unsigned k1 = qsgd_code(p.y, m2, s, smax, random_mode, seed, ((uint64_t)b << 20) + e + 1, 4);
+                dst2[e >> 1] = (uint8_t)(k0 | (k1 << 4));
+                if (EF && err) {
+                    float t0 = (float)(k0 & 7u) * (2.0f * (float)(k0 >> 3) - 1.0f);
+                    float t1 = (float)(k1 & 7u) * (2.0f * (float)(k1 >> 3) - 1.0f);
+                    t0 = t0 * m2;
+                    t1 = t1 * m2;
+                    t0 = t0 * inv_s;
+                    t1 = t1 * inv_s;
+                    *reinterpret_cast<float2 *>(v + e) = p;
+                    *reinterpret_cast<float2 *>(err + e) = make_float2(p.x - t0, p.y - t1);
+                }
+            }
+            continue;   // (the other buckets of this wave take the register path below on their own lanes)
+        }
+        // chunk j of this lane covers elements [8 (c0 + 16 j), + 8)
+        f32x4 x[2][2];
+        float mx = 0.0f;
+#pragma unroll
+        for (int jc = 0; jc < 2; ++jc) {
+            const int e = 8 * (c0 + 16 * jc);
+            if (e < d) {
+                x[jc][0] = *reinterpret_cast<const f32x4 *>(v + e);
+                x[jc][1] = *reinterpret_cast<const f32x4 *>(v + e + 4);
+                if (EF && err) {
+                    const f32x4 q0 = *reinterpret_cast<const f32x4 *>(err + e);
+                    const f32x4 q1 = *reinterpret_cast<const f32x4 *>(err + e + 4);
+                    x[jc][0] = x[jc][0] + q0 * ef_scale;   // product rounded, then the add (-ffp-contract=off)
+                    x[jc][1] = x[jc][1] + q1 * ef_scale;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) mx = fmaxf(mx, fabsf(x[jc][k >> 2][k & 3]));
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));   // the bucket's 16 lanes
+        if (live && c0 == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = mx;
+        const uint64_t g0 = (uint64_t)b << 20;  // RNG stream index: unique per (bucket, element)
+        uint8_t *dst = wire + rec[4] + ((lb * d) >> 1);
+#pragma unroll
+        for (int jc = 0; jc < 2; ++jc) {
+            const int e = 8 * (c0 + 16 * jc);
+            if (e < d) {
+                unsigned word = 0;
+                f32x4 dec[2];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float val = x[jc][k >> 2][k & 3];
+                    const unsigned c = qsgd_code(val, mx, s, smax, random_mode, seed, g0 + e + k, 4);
+                    word |= c << (4 * k);
+                    if (EF) {
+                        // qsgd_compressor.py:69-70 on this element's own code (sign on the float's sign bit)
+                        float t = __uint_as_float(__float_as_uint((float)(c & 7u)) | (((c >> 3) ^ 1u) << 31));
+                        t = t * mx;
+                        dec[k >> 2][k & 3] = t * inv_s;
+                    }
+                }
+                *reinterpret_cast<unsigned *>(dst + 4 * (c0 + 16 * jc)) = word;
+                if (EF && err) {
+                    *reinterpret_cast<f32x4 *>(v + e) = x[jc][0];
+                    *reinterpret_cast<f32x4 *>(v + e + 4) = x[jc][1];
+                    *reinterpret_cast<f32x4 *>(err + e) = x[jc][0] - dec[0];      // ps_quantizer.py:39
+                    *reinterpret_cast<f32x4 *>(err + e + 4) = x[jc][1] - dec[1];
+                }
+            }
+        }
+    }
+}
+
 // decode + mean over R users: one wave per bucket, out = ( sum_r (l * (2*sign-1)) * norm / 2^n_bit ) / R
 __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int n_bit,
@@ -143,6 +260,87 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched_kernel(
     }
 }
 
+// decode + mean for the 4-bit packed wire: 16 lanes per bucket (a wave takes four buckets), a lane
+// decodes 8 consecutive elements from ONE dword per payload and stores 32 contiguous bytes.  The first
+// form (one wave per bucket, an element pair per lane) spent its time on byte loads, float2 stores and two
+// IEEE divisions per element: 41 us (R = 1) ... 146 us (R = 8) for the 23.5 M-element ResNet-50 list.
+// Same arithmetic: ((+-l) * norm) / 2^n_bit with the sign applied to the float's sign bit (l = 0 with a
+// cleared sign bit decodes to -0 like the reference's 0 * -1), the division as an exact scaling.
+__global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int n_bit,
+    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, c0 = lane & 15;
+    const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
+    const float inv_s = 1.0f / (float)(1 << n_bit);
+    const float fR = (float)R;
+    const int64_t nquads = (nbuckets + 3) >> 2;
+    for (int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); qd < nquads; qd += nw) {
+        const int64_t b = 4 * qd + sub;
+        if (b >= nbuckets) continue;
+        const int seg = bucket_seg[b];
+        const int64_t *rec = seg_table + 8 * (int64_t)seg;
+        const int d = (int)rec[1];
+        const int64_t lb = b - rec[2];
+        const int64_t norm_off = rec[3], code_off = rec[4] + ((lb * d) >> 1);
+        float *o = out + rec[5] + lb * d;
+        if ((d & 7) == 0) {
+            for (int c = c0; 8 * c < d; c += 16) {
+                f32x4 acc[2];
+                auto payload = [&](int r, auto first) {
+                    const uint8_t *p = gathered + (int64_t)r * user_stride;
+                    const float norm = reinterpret_cast<const float *>(p + norm_off)[lb];
+                    const unsigned w = *reinterpret_cast<const unsigned *>(p + code_off + 4 * c);
+                    const unsigned nw_ = ~w;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float lf = (float)((w >> (4 * k)) & 7u);
+                        const unsigned sgn = (nw_ >> (4 * k + 3)) & 1u;          // 1: negative
+                        float t = __uint_as_float(__float_as_uint(lf) | (sgn << 31));
+                        t = t * norm;
+                        t = t * inv_s;
+                        if constexpr (decltype(first)::value) {
+                            acc[k >> 2][k & 3] = t;
+                        } else {
+                            acc[k >> 2][k & 3] = acc[k >> 2][k & 3] + t;
+                        }
+                    }
+                };
+                payload(0, std::true_type{});
+                for (int r = 1; r < R; ++r) payload(r, std::false_type{});
+                if (R > 1) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k >> 2][k & 3] = acc[k >> 2][k & 3] / fR;
+                }
+                *reinterpret_cast<f32x4 *>(o + 8 * c) = acc[0];
+                *reinterpret_cast<f32x4 *>(o + 8 * c + 4) = acc[1];
+            }
+        } else {   // odd bucket widths: an element pair (one byte) at a time
+            for (int e = 2 * c0; e < d; e += 32) {
+                float a0 = 0.0f, a1 = 0.0f;
+                for (int r = 0; r < R; ++r) {
+                    const uint8_t *p = gathered + (int64_t)r * user_stride;
+                    const float norm = reinterpret_cast<const float *>(p + norm_off)[lb];
+                    const unsigned byte = p[code_off + (e >> 1)];
+                    const unsigned c0_ = byte & 15u, c1_ = byte >> 4;
+                    float t0 = (float)(c0_ & 7u) * (2.0f * (float)(c0_ >> 3) - 1.0f);
+                    float t1 = (float)(c1_ & 7u) * (2.0f * (float)(c1_ >> 3) - 1.0f);
+                    t0 = t0 * norm;
+                    t1 = t1 * norm;
+                    t0 = t0 * inv_s;
+                    t1 = t1 * inv_s;
+                    a0 = (r == 0) ? t0 : a0 + t0;
+                    a1 = (r == 0) ? t1 : a1 + t1;
+                }
+                if (R > 1) {
+                    a0 = a0 / fR;
+                    a1 = a1 / fR;
+                }
+                *reinterpret_cast<float2 *>(o + e) = make_float2(a0, a1);
+            }
+        }
+    }
+}
+
 static inline int64_t qb_grid(int64_t nbuckets) {
     int64_t blocks = (nbuckets + (QB_THREADS / 64) - 1) / (QB_THREADS / 64);
     const int64_t cap = (int64_t)cu_count() * 8;
@@ -171,9 +369,15 @@ static int qsgd_compress_batched(const char *what, const int64_t *seg_table, con
         return fail(GQ_ERR_UNSUPPORTED, "%s: random_mode must be OFF or DEVICE", what);
     const int bits = gq_qsgd_code_bits(n_bit, random_mode);
     if (!bits) return fail(GQ_ERR_UNSUPPORTED, "%s: n_bit %d has no packed format", what, n_bit);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched_kernel<EF>), dim3((unsigned)qb_grid(nbuckets)),
-                       dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, bits, random_mode,
-                       seed, ef_scale, wire);
+    if (bits == 4) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched4_kernel<EF>), dim3((unsigned)qb_grid((nbuckets + 3) / 4)),
+                           dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, random_mode,
+                           seed, ef_scale, wire);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched_kernel<EF>), dim3((unsigned)qb_grid(nbuckets)),
+                           dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, bits,
+                           random_mode, seed, ef_scale, wire);
+    }
     GQ_CHECK_LAUNCH(what);
     return GQ_OK;
 }
@@ -199,9 +403,16 @@ GQ_API int gq_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *b
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: bad sizes");
     if (!seg_table || !bucket_seg || !gathered || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: null pointer");
-    hipLaunchKernelGGL(gq::qsgd_decode_sum_batched_kernel, dim3((unsigned)gq::qb_grid(nbuckets)), dim3(gq::QB_THREADS),
-                       0, gq::as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, bits, gathered,
-                       user_stride_bytes, R, out);
+    if (bits == 4 && (user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        hipLaunchKernelGGL(gq::qsgd_decode_sum_batched4_kernel, dim3((unsigned)gq::qb_grid((nbuckets + 3) / 4)),
+                           dim3(gq::QB_THREADS), 0, gq::as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit,
+                           gathered, user_stride_bytes, R, out);
+    } else {
+        hipLaunchKernelGGL(gq::qsgd_decode_sum_batched_kernel, dim3((unsigned)gq::qb_grid(nbuckets)),
+                           dim3(gq::QB_THREADS), 0, gq::as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, bits,
+                           gathered, user_stride_bytes, R, out);
+    }
     GQ_CHECK_LAUNCH("gq_qsgd_decode_sum_batched");
     return GQ_OK;
 }

@@ -428,7 +428,7 @@ class BatchedQSGD(_BatchedBase):
             bucket_seg += [s] * cd.Mb
             bucket += cd.Mb
             self.out_off.append(out_off)
-            out_off += cd.numel + (cd.numel & 1)
+            out_off += (cd.numel + 3) & ~3          # tensors start 16-byte aligned in `out` (dwordx4 stores)
         self.nbuckets, self.out_floats = bucket, out_off
         self.bucket_seg = torch.tensor(bucket_seg, dtype=torch.int32, device=device)
         self._setup(table, None, device, slots, user_bytes)

@@ -216,7 +216,7 @@ int gq_pvq_encode(const float *grad, const float *c_dagger, int64_t M, int d, in
  * when the top level is <= 7, 8 when it is <= 127, 0 = no packed format.  Buckets are numbered across
  * tensors: bucket_seg int32[nbuckets]; seg_table int64[nseg][8] = { grad pointer (8-byte aligned),
  * d (even, <= 65536), first bucket, byte offset of the f32 norms / of the codes inside ONE user's wire,
- * float offset of the tensor in `out`, buckets, reserved }.  A zero bucket is written as level 0
+ * float offset of the tensor in `out` (a multiple of 4), buckets, reserved }.  A zero bucket is written as level 0
  * (the reference's NaN level also decodes to 0).
  * gq_qsgd_compress_batched_ef: error feedback in the same pass (ps_quantizer.py:35-39):
  * seg_table[seg][7] = the tensor's error buffer (float*, 8-byte aligned; 0 = none); the bucket is read
