@@ -10,6 +10,7 @@
 // out off (floats), - } (include/gq_hsq.h).  The matching encode is gq_hsq_encode_batched
 // (hsq_encode_pf.hip).
 #include "hsq_encode_common.hpp"
+#include <type_traits>
 
 namespace gq {
 
@@ -187,6 +188,79 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_kernel(
     }
 }
 
+// The same with the decode kernel's conflict-free gather (hsq_decode.hip, hsq_decode_sum_d16u8_kernel): a
+// thread produces one quarter of FOUR consecutive padded subvectors (they share a tile, hence a tensor),
+// two dword loads per payload; the codebook is staged four times (row r, copy c at byte r*256 + c*64)
+// and the four 4-lane teams of every ds_read_b128 lane group read copies 0..3.
+constexpr int BT4_THREADS = 1024;
+
+__global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
+    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
+    float *__restrict__ out) {
+    extern __shared__ float s_cb4[];   // [256][4 copies][16]
+    for (int i = threadIdx.x; i < 256 * 16; i += BT4_THREADS) {   // (row, copy, quarter)
+        const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
+        *reinterpret_cast<f32x4 *>(s_cb4 + row * 64 + c * 16 + 4 * q) = *reinterpret_cast<const f32x4 *>(cb + row * 16 + 4 * q);
+    }
+    __syncthreads();
+    const float inv_s = 1.0f / (float)(1 << n_bit);
+    const float fR = (float)R;
+    const int q = threadIdx.x & 3;
+    const float *const my_cb = s_cb4 + ((threadIdx.x >> 3) & 3) * 16 + 4 * q;   // this lane's copy and quarter
+    const int64_t total = ntiles * 64;   // (group of 4 padded subvectors, quarter) items
+    const int64_t stride = (int64_t)gridDim.x * BT4_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * BT4_THREADS + threadIdx.x; i < total; i += stride) {
+        const int64_t g0 = (i >> 2) * 4;
+        const int64_t tile = g0 >> 6;
+        const int seg = tile_seg[tile];
+        const int64_t *rec = seg_table + 8 * (int64_t)seg;
+        const int64_t local = (tile - rec[2]) * 64 + (g0 & 63);
+        const int64_t left = rec[1] - local;
+        if (left <= 0) continue;
+        const int nv = left < 4 ? (int)left : 4;
+        const int64_t code_off = rec[3] + local, level_off = rec[4] + local, lbub_off = rec[5];
+        f32x4 acc[4];
+        auto payload = [&](int r, auto first) {   // first: payload 0 initialises, the others accumulate
+            const uint8_t *p = gathered + (int64_t)r * user_stride;
+            const unsigned c4 = *reinterpret_cast<const unsigned *>(p + code_off);    // sections are padded to 16 B:
+            const unsigned l4 = *reinterpret_cast<const unsigned *>(p + level_off);   // reading past M stays inside
+            const float *lbub = reinterpret_cast<const float *>(p + lbub_off);
+            const float lb = lbub[0], range = lbub[1] - lb;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float n = (float)((l4 >> (8 * k)) & 255u) * range;   // prob_scalar:31-32, unfused
+                n = n * inv_s;                                       // == / 2^n_bit exactly
+                n = n + lb;
+                const f32x4 c = *reinterpret_cast<const f32x4 *>(my_cb + ((c4 >> (8 * k)) & 255u) * 64);
+                const f32x4 n4 = {n, n, n, n};
+                const f32x4 dec = c * n4;
+                if constexpr (decltype(first)::value) {
+                    acc[k] = dec;
+                } else {
+                    acc[k] = acc[k] + dec;
+                }
+            }
+        };
+        payload(0, std::true_type{});
+        for (int r = 1; r < R; ++r) payload(r, std::false_type{});
+        float *o = out + rec[6] + local * 16 + 4 * q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < nv) {
+                f32x4 a = acc[k];
+                if (R > 1) {
+                    a[0] = a[0] / fR;
+                    a[1] = a[1] / fR;
+                    a[2] = a[2] / fR;
+                    a[3] = a[3] / fR;
+                }
+                *reinterpret_cast<f32x4 *>(o + 16 * k) = a;
+            }
+        }
+    }
+}
+
 static inline int64_t bt_grid(int64_t items) {
     int64_t blocks = (items + BT_THREADS - 1) / BT_THREADS;
     const int64_t cap = (int64_t)cu_count() * 8;
@@ -239,9 +313,27 @@ GQ_API int gq_hsq_decode_sum_batched(const int64_t *seg_table, const int32_t *ti
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: bad sizes");
     if (!seg_table || !tile_seg || !gathered || !codebook || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: null pointer");
-    hipLaunchKernelGGL(gq::hsq_decode_sum_batched_kernel, dim3((unsigned)gq::bt_grid(ntiles * 256)),
-                       dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
-                       user_stride_bytes, R, codebook, n_bit, out);
+    if ((user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0) {
+        static const int bpc = [] {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(gq::hsq_decode_sum_batched4_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipGetLastError();
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gq::hsq_decode_sum_batched4_kernel, gq::BT4_THREADS,
+                                                             (size_t)64 * 1024) != hipSuccess || n < 1)
+                n = 1;
+            return n;
+        }();
+        int64_t blocks = (ntiles * 64 + gq::BT4_THREADS - 1) / gq::BT4_THREADS;
+        if (blocks > (int64_t)gq::cu_count() * bpc) blocks = (int64_t)gq::cu_count() * bpc;
+        hipLaunchKernelGGL(gq::hsq_decode_sum_batched4_kernel, dim3((unsigned)blocks), dim3(gq::BT4_THREADS),
+                           (size_t)64 * 1024, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
+                           user_stride_bytes, R, codebook, n_bit, out);
+    } else {
+        hipLaunchKernelGGL(gq::hsq_decode_sum_batched_kernel, dim3((unsigned)gq::bt_grid(ntiles * 256)),
+                           dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
+                           user_stride_bytes, R, codebook, n_bit, out);
+    }
     GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched");
     return GQ_OK;
 }

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_v4_kernel(
 //  * packed f32 multiplies / adds (separate roundings, as the reference).
 // Same arithmetic and summation order as the kernels above.
 constexpr int DEC16_THREADS = 1024;
+constexpr int DEC16_LBUB = 64;
 
 __global__ __launch_bounds__(DEC16_THREADS) void hsq_decode_sum_d16u8_kernel(
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ levels, const float *__restrict__ lb_ub,
@@ -106,6 +107,13 @@ __global__ __launch_bounds__(DEC16_THREADS) void hsq_decode_sum_d16u8_kernel(
     for (int i = threadIdx.x; i < K * 16; i += DEC16_THREADS) {   // (row, copy, quarter)
         const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
         *reinterpret_cast<f32x4 *>(s_cb + row * 64 + c * 16 + 4 * q) = *reinterpret_cast<const f32x4 *>(cb + row * 16 + 4 * q);
+    }
+    // (lb, ub - lb) of the first DEC16_LBUB payloads once per workgroup: read per payload as a uniform
+    // scalar load, every s_waitcnt lgkmcnt for it also drained the LDS gathers in flight
+    __shared__ float2 s_lbub[DEC16_LBUB];
+    for (int r = threadIdx.x; r < R && r < DEC16_LBUB; r += DEC16_THREADS) {
+        const float lb = lb_ub[r * lbub_stride];
+        s_lbub[r] = make_float2(lb, lb_ub[r * lbub_stride + 1] - lb);
     }
     __syncthreads();
     const float inv_s = 1.0f / (float)(1 << (n_bit & 31));
@@ -132,8 +140,15 @@ __global__ __launch_bounds__(DEC16_THREADS) void hsq_decode_sum_d16u8_kernel(
                     l4 |= (unsigned)lp[k] << (8 * k);
                 }
             }
-            const float lb = lb_ub[r * lbub_stride];
-            const float range = lb_ub[r * lbub_stride + 1] - lb;
+            float lb, range;
+            if (r < DEC16_LBUB) {
+                const float2 lr = s_lbub[r];
+                lb = lr.x;
+                range = lr.y;
+            } else {
+                lb = lb_ub[r * lbub_stride];
+                range = lb_ub[r * lbub_stride + 1] - lb;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float n = level_to_norm<unsigned>((l4 >> (8 * k)) & 255u, lb, range, inv_s);
