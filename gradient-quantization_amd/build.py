@@ -41,7 +41,9 @@ def needs_build():
 EXTRA = {
     # lets fmaxf on MFMA outputs lower to v_max3_f32 without canonicalising v_max x,x,x (see the file)
     "hsq_encode_pf.hip": ["-fno-honor-nans"],
-    "hsq_encode_pfd.hip": ["-fno-honor-nans"],
+    # + MFMA results straight into VGPRs: with 512 registers available (d = 32 runs one wave per SIMD) the
+    # compiler otherwise accumulates in AGPRs and pays 16 v_accvgpr_read per chain (69 -> 61 us)
+    "hsq_encode_pfd.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 }
 
 

@@ -28,7 +28,8 @@ struct PfdArgs {
 
 // D = 32 wants ~360 registers per lane (two tiles of 64 x 32 floats in flight, fragments of both, two
 // accumulators): at two waves per SIMD it spilled 112 VGPRs and ran 101 us per 25 M elements; at one wave
-// per SIMD (512 registers) nothing spills and the in-wave MFMA / key-operation pipeline carries it: 68 us.
+// per SIMD (512 registers) nothing spills and the in-wave MFMA / key-operation pipeline carries it: 61 us
+// (built with -amdgpu-mfma-vgpr-form so that the accumulators stay in VGPRs: build.py).
 template <typename CodeT, int D>
 __global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_kernel(const PfdArgs a) {
     static_assert(D == 8 || D == 32, "built for D = 8 and D = 32 (D = 16: hsq_encode_pf.hip)");
