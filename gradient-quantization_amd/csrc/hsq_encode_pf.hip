@@ -71,7 +71,10 @@ __device__ __forceinline__ float order_unmap(unsigned m) {
 // EF (batched only): error feedback folded into the load -- the tile is read as
 // v = grad + ef_scale * error (product rounded, then the add: ps_quantizer.py:35) and v is written back
 // over grad, as the reference's in-place add_ does; the level kernel later writes error = v - decoded.
-template <typename CodeT, bool BATCHED, bool EF = false>
+// SEGLDS (batched only): the segment records are read from their LDS copy (nseg <= PF_LDS_SEGS) or, for
+// longer tensor lists, from global memory -- as two instantiations, because a run-time choice between
+// the two sources turns the record pointer into a flat pointer (see tile_info).
+template <typename CodeT, bool BATCHED, bool EF = false, bool SEGLDS = true>
 __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfArgs a) {
     const float *__restrict__ cb = a.cb;
     float *__restrict__ ws = a.ws;
@@ -88,8 +91,8 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     // global memory costs two dependent round trips at the top of every tile (tile -> segment -> record),
     // which made this form 3x slower than the single-tensor one; from LDS the record is ~100 cycles away,
     // and the tile -> segment word is fetched one tile ahead.
-    __shared__ int64_t s_seg[BATCHED ? PF_LDS_SEGS * 8 : 1];
-    if (BATCHED) {
+    __shared__ int64_t s_seg[(BATCHED && SEGLDS) ? PF_LDS_SEGS * 8 : 1];
+    if (BATCHED && SEGLDS) {
         const int n = (a.nseg < PF_LDS_SEGS ? a.nseg : PF_LDS_SEGS) * 8;
         for (int i = threadIdx.x; i < n; i += ENC_THREADS) s_seg[i] = a.seg_table[i];
     }
@@ -165,12 +168,21 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     f32x4 nxte[4];   // EF: the error tile that goes with nxt (dead otherwise)
 
     // where tile `tile` lives: base pointer, subvector count of its tensor, local index of its first subvector
+    // Pointers that come out of the segment table are integers to the compiler: cast to plain pointers
+    // they are FLAT (generic address space) and every access becomes a flat_load / flat_store whose wait
+    // is vmcnt(0) AND lgkmcnt(0) -- behind the previous tile's stores, a store round trip per tile (the
+    // batched form ran 70 % slower than the single-tensor one).  Address space 1 = global memory.
+    typedef const float __attribute__((address_space(1))) *gcf_ptr;
+    typedef float __attribute__((address_space(1))) *gf_ptr;
+    typedef const f32x4 __attribute__((address_space(1))) *gcv_ptr;
+    typedef f32x4 __attribute__((address_space(1))) *gv_ptr;
+    typedef CodeT __attribute__((address_space(1))) *gcode_ptr;
     struct Tile {
-        const float *base;
+        gcf_ptr base;
         int64_t m, sv0;
         int seg;
-        CodeT *codes;
-        const float *err;   // EF: this tensor's error buffer or nullptr
+        gcode_ptr codes;
+        gcf_ptr err;   // EF: this tensor's error buffer or nullptr
     };
     auto uniform64 = [](int64_t v) {   // a wave-uniform value read through a vector path -> SGPRs
         const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v);
@@ -181,19 +193,38 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
         Tile ti;
         if (BATCHED) {
             ti.seg = seg;
-            const int64_t *rec = seg < PF_LDS_SEGS ? s_seg + 8 * seg : a.seg_table + 8 * (int64_t)seg;
-            ti.base = reinterpret_cast<const float *>(uniform64(rec[0]));
-            ti.m = uniform64(rec[1]);
-            ti.sv0 = (tile - uniform64(rec[2])) * 64;
-            ti.codes = reinterpret_cast<CodeT *>(a.wire + uniform64(rec[3]));
-            ti.err = EF ? reinterpret_cast<const float *>(uniform64(rec[7])) : nullptr;
+            // One pointer that may point into LDS or into global memory is a FLAT pointer, and the wait for a
+            // flat load (vmcnt AND lgkmcnt) sits right behind the previous tile's stores: a store round trip
+            // per tile.  Hence the compile-time choice of the source.
+            int64_t r0, r1, r2, r3, r7 = 0;
+            if constexpr (SEGLDS) {
+                const int64_t *rec = s_seg + 8 * seg;
+                r0 = rec[0];
+                r1 = rec[1];
+                r2 = rec[2];
+                r3 = rec[3];
+                if (EF) r7 = rec[7];
+            } else {
+                typedef const int64_t __attribute__((address_space(1))) *grec_ptr;
+                const grec_ptr rec = (grec_ptr)(a.seg_table + 8 * (int64_t)seg);
+                r0 = rec[0];
+                r1 = rec[1];
+                r2 = rec[2];
+                r3 = rec[3];
+                if (EF) r7 = rec[7];
+            }
+            ti.base = (gcf_ptr)(uintptr_t)uniform64(r0);
+            ti.m = uniform64(r1);
+            ti.sv0 = (tile - uniform64(r2)) * 64;
+            ti.codes = (gcode_ptr)((uintptr_t)a.wire + (uintptr_t)uniform64(r3));
+            ti.err = EF ? (gcf_ptr)(uintptr_t)uniform64(r7) : (gcf_ptr)0;
         } else {
             ti.seg = 0;
-            ti.base = a.grad;
+            ti.base = (gcf_ptr)a.grad;
             ti.m = M;
             ti.sv0 = tile * 64;
-            ti.codes = static_cast<CodeT *>(a.codes);
-            ti.err = nullptr;
+            ti.codes = (gcode_ptr)static_cast<CodeT *>(a.codes);
+            ti.err = (gcf_ptr)0;
         }
         return ti;
     };
@@ -202,7 +233,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
         for (int blk = 0; blk < 2; ++blk) {
             int64_t sv = ti.sv0 + blk * 32 + j;
             sv = sv < ti.m ? sv : ti.m - 1;  // tail: re-read the last subvector, result is masked
-            const f32x4 *p = reinterpret_cast<const f32x4 *>(ti.base + sv * 16 + 8 * h);
+            const gcv_ptr p = (gcv_ptr)(ti.base + sv * 16 + 8 * h);
             dst[2 * blk] = p[0];
             dst[2 * blk + 1] = p[1];
         }
@@ -213,7 +244,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
             for (int blk = 0; blk < 2; ++blk) {
                 int64_t sv = ti.sv0 + blk * 32 + j;
                 sv = sv < ti.m ? sv : ti.m - 1;
-                const f32x4 *p = reinterpret_cast<const f32x4 *>(ti.err + sv * 16 + 8 * h);
+                const gcv_ptr p = (gcv_ptr)(ti.err + sv * 16 + 8 * h);
                 dst[2 * blk] = p[0];
                 dst[2 * blk + 1] = p[1];
             }
@@ -236,7 +267,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
                 }
                 const int64_t sv = ti.sv0 + blk * 32 + j;
                 if (sv < ti.m) {
-                    f32x4 *p = reinterpret_cast<f32x4 *>(const_cast<float *>(ti.base) + sv * 16 + 8 * h);
+                    const gv_ptr p = (gv_ptr)(gf_ptr)(ti.base + sv * 16 + 8 * h);
                     p[0] = g[2 * blk];
                     p[1] = g[2 * blk + 1];
                 }
@@ -246,8 +277,16 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     auto flush_minmax = [&]() {  // batched: fold this wave's running (min,max) into its segment
         const float lo = wave_min(lmin), hi = wave_max(lmax);
         if (lane == 0 && cur_seg >= 0 && lo <= hi) {
-            atomicMin(&a.seg_minmax[2 * cur_seg], order_map(lo));
-            atomicMax(&a.seg_minmax[2 * cur_seg + 1], order_map(hi));
+            // Look before the atomic: a tensor's (min,max) words are hit by every wave that touched the
+            // tensor (all ~2000 of them for one big tensor, ~90 atomics/us per address: a 23 us tail),
+            // but only the first few still improve them.  The words only ever move towards the extremes,
+            // so a value that is already as good as ours -- however stale -- makes ours redundant.
+            unsigned *mm = a.seg_minmax + 2 * cur_seg;
+            const unsigned mlo = order_map(lo), mhi = order_map(hi);
+            const unsigned seen_lo = __hip_atomic_load(mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned seen_hi = __hip_atomic_load(mm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mlo < seen_lo) atomicMin(mm, mlo);
+            if (mhi > seen_hi) atomicMax(mm + 1, mhi);
         }
         lmin = INFINITY;
         lmax = -INFINITY;
@@ -260,8 +299,10 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
         return (BATCHED && tile < tile_end) ? a.tile_seg[tile] : 0;
     };
     int seg_n = seg_of(t + tstep);      // in flight while the first tile is set up
+    int seg_next = 0;                   // its value, read back BEFORE a tile's stores (see the consume point)
     if (t < tile_end) {
         ti = tile_info(t, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[t]) : 0);
+        seg_next = BATCHED ? __builtin_amdgcn_readfirstlane(seg_n) : 0;
         load_tile(ti, cur);
         load_err(ti, nxte);
         fold_err(ti, cur, nxte);
@@ -272,7 +313,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
         const int64_t tn = t + tstep;
         Tile tin = ti;
         if (tn < tile_end) {
-            tin = tile_info(tn, __builtin_amdgcn_readfirstlane(seg_n));   // seg_n was requested a tile ago
+            tin = tile_info(tn, seg_next);
             load_tile(tin, nxt);  // prefetch the next tile
             load_err(tin, nxte);
         }
@@ -397,6 +438,9 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
         // Done the other way round, the compiler's vmcnt wait at the first use of `nxt` sits right
         // behind the just-issued stores and every tile eats a store round trip.
         bf16x8 nvh[2], nvl[2];
+        // the tile -> tensor word of the tile after next was requested at the top of this tile: read it
+        // back here, with the prefetch, not behind the stores
+        if (BATCHED) seg_next = __builtin_amdgcn_readfirstlane(seg_n);
         if (EF && tn < tile_end) fold_err(tin, nxt, nxte);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) split8(nxt[2 * blk], nxt[2 * blk + 1], nvh[blk], nvl[blk]);
@@ -504,7 +548,7 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
         return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes nseg=%d ntiles=%lld", what, nseg, (long long)ntiles);
     if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
         return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
-    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<uint8_t, true, EF>, ENC_THREADS, 0);
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<uint8_t, true, EF, true>, ENC_THREADS, 0);
     PfArgs a = {};
     a.M = ntiles * 64;
     a.u = u_flat;
@@ -520,8 +564,13 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
     hipStream_t st = as_stream(stream);
     const int64_t blocks = pf_grid(ntiles, bpc);
     a.split_tile = pf_split(ntiles, blocks, bpc);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, true, EF>), dim3((unsigned)blocks),
-                       dim3(ENC_THREADS), 0, st, a);
+    if (nseg <= PF_LDS_SEGS) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, true, EF, true>), dim3((unsigned)blocks),
+                           dim3(ENC_THREADS), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, true, EF, false>), dim3((unsigned)blocks),
+                           dim3(ENC_THREADS), 0, st, a);
+    }
     GQ_CHECK_LAUNCH(what);
     return GQ_OK;
 }
