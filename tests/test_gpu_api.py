@@ -448,3 +448,47 @@ def test_training_driver_resnet50_shapes_and_one_step():
     _, q, hist = train(args)
     assert len(hist) >= 2 and all(np.isfinite(h["loss"]) for h in hist)
     assert len(q._groups[0][1]) == 76 and len(q.dense_idx) == 85
+
+
+def test_prefilter_on_real_resnet50_gradients_equals_exact_kernel(oracle):
+    """BASELINE config 3: REAL back-propagated ResNet-50 gradients (not Gaussian noise) -- every compressed
+    tensor's codes and projections from the prefilter path equal the exact f32 MFMA kernel's, a sampled tensor
+    equals the oracle's, and only a small fraction of subvectors needs the exact recomputation."""
+    from gq_amd import native
+    from gq_amd.codebook import load_codebook
+    from gq_amd.driver import ResNet50
+    torch.manual_seed(5)
+    dev = torch.device("cuda:0")
+    model = ResNet50().to(dev)
+    x = torch.randn(16, 3, 32, 32, device=dev)
+    y = torch.randint(0, 10, (16,), device=dev)
+    torch.nn.functional.cross_entropy(model(x), y).backward()
+    cb_np = load_codebook(16, 256)
+    cb = torch.from_numpy(cb_np).to(dev)
+    total, fixed, checked_oracle = 0, 0, False
+    for p in model.parameters():
+        if p.numel() <= 1000:
+            continue
+        g = p.grad.data.contiguous().view(-1)
+        M = g.numel() // 16
+        res = {}
+        for impl in (1, 4):
+            codes = torch.empty(M, dtype=torch.uint8, device=dev)
+            u = torch.empty(M, dtype=torch.float32, device=dev)
+            ws = native.new_workspace(dev, M)
+            native.mark_worklist(ws, M)
+            native.hsq_encode(g, cb, codes, u, ws, impl=impl)
+            res[impl] = (codes, u, ws)
+        torch.cuda.synchronize()
+        assert torch.equal(res[1][0], res[4][0]), tuple(p.shape)
+        assert torch.equal(res[1][1].view(torch.int32), res[4][1].view(torch.int32)), tuple(p.shape)
+        total += M
+        fixed += native.fixup_count(res[4][2], M)
+        if not checked_oracle and 4096 <= M <= 40000:
+            rc, ru = oracle.hsq_encode(g.cpu().numpy(), cb_np)
+            assert np.array_equal(res[4][0].cpu().numpy().astype(np.int32), rc)
+            assert np.array_equal(res[4][1].cpu().numpy().view(np.uint32), ru.view(np.uint32))
+            checked_oracle = True
+    assert checked_oracle and total > 1_400_000
+    print("real ResNet-50 gradients: %d of %d subvectors (%.3f%%) took the exact fix-up path" % (fixed, total, 100.0 * fixed / total))
+    assert fixed < 0.02 * total
