@@ -261,6 +261,61 @@ __global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
     }
 }
 
+// decode-mean over a segment table for the other prefilter sub-dimensions (D = 8, 32; K = 256): one thread
+// per (padded subvector, 4-float unit); codebook rows an odd number of 16-byte units apart in LDS.
+template <int D>
+__global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_d_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
+    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
+    float *__restrict__ out) {
+    constexpr int UPS = D / 4;                               // 16-byte units per subvector
+    constexpr int RS = ((D / 4) & 1) ? D : D + 4;            // LDS row stride in floats
+    __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];
+    for (int i = threadIdx.x; i < 256 * UPS; i += BT_THREADS)
+        *reinterpret_cast<f32x4 *>(s_cb + (i / UPS) * RS + 4 * (i % UPS)) = reinterpret_cast<const f32x4 *>(cb)[i];
+    __syncthreads();
+    const float inv_s = 1.0f / (float)(1 << n_bit);
+    const float fR = (float)R;
+    const int64_t total = ntiles * 64 * UPS;
+    const int64_t stride = (int64_t)gridDim.x * BT_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * BT_THREADS + threadIdx.x; i < total; i += stride) {
+        const int64_t g = i / UPS;
+        const int q = (int)(i % UPS);
+        const int64_t tile = g >> 6;
+        const int seg = tile_seg[tile];
+        const int64_t *rec = seg_table + 8 * (int64_t)seg;
+        const int64_t local = (tile - rec[2]) * 64 + (g & 63);
+        if (local >= rec[1]) continue;
+        const int64_t code_off = rec[3] + local, level_off = rec[4] + local, lbub_off = rec[5];
+        f32x4 acc;
+        auto payload = [&](int r, auto first) {
+            const uint8_t *p = gathered + (int64_t)r * user_stride;
+            const float *lbub = reinterpret_cast<const float *>(p + lbub_off);
+            const float lb = lbub[0], range = lbub[1] - lb;
+            float n = (float)p[level_off] * range;   // prob_scalar:31-32, unfused
+            n = n * inv_s;                           // == / 2^n_bit exactly
+            n = n + lb;
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(s_cb + (int)p[code_off] * RS + 4 * q);
+            const f32x4 n4 = {n, n, n, n};
+            const f32x4 dec = c * n4;
+            if constexpr (decltype(first)::value) {
+                acc = dec;
+            } else {
+                acc = acc + dec;
+            }
+        };
+        payload(0, std::true_type{});
+        for (int r = 1; r < R; ++r) payload(r, std::false_type{});
+        if (R > 1) {
+            acc[0] = acc[0] / fR;
+            acc[1] = acc[1] / fR;
+            acc[2] = acc[2] / fR;
+            acc[3] = acc[3] / fR;
+        }
+        *reinterpret_cast<f32x4 *>(out + rec[6] + local * D + 4 * q) = acc;
+    }
+}
+
 static inline int64_t bt_grid(int64_t items) {
     int64_t blocks = (items + BT_THREADS - 1) / BT_THREADS;
     const int64_t cap = (int64_t)cu_count() * 8;
@@ -335,5 +390,30 @@ GQ_API int gq_hsq_decode_sum_batched(const int64_t *seg_table, const int32_t *ti
                            user_stride_bytes, R, codebook, n_bit, out);
     }
     GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched");
+    return GQ_OK;
+}
+
+GQ_API int gq_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                       const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                       const float *codebook, int d, int n_bit, float *out, void *stream) {
+    if (d == 16)
+        return gq_hsq_decode_sum_batched(seg_table, tile_seg, nseg, ntiles, gathered, user_stride_bytes, R, codebook,
+                                         n_bit, out, stream);
+    if (nseg < 1 || ntiles < 1 || R < 1 || n_bit < 1 || n_bit > 8)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched_d: bad sizes");
+    if (!seg_table || !tile_seg || !gathered || !codebook || !out)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched_d: null pointer");
+    if (d == 8) {
+        hipLaunchKernelGGL(gq::hsq_decode_sum_batched_d_kernel<8>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 2)),
+                           dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
+                           user_stride_bytes, R, codebook, n_bit, out);
+    } else if (d == 32) {
+        hipLaunchKernelGGL(gq::hsq_decode_sum_batched_d_kernel<32>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 8)),
+                           dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
+                           user_stride_bytes, R, codebook, n_bit, out);
+    } else {
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched_d: d must be 8, 16 or 32 (K = 256)");
+    }
+    GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched_d");
     return GQ_OK;
 }

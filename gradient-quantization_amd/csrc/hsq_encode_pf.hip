@@ -59,18 +59,6 @@ struct PfArgs {
     float ef_scale;           // EF kernels: grad <- grad + ef_scale * error (error pointer = seg_table[seg][7], 0 = none)
 };
 
-// order-preserving float -> uint32 map for integer atomic min/max
-__device__ __forceinline__ unsigned order_map(float f) {
-    const unsigned b = __float_as_uint(f);
-    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
-__device__ __forceinline__ float order_unmap(unsigned m) {
-    return __uint_as_float(m ^ ((m >> 31) ? 0x80000000u : 0xFFFFFFFFu));
-}
-
-// EF (batched only): error feedback folded into the load -- the tile is read as
-// v = grad + ef_scale * error (product rounded, then the add: ps_quantizer.py:35) and v is written back
-// over grad, as the reference's in-place add_ does; the level kernel later writes error = v - decoded.
 // SEGLDS (batched only): the segment records are read from their LDS copy (nseg <= PF_LDS_SEGS) or, for
 // longer tensor lists, from global memory -- as two instantiations, because a run-time choice between
 // the two sources turns the record pointer into a flat pointer (see tile_info).

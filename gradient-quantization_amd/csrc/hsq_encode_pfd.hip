@@ -24,13 +24,25 @@ struct PfdArgs {
     const float *cb;
     float *ws;
     int64_t split_tile;   // pf_split()
+    // batched form (gq_hsq_encode_batched_d): as PfArgs in hsq_encode_pf.hip; M = ntiles * 64
+    const int64_t *seg_table;
+    const int32_t *tile_seg;
+    uint8_t *wire;
+    unsigned *seg_minmax;
+    int64_t ntiles;
+    int nseg;
 };
+
+constexpr int PFD_LDS_SEGS = 384;   // batched form: segment records kept in LDS (24 KiB); longer lists are refused
 
 // D = 32 wants ~360 registers per lane (two tiles of 64 x 32 floats in flight, fragments of both, two
 // accumulators): at two waves per SIMD it spilled 112 VGPRs and ran 101 us per 25 M elements; at one wave
 // per SIMD (512 registers) nothing spills and the in-wave MFMA / key-operation pipeline carries it: 61 us
 // (built with -amdgpu-mfma-vgpr-form so that the accumulators stay in VGPRs: build.py).
-template <typename CodeT, int D>
+// BATCHED: the multi-tensor form -- segment table, one contiguous run of tiles per wave, per-tensor (min,max)
+// by look-before-you-leap atomics, table-derived addresses as global address-space pointers: everything as in
+// hsq_encode_pf.hip, where the reasons are written down.
+template <typename CodeT, int D, bool BATCHED = false>
 __global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_kernel(const PfdArgs a) {
     static_assert(D == 8 || D == 32, "built for D = 8 and D = 32 (D = 16: hsq_encode_pf.hip)");
     constexpr int KS = D > 16 ? D / 16 : 1;    // MFMA k-steps per chain
@@ -39,7 +51,6 @@ __global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_k
     float *__restrict__ ws = a.ws;
     float *__restrict__ u = a.u;
     const float *__restrict__ grad = a.grad;
-    CodeT *__restrict__ codes = static_cast<CodeT *>(a.codes);
     const int64_t M = a.M;
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -68,6 +79,10 @@ __global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_k
         s_a[((rb * KS + s) * 2 + 0) * 64 + l] = hi;
         s_a[((rb * KS + s) * 2 + 1) * 64 + l] = lo;
     }
+    __shared__ int64_t s_seg[BATCHED ? PFD_LDS_SEGS * 8 : 1];
+    if (BATCHED) {
+        for (int i = threadIdx.x; i < a.nseg * 8; i += ENC_THREADS) s_seg[i] = a.seg_table[i];
+    }
     __syncthreads();
     // the error bound scales with max_k ||c_k||_1: measured, not assumed
     __shared__ float s_c1[ENC_WAVES];
@@ -85,32 +100,73 @@ __global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_k
     const float err_scale = c1 * ERR_SCALE;  // E = max|v_j| * err_scale
 
     // static split of the tiles between the two halves of the grid (pf_split)
-    const int64_t ntiles = (M + 63) >> 6;
+    const int64_t ntiles = BATCHED ? a.ntiles : ((M + 63) >> 6);
     int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
     int64_t t = (int64_t)blockIdx.x * ENC_WAVES + wave;
     int64_t tile_end = ntiles;
+    int64_t lo_tile = 0;
     if (a.split_tile >= 0) {
         const int64_t half = gridDim.x / 2;
         nw = half * ENC_WAVES;
         if ((int64_t)blockIdx.x < half) {
             tile_end = a.split_tile;
         } else {
+            lo_tile = a.split_tile;
             t = a.split_tile + ((int64_t)blockIdx.x - half) * ENC_WAVES + wave;
         }
+    }
+    int64_t tstep = nw;
+    if (BATCHED) {   // one contiguous run of tiles per wave
+        const int64_t chunk = (tile_end - lo_tile + nw - 1) / nw;
+        t = lo_tile + (t - lo_tile) * chunk;
+        tile_end = tile_end < t + chunk ? tile_end : t + chunk;
+        tstep = 1;
     }
     int *const counter = ws_counter(ws);
     int *const worklist = ws_worklist(ws);
 
+    typedef const float __attribute__((address_space(1))) *gcf_ptr;
+    typedef const f32x4 __attribute__((address_space(1))) *gcv_ptr;
+    typedef CodeT __attribute__((address_space(1))) *gcode_ptr;
+    struct Tile {
+        gcf_ptr base;      // the tensor's first float
+        int64_t m, sv0;    // its subvector count; this tile's first subvector inside it
+        int seg;
+        gcode_ptr codes;
+    };
+    auto uniform64 = [](int64_t v) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    auto tile_info = [&](int64_t tile, int seg) {
+        Tile ti;
+        if (BATCHED) {
+            const int64_t *rec = s_seg + 8 * seg;
+            ti.seg = seg;
+            ti.base = (gcf_ptr)(uintptr_t)uniform64(rec[0]);
+            ti.m = uniform64(rec[1]);
+            ti.sv0 = (tile - uniform64(rec[2])) * 64;
+            ti.codes = (gcode_ptr)((uintptr_t)a.wire + (uintptr_t)uniform64(rec[3]));
+        } else {
+            ti.seg = 0;
+            ti.base = (gcf_ptr)grad;
+            ti.m = M;
+            ti.sv0 = tile * 64;
+            ti.codes = (gcode_ptr)static_cast<CodeT *>(a.codes);
+        }
+        return ti;
+    };
     // tile data: lane (j, h) holds, for block b and k-step s, floats [16 s + 8 h, + 8) of subvector 32 b + j
-    auto load_tile = [&](int64_t tile, f32x4 (&dst)[2][KS][2]) {
+    auto load_tile = [&](const Tile &ti, f32x4 (&dst)[2][KS][2]) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            int64_t sv = tile * 64 + b * 32 + j;
-            sv = sv < M ? sv : M - 1;  // tail: re-read the last subvector, result is masked
+            int64_t sv = ti.sv0 + b * 32 + j;
+            sv = sv < ti.m ? sv : ti.m - 1;  // tail: re-read the last subvector, result is masked
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 if (16 * s + 8 * h < D) {
-                    const f32x4 *p = reinterpret_cast<const f32x4 *>(grad + sv * D + 16 * s + 8 * h);
+                    const gcv_ptr p = (gcv_ptr)(ti.base + sv * D + 16 * s + 8 * h);
                     dst[b][s][0] = p[0];
                     dst[b][s][1] = p[1];
                 } else {
@@ -129,18 +185,49 @@ __global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_k
     };
 
     float lmin = INFINITY, lmax = -INFINITY;
+    int cur_seg = -1;  // batched: segment the running (lmin, lmax) belongs to
+    auto flush_minmax = [&]() {  // batched: fold this wave's running (min,max) into its segment
+        const float lo = wave_min(lmin), hi = wave_max(lmax);
+        if (lane == 0 && cur_seg >= 0 && lo <= hi) {
+            unsigned *mm = a.seg_minmax + 2 * cur_seg;   // look before the atomic (hsq_encode_pf.hip)
+            const unsigned mlo = order_map(lo), mhi = order_map(hi);
+            const unsigned seen_lo = __hip_atomic_load(mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned seen_hi = __hip_atomic_load(mm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mlo < seen_lo) atomicMin(mm, mlo);
+            if (mhi > seen_hi) atomicMax(mm + 1, mhi);
+        }
+        lmin = INFINITY;
+        lmax = -INFINITY;
+    };
+    auto seg_of = [&](int64_t tile) {   // batched: tile -> tensor, one global word (0 beyond the end)
+        return (BATCHED && tile < tile_end) ? a.tile_seg[tile] : 0;
+    };
     f32x4 cur[2][KS][2], nxt[2][KS][2];
     bf16x8 vh[2][KS], vl[2][KS];
+    Tile ti = {};
+    int seg_n = seg_of(t + tstep);
+    int seg_next = 0;
     if (t < tile_end) {
-        load_tile(t, cur);
+        ti = tile_info(t, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[t]) : 0);
+        seg_next = BATCHED ? __builtin_amdgcn_readfirstlane(seg_n) : 0;
+        load_tile(ti, cur);
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int s = 0; s < KS; ++s) split8(cur[b][s][0], cur[b][s][1], vh[b][s], vl[b][s]);
     }
-    for (; t < tile_end; t += nw) {
-        const int64_t tn = t + nw;
-        if (tn < tile_end) load_tile(tn, nxt);  // prefetch the next tile
+    for (; t < tile_end; t += tstep) {
+        const int64_t tn = t + tstep;
+        Tile tin = ti;
+        if (tn < tile_end) {
+            tin = tile_info(tn, seg_next);
+            load_tile(tin, nxt);  // prefetch the next tile
+        }
+        seg_n = seg_of(tn + tstep);
+        if (BATCHED && ti.seg != cur_seg) {
+            flush_minmax();
+            cur_seg = ti.seg;
+        }
 
         // ---- prefilter: 16 chains in the order (rb, block 0), (rb, block 1); top-2 GROUP keys per
         // (block, row-block half).  The MFMAs of chain c+1 sit between the key operations of chain c.
@@ -257,10 +344,12 @@ __global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_k
         }
         // NaN anywhere makes the comparisons false -> not safe -> exact path
 
-        const int64_t sv = t * 64 + lane;
-        const bool valid = sv < M;
+        const int64_t sv = ti.sv0 + lane;                   // index inside this tile's tensor
+        const bool valid = sv < ti.m;
+        const int64_t gsv = BATCHED ? t * 64 + lane : sv;   // index into u / the fix-up log
 
         // consume the prefetched tile BEFORE this tile's stores are issued (hsq_encode_pf.hip)
+        if (BATCHED) seg_next = __builtin_amdgcn_readfirstlane(seg_n);
         if (tn < tile_end) {
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -312,18 +401,23 @@ __global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_k
                 val = bv;
                 idx = bi;
             }
-            if (lane == 0) {   // diagnostics only: which subvectors took this path
+            if (!BATCHED && lane == 0) {   // diagnostics only: which subvectors took this path
                 const int pos = atomicAdd(counter, 1);
                 worklist[pos] = (int)(t * 64 + fl);
             }
         }
 
         if (valid) {
-            codes[sv] = (CodeT)idx;
-            u[sv] = val;
+            ti.codes[sv] = (CodeT)idx;
+            u[gsv] = val;
             lmin = fminf(lmin, val);
             lmax = fmaxf(lmax, val);
         }
+        ti = tin;
+    }
+    if (BATCHED) {
+        flush_minmax();
+        return;
     }
     pf_finish_minmax<true>(lmin, lmax, ws);
 }
@@ -369,4 +463,52 @@ template int launch_encode_pfd<uint8_t>(const float *, const float *, int64_t, i
 template int launch_encode_pfd<int32_t>(const float *, const float *, int64_t, int, int32_t *, float *, float *,
                                         hipStream_t);
 
+template <int D>
+static int launch_pfd_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                              const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax, float *ws,
+                              hipStream_t st) {
+    constexpr int KS = D > 16 ? D / 16 : 1;
+    constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
+    static const int bpc = [] {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<uint8_t, D, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipGetLastError();
+        return resident_blocks_per_cu(hsq_encode_pfd_kernel<uint8_t, D, true>, ENC_THREADS, lds);
+    }();
+    PfdArgs a = {};
+    a.M = ntiles * 64;
+    a.u = u_flat;
+    a.cb = codebook;
+    a.ws = ws;
+    a.seg_table = seg_table;
+    a.tile_seg = tile_seg;
+    a.wire = wire;
+    a.seg_minmax = seg_minmax;
+    a.ntiles = ntiles;
+    a.nseg = nseg;
+    const int64_t blocks = pf_grid(ntiles, bpc);
+    a.split_tile = pf_split(ntiles, blocks, bpc);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<uint8_t, D, true>), dim3((unsigned)blocks),
+                       dim3(ENC_THREADS), lds, st, a);
+    GQ_CHECK_LAUNCH("gq_hsq_encode_batched_d");
+    return GQ_OK;
+}
+
 }  // namespace gq
+
+GQ_API int gq_hsq_encode_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                   const float *codebook, int d, uint8_t *wire, float *u_flat, uint32_t *seg_minmax,
+                                   float *workspace, void *stream) {
+    if (d == 16)
+        return gq_hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace, stream);
+    if (nseg < 1 || ntiles < 1 || ntiles * 64 > 0x7FFFFFFFLL)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_d: bad sizes nseg=%d ntiles=%lld", nseg, (long long)ntiles);
+    if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_d: null pointer");
+    if (nseg > gq::PFD_LDS_SEGS)
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched_d: at most %d tensors per launch for d = %d", gq::PFD_LDS_SEGS, d);
+    hipStream_t st = gq::as_stream(stream);
+    if (d == 8) return gq::launch_pfd_batched<8>(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace, st);
+    if (d == 32) return gq::launch_pfd_batched<32>(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace, st);
+    return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched_d: d must be 8, 16 or 32 (K = 256)");
+}

@@ -82,6 +82,15 @@ __device__ __forceinline__ f32x4 exact_score_quad(const float *__restrict__ quad
     return r;
 }
 
+// order-preserving float -> uint32 map for integer atomic min/max
+__device__ __forceinline__ unsigned order_map(float f) {
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float order_unmap(unsigned m) {
+    return __uint_as_float(m ^ ((m >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
 // End of a single-tensor prefilter kernel: per-workgroup (min,max) of u -> workspace; the LAST workgroup
 // to arrive (ticket counter; pairs published with agent-scope atomic stores and read back with
 // agent-scope atomic loads -- cdna_hip_programming.md G16) folds them into the final pair at slot 0,

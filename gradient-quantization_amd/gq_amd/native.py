@@ -22,6 +22,7 @@ EXPORTS = [
     "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_workspace_bytes", "gq_hsq_encode", "gq_hsq_encode_impl", "gq_hsq_levels",
     "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched",
     "gq_hsq_encode_batched_ef", "gq_hsq_levels_batched_ef", "gq_qsgd_compress_batched_ef",
+    "gq_hsq_encode_batched_d", "gq_hsq_decode_sum_batched_d",
     "gq_pvq_encode", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
@@ -178,8 +179,22 @@ def hsq_decode_sum_packed(wire, M, codebook, n_bit, out, R, codes_off=0, levels_
 
 
 def hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace, ef_scale=None):
-    """ef_scale given: the error-feedback form (seg_table[:, 7] = error buffers, grads updated in place)."""
+    """ef_scale given: the error-feedback form (seg_table[:, 7] = error buffers, grads updated in place).
+    The codebook's sub-dimension picks the kernel (K = 256; d = 16, or 8 / 32 without error feedback)."""
     assert workspace.numel() >= workspace_floats(ntiles * 64)
+    d = int(codebook.shape[1])
+    if d != 16:
+        if ef_scale is not None:
+            raise GQNativeError("gq_hsq_encode_batched_ef exists for d = 16 only")
+        rc = lib().gq_hsq_encode_batched_d(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                           _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                           ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
+                                           ctypes.c_int(d), _dev_ptr(wire, torch.uint8, "wire"),
+                                           _dev_ptr(u_flat, torch.float32, "u_flat"),
+                                           _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
+                                           _dev_ptr(workspace, torch.float32, "workspace"), _stream())
+        _check(rc, "gq_hsq_encode_batched_d")
+        return
     if ef_scale is not None:
         rc = lib().gq_hsq_encode_batched_ef(_dev_ptr(seg_table, torch.int64, "seg_table"),
                                             _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
@@ -223,6 +238,16 @@ def hsq_levels_batched(seg_table, tile_seg, nseg, ntiles, u_flat, seg_minmax, n_
 
 def hsq_decode_sum_batched(seg_table, tile_seg, nseg, ntiles, gathered, codebook, n_bit, out, R):
     assert gathered.dtype == torch.uint8 and gathered.dim() == 2 and gathered.shape[0] == R and gathered.is_contiguous()
+    d = int(codebook.shape[1])
+    if d != 16:
+        rc = lib().gq_hsq_decode_sum_batched_d(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                               _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                               ctypes.c_int64(ntiles), _dev_ptr(gathered, torch.uint8, "gathered"),
+                                               ctypes.c_int64(gathered.shape[1]), ctypes.c_int(R),
+                                               _dev_ptr(codebook, torch.float32, "codebook"), ctypes.c_int(d),
+                                               ctypes.c_int(n_bit), _dev_ptr(out, torch.float32, "out"), _stream())
+        _check(rc, "gq_hsq_decode_sum_batched_d")
+        return
     rc = lib().gq_hsq_decode_sum_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
                                          _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
                                          ctypes.c_int64(ntiles), _dev_ptr(gathered, torch.uint8, "gathered"),

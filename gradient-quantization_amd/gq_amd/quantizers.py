@@ -342,9 +342,15 @@ class BatchedHSQ(_BatchedBase):
     @staticmethod
     def eligible(codec):
         c = getattr(codec, "c", None)
-        return (type(codec) is HSQCodec and c.dim == 16 and c.K == 256 and c.compressed_norm
+        return (type(codec) is HSQCodec and c.dim in BatchedHSQ.DIMS and c.K == 256 and c.compressed_norm
                 and codec.code_dtype == torch.uint8 and codec.level_dtype == torch.uint8
                 and (not c.norm_compressor.random or c.norm_compressor._rng == "device"))
+
+    DIMS = (16, 8, 32)       # sub-dimensions with a multi-tensor prefilter encode (K = 256); one group per dimension
+
+    @staticmethod
+    def group_key(codec):
+        return codec.c.dim
 
     def __init__(self, codecs, offsets, idxs, device, slots, user_bytes):
         self.idxs = list(idxs)
@@ -382,6 +388,8 @@ class BatchedHSQ(_BatchedBase):
         tensor on this device: the caller then takes the per-tensor path for this step.
         With `errs` (error feedback, ps_quantizer.py:34-39) the same two launches also do
         t += ef_scale*err (in place, before encoding) and err = t - decoded (in place, after)."""
+        if self.codebook.shape[1] != 16 and (errs is not None or self.nseg > 384):
+            return False    # d = 8 / 32: no fused error feedback, at most 384 tensors per launch
         if not self._upload(tensors, slot, 16, errs):
             return False
         seg_table = self._dev[:self._table_words]
@@ -407,6 +415,10 @@ class BatchedQSGD(_BatchedBase):
     @staticmethod
     def eligible(codec):
         return type(codec) is QSGDCodec and codec.bits != 0
+
+    @staticmethod
+    def group_key(codec):
+        return (codec.bits, codec.c.bit)
 
     def __init__(self, codecs, offsets, idxs, device, slots, user_bytes):
         self.idxs = list(idxs)
@@ -516,9 +528,14 @@ class PSQuantizer(object):
         # tensors served by multi-tensor kernels: (class, parameter indices), built at the first record()
         self._groups = []
         for cls in (BatchedHSQ, BatchedQSGD):
-            idx = [i for i, c in enumerate(self.codecs) if cls.eligible(c)]
-            if len(idx) >= 2 and not getattr(args, "gq_no_batch", False):
-                self._groups.append([cls, idx, None])
+            keyed = {}
+            for i, c in enumerate(self.codecs):
+                if cls.eligible(c):
+                    keyed.setdefault(cls.group_key(c), []).append(i)
+            for key in sorted(keyed):
+                idx = keyed[key]
+                if len(idx) >= 2 and not getattr(args, "gq_no_batch", False):
+                    self._groups.append([cls, idx, None])
         self.batch_idx = [i for g in self._groups for i in g[1]]
         self.capacity = max(1, int(args.num_users))
         self.recorded = 0                   # record() calls since the last apply()

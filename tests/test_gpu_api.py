@@ -244,6 +244,25 @@ def test_batched_quantizer_equals_per_tensor_path():
     assert torch.equal(qb._wire, qp._wire)
 
 
+@pytest.mark.parametrize("c_dim", [32, 8])
+def test_batched_quantizer_other_subdimensions_equal_per_tensor_path(c_dim):
+    """The multi-tensor kernels for the other prefilter sub-dimensions (main.py's default --c-dim 32, and 8):
+    aggregates and wire identical to the per-tensor kernels; with error feedback the quantizer falls back
+    to the per-tensor path for these dimensions and still matches."""
+    shapes = RESNET50_COMPRESSED[:14] + RESNET50_SMALL[:3]
+    qb, gb = _run_quantizer(shapes, 2, 11, c_dim=c_dim)
+    qp, gp = _run_quantizer(shapes, 2, 11, c_dim=c_dim, gq_no_batch=True)
+    assert qb._groups and qb._groups[0][2] is not None and qb._groups[0][2].ready and not qp._groups
+    assert qb._groups[0][2].codebook.shape == (256, c_dim)
+    for a, b, s in zip(gb, gp, shapes):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), s
+    assert torch.equal(qb._wire, qp._wire)
+    qe, ge = _run_quantizer(shapes, 2, 11, c_dim=c_dim, ef=True)
+    qf, gf = _run_quantizer(shapes, 2, 11, c_dim=c_dim, ef=True, gq_no_batch=True)
+    for a, b in zip(ge, gf):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 def test_batched_quantizer_device_rng_and_misaligned_fallback():
     shapes = RESNET50_COMPRESSED[:6] + RESNET50_SMALL[:3]
     q, g = _run_quantizer(shapes, 2, 9, random=1)

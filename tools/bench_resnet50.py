@@ -47,3 +47,6 @@ run("QSGD d128 n2 per-tensor launches", QSGDCompressor, c_dim=128, n_bit=2, gq_n
 run("HSQ batched, error feedback", NearestNeighborCompressor, ef=True)
 run("HSQ batched, EF + two-phase", NearestNeighborCompressor, ef=True, two_phase=True)
 run("QSGD d128 n2 batched, error feedback", QSGDCompressor, c_dim=128, n_bit=2, ef=True)
+run("HSQ c-dim 32 batched", NearestNeighborCompressor, c_dim=32)
+run("HSQ c-dim 32 per-tensor launches", NearestNeighborCompressor, c_dim=32, gq_no_batch=True)
+run("HSQ c-dim 8 batched", NearestNeighborCompressor, c_dim=8)
