@@ -35,6 +35,10 @@
 
 namespace gq {
 
+// The d = 16 kernels run ONE workgroup of 8 waves per CU (two waves per SIMD, as before, but in one workgroup):
+// the waves of a workgroup share their tiles through an LDS counter (see the kernel).
+constexpr int PF_WAVES = 8;
+constexpr int PF_THREADS = PF_WAVES * 64;
 constexpr int PF_LDS_SEGS = 384;            // batched form: tensors whose segment records are kept in LDS (24 KiB)
 constexpr int QUAD_STRIDE = 68;             // LDS floats per GROUP of 4 codewords (64 used, 272 B = 17 x 16 B: random groups spread over the banks)
 
@@ -55,7 +59,6 @@ struct PfArgs {
     unsigned *seg_minmax;     // batched: order-mapped (min, max) per segment
     int64_t ntiles;
     int nseg;                 // batched: segments in seg_table
-    int64_t split_tile;       // >= 0: first half of the grid shares tiles [0, split_tile), second half the rest
     float ef_scale;           // EF kernels: grad <- grad + ef_scale * error (error pointer = seg_table[seg][7], 0 = none)
 };
 
@@ -63,7 +66,7 @@ struct PfArgs {
 // longer tensor lists, from global memory -- as two instantiations, because a run-time choice between
 // the two sources turns the record pointer into a flat pointer (see tile_info).
 template <typename CodeT, bool BATCHED, bool EF = false, bool SEGLDS = true>
-__global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfArgs a) {
+__global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfArgs a) {
     const float *__restrict__ cb = a.cb;
     float *__restrict__ ws = a.ws;
     float *__restrict__ u = a.u;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     // f32 codebook for the exact rescoring, codeword pairs interleaved element by element:
     // s_cb[(k>>2)*QUAD_STRIDE + 4*j + (k&3)] = c[k][j]
     __shared__ __attribute__((aligned(16))) float s_cb[64 * QUAD_STRIDE];
-    for (int i = threadIdx.x; i < 256 * 16; i += ENC_THREADS) {
+    for (int i = threadIdx.x; i < 256 * 16; i += PF_THREADS) {
         const int k = i >> 4, jj = i & 15;
         s_cb[(k >> 2) * QUAD_STRIDE + 4 * jj + (k & 3)] = cb[i];
     }
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     __shared__ int64_t s_seg[(BATCHED && SEGLDS) ? PF_LDS_SEGS * 8 : 1];
     if (BATCHED && SEGLDS) {
         const int n = (a.nseg < PF_LDS_SEGS ? a.nseg : PF_LDS_SEGS) * 8;
-        for (int i = threadIdx.x; i < n; i += ENC_THREADS) s_seg[i] = a.seg_table[i];
+        for (int i = threadIdx.x; i < n; i += PF_THREADS) s_seg[i] = a.seg_table[i];
     }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -102,51 +105,41 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     __syncthreads();
     // The error bound scales with max_k ||c_k||_1 (<= 4 for unit-L2 rows); measure it instead of
     // trusting the caller's codebook to be normalised.
-    __shared__ float s_c1[ENC_WAVES];
+    __shared__ float s_c1[PF_WAVES];
     {
         float l1 = 0.0f;
+        const int kk = threadIdx.x & 255;   // 256 codewords, twice
 #pragma unroll
-        for (int e = 0; e < 16; ++e) l1 += fabsf(s_cb[(threadIdx.x >> 2) * QUAD_STRIDE + 4 * e + (threadIdx.x & 3)]);
+        for (int e = 0; e < 16; ++e) l1 += fabsf(s_cb[(kk >> 2) * QUAD_STRIDE + 4 * e + (kk & 3)]);
         l1 = wave_max(l1);
         if ((threadIdx.x & 63) == 0) s_c1[threadIdx.x >> 6] = l1;
     }
     __syncthreads();
     float c1 = s_c1[0];
 #pragma unroll
-    for (int w = 1; w < ENC_WAVES; ++w) c1 = fmaxf(c1, s_c1[w]);
+    for (int w = 1; w < PF_WAVES; ++w) c1 = fmaxf(c1, s_c1[w]);
     const float err_scale = c1 * ERR_SCALE;  // E = max|v_j| * err_scale
 
     const int64_t ntiles = BATCHED ? a.ntiles : ((M + 63) >> 6);
-    // Static split of the tiles.  With two workgroups per CU the one dispatched first wins VALU
-    // arbitration on its SIMDs and runs ~1.55x faster than its partner, which then finishes the tail
-    // alone (tools/stamp_read.py: first half of the grid done after 37 us, second half after 50 us with
-    // an even split).  The launcher therefore gives the first half 63 % of the tiles (swept: 55..66 %).  A speed
-    // heuristic only: any dispatch order produces the same output.
-    int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
-    int64_t t = (int64_t)blockIdx.x * ENC_WAVES + wave;
-    int64_t tile_end = ntiles;
-    if (a.split_tile >= 0) {
-        const int64_t half = gridDim.x / 2;
-        nw = half * ENC_WAVES;
-        if ((int64_t)blockIdx.x < half) {
-            tile_end = a.split_tile;
-        } else {
-            t = a.split_tile + ((int64_t)blockIdx.x - half) * ENC_WAVES + wave;
-        }
-    }
-    // Single tensor: the waves interleave (tile t, t + nw, ...: the grid streams the gradient front to
-    // back).  Batched: every wave takes ONE CONTIGUOUS run of tiles instead, so that its running (min,max)
-    // stays with one tensor for many tiles -- interleaved, nearly every tile changes tensor and costs two
-    // atomics on that tensor's (min,max) words, and with ~2000 waves queueing on the few hot words of the
-    // big tensors (the next vmcnt wait covers them) the kernel ran 3x slower than the single-tensor one.
-    int64_t tstep = nw;
-    if (BATCHED) {
-        const int64_t lo = (a.split_tile >= 0 && (int64_t)blockIdx.x >= (int64_t)gridDim.x / 2) ? a.split_tile : 0;
-        const int64_t chunk = (tile_end - lo + nw - 1) / nw;
-        t = lo + (t - lo) * chunk;
-        tile_end = tile_end < t + chunk ? tile_end : t + chunk;
-        tstep = 1;
-    }
+    // Tiles: every workgroup owns one contiguous run [lo, hi) of them and its 8 waves draw from it through an
+    // LDS counter (ds_add_rtn: ~100 cycles, so a wave is committed to one tile beyond the one it works on --
+    // two in the batched form, which wants the tile -> tensor word a tile early).  The two waves of a SIMD do
+    // not run at one speed (the older one wins VALU arbitration, ~1.6x; profiles/r01_e_pf_kernel_stamps.txt)
+    // and a static split between them, however tuned, left the slowest wave ~15 % behind the mean; drawn from
+    // a shared counter the tiles go to whoever is free.  (Ticket counters in global memory cost an atomic round
+    // trip per tile, ~0.7 us, and commit a wave two tiles ahead: measured slower than the static split.)
+    // Contiguous runs also keep a wave's running (min,max) with one tensor for many tiles in the batched form.
+    const int64_t lo_tile = ((int64_t)blockIdx.x * ntiles) / gridDim.x;
+    const int64_t tile_end = (((int64_t)blockIdx.x + 1) * ntiles) / gridDim.x;
+    __shared__ int s_next;
+    if (threadIdx.x == 0) s_next = PF_WAVES;   // the first PF_WAVES tiles of the run go to the waves by index
+    __syncthreads();
+    auto draw = [&]() {   // the next tile of this workgroup's run (may lie beyond tile_end)
+        int k = 0;
+        if (lane == 0) k = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return lo_tile + __builtin_amdgcn_readfirstlane(k);
+    };
+    int64_t t = lo_tile + wave;
     int *const counter = ws_counter(ws);
     int *const worklist = ws_worklist(ws);
 
@@ -286,7 +279,8 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
     auto seg_of = [&](int64_t tile) {   // batched: tile -> tensor, one global word (0 beyond the end)
         return (BATCHED && tile < tile_end) ? a.tile_seg[tile] : 0;
     };
-    int seg_n = seg_of(t + tstep);      // in flight while the first tile is set up
+    int64_t tn = draw();                // the tile after this wave's first one
+    int seg_n = seg_of(tn);             // in flight while the first tile is set up
     int seg_next = 0;                   // its value, read back BEFORE a tile's stores (see the consume point)
     if (t < tile_end) {
         ti = tile_info(t, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[t]) : 0);
@@ -297,15 +291,16 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) split8(cur[2 * blk], cur[2 * blk + 1], vh[blk], vl[blk]);
     }
-    for (; t < tile_end; t += tstep) {
-        const int64_t tn = t + tstep;
+    while (t < tile_end) {
+        // single tensor: tn was drawn at the end of the previous tile; batched: a whole tile ago
+        const int64_t tnn = BATCHED ? draw() : 0;
         Tile tin = ti;
         if (tn < tile_end) {
             tin = tile_info(tn, seg_next);
             load_tile(tin, nxt);  // prefetch the next tile
             load_err(tin, nxte);
         }
-        seg_n = seg_of(tn + tstep);
+        seg_n = seg_of(tnn);
         if (BATCHED && ti.seg != cur_seg) {
             flush_minmax();
             cur_seg = ti.seg;
@@ -494,19 +489,30 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_pf_kernel(const PfA
             lmax = fmaxf(lmax, val);
         }
         ti = tin;
+        t = tn;
+        tn = BATCHED ? tnn : draw();
     }
     if (BATCHED) {
         flush_minmax();
         return;
     }
-    pf_finish_minmax<true>(lmin, lmax, ws);   // per-workgroup (min,max) -> the last workgroup folds the final (lb, ub)
+    pf_finish_minmax<true, PF_WAVES>(lmin, lmax, ws);   // per-workgroup (min,max) -> the last workgroup folds the final (lb, ub)
+}
+
+// one resident wave of 8-wave workgroups (the (min,max) slots of the workspace cap the grid)
+static int64_t pf16_grid(int64_t ntiles, int bpc) {
+    int64_t blocks = (ntiles + PF_WAVES - 1) / PF_WAVES;
+    int64_t cap = (int64_t)cu_count() * bpc;
+    if (cap > GQ_MAIN_PARTIALS) cap = GQ_MAIN_PARTIALS;
+    if (blocks > cap) blocks = cap;
+    return blocks < 1 ? 1 : blocks;
 }
 
 template <typename CodeT>
 int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *ws,
                      hipStream_t st) {
     if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
-    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<CodeT, false>, ENC_THREADS, 0);
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<CodeT, false>, PF_THREADS, 0);
     PfArgs a = {};
     a.grad = grad;
     a.M = M;
@@ -514,9 +520,8 @@ int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT 
     a.u = u;
     a.cb = codebook;
     a.ws = ws;
-    const int64_t blocks = pf_grid((M + 63) / 64, bpc);
-    a.split_tile = pf_split((M + 63) / 64, blocks, bpc);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, false>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0,
+    const int64_t blocks = pf16_grid((M + 63) / 64, bpc);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, false>), dim3((unsigned)blocks), dim3(PF_THREADS), 0,
                        st, a);
     GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter)");
     return GQ_OK;
@@ -536,7 +541,7 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
         return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes nseg=%d ntiles=%lld", what, nseg, (long long)ntiles);
     if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
         return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
-    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<uint8_t, true, EF, true>, ENC_THREADS, 0);
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<uint8_t, true, EF, true>, PF_THREADS, 0);
     PfArgs a = {};
     a.M = ntiles * 64;
     a.u = u_flat;
@@ -550,14 +555,13 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
     a.nseg = nseg;
     a.ef_scale = ef_scale;
     hipStream_t st = as_stream(stream);
-    const int64_t blocks = pf_grid(ntiles, bpc);
-    a.split_tile = pf_split(ntiles, blocks, bpc);
+    const int64_t blocks = pf16_grid(ntiles, bpc);
     if (nseg <= PF_LDS_SEGS) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, true, EF, true>), dim3((unsigned)blocks),
-                           dim3(ENC_THREADS), 0, st, a);
+                           dim3(PF_THREADS), 0, st, a);
     } else {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, true, EF, false>), dim3((unsigned)blocks),
-                           dim3(ENC_THREADS), 0, st, a);
+                           dim3(PF_THREADS), 0, st, a);
     }
     GQ_CHECK_LAUNCH(what);
     return GQ_OK;

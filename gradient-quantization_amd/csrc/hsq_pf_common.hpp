@@ -97,9 +97,9 @@ __device__ __forceinline__ float order_unmap(unsigned m) {
 // raises the `final` flag the level kernel looks at and re-zeroes the counters: no second launch, no
 // memset node.  `fold` = false (batched form: the per-tensor (min,max) went out by atomics) only resets
 // the counters.  Called by all threads of the workgroup.
-template <bool FOLD>
+template <bool FOLD, int WAVES = ENC_WAVES>
 __device__ __forceinline__ void pf_finish_minmax(float lmin, float lmax, float *__restrict__ ws) {
-    __shared__ float s_min[ENC_WAVES], s_max[ENC_WAVES];
+    __shared__ float s_min[WAVES], s_max[WAVES];
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int *const counter = ws_counter(ws);
@@ -115,7 +115,7 @@ __device__ __forceinline__ void pf_finish_minmax(float lmin, float lmax, float *
         if (FOLD) {
             float lo = s_min[0], hi = s_max[0];
 #pragma unroll
-            for (int w = 1; w < ENC_WAVES; ++w) {
+            for (int w = 1; w < WAVES; ++w) {
                 lo = fminf(lo, s_min[w]);
                 hi = fmaxf(hi, s_max[w]);
             }
@@ -131,7 +131,7 @@ __device__ __forceinline__ void pf_finish_minmax(float lmin, float lmax, float *
     if (!s_last) return;
     float lo = INFINITY, hi = -INFINITY;
     if (FOLD) {
-        for (int i = threadIdx.x; i < (int)gridDim.x; i += ENC_THREADS) {
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += WAVES * 64) {
             lo = fminf(lo, __hip_atomic_load(ws + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             hi = fmaxf(hi, __hip_atomic_load(ws + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
@@ -147,7 +147,7 @@ __device__ __forceinline__ void pf_finish_minmax(float lmin, float lmax, float *
     if (threadIdx.x == 0) {
         if (FOLD) {
 #pragma unroll
-            for (int w = 1; w < ENC_WAVES; ++w) {
+            for (int w = 1; w < WAVES; ++w) {
                 lo = fminf(lo, s_min[w]);
                 hi = fmaxf(hi, s_max[w]);
             }

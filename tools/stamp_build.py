@@ -20,20 +20,20 @@ def rep(old, new):
     s = s.replace(old, new, 1)
 rep("    const float *__restrict__ cb = a.cb;\n    float *__restrict__ ws = a.ws;\n    float *__restrict__ u = a.u;\n    const int64_t M = a.M;\n    // f32 codebook",
     "    const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();\n    const float *__restrict__ cb = a.cb;\n    float *__restrict__ ws = a.ws;\n    float *__restrict__ u = a.u;\n    const int64_t M = a.M;\n    // f32 codebook")
-rep("    for (; t < tile_end; t += tstep) {\n        const int64_t tn = t + tstep;",
+rep("    while (t < tile_end) {\n        // single tensor: tn was drawn at the end of the previous tile; batched: a whole tile ago",
     "    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();\n    unsigned long long ntl = 0;\n    unsigned long long stamp_acc[6] = {0,0,0,0,0,0}; unsigned long long ts_prev; "
-    "asm volatile(\"s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(ts_prev) :: \"memory\");\n    for (; t < tile_end; t += tstep) {\n        const int64_t tn = t + tstep;")
+    "asm volatile(\"s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(ts_prev) :: \"memory\");\n    while (t < tile_end) {\n        // single tensor: tn was drawn at the end of the previous tile; batched: a whole tile ago")
 for i, marker in enumerate(["        // ---- prefilter: 16 (block, row block) chains",
                             "        // ---- per block: merge the two trackers",
                             "        // ---- exact rescoring of the better of the two",
                             "        // Consume the prefetched tile (convert it to the next B fragments)",
                             "        // ---- exact fix-up, in place and wave-wide"]):
     rep(marker, stamp.replace("ID", str(i)) + marker)
-rep("        ti = tin;\n    }\n    if (BATCHED) {\n        flush_minmax();",
-    "        ti = tin;\n" + stamp.replace("ID", "5") + "        ++ntl;\n    }\n"
+rep("        ti = tin;\n        t = tn;\n        tn = BATCHED ? tnn : draw();\n    }\n    if (BATCHED) {\n        flush_minmax();",
+    "        ti = tin;\n        t = tn;\n        tn = BATCHED ? tnn : draw();\n" + stamp.replace("ID", "5") + "        ++ntl;\n    }\n"
     "    { const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();\n"
-    "      if (lane == 0 && blockIdx.x < 512) {\n"
-    "          unsigned long long *o = reinterpret_cast<unsigned long long *>(ws_worklist(ws) + (M - 65536)) + (blockIdx.x * 4 + wave) * 10;\n"
+    "      if (lane == 0 && blockIdx.x < 256) {\n"
+    "          unsigned long long *o = reinterpret_cast<unsigned long long *>(ws_worklist(ws) + (M - 65536)) + (blockIdx.x * 8 + wave) * 10;\n"
     "          for (int i = 0; i < 6; ++i) o[i] = stamp_acc[i];\n"
     "          o[6] = rt_entry; o[7] = rt0; o[8] = rt1; o[9] = ntl; } }\n    if (BATCHED) {\n        flush_minmax();")
 open(p, "w").write(s)

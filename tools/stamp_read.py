@@ -17,12 +17,12 @@ for _ in range(3):
     native.hsq_encode(g, cb, codes, u, ws, impl=4)
 torch.cuda.synchronize()
 wl = ws[2 * native.GQ_MAX_PARTIALS + 4:2 * native.GQ_MAX_PARTIALS + 4 + M]
-raw = wl[M - 65536:M - 65536 + 512 * 4 * 10 * 2].contiguous().view(torch.int64).view(-1, 10).cpu().numpy().astype(np.float64)
+raw = wl[M - 65536:M - 65536 + 256 * 8 * 10 * 2].contiguous().view(torch.int64).view(-1, 10).cpu().numpy().astype(np.float64)
 seg, entry, rt0, rt1 = raw[:, :6], raw[:, 6], raw[:, 7], raw[:, 8]
 names = ["prefetch issue / loop top", "16 chains (MFMA + keys)", "tracker merge + swaps", "exact rescoring (LDS gather)",
          "next-tile bf16 split", "exact fix-up (rare) + stores"]
 tiles_w = raw[:, 9]                                   # tiles each wave actually processed (dynamic scheduling)
-first = np.arange(len(raw)) < len(raw) // 2
+first = (np.arange(len(raw)) % 8) < 4          # waves 0-3 of a workgroup (one per SIMD) vs waves 4-7
 tiles = tiles_w.mean()
 cyc = seg.sum(1).mean()
 loop_us = (rt1 - rt0).mean() / 100
@@ -32,8 +32,8 @@ for n, v in zip(names, seg.mean(0)):
 print("prologue per wave %.1f us (min %.1f, max %.1f); first entry -> last loop end %.1f us; loop-end skew %.1f us"
       % ((rt0 - entry).mean() / 100, (rt0 - entry).min() / 100, (rt0 - entry).max() / 100, (rt1.max() - entry.min()) / 100, (rt1.max() - rt1.min()) / 100))
 end = (rt1 - entry.min()) / 100
-blk = np.arange(len(end)) // 4
-for lo, hi in [(0, 128), (128, 256), (256, 384), (384, 512)]:
+blk = np.arange(len(end)) // 8
+for lo, hi in [(0, 64), (64, 128), (128, 192), (192, 256)]:
     m = (blk >= lo) & (blk < hi)
     print("blocks %3d-%3d: loop ends at %.1f us on average (min %.1f, max %.1f), loop length %.1f us, %.1f tiles per wave, %.0f cycles per tile"
           % (lo, hi - 1, end[m].mean(), end[m].min(), end[m].max(), ((rt1 - rt0)[m] / 100).mean(), tiles_w[m].mean(), (seg.sum(1)[m] / tiles_w[m]).mean()))
@@ -44,6 +44,6 @@ for x in range(8):
     print("  xcd %d: %.2f tiles, %.0f cycles/tile, ends %.1f us (max %.1f) | second half: %.2f tiles, ends %.1f us (max %.1f)"
           % (x, tiles_w[m].mean(), (seg.sum(1)[m] / np.maximum(tiles_w[m], 1)).mean(), end[m].mean(), end[m].max(),
              tiles_w[(xcd == x) & ~first].mean(), end[(xcd == x) & ~first].mean(), end[(xcd == x) & ~first].max()))
-cu = blk % 256
+cu = blk
 slow = np.argsort([end[cu == c].max() for c in range(256)])[-8:]
 print("slowest CUs-slots (workgroup index % 256):", slow, [round(float(end[cu == c].max()), 1) for c in slow])
