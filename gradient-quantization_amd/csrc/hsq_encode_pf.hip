@@ -39,6 +39,7 @@ namespace gq {
 // the waves of a workgroup share their tiles through an LDS counter (see the kernel).
 constexpr int PF_WAVES = 8;
 constexpr int PF_THREADS = PF_WAVES * 64;
+constexpr int PF_TAIL = 6;   // swept 2..12 (52.3 us at 4..8, 54 at 2 and 12)
 constexpr int PF_LDS_SEGS = 384;            // batched form: tensors whose segment records are kept in LDS (24 KiB)
 constexpr int QUAD_STRIDE = 68;             // LDS floats per GROUP of 4 codewords (64 used, 272 B = 17 x 16 B: random groups spread over the banks)
 
@@ -134,9 +135,15 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     __shared__ int s_next;
     if (threadIdx.x == 0) s_next = PF_WAVES;   // the first PF_WAVES tiles of the run go to the waves by index
     __syncthreads();
+    // The second wave of a SIMD (waves 4-7: the slower of the pair) leaves the last PF_TAIL tiles of the run to
+    // the first one: a tile it started that late would finish ~1.5 us after everybody else.
+    const int tail_from = (int)(tile_end - lo_tile) - (wave >= PF_WAVES / 2 ? PF_TAIL : 0);
     auto draw = [&]() {   // the next tile of this workgroup's run (may lie beyond tile_end)
-        int k = 0;
-        if (lane == 0) k = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int k = 0x3FFFFFFF;
+        if (lane == 0) {
+            if (__hip_atomic_load(&s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < tail_from)
+                k = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         return lo_tile + __builtin_amdgcn_readfirstlane(k);
     };
     int64_t t = lo_tile + wave;
