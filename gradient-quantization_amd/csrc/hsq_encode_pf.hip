@@ -75,6 +75,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // f32 codebook for the exact rescoring, codeword pairs interleaved element by element:
     // s_cb[(k>>2)*QUAD_STRIDE + 4*j + (k&3)] = c[k][j]
     __shared__ __attribute__((aligned(16))) float s_cb[64 * QUAD_STRIDE];
+    __shared__ int s_next;                     // tile counter of this workgroup's run (see below)
+    if (threadIdx.x == 0) s_next = PF_WAVES;   // the first PF_WAVES tiles of the run go to the waves by index
     for (int i = threadIdx.x; i < 256 * 16; i += PF_THREADS) {
         const int k = i >> 4, jj = i & 15;
         s_cb[(k >> 2) * QUAD_STRIDE + 4 * jj + (k & 3)] = cb[i];
@@ -132,9 +134,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // Contiguous runs also keep a wave's running (min,max) with one tensor for many tiles in the batched form.
     const int64_t lo_tile = ((int64_t)blockIdx.x * ntiles) / gridDim.x;
     const int64_t tile_end = (((int64_t)blockIdx.x + 1) * ntiles) / gridDim.x;
-    __shared__ int s_next;
-    if (threadIdx.x == 0) s_next = PF_WAVES;   // the first PF_WAVES tiles of the run go to the waves by index
-    __syncthreads();
     // The second wave of a SIMD (waves 4-7: the slower of the pair) leaves the last PF_TAIL tiles of the run to
     // the first one: a tile it started that late would finish ~1.5 us after everybody else.
     const int tail_from = (int)(tile_end - lo_tile) - (wave >= PF_WAVES / 2 ? PF_TAIL : 0);
