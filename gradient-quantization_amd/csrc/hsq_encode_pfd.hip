@@ -23,7 +23,6 @@ struct PfdArgs {
     float *u;
     const float *cb;
     float *ws;
-    int64_t split_tile;   // pf_split()
     // batched form (gq_hsq_encode_batched_d): as PfArgs in hsq_encode_pf.hip; M = ntiles * 64
     const int64_t *seg_table;
     const int32_t *tile_seg;
@@ -43,7 +42,11 @@ constexpr int PFD_LDS_SEGS = 384;   // batched form: segment records kept in LDS
 // by look-before-you-leap atomics, table-derived addresses as global address-space pointers: everything as in
 // hsq_encode_pf.hip, where the reasons are written down.
 template <typename CodeT, int D, bool BATCHED = false>
-__global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_kernel(const PfdArgs a) {
+__global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kernel(const PfdArgs a) {
+    // one workgroup per CU: 8 waves (two per SIMD) for D = 8, 4 waves (one per SIMD) for D = 32; the waves share the
+    // workgroup's contiguous run of tiles through an LDS counter (hsq_encode_pf.hip)
+    constexpr int WAVES = D == 32 ? 4 : 8;
+    constexpr int THREADS = WAVES * 64;
     static_assert(D == 8 || D == 32, "built for D = 8 and D = 32 (D = 16: hsq_encode_pf.hip)");
     constexpr int KS = D > 16 ? D / 16 : 1;    // MFMA k-steps per chain
     constexpr int QS = 4 * D + 4;              // LDS floats per group of 4 codewords: an odd number of 16-byte units
@@ -60,13 +63,15 @@ __global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_k
     const int j = lane & 31, h = lane >> 5;
 
     // exact f32 codebook, groups of 4 codewords interleaved: s_cb[(k>>2)*QS + 4*e + (k&3)] = c[k][e]
-    for (int i = threadIdx.x; i < 256 * D; i += ENC_THREADS) {
+    __shared__ int s_next;
+    if (threadIdx.x == 0) s_next = WAVES;
+    for (int i = threadIdx.x; i < 256 * D; i += THREADS) {
         const int k = i / D, e = i % D;
         s_cb[(k >> 2) * QS + 4 * e + (k & 3)] = cb[i];
     }
     // A fragments of v_mfma_f32_32x32x16_bf16: lane (row j, half h) of k-step s holds
     // c[rb*32 + j][16 s + 8 h .. + 7] (zeros beyond D), split into bf16 hi and lo
-    for (int i = threadIdx.x; i < 8 * KS * 64; i += ENC_THREADS) {
+    for (int i = threadIdx.x; i < 8 * KS * 64; i += THREADS) {
         const int l = i & 63, s = (i >> 6) % KS, rb = i / (64 * KS);
         const int row = rb * 32 + (l & 31), e0 = 16 * s + 8 * (l >> 5);
         f32x4 q0 = {0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0;
@@ -81,47 +86,38 @@ __global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_k
     }
     __shared__ int64_t s_seg[BATCHED ? PFD_LDS_SEGS * 8 : 1];
     if (BATCHED) {
-        for (int i = threadIdx.x; i < a.nseg * 8; i += ENC_THREADS) s_seg[i] = a.seg_table[i];
+        for (int i = threadIdx.x; i < a.nseg * 8; i += THREADS) s_seg[i] = a.seg_table[i];
     }
     __syncthreads();
     // the error bound scales with max_k ||c_k||_1: measured, not assumed
-    __shared__ float s_c1[ENC_WAVES];
+    __shared__ float s_c1[WAVES];
     {
         float l1 = 0.0f;
 #pragma unroll
-        for (int e = 0; e < D; ++e) l1 += fabsf(s_cb[(threadIdx.x >> 2) * QS + 4 * e + (threadIdx.x & 3)]);
+        for (int e = 0; e < D; ++e) l1 += fabsf(s_cb[((threadIdx.x & 255) >> 2) * QS + 4 * e + (threadIdx.x & 3)]);
         l1 = wave_max(l1);
         if (lane == 0) s_c1[wave] = l1;
     }
     __syncthreads();
     float c1 = s_c1[0];
 #pragma unroll
-    for (int w = 1; w < ENC_WAVES; ++w) c1 = fmaxf(c1, s_c1[w]);
+    for (int w = 1; w < WAVES; ++w) c1 = fmaxf(c1, s_c1[w]);
     const float err_scale = c1 * ERR_SCALE;  // E = max|v_j| * err_scale
 
-    // static split of the tiles between the two halves of the grid (pf_split)
     const int64_t ntiles = BATCHED ? a.ntiles : ((M + 63) >> 6);
-    int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
-    int64_t t = (int64_t)blockIdx.x * ENC_WAVES + wave;
-    int64_t tile_end = ntiles;
-    int64_t lo_tile = 0;
-    if (a.split_tile >= 0) {
-        const int64_t half = gridDim.x / 2;
-        nw = half * ENC_WAVES;
-        if ((int64_t)blockIdx.x < half) {
-            tile_end = a.split_tile;
-        } else {
-            lo_tile = a.split_tile;
-            t = a.split_tile + ((int64_t)blockIdx.x - half) * ENC_WAVES + wave;
+    const int64_t lo_tile = ((int64_t)blockIdx.x * ntiles) / gridDim.x;
+    const int64_t tile_end = (((int64_t)blockIdx.x + 1) * ntiles) / gridDim.x;
+    // the slower wave of a SIMD (waves 4-7 of an 8-wave workgroup) leaves the last tiles of the run to the faster one
+    const int tail_from = (int)(tile_end - lo_tile) - ((WAVES == 8 && wave >= 4) ? 6 : 0);
+    auto draw = [&]() {   // the next tile of this workgroup's run (may lie beyond tile_end)
+        int k = 0x3FFFFFFF;
+        if (lane == 0) {
+            if (__hip_atomic_load(&s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < tail_from)
+                k = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-    }
-    int64_t tstep = nw;
-    if (BATCHED) {   // one contiguous run of tiles per wave
-        const int64_t chunk = (tile_end - lo_tile + nw - 1) / nw;
-        t = lo_tile + (t - lo_tile) * chunk;
-        tile_end = tile_end < t + chunk ? tile_end : t + chunk;
-        tstep = 1;
-    }
+        return lo_tile + __builtin_amdgcn_readfirstlane(k);
+    };
+    int64_t t = lo_tile + wave;
     int *const counter = ws_counter(ws);
     int *const worklist = ws_worklist(ws);
 
@@ -205,7 +201,8 @@ __global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_k
     f32x4 cur[2][KS][2], nxt[2][KS][2];
     bf16x8 vh[2][KS], vl[2][KS];
     Tile ti = {};
-    int seg_n = seg_of(t + tstep);
+    int64_t tn = draw();
+    int seg_n = seg_of(tn);
     int seg_next = 0;
     if (t < tile_end) {
         ti = tile_info(t, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[t]) : 0);
@@ -216,14 +213,14 @@ __global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_k
 #pragma unroll
             for (int s = 0; s < KS; ++s) split8(cur[b][s][0], cur[b][s][1], vh[b][s], vl[b][s]);
     }
-    for (; t < tile_end; t += tstep) {
-        const int64_t tn = t + tstep;
+    while (t < tile_end) {
+        const int64_t tnn = BATCHED ? draw() : 0;   // batched: one more tile ahead, for its tile -> tensor word
         Tile tin = ti;
         if (tn < tile_end) {
             tin = tile_info(tn, seg_next);
             load_tile(tin, nxt);  // prefetch the next tile
         }
-        seg_n = seg_of(tn + tstep);
+        seg_n = seg_of(tnn);
         if (BATCHED && ti.seg != cur_seg) {
             flush_minmax();
             cur_seg = ti.seg;
@@ -414,24 +411,35 @@ __global__ __launch_bounds__(ENC_THREADS, D == 32 ? 1 : 2) void hsq_encode_pfd_k
             lmax = fmaxf(lmax, val);
         }
         ti = tin;
+        t = tn;
+        tn = BATCHED ? tnn : draw();
     }
     if (BATCHED) {
         flush_minmax();
         return;
     }
-    pf_finish_minmax<true>(lmin, lmax, ws);
+    pf_finish_minmax<true, WAVES>(lmin, lmax, ws);
+}
+
+static int64_t pfd_grid(int64_t ntiles, int bpc, int waves) {
+    int64_t blocks = (ntiles + waves - 1) / waves;
+    int64_t cap = (int64_t)cu_count() * bpc;
+    if (cap > GQ_MAIN_PARTIALS) cap = GQ_MAIN_PARTIALS;
+    if (blocks > cap) blocks = cap;
+    return blocks < 1 ? 1 : blocks;
 }
 
 template <typename CodeT, int D>
 static int launch_pfd(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *ws,
                       hipStream_t st) {
     constexpr int KS = D > 16 ? D / 16 : 1;
+    constexpr int WAVES = D == 32 ? 4 : 8, THREADS = WAVES * 64;
     constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
     static const int bpc = [] {
         hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<CodeT, D>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
-        return resident_blocks_per_cu(hsq_encode_pfd_kernel<CodeT, D>, ENC_THREADS, lds);
+        return resident_blocks_per_cu(hsq_encode_pfd_kernel<CodeT, D>, THREADS, lds);
     }();
     PfdArgs a = {};
     a.grad = grad;
@@ -441,9 +449,8 @@ static int launch_pfd(const float *grad, const float *codebook, int64_t M, CodeT
     a.cb = codebook;
     a.ws = ws;
     const int64_t ntiles = (M + 63) / 64;
-    const int64_t blocks = pf_grid(ntiles, bpc);
-    a.split_tile = pf_split(ntiles, blocks, bpc);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<CodeT, D>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds,
+    const int64_t blocks = pfd_grid(ntiles, bpc, WAVES);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<CodeT, D>), dim3((unsigned)blocks), dim3(THREADS), lds,
                        st, a);
     GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter, d = 8 / 32)");
     return GQ_OK;
@@ -468,12 +475,13 @@ static int launch_pfd_batched(const int64_t *seg_table, const int32_t *tile_seg,
                               const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax, float *ws,
                               hipStream_t st) {
     constexpr int KS = D > 16 ? D / 16 : 1;
+    constexpr int WAVES = D == 32 ? 4 : 8, THREADS = WAVES * 64;
     constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
     static const int bpc = [] {
         hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<uint8_t, D, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
-        return resident_blocks_per_cu(hsq_encode_pfd_kernel<uint8_t, D, true>, ENC_THREADS, lds);
+        return resident_blocks_per_cu(hsq_encode_pfd_kernel<uint8_t, D, true>, THREADS, lds);
     }();
     PfdArgs a = {};
     a.M = ntiles * 64;
@@ -486,10 +494,9 @@ static int launch_pfd_batched(const int64_t *seg_table, const int32_t *tile_seg,
     a.seg_minmax = seg_minmax;
     a.ntiles = ntiles;
     a.nseg = nseg;
-    const int64_t blocks = pf_grid(ntiles, bpc);
-    a.split_tile = pf_split(ntiles, blocks, bpc);
+    const int64_t blocks = pfd_grid(ntiles, bpc, WAVES);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<uint8_t, D, true>), dim3((unsigned)blocks),
-                       dim3(ENC_THREADS), lds, st, a);
+                       dim3(THREADS), lds, st, a);
     GQ_CHECK_LAUNCH("gq_hsq_encode_batched_d");
     return GQ_OK;
 }

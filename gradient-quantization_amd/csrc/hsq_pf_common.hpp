@@ -160,23 +160,4 @@ __device__ __forceinline__ void pf_finish_minmax(float lmin, float lmax, float *
     }
 }
 
-// Persistent grid of a prefilter kernel and the static split of its tiles: the first-dispatched half of
-// the grid gets `permille` of the tiles when exactly two workgroups share every CU (of the two, the older
-// one wins VALU arbitration and runs ~1.6x faster; profiles/r01_e_pf_kernel_stamps.txt); -1 = even split.
-static inline int64_t pf_grid(int64_t ntiles, int bpc) {
-    int64_t blocks = (ntiles + ENC_WAVES - 1) / ENC_WAVES;
-    int64_t cap = (int64_t)cu_count() * bpc;
-    if (cap > GQ_MAIN_PARTIALS) cap = GQ_MAIN_PARTIALS;
-    if (blocks > cap) blocks = cap;
-    return blocks < 1 ? 1 : blocks;
-}
-static inline int64_t pf_split(int64_t ntiles, int64_t blocks, int bpc) {
-    static const int permille = [] {
-        const char *e = getenv("GQ_PF_SPLIT");
-        return e ? atoi(e) : 625;
-    }();
-    if (permille <= 0 || bpc != 2 || blocks != (int64_t)cu_count() * 2 || ntiles < blocks * ENC_WAVES * 4) return -1;
-    return (ntiles * permille) / 1000;
-}
-
 }  // namespace gq
