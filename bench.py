@@ -13,7 +13,7 @@ owns a full-size gradient (it is one of the reference's `num_users`).
 
 Extra objects on the JSON line:
   roofline      dominant kernel (hsq_encode): algorithmic bytes (4.125 B/element)
-                / its average launch duration, measured with HIP events on the launch stream
+                / its average launch duration, measured with HIP events attached to its dispatch
                 inside the timed region; peak = 8 TB/s HBM3E.
   cpu_baseline  the CPU oracle (oracle/gq_oracle.c, OpenMP) timed on a bounded sample of
                 the same gradient on this box's host cores (rank 0, N=1 only).
@@ -126,19 +126,19 @@ def main():
         compress()
         exchange_and_decode()
 
-    # HIP events around the dominant kernel, live in the timed region.  An event pair costs ~5 us of
-    # queue bubbles on this runtime (calibrated below), so only every 4th step carries one.
-    ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for i in range(0, args.steps, 4)}
+    # HIP events on the dominant kernel, live in the timed region: a start/stop pair ATTACHED to the encode's
+    # dispatch (hipExtLaunchKernelGGL through gq_profile_arm) on up to 64 of the steps.  An event bracket
+    # recorded around the call would also measure 5-8 us of queue bubbles and put them into the timed
+    # region (calibrated below for reference).
+    stride = max(1, -(-args.steps // 64))
+    armed = list(range(0, args.steps, stride))[:64]
+    slot_of = {i: k for k, i in enumerate(armed)}
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i in ev:
-            ev[i][0].record()
-            native.hsq_encode(g, cb, codes, u, partials)
-            ev[i][1].record()
-        else:
-            native.hsq_encode(g, cb, codes, u, partials)
+        if i in slot_of:
+            native.profile_arm(slot_of[i])
+        native.hsq_encode(g, cb, codes, u, partials)
         native.hsq_levels(u, N_BIT, args.random, None, 1234 + rank, partials, lb_ub, levels)
         exchange_and_decode()
     barrier()
@@ -147,7 +147,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev.values()]))
+    enc_ms = float(np.mean([native.profile_read(k) for k in range(len(armed))]))
 
     # ---- untimed breakdown pass (events per phase), for DESIGN.md / the judge ----------
     def phase_ms(fn, n=20):
@@ -159,8 +159,8 @@ def main():
         e.record()
         torch.cuda.synchronize()
         return s.elapsed_time(e) / n
-    # what an event pair measures with NOTHING in between, and the encode launched back to back
-    # (one event pair around 20 launches): the difference to enc_ms is the bracket's own cost
+    # for reference: what an event pair RECORDED on the stream measures with nothing in between, a recorded
+    # bracket around one encode, and the encode launched back to back (one pair around 20 launches)
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
     torch.cuda.synchronize()
     for a, b in pairs:
@@ -169,6 +169,13 @@ def main():
     torch.cuda.synchronize()
     ev_overhead_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))
     enc_b2b_ms = phase_ms(lambda: native.hsq_encode(g, cb, codes, u, partials))
+    torch.cuda.synchronize()
+    for a, b in pairs:
+        a.record()
+        native.hsq_encode(g, cb, codes, u, partials)
+        b.record()
+    torch.cuda.synchronize()
+    enc_bracket_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))
     lv_ms = phase_ms(lambda: native.hsq_levels(u, N_BIT, args.random, None, 1234 + rank, partials, lb_ub, levels))
     cmp_ms = phase_ms(compress)
     dec_ms = phase_ms(exchange_and_decode)
@@ -195,13 +202,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "gq_hsq_encode = hsq_encode_pf_kernel (one launch: prefilter, exact rescoring, in-place exact fix-up, final lb/ub)",
                          "kernel_ms": enc_ms, "kernel_ms_back_to_back": enc_b2b_ms,
-                         "empty_event_pair_ms": ev_overhead_ms,
-                         "achieved_net_of_event_overhead": ALGO_BYTES_PER_ELEM * SIZE / ((enc_ms - ev_overhead_ms) * 1e-3) / 1e9,
+                         "kernel_ms_recorded_bracket": enc_bracket_ms, "empty_recorded_bracket_ms": ev_overhead_ms,
                          "note": "exact f32 scoring would need 512 flop/element (81 us at 157.3 TFLOP/s); the "
-                                 "bf16x3 prefilter + exact rescoring path is bound by VALU issue, not by HBM.  kernel_ms is the "
-                                 "raw HIP-event bracket in the timed region; an EMPTY bracket already reads "
-                                 "empty_event_pair_ms, and the same launch timed back to back (and by rocprofv3, "
-                                 "profiles/) takes kernel_ms_back_to_back"},
+                                 "bf16x3 prefilter + exact rescoring path is bound by VALU issue, not by HBM.  kernel_ms: HIP "
+                                 "start/stop events attached to the kernel's dispatch inside the timed region "
+                                 "(agrees with rocprofv3, profiles/); a bracket RECORDED around the call reads "
+                                 "kernel_ms_recorded_bracket, an empty one empty_recorded_bracket_ms"},
             "phases_ms": {"encode": enc_ms, "levels": lv_ms, "compress": cmp_ms,
                           "exchange+decode_mean": dec_ms},
             "compress_only": {"value": world * SIZE / (cmp_ms * 1e-3), "unit": "elements/s"},

@@ -19,6 +19,20 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// ---- per-dispatch timing (gq_profile_arm / gq_profile_read) -------------------------------------------
+static thread_local int g_armed_slot = -1;
+static hipEvent_t g_prof_events[GQ_PROFILE_SLOTS][2];
+static bool g_prof_created[GQ_PROFILE_SLOTS];
+
+bool profile_take(hipEvent_t *start, hipEvent_t *stop) {
+    const int slot = g_armed_slot;
+    if (slot < 0) return false;
+    g_armed_slot = -1;
+    *start = g_prof_events[slot][0];
+    *stop = g_prof_events[slot][1];
+    return true;
+}
+
 int cu_count() {
     static thread_local int cached_dev = -1;
     static thread_local int cached_cus = 0;
@@ -91,5 +105,25 @@ GQ_API int gq_sub(const float *grad, const float *decoded, float *err, int64_t n
     hipLaunchKernelGGL(gq::sub_kernel, dim3(gq::grid_for(n, 256)), dim3(256), 0, gq::as_stream(stream), grad, decoded,
                        err, n);
     GQ_CHECK_LAUNCH("gq_sub");
+    return GQ_OK;
+}
+
+GQ_API int gq_profile_arm(int slot) {
+    if (slot < 0 || slot >= GQ_PROFILE_SLOTS) return gq::fail(GQ_ERR_INVALID_ARG, "gq_profile_arm: slot %d", slot);
+    if (!gq::g_prof_created[slot]) {
+        if (hipEventCreate(&gq::g_prof_events[slot][0]) != hipSuccess || hipEventCreate(&gq::g_prof_events[slot][1]) != hipSuccess)
+            return gq::fail(GQ_ERR_HIP, "gq_profile_arm: hipEventCreate failed");
+        gq::g_prof_created[slot] = true;
+    }
+    gq::g_armed_slot = slot;
+    return GQ_OK;
+}
+
+GQ_API int gq_profile_read(int slot, float *kernel_ms) {
+    if (slot < 0 || slot >= GQ_PROFILE_SLOTS || !kernel_ms || !gq::g_prof_created[slot])
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_profile_read: slot %d was never armed", slot);
+    if (hipEventSynchronize(gq::g_prof_events[slot][1]) != hipSuccess ||
+        hipEventElapsedTime(kernel_ms, gq::g_prof_events[slot][0], gq::g_prof_events[slot][1]) != hipSuccess)
+        return gq::fail(GQ_ERR_HIP, "gq_profile_read: the armed launch did not happen or has not completed");
     return GQ_OK;
 }

@@ -18,6 +18,8 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 // Number of compute units of the current device (cached).
 int cu_count();
+// true (once) if gq_profile_arm was called on this thread: the events to attach to the next dispatch
+bool profile_take(hipEvent_t *start, hipEvent_t *stop);
 
 #define GQ_CHECK_LAUNCH(what)                                                              \
     do {                                                                                   \

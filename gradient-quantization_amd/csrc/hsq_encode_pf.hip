@@ -31,6 +31,8 @@
 //     Correctness never depends on E being tight -- only on it being an upper bound.
 //  5. The last workgroup to finish folds the per-workgroup (min,max) of u into the final (lb, ub):
 //     the whole encode is ONE launch.
+#include <hip/hip_ext.h>
+
 #include "hsq_pf_common.hpp"
 
 namespace gq {
@@ -527,8 +529,14 @@ int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT 
     a.cb = codebook;
     a.ws = ws;
     const int64_t blocks = pf16_grid((M + 63) / 64, bpc);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, false>), dim3((unsigned)blocks), dim3(PF_THREADS), 0,
-                       st, a);
+    hipEvent_t ev_start, ev_stop;
+    if (profile_take(&ev_start, &ev_stop)) {   // gq_profile_arm: events attached to this dispatch
+        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, false>), dim3((unsigned)blocks),
+                              dim3(PF_THREADS), 0, st, ev_start, ev_stop, 0, a);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, false>), dim3((unsigned)blocks),
+                           dim3(PF_THREADS), 0, st, a);
+    }
     GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter)");
     return GQ_OK;
 }

@@ -22,7 +22,7 @@ EXPORTS = [
     "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_workspace_bytes", "gq_hsq_encode", "gq_hsq_encode_impl", "gq_hsq_levels",
     "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched",
     "gq_hsq_encode_batched_ef", "gq_hsq_levels_batched_ef", "gq_qsgd_compress_batched_ef",
-    "gq_hsq_encode_batched_d", "gq_hsq_decode_sum_batched_d",
+    "gq_hsq_encode_batched_d", "gq_hsq_decode_sum_batched_d", "gq_profile_arm", "gq_profile_read",
     "gq_pvq_encode", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
@@ -99,6 +99,18 @@ def fixup_count(workspace, M):
 
 def mark_worklist(workspace, M):
     workspace[2 * GQ_MAX_PARTIALS + 4:2 * GQ_MAX_PARTIALS + 4 + M].view(torch.int32).fill_(-1)
+
+
+def profile_arm(slot):
+    """The next d16/K256 hsq_encode on this thread carries a start/stop event pair on its dispatch."""
+    _check(lib().gq_profile_arm(ctypes.c_int(slot)), "gq_profile_arm")
+
+
+def profile_read(slot):
+    """Duration (ms) of the dispatch armed under `slot`; waits for it."""
+    ms = ctypes.c_float(0.0)
+    _check(lib().gq_profile_read(ctypes.c_int(slot), ctypes.byref(ms)), "gq_profile_read")
+    return ms.value
 
 
 def device_info(device=0):

@@ -57,6 +57,17 @@ size_t gq_hsq_workspace_bytes(int64_t M);
 /* Library / device identification. */
 int gq_abi_version(void);
 const char *gq_last_error(void);
+/*
+ * Per-dispatch timing of the dominant kernel (bench.py's roofline object): gq_profile_arm(slot) makes the next
+ * d16/K256 gq_hsq_encode issued by this thread attach a start / stop HIP event pair to its kernel dispatch
+ * (hipExtLaunchKernelGGL), so that the pair measures the kernel alone -- an event bracket recorded around the call
+ * also measures ~5-8 us of queue bubbles.  gq_profile_read(slot, &ms) waits for that dispatch and returns its
+ * duration.  Nothing else changes; unarmed calls are not affected.
+ */
+#define GQ_PROFILE_SLOTS 64
+int gq_profile_arm(int slot);
+int gq_profile_read(int slot, float *kernel_ms);
+
 /* Fills CU count and the gcnArchName (e.g. "gfx950:sramecc+:xnack-") of `device`. */
 int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
 
