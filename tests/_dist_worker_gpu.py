@@ -1,0 +1,68 @@
+"""Worker for the world_size-2 GPU test (tests/test_gpu_api.py): both ranks drive the HIP kernels on cuda:0 and
+exchange the wire over gloo (two ranks cannot share one GPU under RCCL).  TEST-ONLY."""
+import os
+import sys
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT, os.path.join(ROOT, "gradient-quantization_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+SHAPES = [(96, 112), (96,), (64, 64, 3, 3), (12,), (40, 128), (1024,)]
+
+
+def make_args(users, **kw):
+    base = dict(c_dim=16, k_bit=8, n_bit=6, no_cuda=False, random=0, ef=False, two_phase=False, scale="exp",
+                num_users=users, mode="ps", cr=256)
+    base.update(kw)
+    return Namespace(**base)
+
+
+def grads_for(global_user, step):
+    g = torch.Generator().manual_seed(1000 * step + global_user)
+    return [torch.randn(s, generator=g) * 1e-2 for s in SHAPES]
+
+
+def run(quantizer, params, local_users, first_global_user, steps=2):
+    out = {}
+    for st in range(steps):
+        for u in range(local_users):
+            for p, gr in zip(params, grads_for(first_global_user + u, st)):
+                p.grad = gr.cuda()
+            quantizer.record(u, epoch=1)
+        quantizer.apply()
+        for i, p in enumerate(params):
+            out["s%d_p%d" % (st, i)] = p.grad.data.cpu().numpy().copy()
+    return out
+
+
+def build(users, mode, quant, **kw):
+    from gq_amd.compressors import NearestNeighborCompressor, QSGDCompressor
+    from gq_amd.quantizers import Quantizer
+    params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in SHAPES]
+    if quant == "qsgd":
+        kw.update(c_dim=128, n_bit=2)
+    comp = QSGDCompressor if quant == "qsgd" else NearestNeighborCompressor
+    return Quantizer(comp, params, make_args(users, mode=mode, **kw)), params
+
+
+def run_single_process(total_users, mode, quant, **kw):
+    q, params = build(total_users, mode, quant, **kw)
+    return run(q, params, total_users, 0)
+
+
+if __name__ == "__main__":
+    rank, world, out, mode, quant, ef = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6] == "1"
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = 2
+    q, params = build(local, mode, quant, ef=ef)
+    res = run(q, params, local, rank * local)
+    np.savez(out + "_rank%d.npz" % rank, **res)
+    dist.barrier()
+    dist.destroy_process_group()
