@@ -80,13 +80,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback)")
+    # GQ_BENCH_BACKEND=gloo is a TEST hook (tests/test_gpu_api.py): it lets two ranks share one GPU, which RCCL
+    # refuses, so that the N > 1 code path can be exercised on a single-GPU box.  The driver never sets it.
+    backend = os.environ.get("GQ_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from gq_amd import native
     from gq_amd.codebook import load_codebook

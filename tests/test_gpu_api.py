@@ -536,3 +536,24 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, mode, quant, ef):
     for k in single:
         assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
 
+
+def test_bench_two_rank_code_path_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one JSON line from rank 0), with the
+    GQ_BENCH_BACKEND=gloo test hook so that both ranks can share this box's one GPU: barriers, all-gather of the
+    wire, decode-mean over two payloads, aggregate value."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, GQ_BENCH_BACKEND="gloo")
+    port = 29650 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["ranks"] == 2 and "cpu_baseline" not in d and d["roofline"]["kernel_ms"] > 0
+
