@@ -9,6 +9,8 @@ and the same user split of each batch (main.py:189-193).  Differences, all host-
     (`--dataset mnist|cifar10`), labels from a fixed random teacher -- no downloads;
   * models: `fcn` (784-256-10, models/fcn.py:12-13) and a CIFAR bottleneck `resnet50` with the
     reference's parameter-shape list (tests/golden/resnet50_cifar_shapes.json), plain torch.nn;
+  * schedule: main.py:136-163's learning-rate steps (new optimizer at epochs 51 and 71, none for MNIST, SignSGD's
+    own constants) are reproduced; the number of epochs stays a flag (main.py hard-codes 20 / 150 / 1000);
   * logging: one JSON object per log point on stdout / --logfile instead of TF1 summaries;
   * real data parallelism: launched under torch.distributed.run every rank is one (or
     --num-users) of the reference's users; the quantizer all-gathers the wire once per step.
@@ -182,12 +184,21 @@ def train(args, log=None):
     model = network_choices[args.network](num_classes=num_classes).to(device)
     quantizer = Quantizer(quantizer_choices[args.quantizer], model.parameters(), args)
     optimizer = optim.SGD(model.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+    # main.py:136-163: the learning-rate steps are NEW optimizers (momentum buffers start over), weight decay 5e-4
+    # from then on; none for MNIST; SignSGD has its own constants
+    steps = {} if args.dataset == 'mnist' else {51: 0.01, 71: 0.005}
+    momentum = args.momentum
+    if args.quantizer == 'sign':
+        steps, momentum = {51: 0.0005, 71: 0.0001}, 0.0
+        optimizer = optim.SGD(model.parameters(), lr=1e-3, momentum=0.0, weight_decay=0.1)
     loss_func = nn.CrossEntropyLoss()
     data = SyntheticClassification(args.dataset, args.train_size, num_classes, device, args.seed)
     out = open(args.logfile, "a") if (args.logfile and rank == 0) else None
     history = []
     it = 0
     for epoch in range(1, args.epochs + 1):
+        if epoch in steps:
+            optimizer = optim.SGD(model.parameters(), lr=steps[epoch], momentum=momentum, weight_decay=5e-4)
         # the loader yields num_users*batch_size samples per rank; split across users as main.py:189-193
         for x, y in data.batches(args.batch_size * args.num_users, 1000 * args.seed + epoch, rank, world):
             ub = x.shape[0] // args.num_users
