@@ -261,6 +261,67 @@ __global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
     }
 }
 
+// Error-feedback level kernel for the other prefilter sub-dimensions (D = 8, 32): as
+// hsq_levels_ef_batched_kernel, one thread per (padded subvector, 4-float unit).
+template <int D>
+__global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_d_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
+    const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
+    uint64_t seed, const float *__restrict__ cb, uint8_t *__restrict__ wire) {
+    constexpr int UPS = D / 4;
+    constexpr int RS = ((D / 4) & 1) ? D : D + 4;
+    __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];
+    for (int i = threadIdx.x; i < 256 * UPS; i += BT_THREADS)
+        *reinterpret_cast<f32x4 *>(s_cb + (i / UPS) * RS + 4 * (i % UPS)) = reinterpret_cast<const f32x4 *>(cb)[i];
+    __syncthreads();
+    const float s = (float)(1 << n_bit), smax = s - 1.0f;
+    const int64_t total = ntiles * 64 * UPS;
+    const int64_t stride = (int64_t)gridDim.x * BT_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * BT_THREADS + threadIdx.x; i < total; i += stride) {
+        const int64_t g = i / UPS;
+        const int q = (int)(i % UPS);
+        const int64_t tile = g >> 6;
+        const int seg = tile_seg[tile];
+        const int64_t *rec = seg_table + 8 * (int64_t)seg;
+        const int64_t local = (tile - rec[2]) * 64 + (g & 63);
+        if (local >= rec[1]) continue;
+        const float lb = order_unmap_f(seg_minmax[2 * seg]), ub = order_unmap_f(seg_minmax[2 * seg + 1]);
+        const float range = ub - lb;
+        int l = 0;
+        if ((lb - ub) != 0.0f) {
+            const float x = fabsf((u_flat[g] - lb) / range) * s;
+            const float c = fminf(fmaxf(x, 0.0f), smax);
+            l = (int)c;
+            if (random_mode == GQ_RANDOM_DEVICE) {
+                const float prob = x - (float)l;
+                l += (prob > uniform01(seed, (uint64_t)g)) ? 1 : 0;
+            }
+        }
+        if (q == 0) {
+            wire[rec[4] + local] = (uint8_t)l;
+            if (local == 0) {
+                float *lbub = reinterpret_cast<float *>(wire + rec[5]);
+                lbub[0] = lb;
+                lbub[1] = ub;
+            }
+        }
+        float *err = reinterpret_cast<float *>(rec[7]);
+        if (!err) continue;
+        float n = (float)l * range;   // prob_scalar:31-32, unfused
+        n = n / s;
+        n = n + lb;
+        const int code = wire[rec[3] + local];
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(s_cb + code * RS + 4 * q);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(rec[0]) + local * D + 4 * q);
+        f32x4 e;
+        e[0] = v[0] - c[0] * n;
+        e[1] = v[1] - c[1] * n;
+        e[2] = v[2] - c[2] * n;
+        e[3] = v[3] - c[3] * n;
+        *reinterpret_cast<f32x4 *>(err + local * D + 4 * q) = e;
+    }
+}
+
 // decode-mean over a segment table for the other prefilter sub-dimensions (D = 8, 32; K = 256): one thread
 // per (padded subvector, 4-float unit); codebook rows an odd number of 16-byte units apart in LDS.
 template <int D>
@@ -415,5 +476,34 @@ GQ_API int gq_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched_d: d must be 8, 16 or 32 (K = 256)");
     }
     GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched_d");
+    return GQ_OK;
+}
+
+GQ_API int gq_hsq_levels_batched_ef_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                      const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
+                                      uint64_t seed, const float *codebook, int d, uint8_t *wire, void *stream) {
+    if (d == 16)
+        return gq_hsq_levels_batched_ef(seg_table, tile_seg, nseg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed,
+                                        codebook, wire, stream);
+    if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > 8)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef_d: bad sizes");
+    if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !codebook || !wire)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef_d: null pointer");
+    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched_ef_d: random_mode must be OFF or DEVICE");
+    if (((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > 255)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef_d: levels do not fit uint8");
+    if (d == 8) {
+        hipLaunchKernelGGL(gq::hsq_levels_ef_batched_d_kernel<8>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 2)),
+                           dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
+                           n_bit, random_mode, seed, codebook, wire);
+    } else if (d == 32) {
+        hipLaunchKernelGGL(gq::hsq_levels_ef_batched_d_kernel<32>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 8)),
+                           dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
+                           n_bit, random_mode, seed, codebook, wire);
+    } else {
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched_ef_d: d must be 8, 16 or 32 (K = 256)");
+    }
+    GQ_CHECK_LAUNCH("gq_hsq_levels_batched_ef_d");
     return GQ_OK;
 }

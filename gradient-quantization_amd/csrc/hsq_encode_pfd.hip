@@ -30,6 +30,7 @@ struct PfdArgs {
     unsigned *seg_minmax;
     int64_t ntiles;
     int nseg;
+    float ef_scale;   // EF form: grad <- grad + ef_scale * error (error pointer = seg_table[seg][7], 0 = none)
 };
 
 constexpr int PFD_LDS_SEGS = 384;   // batched form: segment records kept in LDS (24 KiB); longer lists are refused
@@ -41,7 +42,10 @@ constexpr int PFD_LDS_SEGS = 384;   // batched form: segment records kept in LDS
 // BATCHED: the multi-tensor form -- segment table, one contiguous run of tiles per wave, per-tensor (min,max)
 // by look-before-you-leap atomics, table-derived addresses as global address-space pointers: everything as in
 // hsq_encode_pf.hip, where the reasons are written down.
-template <typename CodeT, int D, bool BATCHED = false>
+// EF (batched only): error feedback folded into the load, as in hsq_encode_pf.hip -- the tile is read as
+// v = grad + ef_scale * error (product rounded, then the add), v is written back over grad, and the level
+// kernel (gq_hsq_levels_batched_ef_d) later writes error = v - decoded.
+template <typename CodeT, int D, bool BATCHED = false, bool EF = false>
 __global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kernel(const PfdArgs a) {
     // one workgroup per CU: 8 waves (two per SIMD) for D = 8, 4 waves (one per SIMD) for D = 32; the waves share the
     // workgroup's contiguous run of tiles through an LDS counter (hsq_encode_pf.hip)
@@ -124,11 +128,13 @@ __global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kern
     typedef const float __attribute__((address_space(1))) *gcf_ptr;
     typedef const f32x4 __attribute__((address_space(1))) *gcv_ptr;
     typedef CodeT __attribute__((address_space(1))) *gcode_ptr;
+    typedef f32x4 __attribute__((address_space(1))) *gv_ptr;
     struct Tile {
         gcf_ptr base;      // the tensor's first float
         int64_t m, sv0;    // its subvector count; this tile's first subvector inside it
         int seg;
         gcode_ptr codes;
+        gcf_ptr err;       // EF: the tensor's error buffer or null
     };
     auto uniform64 = [](int64_t v) {
         const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v);
@@ -144,12 +150,14 @@ __global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kern
             ti.m = uniform64(rec[1]);
             ti.sv0 = (tile - uniform64(rec[2])) * 64;
             ti.codes = (gcode_ptr)((uintptr_t)a.wire + (uintptr_t)uniform64(rec[3]));
+            ti.err = EF ? (gcf_ptr)(uintptr_t)uniform64(rec[7]) : (gcf_ptr)0;
         } else {
             ti.seg = 0;
             ti.base = (gcf_ptr)grad;
             ti.m = M;
             ti.sv0 = tile * 64;
             ti.codes = (gcode_ptr)static_cast<CodeT *>(a.codes);
+            ti.err = (gcf_ptr)0;
         }
         return ti;
     };
@@ -168,6 +176,49 @@ __global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kern
                 } else {
                     dst[b][s][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                     dst[b][s][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            }
+        }
+    };
+    auto load_err = [&](const Tile &ti, f32x4 (&dst)[2][KS][2]) {
+        if (EF && ti.err) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                int64_t sv = ti.sv0 + b * 32 + j;
+                sv = sv < ti.m ? sv : ti.m - 1;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    if (16 * s + 8 * h < D) {
+                        const gcv_ptr p = (gcv_ptr)(ti.err + sv * D + 16 * s + 8 * h);
+                        dst[b][s][0] = p[0];
+                        dst[b][s][1] = p[1];
+                    }
+                }
+            }
+        }
+    };
+    // v = grad + scale * error, written back over grad (valid subvectors only)
+    auto fold_err = [&](const Tile &ti, f32x4 (&g)[2][KS][2], const f32x4 (&e)[2][KS][2]) {
+        if (EF && ti.err) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int64_t sv = ti.sv0 + b * 32 + j;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    if (16 * s + 8 * h < D) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float prod = a.ef_scale * e[b][s][q][c];
+                                g[b][s][q][c] = g[b][s][q][c] + prod;
+                            }
+                        if (sv < ti.m) {
+                            const gv_ptr p = (gv_ptr)(uintptr_t)(ti.base + sv * D + 16 * s + 8 * h);
+                            p[0] = g[b][s][0];
+                            p[1] = g[b][s][1];
+                        }
+                    }
                 }
             }
         }
@@ -199,6 +250,7 @@ __global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kern
         return (BATCHED && tile < tile_end) ? a.tile_seg[tile] : 0;
     };
     f32x4 cur[2][KS][2], nxt[2][KS][2];
+    f32x4 nxte[2][KS][2];   // EF: the error tile that goes with nxt (dead otherwise)
     bf16x8 vh[2][KS], vl[2][KS];
     Tile ti = {};
     int64_t tn = draw();
@@ -208,6 +260,8 @@ __global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kern
         ti = tile_info(t, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[t]) : 0);
         seg_next = BATCHED ? __builtin_amdgcn_readfirstlane(seg_n) : 0;
         load_tile(ti, cur);
+        load_err(ti, nxte);
+        fold_err(ti, cur, nxte);
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -219,6 +273,7 @@ __global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kern
         if (tn < tile_end) {
             tin = tile_info(tn, seg_next);
             load_tile(tin, nxt);  // prefetch the next tile
+            load_err(tin, nxte);
         }
         seg_n = seg_of(tnn);
         if (BATCHED && ti.seg != cur_seg) {
@@ -347,6 +402,7 @@ __global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kern
 
         // consume the prefetched tile BEFORE this tile's stores are issued (hsq_encode_pf.hip)
         if (BATCHED) seg_next = __builtin_amdgcn_readfirstlane(seg_n);
+        if (EF && tn < tile_end) fold_err(tin, nxt, nxte);
         if (tn < tile_end) {
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -470,18 +526,18 @@ template int launch_encode_pfd<uint8_t>(const float *, const float *, int64_t, i
 template int launch_encode_pfd<int32_t>(const float *, const float *, int64_t, int, int32_t *, float *, float *,
                                         hipStream_t);
 
-template <int D>
+template <int D, bool EF>
 static int launch_pfd_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                              const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax, float *ws,
-                              hipStream_t st) {
+                              const float *codebook, float ef_scale, uint8_t *wire, float *u_flat,
+                              uint32_t *seg_minmax, float *ws, hipStream_t st) {
     constexpr int KS = D > 16 ? D / 16 : 1;
     constexpr int WAVES = D == 32 ? 4 : 8, THREADS = WAVES * 64;
     constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
     static const int bpc = [] {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<uint8_t, D, true>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<uint8_t, D, true, EF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
-        return resident_blocks_per_cu(hsq_encode_pfd_kernel<uint8_t, D, true>, THREADS, lds);
+        return resident_blocks_per_cu(hsq_encode_pfd_kernel<uint8_t, D, true, EF>, THREADS, lds);
     }();
     PfdArgs a = {};
     a.M = ntiles * 64;
@@ -494,8 +550,9 @@ static int launch_pfd_batched(const int64_t *seg_table, const int32_t *tile_seg,
     a.seg_minmax = seg_minmax;
     a.ntiles = ntiles;
     a.nseg = nseg;
+    a.ef_scale = ef_scale;
     const int64_t blocks = pfd_grid(ntiles, bpc, WAVES);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<uint8_t, D, true>), dim3((unsigned)blocks),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<uint8_t, D, true, EF>), dim3((unsigned)blocks),
                        dim3(THREADS), lds, st, a);
     GQ_CHECK_LAUNCH("gq_hsq_encode_batched_d");
     return GQ_OK;
@@ -503,19 +560,38 @@ static int launch_pfd_batched(const int64_t *seg_table, const int32_t *tile_seg,
 
 }  // namespace gq
 
+namespace gq {
+template <bool EF>
+static int encode_batched_d(const char *what, const int64_t *seg_table, const int32_t *tile_seg, int nseg,
+                            int64_t ntiles, const float *codebook, int d, float ef_scale, uint8_t *wire, float *u_flat,
+                            uint32_t *seg_minmax, float *workspace, void *stream) {
+    if (nseg < 1 || ntiles < 1 || ntiles * 64 > 0x7FFFFFFFLL)
+        return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes nseg=%d ntiles=%lld", what, nseg, (long long)ntiles);
+    if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
+        return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
+    if (nseg > PFD_LDS_SEGS) return fail(GQ_ERR_UNSUPPORTED, "%s: at most %d tensors per launch for d = %d", what, PFD_LDS_SEGS, d);
+    hipStream_t st = as_stream(stream);
+    if (d == 8) return launch_pfd_batched<8, EF>(seg_table, tile_seg, nseg, ntiles, codebook, ef_scale, wire, u_flat, seg_minmax, workspace, st);
+    if (d == 32) return launch_pfd_batched<32, EF>(seg_table, tile_seg, nseg, ntiles, codebook, ef_scale, wire, u_flat, seg_minmax, workspace, st);
+    return fail(GQ_ERR_UNSUPPORTED, "%s: d must be 8, 16 or 32 (K = 256)", what);
+}
+}  // namespace gq
+
 GQ_API int gq_hsq_encode_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                    const float *codebook, int d, uint8_t *wire, float *u_flat, uint32_t *seg_minmax,
                                    float *workspace, void *stream) {
     if (d == 16)
         return gq_hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace, stream);
-    if (nseg < 1 || ntiles < 1 || ntiles * 64 > 0x7FFFFFFFLL)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_d: bad sizes nseg=%d ntiles=%lld", nseg, (long long)ntiles);
-    if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_d: null pointer");
-    if (nseg > gq::PFD_LDS_SEGS)
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched_d: at most %d tensors per launch for d = %d", gq::PFD_LDS_SEGS, d);
-    hipStream_t st = gq::as_stream(stream);
-    if (d == 8) return gq::launch_pfd_batched<8>(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace, st);
-    if (d == 32) return gq::launch_pfd_batched<32>(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace, st);
-    return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched_d: d must be 8, 16 or 32 (K = 256)");
+    return gq::encode_batched_d<false>("gq_hsq_encode_batched_d", seg_table, tile_seg, nseg, ntiles, codebook, d, 0.0f, wire,
+                                       u_flat, seg_minmax, workspace, stream);
+}
+
+GQ_API int gq_hsq_encode_batched_d_ef(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                      const float *codebook, int d, float ef_scale, uint8_t *wire, float *u_flat,
+                                      uint32_t *seg_minmax, float *workspace, void *stream) {
+    if (d == 16)
+        return gq_hsq_encode_batched_ef(seg_table, tile_seg, nseg, ntiles, codebook, ef_scale, wire, u_flat, seg_minmax,
+                                        workspace, stream);
+    return gq::encode_batched_d<true>("gq_hsq_encode_batched_d_ef", seg_table, tile_seg, nseg, ntiles, codebook, d, ef_scale,
+                                      wire, u_flat, seg_minmax, workspace, stream);
 }

@@ -22,7 +22,8 @@ EXPORTS = [
     "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_workspace_bytes", "gq_hsq_encode", "gq_hsq_encode_impl", "gq_hsq_levels",
     "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched",
     "gq_hsq_encode_batched_ef", "gq_hsq_levels_batched_ef", "gq_qsgd_compress_batched_ef",
-    "gq_hsq_encode_batched_d", "gq_hsq_decode_sum_batched_d", "gq_profile_arm", "gq_profile_read",
+    "gq_hsq_encode_batched_d", "gq_hsq_decode_sum_batched_d", "gq_hsq_encode_batched_d_ef", "gq_hsq_levels_batched_ef_d",
+    "gq_profile_arm", "gq_profile_read",
     "gq_pvq_encode", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
@@ -195,9 +196,17 @@ def hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat
     The codebook's sub-dimension picks the kernel (K = 256; d = 16, or 8 / 32 without error feedback)."""
     assert workspace.numel() >= workspace_floats(ntiles * 64)
     d = int(codebook.shape[1])
+    if d != 16 and ef_scale is not None:
+        rc = lib().gq_hsq_encode_batched_d_ef(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                              _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                              ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
+                                              ctypes.c_int(d), ctypes.c_float(ef_scale), _dev_ptr(wire, torch.uint8, "wire"),
+                                              _dev_ptr(u_flat, torch.float32, "u_flat"),
+                                              _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
+                                              _dev_ptr(workspace, torch.float32, "workspace"), _stream())
+        _check(rc, "gq_hsq_encode_batched_d_ef")
+        return
     if d != 16:
-        if ef_scale is not None:
-            raise GQNativeError("gq_hsq_encode_batched_ef exists for d = 16 only")
         rc = lib().gq_hsq_encode_batched_d(_dev_ptr(seg_table, torch.int64, "seg_table"),
                                            _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
                                            ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
@@ -229,6 +238,17 @@ def hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat
 def hsq_levels_batched(seg_table, tile_seg, nseg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, wire,
                        ef_codebook=None):
     """ef_codebook given: also writes error = grad - decoded into the buffers of seg_table[:, 7]."""
+    if ef_codebook is not None and int(ef_codebook.shape[1]) != 16:
+        rc = lib().gq_hsq_levels_batched_ef_d(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                              _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                              ctypes.c_int64(ntiles), _dev_ptr(u_flat, torch.float32, "u_flat"),
+                                              _dev_ptr(seg_minmax, torch.int32, "seg_minmax"), ctypes.c_int(n_bit),
+                                              ctypes.c_int(random_mode), ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                                              _dev_ptr(ef_codebook, torch.float32, "codebook"),
+                                              ctypes.c_int(int(ef_codebook.shape[1])),
+                                              _dev_ptr(wire, torch.uint8, "wire"), _stream())
+        _check(rc, "gq_hsq_levels_batched_ef_d")
+        return
     if ef_codebook is not None:
         rc = lib().gq_hsq_levels_batched_ef(_dev_ptr(seg_table, torch.int64, "seg_table"),
                                             _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),

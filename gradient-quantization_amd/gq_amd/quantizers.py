@@ -388,8 +388,8 @@ class BatchedHSQ(_BatchedBase):
         tensor on this device: the caller then takes the per-tensor path for this step.
         With `errs` (error feedback, ps_quantizer.py:34-39) the same two launches also do
         t += ef_scale*err (in place, before encoding) and err = t - decoded (in place, after)."""
-        if self.codebook.shape[1] != 16 and (errs is not None or self.nseg > 384):
-            return False    # d = 8 / 32: no fused error feedback, at most 384 tensors per launch
+        if self.codebook.shape[1] != 16 and self.nseg > 384:
+            return False    # d = 8 / 32: at most 384 tensors per launch
         if not self._upload(tensors, slot, 16, errs):
             return False
         seg_table = self._dev[:self._table_words]

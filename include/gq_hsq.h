@@ -181,10 +181,16 @@ int gq_hsq_decode_sum_batched(const int64_t *seg_table, const int32_t *tile_seg,
                               const uint8_t *gathered, int64_t user_stride_bytes, int R, const float *codebook,
                               int n_bit, float *out, void *stream);
 /* The same for the other sub-dimensions that have a prefilter encode (K = 256, d = 8, 16 or 32; d = 16
- * forwards to the entry points above).  No error-feedback form: callers take the per-tensor path then. */
+ * forwards to the entry points above); the _ef forms as gq_hsq_encode_batched_ef / gq_hsq_levels_batched_ef. */
 int gq_hsq_encode_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                             const float *codebook, int d, uint8_t *wire, float *u_flat, uint32_t *seg_minmax,
                             float *workspace, void *stream);
+int gq_hsq_encode_batched_d_ef(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                               const float *codebook, int d, float ef_scale, uint8_t *wire, float *u_flat,
+                               uint32_t *seg_minmax, float *workspace, void *stream);
+int gq_hsq_levels_batched_ef_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                               const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
+                               uint64_t seed, const float *codebook, int d, uint8_t *wire, void *stream);
 int gq_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                 const uint8_t *gathered, int64_t user_stride_bytes, int R, const float *codebook,
                                 int d, int n_bit, float *out, void *stream);

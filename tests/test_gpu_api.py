@@ -247,8 +247,7 @@ def test_batched_quantizer_equals_per_tensor_path():
 @pytest.mark.parametrize("c_dim", [32, 8])
 def test_batched_quantizer_other_subdimensions_equal_per_tensor_path(c_dim):
     """The multi-tensor kernels for the other prefilter sub-dimensions (main.py's default --c-dim 32, and 8):
-    aggregates and wire identical to the per-tensor kernels; with error feedback the quantizer falls back
-    to the per-tensor path for these dimensions and still matches."""
+    aggregates, wire, per-user residuals and the server residual identical to the per-tensor kernels."""
     shapes = RESNET50_COMPRESSED[:14] + RESNET50_SMALL[:3]
     qb, gb = _run_quantizer(shapes, 2, 11, c_dim=c_dim)
     qp, gp = _run_quantizer(shapes, 2, 11, c_dim=c_dim, gq_no_batch=True)
@@ -257,10 +256,18 @@ def test_batched_quantizer_other_subdimensions_equal_per_tensor_path(c_dim):
     for a, b, s in zip(gb, gp, shapes):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), s
     assert torch.equal(qb._wire, qp._wire)
-    qe, ge = _run_quantizer(shapes, 2, 11, c_dim=c_dim, ef=True)
-    qf, gf = _run_quantizer(shapes, 2, 11, c_dim=c_dim, ef=True, gq_no_batch=True)
-    for a, b in zip(ge, gf):
-        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # error feedback / two-phase ride in the same launches for these dimensions too
+    for kw in (dict(ef=True), dict(ef=True, two_phase=True, scale="0.5")):
+        qe, ge = _run_quantizer(shapes, 2, 11, c_dim=c_dim, **kw)
+        qf, gf = _run_quantizer(shapes, 2, 11, c_dim=c_dim, gq_no_batch=True, **kw)
+        assert qe._groups[0][2].ready
+        for a, b in zip(ge, gf):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        for pb, pp in zip(qe.parameters, qf.parameters):
+            for eb, ep in zip(pb.error, pp.error):
+                assert torch.equal(eb, ep)
+            if kw.get("two_phase"):
+                assert torch.equal(pb.server_error, pp.server_error)
 
 
 def test_batched_quantizer_device_rng_and_misaligned_fallback():
