@@ -351,3 +351,15 @@ def test_prefilter_respects_unnormalised_codebooks(nat, oracle, d):
     res = gpu_compress(nat, x, cbn, 32, 0, impl=4)
     assert np.array_equal(res["codes"].cpu().numpy().astype(np.int32), ref_codes)
     assert np.array_equal(_bits(res["u"].cpu().numpy()), _bits(ref_u))
+
+
+def test_prefilter_fuzz_against_exact_kernels():
+    """tools/fuzz_prefilter.py: random sizes / scales / sub-dimensions and adversarial subvectors (sparse, one-hot,
+    integer-valued, duplicated, exact codeword multiples and sums, subnormal and huge magnitudes, unnormalised
+    codebooks): the prefilter encode equals the exact f32 MFMA kernels bit for bit."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_prefilter.py")
+    r = subprocess.run([sys.executable, tool, "120", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "120 rounds, 0 mismatching" in r.stdout
