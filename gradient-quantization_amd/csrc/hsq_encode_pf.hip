@@ -595,3 +595,16 @@ GQ_API int gq_hsq_encode_batched_ef(const int64_t *seg_table, const int32_t *til
     return gq::encode_batched<true>("gq_hsq_encode_batched_ef", seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat,
                                     seg_minmax, workspace, ef_scale, stream);
 }
+
+// Whole compress (nearest_neighbor_compressor.py:63-78 = encode + probabilistic_scalar_compressor.py:12-27) in one
+// call: gq_hsq_encode followed by gq_hsq_levels on the same stream.  (Doing both in ONE launch -- every workgroup
+// quantising its own tiles once the last one has published the final (lb, ub) -- was built and measured: 64 us with
+// a plain launch, 77 us with the cooperative launch the grid barrier needs, against 56.5 us for the two launches.)
+GQ_API int gq_hsq_compress(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes, int code_bytes,
+                           float *u, float *workspace, int n_bit, int random_mode, const float *r, uint64_t seed,
+                           float *lb_ub, void *levels, int level_bytes, void *stream) {
+    const int rc = gq_hsq_encode(grad, codebook, M, d, K, codes, code_bytes, u, workspace, stream);
+    if (rc != GQ_OK) return rc;
+    return gq_hsq_levels(u, M, n_bit, random_mode, r, seed, workspace, lb_ub, levels, level_bytes, stream);
+}
+

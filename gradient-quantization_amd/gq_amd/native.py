@@ -23,7 +23,7 @@ EXPORTS = [
     "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched",
     "gq_hsq_encode_batched_ef", "gq_hsq_levels_batched_ef", "gq_qsgd_compress_batched_ef",
     "gq_hsq_encode_batched_d", "gq_hsq_decode_sum_batched_d", "gq_hsq_encode_batched_d_ef", "gq_hsq_levels_batched_ef_d",
-    "gq_profile_arm", "gq_profile_read",
+    "gq_profile_arm", "gq_profile_read", "gq_hsq_compress",
     "gq_pvq_encode", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
@@ -132,6 +132,23 @@ def hsq_encode(grad, codebook, codes, u, partials, impl=ENCODE_AUTO):
                                   ctypes.c_int(_CODE_BYTES[codes.dtype]), _dev_ptr(u, torch.float32, "u"),
                                   _dev_ptr(partials, torch.float32, "partials"), ctypes.c_int(impl), _stream())
     _check(rc, "gq_hsq_encode")
+
+
+def hsq_compress(grad, codebook, codes, u, workspace, n_bit, random_mode, r, seed, lb_ub, levels):
+    """encode + level quantiser (gq_hsq_compress: one cooperative launch for d16/K256 with byte levels)."""
+    K, d = codebook.shape
+    M = grad.numel() // d
+    assert grad.numel() == M * d and codes.numel() == M and u.numel() == M and levels.numel() == M
+    assert workspace.numel() >= workspace_floats(M)
+    rc = lib().gq_hsq_compress(_dev_ptr(grad, torch.float32, "grad"), _dev_ptr(codebook, torch.float32, "codebook"),
+                               ctypes.c_int64(M), ctypes.c_int(d), ctypes.c_int(K), _dev_ptr(codes, None, "codes"),
+                               ctypes.c_int(_CODE_BYTES[codes.dtype]), _dev_ptr(u, torch.float32, "u"),
+                               _dev_ptr(workspace, torch.float32, "workspace"), ctypes.c_int(n_bit),
+                               ctypes.c_int(random_mode),
+                               _dev_ptr(r, torch.float32, "r") if r is not None else ctypes.c_void_p(0),
+                               ctypes.c_uint64(seed & (2 ** 64 - 1)), _dev_ptr(lb_ub, torch.float32, "lb_ub"),
+                               _dev_ptr(levels, None, "levels"), ctypes.c_int(_LEVEL_BYTES[levels.dtype]), _stream())
+    _check(rc, "gq_hsq_compress")
 
 
 def hsq_levels(u, n_bit, random_mode, r, seed, partials, lb_ub, levels):

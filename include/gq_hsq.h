@@ -85,6 +85,15 @@ int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
 int gq_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes, int code_bytes,
                   float *u, float *workspace, void *stream);
 
+/*
+ * The whole compress of NearestNeighborCompressor (nearest_neighbor_compressor.py:63-78: the encode above, then
+ * probabilistic_scalar_compressor.py:12-27 on u) in one call: gq_hsq_encode followed by gq_hsq_levels (declared
+ * below) on the same stream, same outputs.
+ */
+int gq_hsq_compress(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes, int code_bytes,
+                    float *u, float *workspace, int n_bit, int random_mode, const float *r, uint64_t seed,
+                    float *lb_ub, void *levels, int level_bytes, void *stream);
+
 /* Same, with the kernel chosen explicitly (diagnostics / cross-checks; results are
  * identical for every impl):  0 = auto, 1 = exact f32 MFMA, d16/K256, register-resident
  * codebook, 2 = exact f32 MFMA generic (any d, K), 3 = VALU fmaf chain with the codebook in
