@@ -227,11 +227,19 @@ __global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
             const unsigned l4 = *reinterpret_cast<const unsigned *>(p + level_off);   // reading past M stays inside
             const float *lbub = reinterpret_cast<const float *>(p + lbub_off);
             const float lb = lbub[0], range = lbub[1] - lb;
+            // lane q of a team works out the norm of subvector q; the team shares them by quad-permute DPP moves
+            float n_own = (float)((l4 >> (8 * q)) & 255u) * range;   // prob_scalar:31-32, unfused
+            n_own = n_own * inv_s;                                   // == / 2^n_bit exactly
+            n_own = n_own + lb;
+            const int n_bits = __builtin_bit_cast(int, n_own);
+            const float n_team[4] = {
+                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0x00, 0xF, 0xF, true)),
+                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0x55, 0xF, 0xF, true)),
+                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xAA, 0xF, 0xF, true)),
+                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xFF, 0xF, 0xF, true))};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float n = (float)((l4 >> (8 * k)) & 255u) * range;   // prob_scalar:31-32, unfused
-                n = n * inv_s;                                       // == / 2^n_bit exactly
-                n = n + lb;
+                const float n = n_team[k];
                 const f32x4 c = *reinterpret_cast<const f32x4 *>(my_cb + ((c4 >> (8 * k)) & 255u) * 64);
                 const f32x4 n4 = {n, n, n, n};
                 const f32x4 dec = c * n4;

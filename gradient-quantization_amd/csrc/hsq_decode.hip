@@ -149,9 +149,18 @@ __global__ __launch_bounds__(DEC16_THREADS) void hsq_decode_sum_d16u8_kernel(
                 lb = lb_ub[r * lbub_stride];
                 range = lb_ub[r * lbub_stride + 1] - lb;
             }
+            // the four lanes of a team (quarters 0..3 of the same four subvectors) need the same four norms:
+            // lane q works out the norm of subvector q only and the team exchanges them by quad-permute DPP moves
+            const float n_own = level_to_norm<unsigned>((l4 >> (8 * q)) & 255u, lb, range, inv_s);
+            const int n_bits = __builtin_bit_cast(int, n_own);
+            const float n_team[4] = {   // quad_perm [k,k,k,k]: lane k of the team broadcasts
+                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0x00, 0xF, 0xF, true)),
+                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0x55, 0xF, 0xF, true)),
+                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xAA, 0xF, 0xF, true)),
+                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xFF, 0xF, 0xF, true))};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float n = level_to_norm<unsigned>((l4 >> (8 * k)) & 255u, lb, range, inv_s);
+                const float n = n_team[k];
                 const f32x4 c = *reinterpret_cast<const f32x4 *>(my_cb + ((c4 >> (8 * k)) & 255u) * 64);
                 const f32x4 n4 = {n, n, n, n};
                 const f32x4 dec = c * n4;
