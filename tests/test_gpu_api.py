@@ -270,6 +270,20 @@ def test_batched_quantizer_other_subdimensions_equal_per_tensor_path(c_dim):
                 assert torch.equal(pb.server_error, pp.server_error)
 
 
+@pytest.mark.parametrize("c_dim", [16, 32])
+def test_batched_quantizer_long_tensor_lists(c_dim):
+    """More tensors than the kernels keep segment records for in LDS (384): d = 16 switches to the instantiation
+    that reads the records from global memory, d = 32 falls back to per-tensor launches; same results either way."""
+    shapes = [(1024,)] * 300 + [(32, 64)] * 100 + [(10,)] * 3
+    qb, gb = _run_quantizer(shapes, 1, 4, c_dim=c_dim)
+    qp, gp = _run_quantizer(shapes, 1, 4, c_dim=c_dim, gq_no_batch=True)
+    assert qb._groups and len(qb._groups[0][1]) == 400
+    assert qb._groups[0][2].ready == (c_dim == 16)
+    for a, b in zip(gb, gp):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert torch.equal(qb._wire, qp._wire)
+
+
 def test_batched_quantizer_device_rng_and_misaligned_fallback():
     shapes = RESNET50_COMPRESSED[:6] + RESNET50_SMALL[:3]
     q, g = _run_quantizer(shapes, 2, 9, random=1)
