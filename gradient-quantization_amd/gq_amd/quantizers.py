@@ -130,8 +130,14 @@ class HSQCodec(object):
         cbk = self.c._codebook_on(dev)
         if self.c.compressed_norm:
             u, partials = self._scratch(dev)
-            native.hsq_encode(flat, cbk, codes, u, partials)
-            self._levels(u, partials, levels, lb_ub, salt)
+            nc = self.c.norm_compressor
+            if nc.random and nc._rng == "reference":
+                native.hsq_encode(flat, cbk, codes, u, partials)
+                self._levels(u, partials, levels, lb_ub, salt)
+            else:   # encode + levels in one library call (gq_hsq_compress)
+                mode = native.RANDOM_DEVICE if nc.random else native.RANDOM_OFF
+                native.hsq_compress(flat, cbk, codes, u, partials, nc.n_bit, mode, None,
+                                    (_next_seed() ^ salt) if nc.random else 0, lb_ub, levels)
         else:
             _, partials = self._scratch(dev)
             native.hsq_encode(flat, cbk, codes, levels, partials)  # `levels` section holds f32 u
