@@ -15,6 +15,7 @@
 namespace gq {
 
 constexpr int QB_THREADS = 256;
+constexpr int QB_LDS_SEGS = 256;   // segment records kept in LDS by the 4-bit compress kernel (16 KiB)
 
 __device__ __forceinline__ unsigned qsgd_code(float v, float norm, float s, float smax, int random_mode,
                                               uint64_t seed, uint64_t gidx, int bits) {
@@ -101,29 +102,61 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
 // registers as one dword per 8 elements.  EF as in the kernel above.  (The wave-per-bucket form read
 // every bucket twice with 8-byte loads and spent most of its time in the 64-bit RNG: 71 us for the
 // 23.5 M-element ResNet-50 list.)
-template <bool EF>
+// SEGLDS: the segment records come from an LDS copy (nseg <= QB_LDS_SEGS) and the bucket -> tensor word of the next
+// item is fetched an item ahead: looked up in global memory, bucket -> tensor -> record -> data is three dependent
+// round trips per item and the kernel was bound by that latency (41 us for the ResNet-50 list, the same with the
+// division taken out).
+template <bool EF, bool SEGLDS>
 __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
-    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int n_bit,
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int nseg, int64_t nbuckets, int n_bit,
     int random_mode, uint64_t seed, float ef_scale, uint8_t *__restrict__ wire) {
+    __shared__ int64_t s_seg[SEGLDS ? QB_LDS_SEGS * 8 : 1];
+    if (SEGLDS) {
+        for (int i = threadIdx.x; i < nseg * 8; i += QB_THREADS) s_seg[i] = seg_table[i];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, sub = lane >> 4, c0 = lane & 15;
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float s = (float)(1 << n_bit), smax = s - 1.0f, inv_s = 1.0f / s;
     const int64_t nquads = (nbuckets + 3) >> 2;
-    for (int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); qd < nquads; qd += nw) {
+    int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6);
+    int seg_next = (qd < nquads && 4 * qd + sub < nbuckets) ? bucket_seg[4 * qd + sub] : 0;
+    for (; qd < nquads; qd += nw) {
         const int64_t b = 4 * qd + sub;
         const bool live = b < nbuckets;
-        const int seg = live ? bucket_seg[b] : 0;
-        const int64_t *rec = seg_table + 8 * (int64_t)seg;
+        const int seg = seg_next;
+        {
+            const int64_t bn = 4 * (qd + nw) + sub;
+            seg_next = (qd + nw < nquads && bn < nbuckets) ? bucket_seg[bn] : 0;   // the next item's tensor
+        }
+        int64_t recv[8];
+        if constexpr (SEGLDS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) recv[i] = s_seg[8 * seg + i];
+        } else {
+            typedef const int64_t __attribute__((address_space(1))) *grec_ptr;
+            const grec_ptr gr = (grec_ptr)(seg_table + 8 * (int64_t)seg);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) recv[i] = gr[i];
+        }
+        const int64_t *rec = recv;
         const int d = live ? (int)rec[1] : 0;
         const int64_t lb = b - rec[2];
-        float *v = reinterpret_cast<float *>(rec[0]) + lb * d;
-        float *err = (EF && rec[7]) ? reinterpret_cast<float *>(rec[7]) + lb * d : nullptr;
+        // global address-space pointers: as plain pointers these would be flat (see hsq_encode_pf.hip)
+        typedef float __attribute__((address_space(1))) *gf_ptr;
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        typedef v2f __attribute__((address_space(1))) *gf2_ptr;
+        typedef f32x4 __attribute__((address_space(1))) *gv_ptr;
+        const gf_ptr v = (gf_ptr)(uintptr_t)rec[0] + lb * d;
+        const gf_ptr err = (EF && rec[7]) ? (gf_ptr)(uintptr_t)rec[7] + lb * d : (gf_ptr)0;
         if (live && (d > 256 || (d & 7) != 0)) {
             // other bucket widths: the 16 lanes walk the bucket twice, an element pair at a time
             auto load = [&](int e) {
-                float2 p = *reinterpret_cast<const float2 *>(v + e);
+                const v2f pv = *(gf2_ptr)(v + e);
+                float2 p = make_float2(pv[0], pv[1]);
                 if (EF && err) {
-                    const float2 q = *reinterpret_cast<const float2 *>(err + e);
+                    const v2f qv = *(gf2_ptr)(err + e);
+                    const float2 q = make_float2(qv[0], qv[1]);
                     const float p0 = ef_scale * q.x, p1 = ef_scale * q.y;
                     p.x = p.x + p0;
                     p.y = p.y + p1;
@@ -151,8 +184,8 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
                     t1 = t1 * m2;
                     t0 = t0 * inv_s;
                     t1 = t1 * inv_s;
-                    *reinterpret_cast<float2 *>(v + e) = p;
-                    *reinterpret_cast<float2 *>(err + e) = make_float2(p.x - t0, p.y - t1);
+                    *(gf2_ptr)(v + e) = v2f{p.x, p.y};
+                    *(gf2_ptr)(err + e) = v2f{p.x - t0, p.y - t1};
                 }
             }
             continue;   // (the other buckets of this wave take the register path below on their own lanes)
@@ -164,11 +197,11 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
         for (int jc = 0; jc < 2; ++jc) {
             const int e = 8 * (c0 + 16 * jc);
             if (e < d) {
-                x[jc][0] = *reinterpret_cast<const f32x4 *>(v + e);
-                x[jc][1] = *reinterpret_cast<const f32x4 *>(v + e + 4);
+                x[jc][0] = *(gv_ptr)(v + e);
+                x[jc][1] = *(gv_ptr)(v + e + 4);
                 if (EF && err) {
-                    const f32x4 q0 = *reinterpret_cast<const f32x4 *>(err + e);
-                    const f32x4 q1 = *reinterpret_cast<const f32x4 *>(err + e + 4);
+                    const f32x4 q0 = *(gv_ptr)(err + e);
+                    const f32x4 q1 = *(gv_ptr)(err + e + 4);
                     x[jc][0] = x[jc][0] + q0 * ef_scale;   // product rounded, then the add (-ffp-contract=off)
                     x[jc][1] = x[jc][1] + q1 * ef_scale;
                 }
@@ -201,10 +234,10 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
                 }
                 *reinterpret_cast<unsigned *>(dst + 4 * (c0 + 16 * jc)) = word;
                 if (EF && err) {
-                    *reinterpret_cast<f32x4 *>(v + e) = x[jc][0];
-                    *reinterpret_cast<f32x4 *>(v + e + 4) = x[jc][1];
-                    *reinterpret_cast<f32x4 *>(err + e) = x[jc][0] - dec[0];      // ps_quantizer.py:39
-                    *reinterpret_cast<f32x4 *>(err + e + 4) = x[jc][1] - dec[1];
+                    *(gv_ptr)(v + e) = x[jc][0];
+                    *(gv_ptr)(v + e + 4) = x[jc][1];
+                    *(gv_ptr)(err + e) = x[jc][0] - dec[0];      // ps_quantizer.py:39
+                    *(gv_ptr)(err + e + 4) = x[jc][1] - dec[1];
                 }
             }
         }
@@ -369,10 +402,14 @@ static int qsgd_compress_batched(const char *what, const int64_t *seg_table, con
         return fail(GQ_ERR_UNSUPPORTED, "%s: random_mode must be OFF or DEVICE", what);
     const int bits = gq_qsgd_code_bits(n_bit, random_mode);
     if (!bits) return fail(GQ_ERR_UNSUPPORTED, "%s: n_bit %d has no packed format", what, n_bit);
-    if (bits == 4) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched4_kernel<EF>), dim3((unsigned)qb_grid((nbuckets + 3) / 4)),
-                           dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, random_mode,
-                           seed, ef_scale, wire);
+    if (bits == 4 && nseg <= QB_LDS_SEGS) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched4_kernel<EF, true>), dim3((unsigned)qb_grid((nbuckets + 3) / 4)),
+                           dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nseg, nbuckets, n_bit,
+                           random_mode, seed, ef_scale, wire);
+    } else if (bits == 4) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched4_kernel<EF, false>), dim3((unsigned)qb_grid((nbuckets + 3) / 4)),
+                           dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nseg, nbuckets, n_bit,
+                           random_mode, seed, ef_scale, wire);
     } else {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched_kernel<EF>), dim3((unsigned)qb_grid(nbuckets)),
                            dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, bits,

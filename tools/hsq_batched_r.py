@@ -33,5 +33,5 @@ for R in ([int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]):
     gl = [params[i].grad.data for i in q._groups[0][1]]
     t_enc = ev_time(lambda: grp.encode(gl, wire[0], 0, 0))
     q.apply()
-    print("R=%d: decode-mean %.1f us for %.1f M elements (%.2f TB/s of output); compress (one user) %.1f us (%.2f TB/s of input)"
+    print("R=%d: decode-mean %.1f us for %.1f M elements (%.2f TB/s of output); compress call incl. header upload and its host-side wait %.1f us (%.2f TB/s of input; kernel times: rocprofv3)"
           % (R, t_dec, n / 1e6, 4 * n / t_dec / 1e6, t_enc, 4 * n / t_enc / 1e6))
