@@ -20,7 +20,9 @@ __device__ __forceinline__ float order_unmap_f(unsigned m) {
     return __uint_as_float(m ^ ((m >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
-// 4 consecutive padded subvectors (one tile quarter-row) per thread and iteration.
+// 4 consecutive padded subvectors (one tile quarter-row) per thread and iteration.  LevelT: uint8_t (top level
+// <= 255), int16_t or int32_t (gq_hsq_levels_batched_any: e.g. n_bit = 8 with stochastic rounding reaches 256).
+template <typename LevelT>
 __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
         const float range = ub - lb;
         const bool flat = (lb - ub) == 0.0f;
         const f32x4 uu = *reinterpret_cast<const f32x4 *>(u_flat + 4 * i);
-        uint8_t out[4];
+        LevelT out[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             int l = 0;
@@ -58,11 +60,13 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
                     l += (prob > uniform01(seed, (uint64_t)(4 * i + e))) ? 1 : 0;
                 }
             }
-            out[e] = (uint8_t)l;
+            out[e] = (LevelT)l;
         }
-        uint8_t *dst = wire + rec[4] + local;
+        LevelT *dst = reinterpret_cast<LevelT *>(wire + rec[4]) + local;   // sections start 16-byte aligned
         if (local + 3 < m) {
-            *reinterpret_cast<uchar4 *>(dst) = make_uchar4(out[0], out[1], out[2], out[3]);
+            typedef LevelT L4 __attribute__((ext_vector_type(4)));
+            const L4 o4 = {out[0], out[1], out[2], out[3]};
+            *reinterpret_cast<L4 *>(dst) = o4;
         } else {
             for (int e = 0; e < 4 && local + e < m; ++e) dst[e] = out[e];
         }
@@ -385,6 +389,111 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_d_kernel(
     }
 }
 
+// Any (d, K), any code / level width: decode-mean over a segment table, or -- ERR -- the error-feedback
+// pass  error = grad - decoded  of the single wire just written (ps_quantizer.py:39; the tensors and their
+// error buffers are columns 0 and 7 of the table, rows without an error buffer are skipped).
+// A workgroup walks tiles (64 padded subvectors of one tensor); a thread owns VEC consecutive floats of a
+// subvector (VEC = 4 when d % 4 == 0, else 1).  The codebook is staged in LDS when it fits 64 KiB and
+// comes from L1/L2 otherwise.
+template <typename CodeT, typename LevelT, int VEC, bool ERR>
+__global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_any_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
+    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int d, int K,
+    int n_bit, float *__restrict__ out, int cb_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) float s_cb_any[];
+    const float *cbp = cb;
+    if (cb_in_lds) {
+        for (int i = threadIdx.x; i < K * d; i += BT_THREADS) s_cb_any[i] = cb[i];
+        __syncthreads();
+        cbp = s_cb_any;
+    }
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const float inv_s = 1.0f / (float)(1u << n_bit);   // exact; n * inv_s == n / 2^n_bit
+    const float fR = (float)R;
+    const int ups = d / VEC, units = 64 * ups;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int seg = tile_seg[tile];
+        const int64_t *rec = seg_table + 8 * (int64_t)seg;
+        const int64_t sv0 = (tile - rec[2]) * 64;
+        const int64_t m = rec[1];
+        float *dst = ERR ? reinterpret_cast<float *>(rec[7]) : out + rec[6];
+        if (ERR && !dst) continue;
+        const float *grad = reinterpret_cast<const float *>(rec[0]);
+        for (int unit = threadIdx.x; unit < units; unit += BT_THREADS) {
+            const int sv = unit / ups, q = unit - sv * ups;
+            const int64_t local = sv0 + sv;
+            if (local >= m) continue;
+            vec_t acc;
+            for (int r = 0; r < R; ++r) {
+                const uint8_t *p = gathered + (int64_t)r * user_stride;
+                const float *lbub = reinterpret_cast<const float *>(p + rec[5]);
+                const float lb = lbub[0], range = lbub[1] - lb;
+                float n = (float)reinterpret_cast<const LevelT *>(p + rec[4])[local] * range;   // prob_scalar:31-32, unfused
+                n = n * inv_s;
+                n = n + lb;
+                const int64_t code = (int64_t)reinterpret_cast<const CodeT *>(p + rec[3])[local];
+                const vec_t c = *reinterpret_cast<const vec_t *>(cbp + code * d + VEC * q);
+                const vec_t dec = c * n;
+                if (r == 0) {
+                    acc = dec;
+                } else {
+                    acc = acc + dec;
+                }
+            }
+            if (R > 1) acc = acc / fR;
+            const int64_t at = local * d + VEC * q;
+            if (ERR) acc = *reinterpret_cast<const vec_t *>(grad + at) - acc;
+            *reinterpret_cast<vec_t *>(dst + at) = acc;
+        }
+    }
+}
+
+template <typename CodeT, typename LevelT, bool ERR>
+static int launch_decode_any(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
+                             int64_t user_stride, int R, const float *cb, int d, int K, int n_bit, float *out,
+                             hipStream_t st, const char *what) {
+    const size_t cb_bytes = (size_t)K * d * sizeof(float);
+    const int in_lds = cb_bytes <= 64 * 1024;
+    const size_t lds = in_lds ? cb_bytes : 0;
+    int64_t blocks = ntiles;
+    const int64_t cap = (int64_t)cu_count() * 8;
+    if (blocks > cap) blocks = cap;
+    if ((d & 3) == 0) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched_any_kernel<CodeT, LevelT, 4, ERR>),
+                           dim3((unsigned)blocks), dim3(BT_THREADS), lds, st, seg_table, tile_seg, ntiles, gathered,
+                           user_stride, R, cb, d, K, n_bit, out, in_lds);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched_any_kernel<CodeT, LevelT, 1, ERR>),
+                           dim3((unsigned)blocks), dim3(BT_THREADS), lds, st, seg_table, tile_seg, ntiles, gathered,
+                           user_stride, R, cb, d, K, n_bit, out, in_lds);
+    }
+    GQ_CHECK_LAUNCH(what);
+    return GQ_OK;
+}
+
+template <bool ERR>
+static int decode_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                      const uint8_t *gathered, int64_t user_stride, int R, const float *cb, int d, int K,
+                      int code_bytes, int level_bytes, int n_bit, float *out, void *stream, const char *what) {
+    if (nseg < 1 || ntiles < 1 || R < 1 || d < 1 || K < 1 || n_bit < 1 || n_bit > 30)
+        return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes", what);
+    if (!seg_table || !tile_seg || !gathered || !cb || (!ERR && !out))
+        return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
+    hipStream_t st = as_stream(stream);
+#define GQ_ANY_CASE(CB, LB, CT, LT)                                                                                  \
+    if (code_bytes == CB && level_bytes == LB)                                                                      \
+        return launch_decode_any<CT, LT, ERR>(seg_table, tile_seg, ntiles, gathered, user_stride, R, cb, d, K, n_bit, \
+                                              out, st, what);
+    GQ_ANY_CASE(1, 1, uint8_t, uint8_t)
+    GQ_ANY_CASE(1, 2, uint8_t, int16_t)
+    GQ_ANY_CASE(1, 4, uint8_t, int32_t)
+    GQ_ANY_CASE(4, 1, int32_t, uint8_t)
+    GQ_ANY_CASE(4, 2, int32_t, int16_t)
+    GQ_ANY_CASE(4, 4, int32_t, int32_t)
+#undef GQ_ANY_CASE
+    return fail(GQ_ERR_INVALID_ARG, "%s: code_bytes must be 1 or 4, level_bytes 1, 2 or 4", what);
+}
+
 static inline int64_t bt_grid(int64_t items) {
     int64_t blocks = (items + BT_THREADS - 1) / BT_THREADS;
     const int64_t cap = (int64_t)cu_count() * 8;
@@ -405,7 +514,7 @@ GQ_API int gq_hsq_levels_batched(const int64_t *seg_table, const int32_t *tile_s
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched: random_mode must be OFF or DEVICE");
     if (((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > 255)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: levels do not fit uint8");
-    hipLaunchKernelGGL(gq::hsq_levels_batched_kernel, dim3((unsigned)gq::bt_grid(ntiles * 16)), dim3(gq::BT_THREADS), 0,
+    hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<uint8_t>, dim3((unsigned)gq::bt_grid(ntiles * 16)), dim3(gq::BT_THREADS), 0,
                        gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed,
                        wire);
     GQ_CHECK_LAUNCH("gq_hsq_levels_batched");
@@ -514,4 +623,49 @@ GQ_API int gq_hsq_levels_batched_ef_d(const int64_t *seg_table, const int32_t *t
     }
     GQ_CHECK_LAUNCH("gq_hsq_levels_batched_ef_d");
     return GQ_OK;
+}
+
+GQ_API int gq_hsq_levels_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                     const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
+                                     uint64_t seed, int level_bytes, uint8_t *wire, void *stream) {
+    if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > 30)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: bad sizes");
+    if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !wire)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: null pointer");
+    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched_any: random_mode must be OFF or DEVICE");
+    const int64_t top = ((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0);
+    if ((level_bytes == 1 && top > 255) || (level_bytes == 2 && top > 32767))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: levels up to %lld do not fit %d byte(s)",
+                        (long long)top, level_bytes);
+    const dim3 grid((unsigned)gq::bt_grid(ntiles * 16)), block(gq::BT_THREADS);
+    hipStream_t st = gq::as_stream(stream);
+    if (level_bytes == 1)
+        hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<uint8_t>, grid, block, 0, st, seg_table, tile_seg, ntiles, u_flat,
+                           seg_minmax, n_bit, random_mode, seed, wire);
+    else if (level_bytes == 2)
+        hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<int16_t>, grid, block, 0, st, seg_table, tile_seg, ntiles, u_flat,
+                           seg_minmax, n_bit, random_mode, seed, wire);
+    else if (level_bytes == 4)
+        hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<int32_t>, grid, block, 0, st, seg_table, tile_seg, ntiles, u_flat,
+                           seg_minmax, n_bit, random_mode, seed, wire);
+    else
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: level_bytes must be 1, 2 or 4");
+    GQ_CHECK_LAUNCH("gq_hsq_levels_batched_any");
+    return GQ_OK;
+}
+
+GQ_API int gq_hsq_decode_sum_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                         const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                         const float *codebook, int d, int K, int code_bytes, int level_bytes,
+                                         int n_bit, float *out, void *stream) {
+    return gq::decode_any<false>(seg_table, tile_seg, nseg, ntiles, gathered, user_stride_bytes, R, codebook, d, K,
+                                 code_bytes, level_bytes, n_bit, out, stream, "gq_hsq_decode_sum_batched_any");
+}
+
+GQ_API int gq_hsq_error_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                    const uint8_t *wire, const float *codebook, int d, int K, int code_bytes,
+                                    int level_bytes, int n_bit, void *stream) {
+    return gq::decode_any<true>(seg_table, tile_seg, nseg, ntiles, wire, 0, 1, codebook, d, K, code_bytes, level_bytes,
+                                n_bit, nullptr, stream, "gq_hsq_error_batched_any");
 }

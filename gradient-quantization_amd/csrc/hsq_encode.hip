@@ -251,13 +251,29 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_generic_kernel(const f
 // ------------------------------------------------------------------------------------
 constexpr int LDS_ROW_PAD = 4;
 
-template <typename CodeT>
+// BATCHED: the tiles are those of a segment table (include/gq_hsq.h, gq_hsq_encode_batched_any): tile t belongs to
+// tensor tile_seg[t]; codes go into the tensor's section of `wire`, u into the padded u_flat, and (min,max)
+// of u is folded into seg_minmax per tensor.  EF: a tile is read as grad + ef_scale*error and written back.
+struct LdsBatch {
+    const int64_t *seg_table;
+    const int32_t *tile_seg;
+    uint8_t *wire;
+    unsigned *seg_minmax;
+    float ef_scale;
+};
+
+__device__ __forceinline__ unsigned lds_order_map(float f) {
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+template <typename CodeT, bool BATCHED = false, bool EF = false>
 __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float *__restrict__ grad,
                                                                     const float *__restrict__ cb, int64_t M, int d,
                                                                     int K, CodeT *__restrict__ codes,
                                                                     float *__restrict__ u,
                                                                     float *__restrict__ partials, int dpad,
-                                                                    int chunk_rows) {
+                                                                    int chunk_rows, LdsBatch bt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -280,15 +296,49 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
         }
     };
     // this wave's tile (64 subvectors) -> s_v; subvectors beyond M are zeros (masked at the store)
+    // BATCHED: the tile's tensor (wave-uniform): its record, the tile's first subvector inside it
+    const int64_t *rec = nullptr;
+    int64_t seg_m = M, seg_sv0 = 0;
+    int seg = -1, cur_seg = -1;
     auto stage_tile = [&](int64_t t) {
         const int total = 64 * dpad;
-        const int64_t sv0 = t * 64;
+        int64_t sv0 = t * 64, m = M;
+        const float *g = grad;
+        float *gw = nullptr;
+        const float *err = nullptr;
+        if (BATCHED) {
+            seg = bt.tile_seg[t];
+            rec = bt.seg_table + 8 * (int64_t)seg;
+            m = seg_m = rec[1];
+            sv0 = seg_sv0 = (t - rec[2]) * 64;
+            g = gw = reinterpret_cast<float *>(rec[0]);
+            if (EF) err = reinterpret_cast<const float *>(rec[7]);
+        }
         for (int i = lane; i < total; i += 64) {
             const int r = (int)(((float)i + 0.5f) * inv_dpad);
             const int e = i - r * dpad;
-            const float val = (sv0 + r < M && e < d) ? grad[(sv0 + r) * (int64_t)d + e] : 0.0f;
+            const bool in = sv0 + r < m && e < d;
+            const int64_t at = (sv0 + r) * (int64_t)d + e;
+            float val = in ? g[at] : 0.0f;
+            if (EF && err && in) {   // ps_quantizer.py:35, in place: product rounded, then the add
+                const float p = bt.ef_scale * err[at];
+                val = val + p;
+                gw[at] = val;
+            }
             s_v[r * stride + (e & 1) * half + (e >> 1)] = val;
         }
+    };
+    auto flush_minmax = [&](float &lmin, float &lmax) {   // this wave's running (min,max) -> its tensor's words
+        const float lo = wave_min(lmin), hi = wave_max(lmax);
+        if (lane == 0 && cur_seg >= 0 && lo <= hi) {
+            // look before the atomic (hsq_encode_pf.hip): the words only move towards the extremes
+            unsigned *mm = bt.seg_minmax + 2 * cur_seg;
+            const unsigned mlo = lds_order_map(lo), mhi = lds_order_map(hi);
+            if (mlo < __hip_atomic_load(mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(mm, mlo);
+            if (mhi > __hip_atomic_load(mm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(mm + 1, mhi);
+        }
+        lmin = INFINITY;
+        lmax = -INFINITY;
     };
 
     const int64_t ntiles = (M + 63) >> 6;
@@ -350,6 +400,20 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
         const bool take1 = v1 && (!v0 || (a1 > a0) || (a1 == a0 && bi[1] < bi[0]));
         const float val = take1 ? bv[1] : bv[0];
         const int idx = take1 ? bi[1] : bi[0];
+        if (BATCHED) {
+            if (seg != cur_seg) {
+                flush_minmax(lmin, lmax);
+                cur_seg = seg;
+            }
+            const int64_t local = seg_sv0 + lane;
+            u[t * 64 + lane] = val;   // padded index space; lanes beyond the tensor write their (unused) slot
+            if (local < seg_m) {
+                reinterpret_cast<CodeT *>(bt.wire + rec[3])[local] = (CodeT)idx;
+                lmin = fminf(lmin, val);
+                lmax = fmaxf(lmax, val);
+            }
+            continue;
+        }
         const int64_t sv = t * 64 + lane;
         if (sv < M) {
             codes[sv] = (CodeT)idx;
@@ -357,6 +421,10 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
             lmin = fminf(lmin, val);
             lmax = fmaxf(lmax, val);
         }
+    }
+    if (BATCHED) {
+        flush_minmax(lmin, lmax);
+        return;
     }
     write_minmax_partials(lmin, lmax, partials);
 }
@@ -460,7 +528,7 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
         const int bpc = resident_blocks_per_cu(hsq_encode_lds_kernel<CodeT>, ENC_THREADS, lds_bytes);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_lds_kernel<CodeT>), dim3((unsigned)grid_for(bpc)),
                            dim3(ENC_THREADS), lds_bytes, st, grad, codebook, M, d, K, codes, u, partials, dpad,
-                           chunk_rows);
+                           chunk_rows, LdsBatch{});
         GQ_CHECK_LAUNCH("gq_hsq_encode (lds)");
         return GQ_OK;
     }
@@ -507,7 +575,66 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
     return GQ_OK;
 }
 
+// Multi-tensor launch of the LDS kernel (any d <= 128, any K): gq_hsq_encode_batched_any.
+template <typename CodeT, bool EF>
+static int launch_encode_lds_batched(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles,
+                                     const float *codebook, int d, int K, float ef_scale, uint8_t *wire, float *u_flat,
+                                     uint32_t *seg_minmax, hipStream_t st) {
+    int dpad = 0, chunk_rows = 0;
+    size_t lds_bytes = 0;
+    if (!lds_plan(d, K, &dpad, &chunk_rows, &lds_bytes))
+        return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched_any: needs d <= 128 (d=%d K=%d)", d, K);
+    auto kernel = hsq_encode_lds_kernel<CodeT, true, EF>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  128 * 1024);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
+    const int bpc = resident_blocks_per_cu(kernel, ENC_THREADS, lds_bytes);
+    int64_t blocks = (ntiles + ENC_WAVES - 1) / ENC_WAVES;
+    const int64_t cap = (int64_t)cu_count() * bpc;
+    if (blocks > cap) blocks = cap;
+    LdsBatch bt = {seg_table, tile_seg, wire, seg_minmax, ef_scale};
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_lds_kernel<CodeT, true, EF>), dim3((unsigned)blocks),
+                       dim3(ENC_THREADS), lds_bytes, st, (const float *)nullptr, codebook, ntiles * 64, d, K,
+                       (CodeT *)nullptr, u_flat, (float *)nullptr, dpad, chunk_rows, bt);
+    GQ_CHECK_LAUNCH("gq_hsq_encode_batched_any");
+    return GQ_OK;
+}
+
 }  // namespace gq
+
+GQ_API int gq_hsq_batched_any_supported(int d, int K) {
+    int dpad = 0, chunk_rows = 0;
+    size_t bytes = 0;
+    return (d >= 1 && K >= 1 && K <= 65536 && gq::lds_plan(d, K, &dpad, &chunk_rows, &bytes)) ? 1 : 0;
+}
+
+GQ_API int gq_hsq_encode_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                     const float *codebook, int d, int K, int code_bytes, int ef, float ef_scale,
+                                     uint8_t *wire, float *u_flat, uint32_t *seg_minmax, void *stream) {
+    if (nseg < 1 || ntiles < 1 || ntiles * 64 > 0x7FFFFFFFLL || d < 1 || K < 1 || K > 65536)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_any: bad sizes nseg=%d ntiles=%lld d=%d K=%d", nseg,
+                        (long long)ntiles, d, K);
+    if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_any: null pointer");
+    if (code_bytes != 1 && code_bytes != 4)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_any: code_bytes must be 1 or 4");
+    if (code_bytes == 1 && K > 256)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_any: uint8 codes need K <= 256");
+    hipStream_t st = gq::as_stream(stream);
+    if (code_bytes == 1)
+        return ef ? gq::launch_encode_lds_batched<uint8_t, true>(seg_table, tile_seg, ntiles, codebook, d, K, ef_scale,
+                                                                 wire, u_flat, seg_minmax, st)
+                  : gq::launch_encode_lds_batched<uint8_t, false>(seg_table, tile_seg, ntiles, codebook, d, K, 0.0f, wire,
+                                                                  u_flat, seg_minmax, st);
+    return ef ? gq::launch_encode_lds_batched<int32_t, true>(seg_table, tile_seg, ntiles, codebook, d, K, ef_scale, wire,
+                                                             u_flat, seg_minmax, st)
+              : gq::launch_encode_lds_batched<int32_t, false>(seg_table, tile_seg, ntiles, codebook, d, K, 0.0f, wire,
+                                                              u_flat, seg_minmax, st);
+}
 
 GQ_API size_t gq_hsq_workspace_bytes(int64_t M) {
     if (M < 0) M = 0;

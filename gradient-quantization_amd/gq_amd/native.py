@@ -23,6 +23,8 @@ EXPORTS = [
     "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched",
     "gq_hsq_encode_batched_ef", "gq_hsq_levels_batched_ef", "gq_qsgd_compress_batched_ef",
     "gq_hsq_encode_batched_d", "gq_hsq_decode_sum_batched_d", "gq_hsq_encode_batched_d_ef", "gq_hsq_levels_batched_ef_d",
+    "gq_hsq_encode_batched_any", "gq_hsq_levels_batched_any", "gq_hsq_decode_sum_batched_any", "gq_hsq_error_batched_any",
+    "gq_hsq_batched_any_supported",
     "gq_profile_arm", "gq_profile_read", "gq_hsq_compress",
     "gq_pvq_encode", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
@@ -250,6 +252,64 @@ def hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat
                                      _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
                                      _dev_ptr(workspace, torch.float32, "workspace"), _stream())
     _check(rc, "gq_hsq_encode_batched")
+
+
+def hsq_batched_any_supported(d, K):
+    """True if gq_hsq_encode_batched_any serves sub-dimension d with K codewords (a tile and 32 codebook rows fit the LDS)."""
+    return bool(lib().gq_hsq_batched_any_supported(ctypes.c_int(int(d)), ctypes.c_int(int(K))))
+
+
+def hsq_encode_batched_any(seg_table, tile_seg, nseg, ntiles, codebook, code_dtype, wire, u_flat, seg_minmax,
+                           ef_scale=None):
+    """Any (d <= 128, K): exact scoring; ef_scale given = tiles are read as grad + ef_scale*error, written back."""
+    K, d = int(codebook.shape[0]), int(codebook.shape[1])
+    rc = lib().gq_hsq_encode_batched_any(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                         _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                         ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
+                                         ctypes.c_int(d), ctypes.c_int(K), ctypes.c_int(_CODE_BYTES[code_dtype]),
+                                         ctypes.c_int(0 if ef_scale is None else 1),
+                                         ctypes.c_float(0.0 if ef_scale is None else ef_scale),
+                                         _dev_ptr(wire, torch.uint8, "wire"), _dev_ptr(u_flat, torch.float32, "u_flat"),
+                                         _dev_ptr(seg_minmax, torch.int32, "seg_minmax"), _stream())
+    _check(rc, "gq_hsq_encode_batched_any")
+
+
+def hsq_levels_batched_any(seg_table, tile_seg, nseg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, level_dtype,
+                           wire):
+    rc = lib().gq_hsq_levels_batched_any(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                         _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                         ctypes.c_int64(ntiles), _dev_ptr(u_flat, torch.float32, "u_flat"),
+                                         _dev_ptr(seg_minmax, torch.int32, "seg_minmax"), ctypes.c_int(n_bit),
+                                         ctypes.c_int(random_mode), ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                                         ctypes.c_int(_LEVEL_BYTES[level_dtype]), _dev_ptr(wire, torch.uint8, "wire"),
+                                         _stream())
+    _check(rc, "gq_hsq_levels_batched_any")
+
+
+def hsq_decode_sum_batched_any(seg_table, tile_seg, nseg, ntiles, gathered, codebook, code_dtype, level_dtype, n_bit, out,
+                               R):
+    assert gathered.dim() == 2 and gathered.shape[0] == R and gathered.stride(1) == 1
+    rc = lib().gq_hsq_decode_sum_batched_any(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                             _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                             ctypes.c_int64(ntiles), ctypes.c_void_p(gathered.data_ptr()),
+                                             ctypes.c_int64(gathered.stride(0)), ctypes.c_int(R),
+                                             _dev_ptr(codebook, torch.float32, "codebook"),
+                                             ctypes.c_int(int(codebook.shape[1])), ctypes.c_int(int(codebook.shape[0])),
+                                             ctypes.c_int(_CODE_BYTES[code_dtype]), ctypes.c_int(_LEVEL_BYTES[level_dtype]),
+                                             ctypes.c_int(n_bit), _dev_ptr(out, torch.float32, "out"), _stream())
+    _check(rc, "gq_hsq_decode_sum_batched_any")
+
+
+def hsq_error_batched_any(seg_table, tile_seg, nseg, ntiles, wire, codebook, code_dtype, level_dtype, n_bit):
+    """error = grad - decode(wire) for every row of the table that names an error buffer (column 7)."""
+    rc = lib().gq_hsq_error_batched_any(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                        _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                        ctypes.c_int64(ntiles), _dev_ptr(wire, torch.uint8, "wire"),
+                                        _dev_ptr(codebook, torch.float32, "codebook"),
+                                        ctypes.c_int(int(codebook.shape[1])), ctypes.c_int(int(codebook.shape[0])),
+                                        ctypes.c_int(_CODE_BYTES[code_dtype]), ctypes.c_int(_LEVEL_BYTES[level_dtype]),
+                                        ctypes.c_int(n_bit), _stream())
+    _check(rc, "gq_hsq_error_batched_any")
 
 
 def hsq_levels_batched(seg_table, tile_seg, nseg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, wire,

@@ -59,6 +59,10 @@ class DenseCodec(object):
         return rows.mean(dim=0).view(self.shape)
 
 
+def _esize(dtype):
+    return torch.empty(0, dtype=dtype).element_size()
+
+
 class GenericCodec(object):
     """Any other compressor class (sign, top-k, user supplied): ships the DECODED tensor.
     Keeps the reference semantics (mean of decompress(compress(g))) without a compact format."""
@@ -340,23 +344,30 @@ class _BatchedBase(object):
 
 
 class BatchedHSQ(_BatchedBase):
-    """All NearestNeighborCompressor tensors with d = 16, K = 256 and byte-sized codes / levels are
-    encoded by ONE gq_hsq_encode_batched + ONE gq_hsq_levels_batched launch and decoded by ONE
-    gq_hsq_decode_sum_batched launch (per-tensor lb / ub, identical results).  The reference walks
-    the parameter list in Python (ps_quantizer.py:33,47); ResNet-50 has 76 such tensors."""
+    """All NearestNeighborCompressor tensors that share a codebook are encoded by ONE encode + ONE levels
+    launch and decoded by ONE decode-mean launch (per-tensor lb / ub, identical results).  The reference
+    walks the parameter list in Python (ps_quantizer.py:33,47); ResNet-50 has 76 such tensors.
+    K = 256, d in DIMS with byte-sized codes and levels take the prefilter encode and the specialised
+    levels / decode kernels; every other shape the exact multi-tensor kernels (gq_hsq_*_batched_any)."""
+
+    DIMS = (16, 8, 32)       # sub-dimensions with a multi-tensor prefilter encode (K = 256)
+
+    @staticmethod
+    def _prefilter(codec):
+        return codec.c.K == 256 and codec.c.dim in BatchedHSQ.DIMS and codec.code_dtype == torch.uint8
 
     @staticmethod
     def eligible(codec):
         c = getattr(codec, "c", None)
-        return (type(codec) is HSQCodec and c.dim in BatchedHSQ.DIMS and c.K == 256 and c.compressed_norm
-                and codec.code_dtype == torch.uint8 and codec.level_dtype == torch.uint8
-                and (not c.norm_compressor.random or c.norm_compressor._rng == "device"))
-
-    DIMS = (16, 8, 32)       # sub-dimensions with a multi-tensor prefilter encode (K = 256); one group per dimension
+        if type(codec) is not HSQCodec or not c.compressed_norm or c.K == c.dim:   # K == d: a random codebook per tensor
+            return False
+        if c.norm_compressor.random and c.norm_compressor._rng != "device":
+            return False
+        return BatchedHSQ._prefilter(codec) or native.hsq_batched_any_supported(c.dim, c.K)
 
     @staticmethod
     def group_key(codec):
-        return codec.c.dim
+        return (codec.c.dim, codec.c.K, _esize(codec.code_dtype), _esize(codec.level_dtype))
 
     def __init__(self, codecs, offsets, idxs, device, slots, user_bytes):
         self.idxs = list(idxs)
@@ -386,32 +397,54 @@ class BatchedHSQ(_BatchedBase):
         init[:, 0], init[:, 1] = -1, 0            # 0xFFFFFFFF / 0: identities of the mapped min / max
         self._setup(table, init.view(torch.int64), device, slots, user_bytes)
         self.u_flat = torch.empty(self.ntiles * 64, dtype=torch.float32, device=device)
-        self.ws = native.new_workspace(device, self.ntiles * 64)
+        cd0 = self.codecs[0]
+        self.code_dtype, self.level_dtype = cd0.code_dtype, cd0.level_dtype
+        self.prefilter = BatchedHSQ._prefilter(cd0)                                   # which encode
+        self.bytes = self.prefilter and self.level_dtype == torch.uint8               # which levels / decode
+        self.align = 16 if c0.dim % 4 == 0 else 4
+        self.ws = native.new_workspace(device, self.ntiles * 64) if self.prefilter else None
 
     def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None):
         """Compress `tensors` (one per batched parameter, in order) into one user's wire.
         Returns False (nothing launched) when a tensor is not a contiguous, 16-byte aligned f32
         tensor on this device: the caller then takes the per-tensor path for this step.
-        With `errs` (error feedback, ps_quantizer.py:34-39) the same two launches also do
+        With `errs` (error feedback, ps_quantizer.py:34-39) the same launches also do
         t += ef_scale*err (in place, before encoding) and err = t - decoded (in place, after)."""
-        if self.codebook.shape[1] != 16 and self.nseg > 384:
+        if self.prefilter and self.codebook.shape[1] != 16 and self.nseg > 384:
             return False    # d = 8 / 32: at most 384 tensors per launch
-        if not self._upload(tensors, slot, 16, errs):
+        if not self._upload(tensors, slot, self.align, errs):
             return False
         seg_table = self._dev[:self._table_words]
         minmax = self._dev[self._table_words:].view(torch.int32)
-        native.hsq_encode_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.codebook, wire_user,
-                                  self.u_flat, minmax, self.ws, ef_scale=ef_scale if errs is not None else None)
+        ef = ef_scale if errs is not None else None
+        if self.prefilter:
+            native.hsq_encode_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.codebook, wire_user,
+                                      self.u_flat, minmax, self.ws, ef_scale=ef)
+        else:
+            native.hsq_encode_batched_any(seg_table, self.tile_seg, self.nseg, self.ntiles, self.codebook, self.code_dtype,
+                                          wire_user, self.u_flat, minmax, ef_scale=ef)
         mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
-        native.hsq_levels_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.u_flat, minmax, self.n_bit,
-                                  mode, (_next_seed() ^ salt) if self.random else 0, wire_user,
-                                  ef_codebook=self.codebook if errs is not None else None)
+        seed = (_next_seed() ^ salt) if self.random else 0
+        if self.bytes:
+            native.hsq_levels_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.u_flat, minmax, self.n_bit,
+                                      mode, seed, wire_user, ef_codebook=self.codebook if errs is not None else None)
+            return True
+        native.hsq_levels_batched_any(seg_table, self.tile_seg, self.nseg, self.ntiles, self.u_flat, minmax, self.n_bit,
+                                      mode, seed, self.level_dtype, wire_user)
+        if errs is not None:
+            native.hsq_error_batched_any(seg_table, self.tile_seg, self.nseg, self.ntiles, wire_user, self.codebook,
+                                         self.code_dtype, self.level_dtype, self.n_bit)
         return True
 
     def decode_mean(self, gathered, R):
         out, views = self._out_buffer(gathered.device)
-        native.hsq_decode_sum_batched(self._dev[:self._table_words], self.tile_seg, self.nseg, self.ntiles, gathered,
-                                      self.codebook, self.n_bit, out, R)
+        if self.bytes:
+            native.hsq_decode_sum_batched(self._dev[:self._table_words], self.tile_seg, self.nseg, self.ntiles, gathered,
+                                          self.codebook, self.n_bit, out, R)
+        else:
+            native.hsq_decode_sum_batched_any(self._dev[:self._table_words], self.tile_seg, self.nseg, self.ntiles,
+                                              gathered, self.codebook, self.code_dtype, self.level_dtype, self.n_bit, out,
+                                              R)
         return views
 
 

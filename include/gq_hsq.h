@@ -204,6 +204,28 @@ int gq_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *tile_se
                                 const uint8_t *gathered, int64_t user_stride_bytes, int R, const float *codebook,
                                 int d, int n_bit, float *out, void *stream);
 
+/* The same multi-tensor launches for ANY other shape the reference can be configured to
+ * (nearest_neighbor_compressor.py:23-57: d from --c-dim and its repair loop, K = 2^k_bit or d, int32 codes when
+ * k_bit > 8; probabilistic_scalar_compressor.py:20-25: n_bit = 8 with stochastic rounding reaches level 256):
+ * code_bytes 1 | 4, level_bytes 1 | 2 | 4, sections of the wire 16-byte aligned.  Exact f32 scoring (the LDS
+ * kernel of gq_hsq_encode, d <= 128).  gq_hsq_encode_batched_any: `ef` != 0 reads every tile as
+ * grad + ef_scale*error (seg_table[seg][7]) and writes it back;  gq_hsq_error_batched_any then writes
+ * error = grad - decode(wire) for the rows that have an error buffer (ps_quantizer.py:39).
+ * gq_hsq_levels_batched_any is independent of (d, K) and also serves the prefilter encodes above. */
+int gq_hsq_batched_any_supported(int d, int K);   /* 1 if gq_hsq_encode_batched_any serves (d, K) */
+int gq_hsq_encode_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                              const float *codebook, int d, int K, int code_bytes, int ef, float ef_scale,
+                              uint8_t *wire, float *u_flat, uint32_t *seg_minmax, void *stream);
+int gq_hsq_levels_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                              const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
+                              uint64_t seed, int level_bytes, uint8_t *wire, void *stream);
+int gq_hsq_decode_sum_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                  const uint8_t *gathered, int64_t user_stride_bytes, int R, const float *codebook,
+                                  int d, int K, int code_bytes, int level_bytes, int n_bit, float *out, void *stream);
+int gq_hsq_error_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                             const uint8_t *wire, const float *codebook, int d, int K, int code_bytes,
+                             int level_bytes, int n_bit, void *stream);
+
 /*
  * Error-feedback helpers fused around the codec (ps_quantizer.py:35,39):
  *     gq_axpy_inplace:   grad += scale * err

@@ -270,6 +270,79 @@ def test_batched_quantizer_other_subdimensions_equal_per_tensor_path(c_dim):
                 assert torch.equal(pb.server_error, pp.server_error)
 
 
+def _shapes_for(d):
+    """Tensors whose sizes the sub-dimension d divides (no repair), with ragged last tiles, plus identity ones."""
+    return [(d, 130), (3 * d, 3, 3, 7), (d * 1000 + d,), (d * 64,), (d, 64, 9), (2 * d, 77), (10,), (64,), (d * 20 + d,)]
+
+
+def _write_unit_codebook(root, d, K, seed):
+    """A synthetic codebook file in the reference's format and place (./codebooks/learned_codebook/...)."""
+    rng = np.random.default_rng(seed)
+    cb = rng.standard_normal((K, d)).astype(np.float32)
+    rows = np.empty((K, d + 1), dtype="<i4")
+    rows[:, 0] = d
+    rows[:, 1:] = cb.view("<i4")
+    path = os.path.join(root, "codebooks", "learned_codebook")
+    os.makedirs(path, exist_ok=True)
+    rows.tofile(os.path.join(path, "angular_dim_%d_Ks_%d.fvecs" % (d, K)))
+
+
+ANY_CASES = [dict(c_dim=32, k_bit=8, n_bit=9),     # prefilter encode, 16-bit levels
+             dict(c_dim=12, k_bit=9, n_bit=6),     # K = 512: int32 codes
+             dict(c_dim=24, k_bit=6, n_bit=4),
+             dict(c_dim=8, k_bit=5, n_bit=8),
+             dict(c_dim=10, k_bit=5, n_bit=6),     # d % 4 != 0: scalar loads / stores
+             dict(c_dim=48, k_bit=11, n_bit=17)]   # 384 KiB codebook (chunked in LDS), int32 codes and levels
+
+
+@pytest.mark.parametrize("case", ANY_CASES, ids=lambda c: "d%d_k%d_n%d" % (c["c_dim"], c["k_bit"], c["n_bit"]))
+def test_batched_quantizer_any_shape_equals_per_tensor_path(case, tmp_path, monkeypatch):
+    """The multi-tensor kernels for every other (d, K, code width, level width): aggregates, wire, per-user
+    residuals and the server residual identical to the per-tensor kernels."""
+    d, K = case["c_dim"], 2 ** case["k_bit"]
+    if not os.path.exists(os.path.join(GOLDEN, "codebooks", "learned_codebook", "angular_dim_%d_Ks_%d.fvecs" % (d, K))):
+        _write_unit_codebook(str(tmp_path), d, K, 5)
+        monkeypatch.chdir(tmp_path)
+    shapes = _shapes_for(d)
+    qb, gb = _run_quantizer(shapes, 2, 13, **case)
+    qp, gp = _run_quantizer(shapes, 2, 13, gq_no_batch=True, **case)
+    assert qb._groups and qb._groups[0][2] is not None and qb._groups[0][2].ready and not qp._groups
+    grp = qb._groups[0][2]
+    assert grp.codebook.shape == (K, d) and len(qb.batch_idx) == sum(int(np.prod(s)) > 1000 for s in shapes) >= 5
+    assert grp.prefilter == (K == 256 and d in (8, 16, 32)) and not grp.bytes
+    for a, b, s in zip(gb, gp, shapes):
+        assert a.shape == torch.Size(s)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), s
+    assert torch.equal(qb._wire, qp._wire)
+    for kw in (dict(ef=True), dict(ef=True, two_phase=True, scale="0.5")):
+        qe, ge = _run_quantizer(shapes, 2, 13, **case, **kw)
+        qf, gf = _run_quantizer(shapes, 2, 13, gq_no_batch=True, **case, **kw)
+        assert qe._groups[0][2].ready
+        for a, b in zip(ge, gf):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        for pb, pp in zip(qe.parameters, qf.parameters):
+            for eb, ep in zip(pb.error, pp.error):
+                assert torch.equal(eb, ep)
+            if kw.get("two_phase"):
+                assert torch.equal(pb.server_error, pp.server_error)
+
+
+def test_batched_quantizer_reference_default_flags():
+    """main.py:90-94's defaults (--c-dim 32 --k-bit 8 --n-bit 8 --random 1): stochastic rounding reaches level
+    256, so the levels travel as int16 -- still one launch per stage, and every level within one step of the
+    deterministic rounding."""
+    shapes = RESNET50_COMPRESSED[:8] + RESNET50_SMALL[:3]
+    q, g = _run_quantizer(shapes, 2, 9, c_dim=32, n_bit=8, random=1)
+    det, gd = _run_quantizer(shapes, 2, 9, c_dim=32, n_bit=8, random=0)
+    grp = q._groups[0][2]
+    assert grp.ready and grp.prefilter and not grp.bytes and grp.level_dtype == torch.int16
+    assert det._groups[0][2].bytes
+    for a, b, p in zip(g, gd, q.parameters):
+        if p.numel() > 1000:
+            assert not torch.equal(a, b)
+        assert (a - b).abs().max() <= b.abs().max() * 0.1 + 1e-12   # one step = (ub - lb)/256 of the projection
+
+
 @pytest.mark.parametrize("c_dim", [16, 32])
 def test_batched_quantizer_long_tensor_lists(c_dim):
     """More tensors than the kernels keep segment records for in LDS (384): d = 16 switches to the instantiation

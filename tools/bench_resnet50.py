@@ -50,3 +50,9 @@ run("QSGD d128 n2 batched, error feedback", QSGDCompressor, c_dim=128, n_bit=2, 
 run("HSQ c-dim 32 batched", NearestNeighborCompressor, c_dim=32)
 run("HSQ c-dim 32 per-tensor launches", NearestNeighborCompressor, c_dim=32, gq_no_batch=True)
 run("HSQ c-dim 8 batched", NearestNeighborCompressor, c_dim=8)
+os.environ.setdefault("GQ_CODEBOOK_DIR", os.path.join(ROOT, "tests", "golden", "codebooks"))
+run("HSQ main.py defaults (d32 n8 random) batched", NearestNeighborCompressor, c_dim=32, n_bit=8)
+run("HSQ main.py defaults per-tensor launches", NearestNeighborCompressor, c_dim=32, n_bit=8, gq_no_batch=True)
+run("HSQ d8 K32 batched (exact kernels)", NearestNeighborCompressor, c_dim=8, k_bit=5)
+run("HSQ d8 K32 per-tensor launches", NearestNeighborCompressor, c_dim=8, k_bit=5, gq_no_batch=True)
+run("HSQ d8 K32 batched, EF + two-phase", NearestNeighborCompressor, c_dim=8, k_bit=5, ef=True, two_phase=True)
