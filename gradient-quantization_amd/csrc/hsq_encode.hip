@@ -314,6 +314,46 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
             g = gw = reinterpret_cast<float *>(rec[0]);
             if (EF) err = reinterpret_cast<const float *>(rec[7]);
         }
+        if ((d & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | (EF && err ? reinterpret_cast<uintptr_t>(err) : 0)) & 15) == 0) {
+            // the tile is 64*d contiguous floats: 16-byte loads, four in flight per lane (one element at a time
+            // the staging was a chain of dependent 4-byte round trips and the whole kernel waited on it).
+            // A dwordx4 holds elements e..e+3 of one row: the even ones go to [e/2, e/2+1] of the row's first
+            // run, the odd ones to the same place in its second run.  The zero padding [d, dpad) is never
+            // written here (zeroed once at kernel start).
+            const int upr = d >> 2, units = 64 * upr;          // 16-byte units per row / per tile
+            const float inv_upr = 1.0f / (float)upr;
+            const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g + sv0 * (int64_t)d);
+            f32x4 *gw4 = reinterpret_cast<f32x4 *>(gw + sv0 * (int64_t)d);
+            const f32x4 *e4 = reinterpret_cast<const f32x4 *>(err + sv0 * (int64_t)d);
+            const int64_t rows_in = m - sv0;                    // rows of the tile inside the tensor (may exceed 64)
+            for (int i0 = lane; i0 < units; i0 += 256) {
+                f32x4 p[4];
+                int r[4], q[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + 64 * k;
+                    r[k] = (int)(((float)i + 0.5f) * inv_upr);
+                    q[k] = i - r[k] * upr;
+                    const bool in = i < units && r[k] < rows_in;
+                    p[k] = in ? g4[i] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (EF && err && in) {   // ps_quantizer.py:35, in place: product rounded, then the add
+                        const f32x4 prod = e4[i] * bt.ef_scale;
+                        p[k] = p[k] + prod;
+                        gw4[i] = p[k];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (i0 + 64 * k < units) {
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        float *row = s_v + r[k] * stride + 2 * q[k];
+                        *reinterpret_cast<f32x2 *>(row) = f32x2{p[k][0], p[k][2]};
+                        *reinterpret_cast<f32x2 *>(row + half) = f32x2{p[k][1], p[k][3]};
+                    }
+                }
+            }
+            return;
+        }
         for (int i = lane; i < total; i += 64) {
             const int r = (int)(((float)i + 0.5f) * inv_dpad);
             const int e = i - r * dpad;
@@ -328,6 +368,8 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
             s_v[r * stride + (e & 1) * half + (e >> 1)] = val;
         }
     };
+    // the padding [d, dpad) of this wave's tile rows: zero, once (the 16-byte staging path never writes it)
+    for (int i = lane; i < 64 * stride; i += 64) s_v[i] = 0.0f;
     auto flush_minmax = [&](float &lmin, float &lmax) {   // this wave's running (min,max) -> its tensor's words
         const float lo = wave_min(lmin), hi = wave_max(lmax);
         if (lane == 0 && cur_seg >= 0 && lo <= hi) {
@@ -350,7 +392,11 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
         __syncthreads();
     }
     for (int64_t round = 0; round < rounds; ++round) {
-        const int64_t t = round * nw + (int64_t)blockIdx.x * ENC_WAVES + wave;
+        // BATCHED: a wave takes ONE contiguous run of `rounds` tiles, so that its running (min,max) stays with a
+        // tensor (visited round-robin every tile changed tensor and paid two atomics on the same few cache
+        // lines: 46,000 tiles of the ResNet-50 list at d = 8 took 350 us, most of it queueing there)
+        const int64_t wid = (int64_t)blockIdx.x * ENC_WAVES + wave;
+        const int64_t t = BATCHED ? wid * rounds + round : round * nw + wid;
         const bool active = t < ntiles;
         if (active) stage_tile(t);
         Best best[2] = {{0.0f, 0}, {0.0f, 0}};

@@ -70,14 +70,26 @@ __global__ __launch_bounds__(QS_THREADS) void qsgd_compress_wave_kernel(const fl
 
 // Large buckets (c_dim = 0 -> one bucket spanning the tensor): abs-max by atomicMax on
 // the bit pattern (|v| >= 0, so unsigned order == float order), then an elementwise pass.
+// A wave folds its 64 values first when they share a bucket and looks at the word before the atomic (it only
+// grows): one atomic per element queued 2.4 M of them on one address (~90 per microsecond).
 __global__ __launch_bounds__(QS_THREADS) void qsgd_absmax_kernel(const float *__restrict__ grad, int64_t Mb, int d,
                                                                 unsigned *__restrict__ norm_bits) {
     const int64_t total = Mb * (int64_t)d;
     const int64_t stride = (int64_t)gridDim.x * QS_THREADS;
-    // each thread walks a contiguous chunk so that its running max belongs to few buckets
-    for (int64_t i = (int64_t)blockIdx.x * QS_THREADS + threadIdx.x; i < total; i += stride) {
-        const int64_t b = i / d;
-        atomicMax(&norm_bits[b], __float_as_uint(fabsf(grad[i])));
+    const int lane = threadIdx.x & 63;
+    for (int64_t i0 = (int64_t)blockIdx.x * QS_THREADS + (threadIdx.x & ~63); i0 < total; i0 += stride) {
+        const int64_t i = i0 + lane;
+        const bool in = i < total;
+        const float a = in ? fabsf(grad[i]) : 0.0f;
+        const int64_t last = (i0 + 63 < total ? i0 + 63 : total - 1);
+        const int64_t b0 = i0 / d;
+        if (b0 == last / d) {                       // the wave's elements share a bucket (wave-uniform test)
+            const unsigned m = __float_as_uint(wave_max(a));
+            if (lane == 0 && m > __hip_atomic_load(&norm_bits[b0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(&norm_bits[b0], m);
+        } else if (in) {
+            atomicMax(&norm_bits[i / d], __float_as_uint(a));
+        }
     }
 }
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "gq_hsq_encode_batched_ef", "gq_hsq_levels_batched_ef", "gq_qsgd_compress_batched_ef",
     "gq_hsq_encode_batched_d", "gq_hsq_decode_sum_batched_d", "gq_hsq_encode_batched_d_ef", "gq_hsq_levels_batched_ef_d",
     "gq_hsq_encode_batched_any", "gq_hsq_levels_batched_any", "gq_hsq_decode_sum_batched_any", "gq_hsq_error_batched_any",
-    "gq_hsq_batched_any_supported",
+    "gq_hsq_batched_any_supported", "gq_qsgd_wide_compress", "gq_qsgd_wide_decode_sum",
     "gq_profile_arm", "gq_profile_read", "gq_hsq_compress",
     "gq_pvq_encode", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
@@ -410,6 +410,31 @@ def qsgd_decode_sum_batched(seg_table, bucket_seg, nseg, nbuckets, n_bit, bits, 
                                           ctypes.c_int64(gathered.shape[1]), ctypes.c_int(R),
                                           _dev_ptr(out, torch.float32, "out"), _stream())
     _check(rc, "gq_qsgd_decode_sum_batched")
+
+
+QSGD_WIDE_CHUNK = 1024     # GQ_QSGD_WIDE_CHUNK (include/gq_hsq.h)
+
+
+def qsgd_wide_compress(seg_table, chunk_seg, nseg, nchunks, n_bit, random_mode, seed, norm_bits, wire, ef_scale=None):
+    """Wide buckets (TernGrad: the tensor is one bucket): bucket norms, then codes; ef_scale given = error feedback."""
+    rc = lib().gq_qsgd_wide_compress(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                     _dev_ptr(chunk_seg, torch.int32, "chunk_seg"), ctypes.c_int(nseg),
+                                     ctypes.c_int64(nchunks), ctypes.c_int(n_bit), ctypes.c_int(random_mode),
+                                     ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_int(0 if ef_scale is None else 1),
+                                     ctypes.c_float(0.0 if ef_scale is None else ef_scale),
+                                     _dev_ptr(norm_bits, torch.int32, "norm_bits"), _dev_ptr(wire, torch.uint8, "wire"),
+                                     _stream())
+    _check(rc, "gq_qsgd_wide_compress")
+
+
+def qsgd_wide_decode_sum(seg_table, chunk_seg, nseg, nchunks, n_bit, bits, gathered, out, R):
+    assert gathered.dtype == torch.uint8 and gathered.dim() == 2 and gathered.shape[0] == R and gathered.is_contiguous()
+    rc = lib().gq_qsgd_wide_decode_sum(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                       _dev_ptr(chunk_seg, torch.int32, "chunk_seg"), ctypes.c_int(nseg),
+                                       ctypes.c_int64(nchunks), ctypes.c_int(n_bit), ctypes.c_int(bits),
+                                       _dev_ptr(gathered, torch.uint8, "gathered"), ctypes.c_int64(gathered.shape[1]),
+                                       ctypes.c_int(R), _dev_ptr(out, torch.float32, "out"), _stream())
+    _check(rc, "gq_qsgd_wide_decode_sum")
 
 
 def axpy_inplace(grad, err, scale):

@@ -174,7 +174,7 @@ class HSQCodec(object):
 
 
 class QSGDCodec(object):
-    """QSGDCompressor on the HIP kernels.  Wire per user, packed form (even bucket size <= 65536 and a
+    """QSGDCompressor on the HIP kernels.  Wire per user, packed form (even bucket size and a
     top level that fits 3 or 7 bits):  norm f32[Mb] | one code per element = sign<<(bits-1) | level,
     4-bit codes two per byte.  Otherwise the plain form  norm f32[Mb] | signs u8[n] | levels u8|i32 [n]."""
 
@@ -183,7 +183,7 @@ class QSGDCodec(object):
         self.Mb, self.d = compressor.M, compressor.dim
         mode = native.RANDOM_DEVICE if compressor.random else native.RANDOM_OFF
         self.bits = 0
-        if self.d % 2 == 0 and self.d <= 65536 and (not compressor.random or compressor._rng == "device"):
+        if self.d % 2 == 0 and (not compressor.random or compressor._rng == "device"):
             top = 2 ** compressor.bit - (0 if compressor.random else 1)
             self.bits = 4 if top <= 7 else (8 if top <= 127 else 0)
         self.norm_off = 0
@@ -449,7 +449,11 @@ class BatchedHSQ(_BatchedBase):
 
 
 class BatchedQSGD(_BatchedBase):
-    """All packed-form QSGD tensors in ONE gq_qsgd_compress_batched / gq_qsgd_decode_sum_batched launch."""
+    """All packed-form QSGD tensors in ONE gq_qsgd_compress_batched / gq_qsgd_decode_sum_batched launch.
+    Tensors with WIDE buckets (TernGrad's `--c-dim 0`: the tensor is one bucket; any bucket above WIDE_MIN
+    elements) form their own group on the chunked kernels (gq_qsgd_wide_*: bucket norms, codes, decode)."""
+
+    WIDE_MIN = 4096
 
     @staticmethod
     def eligible(codec):
@@ -457,47 +461,59 @@ class BatchedQSGD(_BatchedBase):
 
     @staticmethod
     def group_key(codec):
-        return (codec.bits, codec.c.bit)
+        return (codec.bits, codec.c.bit, int(codec.d > BatchedQSGD.WIDE_MIN))
 
     def __init__(self, codecs, offsets, idxs, device, slots, user_bytes):
         self.idxs = list(idxs)
         self.codecs = [codecs[i] for i in self.idxs]
         c0 = self.codecs[0]
         self.n_bit, self.bits, self.random = c0.c.bit, c0.bits, bool(c0.c.random)
-        assert all(cd.bits == self.bits and cd.c.bit == self.n_bit for cd in self.codecs)
+        self.wide = c0.d > self.WIDE_MIN
+        assert all(cd.bits == self.bits and cd.c.bit == self.n_bit and (cd.d > self.WIDE_MIN) == self.wide
+                   for cd in self.codecs)
         nseg = len(self.idxs)
         table = torch.zeros((nseg, 8), dtype=torch.int64)
-        bucket_seg = []
-        bucket, out_off = 0, 0
+        item_seg = []
+        item, out_off, word = 0, 0, 0
         self.out_off = []
         for s, (i, cd) in enumerate(zip(self.idxs, self.codecs)):
-            table[s, 1], table[s, 2] = cd.d, bucket
+            # items: buckets, or (wide) chunks of native.QSGD_WIDE_CHUNK elements of a bucket
+            items = cd.Mb * (-(-cd.d // native.QSGD_WIDE_CHUNK)) if self.wide else cd.Mb
+            table[s, 1], table[s, 2] = cd.d, item
             table[s, 3] = offsets[i] + cd.norm_off
             table[s, 4] = offsets[i] + cd.codes_off
             table[s, 5] = out_off
-            table[s, 6] = cd.Mb
-            bucket_seg += [s] * cd.Mb
-            bucket += cd.Mb
+            table[s, 6] = word if self.wide else cd.Mb     # wide: the tensor's first word in norm_bits
+            item_seg += [s] * items
+            item += items
+            word += (cd.Mb + 31) & ~31 if self.wide else 0     # a tensor's norm words start on their own 128-byte line
             self.out_off.append(out_off)
             out_off += (cd.numel + 3) & ~3          # tensors start 16-byte aligned in `out` (dwordx4 stores)
-        self.nbuckets, self.out_floats = bucket, out_off
-        self.bucket_seg = torch.tensor(bucket_seg, dtype=torch.int32, device=device)
-        self._setup(table, None, device, slots, user_bytes)
+        self.nbuckets, self.out_floats = item, out_off
+        self.bucket_seg = torch.tensor(item_seg, dtype=torch.int32, device=device)
+        # wide: max |v| per bucket is folded into words that the per-step header resets to zero
+        extra = torch.zeros((word + 1) // 2, dtype=torch.int64) if self.wide else None
+        self._setup(table, extra, device, slots, user_bytes)
 
     def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None):
         """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place)."""
         if not self._upload(tensors, slot, 8, errs):
             return False
         mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
-        native.qsgd_compress_batched(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets,
-                                     self.n_bit, mode, (_next_seed() ^ salt) if self.random else 0, wire_user,
-                                     ef_scale=ef_scale if errs is not None else None)
+        seed = (_next_seed() ^ salt) if self.random else 0
+        ef = ef_scale if errs is not None else None
+        if self.wide:
+            native.qsgd_wide_compress(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets, self.n_bit,
+                                      mode, seed, self._dev[self._table_words:].view(torch.int32), wire_user, ef_scale=ef)
+        else:
+            native.qsgd_compress_batched(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets,
+                                         self.n_bit, mode, seed, wire_user, ef_scale=ef)
         return True
 
     def decode_mean(self, gathered, R):
         out, views = self._out_buffer(gathered.device)
-        native.qsgd_decode_sum_batched(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets,
-                                       self.n_bit, self.bits, gathered, out, R)
+        fn = native.qsgd_wide_decode_sum if self.wide else native.qsgd_decode_sum_batched
+        fn(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets, self.n_bit, self.bits, gathered, out, R)
         return views
 
 

@@ -288,6 +288,26 @@ int gq_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_s
                                int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                float *out, void *stream);
 
+/*
+ * The same packed wire for WIDE buckets -- the reference's TernGrad command (`--quantizer qsgd --c-dim 0
+ * --n-bit 1`: one bucket spans the tensor, qsgd_compressor.py:15-16) or any c_dim of a few thousand and more.
+ * The unit of work is a chunk of GQ_QSGD_WIDE_CHUNK consecutive elements of one bucket (the last chunk of a
+ * bucket may be shorter; d must be even): chunk_seg int32[nchunks] names the tensor of each chunk, ascending;
+ * seg_table int64[nseg][8] = { grad pointer (8-byte aligned), d, first chunk, byte offset of the norms / of the
+ * codes inside ONE user's wire, float offset of the tensor in `out`, first word of the tensor's buckets in
+ * norm_bits, error buffer (float*, 0 = none) }.  norm_bits (one uint32 per bucket; give every tensor its own
+ * 128-byte line: the words are targets of atomics) must be zero before each
+ * compress (max |v| is folded into it with integer atomics).  gq_qsgd_wide_compress = two launches (bucket
+ * norms, then codes); ef != 0: error feedback as in gq_qsgd_compress_batched_ef.
+ */
+#define GQ_QSGD_WIDE_CHUNK 1024
+int gq_qsgd_wide_compress(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks, int n_bit,
+                          int random_mode, uint64_t seed, int ef, float ef_scale, uint32_t *norm_bits, uint8_t *wire,
+                          void *stream);
+int gq_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks, int n_bit,
+                            int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R, float *out,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

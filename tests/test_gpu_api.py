@@ -434,7 +434,7 @@ def _run_qsgd(shapes, users, seed, **argkw):
     from gq_amd.compressors import QSGDCompressor
     from gq_amd.quantizers import Quantizer
     params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in shapes]
-    q = Quantizer(QSGDCompressor, params, make_args(num_users=users, c_dim=128, n_bit=2, **argkw))
+    q = Quantizer(QSGDCompressor, params, make_args(**dict(dict(num_users=users, c_dim=128, n_bit=2), **argkw)))
     g = torch.Generator(device="cuda").manual_seed(seed)
     for st in range(2):
         for u in range(users):
@@ -472,6 +472,61 @@ def test_batched_packed_qsgd_equals_per_tensor_and_reference_arithmetic(kw, orac
         norm, signs, levels = oracle.qsgd_compress(x.cpu().numpy(), 128, 2, 0)
         want = oracle.qsgd_decompress(norm, signs, levels, 128, 2).reshape(256, 128)
         assert np.array_equal(got, want)
+
+
+WIDE_SHAPES = [(64, 3, 3, 3), (128, 128, 3, 3), (1024,), (2048,), (512, 128, 1, 1), (9000,), (5, 1001, 2), (10,), (64,),
+               (2, 4099)]
+
+
+@pytest.mark.parametrize("kw", [dict(c_dim=0, n_bit=1), dict(c_dim=0, n_bit=1, random=1), dict(c_dim=0, n_bit=1, ef=True),
+                                dict(c_dim=0, n_bit=1, ef=True, two_phase=True, scale="0.5"), dict(c_dim=0, n_bit=5),
+                                dict(c_dim=4098, n_bit=2), dict(c_dim=8192, n_bit=2, ef=True)],
+                         ids=lambda k: "_".join("%s%s" % kv for kv in k.items()))
+def test_wide_bucket_qsgd_terngrad_equals_reference_arithmetic(kw, oracle):
+    """TernGrad (`--quantizer qsgd --c-dim 0 --n-bit 1`: the tensor is ONE bucket) and other wide buckets on the
+    chunked kernels: the multi-tensor launch == one launch per tensor, and -- deterministic rounding -- the aggregate
+    equals the mean of the oracle's decompress(compress(g)) per user, the residuals the oracle's g - decoded."""
+    users = 2
+    if kw["c_dim"]:
+        shapes = [(kw["c_dim"], 3), (kw["c_dim"] * 2,), (7, kw["c_dim"]), (10,)]
+    else:
+        shapes = WIDE_SHAPES
+    qb, gb = _run_qsgd(shapes, users, 5, **kw)
+    qp, gp = _run_qsgd(shapes, users, 5, gq_no_batch=True, **kw)
+    wide = [g for g in qb._groups if g[0].__name__ == "BatchedQSGD" and g[2] is not None and g[2].wide]
+    assert wide and wide[0][2].ready and not qp._groups
+    if kw.get("random"):
+        # the draws are indexed by (bucket, element) of the launch: the two layouts round differently, each within
+        # one level (max|v| / 2^n_bit) of the deterministic rounding
+        _, gd = _run_qsgd(shapes, users, 5, **dict(kw, random=0))
+        for a, b, d in zip(gb, gp, gd):
+            step = d.abs().max() * 1.0001 + 1e-12       # n_bit = 1, deterministic levels {0, 1}: max|decoded| = norm/2
+            assert (a - d).abs().max() <= step and (b - d).abs().max() <= step
+            assert a.numel() <= 1000 or not torch.equal(a, d)
+        return
+    for a, b in zip(gb, gp):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    if kw.get("ef"):
+        for pb, pp in zip(qb.parameters, qp.parameters):
+            for eb, ep in zip(pb.error, pp.error):
+                assert torch.equal(eb, ep)
+    if kw.get("ef") or kw.get("two_phase"):
+        return
+    # the same gradients as _run_qsgd's second step, through the oracle
+    g = torch.Generator(device="cuda").manual_seed(5)
+    grads = [[[torch.randn(s, device="cuda", generator=g) * 1e-2 for s in shapes] for _ in range(users)] for _ in range(2)][1]
+    for k, s in enumerate(shapes):
+        n = int(np.prod(s))
+        if n <= 1000:
+            continue
+        d = qb.codecs[k].d
+        dec = []
+        for u in range(users):
+            x = grads[u][k].cpu().numpy().reshape(-1)
+            norm, signs, levels = oracle.qsgd_compress(x, d, kw["n_bit"], 0)
+            dec.append(oracle.qsgd_decompress(norm, signs, levels, d, kw["n_bit"]).reshape(-1))
+        want = (torch.from_numpy(np.stack(dec)).sum(0) / users).numpy() if users > 1 else dec[0]
+        assert np.array_equal(gb[k].cpu().numpy().reshape(-1), want), s
 
 
 def test_probabilistic_vector_compressor_matches_oracle_and_is_unbiased(oracle):

@@ -56,3 +56,6 @@ run("HSQ main.py defaults per-tensor launches", NearestNeighborCompressor, c_dim
 run("HSQ d8 K32 batched (exact kernels)", NearestNeighborCompressor, c_dim=8, k_bit=5)
 run("HSQ d8 K32 per-tensor launches", NearestNeighborCompressor, c_dim=8, k_bit=5, gq_no_batch=True)
 run("HSQ d8 K32 batched, EF + two-phase", NearestNeighborCompressor, c_dim=8, k_bit=5, ef=True, two_phase=True)
+run("TernGrad (qsgd c-dim 0 n-bit 1) batched", QSGDCompressor, c_dim=0, n_bit=1)
+run("TernGrad per-tensor launches", QSGDCompressor, c_dim=0, n_bit=1, gq_no_batch=True)
+run("TernGrad batched, error feedback", QSGDCompressor, c_dim=0, n_bit=1, ef=True)
