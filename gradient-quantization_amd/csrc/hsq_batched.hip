@@ -38,7 +38,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
         const int64_t local = (tile - rec[2]) * 64 + 4 * (i & 15);
         if (local >= m) continue;
         const float lb = order_unmap_f(seg_minmax[2 * seg]), ub = order_unmap_f(seg_minmax[2 * seg + 1]);
-        if (local == 0) {
+        if (local == 0 && !std::is_same<LevelT, float>::value) {
             float *lbub = reinterpret_cast<float *>(wire + rec[5]);
             lbub[0] = lb;
             lbub[1] = ub;
@@ -49,6 +49,10 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
         LevelT out[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+            if constexpr (std::is_same<LevelT, float>::value) {   // n_bit == 32: the projections travel as they are
+                out[e] = uu[e];
+                continue;
+            }
             int l = 0;
             if (!flat) {
                 const float q = (uu[e] - lb) / range;
@@ -428,9 +432,12 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_any_kernel(
                 const uint8_t *p = gathered + (int64_t)r * user_stride;
                 const float *lbub = reinterpret_cast<const float *>(p + rec[5]);
                 const float lb = lbub[0], range = lbub[1] - lb;
-                float n = (float)reinterpret_cast<const LevelT *>(p + rec[4])[local] * range;   // prob_scalar:31-32, unfused
-                n = n * inv_s;
-                n = n + lb;
+                float n = (float)reinterpret_cast<const LevelT *>(p + rec[4])[local];
+                if constexpr (!std::is_same<LevelT, float>::value) {
+                    n = n * range;   // prob_scalar:31-32, unfused
+                    n = n * inv_s;
+                    n = n + lb;
+                }
                 const int64_t code = (int64_t)reinterpret_cast<const CodeT *>(p + rec[3])[local];
                 const vec_t c = *reinterpret_cast<const vec_t *>(cbp + code * d + VEC * q);
                 const vec_t dec = c * n;
@@ -475,8 +482,9 @@ template <bool ERR>
 static int decode_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                       const uint8_t *gathered, int64_t user_stride, int R, const float *cb, int d, int K,
                       int code_bytes, int level_bytes, int n_bit, float *out, void *stream, const char *what) {
-    if (nseg < 1 || ntiles < 1 || R < 1 || d < 1 || K < 1 || n_bit < 1 || n_bit > 30)
+    if (nseg < 1 || ntiles < 1 || R < 1 || d < 1 || K < 1 || n_bit < 1 || (n_bit > 30 && level_bytes != 0))
         return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes", what);
+    if (level_bytes == 0) n_bit = 1;   // f32 norms: no level scaling
     if (!seg_table || !tile_seg || !gathered || !cb || (!ERR && !out))
         return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
     hipStream_t st = as_stream(stream);
@@ -484,6 +492,8 @@ static int decode_any(const int64_t *seg_table, const int32_t *tile_seg, int nse
     if (code_bytes == CB && level_bytes == LB)                                                                      \
         return launch_decode_any<CT, LT, ERR>(seg_table, tile_seg, ntiles, gathered, user_stride, R, cb, d, K, n_bit, \
                                               out, st, what);
+    GQ_ANY_CASE(1, 0, uint8_t, float)
+    GQ_ANY_CASE(4, 0, int32_t, float)
     GQ_ANY_CASE(1, 1, uint8_t, uint8_t)
     GQ_ANY_CASE(1, 2, uint8_t, int16_t)
     GQ_ANY_CASE(1, 4, uint8_t, int32_t)
@@ -491,7 +501,7 @@ static int decode_any(const int64_t *seg_table, const int32_t *tile_seg, int nse
     GQ_ANY_CASE(4, 2, int32_t, int16_t)
     GQ_ANY_CASE(4, 4, int32_t, int32_t)
 #undef GQ_ANY_CASE
-    return fail(GQ_ERR_INVALID_ARG, "%s: code_bytes must be 1 or 4, level_bytes 1, 2 or 4", what);
+    return fail(GQ_ERR_INVALID_ARG, "%s: code_bytes must be 1 or 4, level_bytes 0 (f32 norms), 1, 2 or 4", what);
 }
 
 static inline int64_t bt_grid(int64_t items) {
@@ -628,12 +638,19 @@ GQ_API int gq_hsq_levels_batched_ef_d(const int64_t *seg_table, const int32_t *t
 GQ_API int gq_hsq_levels_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                      const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
                                      uint64_t seed, int level_bytes, uint8_t *wire, void *stream) {
-    if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > 30)
+    if (nseg < 1 || ntiles < 1 || n_bit < 1 || (n_bit > 30 && level_bytes != 0))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: bad sizes");
     if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !wire)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: null pointer");
     if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched_any: random_mode must be OFF or DEVICE");
+    if (level_bytes == 0) {   // n_bit == 32 (nearest_neighbor_compressor.py:14,75-76): u itself is the payload
+        hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<float>, dim3((unsigned)gq::bt_grid(ntiles * 16)),
+                           dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
+                           1, GQ_RANDOM_OFF, (uint64_t)0, wire);
+        GQ_CHECK_LAUNCH("gq_hsq_levels_batched_any");
+        return GQ_OK;
+    }
     const int64_t top = ((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0);
     if ((level_bytes == 1 && top > 255) || (level_bytes == 2 && top > 32767))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: levels up to %lld do not fit %d byte(s)",

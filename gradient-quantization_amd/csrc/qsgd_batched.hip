@@ -2,7 +2,7 @@
 //
 // Same arithmetic as qsgd.hip (which mirrors the reference's signature: f32 norm per bucket,
 // bool signs, int32 levels -- qsgd_compressor.py:42-71), but what is WRITTEN is a real wire format:
-//     norm f32[buckets] | one code per element = sign<<(bits-1) | level ,  bits = 4 (n_bit <= 2) or 8 (n_bit <= 6)
+//     norm f32[buckets] | one code per element = sign<<(bits-1) | level ,  bits = 4 (n_bit <= 2), 8 (n_bit <= 6) or 16
 // 4-bit codes are packed two per byte (element 2i in the low nibble).  ResNet-50 with c_dim=128,
 // n_bit=2: 0.53 B per gradient element instead of the 2 B of separate sign / level arrays.
 // One launch serves every tensor of a model: bucket_seg[bucket] names its tensor and
@@ -71,15 +71,17 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
         mx = wave_max(mx);
         if (lane == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = mx;
         const uint64_t g0 = (uint64_t)b << 20;  // RNG stream index: unique per (bucket, element)
-        uint8_t *dst = wire + rec[4] + (bits == 4 ? ((lb * d) >> 1) : lb * d);
+        uint8_t *dst = wire + rec[4] + ((lb * d * bits) >> 3);
         for (int e = 2 * lane; e < d; e += 128) {
             const float2 p = load(e);
             const unsigned c0 = qsgd_code(p.x, mx, s, smax, random_mode, seed, g0 + e, bits);
             const unsigned c1 = qsgd_code(p.y, mx, s, smax, random_mode, seed, g0 + e + 1, bits);
             if (bits == 4) {
                 dst[e >> 1] = (uint8_t)(c0 | (c1 << 4));
-            } else {
+            } else if (bits == 8) {
                 *reinterpret_cast<uchar2 *>(dst + e) = make_uchar2((uint8_t)c0, (uint8_t)c1);
+            } else {
+                *reinterpret_cast<unsigned *>(dst + 2 * e) = c0 | (c1 << 16);
             }
             if (EF && err) {
                 // qsgd_compressor.py:69-70 on this element's own code, then ps_quantizer.py:39
@@ -269,10 +271,14 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched_kernel(
                     const unsigned byte = p[rec[4] + ((lb * d + e) >> 1)];
                     c0 = byte & 15u;
                     c1 = byte >> 4;
-                } else {
+                } else if (bits == 8) {
                     const uchar2 cc = *reinterpret_cast<const uchar2 *>(p + rec[4] + lb * d + e);
                     c0 = cc.x;
                     c1 = cc.y;
+                } else {
+                    const unsigned cc = *reinterpret_cast<const unsigned *>(p + rec[4] + 2 * (lb * d + e));
+                    c0 = cc & 0xFFFFu;
+                    c1 = cc >> 16;
                 }
                 // qsgd_compressor.py:69-70: (l * (2*signs - 1)) * norm / s
                 float t0 = (float)(c0 & lmask) * (2.0f * (float)(c0 >> (bits - 1)) - 1.0f);
@@ -388,6 +394,7 @@ GQ_API int gq_qsgd_code_bits(int n_bit, int random_mode) {
     const int top = (1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0);
     if (top <= 7) return 4;
     if (top <= 127) return 8;
+    if (top <= 32767) return 16;   // e.g. 8-bit QSGD with stochastic rounding (level 256)
     return 0;  // no packed format: use gq_qsgd_compress / gq_qsgd_decode_sum
 }
 
@@ -436,7 +443,7 @@ GQ_API int gq_qsgd_compress_batched_ef(const int64_t *seg_table, const int32_t *
 GQ_API int gq_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
                                       int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                       float *out, void *stream) {
-    if (nseg < 1 || nbuckets < 1 || n_bit < 1 || R < 1 || (bits != 4 && bits != 8))
+    if (nseg < 1 || nbuckets < 1 || n_bit < 1 || R < 1 || (bits != 4 && bits != 8 && bits != 16))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: bad sizes");
     if (!seg_table || !bucket_seg || !gathered || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: null pointer");

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_quantise_kernel(
         float *err = (EF && it.rec[7]) ? reinterpret_cast<float *>(it.rec[7]) + at : nullptr;
         const float norm = __uint_as_float(norm_bits[it.rec[6] + it.b]);
         if (it.first == 0 && lane == 0) reinterpret_cast<float *>(wire + it.rec[3])[it.b] = norm;
-        uint8_t *dst = wire + it.rec[4] + (BITS == 4 ? (at >> 1) : at);
+        uint8_t *dst = wire + it.rec[4] + ((at * BITS) >> 3);
         const bool dwords = ((at & 7) == 0);                       // code dwords of whole 8-element groups are aligned
         const uint64_t g0 = ((uint64_t)(it.rec[6] + it.b) << 32) + (uint64_t)it.first;   // RNG index: (bucket, element)
 #pragma unroll
@@ -172,6 +172,16 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_quantise_kernel(
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (e0 + 2 * k < it.n) dst[(e0 >> 1) + k] = (uint8_t)(code[2 * k] | (code[2 * k + 1] << 4));
+                }
+            } else if (BITS == 16) {
+                if (whole && dwords) {
+                    *reinterpret_cast<uint4 *>(dst + 2 * e0) = make_uint4(code[0] | (code[1] << 16), code[2] | (code[3] << 16),
+                                                                          code[4] | (code[5] << 16), code[6] | (code[7] << 16));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (e0 + 2 * k < it.n)
+                            *reinterpret_cast<unsigned *>(dst + 2 * (e0 + 2 * k)) = code[2 * k] | (code[2 * k + 1] << 16);
                 }
             } else {
                 if (whole && dwords) {
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_decode_kernel(const int6
         const WideItem it = wide_item(seg_table, chunk_seg, c);
         const int64_t at = it.b * it.d + it.first;
         float *o = out + it.rec[5] + at;
-        const int64_t code_off = it.rec[4] + (BITS == 4 ? (at >> 1) : at);
+        const int64_t code_off = it.rec[4] + ((at * BITS) >> 3);
         const bool dwords = ((at & 7) == 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -248,6 +258,14 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_decode_kernel(const int6
                     }
 #pragma unroll
                     for (int k = 0; k < 8; ++k) code[k] = (w >> (4 * k)) & 15u;
+                } else if (BITS == 16) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned cc = (e0 + 2 * k < it.n)
+                                                ? *reinterpret_cast<const unsigned *>(p + code_off + 2 * (e0 + 2 * k)) : 0u;
+                        code[2 * k] = cc & 0xFFFFu;
+                        code[2 * k + 1] = cc >> 16;
+                    }
                 } else {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) code[k] = (e0 + k < it.n) ? (unsigned)p[code_off + e0 + k] : 0u;
@@ -309,9 +327,11 @@ GQ_API int gq_qsgd_wide_compress(const int64_t *seg_table, const int32_t *chunk_
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gq::qsgd_wide_quantise_kernel<EFV, BITSV>), grid, block, 0, st, seg_table, chunk_seg, \
                        nchunks, n_bit, random_mode, seed, norm_bits, wire)
     if (ef && bits == 4) GQ_QW_LAUNCH(true, 4);
-    else if (ef) GQ_QW_LAUNCH(true, 8);
+    else if (ef && bits == 8) GQ_QW_LAUNCH(true, 8);
+    else if (ef) GQ_QW_LAUNCH(true, 16);
     else if (bits == 4) GQ_QW_LAUNCH(false, 4);
-    else GQ_QW_LAUNCH(false, 8);
+    else if (bits == 8) GQ_QW_LAUNCH(false, 8);
+    else GQ_QW_LAUNCH(false, 16);
 #undef GQ_QW_LAUNCH
     GQ_CHECK_LAUNCH("gq_qsgd_wide_compress");
     return GQ_OK;
@@ -320,7 +340,7 @@ GQ_API int gq_qsgd_wide_compress(const int64_t *seg_table, const int32_t *chunk_
 GQ_API int gq_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks,
                                    int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                    float *out, void *stream) {
-    if (nseg < 1 || nchunks < 1 || n_bit < 1 || R < 1 || (bits != 4 && bits != 8))
+    if (nseg < 1 || nchunks < 1 || n_bit < 1 || R < 1 || (bits != 4 && bits != 8 && bits != 16))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_wide_decode_sum: bad sizes");
     if (!seg_table || !chunk_seg || !gathered || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_wide_decode_sum: null pointer");
@@ -330,6 +350,9 @@ GQ_API int gq_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chun
     const dim3 grid((unsigned)gq::qw_grid(nchunks)), block(gq::QW_THREADS);
     if (bits == 4)
         hipLaunchKernelGGL(gq::qsgd_wide_decode_kernel<4>, grid, block, 0, gq::as_stream(stream), seg_table, chunk_seg,
+                           nchunks, n_bit, gathered, user_stride_bytes, R, out);
+    else if (bits == 16)
+        hipLaunchKernelGGL(gq::qsgd_wide_decode_kernel<16>, grid, block, 0, gq::as_stream(stream), seg_table, chunk_seg,
                            nchunks, n_bit, gathered, user_stride_bytes, R, out);
     else
         hipLaunchKernelGGL(gq::qsgd_wide_decode_kernel<8>, grid, block, 0, gq::as_stream(stream), seg_table, chunk_seg,

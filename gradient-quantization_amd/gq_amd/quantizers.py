@@ -175,7 +175,7 @@ class HSQCodec(object):
 
 class QSGDCodec(object):
     """QSGDCompressor on the HIP kernels.  Wire per user, packed form (even bucket size and a
-    top level that fits 3 or 7 bits):  norm f32[Mb] | one code per element = sign<<(bits-1) | level,
+    top level that fits 3, 7 or 15 bits):  norm f32[Mb] | one code per element = sign<<(bits-1) | level,
     4-bit codes two per byte.  Otherwise the plain form  norm f32[Mb] | signs u8[n] | levels u8|i32 [n]."""
 
     def __init__(self, compressor, numel, shape):
@@ -185,7 +185,7 @@ class QSGDCodec(object):
         self.bits = 0
         if self.d % 2 == 0 and (not compressor.random or compressor._rng == "device"):
             top = 2 ** compressor.bit - (0 if compressor.random else 1)
-            self.bits = 4 if top <= 7 else (8 if top <= 127 else 0)
+            self.bits = 4 if top <= 7 else (8 if top <= 127 else (16 if top <= 32767 else 0))
         self.norm_off = 0
         if self.bits:
             self.codes_off = _up(self.Mb * 4)
@@ -359,21 +359,22 @@ class BatchedHSQ(_BatchedBase):
     @staticmethod
     def eligible(codec):
         c = getattr(codec, "c", None)
-        if type(codec) is not HSQCodec or not c.compressed_norm or c.K == c.dim:   # K == d: a random codebook per tensor
+        if type(codec) is not HSQCodec or c.K == c.dim:   # K == d: a random codebook per tensor
             return False
-        if c.norm_compressor.random and c.norm_compressor._rng != "device":
+        if c.compressed_norm and c.norm_compressor.random and c.norm_compressor._rng != "device":
             return False
         return BatchedHSQ._prefilter(codec) or native.hsq_batched_any_supported(c.dim, c.K)
 
     @staticmethod
     def group_key(codec):
-        return (codec.c.dim, codec.c.K, _esize(codec.code_dtype), _esize(codec.level_dtype))
+        return (codec.c.dim, codec.c.K, _esize(codec.code_dtype), _esize(codec.level_dtype), int(codec.c.n_bit))
 
     def __init__(self, codecs, offsets, idxs, device, slots, user_bytes):
         self.idxs = list(idxs)
         self.codecs = [codecs[i] for i in self.idxs]
         c0 = self.codecs[0].c
-        self.n_bit, self.random = c0.n_bit, bool(c0.norm_compressor.random)
+        self.n_bit = c0.n_bit                                  # 32: the projections travel as f32 (no level quantiser)
+        self.random = bool(c0.compressed_norm and c0.norm_compressor.random)
         self.codebook = c0._codebook_on(device)
         nseg = len(self.idxs)
         table = torch.zeros((nseg, 8), dtype=torch.int64)

@@ -269,7 +269,8 @@ int gq_pvq_encode(const float *grad, const float *c_dagger, int64_t M, int d, in
  * QSGD on a packed wire, multi-tensor form (one launch for all tensors; same arithmetic as
  * gq_qsgd_compress / gq_qsgd_decode_sum).  Per element one code = sign<<(bits-1) | level with
  * bits = gq_qsgd_code_bits(n_bit, random_mode): 4 (two codes per byte, element 2i in the low nibble)
- * when the top level is <= 7, 8 when it is <= 127, 0 = no packed format.  Buckets are numbered across
+ * when the top level is <= 7, 8 when it is <= 127, 16 (little-endian) when it is <= 32767, 0 = no packed
+ * format.  Buckets are numbered across
  * tensors: bucket_seg int32[nbuckets]; seg_table int64[nseg][8] = { grad pointer (8-byte aligned),
  * d (even, <= 65536), first bucket, byte offset of the f32 norms / of the codes inside ONE user's wire,
  * float offset of the tensor in `out` (a multiple of 4), buckets, reserved }.  A zero bucket is written as level 0

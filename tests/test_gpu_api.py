@@ -292,7 +292,9 @@ ANY_CASES = [dict(c_dim=32, k_bit=8, n_bit=9),     # prefilter encode, 16-bit le
              dict(c_dim=24, k_bit=6, n_bit=4),
              dict(c_dim=8, k_bit=5, n_bit=8),
              dict(c_dim=10, k_bit=5, n_bit=6),     # d % 4 != 0: scalar loads / stores
-             dict(c_dim=48, k_bit=11, n_bit=17)]   # 384 KiB codebook (chunked in LDS), int32 codes and levels
+             dict(c_dim=48, k_bit=11, n_bit=17),   # 384 KiB codebook (chunked in LDS), int32 codes and levels
+             dict(c_dim=16, k_bit=8, n_bit=32),    # uncompressed norms: the projections travel as f32
+             dict(c_dim=24, k_bit=6, n_bit=32)]
 
 
 @pytest.mark.parametrize("case", ANY_CASES, ids=lambda c: "d%d_k%d_n%d" % (c["c_dim"], c["k_bit"], c["n_bit"]))
@@ -445,6 +447,35 @@ def _run_qsgd(shapes, users, seed, **argkw):
     return q, [p.grad.data.clone() for p in params]
 
 
+@pytest.mark.parametrize("kw", [dict(n_bit=8), dict(n_bit=8, c_dim=512, ef=True), dict(n_bit=5)])
+def test_batched_packed_qsgd_wider_codes(kw, oracle):
+    """8- and 16-bit packed codes (e.g. the usual "8-bit QSGD"): batched launch == per-tensor path and, for the
+    deterministic rounding, the mean of the oracle's decompress(compress(g))."""
+    shapes = RESNET50_COMPRESSED[:10] + RESNET50_SMALL[:3]
+    qb, gb = _run_qsgd(shapes, 2, 5, **kw)
+    qp, gp = _run_qsgd(shapes, 2, 5, gq_no_batch=True, **kw)
+    assert qb._groups and qb._groups[0][2].ready and qb.codecs[0].bits == (16 if kw["n_bit"] == 8 else 8)
+    for a, b in zip(gb, gp):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    if kw.get("ef"):
+        for pb, pp in zip(qb.parameters, qp.parameters):
+            for eb, ep in zip(pb.error, pp.error):
+                assert torch.equal(eb, ep)
+        return
+    g = torch.Generator(device="cuda").manual_seed(5)
+    grads = [[[torch.randn(s, device="cuda", generator=g) * 1e-2 for s in shapes] for _ in range(2)] for _ in range(2)][1]
+    for k, s in enumerate(shapes):
+        if int(np.prod(s)) <= 1000:
+            continue
+        d = qb.codecs[k].d
+        dec = []
+        for u in range(2):
+            norm, signs, levels = oracle.qsgd_compress(grads[u][k].cpu().numpy().reshape(-1), d, kw["n_bit"], 0)
+            dec.append(oracle.qsgd_decompress(norm, signs, levels, d, kw["n_bit"]).reshape(-1))
+        want = (torch.from_numpy(np.stack(dec)).sum(0) / 2).numpy()
+        assert np.array_equal(gb[k].cpu().numpy().reshape(-1), want), s
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(ef=True), dict(two_phase=True)])
 def test_batched_packed_qsgd_equals_per_tensor_and_reference_arithmetic(kw, oracle):
     """QSGD on the packed 4-bit wire: batched launch == per-tensor path, and the single-user decode
@@ -480,7 +511,8 @@ WIDE_SHAPES = [(64, 3, 3, 3), (128, 128, 3, 3), (1024,), (2048,), (512, 128, 1, 
 
 @pytest.mark.parametrize("kw", [dict(c_dim=0, n_bit=1), dict(c_dim=0, n_bit=1, random=1), dict(c_dim=0, n_bit=1, ef=True),
                                 dict(c_dim=0, n_bit=1, ef=True, two_phase=True, scale="0.5"), dict(c_dim=0, n_bit=5),
-                                dict(c_dim=4098, n_bit=2), dict(c_dim=8192, n_bit=2, ef=True)],
+                                dict(c_dim=4098, n_bit=2), dict(c_dim=8192, n_bit=2, ef=True), dict(c_dim=0, n_bit=8),
+                                dict(c_dim=4098, n_bit=9, ef=True)],
                          ids=lambda k: "_".join("%s%s" % kv for kv in k.items()))
 def test_wide_bucket_qsgd_terngrad_equals_reference_arithmetic(kw, oracle):
     """TernGrad (`--quantizer qsgd --c-dim 0 --n-bit 1`: the tensor is ONE bucket) and other wide buckets on the
