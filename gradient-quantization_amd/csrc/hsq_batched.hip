@@ -558,7 +558,7 @@ GQ_API int gq_hsq_decode_sum_batched(const int64_t *seg_table, const int32_t *ti
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: null pointer");
     if ((user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0) {
         static const int bpc = [] {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(gq::hsq_decode_sum_batched4_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gq::hsq_decode_sum_batched4_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
             (void)hipGetLastError();
             int n = 0;

@@ -229,7 +229,7 @@ static int launch_decode(const CodeT *codes, const LevelT *levels, const float *
             const int64_t total = ((M + 3) >> 2) * 4;
             const size_t lds = (size_t)K * 64 * sizeof(float);   // four copies of every row
             static const int bpc = [] {
-                hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_d16u8_kernel),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_d16u8_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
                 (void)hipGetLastError();
                 int n = 0;

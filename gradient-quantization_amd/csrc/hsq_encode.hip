@@ -17,6 +17,7 @@
 //   valu     one subvector per lane, codebook broadcast from LDS, __fmaf_rn chain,
 //            wave-level min/max by shuffles; kept as the cross-check of the MFMA path.
 #include "hsq_encode_common.hpp"
+#include <type_traits>
 
 namespace gq {
 
@@ -557,7 +558,20 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
     size_t lds_bytes = 0;
     const bool lds_ok = lds_plan(d, K, &dpad, &chunk_rows, &lds_bytes);
     const bool pf_ok = K == 256 && (d == 8 || d == 16 || d == 32) && (reinterpret_cast<uintptr_t>(grad) & 15) == 0;
-    if (impl == 0) impl = pf_ok ? 4 : (lds_ok ? 5 : 2);
+    // larger codebooks of the d = 16 family: the prefilter kernel once per page of 256 codewords
+    const bool paged_ok = std::is_same<CodeT, int32_t>::value && (d == 8 || d == 16 || d == 32) && K > 256 &&
+                          (K & 255) == 0 && (reinterpret_cast<uintptr_t>(grad) & 15) == 0;
+    if (impl == 0) impl = (pf_ok || paged_ok) ? 4 : (lds_ok ? 5 : 2);
+    if (impl == 4 && K > 256) {
+        if constexpr (std::is_same<CodeT, int32_t>::value) {
+            if (!paged_ok)
+                return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 4 with K > 256 needs d in {8, 16, 32}, K %% 256 == 0, aligned grad");
+            if (d != 16) return launch_encode_pfd_paged(grad, codebook, M, d, K, codes, u, partials, st);
+            return launch_encode_pf_paged(grad, codebook, M, K, codes, u, partials, st);
+        } else {
+            return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: K > 256 needs int32 codes");
+        }
+    }
     if (impl == 4 && K == 256 && (d == 8 || d == 32)) {
         if (!pf_ok) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: grad must be 16-byte aligned");
         return launch_encode_pfd<CodeT>(grad, codebook, M, d, codes, u, partials, st);
@@ -566,7 +580,7 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
         if (!lds_ok) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: impl 5 needs d <= 128 (d=%d K=%d)", d, K);
         static bool attr_set = false;
         if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_lds_kernel<CodeT>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_lds_kernel<CodeT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipGetLastError();
             attr_set = true;

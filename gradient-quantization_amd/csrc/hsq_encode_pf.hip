@@ -63,12 +63,18 @@ struct PfArgs {
     int64_t ntiles;
     int nseg;                 // batched: segments in seg_table
     float ef_scale;           // EF kernels: grad <- grad + ef_scale * error (error pointer = seg_table[seg][7], 0 = none)
+    int code_base;            // PAGED: index of this page's first codeword (a multiple of 256)
+    int merge;                // PAGED: keep the (code, u) already in the output unless this page beats it
+    int last_page;            // PAGED: this launch produces the final projections (fold their min / max)
 };
 
 // SEGLDS (batched only): the segment records are read from their LDS copy (nseg <= PF_LDS_SEGS) or, for
 // longer tensor lists, from global memory -- as two instantiations, because a run-time choice between
 // the two sources turns the record pointer into a flat pointer (see tile_info).
-template <typename CodeT, bool BATCHED, bool EF = false, bool SEGLDS = true>
+// PAGED (single tensor, K a multiple of 256 above 256): one launch per page of 256 codewords, a.cb = the page; a
+// page's winner is exact, so max |u| over the pages -- an earlier page keeps a tie: the first maximum -- is the
+// exact argmax over the whole codebook.  The merge reads the (code, u) the previous pages left in the output.
+template <typename CodeT, bool BATCHED, bool EF = false, bool SEGLDS = true, bool PAGED = false>
 __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfArgs a) {
     const float *__restrict__ cb = a.cb;
     float *__restrict__ ws = a.ws;
@@ -313,6 +319,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             flush_minmax();
             cur_seg = ti.seg;
         }
+        // PAGED: what the earlier pages left for this lane's subvector, requested a whole tile before its use
+        float prev_u = 0.0f;
+        int prev_idx = 0;
+        if (PAGED && a.merge && ti.sv0 + lane < ti.m) {
+            prev_u = u[BATCHED ? t * 64 + lane : ti.sv0 + lane];
+            prev_idx = (int)ti.codes[ti.sv0 + lane];
+        }
 
         // ---- prefilter: 16 (block, row block) chains; top-2 GROUP keys per (block, row-block half) ----
         // The three MFMAs of chain c+1 depend on each other and issue is in order, so they are
@@ -490,11 +503,20 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             }
         }
 
+        if (PAGED && valid) {
+            idx += a.code_base;
+            if (a.merge && !(fabsf(val) > fabsf(prev_u))) {   // strict: ties stay with the earlier page
+                val = prev_u;
+                idx = prev_idx;
+            }
+        }
         if (valid) {
             ti.codes[sv] = (CodeT)idx;
             u[gsv] = val;
-            lmin = fminf(lmin, val);
-            lmax = fmaxf(lmax, val);
+            if (!PAGED || a.last_page) {   // (min,max) of the FINAL projections only: earlier pages' values may be replaced
+                lmin = fminf(lmin, val);
+                lmax = fmaxf(lmax, val);
+            }
         }
         ti = tin;
         t = tn;
@@ -541,6 +563,30 @@ int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT 
     return GQ_OK;
 }
 
+// K = 256 * pages, d = 16: one launch per page (see PAGED)
+int launch_encode_pf_paged(const float *grad, const float *codebook, int64_t M, int K, int32_t *codes, float *u, float *ws,
+                           hipStream_t st) {
+    if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<int32_t, false, false, true, true>, PF_THREADS, 0);
+    const int64_t blocks = pf16_grid((M + 63) / 64, bpc);
+    for (int page = 0; page * 256 < K; ++page) {
+        PfArgs a = {};
+        a.grad = grad;
+        a.M = M;
+        a.codes = codes;
+        a.u = u;
+        a.cb = codebook + (size_t)page * 256 * 16;
+        a.ws = ws;
+        a.code_base = page * 256;
+        a.merge = page > 0;
+        a.last_page = (page + 1) * 256 >= K;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<int32_t, false, false, true, true>), dim3((unsigned)blocks),
+                           dim3(PF_THREADS), 0, st, a);
+    }
+    GQ_CHECK_LAUNCH("gq_hsq_encode (paged prefilter)");
+    return GQ_OK;
+}
+
 template int launch_encode_pf<uint8_t>(const float *, const float *, int64_t, uint8_t *, float *, float *, hipStream_t);
 template int launch_encode_pf<int32_t>(const float *, const float *, int64_t, int32_t *, float *, float *, hipStream_t);
 
@@ -581,6 +627,65 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
     return GQ_OK;
 }
 }  // namespace gq
+
+namespace gq {
+int launch_pfd_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                             const float *codebook, int d, int K, int ef, float ef_scale, uint8_t *wire, float *u_flat,
+                             uint32_t *seg_minmax, float *ws, hipStream_t st);   // hsq_encode_pfd.hip
+
+// multi-tensor, K = 256 * pages, int32 codes: one launch per page (PAGED); error feedback rides in page 0
+static int encode_batched_paged16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                  const float *codebook, int K, int ef, float ef_scale, uint8_t *wire, float *u_flat,
+                                  uint32_t *seg_minmax, float *workspace, hipStream_t st) {
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<int32_t, true, true, true, true>, PF_THREADS, 0);
+    const int64_t blocks = pf16_grid(ntiles, bpc);
+    for (int page = 0; page * 256 < K; ++page) {
+        PfArgs a = {};
+        a.M = ntiles * 64;
+        a.u = u_flat;
+        a.cb = codebook + (size_t)page * 256 * 16;
+        a.ws = workspace;
+        a.seg_table = seg_table;
+        a.tile_seg = tile_seg;
+        a.wire = wire;
+        a.seg_minmax = seg_minmax;
+        a.ntiles = ntiles;
+        a.nseg = nseg;
+        a.ef_scale = ef_scale;
+        a.code_base = page * 256;
+        a.merge = page > 0;
+        a.last_page = (page + 1) * 256 >= K;
+        if (ef && page == 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<int32_t, true, true, true, true>), dim3((unsigned)blocks),
+                               dim3(PF_THREADS), 0, st, a);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<int32_t, true, false, true, true>), dim3((unsigned)blocks),
+                               dim3(PF_THREADS), 0, st, a);
+    }
+    GQ_CHECK_LAUNCH("gq_hsq_encode_batched_paged");
+    return GQ_OK;
+}
+}  // namespace gq
+
+GQ_API int gq_hsq_encode_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                       const float *codebook, int d, int K, int ef, float ef_scale, uint8_t *wire,
+                                       float *u_flat, uint32_t *seg_minmax, float *workspace, void *stream) {
+    if (nseg < 1 || ntiles < 1 || ntiles * 64 > 0x7FFFFFFFLL)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_paged: bad sizes nseg=%d ntiles=%lld", nseg,
+                        (long long)ntiles);
+    if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_paged: null pointer");
+    if ((d != 8 && d != 16 && d != 32) || K <= 256 || (K & 255) != 0 || K > 65536)
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched_paged: d must be 8, 16 or 32 and K a multiple of 256 above 256");
+    if (nseg > (d == 16 ? gq::PF_LDS_SEGS : 384))
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched_paged: at most 384 tensors per launch");
+    hipStream_t st = gq::as_stream(stream);
+    if (d == 16)
+        return gq::encode_batched_paged16(seg_table, tile_seg, nseg, ntiles, codebook, K, ef, ef_scale, wire, u_flat,
+                                          seg_minmax, workspace, st);
+    return gq::launch_pfd_batched_paged(seg_table, tile_seg, nseg, ntiles, codebook, d, K, ef, ef_scale, wire, u_flat,
+                                        seg_minmax, workspace, st);
+}
 
 GQ_API int gq_hsq_encode_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                  const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax,

@@ -31,6 +31,9 @@ struct PfdArgs {
     int64_t ntiles;
     int nseg;
     float ef_scale;   // EF form: grad <- grad + ef_scale * error (error pointer = seg_table[seg][7], 0 = none)
+    int code_base;    // PAGED (hsq_encode_pf.hip): index of this page's first codeword, and whether to keep
+    int merge;        // the (code, u) already in the output unless this page beats it
+    int last_page;    // PAGED: this launch produces the final projections (fold their min / max)
 };
 
 constexpr int PFD_LDS_SEGS = 384;   // batched form: segment records kept in LDS (24 KiB); longer lists are refused
@@ -45,7 +48,7 @@ constexpr int PFD_LDS_SEGS = 384;   // batched form: segment records kept in LDS
 // EF (batched only): error feedback folded into the load, as in hsq_encode_pf.hip -- the tile is read as
 // v = grad + ef_scale * error (product rounded, then the add), v is written back over grad, and the level
 // kernel (gq_hsq_levels_batched_ef_d) later writes error = v - decoded.
-template <typename CodeT, int D, bool BATCHED = false, bool EF = false>
+template <typename CodeT, int D, bool BATCHED = false, bool EF = false, bool PAGED = false>
 __global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kernel(const PfdArgs a) {
     // one workgroup per CU: 8 waves (two per SIMD) for D = 8, 4 waves (one per SIMD) for D = 32; the waves share the
     // workgroup's contiguous run of tiles through an LDS counter (hsq_encode_pf.hip)
@@ -280,6 +283,13 @@ __global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kern
             flush_minmax();
             cur_seg = ti.seg;
         }
+        // PAGED: what the earlier pages left for this lane's subvector, requested a whole tile before its use
+        float prev_u = 0.0f;
+        int prev_idx = 0;
+        if (PAGED && a.merge && ti.sv0 + lane < ti.m) {
+            prev_u = u[BATCHED ? t * 64 + lane : ti.sv0 + lane];
+            prev_idx = (int)ti.codes[ti.sv0 + lane];
+        }
 
         // ---- prefilter: 16 chains in the order (rb, block 0), (rb, block 1); top-2 GROUP keys per
         // (block, row-block half).  The MFMAs of chain c+1 sit between the key operations of chain c.
@@ -460,11 +470,20 @@ __global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kern
             }
         }
 
+        if (PAGED && valid) {
+            idx += a.code_base;
+            if (a.merge && !(fabsf(val) > fabsf(prev_u))) {   // strict: ties stay with the earlier page
+                val = prev_u;
+                idx = prev_idx;
+            }
+        }
         if (valid) {
             ti.codes[sv] = (CodeT)idx;
             u[gsv] = val;
-            lmin = fminf(lmin, val);
-            lmax = fmaxf(lmax, val);
+            if (!PAGED || a.last_page) {   // (min,max) of the FINAL projections only: earlier pages' values may be replaced
+                lmin = fminf(lmin, val);
+                lmax = fmaxf(lmax, val);
+            }
         }
         ti = tin;
         t = tn;
@@ -492,7 +511,7 @@ static int launch_pfd(const float *grad, const float *codebook, int64_t M, CodeT
     constexpr int WAVES = D == 32 ? 4 : 8, THREADS = WAVES * 64;
     constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
     static const int bpc = [] {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<CodeT, D>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<CodeT, D>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
         return resident_blocks_per_cu(hsq_encode_pfd_kernel<CodeT, D>, THREADS, lds);
@@ -512,6 +531,46 @@ static int launch_pfd(const float *grad, const float *codebook, int64_t M, CodeT
     return GQ_OK;
 }
 
+// K = 256 * pages: one launch per page of 256 codewords, merged in place (PAGED, hsq_encode_pf.hip)
+template <int D>
+static int launch_pfd_paged(const float *grad, const float *codebook, int64_t M, int K, int32_t *codes, float *u, float *ws,
+                            hipStream_t st) {
+    constexpr int KS = D > 16 ? D / 16 : 1;
+    constexpr int WAVES = D == 32 ? 4 : 8, THREADS = WAVES * 64;
+    constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
+    auto kernel = hsq_encode_pfd_kernel<int32_t, D, false, false, true>;
+    static const int bpc = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<int32_t, D, false, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipGetLastError();
+        return resident_blocks_per_cu(hsq_encode_pfd_kernel<int32_t, D, false, false, true>, THREADS, lds);
+    }();
+    const int64_t blocks = pfd_grid((M + 63) / 64, bpc, WAVES);
+    for (int page = 0; page * 256 < K; ++page) {
+        PfdArgs a = {};
+        a.grad = grad;
+        a.M = M;
+        a.codes = codes;
+        a.u = u;
+        a.cb = codebook + (size_t)page * 256 * D;
+        a.ws = ws;
+        a.code_base = page * 256;
+        a.merge = page > 0;
+        a.last_page = (page + 1) * 256 >= K;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, st, a);
+    }
+    GQ_CHECK_LAUNCH("gq_hsq_encode (paged prefilter, d = 8 / 32)");
+    return GQ_OK;
+}
+
+int launch_encode_pfd_paged(const float *grad, const float *codebook, int64_t M, int d, int K, int32_t *codes, float *u,
+                            float *ws, hipStream_t st) {
+    if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
+    if (d == 8) return launch_pfd_paged<8>(grad, codebook, M, K, codes, u, ws, st);
+    if (d == 32) return launch_pfd_paged<32>(grad, codebook, M, K, codes, u, ws, st);
+    return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: the d = 8 / 32 prefilter kernel was asked for d = %d", d);
+}
+
 template <typename CodeT>
 int launch_encode_pfd(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u, float *ws,
                       hipStream_t st) {
@@ -526,6 +585,57 @@ template int launch_encode_pfd<uint8_t>(const float *, const float *, int64_t, i
 template int launch_encode_pfd<int32_t>(const float *, const float *, int64_t, int, int32_t *, float *, float *,
                                         hipStream_t);
 
+template <int D>
+static int pfd_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                             const float *codebook, int K, int ef, float ef_scale, uint8_t *wire, float *u_flat,
+                             uint32_t *seg_minmax, float *ws, hipStream_t st) {
+    constexpr int KS = D > 16 ? D / 16 : 1;
+    constexpr int WAVES = D == 32 ? 4 : 8, THREADS = WAVES * 64;
+    constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
+    static const int bpc = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<int32_t, D, true, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<int32_t, D, true, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipGetLastError();
+        return resident_blocks_per_cu(hsq_encode_pfd_kernel<int32_t, D, true, true, true>, THREADS, lds);
+    }();
+    const int64_t blocks = pfd_grid(ntiles, bpc, WAVES);
+    for (int page = 0; page * 256 < K; ++page) {
+        PfdArgs a = {};
+        a.M = ntiles * 64;
+        a.u = u_flat;
+        a.cb = codebook + (size_t)page * 256 * D;
+        a.ws = ws;
+        a.seg_table = seg_table;
+        a.tile_seg = tile_seg;
+        a.wire = wire;
+        a.seg_minmax = seg_minmax;
+        a.ntiles = ntiles;
+        a.nseg = nseg;
+        a.ef_scale = ef_scale;
+        a.code_base = page * 256;
+        a.merge = page > 0;
+        a.last_page = (page + 1) * 256 >= K;
+        if (ef && page == 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<int32_t, D, true, true, true>), dim3((unsigned)blocks),
+                               dim3(THREADS), lds, st, a);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<int32_t, D, true, false, true>), dim3((unsigned)blocks),
+                               dim3(THREADS), lds, st, a);
+    }
+    GQ_CHECK_LAUNCH("gq_hsq_encode_batched_paged");
+    return GQ_OK;
+}
+
+int launch_pfd_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                             const float *codebook, int d, int K, int ef, float ef_scale, uint8_t *wire, float *u_flat,
+                             uint32_t *seg_minmax, float *ws, hipStream_t st) {
+    if (d == 8)
+        return pfd_batched_paged<8>(seg_table, tile_seg, nseg, ntiles, codebook, K, ef, ef_scale, wire, u_flat, seg_minmax, ws, st);
+    return pfd_batched_paged<32>(seg_table, tile_seg, nseg, ntiles, codebook, K, ef, ef_scale, wire, u_flat, seg_minmax, ws, st);
+}
+
 template <int D, bool EF>
 static int launch_pfd_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                               const float *codebook, float ef_scale, uint8_t *wire, float *u_flat,
@@ -534,7 +644,7 @@ static int launch_pfd_batched(const int64_t *seg_table, const int32_t *tile_seg,
     constexpr int WAVES = D == 32 ? 4 : 8, THREADS = WAVES * 64;
     constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
     static const int bpc = [] {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<uint8_t, D, true, EF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<uint8_t, D, true, EF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
         return resident_blocks_per_cu(hsq_encode_pfd_kernel<uint8_t, D, true, EF>, THREADS, lds);

@@ -24,7 +24,7 @@ EXPORTS = [
     "gq_hsq_encode_batched_ef", "gq_hsq_levels_batched_ef", "gq_qsgd_compress_batched_ef",
     "gq_hsq_encode_batched_d", "gq_hsq_decode_sum_batched_d", "gq_hsq_encode_batched_d_ef", "gq_hsq_levels_batched_ef_d",
     "gq_hsq_encode_batched_any", "gq_hsq_levels_batched_any", "gq_hsq_decode_sum_batched_any", "gq_hsq_error_batched_any",
-    "gq_hsq_batched_any_supported", "gq_qsgd_wide_compress", "gq_qsgd_wide_decode_sum",
+    "gq_hsq_batched_any_supported", "gq_hsq_encode_batched_paged", "gq_qsgd_wide_compress", "gq_qsgd_wide_decode_sum",
     "gq_profile_arm", "gq_profile_read", "gq_hsq_compress",
     "gq_pvq_encode", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
@@ -272,6 +272,22 @@ def hsq_encode_batched_any(seg_table, tile_seg, nseg, ntiles, codebook, code_dty
                                          _dev_ptr(wire, torch.uint8, "wire"), _dev_ptr(u_flat, torch.float32, "u_flat"),
                                          _dev_ptr(seg_minmax, torch.int32, "seg_minmax"), _stream())
     _check(rc, "gq_hsq_encode_batched_any")
+
+
+def hsq_encode_batched_paged(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace,
+                             ef_scale=None):
+    """d in {8, 16, 32}, K = 256 * pages, int32 codes: the prefilter kernel once per page of 256 codewords."""
+    K, d = int(codebook.shape[0]), int(codebook.shape[1])
+    assert workspace.numel() >= workspace_floats(ntiles * 64)
+    rc = lib().gq_hsq_encode_batched_paged(_dev_ptr(seg_table, torch.int64, "seg_table"),
+                                           _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
+                                           ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
+                                           ctypes.c_int(d), ctypes.c_int(K), ctypes.c_int(0 if ef_scale is None else 1),
+                                           ctypes.c_float(0.0 if ef_scale is None else ef_scale),
+                                           _dev_ptr(wire, torch.uint8, "wire"), _dev_ptr(u_flat, torch.float32, "u_flat"),
+                                           _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
+                                           _dev_ptr(workspace, torch.float32, "workspace"), _stream())
+    _check(rc, "gq_hsq_encode_batched_paged")
 
 
 def hsq_levels_batched_any(seg_table, tile_seg, nseg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, level_dtype,

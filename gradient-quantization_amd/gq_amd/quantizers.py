@@ -401,9 +401,12 @@ class BatchedHSQ(_BatchedBase):
         cd0 = self.codecs[0]
         self.code_dtype, self.level_dtype = cd0.code_dtype, cd0.level_dtype
         self.prefilter = BatchedHSQ._prefilter(cd0)                                   # which encode
+        # larger codebooks of the prefilter dimensions: the prefilter kernel once per page of 256 codewords
+        self.paged = (c0.dim in BatchedHSQ.DIMS and c0.K > 256 and c0.K % 256 == 0 and self.code_dtype == torch.int32
+                      and nseg <= 384)
         self.bytes = self.prefilter and self.level_dtype == torch.uint8               # which levels / decode
         self.align = 16 if c0.dim % 4 == 0 else 4
-        self.ws = native.new_workspace(device, self.ntiles * 64) if self.prefilter else None
+        self.ws = native.new_workspace(device, self.ntiles * 64) if (self.prefilter or self.paged) else None
 
     def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None):
         """Compress `tensors` (one per batched parameter, in order) into one user's wire.
@@ -421,6 +424,9 @@ class BatchedHSQ(_BatchedBase):
         if self.prefilter:
             native.hsq_encode_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.codebook, wire_user,
                                       self.u_flat, minmax, self.ws, ef_scale=ef)
+        elif self.paged:
+            native.hsq_encode_batched_paged(seg_table, self.tile_seg, self.nseg, self.ntiles, self.codebook, wire_user,
+                                            self.u_flat, minmax, self.ws, ef_scale=ef)
         else:
             native.hsq_encode_batched_any(seg_table, self.tile_seg, self.nseg, self.ntiles, self.codebook, self.code_dtype,
                                           wire_user, self.u_flat, minmax, ef_scale=ef)

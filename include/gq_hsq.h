@@ -212,6 +212,14 @@ int gq_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *tile_se
  * grad + ef_scale*error (seg_table[seg][7]) and writes it back;  gq_hsq_error_batched_any then writes
  * error = grad - decode(wire) for the rows that have an error buffer (ps_quantizer.py:39).
  * gq_hsq_levels_batched_any is independent of (d, K) and also serves the prefilter encodes above. */
+/* Multi-tensor prefilter encode for the larger codebooks of the prefilter dimensions (d = 8, 16 or 32; K = 512,
+ * 768, ... : `--k-bit 9` and up, int32 codes): one launch per page of 256 codewords, a page's exact winner merged
+ * into the (code, u) the earlier pages left in `wire` / `u_flat` (an earlier page keeps a tie: the first maximum);
+ * same table, workspace and results as gq_hsq_encode_batched_any, 3-4x faster.  ef != 0: error feedback (in the
+ * first page's launch).  At most 384 tensors per launch. */
+int gq_hsq_encode_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                const float *codebook, int d, int K, int ef, float ef_scale, uint8_t *wire,
+                                float *u_flat, uint32_t *seg_minmax, float *workspace, void *stream);
 int gq_hsq_batched_any_supported(int d, int K);   /* 1 if gq_hsq_encode_batched_any serves (d, K) */
 int gq_hsq_encode_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                               const float *codebook, int d, int K, int code_bytes, int ef, float ef_scale,

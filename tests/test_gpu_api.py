@@ -294,7 +294,10 @@ ANY_CASES = [dict(c_dim=32, k_bit=8, n_bit=9),     # prefilter encode, 16-bit le
              dict(c_dim=10, k_bit=5, n_bit=6),     # d % 4 != 0: scalar loads / stores
              dict(c_dim=48, k_bit=11, n_bit=17),   # 384 KiB codebook (chunked in LDS), int32 codes and levels
              dict(c_dim=16, k_bit=8, n_bit=32),    # uncompressed norms: the projections travel as f32
-             dict(c_dim=24, k_bit=6, n_bit=32)]
+             dict(c_dim=24, k_bit=6, n_bit=32),
+             dict(c_dim=16, k_bit=9, n_bit=6),     # K = 512 ... : the prefilter kernel once per page of 256 codewords
+             dict(c_dim=32, k_bit=10, n_bit=8),
+             dict(c_dim=8, k_bit=9, n_bit=4)]
 
 
 @pytest.mark.parametrize("case", ANY_CASES, ids=lambda c: "d%d_k%d_n%d" % (c["c_dim"], c["k_bit"], c["n_bit"]))
@@ -312,6 +315,7 @@ def test_batched_quantizer_any_shape_equals_per_tensor_path(case, tmp_path, monk
     grp = qb._groups[0][2]
     assert grp.codebook.shape == (K, d) and len(qb.batch_idx) == sum(int(np.prod(s)) > 1000 for s in shapes) >= 5
     assert grp.prefilter == (K == 256 and d in (8, 16, 32)) and not grp.bytes
+    assert grp.paged == (K > 256 and K % 256 == 0 and d in (8, 16, 32))
     for a, b, s in zip(gb, gp, shapes):
         assert a.shape == torch.Size(s)
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), s

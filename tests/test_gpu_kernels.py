@@ -137,6 +137,35 @@ def test_lds_staged_encode_any_shape_matches_generic_and_oracle(nat, oracle, d, 
     assert np.array_equal(_bits(got["u"].cpu().numpy()), _bits(u))
 
 
+@pytest.mark.parametrize("d,K,M", [(16, 512, 100003), (16, 768, 4097), (16, 1024, 65), (16, 4096, 20000),
+                                   (8, 512, 50001), (8, 2048, 4097), (32, 512, 30001), (32, 1024, 65)])
+def test_paged_prefilter_encode_larger_codebooks(nat, oracle, d, K, M):
+    """d in {8, 16, 32}, K = 256 * pages (--k-bit 9 ... 12): the prefilter kernel once per page of 256 codewords, the pages'
+    exact winners merged in place (an earlier page keeps a tie).  Codes, u, lb, ub and levels bit-identical to the
+    exact LDS kernel and the oracle, including exact ties ACROSS pages."""
+    rng = np.random.RandomState(K + M)
+    cb = rng.standard_normal((K, d)).astype(np.float32)
+    cb /= np.linalg.norm(cb, axis=1, keepdims=True)
+    cb[300] = cb[10]            # the same codeword on two pages: the first one wins
+    cb[K - 1] = -cb[20]         # |score| tie with opposite signs
+    cb[256 + 7] = cb[256 + 200] # and a tie inside a later page
+    x = (rng.standard_normal(M * d) * 0.05).astype(np.float32)
+    x[0:d] = 0.0
+    x[d:2 * d] = cb[10] * 0.5
+    x[2 * d:3 * d] = cb[20] * -0.25
+    x[3 * d:4 * d] = cb[256 + 7] * 3.0
+    got = gpu_compress(nat, x, cb, 6, 0, impl=0)
+    ref = gpu_compress(nat, x, cb, 6, 0, impl=5)
+    assert torch.equal(got["codes"], ref["codes"]) and torch.equal(got["u"].view(torch.int32), ref["u"].view(torch.int32))
+    assert torch.equal(got["lb_ub"].view(torch.int32), ref["lb_ub"].view(torch.int32))
+    assert torch.equal(got["levels"], ref["levels"])
+    codes, u = oracle.hsq_encode(x, cb)
+    assert np.array_equal(got["codes"].cpu().numpy().astype(np.int64), codes.astype(np.int64))
+    assert np.array_equal(_bits(got["u"].cpu().numpy()), _bits(u))
+    c = got["codes"].cpu().numpy()
+    assert c[0] == 0 and c[1] == 10 and c[2] == 20 and c[3] == 256 + 7
+
+
 @pytest.mark.parametrize("scale", [1.0, 1e-3])
 @pytest.mark.parametrize("M", [1, 2, 31, 32, 33, 63, 64, 65, 127, 4095, 4096, 4097, 100003])
 def test_hsq_encode_vs_oracle_ragged(nat, oracle, M, scale):
