@@ -586,6 +586,7 @@ class PSQuantizer(object):
             off += self.codecs[i].nbytes
         self.dense_bytes = off - self.dense_off
         self._dense_mean, self._dense_views, self._dense_turn = [None, None], [None, None], 0
+        self._dense_in = {}                 # (wire pointer, slot) -> views of the slot's dense region
         self.user_bytes = _up(off)          # one user's payload (all tensors)
         # tensors served by multi-tensor kernels: (class, parameter indices), built at the first record()
         self._groups = []
@@ -640,8 +641,18 @@ class PSQuantizer(object):
         if len(self.dense_idx) >= 2:
             # all small tensors with one concatenation straight into the packed wire region.  Under
             # error feedback their residual is identically zero (decoded == grad), so nothing else to do.
-            torch.cat([self.parameters[i].grad.data.reshape(-1) for i in self.dense_idx],
-                      out=wire[self.dense_off:self.dense_off + self.dense_bytes].view(torch.float32))
+            key = (self._wire.data_ptr(), slot)
+            views = self._dense_in.get(key)
+            if views is None:       # parameter-shaped views of this slot's dense region, built once
+                region = wire[self.dense_off:self.dense_off + self.dense_bytes].view(torch.float32)
+                views, o = [], 0
+                for i in self.dense_idx:
+                    n = self.codecs[i].numel
+                    views.append(region[o:o + n].view(self.codecs[i].shape))
+                    o += n
+                self._dense_in = {k: v for k, v in self._dense_in.items() if k[0] == key[0]}   # drop a replaced wire's
+                self._dense_in[key] = views
+            torch._foreach_copy_(views, [self.parameters[i].grad.data for i in self.dense_idx])
             skip.update(self.dense_idx)
         for i, param in enumerate(self.parameters):
             if i in skip:

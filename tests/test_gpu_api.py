@@ -208,6 +208,22 @@ def test_nccl_single_rank_group_path():
         dist.destroy_process_group()
 
 
+def test_kernels_launch_on_pytorch_current_stream():
+    """The library takes the stream PyTorch would launch on (raw handle), also inside a stream context."""
+    from gq_amd import native
+    assert (native._stream().value or 0) == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert native._stream().value == side.cuda_stream
+        x = torch.randn(4096 * 16, device="cuda")
+        from gq_amd.compressors import NearestNeighborCompressor
+        comp = NearestNeighborCompressor(x.numel(), x.shape, make_args())
+        y = comp.decompress(comp.compress(x))
+    side.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(y, comp.decompress(comp.compress(x)))
+
+
 RESNET50_COMPRESSED = ([(64, 3, 3, 3)] + [(64, 64, 1, 1), (64, 64, 3, 3), (256, 64, 1, 1)] * 2 + [(1024,)] * 4
                        + [(128, 256, 1, 1), (128, 128, 3, 3), (512, 128, 1, 1), (512, 256, 1, 1)]
                        + [(256, 512, 1, 1), (256, 256, 3, 3), (1024, 256, 1, 1), (2048,)]
