@@ -76,8 +76,12 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_absmax_kernel(const int6
         }
         run_mx = 0.0f;
     };
+    // the chunk -> tensor -> record lookups of chunk c + 1 are issued before chunk c's data is touched: three
+    // dependent round trips per chunk otherwise, and a wave only has a handful of chunks to hide them behind
+    WideItem nxt = wide_item(seg_table, chunk_seg, c_begin < c_end ? c_begin : 0);
     for (int64_t c = c_begin; c < c_end; ++c) {
-        const WideItem it = wide_item(seg_table, chunk_seg, c);
+        const WideItem it = nxt;
+        if (c + 1 < c_end) nxt = wide_item(seg_table, chunk_seg, c + 1);
         float *v = reinterpret_cast<float *>(it.rec[0]) + it.b * it.d + it.first;
         const float *err = (EF && it.rec[7]) ? reinterpret_cast<const float *>(it.rec[7]) + it.b * it.d + it.first : nullptr;
         unsigned *word = norm_bits + it.rec[6] + it.b;
@@ -134,8 +138,12 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_quantise_kernel(
     constexpr unsigned lmask = (1u << (BITS - 1)) - 1u;
     int64_t c_begin, c_end;
     wide_run(nchunks, c_begin, c_end);
+    // the chunk -> tensor -> record lookups of chunk c + 1 are issued before chunk c's data is touched: three
+    // dependent round trips per chunk otherwise, and a wave only has a handful of chunks to hide them behind
+    WideItem nxt = wide_item(seg_table, chunk_seg, c_begin < c_end ? c_begin : 0);
     for (int64_t c = c_begin; c < c_end; ++c) {
-        const WideItem it = wide_item(seg_table, chunk_seg, c);
+        const WideItem it = nxt;
+        if (c + 1 < c_end) nxt = wide_item(seg_table, chunk_seg, c + 1);
         const int64_t at = it.b * it.d + it.first;                 // first element of the chunk inside the tensor
         const float *v = reinterpret_cast<const float *>(it.rec[0]) + at;
         float *err = (EF && it.rec[7]) ? reinterpret_cast<float *>(it.rec[7]) + at : nullptr;
@@ -231,8 +239,12 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_decode_kernel(const int6
     constexpr unsigned lmask = (1u << (BITS - 1)) - 1u;
     int64_t c_begin, c_end;
     wide_run(nchunks, c_begin, c_end);
+    // the chunk -> tensor -> record lookups of chunk c + 1 are issued before chunk c's data is touched: three
+    // dependent round trips per chunk otherwise, and a wave only has a handful of chunks to hide them behind
+    WideItem nxt = wide_item(seg_table, chunk_seg, c_begin < c_end ? c_begin : 0);
     for (int64_t c = c_begin; c < c_end; ++c) {
-        const WideItem it = wide_item(seg_table, chunk_seg, c);
+        const WideItem it = nxt;
+        if (c + 1 < c_end) nxt = wide_item(seg_table, chunk_seg, c + 1);
         const int64_t at = it.b * it.d + it.first;
         float *o = out + it.rec[5] + at;
         const int64_t code_off = it.rec[4] + ((at * BITS) >> 3);
@@ -280,16 +292,18 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_decode_kernel(const int6
                     acc[k] = (r == 0) ? t : acc[k] + t;
                 }
             }
+            if (R > 1) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = e0 + 2 * k;
-                if (e < it.n) {
-                    v2f a = {acc[2 * k], acc[2 * k + 1]};
-                    if (R > 1) {
-                        a[0] = a[0] / fR;
-                        a[1] = a[1] / fR;
-                    }
-                    *reinterpret_cast<v2f *>(o + e) = a;
+                for (int k = 0; k < 8; ++k) acc[k] = acc[k] / fR;
+            }
+            if (whole && dwords) {   // tensors start 16-byte aligned in `out` and at % 8 == 0: two 16-byte stores
+                *reinterpret_cast<f32x4 *>(o + e0) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+                *reinterpret_cast<f32x4 *>(o + e0 + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = e0 + 2 * k;
+                    if (e < it.n) *reinterpret_cast<v2f *>(o + e) = v2f{acc[2 * k], acc[2 * k + 1]};
                 }
             }
         }
@@ -345,8 +359,8 @@ GQ_API int gq_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chun
     if (!seg_table || !chunk_seg || !gathered || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_wide_decode_sum: null pointer");
     if ((user_stride_bytes & 3) != 0 || (reinterpret_cast<uintptr_t>(gathered) & 3) != 0 ||
-        (reinterpret_cast<uintptr_t>(out) & 7) != 0)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_wide_decode_sum: wires must be 4-byte, out 8-byte aligned");
+        (reinterpret_cast<uintptr_t>(out) & 15) != 0)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_wide_decode_sum: wires must be 4-byte, out 16-byte aligned");
     const dim3 grid((unsigned)gq::qw_grid(nchunks)), block(gq::QW_THREADS);
     if (bits == 4)
         hipLaunchKernelGGL(gq::qsgd_wide_decode_kernel<4>, grid, block, 0, gq::as_stream(stream), seg_table, chunk_seg,

@@ -303,7 +303,7 @@ int gq_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_s
  * The unit of work is a chunk of GQ_QSGD_WIDE_CHUNK consecutive elements of one bucket (the last chunk of a
  * bucket may be shorter; d must be even): chunk_seg int32[nchunks] names the tensor of each chunk, ascending;
  * seg_table int64[nseg][8] = { grad pointer (8-byte aligned), d, first chunk, byte offset of the norms / of the
- * codes inside ONE user's wire, float offset of the tensor in `out`, first word of the tensor's buckets in
+ * codes inside ONE user's wire, float offset of the tensor in `out` (a multiple of 4), first word of the tensor's buckets in
  * norm_bits, error buffer (float*, 0 = none) }.  norm_bits (one uint32 per bucket; give every tensor its own
  * 128-byte line: the words are targets of atomics) must be zero before each
  * compress (max |v| is folded into it with integer atomics).  gq_qsgd_wide_compress = two launches (bucket
