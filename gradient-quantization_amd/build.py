@@ -18,7 +18,13 @@ LIB = os.path.join(HERE, "libgq_hsq.so")
 SOURCES = ["gq_common.hip", "hsq_encode.hip", "hsq_encode_pf.hip", "hsq_encode_pfd.hip", "hsq_levels.hip", "hsq_batched.hip", "hsq_decode.hip", "qsgd.hip", "qsgd_batched.hip", "qsgd_wide.hip", "pvq.hip"]
 # -ffp-contract=off: the reference's elementwise ops are separately rounded; hipcc's
 # default ("fast") would fuse the decode's mul/add and the level quantiser's sub/div.
+# -packed-fp32-ops (target feature off): no v_pk_{fma,mul,add}_f32.  One instantiation of the encode kernel came out
+# with a packed FMA whose destination pair was also its multiplicand pair, read crosswise through op_sel, and on
+# the MI355X one result in ~1e5 (low half, lanes 48-63 only) was wrong (tools/fuzz_batched.py found it; see
+# hsq_pf_common.hpp).  The compiler emits the same crosswise in-place form for `vector * scalar` in the decode
+# kernels; rather than trust them, the library is built without packed f32 (decode R=8: see DESIGN.md).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
          "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

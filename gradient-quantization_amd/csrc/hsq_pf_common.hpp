@@ -63,22 +63,26 @@ __device__ __forceinline__ float absmax4(float a, float b, float c, float d) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Exact reference arithmetic for FOUR consecutive codewords at once: p = fmaf chain over j
-// ascending, from +0, as packed f32 FMAs (v_pk_fma_f32 rounds each half like v_fma_f32).
-// `quad` points at the group-interleaved LDS image: (c0[j], c1[j], c2[j], c3[j]) for j = 0..D-1.
+// ascending, from +0.  `quad` points at the group-interleaved LDS image: (c0[j], c1[j], c2[j], c3[j]) for
+// j = 0..D-1.  Four plain v_fma_f32 per element, pinned by inline assembly: written as vector code (or as
+// scalar fmaf, which the compiler packs again) this became v_pk_fma_f32 whose destination pair overlapped
+// its multiplicand pair under op_sel (v_pk_fma v[2:3], v[188:189], v[2:3], v[6:7] op_sel:[0,1,0]) in the
+// register-tight error-feedback instantiation, and there ONE result in ~1e5 -- always the low half, always
+// lanes 48-63 -- came out with a wrong term (found by tools/fuzz_batched.py; codes right, u off by 1e-3
+// relative).  The plain form is also faster beside the MFMAs (encode 52-54 -> 49 us).
 template <int D>
 __device__ __forceinline__ f32x4 exact_score_quad(const float *__restrict__ quad, const float (&v)[D]) {
-    f32x2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll
     for (int jj = 0; jj < D; ++jj) {
-        // at most 16 row reads (64 VGPRs) in flight: left alone, the scheduler hoists all D of them
         if (jj > 0 && jj % 16 == 0) __builtin_amdgcn_sched_barrier(0);
         const f32x4 c = *reinterpret_cast<const f32x4 *>(quad + 4 * jj);
-        const f32x2 c01 = {c[0], c[1]}, c23 = {c[2], c[3]};
-        const f32x2 vv = {v[jj], v[jj]};
-        a01 = __builtin_elementwise_fma(c01, vv, a01);
-        a23 = __builtin_elementwise_fma(c23, vv, a23);
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(c[0]), "v"(v[jj]));
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(c[1]), "v"(v[jj]));
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a2) : "v"(c[2]), "v"(v[jj]));
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a3) : "v"(c[3]), "v"(v[jj]));
     }
-    const f32x4 r = {a01[0], a01[1], a23[0], a23[1]};
+    const f32x4 r = {a0, a1, a2, a3};
     return r;
 }
 
