@@ -358,10 +358,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
                 track(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
                 __builtin_amdgcn_sched_barrier(0);
                 nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vl[nb], nacc, 0, 0, 0);
+                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vh[nb], nacc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 track(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
-                __builtin_amdgcn_sched_barrier(0);
-                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vh[nb], nacc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 acc = nacc;
             } else {
