@@ -328,11 +328,10 @@ __global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kern
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < KS; ++s) nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ab][s], vl[nb][s], nacc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                track(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < KS; ++s) nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ab][s], vh[nb][s], nacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                track(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
                 __builtin_amdgcn_sched_barrier(0);
                 acc = nacc;
             } else {

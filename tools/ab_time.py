@@ -1,4 +1,4 @@
-"""A/B timing of gq_hsq_encode (25 M elements) for library builds, alternated in child processes on one box:
+"""A/B timing of gq_hsq_encode (25 M elements; GQ_AB_D = sub-dimension, default 16) for library builds, alternated in child processes on one box:
     python tools/ab_time.py product tools/exp/libgq_B.so ...      ('product' = the in-tree library)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,10 +9,11 @@ import torch
 from gq_amd import native
 from gq_amd.codebook import load_codebook
 dev = torch.device("cuda:0")
-cb = torch.from_numpy(load_codebook(16, 256)).to(dev)
+D = int(os.environ.get("GQ_AB_D", "16"))
+cb = torch.from_numpy(load_codebook(D, 256)).to(dev)
 torch.manual_seed(1234)
 g = torch.randn(25_000_000, device=dev)
-M = g.numel() // 16
+M = g.numel() // D
 codes = torch.empty(M, dtype=torch.uint8, device=dev); u = torch.empty(M, dtype=torch.float32, device=dev)
 ws = native.new_workspace(dev, M)
 for _ in range(3000):
