@@ -303,6 +303,41 @@ def test_full_size_properties(nat, oracle):
     assert np.array_equal(_bits(u[123457:123457 + 65536].cpu().numpy()), _bits(ru))
 
 
+def test_full_size_compress_and_decode_mean_equal_the_oracle(nat, oracle):
+    """BASELINE size, everything against the oracle bit for bit: three ranks' 25 M-element gradients compressed
+    (codes, u, lb, ub, levels) and their decode-mean (R = 1 and R = 3) -- rare-event errors (one subvector in
+    1e5, as the packed-FMA trap produced) cannot hide at this size."""
+    dev = torch.device("cuda:0")
+    cb_np = _cb(16, 256)
+    cb = torch.from_numpy(cb_np).to(dev)
+    M = 25_000_000 // 16
+    codes = torch.empty((3, M), dtype=torch.uint8, device=dev)
+    levels = torch.empty((3, M), dtype=torch.uint8, device=dev)
+    lb_ub = torch.empty((3, 2), dtype=torch.float32, device=dev)
+    u = torch.empty(M, dtype=torch.float32, device=dev)
+    ws = nat.new_workspace(dev, M)
+    dec = []
+    for r in range(3):
+        torch.manual_seed(100 + r)
+        g = torch.randn(25_000_000, device=dev) * (1e-3 if r == 1 else 1.0)
+        nat.hsq_encode(g, cb, codes[r], u, ws)
+        nat.hsq_levels(u, 6, 0, None, 0, ws, lb_ub[r], levels[r])
+        torch.cuda.synchronize()
+        oc, ou = oracle.hsq_encode(g.cpu().numpy(), cb_np)
+        lb, ub, lv = oracle.scalar_levels(ou, 6, 0, None)
+        assert np.array_equal(codes[r].cpu().numpy(), oc.astype(np.uint8)), r
+        assert np.array_equal(_bits(u.cpu().numpy()), _bits(ou)), r
+        assert np.array_equal(_bits(lb_ub[r].cpu().numpy()), _bits(np.array([lb, ub], dtype=np.float32).reshape(-1)))
+        assert np.array_equal(levels[r].cpu().numpy().astype(np.int64), lv.astype(np.int64)), r
+        dec.append(oracle.hsq_decompress(oc, lv, lb, ub, cb_np, 6).reshape(-1))
+    out = torch.empty(25_000_000, dtype=torch.float32, device=dev)
+    nat.hsq_decode_sum(codes[0], levels[0], lb_ub[0], cb, 6, out, R=1)
+    assert np.array_equal(_bits(out.cpu().numpy()), _bits(dec[0]))
+    nat.hsq_decode_sum(codes.reshape(-1), levels.reshape(-1), lb_ub.reshape(-1), cb, 6, out, R=3)
+    want = ((dec[0] + dec[1]) + dec[2]) / np.float32(3.0)        # stack().mean(0): ascending sum, then / R
+    assert np.array_equal(_bits(out.cpu().numpy()), _bits(want))
+
+
 @pytest.mark.parametrize("d", [16, 8, 32])
 def test_prefilter_equals_exact_mfma_at_full_size_and_fixup_rate(nat, d):
     """The bf16x3 prefilter path (d = 16, and its d = 8 / d = 32 form) must reproduce the exact f32 MFMA
