@@ -556,6 +556,26 @@ def test_batched_packed_qsgd_equals_per_tensor_and_reference_arithmetic(kw, orac
         assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("kw", [dict(c_dim=128, n_bit=2), dict(c_dim=0, n_bit=1), dict(c_dim=512, n_bit=8)],
+                         ids=lambda k: "d%d_n%d" % (k["c_dim"], k["n_bit"]))
+def test_qsgd_large_tensors_match_the_oracle(kw, oracle):
+    """Rare-event check at size: 2 x 12.6 M elements per user through the packed kernels (bucketed, wide and
+    16-bit forms), the aggregate of two users against the oracle's decompress(compress(g)) mean, bit for bit."""
+    shapes = [(2048, 4096), (4_194_304 + 2048,), (10,)]
+    qb, gb = _run_qsgd(shapes, 2, 9, **kw)
+    assert qb._groups and qb._groups[0][2].ready
+    g = torch.Generator(device="cuda").manual_seed(9)
+    grads = [[[torch.randn(s, device="cuda", generator=g) * 1e-2 for s in shapes] for _ in range(2)] for _ in range(2)][1]
+    for k in (0, 1):
+        d = qb.codecs[k].d
+        dec = []
+        for u in range(2):
+            norm, signs, levels = oracle.qsgd_compress(grads[u][k].cpu().numpy().reshape(-1), d, kw["n_bit"], 0)
+            dec.append(oracle.qsgd_decompress(norm, signs, levels, d, kw["n_bit"]).reshape(-1))
+        want = (dec[0] + dec[1]) / np.float32(2.0)
+        assert np.array_equal(gb[k].cpu().numpy().reshape(-1).view(np.uint32), want.view(np.uint32)), k
+
+
 WIDE_SHAPES = [(64, 3, 3, 3), (128, 128, 3, 3), (1024,), (2048,), (512, 128, 1, 1), (9000,), (5, 1001, 2), (10,), (64,),
                (2, 4099)]
 
