@@ -13,6 +13,15 @@
 // A tile is 64 subvectors (64 * D floats); scores per gradient element are 256 / D, so D = 32 costs half of
 // D = 16 per element and D = 8 twice as much.
 #include "hsq_pf_common.hpp"
+// waves per workgroup (one workgroup per CU): D = 32 two per SIMD (<= 251 VGPRs per lane since the library is built
+// without packed f32 operations; with them the kernel wanted ~330 and ran one wave per SIMD: 59 -> 52 us),
+// D = 8 three per SIMD (<= 168 VGPRs; 78 -> 76 us)
+#ifndef GQ_W32
+#define GQ_W32 8
+#endif
+#ifndef GQ_W8
+#define GQ_W8 12
+#endif
 
 namespace gq {
 
@@ -38,10 +47,10 @@ struct PfdArgs {
 
 constexpr int PFD_LDS_SEGS = 384;   // batched form: segment records kept in LDS (24 KiB); longer lists are refused
 
-// D = 32 wants ~360 registers per lane (two tiles of 64 x 32 floats in flight, fragments of both, two
-// accumulators): at two waves per SIMD it spilled 112 VGPRs and ran 101 us per 25 M elements; at one wave
-// per SIMD (512 registers) nothing spills and the in-wave MFMA / key-operation pipeline carries it: 61 us
-// (built with -amdgpu-mfma-vgpr-form so that the accumulators stay in VGPRs: build.py).
+// D = 32 holds two tiles of 64 x 32 floats, the fragments of both and two accumulators: 205-251 VGPRs per lane
+// (built with -amdgpu-mfma-vgpr-form so that the accumulators stay in VGPRs: build.py).  While packed f32
+// operations were in the build the same source wanted ~330, spilled 112 at two waves per SIMD (101 us per 25 M
+// elements) and ran at one wave per SIMD (61 us).
 // BATCHED: the multi-tensor form -- segment table, one contiguous run of tiles per wave, per-tensor (min,max)
 // by look-before-you-leap atomics, table-derived addresses as global address-space pointers: everything as in
 // hsq_encode_pf.hip, where the reasons are written down.
@@ -49,10 +58,10 @@ constexpr int PFD_LDS_SEGS = 384;   // batched form: segment records kept in LDS
 // v = grad + ef_scale * error (product rounded, then the add), v is written back over grad, and the level
 // kernel (gq_hsq_levels_batched_ef_d) later writes error = v - decoded.
 template <typename CodeT, int D, bool BATCHED = false, bool EF = false, bool PAGED = false>
-__global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kernel(const PfdArgs a) {
-    // one workgroup per CU: 8 waves (two per SIMD) for D = 8, 4 waves (one per SIMD) for D = 32; the waves share the
-    // workgroup's contiguous run of tiles through an LDS counter (hsq_encode_pf.hip)
-    constexpr int WAVES = D == 32 ? 4 : 8;
+__global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode_pfd_kernel(const PfdArgs a) {
+    // one workgroup per CU: 12 waves (three per SIMD) for D = 8, 8 waves (two per SIMD) for D = 32; the waves share
+    // the workgroup's contiguous run of tiles through an LDS counter (hsq_encode_pf.hip)
+    constexpr int WAVES = D == 32 ? GQ_W32 : GQ_W8;
     constexpr int THREADS = WAVES * 64;
     static_assert(D == 8 || D == 32, "built for D = 8 and D = 32 (D = 16: hsq_encode_pf.hip)");
     constexpr int KS = D > 16 ? D / 16 : 1;    // MFMA k-steps per chain
@@ -115,7 +124,7 @@ __global__ __launch_bounds__((D == 32 ? 4 : 8) * 64, 1) void hsq_encode_pfd_kern
     const int64_t lo_tile = ((int64_t)blockIdx.x * ntiles) / gridDim.x;
     const int64_t tile_end = (((int64_t)blockIdx.x + 1) * ntiles) / gridDim.x;
     // the slower wave of a SIMD (waves 4-7 of an 8-wave workgroup) leaves the last tiles of the run to the faster one
-    const int tail_from = (int)(tile_end - lo_tile) - ((WAVES == 8 && wave >= 4) ? 6 : 0);
+    const int tail_from = (int)(tile_end - lo_tile) - ((WAVES >= 8 && wave >= 4) ? 6 : 0);
     auto draw = [&]() {   // the next tile of this workgroup's run (may lie beyond tile_end)
         int k = 0x3FFFFFFF;
         if (lane == 0) {
@@ -507,7 +516,7 @@ template <typename CodeT, int D>
 static int launch_pfd(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *ws,
                       hipStream_t st) {
     constexpr int KS = D > 16 ? D / 16 : 1;
-    constexpr int WAVES = D == 32 ? 4 : 8, THREADS = WAVES * 64;
+    constexpr int WAVES = D == 32 ? GQ_W32 : GQ_W8, THREADS = WAVES * 64;
     constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
     static const int bpc = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<CodeT, D>),
@@ -535,7 +544,7 @@ template <int D>
 static int launch_pfd_paged(const float *grad, const float *codebook, int64_t M, int K, int32_t *codes, float *u, float *ws,
                             hipStream_t st) {
     constexpr int KS = D > 16 ? D / 16 : 1;
-    constexpr int WAVES = D == 32 ? 4 : 8, THREADS = WAVES * 64;
+    constexpr int WAVES = D == 32 ? GQ_W32 : GQ_W8, THREADS = WAVES * 64;
     constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
     auto kernel = hsq_encode_pfd_kernel<int32_t, D, false, false, true>;
     static const int bpc = [] {
@@ -589,7 +598,7 @@ static int pfd_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, 
                              const float *codebook, int K, int ef, float ef_scale, uint8_t *wire, float *u_flat,
                              uint32_t *seg_minmax, float *ws, hipStream_t st) {
     constexpr int KS = D > 16 ? D / 16 : 1;
-    constexpr int WAVES = D == 32 ? 4 : 8, THREADS = WAVES * 64;
+    constexpr int WAVES = D == 32 ? GQ_W32 : GQ_W8, THREADS = WAVES * 64;
     constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
     static const int bpc = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<int32_t, D, true, true, true>),
@@ -640,7 +649,7 @@ static int launch_pfd_batched(const int64_t *seg_table, const int32_t *tile_seg,
                               const float *codebook, float ef_scale, uint8_t *wire, float *u_flat,
                               uint32_t *seg_minmax, float *ws, hipStream_t st) {
     constexpr int KS = D > 16 ? D / 16 : 1;
-    constexpr int WAVES = D == 32 ? 4 : 8, THREADS = WAVES * 64;
+    constexpr int WAVES = D == 32 ? GQ_W32 : GQ_W8, THREADS = WAVES * 64;
     constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
     static const int bpc = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<uint8_t, D, true, EF>),
