@@ -250,7 +250,6 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_generic_kernel(const f
 // blocks) share every A fragment.  When the codebook is chunked the workgroup re-stages the next
 // chunk between barriers and each wave carries its tile's running (best, index) in registers.
 // ------------------------------------------------------------------------------------
-constexpr int LDS_ROW_PAD = 4;
 
 // BATCHED: the tiles are those of a segment table (include/gq_hsq.h, gq_hsq_encode_batched_any): tile t belongs to
 // tensor tile_seg[t]; codes go into the tensor's section of `wire`, u into the padded u_flat, and (min,max)
@@ -477,7 +476,7 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
 }
 
 // LDS plan of hsq_encode_lds_kernel: false if (d, K) does not fit
-static bool lds_plan(int d, int K, int *dpad, int *chunk_rows, size_t *bytes) {
+bool lds_plan(int d, int K, int *dpad, int *chunk_rows, size_t *bytes) {
     static const int limit = [] {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, 0) != hipSuccess || v < 65536) v = 65536;

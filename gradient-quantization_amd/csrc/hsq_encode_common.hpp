@@ -94,6 +94,10 @@ template <typename CodeT>
 int launch_encode_pfd(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u,
                       float *workspace, hipStream_t st);
 
+// LDS plan of the operand-staging kernels (hsq_encode_lds_kernel, pvq_encode_lds_kernel): false if (d, K) does not fit
+constexpr int LDS_ROW_PAD = 4;
+bool lds_plan(int d, int K, int *dpad, int *chunk_rows, size_t *bytes);
+
 int launch_encode_pfd_paged(const float *grad, const float *codebook, int64_t M, int d, int K, int32_t *codes, float *u,
                             float *workspace, hipStream_t st);
 

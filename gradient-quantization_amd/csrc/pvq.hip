@@ -9,10 +9,11 @@
 //     code  = first k with  cumsum_k(|p|) / l1  >=  r - 1e-5 ,   r ~ U[0,1) per subvector (:52-58)
 //     u     = sign(p_code) * l1                                                     (:60-61)
 // so that E[ codewords[code] * u ] = sum_k p_k c_k = v  (unbiased for a full-rank codebook).
-// One subvector per lane; C_dagger is broadcast from LDS (or read through L1 when it does not
-// fit); two sweeps over the K codewords (l1, then the inverse-CDF walk) with the same fmaf chain
-// as the NearestNeighbor encode.  Not on the headline path: VALU-bound, ~2*K*d FMAs per subvector.
-#include "gq_common.hpp"
+// pvq_encode_lds_kernel (below) runs it on the matrix cores for any d <= 104; pvq_encode_kernel is the VALU
+// cross-check and the fallback for wider subvectors: one subvector per lane; C_dagger is broadcast from LDS (or
+// read through L1 when it does not fit); two sweeps over the K codewords (l1, then the inverse-CDF walk) with the
+// same fmaf chain as the NearestNeighbor encode, ~2*K*d FMAs per subvector.
+#include "hsq_encode_common.hpp"
 
 namespace gq {
 
@@ -94,6 +95,176 @@ __global__ __launch_bounds__(PV_THREADS) void pvq_encode_kernel(const float *__r
         }
 }
 
+// ------------------------------------------------------------------------------------
+// The same on the matrix cores, any d <= 104 and any K: both operands staged in LDS exactly as in
+// hsq_encode_lds_kernel (hsq_encode.hip, where the layout is described); v_mfma_f32_32x32x2_f32 evaluates the
+// oracle's fmaf chain bit for bit.  A wave owns a tile of 64 subvectors as two 32-column blocks; after a row
+// block's two accumulators are exchanged across the wave halves (v_permlane32_swap), LANE L holds all 32
+// scores of ITS subvector L: registers x[4q..4q+3] are codewords 8q..8q+3 of the block, y[4q..4q+3] codewords
+// 8q+4..8q+7 -- so the two sequential sums of the oracle (l1, then the running inverse-CDF sum with its
+// division per term) run lane-locally, in ascending k, with no cross-lane step.  Two sweeps over the codebook
+// (l1 has to be complete before the walk); the code is the number of terms whose running sum stayed below the
+// threshold (the sums never decrease, so "first k with cum >= thr" == that count; NaN -- an all-zero
+// subvector -- counts every term and lands on K-1 like the oracle); the selected projection is recomputed as
+// one explicit fmaf chain.  Padded codewords (K not a multiple of 32) score +0 and change neither sum.
+// ------------------------------------------------------------------------------------
+template <typename CodeT>
+__global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float *__restrict__ grad,
+                                                                    const float *__restrict__ cdag, int64_t M, int d,
+                                                                    int K, int random_mode,
+                                                                    const float *__restrict__ r, uint64_t seed,
+                                                                    CodeT *__restrict__ codes, float *__restrict__ u,
+                                                                    float *__restrict__ partials, int dpad,
+                                                                    int chunk_rows) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int stride = dpad + LDS_ROW_PAD, half = dpad >> 1;
+    float *const s_cb = lds;
+    float *const s_v = lds + (size_t)chunk_rows * stride + (size_t)wave * 64 * stride;
+    const int kpad = (K + 31) & ~31;
+    const int nchunks = (kpad + chunk_rows - 1) / chunk_rows;
+    const float inv_dpad = 1.0f / (float)dpad;
+    auto stage_codebook = [&](int row0) {
+        const int total = chunk_rows * dpad;
+        for (int i = threadIdx.x; i < total; i += ENC_THREADS) {
+            const int rr = (int)(((float)i + 0.5f) * inv_dpad);
+            const int e = i - rr * dpad;
+            const int row = row0 + rr;
+            const float val = (row < K && e < d) ? cdag[(int64_t)row * d + e] : 0.0f;
+            s_cb[rr * stride + (e & 1) * half + (e >> 1)] = val;
+        }
+    };
+    auto stage_tile = [&](int64_t t) {
+        const int total = 64 * dpad;
+        const int64_t sv0 = t * 64;
+        for (int i = lane; i < total; i += 64) {
+            const int rr = (int)(((float)i + 0.5f) * inv_dpad);
+            const int e = i - rr * dpad;
+            const float val = (sv0 + rr < M && e < d) ? grad[(sv0 + rr) * (int64_t)d + e] : 0.0f;
+            s_v[rr * stride + (e & 1) * half + (e >> 1)] = val;
+        }
+    };
+    const int64_t ntiles = (M + 63) >> 6;
+    const int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
+    const int64_t rounds = (ntiles + nw - 1) / nw;   // the same for every wave: barriers stay uniform
+    float lmin = INFINITY, lmax = -INFINITY;
+    if (nchunks == 1) {
+        stage_codebook(0);
+        __syncthreads();
+    }
+    for (int64_t round = 0; round < rounds; ++round) {
+        const int64_t t = round * nw + (int64_t)blockIdx.x * ENC_WAVES + wave;
+        const bool active = t < ntiles;
+        const int64_t sv = t * 64 + lane;           // this lane's subvector
+        if (active) stage_tile(t);
+        float l1 = 0.0f, cum = 0.0f, thr = 0.0f;
+        int count = 0;
+        for (int sweep = 0; sweep < 2; ++sweep) {
+            if (sweep == 1) {
+                const float rr = (active && sv < M) ? ((random_mode == GQ_RANDOM_GIVEN) ? r[sv] : uniform01(seed, (uint64_t)sv))
+                                                    : 0.0f;
+                thr = rr - 1e-5f;
+            }
+            for (int chunk = 0; chunk < nchunks; ++chunk) {
+                const int row0 = chunk * chunk_rows;
+                if (nchunks > 1) {
+                    __syncthreads();   // everyone is done with the previous chunk
+                    stage_codebook(row0);
+                    __syncthreads();
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (!active) continue;
+                const int rblocks = min(chunk_rows, kpad - row0) >> 5;
+                for (int rb = 0; rb < rblocks; ++rb) {
+                    const float *arow = s_cb + (rb * 32 + j) * stride + h * half;
+                    const float *b0 = s_v + j * stride + h * half;
+                    const float *b1 = s_v + (32 + j) * stride + h * half;
+                    f32x16 acc0 = {0}, acc1 = {0};
+                    for (int k4 = 0; k4 < half; k4 += 4) {
+                        const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + k4);
+                        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(b0 + k4);
+                        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(b1 + k4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], x0[q], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], x1[q], acc1, 0, 0, 0);
+                        }
+                    }
+                    // lane L <- the 32 scores of subvector L: x = rows acc_row(r), y = rows acc_row(r) + 4
+                    float x[16], y[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        x[q] = acc0[q];
+                        y[q] = acc1[q];
+                        swap32(x[q], y[q]);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                        for (int part = 0; part < 2; ++part) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float a = fabsf(part ? y[4 * g + e] : x[4 * g + e]);   // codeword 32 rb + 8 g + 4 part + e
+                                if (sweep == 0) {
+                                    l1 = l1 + a;
+                                } else {
+                                    cum = cum + a / l1;   // the reference divides first (:49,:57)
+                                    count += (cum >= thr) ? 0 : 1;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!active || sv >= M) continue;
+        const int code = count < K - 1 ? count : K - 1;
+        float sel = 0.0f;
+        {
+            const float *row = cdag + (int64_t)code * d;
+            const float *v = s_v + lane * stride;
+            for (int e = 0; e < d; ++e) sel = __fmaf_rn(row[e], v[(e & 1) * half + (e >> 1)], sel);
+        }
+        const float sg = (sel > 0.0f) ? 1.0f : ((sel < 0.0f) ? -1.0f : 0.0f);
+        const float val = sg * l1;
+        codes[sv] = (CodeT)code;
+        u[sv] = val;
+        lmin = fminf(lmin, val);
+        lmax = fmaxf(lmax, val);
+    }
+    write_minmax_partials(lmin, lmax, partials);
+}
+
+template <typename CodeT>
+static int launch_pvq_lds(const float *grad, const float *cdag, int64_t M, int d, int K, int random_mode, const float *r,
+                          uint64_t seed, CodeT *codes, float *u, float *ws, hipStream_t st, bool *done) {
+    int dpad = 0, chunk_rows = 0;
+    size_t lds_bytes = 0;
+    *done = false;
+    if (!lds_plan(d, K, &dpad, &chunk_rows, &lds_bytes)) return GQ_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pvq_encode_lds_kernel<CodeT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
+    const int bpc = resident_blocks_per_cu(pvq_encode_lds_kernel<CodeT>, ENC_THREADS, lds_bytes);
+    const int64_t ntiles = (M + 63) / 64;
+    int64_t blocks = (ntiles + ENC_WAVES - 1) / ENC_WAVES;
+    int64_t cap = (int64_t)cu_count() * bpc;
+    if (cap > GQ_MAIN_PARTIALS) cap = GQ_MAIN_PARTIALS;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(pvq_encode_lds_kernel<CodeT>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds_bytes,
+                       st, grad, cdag, M, d, K, random_mode, r, seed, codes, u, ws, dpad, chunk_rows);
+    GQ_CHECK_LAUNCH("gq_pvq_encode (mfma)");
+    *done = true;
+    return GQ_OK;
+}
+
 template <typename CodeT, int D>
 static int launch_pvq(const float *grad, const float *cdag, int64_t M, int K, int random_mode, const float *r,
                       uint64_t seed, CodeT *codes, float *u, float *ws, hipStream_t st) {
@@ -116,6 +287,12 @@ static int launch_pvq(const float *grad, const float *cdag, int64_t M, int K, in
 template <typename CodeT>
 static int dispatch_pvq(const float *grad, const float *cdag, int64_t M, int d, int K, int random_mode,
                         const float *r, uint64_t seed, CodeT *codes, float *u, float *ws, hipStream_t st) {
+    static const bool valu_only = getenv("GQ_PVQ_VALU") != nullptr;   // tests: the VALU cross-check kernel
+    if (!valu_only) {
+        bool done = false;
+        const int rc = launch_pvq_lds<CodeT>(grad, cdag, M, d, K, random_mode, r, seed, codes, u, ws, st, &done);
+        if (rc != GQ_OK || done) return rc;
+    }
     switch (d) {
 #define GQ_PV_CASE(DD) \
     case DD:           \

@@ -268,7 +268,8 @@ int gq_qsgd_decode_sum(const float *norm, const uint8_t *signs, const void *leve
  * r: one uniform draw per subvector (GQ_RANDOM_GIVEN: caller-supplied r[M]; GQ_RANDOM_DEVICE: in-kernel).
  * Outputs codes[M], u[M] and the (min,max) partials of u in `workspace` (gq_hsq_workspace_bytes(0)
  * bytes suffice) so that gq_hsq_levels / gq_hsq_decode_sum finish the compress / decompress
- * exactly as for the NearestNeighbor compressor.  d in {4,8,12,16,24,32,64}.
+ * exactly as for the NearestNeighbor compressor.  Any d <= 104 and any K on the matrix cores (exact f32 MFMA, the
+ * two sequential sums lane-local); beyond that d in {4,8,12,16,24,32,64} on the VALU kernel.
  */
 int gq_pvq_encode(const float *grad, const float *c_dagger, int64_t M, int d, int K, int random_mode, const float *r,
                   uint64_t seed, void *codes, int code_bytes, float *u, float *workspace, void *stream);

@@ -303,6 +303,37 @@ def test_full_size_properties(nat, oracle):
     assert np.array_equal(_bits(u[123457:123457 + 65536].cpu().numpy()), _bits(ru))
 
 
+@pytest.mark.parametrize("d,K,M", [(16, 256, 100003), (8, 32, 5000), (12, 100, 777), (32, 512, 3000), (48, 2048, 500),
+                                   (4, 16, 64), (10, 33, 4097), (16, 256, 1)])
+def test_pvq_encode_on_the_matrix_cores_matches_the_oracle(nat, oracle, d, K, M):
+    """ProbabilisticVectorCompressor encode (intended semantics; parity with the reference unpinned): the MFMA
+    kernel (any d <= 104, any K; whole and chunked codebooks, K no multiple of 32, ragged tiles) against the CPU
+    restatement for the same draws r -- codes, u and the (min,max) of u bit for bit; and against the VALU
+    cross-check kernel where that one is built."""
+    rng = np.random.RandomState(d * 131 + K)
+    cdag = rng.standard_normal((K, d)).astype(np.float32) * 0.3
+    x = (rng.standard_normal(M * d) * 0.05).astype(np.float32)
+    if M > 2:
+        x[d:2 * d] = 0.0                      # an all-zero subvector: l1 = 0, NaN walk -> code K-1, u = 0
+    r = rng.random_sample(M).astype(np.float32)
+    r[0] = 0.0
+    r[-1] = np.float32(1.0) - np.float32(2.0 ** -24)
+    dev = torch.device("cuda:0")
+    g, c, rt = torch.from_numpy(x).to(dev), torch.from_numpy(cdag).to(dev), torch.from_numpy(r).to(dev)
+    codes = torch.empty(M, dtype=torch.uint8 if K <= 256 else torch.int32, device=dev)
+    u = torch.empty(M, dtype=torch.float32, device=dev)
+    ws = nat.new_workspace(dev, M)
+    nat.pvq_encode(g, c, codes, u, ws, nat.RANDOM_GIVEN, rt, 0)
+    torch.cuda.synchronize()
+    oc, ou = oracle.pvq_encode(x, cdag, r)
+    assert np.array_equal(codes.cpu().numpy().astype(np.int64), oc.astype(np.int64))
+    assert np.array_equal(_bits(u.cpu().numpy()), _bits(ou))
+    lb_ub = torch.empty(2, dtype=torch.float32, device=dev)
+    levels = torch.empty(M, dtype=torch.uint8, device=dev)
+    nat.hsq_levels(u, 6, 0, None, 0, ws, lb_ub, levels)
+    assert lb_ub[0].item() == float(ou.min()) and lb_ub[1].item() == float(ou.max())
+
+
 def test_full_size_compress_and_decode_mean_equal_the_oracle(nat, oracle):
     """BASELINE size, everything against the oracle bit for bit: three ranks' 25 M-element gradients compressed
     (codes, u, lb, ub, levels) and their decode-mean (R = 1 and R = 3) -- rare-event errors (one subvector in

@@ -1,21 +1,23 @@
-"""ProbabilisticVectorCompressor / ResidualCompressor compress times on a 25 M-element gradient."""
-import os, sys, time
-from argparse import Namespace
+"""gq_pvq_encode on 25 M elements (d 16, K 256): the MFMA kernel and, with GQ_PVQ_VALU=1, the VALU cross-check."""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gradient-quantization_amd"))
-import torch
-from gq_amd.compressors import ProbabilisticVectorCompressor, ResidualCompressor, NearestNeighborCompressor
-x = torch.randn(25_000_000, device="cuda")
-def t(fn, reps=5):
-    for _ in range(2): fn()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(reps): fn()
-    torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
-for k_bit in (8, 0):
-    a = Namespace(c_dim=16, k_bit=k_bit, n_bit=6, no_cuda=False, random=1, ef=False, two_phase=False, scale="exp", num_users=1, mode="ps", cr=256)
-    for cls in (ProbabilisticVectorCompressor, ResidualCompressor, NearestNeighborCompressor):
-        try:
-            c = cls(x.numel(), x.shape, a)
-            print("%-32s k_bit=%d: compress %.3f ms, roundtrip %.3f ms" % (cls.__name__, k_bit, t(lambda: c.compress(x)), t(lambda: c.decompress(c.compress(x)))))
-        except Exception as e:
-            print(cls.__name__, k_bit, "->", type(e).__name__, str(e)[:100])
+import numpy as np, torch
+from gq_amd import native
+from gq_amd.codebook import load_codebook
+dev = torch.device("cuda:0")
+cb = load_codebook(16, 256)
+cdag = torch.from_numpy(np.linalg.pinv(cb.T).astype(np.float32)).contiguous().to(dev)
+g = torch.randn(25_000_000, device=dev) * 1e-2
+M = g.numel() // 16
+codes = torch.empty(M, dtype=torch.uint8, device=dev); u = torch.empty(M, dtype=torch.float32, device=dev)
+ws = native.new_workspace(dev, M)
+for _ in range(3):
+    native.pvq_encode(g, cdag, codes, u, ws, native.RANDOM_DEVICE, None, 7)
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(10):
+    native.pvq_encode(g, cdag, codes, u, ws, native.RANDOM_DEVICE, None, 7)
+e.record(); torch.cuda.synchronize()
+print("%s: %.1f us per 25 M elements" % ("VALU kernel" if os.environ.get("GQ_PVQ_VALU") else "MFMA kernel", s.elapsed_time(e) / 10 * 1e3))
