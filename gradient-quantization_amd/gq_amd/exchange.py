@@ -1,0 +1,165 @@
+"""The exchange step of the parameter-server aggregate: every rank's compressed wire to every rank.
+
+The reference has no exchange at all -- its `num_users` live in one process and `apply()` stacks their
+DECODED tensors (quantizers/ps_quantizer.py:44-48).  Here each rank owns `users` rows of ONE buffer
+
+    gathered  uint8 [world * users, user_bytes]        (row = rank * users + user)
+
+and its kernels write the wire straight into those rows, so there is no staging copy on either side
+of the exchange.  Three ways to fill the other ranks' rows, all bit-identical in their result:
+
+    "allgather"  one in-place all_gather_into_tensor (RCCL picks ring / tree).
+    "direct"     all-pairs: one grouped isend / irecv per peer (RCCL: ncclGroupStart .. ncclSend/ncclRecv
+                 .. ncclGroupEnd).  xGMI on an MI355X node is point-to-point -- 7 links of ~153 GB/s per
+                 GPU -- so every peer's row can travel over its own link at the same time, whereas a ring
+                 pushes world-1 rows through one link one after the other.
+    "split"      "direct" in two byte ranges [0, cut) and [cut, user_bytes): both are queued at once, the
+                 caller decodes the first range while the second is still in flight (needs one user per
+                 rank so that a row's byte range is contiguous; otherwise it degrades to "direct").
+
+`GQ_EXCHANGE` selects the mode ("auto": time all of them on the first exchange and keep the fastest,
+every rank taking the same decision from the all-reduced maxima).  Collectives run on the process
+group's own stream; `Work.wait()` makes torch's current stream wait for them without blocking the host.
+"""
+import os
+import time
+
+import torch
+
+MODES = ("allgather", "direct", "split")
+
+
+def configured_mode(default="allgather"):
+    mode = os.environ.get("GQ_EXCHANGE", default)
+    if mode not in MODES + ("auto",):
+        raise ValueError("GQ_EXCHANGE must be one of %s or 'auto', got %r" % (", ".join(MODES), mode))
+    return mode
+
+
+class _Pending(object):
+    """Outstanding transfers of one byte range; wait() orders the current stream behind them."""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+class WireExchange(object):
+    """Owns the [world * users, user_bytes] buffer of one quantizer / bench and moves the rows."""
+
+    def __init__(self, world, rank, users, user_bytes, device, group=None):
+        self.world, self.rank, self.users, self.user_bytes = world, rank, users, user_bytes
+        self.group = group
+        self.gathered = torch.zeros((world * users, user_bytes), dtype=torch.uint8, device=device)
+        self.timings_ms = None          # filled by autotune()
+
+    # ---- views ------------------------------------------------------------------------------
+    @property
+    def local(self):
+        """This rank's own rows: the kernels write the wire here."""
+        return self.gathered[self.rank * self.users:(self.rank + 1) * self.users]
+
+    def _peer(self, group_rank):
+        import torch.distributed as dist
+        return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
+
+    # ---- the three transports ---------------------------------------------------------------
+    def _allgather(self, rows):
+        import torch.distributed as dist
+        n = rows * self.user_bytes
+        flat = self.gathered.view(-1)
+        if rows == self.users:
+            out = flat
+            inp = flat[self.rank * n:(self.rank + 1) * n]
+        else:   # fewer records than slots this step: gather the used rows of every rank, rank-major
+            out = self._partial_buffer(rows).view(-1)
+            inp = self.local[:rows].reshape(-1)
+        w = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
+        return _Pending([w])
+
+    def _partial_buffer(self, rows):
+        buf = getattr(self, "_partial", None)
+        if buf is None or buf.shape[0] != self.world * rows:
+            buf = self._partial = torch.empty((self.world * rows, self.user_bytes), dtype=torch.uint8,
+                                              device=self.gathered.device)
+        return buf
+
+    def _direct(self, rows, lo, hi):
+        """Grouped point-to-point transfers of bytes [lo, hi) of the first `rows` rows of every rank."""
+        import torch.distributed as dist
+        ops = []
+        whole = lo == 0 and hi == self.user_bytes
+        target = self.gathered if rows == self.users else self._partial_buffer(rows)
+        if rows != self.users:
+            target[self.rank * rows:(self.rank + 1) * rows].copy_(self.local[:rows])
+        for step in range(1, self.world):
+            # peers in a rotated order: at step s every rank sends to rank+s and receives from rank-s, so
+            # that no two ranks aim at the same receiver in the same position of their groups
+            dst = (self.rank + step) % self.world
+            src = (self.rank - step) % self.world
+            mine = target[self.rank * rows:(self.rank + 1) * rows]
+            theirs = target[src * rows:(src + 1) * rows]
+            if whole:
+                send_t, recv_t = mine.view(-1), theirs.view(-1)
+            else:
+                assert rows == 1, "a byte range of several rows is not contiguous"
+                send_t, recv_t = mine[0, lo:hi], theirs[0, lo:hi]
+            ops.append(dist.P2POp(dist.isend, send_t, self._peer(dst), group=self.group))
+            ops.append(dist.P2POp(dist.irecv, recv_t, self._peer(src), group=self.group))
+        return _Pending(dist.batch_isend_irecv(ops) if ops else [])
+
+    # ---- public -----------------------------------------------------------------------------
+    def start(self, mode, rows=None, cut=None):
+        """Queue the exchange of the first `rows` rows per rank.  Returns (buffer, [pending...]): one pending
+        transfer for "allgather" / "direct", two for "split" (bytes [0, cut) then [cut, user_bytes))."""
+        rows = self.users if rows is None else rows
+        buf = self.gathered if rows == self.users else self._partial_buffer(rows)
+        if self.world == 1:
+            return (self.gathered[:rows], [])
+        if mode == "split" and (rows != 1 or not cut or cut <= 0 or cut >= self.user_bytes):
+            mode = "direct"
+        if mode == "allgather":
+            return buf, [self._allgather(rows)]
+        if mode == "direct":
+            return buf, [self._direct(rows, 0, self.user_bytes)]
+        if mode == "split":
+            first = self._direct(rows, 0, cut)
+            second = self._direct(rows, cut, self.user_bytes)
+            return buf, [first, second]
+        raise ValueError(mode)
+
+    def run(self, mode, rows=None):
+        """Exchange and wait (stream-ordered): the whole gathered buffer is valid for kernels queued next."""
+        buf, pending = self.start(mode, rows, cut=self.user_bytes // 2 // 16 * 16)
+        for p in pending:
+            p.wait()
+        return buf
+
+    def autotune(self, step_fn, rounds=10):
+        """Time step_fn(mode) -- the caller's exchange (+ decode) for that transport; it is idempotent -- for
+        every mode and return the fastest.  Times are maxima over ranks: every rank returns the same mode."""
+        import torch.distributed as dist
+        if self.world == 1:
+            return "allgather"
+        cuda = self.gathered.device.type == "cuda"
+        res = {}
+        for mode in MODES:
+            for _ in range(2):
+                step_fn(mode)
+            if cuda:
+                torch.cuda.synchronize()
+            dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            for _ in range(rounds):
+                step_fn(mode)
+            if cuda:
+                torch.cuda.synchronize()
+            res[mode] = (time.perf_counter() - t0) / rounds * 1e3
+        t = torch.tensor([res[m] for m in MODES], dtype=torch.float64, device=self.gathered.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        self.timings_ms = {m: float(v) for m, v in zip(MODES, t.tolist())}
+        return min(MODES, key=lambda m: (self.timings_ms[m], MODES.index(m)))

@@ -26,7 +26,7 @@ import math
 
 import torch
 
-from . import native
+from . import exchange, native
 from .compressors import (IdenticalCompressor, NearestNeighborCompressor, QSGDCompressor, _next_seed,
                           _require_device)
 
@@ -282,11 +282,17 @@ class _BatchedBase(object):
         self._tmp_wire = None
         self.ready = False      # the device header has been written at least once
         self._outs, self._out_views, self._out_turn = [None, None], [None, None], 0
+        self._layout = table.clone()    # host copy of the segment table without pointers (decode needs no pointers)
+        self._tail = None               # (first segment, first item, table, item->segment) of a split decode's second part
 
-    def _out_buffer(self, device):
+    def _out_buffer(self, device, advance=True):
         """Decode target + its per-tensor views.  Two buffers used in turn (the mean and its two-phase
         re-decode never alias; last step's gradients stay intact for one more apply) and the 76+
-        slice/view objects of a model are built once instead of every step."""
+        slice/view objects of a model are built once instead of every step.  advance=False: the buffer
+        of the previous call again (second part of a split decode)."""
+        if not advance:
+            k = self._out_turn ^ 1
+            return self._outs[k], self._out_views[k]
         k = self._out_turn
         self._out_turn ^= 1
         if self._outs[k] is None or self._outs[k].device != device:
@@ -323,6 +329,40 @@ class _BatchedBase(object):
         ev.record()
         self._events[slot] = ev
         return True
+
+    def _part(self, part, first_seg):
+        """Tables of one part of a split decode (PSQuantizer.apply under GQ_EXCHANGE=split): "head" = the
+        tensors before segment `first_seg` (the same device table, fewer items), "tail" = the others (a table
+        of their own, built once: segment and item indices restart at zero).  Returns (table, item->segment,
+        nseg, nitems) or None when the part is empty."""
+        first_item = int(self._layout[first_seg, 2]) if first_seg < self.nseg else self._nitems
+        if part == "head":
+            if first_seg == 0:
+                return None
+            return self._dev[:self._table_words], self._item_seg, first_seg, first_item
+        if first_seg >= self.nseg:
+            return None
+        if self._tail is None or self._tail[0] != first_seg:
+            tab = self._layout[first_seg:].clone()
+            tab[:, 2] -= first_item
+            items = (self._item_seg[first_item:] - first_seg).contiguous()
+            self._tail = (first_seg, first_item, tab.view(-1).to(self.device), items)
+        return self._tail[2], self._tail[3], self.nseg - first_seg, self._nitems - first_item
+
+    def decode_mean(self, gathered, R, part=None, first_seg=0):
+        """Mean of the R payloads of `gathered` for every tensor of the group (views of one output buffer).
+        part = "head" / "tail": only the tensors before / from segment `first_seg` (the two halves of a split
+        exchange land in the same buffer: "head" first, then "tail")."""
+        if not self.ready:      # a rank that decodes before it has encoded anything (ring hop, late joiner)
+            self.upload_layout()
+        out, views = self._out_buffer(gathered.device, advance=part != "tail")
+        if part is None:
+            self._launch_decode(self._dev[:self._table_words], self._item_seg, self.nseg, self._nitems, gathered, R, out)
+        else:
+            tabs = self._part(part, first_seg)
+            if tabs is not None:
+                self._launch_decode(tabs[0], tabs[1], tabs[2], tabs[3], gathered, R, out)
+        return views
 
     def upload_layout(self):
         """Device header with the layout columns only (no tensor pointers): enough for decode_mean,
@@ -394,6 +434,7 @@ class BatchedHSQ(_BatchedBase):
             out_off += cd.numel
         self.ntiles, self.out_floats = tile, out_off
         self.tile_seg = torch.tensor(tile_seg, dtype=torch.int32, device=device)
+        self._item_seg, self._nitems = self.tile_seg, tile
         init = torch.empty((nseg, 2), dtype=torch.int32)
         init[:, 0], init[:, 1] = -1, 0            # 0xFFFFFFFF / 0: identities of the mapped min / max
         self._setup(table, init.view(torch.int64), device, slots, user_bytes)
@@ -443,16 +484,12 @@ class BatchedHSQ(_BatchedBase):
                                          self.code_dtype, self.level_dtype, self.n_bit)
         return True
 
-    def decode_mean(self, gathered, R):
-        out, views = self._out_buffer(gathered.device)
+    def _launch_decode(self, table, tile_seg, nseg, ntiles, gathered, R, out):
         if self.bytes:
-            native.hsq_decode_sum_batched(self._dev[:self._table_words], self.tile_seg, self.nseg, self.ntiles, gathered,
-                                          self.codebook, self.n_bit, out, R)
+            native.hsq_decode_sum_batched(table, tile_seg, nseg, ntiles, gathered, self.codebook, self.n_bit, out, R)
         else:
-            native.hsq_decode_sum_batched_any(self._dev[:self._table_words], self.tile_seg, self.nseg, self.ntiles,
-                                              gathered, self.codebook, self.code_dtype, self.level_dtype, self.n_bit, out,
-                                              R)
-        return views
+            native.hsq_decode_sum_batched_any(table, tile_seg, nseg, ntiles, gathered, self.codebook, self.code_dtype,
+                                              self.level_dtype, self.n_bit, out, R)
 
 
 class BatchedQSGD(_BatchedBase):
@@ -498,6 +535,7 @@ class BatchedQSGD(_BatchedBase):
             out_off += (cd.numel + 3) & ~3          # tensors start 16-byte aligned in `out` (dwordx4 stores)
         self.nbuckets, self.out_floats = item, out_off
         self.bucket_seg = torch.tensor(item_seg, dtype=torch.int32, device=device)
+        self._item_seg, self._nitems = self.bucket_seg, item
         # wide: max |v| per bucket is folded into words that the per-step header resets to zero
         extra = torch.zeros((word + 1) // 2, dtype=torch.int64) if self.wide else None
         self._setup(table, extra, device, slots, user_bytes)
@@ -517,11 +555,9 @@ class BatchedQSGD(_BatchedBase):
                                          self.n_bit, mode, seed, wire_user, ef_scale=ef)
         return True
 
-    def decode_mean(self, gathered, R):
-        out, views = self._out_buffer(gathered.device)
+    def _launch_decode(self, table, bucket_seg, nseg, nbuckets, gathered, R, out):
         fn = native.qsgd_wide_decode_sum if self.wide else native.qsgd_decode_sum_batched
-        fn(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets, self.n_bit, self.bits, gathered, out, R)
-        return views
+        fn(table, bucket_seg, nseg, nbuckets, self.n_bit, self.bits, gathered, out, R)
 
 
 def default_codec_factory(compressor, numel, shape):
@@ -603,15 +639,31 @@ class PSQuantizer(object):
         self.capacity = max(1, int(args.num_users))
         self.recorded = 0                   # record() calls since the last apply()
         self._wire = None
-        self._gathered = None
+        self._ex = None                     # exchange.WireExchange when torch.distributed is initialised
+        self.exchange_mode = exchange.configured_mode()    # $GQ_EXCHANGE: allgather | direct | split | auto
+        # split exchange: bytes [0, cut) travel (and are decoded) first; the cut lies on a tensor boundary near the
+        # middle of the compressed part of the wire
+        bounds = [self.offsets[i] for i in range(self.num_layers) if i not in self.dense_idx]
+        later = [o for o in bounds if o >= self.dense_off // 2]
+        self.cut = min(later) if later else 0
 
     # ---- buffers -------------------------------------------------------------------------
     def _ensure_wire(self, device, slots):
-        if self._wire is None or self._wire.device != device or self._wire.shape[0] < slots:
+        """This rank's [capacity, user_bytes] wire.  Under torch.distributed it is this rank's block of rows of
+        the exchange buffer (gq_amd.exchange): the kernels write where the collective reads."""
+        world, rank = _dist_world(self.process_group)
+        if (self._wire is None or self._wire.device != device or self._wire.shape[0] < slots
+                or (world > 1) != (self._ex is not None)):
             cap = max(self.capacity, slots)
-            new = torch.zeros((cap, self.user_bytes), dtype=torch.uint8, device=device)
-            if self._wire is not None and self._wire.device == device:
-                new[:self._wire.shape[0]].copy_(self._wire)
+            old = self._wire
+            if world > 1:
+                self._ex = exchange.WireExchange(world, rank, cap, self.user_bytes, device, self.process_group)
+                new = self._ex.local
+            else:
+                self._ex = None
+                new = torch.zeros((cap, self.user_bytes), dtype=torch.uint8, device=device)
+            if old is not None and old.device == device:
+                new[:min(cap, old.shape[0])].copy_(old[:cap])
             self._wire = new
             self.capacity = cap
         return self._wire
@@ -682,22 +734,49 @@ class PSQuantizer(object):
                 codec.encode_into(grad, wire, off, salt)
         self.recorded += 1
 
-    def _decode_all(self, gathered, two_phase):
+    def _decode_all(self, gathered, two_phase, pending=()):
         """Mean of the R = gathered.shape[0] user payloads for every parameter (ps_quantizer.py:47-61),
-        as a list of tensors in parameter order."""
+        as a list of tensors in parameter order.  `pending`: the transfers that fill `gathered`
+        (exchange.WireExchange.start) -- one, or two for a split exchange, in which case the tensors below
+        self.cut are decoded while the rest of the wire is still in flight."""
         R = gathered.shape[0]
         done = {}
-        for cls, idxs, obj in (self._groups if gathered.device.type == "cuda" else []):
-            if obj is None or not obj.ready:
-                continue
-            gs = obj.decode_mean(gathered, R)
+        pending = list(pending)
+        split = len(pending) == 2
+        on_gpu = gathered.device.type == "cuda"
+        groups = [g for g in (self._groups if on_gpu else []) if g[2] is not None]
+        batched = set(i for g in groups for i in g[1])
+        single = [i for i in range(self.num_layers) if i not in batched and i not in self.dense_idx or
+                  (i in self.dense_idx and len(self.dense_idx) < 2)]
+        group_views = {}
+
+        def decode_part(part):
+            for gi, (cls, idxs, obj) in enumerate(groups):
+                first = sum(1 for i in idxs if self.offsets[i] < self.cut) if split else 0
+                group_views[gi] = obj.decode_mean(gathered, R, part if split else None, first)
+            for i in single:
+                if split and (self.offsets[i] < self.cut) != (part == "head"):
+                    continue
+                done[i] = self.codecs[i].decode_mean(gathered, self.offsets[i], R)
+
+        if pending:
+            pending.pop(0).wait()
+        decode_part("head")
+        if split:
+            pending.pop(0).wait()
+            decode_part("tail")
+        for gi, (cls, idxs, obj) in enumerate(groups):
+            gs = group_views[gi]
             if two_phase:
                 # ps_quantizer.py:52-61, replicated on every rank (salt 0, same call count); with error
                 # feedback g += server_error and server_error = g - decoded happen inside the launches
                 serr = [self.parameters[i].server_error for i in idxs] if self.error_feedback else None
                 dec = obj.roundtrip(list(gs), self.capacity, 0, serr, 1.0)
-                if dec is None:
-                    continue     # not batchable: the per-tensor loop below handles these tensors
+                if dec is None:     # not batchable this step: per-tensor second phase below
+                    for i, g in zip(idxs, gs):
+                        done[i] = g
+                        single.append(i)
+                    continue
                 gs = dec
             for i, g in zip(idxs, gs):
                 done[i] = g
@@ -717,15 +796,10 @@ class PSQuantizer(object):
             torch.mean(rows, dim=0, out=self._dense_mean[k])   # stack().mean(0) of the reference, all at once
             for i, v in zip(self.dense_idx, self._dense_views[k]):
                 done[i] = v
-        out = []
-        for i, param in enumerate(self.parameters):
-            if i in done:
-                out.append(done[i])
-                continue
-            codec, off = self.codecs[i], self.offsets[i]
-            g = codec.decode_mean(gathered, off, R)
-            if two_phase:
+        if two_phase:
+            for i in single:
                 # ps_quantizer.py:52-61 -- identical on every rank (salt 0, same call count)
+                param, codec, g = self.parameters[i], self.codecs[i], done[i]
                 if self.error_feedback:
                     g = g + param.server_error
                     decoded = codec.roundtrip(g, 0)
@@ -733,26 +807,25 @@ class PSQuantizer(object):
                     g = decoded
                 else:
                     g = codec.roundtrip(g, 0)
-            out.append(g)
-        return out
+                done[i] = g
+        return [done[i] for i in range(self.num_layers)]
 
     def apply(self):
         if self.recorded == 0:
             return
         world, rank = _dist_world(self.process_group)
-        local = self._wire[:self.recorded]
         if world > 1:
-            import torch.distributed as dist
-            need = (world * self.recorded, self.user_bytes)
-            if self._gathered is None or tuple(self._gathered.shape) != need or self._gathered.device != local.device:
-                self._gathered = torch.empty(need, dtype=torch.uint8, device=local.device)
-            # ONE collective per step: every rank's [users, bytes] block, rank-major
-            dist.all_gather_into_tensor(self._gathered.view(-1), local.contiguous().view(-1),
-                                        group=self.process_group)
-            gathered = self._gathered
+            # ONE exchange per step: every rank's [users, bytes] block, rank-major (gq_amd.exchange)
+            ex = self._ex
+            if self.exchange_mode == "auto":
+                def step(mode):
+                    buf, pend = ex.start(mode, self.recorded, self.cut)
+                    self._decode_all(buf, False, pend)
+                self.exchange_mode = ex.autotune(step)
+            gathered, pending = ex.start(self.exchange_mode, self.recorded, self.cut)
         else:
-            gathered = local
-        for param, g in zip(self.parameters, self._decode_all(gathered, self.two_phase)):
+            gathered, pending = self._wire[:self.recorded], ()
+        for param, g in zip(self.parameters, self._decode_all(gathered, self.two_phase, pending)):
             param.grad.data = g
         self.recorded = 0
 

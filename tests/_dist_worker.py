@@ -1,4 +1,4 @@
-"""Worker for the gloo world_size-2 test (tests/test_host_logic.py).  TEST-ONLY."""
+"""Worker for the multi-rank gloo tests (tests/test_host_logic.py): world 1..8, every exchange mode.  TEST-ONLY."""
 import os
 import sys
 from argparse import Namespace
@@ -40,12 +40,12 @@ def run(quantizer, params, local_users, first_global_user, steps=2):
     return out
 
 
-def build(users, mode="ps"):
+def build(users, mode="ps", slots=None):
     from oracle_codec import oracle_codec_factory
     from gq_amd.compressors import NearestNeighborCompressor
     from gq_amd.quantizers import Quantizer
     params = [torch.nn.Parameter(torch.zeros(*s)) for s in SHAPES]
-    q = Quantizer(NearestNeighborCompressor, params, make_args(users, mode=mode), codec_factory=oracle_codec_factory)
+    q = Quantizer(NearestNeighborCompressor, params, make_args(slots or users, mode=mode), codec_factory=oracle_codec_factory)
     return q, params
 
 
@@ -57,11 +57,14 @@ def run_single_process(total_users, mode="ps"):
 if __name__ == "__main__":
     rank, world, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     mode = sys.argv[4] if len(sys.argv) > 4 else "ps"
+    local = int(sys.argv[5]) if len(sys.argv) > 5 else 2          # users recorded per rank and step
+    slots = int(sys.argv[6]) if len(sys.argv) > 6 else local      # args.num_users (wire slots per rank)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    local = 2
-    q, params = build(local, mode)
+    q, params = build(local, mode, slots)
     res = run(q, params, local, rank * local)
+    if mode == "ps":
+        res["exchange_mode"] = np.array(q.exchange_mode)
     np.savez(out + "_rank%d.npz" % rank, **res)
     dist.barrier()
     dist.destroy_process_group()

@@ -47,7 +47,9 @@ def build(users, mode, quant, **kw):
     params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in SHAPES]
     if quant == "qsgd":
         kw.update(c_dim=128, n_bit=2)
-    comp = QSGDCompressor if quant == "qsgd" else NearestNeighborCompressor
+    if quant == "terngrad":     # one bucket per tensor: wide and narrow tensors end up in single-tensor groups
+        kw.update(c_dim=0, n_bit=1, gq_no_batch=True)
+    comp = NearestNeighborCompressor if quant == "hsq" else QSGDCompressor
     return Quantizer(comp, params, make_args(users, mode=mode, **kw)), params
 
 
@@ -60,7 +62,7 @@ if __name__ == "__main__":
     rank, world, out, mode, quant, ef = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6] == "1"
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    local = 2
+    local = int(sys.argv[7]) if len(sys.argv) > 7 else 2
     q, params = build(local, mode, quant, ef=ef)
     res = run(q, params, local, rank * local)
     np.savez(out + "_rank%d.npz" % rank, **res)

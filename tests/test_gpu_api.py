@@ -765,7 +765,8 @@ def test_prefilter_on_real_resnet50_gradients_equals_exact_kernel(oracle):
     assert fixed < 0.02 * total
 
 
-@pytest.mark.parametrize("mode,quant,ef", [("ps", "hsq", False), ("ps", "hsq", True), ("ring", "hsq", True), ("ps", "qsgd", False)])
+@pytest.mark.parametrize("mode,quant,ef", [("ps", "hsq", False), ("ps", "hsq", True), ("ring", "hsq", True), ("ps", "qsgd", False),
+                                           ("ring", "qsgd", False), ("ring", "terngrad", False)])
 def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, mode, quant, ef):
     """The distributed product path with the REAL kernels: two ranks (two local users each) drive the HIP library
     on cuda:0 and exchange the wire over gloo (RCCL refuses two ranks on one GPU); the result equals four users
@@ -774,7 +775,7 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, mode, quant, ef):
     import sys
     script = os.path.join(HERE, "_dist_worker_gpu.py")
     out = str(tmp_path / "res")
-    port = 29800 + (os.getpid() % 1500) + {"ps": 0, "ring": 3}[mode] + (5 if quant == "qsgd" else 0) + (11 if ef else 0)
+    port = 29800 + (os.getpid() % 1500) + {"ps": 0, "ring": 3}[mode] + {"hsq": 0, "qsgd": 5, "terngrad": 17}[quant] + (11 if ef else 0)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     procs = [subprocess.Popen([sys.executable, script, str(r), "2", out, mode, quant, "1" if ef else "0"], env=env) for r in range(2)]
     for p in procs:
@@ -785,6 +786,30 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, mode, quant, ef):
     sys.path.insert(0, HERE)
     import _dist_worker_gpu as w
     single = w.run_single_process(4, mode, quant, ef=ef)
+    for k in single:
+        assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
+
+
+@pytest.mark.parametrize("exchange,users", [("direct", 2), ("split", 1), ("auto", 1)])
+def test_two_ranks_on_one_gpu_every_exchange_transport(tmp_path, exchange, users):
+    """gq_amd/exchange.py with the real kernels: direct all-pairs, split (the tensors below the cut are decoded by the
+    multi-tensor kernels' "head" launch while the rest of the wire is in flight, then the "tail" launch) and auto ==
+    the same users in one process, bit for bit (HSQ and the small dense tensors; error feedback on)."""
+    import subprocess
+    import sys
+    script = os.path.join(HERE, "_dist_worker_gpu.py")
+    out = str(tmp_path / "res")
+    port = 29900 + (os.getpid() % 1500) + len(exchange)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GQ_EXCHANGE=exchange)
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", out, "ps", "hsq", "1", str(users)], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r0, r1 = np.load(out + "_rank0.npz"), np.load(out + "_rank1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k].view(np.uint32), r1[k].view(np.uint32)), "ranks disagree on " + k
+    sys.path.insert(0, HERE)
+    import _dist_worker_gpu as w
+    single = w.run_single_process(2 * users, "ps", "hsq", ef=True)
     for k in single:
         assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
 

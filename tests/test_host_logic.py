@@ -255,28 +255,52 @@ def test_ring_quantizer_semantics(oracle):
     assert np.array_equal(p.grad.data.numpy(), run)
 
 
-# ---- world_size 2 over gloo -----------------------------------------------------------
-@pytest.mark.parametrize("mode", ["ps", "ring"])
-def test_quantizer_two_ranks_gloo(tmp_path, oracle, mode):
-    """2 ranks x 2 local users over gloo == 4 simulated users in one process, bitwise.  ps: the
-    payloads are summed in (rank, user) order either way.  ring: the compressed running sum hops
-    rank 0 -> rank 1 and the last rank's wire is broadcast (ring_quantizer.py semantics with the users
-    numbered rank-major)."""
+# ---- world_size 1..8 over gloo ---------------------------------------------------------
+def _run_ranks(tmp_path, world, mode, users, exchange, slots=None, tag=0):
     script = os.path.join(HERE, "_dist_worker.py")
     out = str(tmp_path / "res")
-    port = 29500 + (os.getpid() % 2000) + (7 if mode == "ring" else 0)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GQ_CODEBOOK_DIR=os.path.join(GOLDEN, "codebooks"))
-    procs = [subprocess.Popen([sys.executable, script, str(r), "2", out, mode], env=env) for r in range(2)]
+    port = 29500 + (os.getpid() * 7 + tag * 13) % 2000
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GQ_EXCHANGE=exchange,
+               GQ_CODEBOOK_DIR=os.path.join(GOLDEN, "codebooks"), OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), out, mode, str(users), str(slots or users)],
+                              env=env) for r in range(world)]
     for p in procs:
-        assert p.wait(timeout=300) == 0
-    r0 = np.load(out + "_rank0.npz")
-    r1 = np.load(out + "_rank1.npz")
-    for k in r0.files:
-        assert np.array_equal(r0[k], r1[k]), "ranks disagree on " + k
-    # single-process reference run with 4 users
+        assert p.wait(timeout=600) == 0
+    res = [np.load(out + "_rank%d.npz" % r) for r in range(world)]
+    for r in range(1, world):
+        for k in res[0].files:
+            assert np.array_equal(res[0][k], res[r][k]), "ranks 0 and %d disagree on %s" % (r, k)
+    return res[0]
+
+
+@pytest.mark.parametrize("world,users,mode,exchange", [
+    (2, 2, "ps", "allgather"), (2, 2, "ring", "allgather"), (2, 2, "ps", "direct"), (2, 1, "ps", "split"),
+    (1, 4, "ps", "allgather"), (4, 1, "ps", "split"), (4, 2, "ps", "auto"), (8, 1, "ps", "direct"),
+    (8, 1, "ps", "allgather"), (8, 1, "ring", "allgather")])
+def test_quantizer_ranks_gloo(tmp_path, oracle, world, users, mode, exchange):
+    """R ranks x U local users over gloo == R*U simulated users in one process, bitwise, for R = 1, 2, 4, 8 and every
+    exchange transport (gq_amd/exchange.py: all-gather, direct all-pairs, split with the decode of the first half
+    under the second half's transfer, auto = pick by timing).  ps: the payloads are summed in (rank, user) order
+    either way (ps_quantizer.py:48).  ring: the compressed running sum hops rank r -> r+1 and the last rank's wire
+    is broadcast (ring_quantizer.py semantics with the users numbered rank-major)."""
+    r0 = _run_ranks(tmp_path, world, mode, users, exchange, tag=world * 10 + users + len(exchange) + len(mode))
+    if mode == "ps" and exchange != "auto":
+        assert str(r0["exchange_mode"]) == exchange
     sys.path.insert(0, HERE)
     import _dist_worker as w
-    single = w.run_single_process(4, mode)
+    single = w.run_single_process(world * users, mode)
+    for k in single:
+        assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
+
+
+@pytest.mark.parametrize("exchange", ["allgather", "direct", "split"])
+def test_quantizer_ranks_gloo_fewer_records_than_slots(tmp_path, oracle, exchange):
+    """args.num_users = 3 wire slots per rank, but only 2 users are recorded per step: the exchange moves the used
+    rows only and the mean is over 2 * world payloads."""
+    r0 = _run_ranks(tmp_path, 2, "ps", 2, exchange, slots=3, tag=91 + len(exchange))
+    sys.path.insert(0, HERE)
+    import _dist_worker as w
+    single = w.run_single_process(4, "ps")
     for k in single:
         assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
 
