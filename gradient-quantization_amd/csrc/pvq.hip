@@ -1,12 +1,13 @@
 // ProbabilisticVectorCompressor encode (unbiased vector quantisation) for gfx950.
 //
-// Replaces probabilistic_vector_compressor.py:42-63 of the reference with its INTENDED
-// semantics (the reference's own implementation cannot run: it opens a codebook directory that
-// does not exist and calls argmin on a bool tensor, which torch >= 1.x rejects -- SURVEY.md 8c;
-// parity is therefore pinned by self-consistency tests, not by golden vectors):
-//     p     = C_dagger . v                    C_dagger = pinv(codewords^T),  [K, d]     (:47)
-//     l1    = sum_k |p_k|                                                            (:48)
-//     code  = first k with  cumsum_k(|p|) / l1  >=  r - 1e-5 ,   r ~ U[0,1) per subvector (:52-58)
+// Replaces probabilistic_vector_compressor.py:42-63 of the reference.  Pinned by tests/golden/pvq_*.npz and
+// residual_*.npz: the reference's own class produced them with ONE operation defined by the generator
+// (torch.argmin of a bool tensor, :58, exists in no torch: defined as "first True - 1", the inverse-CDF sample
+// the line is written for; tests/golden/make_golden.py), every other line unedited:
+//     p     = C_dagger . v                    C_dagger = pinv(codewords^T),  [K, d]     (:47)  fmaf chain
+//     l1    = sum_k |p_k|                     sequential f32 adds, k ascending               (:48)
+//     cum_k = f32( sum_{i<=k} f64(|p_i| / l1) )   torch.cumsum on the CPU accumulates in DOUBLE   (:49,:57)
+//     code  = first k with  cum_k  >=  r - 1e-5 ,   r ~ U[0,1) per subvector              (:52-58)
 //     u     = sign(p_code) * l1                                                     (:60-61)
 // so that E[ codewords[code] * u ] = sum_k p_k c_k = v  (unbiased for a full-rank codebook).
 // pvq_encode_lds_kernel (below) runs it on the matrix cores for any d <= 104; pvq_encode_kernel is the VALU
@@ -47,15 +48,16 @@ __global__ __launch_bounds__(PV_THREADS) void pvq_encode_kernel(const float *__r
         }
         const float rr = (random_mode == GQ_RANDOM_GIVEN) ? r[m] : uniform01(seed, (uint64_t)m);
         const float thr = rr - 1e-5f;
-        float cum = 0.0f, sel = 0.0f;
+        double cum = 0.0;   // torch.cumsum's accumulator on the CPU (acc_type<float> = double), outputs rounded to f32
+        float sel = 0.0f;
         int code = K - 1;
         bool found = false;
         for (int k = 0; k < K; ++k) {
             float acc = 0.0f;
 #pragma unroll
             for (int j = 0; j < D; ++j) acc = __fmaf_rn(cd[k * D + j], v[j], acc);
-            cum = cum + fabsf(acc) / l1;   // cumsum(|p| / l1), as the reference divides first (:49,:57)
-            const bool hit = !found && (cum >= thr);
+            cum = cum + (double)(fabsf(acc) / l1);   // cumsum(|p| / l1), as the reference divides first (:49,:57)
+            const bool hit = !found && ((float)cum >= thr);
             if (hit || (!found && k == K - 1)) {
                 code = k;
                 sel = acc;
@@ -158,7 +160,8 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float
         const bool active = t < ntiles;
         const int64_t sv = t * 64 + lane;           // this lane's subvector
         if (active) stage_tile(t);
-        float l1 = 0.0f, cum = 0.0f, thr = 0.0f;
+        float l1 = 0.0f, thr = 0.0f;
+        double cum = 0.0;   // torch.cumsum accumulates f32 input in double on the CPU; every output is rounded to f32
         int count = 0;
         for (int sweep = 0; sweep < 2; ++sweep) {
             if (sweep == 1) {
@@ -211,8 +214,8 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float
                                 if (sweep == 0) {
                                     l1 = l1 + a;
                                 } else {
-                                    cum = cum + a / l1;   // the reference divides first (:49,:57)
-                                    count += (cum >= thr) ? 0 : 1;
+                                    cum = cum + (double)(a / l1);   // the reference divides first (:49,:57)
+                                    count += ((float)cum >= thr) ? 0 : 1;
                                 }
                             }
                         }

@@ -744,7 +744,9 @@ class PSQuantizer(object):
         pending = list(pending)
         split = len(pending) == 2
         on_gpu = gathered.device.type == "cuda"
-        groups = [g for g in (self._groups if on_gpu else []) if g[2] is not None]
+        # a group that did not encode in multi-tensor form this run (unaligned tensors, too many of them) is not
+        # `ready`: its tensors take the per-tensor decode below
+        groups = [g for g in (self._groups if on_gpu else []) if g[2] is not None and g[2].ready]
         batched = set(i for g in groups for i in g[1])
         single = [i for i in range(self.num_layers) if i not in batched and i not in self.dense_idx or
                   (i in self.dense_idx and len(self.dense_idx) < 2)]

@@ -1,4 +1,4 @@
-"""Wire format of one rank's compressed gradient (what RCCL all-gathers over xGMI).
+"""Wire format of one rank's compressed gradient (what RCCL moves over xGMI).
 
 The reference never ships compressed bytes (ps_quantizer.py:41-43 decodes in place);
 this layout is what makes the (codes, levels) payload real.  For one HSQ tensor of M
@@ -8,6 +8,14 @@ subvectors with k_bit <= 8 and levels that fit a byte:
 
 All sections are 16-byte aligned so the kernels can write them in place (the encode
 and level kernels write straight into views of this buffer; nothing is repacked).
+
+`SplitHSQWire` is the same payload arranged for a two-part exchange (gq_amd/exchange.py,
+"split"): bytes [0, cut) hold everything the first MA subvectors need,
+
+    [ lb f32 | ub f32 | pad | levels[0:MA] | codes[0:MA] ]  cut  [ codes[MA:M] | pad | levels[MA:M] | pad ]
+
+so that they can be decoded while bytes [cut, nbytes) are still in flight; the codes stay
+ONE contiguous u8[M] section (the encode kernel writes them in one piece).
 """
 import torch
 
@@ -37,3 +45,27 @@ class HSQWire:
         levels = buf[self.levels_off:self.levels_off + self.M]
         lb_ub = buf[self.lbub_off:self.lbub_off + 8].view(torch.float32)
         return codes, levels, lb_ub
+
+
+class SplitHSQWire:
+    """The two-part arrangement (see the module docstring).  MA is a multiple of 64."""
+
+    def __init__(self, M):
+        self.M = M
+        self.MA = (M // 2) // 64 * 64
+        self.MB = M - self.MA
+        self.lbub_off = 0
+        self.levels_a_off = 16
+        self.codes_off = 16 + self.MA
+        self.cut = self.codes_off + self.MA
+        self.levels_b_off = _up(self.codes_off + M)
+        self.nbytes = _up(self.levels_b_off + self.MB)
+
+    def views(self, buf):
+        """(codes u8[M], levels u8[MA], levels u8[MB], lb_ub f32[2]) views into a 1-D payload buffer."""
+        assert buf.dim() == 1 and buf.numel() == self.nbytes
+        codes = buf[self.codes_off:self.codes_off + self.M]
+        la = buf[self.levels_a_off:self.levels_a_off + self.MA]
+        lb = buf[self.levels_b_off:self.levels_b_off + self.MB]
+        lb_ub = buf[self.lbub_off:self.lbub_off + 8].view(torch.float32)
+        return codes, la, lb, lb_ub

@@ -236,16 +236,26 @@ GQ_EXPORT void gq_oracle_qsgd_decompress(const float *norm, const uint8_t *signs
 }
 
 /*
- * ProbabilisticVectorCompressor encode -- INTENDED semantics of
- * compressors/probabilistic_vector_compressor.py:42-63.  PARITY UNPINNED: the reference's own
- * implementation cannot run in this environment (it opens ./codebook/..., which does not exist, and
- * calls torch.argmin on a bool tensor), so there are no golden vectors; the tests pin
- * self-consistency (unbiasedness, inverse-CDF property) instead.
- *   p = c_dagger . v (:47); l1 = sum|p| (:48); code = first k with cumsum(|p|/l1) >= r - 1e-5 (:52-58);
- *   u = sign(p_code) * l1 (:60-61)
+ * ProbabilisticVectorCompressor encode -- compressors/probabilistic_vector_compressor.py:42-63.
+ * PINNED by tests/golden/pvq_*.npz and residual_*.npz, which the reference itself produced with ONE
+ * operation defined by the generator: the class calls torch.argmin on a bool tensor (:58), which no torch
+ * with bool tensors implements; make_golden.py defines it as (index of the first True) - 1, i.e. the line's
+ * `+ 1` lands on the first index whose cumulative probability reaches the draw -- the inverse-CDF sample
+ * the code is written for (K-1 when no entry is True: all-zero subvector, 0/0 probabilities).  Every other
+ * line ran unedited, and their arithmetic is what this function restates:
+ *   p = c_dagger . v            :47  torch.mm == the ascending fmaf chain (as in hsq_encode)
+ *   l1 = sum_k |p_k|            :48  torch.norm(p, 1, dim=1) over the strided view: sequential f32 adds, k ascending
+ *   prob_k = |p_k| / l1         :49  IEEE f32 division
+ *   cum_k = f32( sum_{i<=k} f64(prob_i) )   :57  torch.cumsum on the CPU accumulates in DOUBLE and rounds every
+ *                                    output to f32 (measured: 100 % bit-equal on 2.8e8 entries; a f32 running
+ *                                    sum matches only 25 % of them at K = 256)
+ *   code = first k with cum_k >= r - 1e-5f  :52-58
+ *   u = sign(p_code) * l1       :60-61
+ * `cum_out` (nullable): the K cumulative sums of the first `cum_rows` subvectors, for the sub-expression test.
  */
-GQ_EXPORT void gq_oracle_pvq_encode(const float *grad, const float *cdag, int64_t M, int d, int K, const float *r,
-                                    int32_t *codes, float *u) {
+GQ_EXPORT void gq_oracle_pvq_encode_ex(const float *grad, const float *cdag, int64_t M, int d, int K, const float *r,
+                                       int32_t *codes, float *u, float *l1_out, float *p_out, float *cum_out,
+                                       int64_t cum_rows) {
 #pragma omp parallel for schedule(static)
     for (int64_t m = 0; m < M; ++m) {
         const float *v = grad + m * (int64_t)d;
@@ -254,15 +264,21 @@ GQ_EXPORT void gq_oracle_pvq_encode(const float *grad, const float *cdag, int64_
             float acc = 0.0f;
             for (int j = 0; j < d; ++j) acc = fmaf(cdag[(int64_t)k * d + j], v[j], acc);
             l1 = l1 + fabsf(acc);
+            if (p_out && m < cum_rows) p_out[m * (int64_t)K + k] = acc;
         }
+        if (l1_out) l1_out[m] = l1;
         const float thr = r[m] - 1e-5f;
-        float cum = 0.0f, sel = 0.0f;
+        double cum = 0.0;
+        float sel = 0.0f;
         int code = K - 1, found = 0;
         for (int k = 0; k < K; ++k) {
             float acc = 0.0f;
             for (int j = 0; j < d; ++j) acc = fmaf(cdag[(int64_t)k * d + j], v[j], acc);
-            cum = cum + fabsf(acc) / l1;
-            int hit = !found && (cum >= thr);
+            const float prob = fabsf(acc) / l1;
+            cum = cum + (double)prob;
+            const float cf = (float)cum;
+            if (cum_out && m < cum_rows) cum_out[m * (int64_t)K + k] = cf;
+            int hit = !found && (cf >= thr);
             if (hit || (!found && k == K - 1)) {
                 code = k;
                 sel = acc;
@@ -272,4 +288,9 @@ GQ_EXPORT void gq_oracle_pvq_encode(const float *grad, const float *cdag, int64_
         codes[m] = code;
         u[m] = (sel > 0.0f ? 1.0f : (sel < 0.0f ? -1.0f : 0.0f)) * l1;
     }
+}
+
+GQ_EXPORT void gq_oracle_pvq_encode(const float *grad, const float *cdag, int64_t M, int d, int K, const float *r,
+                                    int32_t *codes, float *u) {
+    gq_oracle_pvq_encode_ex(grad, cdag, M, d, K, r, codes, u, 0, 0, 0, 0);
 }

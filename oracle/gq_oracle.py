@@ -171,8 +171,9 @@ def qsgd_decompress(norm, signs, levels, d, n_bit):
     return out
 
 
-def pvq_encode(grad, c_dagger, r):
-    """ProbabilisticVectorCompressor encode (intended semantics; parity unpinned) -> (codes, u)."""
+def pvq_encode(grad, c_dagger, r, sub_rows=0):
+    """ProbabilisticVectorCompressor encode (pinned by tests/golden/pvq_*.npz) -> (codes, u), or with
+    sub_rows > 0 -> (codes, u, l1 f32[M], p f32[sub_rows, K], cumsum f32[sub_rows, K])."""
     cd = _f32(c_dagger)
     K, d = cd.shape
     g = _f32(grad).reshape(-1)
@@ -181,6 +182,42 @@ def pvq_encode(grad, c_dagger, r):
     assert r.size == M
     codes = np.empty(M, np.int32)
     u = np.empty(M, np.float32)
-    lib().gq_oracle_pvq_encode(_p(g, _f32p), _p(cd, _f32p), ctypes.c_int64(M), ctypes.c_int(d), ctypes.c_int(K),
-                               _p(r, _f32p), _p(codes, _i32p), _p(u, _f32p))
+    sub_rows = min(int(sub_rows), M)
+    l1 = np.empty(M, np.float32)
+    p = np.empty((sub_rows, K), np.float32) if sub_rows else None
+    cum = np.empty((sub_rows, K), np.float32) if sub_rows else None
+    lib().gq_oracle_pvq_encode_ex(_p(g, _f32p), _p(cd, _f32p), ctypes.c_int64(M), ctypes.c_int(d), ctypes.c_int(K),
+                                  _p(r, _f32p), _p(codes, _i32p), _p(u, _f32p), _p(l1, _f32p), _p(p, _f32p),
+                                  _p(cum, _f32p), ctypes.c_int64(sub_rows))
+    if sub_rows:
+        return codes, u, l1, p, cum
     return codes, u
+
+
+def pvq_compress(grad, c_dagger, r, n_bit):
+    """ProbabilisticVectorCompressor.compress with deterministic norms (args.random = 0) -> dict."""
+    codes, u = pvq_encode(grad, c_dagger, r)
+    out = dict(codes=codes, u=u)
+    if n_bit != 32:
+        lb, ub, levels = scalar_levels(u, n_bit)
+        out.update(lb=lb, ub=ub, levels=levels)
+    return out
+
+
+def pvq_decompress(sig, codewords, n_bit):
+    norms = sig["u"] if n_bit == 32 else scalar_decode(sig["levels"], n_bit, sig["lb"], sig["ub"])
+    return hsq_decode(sig["codes"], norms, codewords)
+
+
+def residual_compress(grad, codewords1, codewords2, c_dagger, r, n_bit):
+    """ResidualCompressor.compress (residual_compressor.py:15-24), deterministic norms:
+    stage 1 nearest neighbour -> residual -= decoded (in place, f32) -> stage 2 probabilistic vector."""
+    g = _f32(grad).reshape(-1).copy()
+    s1 = hsq_compress(g, codewords1, n_bit) if n_bit != 32 else dict(zip(("codes", "u"), hsq_encode(g, codewords1)))
+    dec1 = (hsq_decompress(s1["codes"], s1["levels"], s1["lb"], s1["ub"], codewords1, n_bit) if n_bit != 32
+            else hsq_decode(s1["codes"], s1["u"], codewords1))
+    g = (g - dec1).astype(np.float32)
+    s2 = pvq_compress(g, c_dagger, r, n_bit)
+    dec2 = pvq_decompress(s2, codewords2, n_bit)
+    # residual_compressor.py:26-32: torch.stack([d1, d2]).sum(0) == d1 + d2 in f32
+    return s1, s2, dec1, dec2, (dec1 + dec2).astype(np.float32)

@@ -668,6 +668,66 @@ def test_probabilistic_vector_compressor_matches_oracle_and_is_unbiased(oracle):
     assert torch.allclose(c4.c_dagger, c4.codewords, atol=1e-5)
 
 
+PVQ_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "pvq_*.npz")))
+RESIDUAL_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "residual_*.npz")))
+
+
+def _inject(comp, codewords, c_dagger):
+    """The fixture's codebook and pseudo-inverse (LAPACK output / ortho_group draws of the generating run)."""
+    comp.codewords = torch.from_numpy(np.ascontiguousarray(codewords))
+    if c_dagger is not None:
+        comp.c_dagger = torch.from_numpy(np.ascontiguousarray(c_dagger))
+
+
+def _check_sig(sig, g, prefix, n_bit):
+    norms, codes = sig
+    assert np.array_equal(codes.cpu().numpy().astype(np.int32), g[prefix + "codes"].astype(np.int32)), prefix + "codes"
+    if n_bit == 32:
+        assert np.array_equal(_bits(norms.cpu().numpy()), _bits(g[prefix + "u"])), prefix + "u"
+    else:
+        lb, ub, l = norms
+        assert _bits(lb.cpu().numpy()) == _bits(g[prefix + "lb"]) and _bits(ub.cpu().numpy()) == _bits(g[prefix + "ub"])
+        assert l.dtype == torch.int32 and np.array_equal(l.cpu().numpy(), g[prefix + "levels"]), prefix + "levels"
+
+
+@pytest.mark.parametrize("name", PVQ_CASES)
+def test_probabilistic_vector_compressor_matches_reference(name):
+    """a12 against the reference's own output (tests/golden/pvq_*.npz; make_golden.py explains the one operation it
+    had to define): codes, magnitudes / levels, lb, ub and the decode, bit for bit, for the reference's draws r."""
+    from gq_amd.compressors import ProbabilisticVectorCompressor
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d, K, n_bit = int(g["dim"]), int(g["K"]), int(g["n_bit"])
+    x = torch.from_numpy(g["x"])
+    comp = ProbabilisticVectorCompressor(x.numel(), x.shape, make_args(c_dim=d, k_bit=int(np.log2(K)), n_bit=n_bit,
+                                                                       random=0, gq_rng="reference"))
+    _inject(comp, g["codewords"], g["c_dagger"])
+    torch.manual_seed({"pvq_d16_k256_n32": 51, "pvq_d16_k256_n6": 52, "pvq_d16_k16_n32": 53, "pvq_d8_k32_n32": 54,
+                       "pvq_d16_k256_zero_rows": 55}[name])
+    sig = comp.compress(x.cuda())
+    _check_sig(sig, g, "", n_bit)
+    assert np.array_equal(_bits(comp.decompress(sig).cpu().numpy()), _bits(g["decoded"]))
+
+
+@pytest.mark.parametrize("name", RESIDUAL_CASES)
+def test_residual_compressor_matches_reference(name):
+    """a11 against the reference's own output (tests/golden/residual_*.npz): both stage signatures and the summed
+    decode, bit for bit."""
+    from gq_amd.compressors import ResidualCompressor
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d, K, n_bit = int(g["dim"]), int(g["K"]), int(g["n_bit"])
+    x = torch.from_numpy(g["x"])
+    np.random.seed(0)
+    comp = ResidualCompressor(x.numel(), x.shape, make_args(c_dim=d, k_bit=int(np.log2(K)), n_bit=n_bit, random=0,
+                                                            gq_rng="reference"))
+    _inject(comp.compressors[0], g["codewords1"], None)
+    _inject(comp.compressors[1], g["codewords2"], g["c_dagger"])
+    torch.manual_seed({"residual_d16_k256_n6": 56, "residual_d16_k256_n32": 57, "residual_d16_k16_n32": 58}[name])
+    sigs = comp.compress(x.cuda())
+    _check_sig(sigs[0], g, "s1_", n_bit)
+    _check_sig(sigs[1], g, "s2_", n_bit)
+    assert np.array_equal(_bits(comp.decompress(sigs).cpu().numpy()), _bits(g["decoded"]))
+
+
 def test_residual_compressor_two_stages():
     """a11: stage 1 (nearest neighbour) + stage 2 (probabilistic vector) on the residual."""
     from gq_amd.compressors import ResidualCompressor, NearestNeighborCompressor
@@ -834,3 +894,27 @@ def test_bench_two_rank_code_path_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["ranks"] == 2 and "cpu_baseline" not in d and d["roofline"]["kernel_ms"] > 0
 
+
+
+@pytest.mark.parametrize("extra", [[], ["--exchange", "split"], ["--workload", "qsgd"]])
+def test_bench_launches_its_own_ranks(extra):
+    """`python bench.py --gpus 2` from a bare shell (no RANK / WORLD_SIZE): bench.py starts its own two ranks before
+    anything touches the GPU and rank 0 prints the one JSON line (GQ_BENCH_BACKEND=gloo: both ranks share this GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GQ_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["ranks_bit_identical"] is True
+    assert d["exchange"]["ranks"] == 2 and d["exchange"]["backend"] == "gloo"
+    if extra[:1] == ["--exchange"]:
+        assert d["exchange"]["transport"] == "split"
+    elif not extra:
+        assert d["exchange"]["transport"] in ("allgather", "direct", "split") and set(d["exchange"]["autotune_ms"]) == {"allgather", "direct", "split"}

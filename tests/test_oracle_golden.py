@@ -191,3 +191,61 @@ def test_pvq_oracle_is_an_unbiased_inverse_cdf_sampler(oracle):
     assert np.linalg.norm(mean - v) / np.linalg.norm(v) < 2e-2
     freq = np.bincount(codes, minlength=256) / draws
     assert np.abs(freq - prob).max() < 5e-3
+
+
+# ---- ProbabilisticVectorCompressor / ResidualCompressor (a12 / a11) --------------------------------------
+PVQ_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "pvq_*.npz")))
+RESIDUAL_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "residual_*.npz")))
+
+
+@pytest.mark.parametrize("name", PVQ_CASES)
+def test_pvq_matches_reference(oracle, name):
+    """The reference's own ProbabilisticVectorCompressor (run by make_golden.py with torch.argmin defined for bool
+    input, see its docstring): the sub-expressions p (torch.mm), l1 (torch.norm) and the cumulative probabilities
+    (torch.cumsum: DOUBLE accumulation on the CPU) bit for bit, then codes, u, levels, lb, ub and the decode."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n_bit, keep = int(g["n_bit"]), g["p_head"].shape[0]
+    codes, u, l1, p, cum = oracle.pvq_encode(g["x"], g["c_dagger"], g["r"], sub_rows=keep)
+    assert np.array_equal(_bits(p), _bits(g["p_head"])), "p = c_dagger . v differs from torch.mm"
+    assert np.array_equal(_bits(l1), _bits(g["l1"])), "l1 differs from torch.norm(p, 1, dim=1)"
+    assert np.array_equal(_bits(cum), _bits(g["cumsum_head"])), "cumulative sums differ from torch.cumsum"
+    thr = (g["r"][:keep] - np.float32(1e-5)).astype(np.float32)
+    hit = g["cumsum_head"] >= thr[:, None]
+    first = np.where(hit.any(1), hit.argmax(1), hit.shape[1] - 1)
+    assert np.array_equal(first, g["codes"][:keep].astype(np.int64)), "fixture codes are not the first index that reaches the draw"
+    assert np.array_equal(codes, g["codes"].astype(np.int32))
+    assert np.array_equal(_bits(u), _bits(g["u"]))
+    if n_bit != 32:
+        sig = oracle.pvq_compress(g["x"], g["c_dagger"], g["r"], n_bit)
+        assert _bits(sig["lb"]) == _bits(g["lb"]) and _bits(sig["ub"]) == _bits(g["ub"])
+        assert np.array_equal(sig["levels"], g["levels"])
+    else:
+        sig = dict(codes=codes, u=u)
+    assert np.array_equal(_bits(oracle.pvq_decompress(sig, g["codewords"], n_bit)), _bits(g["decoded"].reshape(-1)))
+
+
+@pytest.mark.parametrize("name", RESIDUAL_CASES)
+def test_residual_compressor_matches_reference(oracle, name):
+    """ResidualCompressor.compress / decompress of the reference (same generator): both stage signatures, the stage
+    decodes and their sum, bit for bit."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n_bit = int(g["n_bit"])
+    s1, s2, d1, d2, dec = oracle.residual_compress(g["x"], g["codewords1"], g["codewords2"], g["c_dagger"], g["r"], n_bit)
+    for tag, sig in (("s1_", s1), ("s2_", s2)):
+        assert np.array_equal(sig["codes"], g[tag + "codes"].astype(np.int32)), tag
+        if n_bit == 32:
+            assert np.array_equal(_bits(sig["u"]), _bits(g[tag + "u"])), tag
+        else:
+            assert np.array_equal(sig["levels"], g[tag + "levels"]), tag
+            assert _bits(sig["lb"]) == _bits(g[tag + "lb"]) and _bits(sig["ub"]) == _bits(g[tag + "ub"]), tag
+    assert np.array_equal(_bits(d1), _bits(g["decoded1"].reshape(-1)))
+    assert np.array_equal(_bits(d2), _bits(g["decoded2"].reshape(-1)))
+    assert np.array_equal(_bits(dec), _bits(g["decoded"].reshape(-1)))
+
+
+def test_pvq_pseudo_inverse_is_reproducible():
+    """c_dagger = np.linalg.pinv(codewords.T) (probabilistic_vector_compressor.py:28) is LAPACK arithmetic: the
+    fixtures carry the reference's array; this build's NumPy agrees to rounding."""
+    g = np.load(os.path.join(GOLDEN, "pvq_d16_k256_n32.npz"))
+    cd = np.linalg.pinv(g["codewords"].T)
+    assert cd.dtype == np.float32 and np.allclose(cd, g["c_dagger"], rtol=1e-4, atol=1e-6)
