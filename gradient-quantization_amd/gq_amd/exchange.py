@@ -39,13 +39,17 @@ def configured_mode(default="allgather"):
 class _Pending(object):
     """Outstanding transfers of one byte range; wait() orders the current stream behind them."""
 
-    def __init__(self, works):
+    def __init__(self, works, after=()):
         self.works = works
+        self.after = list(after)      # (device view, host buffer) pairs to copy once the transfers are done
 
     def wait(self):
         for w in self.works:
             w.wait()
         self.works = []
+        for dst, src in self.after:
+            dst.copy_(src)      # staged (gloo test) path only; blocking, so that the host buffer can be reused
+        self.after = []
 
 
 class WireExchange(object):
@@ -56,6 +60,14 @@ class WireExchange(object):
         self.group = group
         self.gathered = torch.zeros((world * users, user_bytes), dtype=torch.uint8, device=device)
         self.timings_ms = None          # filled by autotune()
+        # Point-to-point messages between device buffers are RCCL's business.  Under the gloo TEST backend (several
+        # ranks on one GPU: tests, GQ_BENCH_BACKEND=gloo) they are staged through pinned host memory: gloo would
+        # write the device buffer from the CPU, unordered with the kernels that read it.
+        self._staged = False
+        if world > 1 and device.type == "cuda":
+            import torch.distributed as dist
+            self._staged = dist.get_backend(group) != "nccl"
+        self._host = {}
 
     # ---- views ------------------------------------------------------------------------------
     @property
@@ -91,7 +103,7 @@ class WireExchange(object):
     def _direct(self, rows, lo, hi):
         """Grouped point-to-point transfers of bytes [lo, hi) of the first `rows` rows of every rank."""
         import torch.distributed as dist
-        ops = []
+        ops, after = [], []
         whole = lo == 0 and hi == self.user_bytes
         target = self.gathered if rows == self.users else self._partial_buffer(rows)
         if rows != self.users:
@@ -108,9 +120,22 @@ class WireExchange(object):
             else:
                 assert rows == 1, "a byte range of several rows is not contiguous"
                 send_t, recv_t = mine[0, lo:hi], theirs[0, lo:hi]
+            if self._staged:
+                if step == 1:     # one host copy of the outgoing bytes serves every peer
+                    out_h = self._host_buffer(("out", lo, hi), send_t.numel())
+                    out_h.copy_(send_t)           # synchronous: the kernels that wrote the wire have finished
+                in_h = self._host_buffer(("in", src, lo, hi), recv_t.numel())
+                after.append((recv_t, in_h))
+                send_t, recv_t = out_h, in_h
             ops.append(dist.P2POp(dist.isend, send_t, self._peer(dst), group=self.group))
             ops.append(dist.P2POp(dist.irecv, recv_t, self._peer(src), group=self.group))
-        return _Pending(dist.batch_isend_irecv(ops) if ops else [])
+        return _Pending(dist.batch_isend_irecv(ops) if ops else [], after)
+
+    def _host_buffer(self, key, n):
+        buf = self._host.get(key)
+        if buf is None or buf.numel() != n:
+            buf = self._host[key] = torch.empty(n, dtype=torch.uint8).pin_memory()
+        return buf
 
     # ---- public -----------------------------------------------------------------------------
     def start(self, mode, rows=None, cut=None):
