@@ -33,6 +33,8 @@
 //     the whole encode is ONE launch.
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 #include "hsq_pf_common.hpp"
 
 namespace gq {
@@ -84,52 +86,17 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // s_cb[(k>>2)*QUAD_STRIDE + 4*j + (k&3)] = c[k][j]
     __shared__ __attribute__((aligned(16))) float s_cb[64 * QUAD_STRIDE];
     __shared__ int s_next;                     // tile counter of this workgroup's run (see below)
-    if (threadIdx.x == 0) s_next = PF_WAVES;   // the first PF_WAVES tiles of the run go to the waves by index
-    for (int i = threadIdx.x; i < 256 * 16; i += PF_THREADS) {
-        const int k = i >> 4, jj = i & 15;
-        s_cb[(k >> 2) * QUAD_STRIDE + 4 * jj + (k & 3)] = cb[i];
-    }
     // Batched form: the segment table (64 B per tensor) goes to LDS once.  Looking a tile's tensor up in
     // global memory costs two dependent round trips at the top of every tile (tile -> segment -> record),
     // which made this form 3x slower than the single-tensor one; from LDS the record is ~100 cycles away,
     // and the tile -> segment word is fetched one tile ahead.
     __shared__ int64_t s_seg[(BATCHED && SEGLDS) ? PF_LDS_SEGS * 8 : 1];
-    if (BATCHED && SEGLDS) {
-        const int n = (a.nseg < PF_LDS_SEGS ? a.nseg : PF_LDS_SEGS) * 8;
-        for (int i = threadIdx.x; i < n; i += PF_THREADS) s_seg[i] = a.seg_table[i];
-    }
+    // bf16 hi / lo A fragments of the 8 row blocks as the waves of the workgroup produce them (one row block each)
+    __shared__ __attribute__((aligned(16))) u32x4 s_frag[8 * 2 * 64];
+    __shared__ float s_c1[PF_WAVES];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-
-    // A fragments of v_mfma_f32_32x32x16_bf16: lane (row j, half h) holds c[rb*32+j][8h .. 8h+7];
-    // hi and lo bf16 parts, 64 VGPRs, resident for the kernel's lifetime.  (Keeping them in LDS
-    // instead and running 4 waves/SIMD measured slower: the kernel is bound by VALU issue, not
-    // by latency.)
-    bf16x8 ch[8], cl[8];
-#pragma unroll
-    for (int rb = 0; rb < 8; ++rb) {
-        const f32x4 q0 = *reinterpret_cast<const f32x4 *>(cb + (rb * 32 + j) * 16 + 8 * h);
-        const f32x4 q1 = *reinterpret_cast<const f32x4 *>(cb + (rb * 32 + j) * 16 + 8 * h + 4);
-        split8(q0, q1, ch[rb], cl[rb]);
-    }
-    __syncthreads();
-    // The error bound scales with max_k ||c_k||_1 (<= 4 for unit-L2 rows); measure it instead of
-    // trusting the caller's codebook to be normalised.
-    __shared__ float s_c1[PF_WAVES];
-    {
-        float l1 = 0.0f;
-        const int kk = threadIdx.x & 255;   // 256 codewords, twice
-#pragma unroll
-        for (int e = 0; e < 16; ++e) l1 += fabsf(s_cb[(kk >> 2) * QUAD_STRIDE + 4 * e + (kk & 3)]);
-        l1 = wave_max(l1);
-        if ((threadIdx.x & 63) == 0) s_c1[threadIdx.x >> 6] = l1;
-    }
-    __syncthreads();
-    float c1 = s_c1[0];
-#pragma unroll
-    for (int w = 1; w < PF_WAVES; ++w) c1 = fmaxf(c1, s_c1[w]);
-    const float err_scale = c1 * ERR_SCALE;  // E = max|v_j| * err_scale
 
     const int64_t ntiles = BATCHED ? a.ntiles : ((M + 63) >> 6);
     // Tiles: every workgroup owns one contiguous run [lo, hi) of them and its 8 waves draw from it through an
@@ -184,7 +151,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
         return (int64_t)(((uint64_t)hi << 32) | lo);
     };
-    auto tile_info = [&](int64_t tile, int seg) {   // seg: the tile's tensor (batched; fetched ahead by the caller)
+    // FROM_GLOBAL: the record comes from global memory even in the SEGLDS form (the first tile is set up
+    // before the LDS copy of the table exists)
+    auto tile_info = [&](int64_t tile, int seg, auto from_global) {   // seg: the tile's tensor (batched; fetched ahead by the caller)
+        constexpr bool FROM_GLOBAL = decltype(from_global)::value;
         Tile ti;
         if (BATCHED) {
             ti.seg = seg;
@@ -192,7 +162,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             // flat load (vmcnt AND lgkmcnt) sits right behind the previous tile's stores: a store round trip
             // per tile.  Hence the compile-time choice of the source.
             int64_t r0, r1, r2, r3, r7 = 0;
-            if constexpr (SEGLDS) {
+            if constexpr (SEGLDS && !FROM_GLOBAL) {
                 const int64_t *rec = s_seg + 8 * seg;
                 r0 = rec[0];
                 r1 = rec[1];
@@ -293,14 +263,68 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     auto seg_of = [&](int64_t tile) {   // batched: tile -> tensor, one global word (0 beyond the end)
         return (BATCHED && tile < tile_end) ? a.tile_seg[tile] : 0;
     };
+
+    // ---- prologue.  Everything the workgroup needs from memory is requested first, in the order it is used
+    // (vector-memory results return in order): the codebook words for the LDS image, this wave's row block of
+    // the codebook (A fragments: every wave splits ONE of the 8 row blocks into bf16 hi / lo and shares it
+    // through LDS -- each wave splitting all 8 cost 0.8 us of VALU time per SIMD), and the wave's first tile,
+    // whose HBM latency then hides behind the staging.  One barrier.  (Before: staging, fragments, barrier,
+    // ||c||_1, barrier and only then the first tile's loads: 5.2 us; profiles/r02_pf_prologue_stamps.txt.)
+    float cbv[256 * 16 / PF_THREADS];
+#pragma unroll
+    for (int n = 0; n < 256 * 16 / PF_THREADS; ++n) cbv[n] = cb[threadIdx.x + n * PF_THREADS];
+    const f32x4 q0 = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * 16 + 8 * h);
+    const f32x4 q1 = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * 16 + 8 * h + 4);
+    if (t < tile_end) {
+        ti = tile_info(t, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[t]) : 0, std::true_type{});
+        load_tile(ti, cur);
+        load_err(ti, nxte);
+    }
+    if (threadIdx.x == 0) s_next = PF_WAVES;   // the first PF_WAVES tiles of the run go to the waves by index
+#pragma unroll
+    for (int n = 0; n < 256 * 16 / PF_THREADS; ++n) {
+        const int i = threadIdx.x + n * PF_THREADS, k = i >> 4, jj = i & 15;
+        s_cb[(k >> 2) * QUAD_STRIDE + 4 * jj + (k & 3)] = cbv[n];
+    }
+    if (BATCHED && SEGLDS) {
+        const int n = (a.nseg < PF_LDS_SEGS ? a.nseg : PF_LDS_SEGS) * 8;
+        for (int i = threadIdx.x; i < n; i += PF_THREADS) s_seg[i] = a.seg_table[i];
+    }
+    {
+        bf16x8 fh, fl;
+        split8(q0, q1, fh, fl);
+        s_frag[(wave * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, fh);
+        s_frag[(wave * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, fl);
+        // The error bound scales with max_k ||c_k||_1 (<= 4 for unit-L2 rows); measure it instead of
+        // trusting the caller's codebook to be normalised.  Row wave*32 + j: this lane's 8 elements + its partner's.
+        float l1 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) l1 += fabsf(q0[e]) + fabsf(q1[e]);
+        l1 += __shfl_xor(l1, 32, 64);
+        l1 = wave_max(l1);
+        if (lane == 0) s_c1[wave] = l1;
+    }
+    __syncthreads();
+    // A fragments of v_mfma_f32_32x32x16_bf16: lane (row j, half h) holds c[rb*32+j][8h .. 8h+7];
+    // hi and lo bf16 parts, 64 VGPRs, resident for the kernel's lifetime.  (Keeping them in LDS
+    // instead and running 4 waves/SIMD measured slower: the kernel is bound by VALU issue, not
+    // by latency.)
+    bf16x8 ch[8], cl[8];
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) {
+        ch[rb] = __builtin_bit_cast(bf16x8, s_frag[(rb * 2 + 0) * 64 + lane]);
+        cl[rb] = __builtin_bit_cast(bf16x8, s_frag[(rb * 2 + 1) * 64 + lane]);
+    }
+    float c1 = s_c1[0];
+#pragma unroll
+    for (int w = 1; w < PF_WAVES; ++w) c1 = fmaxf(c1, s_c1[w]);
+    const float err_scale = c1 * ERR_SCALE;  // E = max|v_j| * err_scale
+
     int64_t tn = draw();                // the tile after this wave's first one
     int seg_n = seg_of(tn);             // in flight while the first tile is set up
     int seg_next = 0;                   // its value, read back BEFORE a tile's stores (see the consume point)
     if (t < tile_end) {
-        ti = tile_info(t, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[t]) : 0);
         seg_next = BATCHED ? __builtin_amdgcn_readfirstlane(seg_n) : 0;
-        load_tile(ti, cur);
-        load_err(ti, nxte);
         fold_err(ti, cur, nxte);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) split8(cur[2 * blk], cur[2 * blk + 1], vh[blk], vl[blk]);
@@ -310,7 +334,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         const int64_t tnn = BATCHED ? draw() : 0;
         Tile tin = ti;
         if (tn < tile_end) {
-            tin = tile_info(tn, seg_next);
+            tin = tile_info(tn, seg_next, std::false_type{});
             load_tile(tin, nxt);  // prefetch the next tile
             load_err(tin, nxte);
         }
