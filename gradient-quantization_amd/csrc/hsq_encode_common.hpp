@@ -42,9 +42,13 @@ __host__ __device__ inline const int *ws_counter(const float *ws) {
 }
 __host__ __device__ inline int *ws_worklist(float *ws) { return reinterpret_cast<int *>(ws + 2 * GQ_MAX_PARTIALS) + 4; }
 
-// Per-block (min,max) of u -> partials[2*blockIdx.x], and block 0 pads the unused slots.
+// Per-block (min,max) of u -> partials[2*blockIdx.x], and block 0 pads the unused slots.  The level kernel
+// (gq_hsq_levels) folds the pairs into (lb, ub): every one of its workgroups reads the 8 KiB from L2, which costs it
+// ~0.3 us once -- less than a last-workgroup fold inside the encode did (ticket round trip + fold: ~1.8 us on the
+// encode's critical path; profiles/r02_pf_prologue_stamps.txt).
+template <int WAVES = ENC_WAVES>
 __device__ __forceinline__ void write_minmax_partials(float lmin, float lmax, float *__restrict__ partials) {
-    __shared__ float s_min[ENC_WAVES], s_max[ENC_WAVES];
+    __shared__ float s_min[WAVES], s_max[WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     lmin = wave_min(lmin);
     lmax = wave_max(lmax);
@@ -56,7 +60,7 @@ __device__ __forceinline__ void write_minmax_partials(float lmin, float lmax, fl
     if (threadIdx.x == 0) {
         float a = s_min[0], b = s_max[0];
 #pragma unroll
-        for (int w = 1; w < ENC_WAVES; ++w) {
+        for (int w = 1; w < WAVES; ++w) {
             a = fminf(a, s_min[w]);
             b = fmaxf(b, s_max[w]);
         }

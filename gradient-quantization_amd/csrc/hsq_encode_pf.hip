@@ -121,7 +121,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         return lo_tile + __builtin_amdgcn_readfirstlane(k);
     };
     int64_t t = lo_tile + wave;
-    int *const counter = ws_counter(ws);
     int *const worklist = ws_worklist(ws);
 
     float lmin = INFINITY, lmax = -INFINITY;
@@ -520,10 +519,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
                 val = bv;
                 idx = bi;
             }
-            if (!BATCHED && lane == 0) {   // diagnostics only: which subvectors took this path
-                const int pos = atomicAdd(counter, 1);
-                worklist[pos] = (int)(ti.sv0 + fl);
-            }
+            if (!BATCHED && lane == 0) worklist[ti.sv0 + fl] = (int)(ti.sv0 + fl);   // diagnostics only: which subvectors took this path
         }
 
         if (PAGED && valid) {
@@ -549,7 +545,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         flush_minmax();
         return;
     }
-    pf_finish_minmax<true, PF_WAVES>(lmin, lmax, ws);   // per-workgroup (min,max) -> the last workgroup folds the final (lb, ub)
+    write_minmax_partials<PF_WAVES>(lmin, lmax, ws);   // per-workgroup (min,max); the level kernel folds them
 }
 
 // one resident wave of 8-wave workgroups (the (min,max) slots of the workspace cap the grid)

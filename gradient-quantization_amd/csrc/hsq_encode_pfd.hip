@@ -134,7 +134,6 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode
         return lo_tile + __builtin_amdgcn_readfirstlane(k);
     };
     int64_t t = lo_tile + wave;
-    int *const counter = ws_counter(ws);
     int *const worklist = ws_worklist(ws);
 
     typedef const float __attribute__((address_space(1))) *gcf_ptr;
@@ -472,10 +471,7 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode
                 val = bv;
                 idx = bi;
             }
-            if (!BATCHED && lane == 0) {   // diagnostics only: which subvectors took this path
-                const int pos = atomicAdd(counter, 1);
-                worklist[pos] = (int)(t * 64 + fl);
-            }
+            if (!BATCHED && lane == 0) worklist[t * 64 + fl] = (int)(t * 64 + fl);   // diagnostics only: which subvectors took this path
         }
 
         if (PAGED && valid) {
@@ -501,7 +497,7 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode
         flush_minmax();
         return;
     }
-    pf_finish_minmax<true, WAVES>(lmin, lmax, ws);
+    write_minmax_partials<WAVES>(lmin, lmax, ws);   // per-workgroup (min,max); the level kernel folds them
 }
 
 static int64_t pfd_grid(int64_t ntiles, int bpc, int waves) {

@@ -95,73 +95,4 @@ __device__ __forceinline__ float order_unmap(unsigned m) {
     return __uint_as_float(m ^ ((m >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
-// End of a single-tensor prefilter kernel: per-workgroup (min,max) of u -> workspace; the LAST workgroup
-// to arrive (ticket counter; pairs published with agent-scope atomic stores and read back with
-// agent-scope atomic loads -- cdna_hip_programming.md G16) folds them into the final pair at slot 0,
-// raises the `final` flag the level kernel looks at and re-zeroes the counters: no second launch, no
-// memset node.  `fold` = false (batched form: the per-tensor (min,max) went out by atomics) only resets
-// the counters.  Called by all threads of the workgroup.
-template <bool FOLD, int WAVES = ENC_WAVES>
-__device__ __forceinline__ void pf_finish_minmax(float lmin, float lmax, float *__restrict__ ws) {
-    __shared__ float s_min[WAVES], s_max[WAVES];
-    __shared__ int s_last;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int *const counter = ws_counter(ws);
-    {
-        const float lo = wave_min(lmin), hi = wave_max(lmax);
-        if (lane == 0) {
-            s_min[wave] = lo;
-            s_max[wave] = hi;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (FOLD) {
-            float lo = s_min[0], hi = s_max[0];
-#pragma unroll
-            for (int w = 1; w < WAVES; ++w) {
-                lo = fminf(lo, s_min[w]);
-                hi = fmaxf(hi, s_max[w]);
-            }
-            float *slot = ws + 2 * blockIdx.x;
-            __hip_atomic_store(slot, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(slot + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left before the ticket is drawn
-        }
-        const int ticket = __hip_atomic_fetch_add(&counter[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (ticket == (int)gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    float lo = INFINITY, hi = -INFINITY;
-    if (FOLD) {
-        for (int i = threadIdx.x; i < (int)gridDim.x; i += WAVES * 64) {
-            lo = fminf(lo, __hip_atomic_load(ws + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            hi = fmaxf(hi, __hip_atomic_load(ws + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
-        lo = wave_min(lo);
-        hi = wave_max(hi);
-    }
-    __syncthreads();  // everyone has read pair 0 and the LDS scratch is free again
-    if (lane == 0) {
-        s_min[wave] = lo;
-        s_max[wave] = hi;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (FOLD) {
-#pragma unroll
-            for (int w = 1; w < WAVES; ++w) {
-                lo = fminf(lo, s_min[w]);
-                hi = fmaxf(hi, s_max[w]);
-            }
-            ws[0] = lo;
-            ws[1] = hi;
-            counter[2] = 1;  // pair 0 holds the final (lb, ub)
-        }
-        counter[0] = 0;  // fix-up log empty for the next call
-        counter[1] = 0;
-    }
-}
-
 }  // namespace gq
