@@ -43,7 +43,13 @@ struct PfdArgs {
     int code_base;    // PAGED (hsq_encode_pf.hip): index of this page's first codeword, and whether to keep
     int merge;        // the (code, u) already in the output unless this page beats it
     int last_page;    // PAGED: this launch produces the final projections (fold their min / max)
+    int tiles_q, tiles_r;   // tiles per workgroup, split on the host (hsq_encode_pf.hip): the first tiles_r take one more
 };
+
+static void pfd_split(PfdArgs &a, int64_t ntiles, int64_t blocks) {
+    a.tiles_q = (int)(ntiles / blocks);
+    a.tiles_r = (int)(ntiles % blocks);
+}
 
 constexpr int PFD_LDS_SEGS = 384;   // batched form: segment records kept in LDS (24 KiB); longer lists are refused
 
@@ -121,8 +127,9 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode
     const float err_scale = c1 * ERR_SCALE;  // E = max|v_j| * err_scale
 
     const int64_t ntiles = BATCHED ? a.ntiles : ((M + 63) >> 6);
-    const int64_t lo_tile = ((int64_t)blockIdx.x * ntiles) / gridDim.x;
-    const int64_t tile_end = (((int64_t)blockIdx.x + 1) * ntiles) / gridDim.x;
+    const int b = (int)blockIdx.x;
+    const int64_t lo_tile = (int64_t)b * a.tiles_q + (b < a.tiles_r ? b : a.tiles_r);
+    const int64_t tile_end = lo_tile + a.tiles_q + (b < a.tiles_r ? 1 : 0);
     // the slower wave of a SIMD (waves 4-7 of an 8-wave workgroup) leaves the last tiles of the run to the faster one
     const int tail_from = (int)(tile_end - lo_tile) - ((WAVES >= 8 && wave >= 4) ? 6 : 0);
     auto draw = [&]() {   // the next tile of this workgroup's run (may lie beyond tile_end)
@@ -529,6 +536,7 @@ static int launch_pfd(const float *grad, const float *codebook, int64_t M, CodeT
     a.ws = ws;
     const int64_t ntiles = (M + 63) / 64;
     const int64_t blocks = pfd_grid(ntiles, bpc, WAVES);
+    pfd_split(a, ntiles, blocks);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<CodeT, D>), dim3((unsigned)blocks), dim3(THREADS), lds,
                        st, a);
     GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter, d = 8 / 32)");
@@ -561,6 +569,7 @@ static int launch_pfd_paged(const float *grad, const float *codebook, int64_t M,
         a.code_base = page * 256;
         a.merge = page > 0;
         a.last_page = (page + 1) * 256 >= K;
+        pfd_split(a, (M + 63) / 64, blocks);
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, st, a);
     }
     GQ_CHECK_LAUNCH("gq_hsq_encode (paged prefilter, d = 8 / 32)");
@@ -621,6 +630,7 @@ static int pfd_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, 
         a.code_base = page * 256;
         a.merge = page > 0;
         a.last_page = (page + 1) * 256 >= K;
+        pfd_split(a, ntiles, blocks);
         if (ef && page == 0)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<int32_t, D, true, true, true>), dim3((unsigned)blocks),
                                dim3(THREADS), lds, st, a);
@@ -666,6 +676,7 @@ static int launch_pfd_batched(const int64_t *seg_table, const int32_t *tile_seg,
     a.nseg = nseg;
     a.ef_scale = ef_scale;
     const int64_t blocks = pfd_grid(ntiles, bpc, WAVES);
+    pfd_split(a, ntiles, blocks);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<uint8_t, D, true, EF>), dim3((unsigned)blocks),
                        dim3(THREADS), lds, st, a);
     GQ_CHECK_LAUNCH("gq_hsq_encode_batched_d");

@@ -22,8 +22,8 @@ if sys.argv[1:] == ["read"]:
     wl = ws[2 * native.GQ_MAX_PARTIALS + 4:2 * native.GQ_MAX_PARTIALS + 4 + M]
     raw = wl[M - 65536:M - 65536 + 256 * 8 * 8 * 2].contiguous().view(torch.int64).view(-1, 8).cpu().numpy().astype(np.float64)
     t0 = raw[:, 0].min()
-    names = ["entry (after first wave's entry)", "codebook staged (stores issued)", "A fragments loaded + split", "barrier 1 passed",
-             "l1 norms + barrier 2 passed", "first tile loaded + split (loop starts)", "loop ends", "kernel end of wave"]
+    names = ["entry (after first wave's entry)", "all prologue loads issued", "LDS image + own row block's fragments written", "barrier passed",
+             "fragments read back, ||c||_1", "first tile split (loop starts)", "loop ends", "end of wave (partials written)"]
     for i, n in enumerate(names):
         c = (raw[:, i] - t0) / 100
         print("  %-42s mean %6.2f us  min %6.2f  max %6.2f" % (n, c.mean(), c.min(), c.max()))
@@ -41,12 +41,12 @@ def rep(old, new):
 ST = '    __builtin_amdgcn_sched_barrier(0); pst[%d] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0);\n'
 rep("    const float *__restrict__ cb = a.cb;\n    float *__restrict__ ws = a.ws;",
     "    unsigned long long pst[8];\n" + ST % 0 + "    const float *__restrict__ cb = a.cb;\n    float *__restrict__ ws = a.ws;")
-rep("    // Batched form: the segment table (64 B per tensor) goes to LDS once.", ST % 1 + "    // Batched form: the segment table (64 B per tensor) goes to LDS once.")
-rep("    __syncthreads();\n    // The error bound scales with max_k", ST % 2 + "    __syncthreads();\n" + ST % 3 + "    // The error bound scales with max_k")
-rep("    float c1 = s_c1[0];", ST % 4 + "    float c1 = s_c1[0];")
+rep("    if (threadIdx.x == 0) s_next = PF_WAVES;", ST % 1 + "    if (threadIdx.x == 0) s_next = PF_WAVES;")           # all loads issued
+rep("    __syncthreads();\n    // A fragments of v_mfma", ST % 2 + "    __syncthreads();\n" + ST % 3 + "    // A fragments of v_mfma")   # LDS written / barrier passed
+rep("    int64_t tn = draw();                // the tile after", ST % 4 + "    int64_t tn = draw();                // the tile after")   # fragments read
 rep("    while (t < tile_end) {\n        // single tensor: tn was drawn", ST % 5 + "    while (t < tile_end) {\n        // single tensor: tn was drawn")
-rep("    if (BATCHED) {\n        flush_minmax();\n        return;\n    }\n    pf_finish_minmax<true, PF_WAVES>(lmin, lmax, ws);",
-    ST % 6 + "    if (BATCHED) {\n        flush_minmax();\n        return;\n    }\n    pf_finish_minmax<true, PF_WAVES>(lmin, lmax, ws);\n" + ST % 7 +
+rep("    write_minmax_partials<PF_WAVES>(lmin, lmax, ws);",
+    ST % 6 + "    write_minmax_partials<PF_WAVES>(lmin, lmax, ws);\n" + ST % 7 +
     "    if (lane == 0 && blockIdx.x < 256) {\n"
     "        unsigned long long *o = reinterpret_cast<unsigned long long *>(ws_worklist(ws) + (M - 65536)) + (blockIdx.x * 8 + wave) * 8;\n"
     "        for (int i = 0; i < 8; ++i) o[i] = pst[i];\n    }")
