@@ -73,14 +73,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int D>
 __device__ __forceinline__ f32x4 exact_score_quad(const float *__restrict__ quad, const float (&v)[D]) {
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    // the rows are fetched in batches of 8 (the accumulators of the prefilter are dead by now, there is room): with
+    // the reads issued one by one beside their FMAs the group cost 16 LDS round trips in a row
 #pragma unroll
-    for (int jj = 0; jj < D; ++jj) {
-        if (jj > 0 && jj % 16 == 0) __builtin_amdgcn_sched_barrier(0);
-        const f32x4 c = *reinterpret_cast<const f32x4 *>(quad + 4 * jj);
-        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(c[0]), "v"(v[jj]));
-        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(c[1]), "v"(v[jj]));
-        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a2) : "v"(c[2]), "v"(v[jj]));
-        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a3) : "v"(c[3]), "v"(v[jj]));
+    for (int j0 = 0; j0 < D; j0 += 8) {
+        f32x4 c[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) c[jj] = *reinterpret_cast<const f32x4 *>(quad + 4 * (j0 + jj));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(c[jj][0]), "v"(v[j0 + jj]));
+            asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(c[jj][1]), "v"(v[j0 + jj]));
+            asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a2) : "v"(c[jj][2]), "v"(v[j0 + jj]));
+            asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a3) : "v"(c[jj][3]), "v"(v[j0 + jj]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     const f32x4 r = {a0, a1, a2, a3};
     return r;
