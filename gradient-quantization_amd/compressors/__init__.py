@@ -3,7 +3,9 @@
 `from compressors import *` in main.py resolves to the MI355X implementations."""
 from gq_amd.compressors import (IdenticalCompressor, QSGDCompressor, NearestNeighborCompressor,  # noqa: F401
                                 ProbabilisticScalarCompressor, ProbabilisticVectorCompressor,
-                                ResidualCompressor, SignSGDCompressor, TopKSparsificationCompressor)
+                                ResidualCompressor, SignSGDCompressor, TopKSparsificationCompressor,
+                                MaureySparsification)
 
 __all__ = ["IdenticalCompressor", "QSGDCompressor", "NearestNeighborCompressor", "ProbabilisticScalarCompressor",
-           "ProbabilisticVectorCompressor", "ResidualCompressor", "SignSGDCompressor", "TopKSparsificationCompressor"]
+           "ProbabilisticVectorCompressor", "ResidualCompressor", "SignSGDCompressor", "TopKSparsificationCompressor",
+           "MaureySparsification"]

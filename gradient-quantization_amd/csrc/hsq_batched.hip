@@ -58,7 +58,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
                 const float q = (uu[e] - lb) / range;
                 const float x = fabsf(q) * s;
                 const float c = fminf(fmaxf(x, 0.0f), smax);
-                l = (int)c;
+                l = (x != x) ? INT32_MIN : (int)c;   // clamp(NaN) stays NaN and NaN -> int32 is INT_MIN in the reference (x86)
                 if (random_mode == GQ_RANDOM_DEVICE) {
                     const float prob = x - (float)l;
                     l += (prob > uniform01(seed, (uint64_t)(4 * i + e))) ? 1 : 0;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_kernel(
         if ((lb - ub) != 0.0f) {
             const float x = fabsf((u_flat[g] - lb) / range) * s;
             const float c = fminf(fmaxf(x, 0.0f), smax);
-            l = (int)c;
+            l = (x != x) ? INT32_MIN : (int)c;   // clamp(NaN) stays NaN and NaN -> int32 is INT_MIN in the reference (x86)
             if (random_mode == GQ_RANDOM_DEVICE) {
                 const float prob = x - (float)l;
                 l += (prob > uniform01(seed, (uint64_t)g)) ? 1 : 0;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_d_kernel(
         if ((lb - ub) != 0.0f) {
             const float x = fabsf((u_flat[g] - lb) / range) * s;
             const float c = fminf(fmaxf(x, 0.0f), smax);
-            l = (int)c;
+            l = (x != x) ? INT32_MIN : (int)c;   // clamp(NaN) stays NaN and NaN -> int32 is INT_MIN in the reference (x86)
             if (random_mode == GQ_RANDOM_DEVICE) {
                 const float prob = x - (float)l;
                 l += (prob > uniform01(seed, (uint64_t)g)) ? 1 : 0;

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_d16k256_kernel(cons
     int64_t t = (int64_t)blockIdx.x * ENC_WAVES + wave;
 
     float lmin = INFINITY, lmax = -INFINITY;
+    bool sawnan = false;   // a projection of this wave is NaN (wave-uniform)
     f32x4 cur[4], nxt[4];
 
     auto load_tile = [&](int64_t tile, f32x4(&dst)[4]) {
@@ -149,10 +150,37 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_d16k256_kernel(cons
         swap32(bi[0], bi[1]);
         const float a0 = fabsf(bv[0]), a1 = fabsf(bv[1]);
         const bool take1 = (a1 > a0) || (a1 == a0 && bi[1] < bi[0]);
-        const float val = take1 ? bv[1] : bv[0];
-        const int idx = take1 ? bi[1] : bi[0];
+        float val = take1 ? bv[1] : bv[0];
+        int idx = take1 ? bi[1] : bi[0];
 
         const int64_t sv = t * 64 + lane;
+        // non-finite inputs (hsq_encode_common.hpp): x * 0 is NaN exactly for NaN and the infinities
+        {
+            float z0 = 0.0f, z1 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                z0 = __fmaf_rn(cur[0][e], 0.0f, z0);
+                z0 = __fmaf_rn(cur[1][e], 0.0f, z0);
+                z1 = __fmaf_rn(cur[2][e], 0.0f, z1);
+                z1 = __fmaf_rn(cur[3][e], 0.0f, z1);
+            }
+            const uint64_t b0 = __ballot(z0 != z0), b1 = __ballot(z1 != z1);   // lanes (j, h): halves of subvector j
+            uint64_t todo = ((b0 | (b0 >> 32)) & 0xFFFFFFFFull) | (((b1 | (b1 >> 32)) & 0xFFFFFFFFull) << 32);
+            todo &= __ballot(sv < M);
+            while (todo) {
+                const int fl = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const float *v = grad + (t * 64 + fl) * 16;
+                float bvv;
+                int bii;
+                nonfinite_argmax(256, 16, [&](int k, int e) { return cb[k * 16 + e]; }, [&](int e) { return v[e]; }, bvv, bii);
+                if (lane == fl) {
+                    val = bvv;
+                    idx = bii;
+                }
+                sawnan = sawnan || (bvv != bvv);
+            }
+        }
         if (sv < M) {
             codes[sv] = (CodeT)idx;
             u[sv] = val;
@@ -162,7 +190,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void hsq_encode_d16k256_kernel(cons
 #pragma unroll
         for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
     }
-    write_minmax_partials(lmin, lmax, partials);
+    write_minmax_partials(lmin, lmax, partials, sawnan);
 }
 
 // ------------------------------------------------------------------------------------
@@ -185,6 +213,7 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_generic_kernel(const f
     const int64_t ntiles = (M + 63) >> 6;
     const int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
     float lmin = INFINITY, lmax = -INFINITY;
+    bool sawnan = false;   // a projection of this wave is NaN (wave-uniform)
 
     for (int64_t t = (int64_t)blockIdx.x * ENC_WAVES + wave; t < ntiles; t += nw) {
         float bv[2];
@@ -223,9 +252,28 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_generic_kernel(const f
         const bool v0 = bi[0] < K, v1 = bi[1] < K;
         const float a0 = fabsf(bv[0]), a1 = fabsf(bv[1]);
         const bool take1 = v1 && (!v0 || (a1 > a0) || (a1 == a0 && bi[1] < bi[0]));
-        const float val = take1 ? bv[1] : bv[0];
-        const int idx = take1 ? bi[1] : bi[0];
+        float val = take1 ? bv[1] : bv[0];
+        int idx = take1 ? bi[1] : bi[0];
         const int64_t sv = t * 64 + lane;
+        {   // non-finite inputs (hsq_encode_common.hpp): this lane's own subvector, re-read (L1 / L2)
+            float z = 0.0f;
+            if (sv < M)
+                for (int e = 0; e < d; ++e) z = __fmaf_rn(grad[sv * (int64_t)d + e], 0.0f, z);
+            uint64_t todo = __ballot(z != z);
+            while (todo) {
+                const int fl = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const float *v = grad + (t * 64 + fl) * (int64_t)d;
+                float bvv;
+                int bii;
+                nonfinite_argmax(K, d, [&](int k, int e) { return cb[(int64_t)k * d + e]; }, [&](int e) { return v[e]; }, bvv, bii);
+                if (lane == fl) {
+                    val = bvv;
+                    idx = bii;
+                }
+                sawnan = sawnan || (bvv != bvv);
+            }
+        }
         if (sv < M) {
             codes[sv] = (CodeT)idx;
             u[sv] = val;
@@ -233,7 +281,7 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_generic_kernel(const f
             lmax = fmaxf(lmax, val);
         }
     }
-    write_minmax_partials(lmin, lmax, partials);
+    write_minmax_partials(lmin, lmax, partials, sawnan);
 }
 
 // ------------------------------------------------------------------------------------
@@ -387,6 +435,7 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
     const int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
     const int64_t rounds = (ntiles + nw - 1) / nw;   // the same for every wave of the grid: barriers stay uniform
     float lmin = INFINITY, lmax = -INFINITY;
+    bool sawnan = false;   // a projection of this wave is NaN (wave-uniform)
     if (nchunks == 1) {
         stage_codebook(0);
         __syncthreads();
@@ -444,8 +493,37 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
         const bool v0 = bi[0] < K, v1 = bi[1] < K;
         const float a0 = fabsf(bv[0]), a1 = fabsf(bv[1]);
         const bool take1 = v1 && (!v0 || (a1 > a0) || (a1 == a0 && bi[1] < bi[0]));
-        const float val = take1 ? bv[1] : bv[0];
-        const int idx = take1 ? bi[1] : bi[0];
+        float val = take1 ? bv[1] : bv[0];
+        int idx = take1 ? bi[1] : bi[0];
+        {   // non-finite inputs (hsq_encode_common.hpp): this lane's own subvector from the staged tile (rows beyond
+            // the tensor are zeros); the rare scan reads the codebook from global memory (it may be chunked in LDS)
+            const float *row = s_v + lane * stride;
+            float z = 0.0f;
+            for (int e = 0; e < dpad; ++e) z = __fmaf_rn(row[e], 0.0f, z);
+            uint64_t todo = __ballot(z != z);
+            bool nanhere = false;
+            while (todo) {
+                const int fl = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const float *v = s_v + fl * stride;
+                float bvv;
+                int bii;
+                nonfinite_argmax(K, d, [&](int k, int e) { return cb[(int64_t)k * d + e]; },
+                                 [&](int e) { return v[(e & 1) * half + (e >> 1)]; }, bvv, bii);
+                if (lane == fl) {
+                    val = bvv;
+                    idx = bii;
+                }
+                nanhere = nanhere || (bvv != bvv);
+            }
+            if (nanhere) {
+                sawnan = true;
+                if (BATCHED && lane == 0) {   // this tensor's (lb, ub) become NaN
+                    atomicMin(bt.seg_minmax + 2 * seg, MAPPED_NAN_LO);
+                    atomicMax(bt.seg_minmax + 2 * seg + 1, MAPPED_NAN_HI);
+                }
+            }
+        }
         if (BATCHED) {
             if (seg != cur_seg) {
                 flush_minmax(lmin, lmax);
@@ -472,7 +550,7 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
         flush_minmax(lmin, lmax);
         return;
     }
-    write_minmax_partials(lmin, lmax, partials);
+    write_minmax_partials(lmin, lmax, partials, sawnan);
 }
 
 // LDS plan of hsq_encode_lds_kernel: false if (d, K) does not fit
@@ -516,25 +594,38 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_valu_kernel(const floa
     for (int i = threadIdx.x; i < K * D; i += blockDim.x) s_cb[i] = cb[i];
     __syncthreads();
     float lmin = INFINITY, lmax = -INFINITY;
+    bool sawnan = false;   // a projection of this wave is NaN (wave-uniform)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += stride) {
         float v[D];
 #pragma unroll
         for (int jj = 0; jj < D; ++jj) v[jj] = grad[m * D + jj];
-        float best_v = 0.0f;
+        float best_v = 0.0f, z = 0.0f;
         int best_i = 0;
+#pragma unroll
+        for (int jj = 0; jj < D; ++jj) z = __fmaf_rn(v[jj], 0.0f, z);
+        const bool odd = z != z;   // a NaN or an infinity in this subvector: torch.argmax's order (hsq_encode_common.hpp)
         for (int k = 0; k < K; ++k) {
             float acc = 0.0f;
 #pragma unroll
             for (int jj = 0; jj < D; ++jj) acc = __fmaf_rn(s_cb[k * D + jj], v[jj], acc);
-            take_if_greater(best_v, best_i, acc, k);
+            if (odd) {
+                if (k == 0) {
+                    best_v = acc;
+                } else {
+                    take_if_greater_nan(best_v, best_i, acc, k);
+                }
+            } else {
+                take_if_greater(best_v, best_i, acc, k);
+            }
         }
         codes[m] = (CodeT)best_i;
         u[m] = best_v;
+        sawnan = sawnan || (__ballot(best_v != best_v) != 0);
         lmin = fminf(lmin, best_v);
         lmax = fmaxf(lmax, best_v);
     }
-    write_minmax_partials(lmin, lmax, partials);
+    write_minmax_partials(lmin, lmax, partials, sawnan);
 }
 
 template <typename CodeT>

@@ -27,6 +27,64 @@ __device__ __forceinline__ void take_if_greater(float &bv, int &bi, float v, int
     bi = gt ? idx : bi;
 }
 
+// ---- non-finite gradients --------------------------------------------------------------------------------
+// The reference's torch.argmax ranks NaN above every number and keeps the first one
+// (nearest_neighbor_compressor.py:72), and torch.min / torch.max propagate NaN into (lb, ub)
+// (probabilistic_scalar_compressor.py:13-14).  The kernels' hot loops compare with '>' and fminf / fmaxf, which
+// ignore NaN; a subvector that holds a NaN or an infinity is therefore re-done by the wave-wide scan below (a
+// rare path), and a NaN projection poisons (lb, ub) explicitly.  Bit tests: two files of the library are built
+// with -fno-honor-nans, where `x != x` folds to false.
+__device__ __forceinline__ bool nan_bits(float v) { return (__float_as_uint(v) & 0x7FFFFFFFu) > 0x7F800000u; }
+__device__ __forceinline__ bool nonfinite_bits(float v) { return (__float_as_uint(v) & 0x7F800000u) == 0x7F800000u; }
+// |v| as an ordered integer with every NaN equal and above +infinity
+__device__ __forceinline__ unsigned nan_rank(float v) {
+    const unsigned a = __float_as_uint(v) & 0x7FFFFFFFu;
+    return a > 0x7F800000u ? 0x7F800001u : a;
+}
+__device__ __forceinline__ void take_if_greater_nan(float &bv, int &bi, float v, int idx) {
+    const bool gt = nan_rank(v) > nan_rank(bv);
+    bv = gt ? v : bv;
+    bi = gt ? idx : bi;
+}
+// first maximum of (value, index) pairs across the wave in torch.argmax's order; every lane gets the result.
+// A lane without a candidate passes idx = 0x7FFFFFFF.
+__device__ __forceinline__ void wave_first_max_nan(float &bv, int &bi) {
+    unsigned br = nan_rank(bv);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        const unsigned orr = nan_rank(ov);
+        const bool take = oi != 0x7FFFFFFF && (bi == 0x7FFFFFFF || orr > br || (orr == br && oi < bi));
+        bv = take ? ov : bv;
+        bi = take ? oi : bi;
+        br = take ? orr : br;
+    }
+}
+// Wave-wide exact argmax for ONE subvector (rare path of the exact kernels): lane L scores codewords L, L + 64, ...
+// with the reference's fmaf chain, c(k, e) and v(e) supplied by the caller (v wave-uniform).
+template <class RowGet, class VGet>
+__device__ __forceinline__ void nonfinite_argmax(int K, int d, RowGet c, VGet v, float &val, int &idx) {
+    const int lane = threadIdx.x & 63;
+    float bv = 0.0f;
+    int bi = 0x7FFFFFFF;
+    for (int k = lane; k < K; k += 64) {
+        float acc = 0.0f;
+        for (int e = 0; e < d; ++e) acc = __fmaf_rn(c(k, e), v(e), acc);
+        if (bi == 0x7FFFFFFF || nan_rank(acc) > nan_rank(bv)) {
+            bv = acc;
+            bi = k;
+        }
+    }
+    wave_first_max_nan(bv, bi);
+    val = bv;
+    idx = bi;
+}
+// order-mapped (hsq_pf_common.hpp: order_map) images of -NaN / +NaN: below every mapped number / above every one.
+// Sent to a tensor's (min, max) words by atomicMin / atomicMax they make its (lb, ub) NaN.
+constexpr unsigned MAPPED_NAN_LO = 0x003FFFFFu;   // order_map(0xFFC00000)
+constexpr unsigned MAPPED_NAN_HI = 0xFFC00000u;   // order_map(0x7FC00000)
+
 // Row of the 32x32 MFMA result held in accumulator register r of a lane in half h
 // is  (r&3) + 8*(r>>2) + 4*h ; this is the h-independent part.
 __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
@@ -46,12 +104,16 @@ __host__ __device__ inline int *ws_worklist(float *ws) { return reinterpret_cast
 // (gq_hsq_levels) folds the pairs into (lb, ub): every one of its workgroups reads the 8 KiB from L2, which costs it
 // ~0.3 us once -- less than a last-workgroup fold inside the encode did (ticket round trip + fold: ~1.8 us on the
 // encode's critical path; profiles/r02_pf_prologue_stamps.txt).
+// sawnan (wave-uniform): a projection of this wave's tiles is NaN -> the workgroup's pair is (NaN, NaN) and the
+// level kernel's fold makes (lb, ub) NaN, as torch.min / torch.max do.
 template <int WAVES = ENC_WAVES>
-__device__ __forceinline__ void write_minmax_partials(float lmin, float lmax, float *__restrict__ partials) {
+__device__ __forceinline__ void write_minmax_partials(float lmin, float lmax, float *__restrict__ partials,
+                                                      bool sawnan = false) {
     __shared__ float s_min[WAVES], s_max[WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     lmin = wave_min(lmin);
     lmax = wave_max(lmax);
+    if (sawnan) lmin = lmax = __uint_as_float(0x7FC00000u);
     if (lane == 0) {
         s_min[wave] = lmin;
         s_max[wave] = lmax;
@@ -59,11 +121,14 @@ __device__ __forceinline__ void write_minmax_partials(float lmin, float lmax, fl
     __syncthreads();
     if (threadIdx.x == 0) {
         float a = s_min[0], b = s_max[0];
+        bool anynan = nan_bits(a);
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) {
+            anynan = anynan || nan_bits(s_min[w]);
             a = fminf(a, s_min[w]);
             b = fmaxf(b, s_max[w]);
         }
+        if (anynan) a = b = __uint_as_float(0x7FC00000u);
         partials[2 * blockIdx.x] = a;
         partials[2 * blockIdx.x + 1] = b;
         if (blockIdx.x == 0) ws_counter(partials)[2] = 0;  // pairs are partials, not yet the final (lb, ub)

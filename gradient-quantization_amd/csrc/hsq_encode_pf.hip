@@ -133,6 +133,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     int *const worklist = ws_worklist(ws);
 
     float lmin = INFINITY, lmax = -INFINITY;
+    bool sawnan = false;   // a projection of this wave is NaN (wave-uniform)
     int cur_seg = -1;  // batched: segment the running (lmin, lmax) belongs to
     f32x4 cur[4], nxt[4];
     f32x4 nxte[4];   // EF: the error tile that goes with nxt (dead otherwise)
@@ -457,7 +458,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         const float E = vmax * err_scale;
         const float others = __uint_as_float(rest);  // >= every s~ outside the rescored group
         bool safe = (others + E < fabsf(val)) && (vmax >= 8.27e-25f) && (vmax <= 1.0e30f);
-        if (vmax == 0.0f) {  // all-zero subvector: every score is +0 -> first index, u = +0
+        // a NaN score: the float comparisons above are compiled for NaN-free operands (-fno-honor-nans: the
+        // complement `others + E >= |val|` is what is evaluated, false for NaN), so the bits decide
+        if (nan_bits(val)) safe = false;
+        if (vmax == 0.0f && !nan_bits(val)) {  // all-zero subvector: every score is +0 -> first index, u = +0
             safe = true;
             val = 0.0f;
             idx = 0;
@@ -512,30 +516,36 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
                 if (q == 0) {
                     bv = acc;
                 } else {
-                    take_if_greater(bv, bi, acc, k);
+                    take_if_greater_nan(bv, bi, acc, k);   // torch.argmax's order: NaN is the largest, the first one wins
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                const float a0 = fabsf(bv), a1 = fabsf(ov);
-                const bool take = (a1 > a0) || (a1 == a0 && oi < bi);
-                bv = take ? ov : bv;
-                bi = take ? oi : bi;
-            }
+            wave_first_max_nan(bv, bi);
             if (lane == fl) {
                 val = bv;
                 idx = bi;
+            }
+            if (nan_bits(bv)) {   // (lb, ub) of this tensor become NaN (torch.min / torch.max propagate it)
+                sawnan = true;
+                if (BATCHED && lane == 0) {
+                    atomicMin(a.seg_minmax + 2 * ti.seg, MAPPED_NAN_LO);
+                    atomicMax(a.seg_minmax + 2 * ti.seg + 1, MAPPED_NAN_HI);
+                }
             }
             if (!BATCHED && lane == 0) worklist[ti.sv0 + fl] = (int)(ti.sv0 + fl);   // diagnostics only: which subvectors took this path
         }
 
         if (PAGED && valid) {
             idx += a.code_base;
-            if (a.merge && !(fabsf(val) > fabsf(prev_u))) {   // strict: ties stay with the earlier page
+            if (a.merge && !(nan_rank(val) > nan_rank(prev_u))) {   // strict: ties (and an earlier NaN) stay with the earlier page
                 val = prev_u;
                 idx = prev_idx;
+            }
+        }
+        if (PAGED && __ballot(valid && nan_bits(val)) != 0) {   // a NaN kept from an earlier page counts as well
+            sawnan = true;
+            if (BATCHED && lane == 0) {
+                atomicMin(a.seg_minmax + 2 * ti.seg, MAPPED_NAN_LO);
+                atomicMax(a.seg_minmax + 2 * ti.seg + 1, MAPPED_NAN_HI);
             }
         }
         if (valid) {
@@ -554,7 +564,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         flush_minmax();
         return;
     }
-    write_minmax_partials<PF_WAVES>(lmin, lmax, ws);   // per-workgroup (min,max); the level kernel folds them
+    write_minmax_partials<PF_WAVES>(lmin, lmax, ws, sawnan);   // per-workgroup (min,max); the level kernel folds them
 }
 
 // one resident wave of 8-wave workgroups (the (min,max) slots of the workspace cap the grid)

@@ -250,6 +250,7 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode
     };
 
     float lmin = INFINITY, lmax = -INFINITY;
+    bool sawnan = false;   // a projection of this wave is NaN (wave-uniform)
     int cur_seg = -1;  // batched: segment the running (lmin, lmax) belongs to
     auto flush_minmax = [&]() {  // batched: fold this wave's running (min,max) into its segment
         const float lo = wave_min(lmin), hi = wave_max(lmax);
@@ -413,7 +414,10 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode
         const float E = vmax * err_scale;
         const float others = __uint_as_float(rest);  // >= every s~ outside the rescored group
         bool safe = (others + E < fabsf(val)) && (vmax >= 8.27e-25f) && (vmax <= 1.0e30f);
-        if (vmax == 0.0f) {  // all-zero subvector: every score is +0 -> first index, u = +0
+        // a NaN score: the float comparisons above are compiled for NaN-free operands (-fno-honor-nans: the
+        // complement `others + E >= |val|` is what is evaluated, false for NaN), so the bits decide
+        if (nan_bits(val)) safe = false;
+        if (vmax == 0.0f && !nan_bits(val)) {  // all-zero subvector: every score is +0 -> first index, u = +0
             safe = true;
             val = 0.0f;
             idx = 0;
@@ -462,30 +466,36 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode
                 if (q == 0) {
                     bv = sc;
                 } else {
-                    take_if_greater(bv, bi, sc, k);
+                    take_if_greater_nan(bv, bi, sc, k);   // torch.argmax's order: NaN is the largest, the first one wins
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                const float a0 = fabsf(bv), a1 = fabsf(ov);
-                const bool take = (a1 > a0) || (a1 == a0 && oi < bi);
-                bv = take ? ov : bv;
-                bi = take ? oi : bi;
-            }
+            wave_first_max_nan(bv, bi);
             if (lane == fl) {
                 val = bv;
                 idx = bi;
+            }
+            if (nan_bits(bv)) {   // (lb, ub) of this tensor become NaN (torch.min / torch.max propagate it)
+                sawnan = true;
+                if (BATCHED && lane == 0) {
+                    atomicMin(a.seg_minmax + 2 * ti.seg, MAPPED_NAN_LO);
+                    atomicMax(a.seg_minmax + 2 * ti.seg + 1, MAPPED_NAN_HI);
+                }
             }
             if (!BATCHED && lane == 0) worklist[t * 64 + fl] = (int)(t * 64 + fl);   // diagnostics only: which subvectors took this path
         }
 
         if (PAGED && valid) {
             idx += a.code_base;
-            if (a.merge && !(fabsf(val) > fabsf(prev_u))) {   // strict: ties stay with the earlier page
+            if (a.merge && !(nan_rank(val) > nan_rank(prev_u))) {   // strict: ties (and an earlier NaN) stay with the earlier page
                 val = prev_u;
                 idx = prev_idx;
+            }
+        }
+        if (PAGED && __ballot(valid && nan_bits(val)) != 0) {   // a NaN kept from an earlier page counts as well
+            sawnan = true;
+            if (BATCHED && lane == 0) {
+                atomicMin(a.seg_minmax + 2 * ti.seg, MAPPED_NAN_LO);
+                atomicMax(a.seg_minmax + 2 * ti.seg + 1, MAPPED_NAN_HI);
             }
         }
         if (valid) {
@@ -504,7 +514,7 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode
         flush_minmax();
         return;
     }
-    write_minmax_partials<WAVES>(lmin, lmax, ws);   // per-workgroup (min,max); the level kernel folds them
+    write_minmax_partials<WAVES>(lmin, lmax, ws, sawnan);   // per-workgroup (min,max); the level kernel folds them
 }
 
 static int64_t pfd_grid(int64_t ntiles, int bpc, int waves) {

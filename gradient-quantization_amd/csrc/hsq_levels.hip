@@ -28,13 +28,16 @@ __global__ __launch_bounds__(LV_THREADS) void hsq_levels_kernel(const float *__r
     } else {
         lo = INFINITY;
         hi = -INFINITY;
+        bool nan = false;   // a (NaN, NaN) pair: some projection was NaN -> lb = ub = NaN, as torch.min / torch.max give
         for (int i = threadIdx.x; i < GQ_MAX_PARTIALS; i += LV_THREADS) {
             const float2 p = reinterpret_cast<const float2 *>(partials)[i];
+            nan = nan || (p.x != p.x);
             lo = fminf(lo, p.x);
             hi = fmaxf(hi, p.y);
         }
         lo = wave_min(lo);
         hi = wave_max(hi);
+        if (__ballot(nan) != 0) lo = hi = __uint_as_float(0x7FC00000u);
         if ((threadIdx.x & 63) == 0) {
             s_min[threadIdx.x >> 6] = lo;
             s_max[threadIdx.x >> 6] = hi;
@@ -42,11 +45,14 @@ __global__ __launch_bounds__(LV_THREADS) void hsq_levels_kernel(const float *__r
         __syncthreads();
         lo = s_min[0];
         hi = s_max[0];
+        nan = lo != lo;
 #pragma unroll
         for (int w = 1; w < LV_THREADS / 64; ++w) {
+            nan = nan || (s_min[w] != s_min[w]);
             lo = fminf(lo, s_min[w]);
             hi = fmaxf(hi, s_max[w]);
         }
+        if (nan) lo = hi = __uint_as_float(0x7FC00000u);
     }
     const float lb = lo, ub = hi;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(LV_THREADS) void hsq_levels_kernel(const float *__r
         const float q = (uu - lb) / range;
         const float x = fabsf(q) * s;
         const float c = fminf(fmaxf(x, 0.0f), smax);
-        int l = (int)c;
+        int l = (x != x) ? INT32_MIN : (int)c;   // clamp(NaN) stays NaN and NaN -> int32 is INT_MIN in the reference (x86)
         if (random_mode != GQ_RANDOM_OFF) {
             const float prob = x - (float)l;
             const float rr = (random_mode == GQ_RANDOM_GIVEN) ? r[i] : uniform01(seed, (uint64_t)i);
@@ -133,24 +139,30 @@ __global__ __launch_bounds__(LV_THREADS) void minmax_partials_kernel(const float
     __shared__ float s_min[LV_THREADS / 64], s_max[LV_THREADS / 64];
     float lo = INFINITY, hi = -INFINITY;
     const int64_t stride = (int64_t)gridDim.x * LV_THREADS;
+    bool nan = false;
     for (int64_t i = (int64_t)blockIdx.x * LV_THREADS + threadIdx.x; i < n; i += stride) {
         const float x = v[i];
+        nan = nan || (x != x);
         lo = fminf(lo, x);
         hi = fmaxf(hi, x);
     }
     lo = wave_min(lo);
     hi = wave_max(hi);
+    if (__ballot(nan) != 0) lo = hi = __uint_as_float(0x7FC00000u);   // torch.min / torch.max propagate NaN
     if ((threadIdx.x & 63) == 0) {
         s_min[threadIdx.x >> 6] = lo;
         s_max[threadIdx.x >> 6] = hi;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        bool anynan = lo != lo;
 #pragma unroll
         for (int w = 1; w < LV_THREADS / 64; ++w) {
+            anynan = anynan || (s_min[w] != s_min[w]);
             lo = fminf(lo, s_min[w]);
             hi = fmaxf(hi, s_max[w]);
         }
+        if (anynan) lo = hi = __uint_as_float(0x7FC00000u);
         partials[2 * blockIdx.x] = lo;
         partials[2 * blockIdx.x + 1] = hi;
         if (blockIdx.x == 0) ws_counter(partials)[2] = 0;

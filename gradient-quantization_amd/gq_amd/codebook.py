@@ -7,7 +7,7 @@ Host-side, one-off per compressor (the reference does this in NumPy too):
   * file name  codebooks/learned_codebook/angular_dim_{d}_Ks_{K}.fvecs, looked up
     relative to the cwd first, exactly like the reference
     (compressors/nearest_neighbor_compressor.py:50-51), then in $GQ_CODEBOOK_DIR,
-    then in the copy shipped with this package (only d=16, K=256 is shipped).
+    then in the copies shipped with this package (K = 256 for d = 8, 16 and 32: gq_amd/data/codebooks).
 """
 import os
 

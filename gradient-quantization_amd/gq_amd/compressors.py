@@ -419,5 +419,34 @@ class TopKSparsificationCompressor(object):
         return signature.view(self.shape)
 
 
+class MaureySparsification(object):
+    """Maurey sampling (maurey_sparsification.py:4-50): k coordinates drawn with probability |v_i| / ||v||_1, each
+    carrying sign(v_i) * ||v||_1 / k.  A name export like the two classes above (the reference does not wire it into
+    main.py's table either): same constructor arithmetic for k, the draws come from torch.multinomial on the
+    tensor's device instead of a k x size cumulative-sum comparison on the CPU -- the same distribution, other
+    random numbers."""
+
+    def __init__(self, size, shape, args):
+        self.cr = 32 * args.c_dim // (args.k_bit + args.n_bit)
+        bit_for_idx = 32 if size > 65536 else 16
+        self.k = max(1, 32 * size // ((bit_for_idx + 1) * self.cr))
+        self.cuda = not args.no_cuda
+        self.size, self.shape = size, shape
+
+    def compress(self, vec):
+        flat = vec.reshape(-1)
+        mag = flat.abs()
+        l1_norm = mag.sum()
+        codes = torch.multinomial(mag / l1_norm, self.k, replacement=True)
+        return [l1_norm / self.k, codes, torch.sign(flat[codes])]
+
+    def decompress(self, signature):
+        scale, codes, signs = signature
+        out = torch.zeros(self.size, dtype=signs.dtype, device=signs.device)
+        out.index_add_(0, codes.reshape(-1).long(), signs.reshape(-1))
+        return (scale * out).view(self.shape)
+
+
 __all__ = ["IdenticalCompressor", "QSGDCompressor", "NearestNeighborCompressor", "ProbabilisticScalarCompressor",
-           "ProbabilisticVectorCompressor", "ResidualCompressor", "SignSGDCompressor", "TopKSparsificationCompressor"]
+           "ProbabilisticVectorCompressor", "ResidualCompressor", "SignSGDCompressor", "TopKSparsificationCompressor",
+           "MaureySparsification"]

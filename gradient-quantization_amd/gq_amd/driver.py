@@ -179,6 +179,7 @@ def train(args, log=None):
     if args.no_cuda or not torch.cuda.is_available():
         raise RuntimeError("gq_amd runs on MI355X only: there is no CPU path (drop --no-cuda)")
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(device)      # the HIP library launches on the current device's current stream
     torch.manual_seed(args.seed)
     num_classes = 10
     model = network_choices[args.network](num_classes=num_classes).to(device)

@@ -66,6 +66,10 @@ def _dev_ptr(t, dtype=None, name="tensor"):
     if t.device.type != "cuda":
         raise GQNativeError("%s is on %s: the HIP kernels need a tensor in MI355X HBM (no CPU fallback)"
                             % (name, t.device))
+    if t.device.index != torch._C._cuda_getDevice():
+        # the launch goes to the CURRENT device's current stream (see _stream) and is sized by its CU count
+        raise GQNativeError("%s is on %s but the current device is cuda:%d: wrap the call in torch.cuda.device(...) "
+                            "or call torch.cuda.set_device first" % (name, t.device, torch._C._cuda_getDevice()))
     if dtype is not None and t.dtype != dtype:
         raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
     if not t.is_contiguous():
