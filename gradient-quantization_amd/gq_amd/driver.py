@@ -5,8 +5,12 @@ Same flag names and defaults as main.py:83-122, same iteration order as one_iter
     for user in range(num_users): zero_grad -> forward -> backward -> quantizer.record(user, epoch)
     quantizer.apply() -> optimizer.step()
 and the same user split of each batch (main.py:189-193).  Differences, all host-side plumbing:
-  * data: a synthetic, learnable classification set with the named dataset's shapes
-    (`--dataset mnist|cifar10`), labels from a fixed random teacher -- no downloads;
+  * data: `--data synthetic` (default): a learnable classification set with the named dataset's shapes
+    (`--dataset mnist|cifar10`), labels from a fixed random teacher -- no downloads;  `--data disk`: the real
+    MNIST (IDX files) / CIFAR-10 (python pickles) under `--data-root`, read without torchvision, normalised and
+    augmented on the device as dataloaders.py:5-47 does (gq_amd/datasets.py);
+  * evaluation: main.py:236-255's test() -- accuracy and summed batch loss over the test split -- at every log
+    point, as main.py:197-211 logs loss and accuracy together;
   * models: `fcn` (784-256-10, models/fcn.py:12-13) and a CIFAR bottleneck `resnet50` with the
     reference's parameter-shape list (tests/golden/resnet50_cifar_shapes.json), plain torch.nn;
   * schedule: main.py:136-163's learning-rate steps (new optimizer at epochs 51 and 71, none for MNIST, SignSGD's
@@ -27,6 +31,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.optim as optim
 
+from .datasets import OnDiskClassification
 from .compressors import (IdenticalCompressor, NearestNeighborCompressor, QSGDCompressor, SignSGDCompressor,
                           TopKSparsificationCompressor)
 from .quantizers import Quantizer
@@ -110,22 +115,30 @@ dataset_shapes = {'mnist': (1, 28, 28), 'cifar10': (3, 32, 32)}
 class SyntheticClassification(object):
     """Fixed random inputs with labels from a random linear teacher: learnable, no files."""
 
-    def __init__(self, dataset, n, num_classes, device, seed):
-        g = torch.Generator().manual_seed(seed)
-        shape = dataset_shapes[dataset]
-        self.x = torch.randn((n,) + shape, generator=g)
-        teacher = torch.randn(self.x[0].numel(), num_classes, generator=g)
-        self.y = (self.x.view(n, -1) @ teacher).argmax(1)
-        self.x, self.y = self.x.to(device), self.y.to(device)
-        self.n = n
+    def __init__(self, dataset, n, num_classes, device, seed, x=None, y=None):
+        if x is None:
+            g = torch.Generator().manual_seed(seed)
+            shape = dataset_shapes[dataset]
+            x = torch.randn((n,) + shape, generator=g)
+            teacher = torch.randn(x[0].numel(), num_classes, generator=g)
+            y = (x.view(n, -1) @ teacher).argmax(1)
+        self.x, self.y = x.to(device), y.to(device)
+        self.n = int(self.x.shape[0])
 
-    def batches(self, batch, epoch_seed, rank=0, world=1):
+    def split(self, n_test):
+        """(train, test): the last n_test samples become a held-out set labelled by the same teacher."""
+        k = self.n - n_test
+        return (SyntheticClassification(None, 0, 0, self.x.device, 0, self.x[:k], self.y[:k]),
+                SyntheticClassification(None, 0, 0, self.x.device, 0, self.x[k:], self.y[k:]))
+
+    def batches(self, batch, epoch_seed, rank=0, world=1, shuffle=True):
         g = torch.Generator().manual_seed(epoch_seed)
-        perm = torch.randperm(self.n, generator=g).to(self.x.device)
+        perm = (torch.randperm(self.n, generator=g) if shuffle else torch.arange(self.n)).to(self.x.device)
         per = batch * world
-        for i in range(0, self.n - per + 1, per):
+        for i in range(0, (self.n - per + 1) if shuffle else self.n, per):
             idx = perm[i + rank * batch:i + (rank + 1) * batch]
-            yield self.x[idx], self.y[idx]
+            if idx.numel():
+                yield self.x[idx], self.y[idx]
 
 
 def build_parser():
@@ -154,7 +167,27 @@ def build_parser():
     p.add_argument('--log-interval', type=int, default=8, help='iterations between JSON log lines')
     p.add_argument('--logfile', type=str, default=None)
     p.add_argument('--gq-rng', type=str, default=None, choices=[None, 'device', 'reference'])
+    p.add_argument('--data', type=str, default='synthetic', choices=['synthetic', 'disk'],
+                   help="disk: MNIST idx files / CIFAR-10 pickles under --data-root (no torchvision)")
+    p.add_argument('--data-root', type=str, default='./data')
+    p.add_argument('--test-batch-size', type=int, default=1000)
+    p.add_argument('--test-size', type=int, default=0, help='synthetic data: held-out samples for the accuracy loop (0 = none)')
     return p
+
+
+def test(model, loss_func, test_data, test_batch_size):
+    """main.py:236-255: accuracy over the test split; the loss is the reference's sum of per-batch MEAN losses
+    divided by the number of samples (LOSS_FUNC is CrossEntropyLoss with mean reduction, `.sum()` of a scalar)."""
+    model.eval()
+    test_loss, correct = 0.0, 0
+    with torch.no_grad():
+        for data, target in test_data.batches(test_batch_size, 0, shuffle=False):
+            output = model(data)
+            test_loss += loss_func(output, target).sum().item()
+            pred = output.argmax(dim=1, keepdim=True)
+            correct += pred.eq(target.view_as(pred)).sum().item()
+    model.train()
+    return correct / test_data.n, test_loss / test_data.n
 
 
 def one_iter(model, loss_func, optimizer, quantizer, train_data, epoch):
@@ -193,7 +226,15 @@ def train(args, log=None):
         steps, momentum = {51: 0.0005, 71: 0.0001}, 0.0
         optimizer = optim.SGD(model.parameters(), lr=1e-3, momentum=0.0, weight_decay=0.1)
     loss_func = nn.CrossEntropyLoss()
-    data = SyntheticClassification(args.dataset, args.train_size, num_classes, device, args.seed)
+    test_data = None
+    if getattr(args, "data", "synthetic") == "disk":
+        data = OnDiskClassification(args.dataset, args.data_root, device, train=True)
+        test_data = OnDiskClassification(args.dataset, args.data_root, device, train=False)
+    else:
+        n_test = int(getattr(args, "test_size", 0))
+        data = SyntheticClassification(args.dataset, args.train_size + n_test, num_classes, device, args.seed)
+        if n_test:
+            data, test_data = data.split(n_test)
     out = open(args.logfile, "a") if (args.logfile and rank == 0) else None
     history = []
     it = 0
@@ -211,6 +252,10 @@ def train(args, log=None):
             if it % args.log_interval == 0 or it == 1:
                 rec = {"iter": it, "epoch": epoch, "loss": float(loss), "ms_per_iter": (time.perf_counter() - t0) * 1e3,
                        "ranks": world, "users_per_rank": args.num_users}
+                if test_data is not None:      # main.py:197-211: loss and test accuracy are logged together
+                    acc, tl = test(model, loss_func, test_data, getattr(args, "test_batch_size", 1000))
+                    rec["accuracy(%)"] = 100.0 * acc
+                    rec["test_loss"] = tl
                 history.append(rec)
                 if rank == 0:
                     line = json.dumps(rec)

@@ -144,6 +144,11 @@ def test_psquantizer_matches_reference(oracle, name):
                 else:
                     agg = roundtrip(agg)
             ref = g["agg_s%d_p%d" % (st, i)]
+            if not np.isfinite(ref).all():     # non-finite gradients: the same entries are finite, and those agree
+                assert np.array_equal(np.isfinite(agg), np.isfinite(ref)), (name, st, i)
+                agg, ref = agg[np.isfinite(ref)], ref[np.isfinite(ref)]
+                if ref.size == 0:
+                    continue
             rel = np.linalg.norm((agg - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-30)
             assert rel <= 1e-6, (name, st, i, rel)
     if ef:
