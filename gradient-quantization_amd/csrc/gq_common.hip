@@ -108,6 +108,22 @@ GQ_API int gq_sub(const float *grad, const float *decoded, float *err, int64_t n
     return GQ_OK;
 }
 
+// ---- caller-supplied draws for the multi-tensor level kernels (gq_hsq_given_draws) -------------------------
+namespace gq {
+static thread_local const float *g_given_draws = nullptr;
+const float *take_given_draws() {
+    const float *r = g_given_draws;
+    g_given_draws = nullptr;
+    return r;
+}
+}  // namespace gq
+
+GQ_API int gq_hsq_given_draws(const float *r_flat) {
+    if (!r_flat) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_given_draws: null pointer");
+    gq::g_given_draws = r_flat;
+    return GQ_OK;
+}
+
 GQ_API int gq_profile_arm(int slot) {
     if (slot < 0 || slot >= GQ_PROFILE_SLOTS) return gq::fail(GQ_ERR_INVALID_ARG, "gq_profile_arm: slot %d", slot);
     if (!gq::g_prof_created[slot]) {

@@ -18,6 +18,8 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 // Number of compute units of the current device (cached).
 int cu_count();
+// the draws handed over by gq_hsq_given_draws on this thread (once), or nullptr
+const float *take_given_draws();
 // true (once) if gq_profile_arm was called on this thread: the events to attach to the next dispatch
 bool profile_take(hipEvent_t *start, hipEvent_t *stop);
 

@@ -26,7 +26,7 @@ template <typename LevelT>
 __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
-    uint64_t seed, uint8_t *__restrict__ wire) {
+    uint64_t seed, const float *__restrict__ r_flat, uint8_t *__restrict__ wire) {
     const float s = (float)(1 << n_bit), smax = s - 1.0f;
     const int64_t total4 = ntiles * 16;
     const int64_t stride = (int64_t)gridDim.x * BT_THREADS;
@@ -59,9 +59,10 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
                 const float x = fabsf(q) * s;
                 const float c = fminf(fmaxf(x, 0.0f), smax);
                 l = (x != x) ? INT32_MIN : (int)c;   // clamp(NaN) stays NaN and NaN -> int32 is INT_MIN in the reference (x86)
-                if (random_mode == GQ_RANDOM_DEVICE) {
+                if (random_mode != GQ_RANDOM_OFF) {   // GIVEN: the reference's draws, laid out like u_flat
                     const float prob = x - (float)l;
-                    l += (prob > uniform01(seed, (uint64_t)(4 * i + e))) ? 1 : 0;
+                    const float rr = random_mode == GQ_RANDOM_GIVEN ? r_flat[4 * i + e] : uniform01(seed, (uint64_t)(4 * i + e));
+                    l += (prob > rr) ? 1 : 0;
                 }
             }
             out[e] = (LevelT)l;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
 __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
-    uint64_t seed, const float *__restrict__ cb, uint8_t *__restrict__ wire) {
+    uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire) {
     // rows 20 floats apart: an odd number of 16-byte units spreads the random-row gathers over the banks
     __shared__ __attribute__((aligned(16))) float s_cb[256 * 20];
     for (int i = threadIdx.x; i < 256 * 16 / 4; i += BT_THREADS)
@@ -110,9 +111,10 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_kernel(
             const float x = fabsf((u_flat[g] - lb) / range) * s;
             const float c = fminf(fmaxf(x, 0.0f), smax);
             l = (x != x) ? INT32_MIN : (int)c;   // clamp(NaN) stays NaN and NaN -> int32 is INT_MIN in the reference (x86)
-            if (random_mode == GQ_RANDOM_DEVICE) {
+            if (random_mode != GQ_RANDOM_OFF) {   // GIVEN: the reference's draws, laid out like u_flat
                 const float prob = x - (float)l;
-                l += (prob > uniform01(seed, (uint64_t)g)) ? 1 : 0;
+                const float rr = random_mode == GQ_RANDOM_GIVEN ? r_flat[g] : uniform01(seed, (uint64_t)g);
+                l += (prob > rr) ? 1 : 0;
             }
         }
         if (q == 0) {
@@ -283,7 +285,7 @@ template <int D>
 __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_d_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
-    uint64_t seed, const float *__restrict__ cb, uint8_t *__restrict__ wire) {
+    uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire) {
     constexpr int UPS = D / 4;
     constexpr int RS = ((D / 4) & 1) ? D : D + 4;
     __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];
@@ -308,9 +310,10 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_d_kernel(
             const float x = fabsf((u_flat[g] - lb) / range) * s;
             const float c = fminf(fmaxf(x, 0.0f), smax);
             l = (x != x) ? INT32_MIN : (int)c;   // clamp(NaN) stays NaN and NaN -> int32 is INT_MIN in the reference (x86)
-            if (random_mode == GQ_RANDOM_DEVICE) {
+            if (random_mode != GQ_RANDOM_OFF) {   // GIVEN: the reference's draws, laid out like u_flat
                 const float prob = x - (float)l;
-                l += (prob > uniform01(seed, (uint64_t)g)) ? 1 : 0;
+                const float rr = random_mode == GQ_RANDOM_GIVEN ? r_flat[g] : uniform01(seed, (uint64_t)g);
+                l += (prob > rr) ? 1 : 0;
             }
         }
         if (q == 0) {
@@ -520,13 +523,14 @@ GQ_API int gq_hsq_levels_batched(const int64_t *seg_table, const int32_t *tile_s
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: bad sizes");
     if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !wire)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: null pointer");
-    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched: random_mode must be OFF or DEVICE");
+    const float *r_flat = random_mode == GQ_RANDOM_GIVEN ? gq::take_given_draws() : nullptr;
+    if (random_mode == GQ_RANDOM_GIVEN && !r_flat)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: GQ_RANDOM_GIVEN needs gq_hsq_given_draws() on this thread first");
     if (((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > 255)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: levels do not fit uint8");
     hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<uint8_t>, dim3((unsigned)gq::bt_grid(ntiles * 16)), dim3(gq::BT_THREADS), 0,
                        gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed,
-                       wire);
+                       r_flat, wire);
     GQ_CHECK_LAUNCH("gq_hsq_levels_batched");
     return GQ_OK;
 }
@@ -538,13 +542,14 @@ GQ_API int gq_hsq_levels_batched_ef(const int64_t *seg_table, const int32_t *til
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef: bad sizes");
     if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !codebook || !wire)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef: null pointer");
-    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched_ef: random_mode must be OFF or DEVICE");
+    const float *r_flat = random_mode == GQ_RANDOM_GIVEN ? gq::take_given_draws() : nullptr;
+    if (random_mode == GQ_RANDOM_GIVEN && !r_flat)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef: GQ_RANDOM_GIVEN needs gq_hsq_given_draws() on this thread first");
     if (((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > 255)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef: levels do not fit uint8");
     hipLaunchKernelGGL(gq::hsq_levels_ef_batched_kernel, dim3((unsigned)gq::bt_grid(ntiles * 256)), dim3(gq::BT_THREADS),
                        0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed,
-                       codebook, wire);
+                       r_flat, codebook, wire);
     GQ_CHECK_LAUNCH("gq_hsq_levels_batched_ef");
     return GQ_OK;
 }
@@ -616,18 +621,19 @@ GQ_API int gq_hsq_levels_batched_ef_d(const int64_t *seg_table, const int32_t *t
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef_d: bad sizes");
     if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !codebook || !wire)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef_d: null pointer");
-    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched_ef_d: random_mode must be OFF or DEVICE");
+    const float *r_flat = random_mode == GQ_RANDOM_GIVEN ? gq::take_given_draws() : nullptr;
+    if (random_mode == GQ_RANDOM_GIVEN && !r_flat)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef_d: GQ_RANDOM_GIVEN needs gq_hsq_given_draws() on this thread first");
     if (((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > 255)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef_d: levels do not fit uint8");
     if (d == 8) {
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_d_kernel<8>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 2)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
-                           n_bit, random_mode, seed, codebook, wire);
+                           n_bit, random_mode, seed, r_flat, codebook, wire);
     } else if (d == 32) {
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_d_kernel<32>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 8)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
-                           n_bit, random_mode, seed, codebook, wire);
+                           n_bit, random_mode, seed, r_flat, codebook, wire);
     } else {
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched_ef_d: d must be 8, 16 or 32 (K = 256)");
     }
@@ -642,12 +648,13 @@ GQ_API int gq_hsq_levels_batched_any(const int64_t *seg_table, const int32_t *ti
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: bad sizes");
     if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !wire)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: null pointer");
-    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched_any: random_mode must be OFF or DEVICE");
+    const float *r_flat = random_mode == GQ_RANDOM_GIVEN ? gq::take_given_draws() : nullptr;
+    if (random_mode == GQ_RANDOM_GIVEN && !r_flat)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: GQ_RANDOM_GIVEN needs gq_hsq_given_draws() on this thread first");
     if (level_bytes == 0) {   // n_bit == 32 (nearest_neighbor_compressor.py:14,75-76): u itself is the payload
         hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<float>, dim3((unsigned)gq::bt_grid(ntiles * 16)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
-                           1, GQ_RANDOM_OFF, (uint64_t)0, wire);
+                           1, GQ_RANDOM_OFF, (uint64_t)0, (const float *)nullptr, wire);
         GQ_CHECK_LAUNCH("gq_hsq_levels_batched_any");
         return GQ_OK;
     }
@@ -659,13 +666,13 @@ GQ_API int gq_hsq_levels_batched_any(const int64_t *seg_table, const int32_t *ti
     hipStream_t st = gq::as_stream(stream);
     if (level_bytes == 1)
         hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<uint8_t>, grid, block, 0, st, seg_table, tile_seg, ntiles, u_flat,
-                           seg_minmax, n_bit, random_mode, seed, wire);
+                           seg_minmax, n_bit, random_mode, seed, r_flat, wire);
     else if (level_bytes == 2)
         hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<int16_t>, grid, block, 0, st, seg_table, tile_seg, ntiles, u_flat,
-                           seg_minmax, n_bit, random_mode, seed, wire);
+                           seg_minmax, n_bit, random_mode, seed, r_flat, wire);
     else if (level_bytes == 4)
         hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<int32_t>, grid, block, 0, st, seg_table, tile_seg, ntiles, u_flat,
-                           seg_minmax, n_bit, random_mode, seed, wire);
+                           seg_minmax, n_bit, random_mode, seed, r_flat, wire);
     else
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: level_bytes must be 1, 2 or 4");
     GQ_CHECK_LAUNCH("gq_hsq_levels_batched_any");

@@ -25,7 +25,7 @@ EXPORTS = [
     "gq_hsq_encode_batched_d", "gq_hsq_decode_sum_batched_d", "gq_hsq_encode_batched_d_ef", "gq_hsq_levels_batched_ef_d",
     "gq_hsq_encode_batched_any", "gq_hsq_levels_batched_any", "gq_hsq_decode_sum_batched_any", "gq_hsq_error_batched_any",
     "gq_hsq_batched_any_supported", "gq_hsq_encode_batched_paged", "gq_qsgd_wide_compress", "gq_qsgd_wide_decode_sum",
-    "gq_profile_arm", "gq_profile_read", "gq_hsq_compress",
+    "gq_profile_arm", "gq_profile_read", "gq_hsq_compress", "gq_hsq_given_draws",
     "gq_pvq_encode", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
@@ -260,6 +260,11 @@ def hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat
                                      _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
                                      _dev_ptr(workspace, torch.float32, "workspace"), _stream())
     _check(rc, "gq_hsq_encode_batched")
+
+
+def hsq_given_draws(r_flat):
+    """The reference's draws (laid out like u_flat) for the next hsq_levels_batched* call with RANDOM_GIVEN."""
+    _check(lib().gq_hsq_given_draws(_dev_ptr(r_flat, torch.float32, "r_flat")), "gq_hsq_given_draws")
 
 
 def hsq_batched_any_supported(d, K):

@@ -116,17 +116,24 @@ class HSQCodec(object):
             self._partials = native.new_workspace(dev, self.M)
         return self._u, self._partials
 
-    def _levels(self, u, partials, levels, lb_ub, salt):
+    def uses_reference_draws(self):
+        """True if compress draws r = torch.rand(M) from the CPU generator as the reference does
+        (probabilistic_scalar_compressor.py:23-25; args.random with gq_rng = "reference")."""
+        nc = getattr(self.c, "norm_compressor", None)
+        return bool(self.c.compressed_norm and nc is not None and nc.random and nc._rng == "reference")
+
+    def _levels(self, u, partials, levels, lb_ub, salt, r=None):
         nc = self.c.norm_compressor
         if not nc.random:
             native.hsq_levels(u, nc.n_bit, native.RANDOM_OFF, None, 0, partials, lb_ub, levels)
         elif nc._rng == "reference":
-            r = torch.rand(self.M)
-            native.hsq_levels(u, nc.n_bit, native.RANDOM_GIVEN, r.to(u.device), 0, partials, lb_ub, levels)
+            if r is None:       # the quantizer hands over its slice of ONE torch.rand per record (same stream)
+                r = torch.rand(self.M).to(u.device)
+            native.hsq_levels(u, nc.n_bit, native.RANDOM_GIVEN, r, 0, partials, lb_ub, levels)
         else:
             native.hsq_levels(u, nc.n_bit, native.RANDOM_DEVICE, None, _next_seed() ^ salt, partials, lb_ub, levels)
 
-    def encode_into(self, grad, wire_user, off, salt):
+    def encode_into(self, grad, wire_user, off, salt, r=None):
         _require_device(grad, "HSQCodec.encode_into")
         dev = grad.device
         flat = grad.contiguous().view(-1)
@@ -137,7 +144,7 @@ class HSQCodec(object):
             nc = self.c.norm_compressor
             if nc.random and nc._rng == "reference":
                 native.hsq_encode(flat, cbk, codes, u, partials)
-                self._levels(u, partials, levels, lb_ub, salt)
+                self._levels(u, partials, levels, lb_ub, salt, r)
             else:   # encode + levels in one library call (gq_hsq_compress)
                 mode = native.RANDOM_DEVICE if nc.random else native.RANDOM_OFF
                 native.hsq_compress(flat, cbk, codes, u, partials, nc.n_bit, mode, None,
@@ -159,10 +166,10 @@ class HSQCodec(object):
                                      level_dtype=self.level_dtype)
         assert P == gathered.stride(0)
 
-    def roundtrip(self, grad, salt):
+    def roundtrip(self, grad, salt, r=None):
         dev = grad.device
         tmp = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
-        self.encode_into(grad, tmp, 0, salt)
+        self.encode_into(grad, tmp, 0, salt, r)
         out = torch.empty(self.numel, dtype=torch.float32, device=dev)
         self.decode_wire(tmp, 0, out)
         return out.view(self.shape)
@@ -373,12 +380,12 @@ class _BatchedBase(object):
         self._events[0] = ev
         self.ready = True
 
-    def roundtrip(self, tensors, slot, salt, errs=None, ef_scale=None):
+    def roundtrip(self, tensors, slot, salt, errs=None, ef_scale=None, draws=None):
         """decompress(compress(t)) for every batched tensor in a few launches; None if not batchable.
         With `errs`: t <- t + ef_scale*err in place first and err <- t - decoded afterwards."""
         if self._tmp_wire is None:
             self._tmp_wire = torch.zeros((1, self.user_bytes), dtype=torch.uint8, device=self.device)
-        if not self.encode(tensors, self._tmp_wire[0], slot, salt, errs, ef_scale):
+        if not self.encode(tensors, self._tmp_wire[0], slot, salt, errs, ef_scale, draws=draws):
             return None
         return self.decode_mean(self._tmp_wire, 1)
 
@@ -401,8 +408,6 @@ class BatchedHSQ(_BatchedBase):
         c = getattr(codec, "c", None)
         if type(codec) is not HSQCodec or c.K == c.dim:   # K == d: a random codebook per tensor
             return False
-        if c.compressed_norm and c.norm_compressor.random and c.norm_compressor._rng != "device":
-            return False
         return BatchedHSQ._prefilter(codec) or native.hsq_batched_any_supported(c.dim, c.K)
 
     @staticmethod
@@ -415,6 +420,8 @@ class BatchedHSQ(_BatchedBase):
         c0 = self.codecs[0].c
         self.n_bit = c0.n_bit                                  # 32: the projections travel as f32 (no level quantiser)
         self.random = bool(c0.compressed_norm and c0.norm_compressor.random)
+        self.reference_draws = self.codecs[0].uses_reference_draws()     # the reference's CPU draws, handed in per record
+        self._r_index = self._r_flat = None
         self.codebook = c0._codebook_on(device)
         nseg = len(self.idxs)
         table = torch.zeros((nseg, 8), dtype=torch.int64)
@@ -449,12 +456,29 @@ class BatchedHSQ(_BatchedBase):
         self.align = 16 if c0.dim % 4 == 0 else 4
         self.ws = native.new_workspace(device, self.ntiles * 64) if (self.prefilter or self.paged) else None
 
-    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None):
+    def _given_draws(self, draws):
+        """draws = (r_all on the device, {parameter index: offset of its M draws}): the reference's
+        torch.rand(M) per tensor, drawn by the quantizer in ONE call per record.  Laid out like u_flat for
+        the level kernels (one gather through an index built once)."""
+        r_all, offsets = draws
+        if self._r_index is None:
+            idx = torch.zeros(self.ntiles * 64, dtype=torch.int64)
+            for s, (i, cd) in enumerate(zip(self.idxs, self.codecs)):
+                first = int(self._layout[s, 2]) * 64
+                idx[first:first + cd.M] = torch.arange(offsets[i], offsets[i] + cd.M)
+            self._r_index = idx.to(self.device)
+            self._r_flat = torch.empty(self.ntiles * 64, dtype=torch.float32, device=self.device)
+        torch.index_select(r_all, 0, self._r_index, out=self._r_flat)
+        return self._r_flat
+
+    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None):
         """Compress `tensors` (one per batched parameter, in order) into one user's wire.
         Returns False (nothing launched) when a tensor is not a contiguous, 16-byte aligned f32
         tensor on this device: the caller then takes the per-tensor path for this step.
         With `errs` (error feedback, ps_quantizer.py:34-39) the same launches also do
         t += ef_scale*err (in place, before encoding) and err = t - decoded (in place, after)."""
+        if self.reference_draws and draws is None:
+            return False
         if self.prefilter and self.codebook.shape[1] != 16 and self.nseg > 384:
             return False    # d = 8 / 32: at most 384 tensors per launch
         if not self._upload(tensors, slot, self.align, errs):
@@ -473,6 +497,9 @@ class BatchedHSQ(_BatchedBase):
                                           wire_user, self.u_flat, minmax, ef_scale=ef)
         mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
         seed = (_next_seed() ^ salt) if self.random else 0
+        if self.reference_draws:
+            mode, seed = native.RANDOM_GIVEN, 0
+            native.hsq_given_draws(self._given_draws(draws))      # consumed by the level launch below
         if self.bytes:
             native.hsq_levels_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.u_flat, minmax, self.n_bit,
                                       mode, seed, wire_user, ef_codebook=self.codebook if errs is not None else None)
@@ -540,7 +567,7 @@ class BatchedQSGD(_BatchedBase):
         extra = torch.zeros((word + 1) // 2, dtype=torch.int64) if self.wide else None
         self._setup(table, extra, device, slots, user_bytes)
 
-    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None):
+    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None):
         """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place)."""
         if not self._upload(tensors, slot, 8, errs):
             return False
@@ -636,6 +663,17 @@ class PSQuantizer(object):
                 if len(idx) >= 2 and not getattr(args, "gq_no_batch", False):
                     self._groups.append([cls, idx, None])
         self.batch_idx = [i for g in self._groups for i in g[1]]
+        # gq_rng = "reference": the reference draws r = torch.rand(M) per compressed tensor, in parameter order, from
+        # the CPU generator (probabilistic_scalar_compressor.py:23).  torch.rand is one sequential stream, so ONE
+        # torch.rand(sum of M) per record (and one per two-phase apply) gives every tensor the same numbers; the
+        # multi-tensor kernels and the per-tensor path both take their slices from it.
+        self._draw_off, n = {}, 0
+        for i, c in enumerate(self.codecs):
+            if isinstance(c, HSQCodec) and c.uses_reference_draws():
+                self._draw_off[i] = n
+                n += c.M
+        self._draw_total = n
+        self._draw_host = None
         self.capacity = max(1, int(args.num_users))
         self.recorded = 0                   # record() calls since the last apply()
         self._wire = None
@@ -671,6 +709,27 @@ class PSQuantizer(object):
     def wire_bytes_per_user(self):
         return self.user_bytes
 
+    def _draws(self, device):
+        """One torch.rand for all reference-parity tensors of this record / two-phase apply -> (device tensor, offsets)."""
+        if not self._draw_total:
+            return None
+        if device.type != "cuda":
+            return torch.rand(self._draw_total), self._draw_off
+        if self._draw_host is None:
+            self._draw_host = [torch.empty(self._draw_total).pin_memory() for _ in range(2)]
+            self._draw_turn = 0
+            self._draw_events = [None, None]
+        k = self._draw_turn
+        self._draw_turn ^= 1
+        if self._draw_events[k] is not None:
+            self._draw_events[k].synchronize()      # the previous copy out of this pinned buffer
+        torch.rand(self._draw_total, out=self._draw_host[k])     # straight into pinned memory (a fresh 6 MB tensor per
+        dev_r = self._draw_host[k].to(device, non_blocking=True)  # record cost 20 ms of page faults on the GPU box)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._draw_events[k] = ev
+        return dev_r, self._draw_off
+
     # ---- reference protocol -------------------------------------------------------------
     def record(self, user, epoch):
         scale = _ef_scale(self.args, epoch)
@@ -680,6 +739,7 @@ class PSQuantizer(object):
         world, rank = _dist_world(self.process_group)
         salt = ((rank * 1000003 + user) * 0x9E3779B1) & (2 ** 62 - 1)
         skip = set()
+        draws = self._draws(dev)
         for grp in (self._groups if dev.type == "cuda" else []):
             cls, idxs, obj = grp
             if obj is None:
@@ -688,7 +748,7 @@ class PSQuantizer(object):
             # error feedback (ps_quantizer.py:35,39) rides in the same launches: grad += scale*error
             # before the encode, error = grad - decoded after it, both in place
             errs = [self.parameters[i].error[user] for i in idxs] if self.error_feedback else None
-            if obj.encode(grads, wire, slot, salt, errs, scale):
+            if obj.encode(grads, wire, slot, salt, errs, scale, draws=draws):
                 skip.update(idxs)
         if len(self.dense_idx) >= 2:
             # all small tensors with one concatenation straight into the packed wire region.  Under
@@ -717,7 +777,7 @@ class PSQuantizer(object):
                     native.axpy_inplace(grad, param.error[user].contiguous(), scale)
                 else:
                     grad.add_(scale * param.error[user])
-                codec.encode_into(grad, wire, off, salt)
+                codec.encode_into(grad, wire, off, salt, **self._slice(draws, i))
                 if hasattr(codec, "decode_wire"):
                     decoded = torch.empty(grad.numel(), dtype=torch.float32, device=grad.device)
                     codec.decode_wire(wire, off, decoded)
@@ -731,8 +791,15 @@ class PSQuantizer(object):
                 else:
                     param.error[user].data = grad - decoded
             else:
-                codec.encode_into(grad, wire, off, salt)
+                codec.encode_into(grad, wire, off, salt, **self._slice(draws, i))
         self.recorded += 1
+
+    def _slice(self, draws, i):
+        """This parameter's share of the record's draws as a keyword for the codec (nothing for the other codecs)."""
+        if draws is None or i not in self._draw_off:
+            return {}
+        o = self._draw_off[i]
+        return {"r": draws[0][o:o + self.codecs[i].M]}
 
     def _decode_all(self, gathered, two_phase, pending=()):
         """Mean of the R = gathered.shape[0] user payloads for every parameter (ps_quantizer.py:47-61),
@@ -767,13 +834,14 @@ class PSQuantizer(object):
         if split:
             pending.pop(0).wait()
             decode_part("tail")
+        draws2 = self._draws(gathered.device) if two_phase else None     # the second phase compresses again: new draws
         for gi, (cls, idxs, obj) in enumerate(groups):
             gs = group_views[gi]
             if two_phase:
                 # ps_quantizer.py:52-61, replicated on every rank (salt 0, same call count); with error
                 # feedback g += server_error and server_error = g - decoded happen inside the launches
                 serr = [self.parameters[i].server_error for i in idxs] if self.error_feedback else None
-                dec = obj.roundtrip(list(gs), self.capacity, 0, serr, 1.0)
+                dec = obj.roundtrip(list(gs), self.capacity, 0, serr, 1.0, draws=draws2)
                 if dec is None:     # not batchable this step: per-tensor second phase below
                     for i, g in zip(idxs, gs):
                         done[i] = g
@@ -802,13 +870,14 @@ class PSQuantizer(object):
             for i in single:
                 # ps_quantizer.py:52-61 -- identical on every rank (salt 0, same call count)
                 param, codec, g = self.parameters[i], self.codecs[i], done[i]
+                kw = self._slice(draws2, i)
                 if self.error_feedback:
                     g = g + param.server_error
-                    decoded = codec.roundtrip(g, 0)
+                    decoded = codec.roundtrip(g, 0, **kw)
                     param.server_error = g - decoded
                     g = decoded
                 else:
-                    g = codec.roundtrip(g, 0)
+                    g = codec.roundtrip(g, 0, **kw)
                 done[i] = g
         return [done[i] for i in range(self.num_layers)]
 

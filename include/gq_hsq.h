@@ -221,6 +221,14 @@ int gq_hsq_encode_batched_paged(const int64_t *seg_table, const int32_t *tile_se
                                 const float *codebook, int d, int K, int ef, float ef_scale, uint8_t *wire,
                                 float *u_flat, uint32_t *seg_minmax, float *workspace, void *stream);
 int gq_hsq_batched_any_supported(int d, int K);   /* 1 if gq_hsq_encode_batched_any serves (d, K) */
+/* Stochastic rounding with the REFERENCE's draws in the multi-tensor level kernels
+ * (probabilistic_scalar_compressor.py:23-26: r = torch.rand(M) per tensor, CPU generator): the caller draws them --
+ * torch.rand is one sequential stream, so ONE torch.rand(sum of M) per record() equals the reference's per-tensor
+ * calls in parameter order -- lays them out like u_flat (r_flat[tile * 64 + i] belongs to subvector i of tile
+ * `tile`; padding slots are not read) and hands the device pointer over with gq_hsq_given_draws; the NEXT
+ * gq_hsq_levels_batched* call on this thread with random_mode = GQ_RANDOM_GIVEN consumes it (compare is the
+ * reference's strict `frac > r`). */
+int gq_hsq_given_draws(const float *r_flat);
 int gq_hsq_encode_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                               const float *codebook, int d, int K, int code_bytes, int ef, float ef_scale,
                               uint8_t *wire, float *u_flat, uint32_t *seg_minmax, void *stream);

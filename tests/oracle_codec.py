@@ -11,11 +11,15 @@ from gq_amd.quantizers import DenseCodec, GenericCodec, HSQCodec, QSGDCodec
 
 
 class OracleHSQCodec(HSQCodec):
-    def encode_into(self, grad, wire_user, off, salt):
+    def encode_into(self, grad, wire_user, off, salt, r=None):
         c = self.c
-        assert c.compressed_norm and not c.norm_compressor.random, "oracle codec: deterministic levels only"
+        assert c.compressed_norm
+        random = bool(c.norm_compressor.random)
+        if random:      # reference-parity draws only: handed in by the quantizer, or drawn here as the reference does
+            assert c.norm_compressor._rng == "reference", "oracle codec: deterministic levels or the reference's draws"
+            r = (torch.rand(self.M) if r is None else r).cpu().numpy()
         cb = c.codewords.cpu().numpy()
-        res = oracle.hsq_compress(grad.detach().cpu().numpy().reshape(-1), cb, c.n_bit, 0)
+        res = oracle.hsq_compress(grad.detach().cpu().numpy().reshape(-1), cb, c.n_bit, 1 if random else 0, r)
         codes, levels, lb_ub = self._views(wire_user, off)
         codes.copy_(torch.from_numpy(res["codes"].astype(np.uint8 if self.code_dtype == torch.uint8 else np.int32)))
         levels.copy_(torch.from_numpy(res["levels"]).to(self.level_dtype))

@@ -152,6 +152,8 @@ def test_psquantizer_on_gpu_matches_reference(name):
     from test_host_logic import run_psq_fixture
     q = run_psq_fixture(name, None, device="cuda", tol=1e-6)
     assert q.codecs[0].__class__.__name__ in ("HSQCodec", "QSGDCodec")
+    if "_rand" in name:     # the reference's own draws, through the multi-tensor kernels (gq_hsq_given_draws)
+        assert q._groups and q._groups[0][2].ready and q._groups[0][2].reference_draws
 
 
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "psqd_*.npz"))))

@@ -183,6 +183,8 @@ def _psq_args(name, users):
         kw.update(c_dim=128, n_bit=2)
     if name.startswith("ring_"):
         kw["mode"] = "ring"
+    if "_rand" in name:      # the reference's stochastic rounding with its own CPU draws
+        kw.update(random=1, gq_rng="reference")
     return make_args(**kw)
 
 
@@ -196,6 +198,8 @@ def run_psq_fixture(name, factory, device="cpu", tol=1e-6):
     params = [torch.nn.Parameter(torch.zeros(*s, device=device)) for s in shapes]
     q = Quantizer(QSGDCompressor if "qsgd" in name else NearestNeighborCompressor, params, args,
                   codec_factory=factory)
+    if "seed_r" in g.files:
+        torch.manual_seed(int(g["seed_r"]))
     for st in range(steps):
         for u in range(U):
             for i, p in enumerate(params):

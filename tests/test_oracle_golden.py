@@ -111,10 +111,15 @@ def test_psquantizer_matches_reference(oracle, name):
     scale = 0.5 if "scale0.5" in name else (2 / (math.exp(-epoch) + 1) - 1)
     cb = _cb(16, 256)
 
+    random = "seed_r" in g.files          # args.random: r = torch.rand(M) per compress, global CPU generator
+    if random:
+        import torch
+        torch.manual_seed(int(g["seed_r"]))
+
     def roundtrip(x):
         if x.size <= 1000:
             return x.copy()
-        c = oracle.hsq_compress(x, cb, 6, 0)
+        c = oracle.hsq_compress(x, cb, 6, 1, torch.rand(x.size // 16).numpy()) if random else oracle.hsq_compress(x, cb, 6, 0)
         return oracle.hsq_decompress(c["codes"], c["levels"], c["lb"], c["ub"], cb, 6).reshape(x.shape)
 
     err = {(i, u): None for i in range(P) for u in range(U)}

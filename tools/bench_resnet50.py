@@ -40,6 +40,7 @@ def run(tag, comp, users=1, steps=20, **kw):
 
 
 run("HSQ batched (segment table)", NearestNeighborCompressor)
+run("HSQ batched, the reference's CPU draws", NearestNeighborCompressor, gq_rng="reference")
 run("HSQ per-tensor launches", NearestNeighborCompressor, gq_no_batch=True)
 run("HSQ batched, 8 simulated users", NearestNeighborCompressor, users=8, steps=5)
 run("QSGD d128 n2 batched, packed wire", QSGDCompressor, c_dim=128, n_bit=2)
