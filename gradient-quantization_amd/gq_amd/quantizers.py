@@ -284,6 +284,9 @@ class _BatchedBase(object):
         self._table_words = self.nseg * 8
         host = torch.cat([table.view(-1), extra.view(-1)]) if extra is not None else table.view(-1).clone()
         self._host = [host.clone().pin_memory() for _ in range(slots + 1)]
+        self._host_np = [h[:self._table_words].view(self.nseg, 8).numpy() for h in self._host]   # views of the pinned tables
+        self._zeros = [0] * self.nseg
+        self._last_ptrs = self._last_eptrs = None
         self._events = [None] * (slots + 1)
         self._dev = torch.empty_like(host, device=device)
         self._tmp_wire = None
@@ -310,31 +313,34 @@ class _BatchedBase(object):
 
     def _upload(self, tensors, slot, align, errs=None):
         """Column 0 of the segment table <- the tensors' device pointers; column 7 <- the error
-        buffers' (error-feedback kernels) or 0.  False if any tensor cannot be addressed that way."""
-        def pointers(ts):
-            out = []
+        buffers' (error-feedback kernels) or 0.  False if any tensor cannot be addressed that way.
+        The header goes to the device every time (it also carries the reset values of the kernels' min / max
+        accumulators); when the pointers are the ones of the last upload (gradients that keep their storage from
+        step to step) the pinned copy is sent as it is, without checking and rewriting the table."""
+        ptrs = [g.data_ptr() for g in tensors]
+        eptrs = [e.data_ptr() for e in errs] if errs is not None else self._zeros
+        if self.ready and ptrs == self._last_ptrs and eptrs == self._last_eptrs:
+            self._dev.copy_(self._host[self._last_slot], non_blocking=True)     # unchanged since its last copy
+            self._events[self._last_slot].record()     # a later rewrite of this pinned buffer waits for this copy too
+            return True
+        for ts in (tensors, errs or ()):
             for g in ts:
-                ptr = g.data_ptr()
-                if g.device != self.device or g.dtype != torch.float32 or not g.is_contiguous() or ptr % align:
-                    return None
-                out.append(ptr)
-            return out
-        ptrs = pointers(tensors)
-        eptrs = pointers(errs) if errs is not None else [0] * len(tensors)
-        if ptrs is None or eptrs is None or len(eptrs) != len(ptrs):
+                if g.device != self.device or g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() % align:
+                    return False
+        if len(eptrs) != len(ptrs):
             return False
         slot %= len(self._host)
         if self._events[slot] is not None:
             self._events[slot].synchronize()       # the previous copy out of this pinned buffer
-        host = self._host[slot]
-        tab = host[:self._table_words].view(self.nseg, 8)
-        tab[:, 0] = torch.tensor(ptrs, dtype=torch.int64)
-        tab[:, 7] = torch.tensor(eptrs, dtype=torch.int64)
-        self._dev.copy_(host, non_blocking=True)
+        tab = self._host_np[slot]
+        tab[:, 0] = ptrs
+        tab[:, 7] = eptrs
+        self._dev.copy_(self._host[slot], non_blocking=True)
         self.ready = True
-        ev = torch.cuda.Event()
-        ev.record()
-        self._events[slot] = ev
+        self._last_ptrs, self._last_eptrs, self._last_slot = ptrs, eptrs, slot
+        if self._events[slot] is None:
+            self._events[slot] = torch.cuda.Event()
+        self._events[slot].record()
         return True
 
     def _part(self, part, first_seg):
@@ -374,6 +380,7 @@ class _BatchedBase(object):
     def upload_layout(self):
         """Device header with the layout columns only (no tensor pointers): enough for decode_mean,
         which a ring rank may need before it has encoded anything."""
+        self._last_ptrs = self._last_eptrs = None
         self._dev.copy_(self._host[0], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -455,6 +462,11 @@ class BatchedHSQ(_BatchedBase):
         self.bytes = self.prefilter and self.level_dtype == torch.uint8               # which levels / decode
         self.align = 16 if c0.dim % 4 == 0 else 4
         self.ws = native.new_workspace(device, self.ntiles * 64) if (self.prefilter or self.paged) else None
+        # the default configuration's launches with their constant arguments marshalled once
+        self._fast = None
+        if self.prefilter and self.bytes and c0.dim == 16:
+            self._fast = native.PreparedHSQ16(self._dev[:self._table_words], self.tile_seg, self.nseg, self.ntiles, self.codebook,
+                                              self.u_flat, self._dev[self._table_words:].view(torch.int32), self.ws, self.n_bit)
 
     def _given_draws(self, draws):
         """draws = (r_all on the device, {parameter index: offset of its M draws}): the reference's
@@ -483,9 +495,19 @@ class BatchedHSQ(_BatchedBase):
             return False    # d = 8 / 32: at most 384 tensors per launch
         if not self._upload(tensors, slot, self.align, errs):
             return False
+        ef = ef_scale if errs is not None else None
+        if self._fast is not None:
+            self._fast.encode(wire_user, ef)
+            if self.reference_draws:
+                native.hsq_given_draws(self._given_draws(draws))
+                self._fast.levels(wire_user, native.RANDOM_GIVEN, 0, errs is not None)
+            elif self.random:
+                self._fast.levels(wire_user, native.RANDOM_DEVICE, _next_seed() ^ salt, errs is not None)
+            else:
+                self._fast.levels(wire_user, native.RANDOM_OFF, 0, errs is not None)
+            return True
         seg_table = self._dev[:self._table_words]
         minmax = self._dev[self._table_words:].view(torch.int32)
-        ef = ef_scale if errs is not None else None
         if self.prefilter:
             native.hsq_encode_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.codebook, wire_user,
                                       self.u_flat, minmax, self.ws, ef_scale=ef)
@@ -512,6 +534,9 @@ class BatchedHSQ(_BatchedBase):
         return True
 
     def _launch_decode(self, table, tile_seg, nseg, ntiles, gathered, R, out):
+        if self._fast is not None and nseg == self.nseg and ntiles == self.ntiles and table.data_ptr() == self._dev.data_ptr():
+            self._fast.decode(gathered, R, out)
+            return
         if self.bytes:
             native.hsq_decode_sum_batched(table, tile_seg, nseg, ntiles, gathered, self.codebook, self.n_bit, out, R)
         else:
@@ -674,6 +699,7 @@ class PSQuantizer(object):
                 n += c.M
         self._draw_total = n
         self._draw_host = None
+        self._plan = None
         self.capacity = max(1, int(args.num_users))
         self.recorded = 0                   # record() calls since the last apply()
         self._wire = None
@@ -740,11 +766,12 @@ class PSQuantizer(object):
         salt = ((rank * 1000003 + user) * 0x9E3779B1) & (2 ** 62 - 1)
         skip = set()
         draws = self._draws(dev)
+        all_grads = [p.grad for p in self.parameters]     # (p.grad.data builds an alias tensor per access: ~1 us each)
         for grp in (self._groups if dev.type == "cuda" else []):
             cls, idxs, obj = grp
             if obj is None:
                 obj = grp[2] = cls(self.codecs, self.offsets, idxs, dev, self.capacity, self.user_bytes)
-            grads = [self.parameters[i].grad.data for i in idxs]
+            grads = [all_grads[i] for i in idxs]
             # error feedback (ps_quantizer.py:35,39) rides in the same launches: grad += scale*error
             # before the encode, error = grad - decoded after it, both in place
             errs = [self.parameters[i].error[user] for i in idxs] if self.error_feedback else None
@@ -764,8 +791,12 @@ class PSQuantizer(object):
                     o += n
                 self._dense_in = {k: v for k, v in self._dense_in.items() if k[0] == key[0]}   # drop a replaced wire's
                 self._dense_in[key] = views
-            torch._foreach_copy_(views, [self.parameters[i].grad.data for i in self.dense_idx])
+            with torch.no_grad():
+                torch._foreach_copy_(views, [all_grads[i] for i in self.dense_idx])
             skip.update(self.dense_idx)
+        if len(skip) == self.num_layers:     # the usual case: everything went through the multi-tensor launches
+            self.recorded += 1
+            return
         for i, param in enumerate(self.parameters):
             if i in skip:
                 continue
@@ -813,16 +844,21 @@ class PSQuantizer(object):
         on_gpu = gathered.device.type == "cuda"
         # a group that did not encode in multi-tensor form this run (unaligned tensors, too many of them) is not
         # `ready`: its tensors take the per-tensor decode below
-        groups = [g for g in (self._groups if on_gpu else []) if g[2] is not None and g[2].ready]
-        batched = set(i for g in groups for i in g[1])
-        single = [i for i in range(self.num_layers) if i not in batched and i not in self.dense_idx or
-                  (i in self.dense_idx and len(self.dense_idx) < 2)]
+        key = (on_gpu,) + tuple(g[2] is not None and g[2].ready for g in self._groups)
+        if self._plan is None or self._plan[0] != key:      # who decodes what: rebuilt only when a group's state changes
+            groups = [g for g in (self._groups if on_gpu else []) if g[2] is not None and g[2].ready]
+            batched = set(i for g in groups for i in g[1])
+            dense = set(self.dense_idx) if len(self.dense_idx) >= 2 else set()
+            single = [i for i in range(self.num_layers) if i not in batched and i not in dense]
+            firsts = [sum(1 for i in g[1] if self.offsets[i] < self.cut) for g in groups]
+            self._plan = (key, groups, single, firsts)
+        _, groups, single, firsts = self._plan
+        single = list(single)
         group_views = {}
 
         def decode_part(part):
             for gi, (cls, idxs, obj) in enumerate(groups):
-                first = sum(1 for i in idxs if self.offsets[i] < self.cut) if split else 0
-                group_views[gi] = obj.decode_mean(gathered, R, part if split else None, first)
+                group_views[gi] = obj.decode_mean(gathered, R, part if split else None, firsts[gi] if split else 0)
             for i in single:
                 if split and (self.offsets[i] < self.cut) != (part == "head"):
                     continue

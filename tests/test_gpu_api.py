@@ -701,6 +701,38 @@ def test_probabilistic_vector_compressor_matches_oracle_and_is_unbiased(oracle):
     assert torch.allclose(c4.c_dagger, c4.codewords, atol=1e-5)
 
 
+@pytest.mark.parametrize("quant", ["hsq", "qsgd", "terngrad"])
+def test_batched_quantizer_gradients_updated_in_place_between_steps(quant):
+    """Gradients that KEEP their storage from step to step (the pointer table is then not rewritten) but change their
+    values, shrinking: the per-tensor (min, max) accumulators must start afresh every step.  Multi-tensor path ==
+    per-tensor path over three steps, bit for bit."""
+    from gq_amd.compressors import NearestNeighborCompressor, QSGDCompressor
+    from gq_amd.quantizers import Quantizer
+    shapes = [(96, 112), (96,), (64, 64, 3, 3), (40, 128), (12,), (1024,)]
+    kw = {"hsq": {}, "qsgd": dict(c_dim=128, n_bit=2), "terngrad": dict(c_dim=0, n_bit=1)}[quant]
+    comp = NearestNeighborCompressor if quant == "hsq" else QSGDCompressor
+    outs = []
+    for no_batch in (False, True):
+        torch.manual_seed(3)
+        params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in shapes]
+        q = Quantizer(comp, params, make_args(num_users=1, gq_no_batch=no_batch, **kw))
+        grads = [torch.randn(s, device="cuda") for s in shapes]
+        res = []
+        for step in range(3):
+            for p, g in zip(params, grads):
+                p.grad = g
+            q.record(0, epoch=1)
+            q.apply()
+            res.append([p.grad.data.clone() for p in params])
+            for g in grads:
+                g.mul_(0.25)            # same storage, smaller range: a stale (min, max) would show
+        outs.append(res)
+        assert bool(q._groups) != no_batch
+    for a, b in zip(outs[0], outs[1]):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+
+
 PVQ_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "pvq_*.npz")))
 RESIDUAL_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "residual_*.npz")))
 

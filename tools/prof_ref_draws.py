@@ -6,7 +6,7 @@ import torch
 from gq_amd.compressors import NearestNeighborCompressor
 from gq_amd.quantizers import Quantizer
 shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "resnet50_cifar_shapes.json")))["parameter_shapes"]
-args=Namespace(c_dim=16,k_bit=8,n_bit=6,no_cuda=False,random=1,ef=False,two_phase=False,scale="exp",num_users=1,mode="ps",cr=256,gq_rng="reference")
+args=Namespace(c_dim=16,k_bit=8,n_bit=6,no_cuda=False,random=1,ef=False,two_phase=False,scale="exp",num_users=1,mode="ps",cr=256,gq_rng=os.environ.get("GQ_PROF_RNG", "device"))
 params=[torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in shapes]
 q=Quantizer(NearestNeighborCompressor, params, args)
 grads=[torch.randn(p.shape, device="cuda")*1e-3 for p in params]
