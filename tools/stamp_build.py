@@ -36,6 +36,8 @@ rep("        ti = tin;\n        t = tn;\n        tn = BATCHED ? tnn : draw();\n 
     "          unsigned long long *o = reinterpret_cast<unsigned long long *>(ws_worklist(ws) + (M - 65536)) + (blockIdx.x * 8 + wave) * 10;\n"
     "          for (int i = 0; i < 6; ++i) o[i] = stamp_acc[i];\n"
     "          o[6] = rt_entry; o[7] = rt0; o[8] = rt1; o[9] = ntl; } }\n    if (BATCHED) {\n        flush_minmax();")
+# diagnostics marks off: the fix-up log shares the workspace region the stamps are written to
+rep("if (!BATCHED && lane == 0) worklist[", "if (false) worklist[")
 open(p, "w").write(s)
 out = os.path.join(ROOT, "tools", "exp")
 os.makedirs(out, exist_ok=True)

@@ -45,11 +45,13 @@ rep("    if (threadIdx.x == 0) s_next = PF_WAVES;", ST % 1 + "    if (threadIdx.
 rep("    __syncthreads();\n    // A fragments of v_mfma", ST % 2 + "    __syncthreads();\n" + ST % 3 + "    // A fragments of v_mfma")   # LDS written / barrier passed
 rep("    int64_t tn = draw();                // the tile after", ST % 4 + "    int64_t tn = draw();                // the tile after")   # fragments read
 rep("    while (t < tile_end) {\n        // single tensor: tn was drawn", ST % 5 + "    while (t < tile_end) {\n        // single tensor: tn was drawn")
-rep("    write_minmax_partials<PF_WAVES>(lmin, lmax, ws);",
-    ST % 6 + "    write_minmax_partials<PF_WAVES>(lmin, lmax, ws);\n" + ST % 7 +
+rep("    write_minmax_partials<PF_WAVES>(lmin, lmax, ws, sawnan);",
+    ST % 6 + "    write_minmax_partials<PF_WAVES>(lmin, lmax, ws, sawnan);\n" + ST % 7 +
     "    if (lane == 0 && blockIdx.x < 256) {\n"
     "        unsigned long long *o = reinterpret_cast<unsigned long long *>(ws_worklist(ws) + (M - 65536)) + (blockIdx.x * 8 + wave) * 8;\n"
     "        for (int i = 0; i < 8; ++i) o[i] = pst[i];\n    }")
+# diagnostics marks off: the fix-up log shares the workspace region the stamps are written to
+rep("if (!BATCHED && lane == 0) worklist[", "if (false) worklist[")
 open(p, "w").write(s)
 out = os.path.join(ROOT, "tools", "exp")
 os.makedirs(out, exist_ok=True)
