@@ -722,9 +722,6 @@ GQ_API int gq_hsq_encode_batched_paged(const int64_t *seg_table, const int32_t *
     if (nseg > (d == 16 ? gq::PF_LDS_SEGS : 384))
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched_paged: at most 384 tensors per launch");
     hipStream_t st = gq::as_stream(stream);
-    if (d == 16)
-        return gq::encode_batched_paged16(seg_table, tile_seg, nseg, ntiles, codebook, K, ef, ef_scale, wire, u_flat,
-                                          seg_minmax, workspace, st);
     return gq::launch_pfd_batched_paged(seg_table, tile_seg, nseg, ntiles, codebook, d, K, ef, ef_scale, wire, u_flat,
                                         seg_minmax, workspace, st);
 }

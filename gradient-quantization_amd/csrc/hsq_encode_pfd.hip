@@ -44,6 +44,7 @@ struct PfdArgs {
     int merge;        // the (code, u) already in the output unless this page beats it
     int last_page;    // PAGED: this launch produces the final projections (fold their min / max)
     int tiles_q, tiles_r;   // tiles per workgroup, split on the host (hsq_encode_pf.hip): the first tiles_r take one more
+    int npages;             // PAGED: pages of 256 codewords THIS launch scores (all of them resident in LDS)
 };
 
 static void pfd_split(PfdArgs &a, int64_t ntiles, int64_t blocks) {
@@ -64,12 +65,19 @@ constexpr int PFD_LDS_SEGS = 384;   // batched form: segment records kept in LDS
 // v = grad + ef_scale * error (product rounded, then the add), v is written back over grad, and the level
 // kernel (gq_hsq_levels_batched_ef_d) later writes error = v - decoded.
 template <typename CodeT, int D, bool BATCHED = false, bool EF = false, bool PAGED = false>
-__global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode_pfd_kernel(const PfdArgs a) {
+__global__ __launch_bounds__((D == 32 ? GQ_W32 : (D == 16 ? 8 : GQ_W8)) * 64, 1) void hsq_encode_pfd_kernel(const PfdArgs a) {
     // one workgroup per CU: 12 waves (three per SIMD) for D = 8, 8 waves (two per SIMD) for D = 32; the waves share
     // the workgroup's contiguous run of tiles through an LDS counter (hsq_encode_pf.hip)
-    constexpr int WAVES = D == 32 ? GQ_W32 : GQ_W8;
+    constexpr int WAVES = D == 32 ? GQ_W32 : (D == 16 ? 8 : GQ_W8);   // D = 16: two waves per SIMD, as hsq_encode_pf.hip
     constexpr int THREADS = WAVES * 64;
-    static_assert(D == 8 || D == 32, "built for D = 8 and D = 32 (D = 16: hsq_encode_pf.hip)");
+    static_assert(D == 8 || D == 16 || D == 32, "built for D = 8, 16 (PAGED only; K = 256: hsq_encode_pf.hip) and 32");
+    // PAGED: K = 256 * pages.  A launch keeps `a.npages` pages of the codebook in LDS (bf16 fragments and the f32
+    // image for the exact rescoring: as many as fit), a tile's subvectors are loaded and split ONCE and scored
+    // against one page after the other (per-page top-2 trackers, folded into running ones that remember the
+    // page), and the ONE exact rescoring / fix-up at the end of the tile covers all of them.  Before, every page
+    // was a launch of its own that re-read the gradient (K = 1024: 4x, K = 4096: 16x the traffic and 4x / 16x the
+    // per-tile overhead).  Codebooks beyond the LDS take several such launches, merged in place as before.
+    const int npages = PAGED ? a.npages : 1;
     constexpr int KS = D > 16 ? D / 16 : 1;    // MFMA k-steps per chain
     constexpr int QS = 4 * D + 4;              // LDS floats per group of 4 codewords: an odd number of 16-byte units
     const float *__restrict__ cb = a.cb;
@@ -79,21 +87,21 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode
     const int64_t M = a.M;
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *const s_cb = lds;                                                         // [64 groups][QS]
-    bf16x8 *const s_a = reinterpret_cast<bf16x8 *>(lds + 64 * QS);                   // [8 * KS * 2][64 lanes]
+    float *const s_cb = lds;                                                         // [npages * 64 groups][QS]
+    bf16x8 *const s_a = reinterpret_cast<bf16x8 *>(lds + npages * 64 * QS);          // [npages * 8 * KS * 2][64 lanes]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
 
     // exact f32 codebook, groups of 4 codewords interleaved: s_cb[(k>>2)*QS + 4*e + (k&3)] = c[k][e]
     __shared__ int s_next;
     if (threadIdx.x == 0) s_next = WAVES;
-    for (int i = threadIdx.x; i < 256 * D; i += THREADS) {
+    for (int i = threadIdx.x; i < npages * 256 * D; i += THREADS) {
         const int k = i / D, e = i % D;
         s_cb[(k >> 2) * QS + 4 * e + (k & 3)] = cb[i];
     }
     // A fragments of v_mfma_f32_32x32x16_bf16: lane (row j, half h) of k-step s holds
     // c[rb*32 + j][16 s + 8 h .. + 7] (zeros beyond D), split into bf16 hi and lo
-    for (int i = threadIdx.x; i < 8 * KS * 64; i += THREADS) {
+    for (int i = threadIdx.x; i < npages * 8 * KS * 64; i += THREADS) {
         const int l = i & 63, s = (i >> 6) % KS, rb = i / (64 * KS);
         const int row = rb * 32 + (l & 31), e0 = 16 * s + 8 * (l >> 5);
         f32x4 q0 = {0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0;
@@ -115,8 +123,12 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode
     __shared__ float s_c1[WAVES];
     {
         float l1 = 0.0f;
+        for (int k = threadIdx.x & 255; k < npages * 256; k += 256) {
+            float rowsum = 0.0f;
 #pragma unroll
-        for (int e = 0; e < D; ++e) l1 += fabsf(s_cb[((threadIdx.x & 255) >> 2) * QS + 4 * e + (threadIdx.x & 3)]);
+            for (int e = 0; e < D; ++e) rowsum += fabsf(s_cb[(k >> 2) * QS + 4 * e + (k & 3)]);
+            l1 = fmaxf(l1, rowsum);
+        }
         l1 = wave_max(l1);
         if (lane == 0) s_c1[wave] = l1;
     }
@@ -310,49 +322,67 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode
         // ---- prefilter: 16 chains in the order (rb, block 0), (rb, block 1); top-2 GROUP keys per
         // (block, row-block half).  The MFMAs of chain c+1 sit between the key operations of chain c.
         unsigned best[4] = {0, 0, 0, 0}, second[4] = {0, 0, 0, 0};
+        int bpage[4] = {0, 0, 0, 0};     // PAGED: the page each tracker's best group belongs to
         unsigned vmask = KEY_MASK;
         asm volatile("" : "+v"(vmask));  // keep the mask in a VGPR: v_and_or with an SGPR operand issues slower
-        auto group_key = [&](const f32x16 &x, int rb, int q) {   // group q = registers 4q..4q+3 = four consecutive rows
-            return and_or(__float_as_uint(absmax4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3])), vmask,
-                          (unsigned)((rb & 3) * 4 + q));
-        };
-        auto track = [&](int trk, unsigned k0, unsigned k1) {
-            second[trk] = max(second[trk], med3u(best[trk], k0, k1));
-            best[trk] = max3u(best[trk], k0, k1);
-        };
-        bf16x8 ahi[2][KS], alo[2][KS];   // A fragments, double-buffered by row-block parity
-        load_a(0, ahi[0], alo[0]);
-        f32x16 acc = {0};
+        for (int page = 0; page < npages; ++page) {
+            unsigned pbest[4] = {0, 0, 0, 0}, psecond[4] = {0, 0, 0, 0};   // this page's top-2 group keys
+            auto group_key = [&](const f32x16 &x, int rb, int q) {   // group q = registers 4q..4q+3 = four consecutive rows
+                return and_or(__float_as_uint(absmax4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3])), vmask,
+                              (unsigned)((rb & 3) * 4 + q));
+            };
+            auto track = [&](int trk, unsigned k0, unsigned k1) {
+                psecond[trk] = max(psecond[trk], med3u(pbest[trk], k0, k1));
+                pbest[trk] = max3u(pbest[trk], k0, k1);
+            };
+            const int rb0 = page * 8;        // the page's first row block in s_a
+            bf16x8 ahi[2][KS], alo[2][KS];   // A fragments, double-buffered by row-block parity
+            load_a(rb0, ahi[0], alo[0]);
+            f32x16 acc = {0};
 #pragma unroll
-        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[0][s], vh[0][s], acc, 0, 0, 0);
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[0][s], vh[0][s], acc, 0, 0, 0);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[0][s], vl[0][s], acc, 0, 0, 0);
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[0][s], vl[0][s], acc, 0, 0, 0);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[0][s], vh[0][s], acc, 0, 0, 0);
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[0][s], vh[0][s], acc, 0, 0, 0);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int rb = c >> 1, blk = c & 1, trk = blk * 2 + (rb >> 2);
-            if (blk == 0 && rb + 1 < 8) load_a(rb + 1, ahi[(rb + 1) & 1], alo[(rb + 1) & 1]);   // a row block ahead
-            if (c + 1 < 16) {
-                const int nr = (c + 1) >> 1, nb = (c + 1) & 1, ab = nr & 1;
-                f32x16 nacc = {0};
-                __builtin_amdgcn_sched_barrier(0);
+            for (int c = 0; c < 16; ++c) {
+                const int rb = c >> 1, blk = c & 1, trk = blk * 2 + (rb >> 2);
+                if (blk == 0 && rb + 1 < 8) load_a(rb0 + rb + 1, ahi[(rb + 1) & 1], alo[(rb + 1) & 1]);   // a row block ahead
+                if (c + 1 < 16) {
+                    const int nr = (c + 1) >> 1, nb = (c + 1) & 1, ab = nr & 1;
+                    f32x16 nacc = {0};
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s = 0; s < KS; ++s) nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[ab][s], vh[nb][s], nacc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                track(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int s = 0; s < KS; ++s) nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[ab][s], vh[nb][s], nacc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    track(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s = 0; s < KS; ++s) nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ab][s], vl[nb][s], nacc, 0, 0, 0);
+                    for (int s = 0; s < KS; ++s) nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ab][s], vl[nb][s], nacc, 0, 0, 0);
 #pragma unroll
-                for (int s = 0; s < KS; ++s) nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ab][s], vh[nb][s], nacc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                track(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
-                __builtin_amdgcn_sched_barrier(0);
-                acc = nacc;
-            } else {
-                track(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
-                track(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
+                    for (int s = 0; s < KS; ++s) nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ab][s], vh[nb][s], nacc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    track(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = nacc;
+                } else {
+                    track(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
+                    track(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
+                }
+            }
+            // fold the page's trackers into the running ones (a later page wins only with a strictly larger key)
+#pragma unroll
+            for (int trk = 0; trk < 4; ++trk) {
+                if (!PAGED) {
+                    best[trk] = pbest[trk];
+                    second[trk] = psecond[trk];
+                } else {
+                    const bool take = (pbest[trk] & KEY_MASK) > (best[trk] & KEY_MASK);
+                    second[trk] = max3u(second[trk], psecond[trk], take ? best[trk] : pbest[trk]);
+                    bpage[trk] = take ? page : bpage[trk];
+                    best[trk] = take ? pbest[trk] : best[trk];
+                }
             }
         }
 
@@ -365,7 +395,8 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode
             const bool useB = (bB & KEY_MASK) > (bA & KEY_MASK);
             const unsigned bw = useB ? bB : bA, bl = useB ? bA : bB;
             const int gid = (int)(bw & 31u);
-            k1[blk] = ((gid >> 2) + (useB ? 4 : 0)) * 32 + 8 * (gid & 3) + 4 * h;   // rows k1 .. k1+3 (registers 4q..4q+3)
+            const int pg = PAGED ? (useB ? bpage[2 * blk + 1] : bpage[2 * blk]) : 0;
+            k1[blk] = pg * 256 + ((gid >> 2) + (useB ? 4 : 0)) * 32 + 8 * (gid & 3) + 4 * h;   // rows k1 .. k1+3 (registers 4q..4q+3)
             s2[blk] = max3u(second[2 * blk], second[2 * blk + 1], bl) | 31u;         // upper end of its bucket
             bk[blk] = bw;
         }
@@ -453,7 +484,7 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : GQ_W8) * 64, 1) void hsq_encode
             int bi = lane;
             // rare path: keep it light on registers (one codeword at a time, 8 LDS reads in flight)
 #pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 4 * npages; ++q) {
                 const int k = q * 64 + lane;
                 const float *row = s_cb + (k >> 2) * QS + (k & 3);
                 float sc = 0.0f;
@@ -553,22 +584,37 @@ static int launch_pfd(const float *grad, const float *codebook, int64_t M, CodeT
     return GQ_OK;
 }
 
-// K = 256 * pages: one launch per page of 256 codewords, merged in place (PAGED, hsq_encode_pf.hip)
+// LDS of a launch that keeps `pages` pages resident: the f32 image for the exact rescoring + the bf16 fragments
+template <int D>
+static constexpr size_t pfd_lds_bytes(int pages) {
+    constexpr int KS = D > 16 ? D / 16 : 1;
+    return (size_t)pages * ((size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16);
+}
+// pages per launch: what fits beside the kernel's static LDS (the batched form keeps 24 KiB of segment records there);
+// a dynamic allocation that fills the CU's 160 KiB to the last byte is refused at dispatch
+template <int D>
+static int pfd_pages_per_launch(bool batched) {
+    const size_t budget = batched ? (size_t)132 * 1024 : (size_t)150 * 1024;
+    int p = (int)(budget / pfd_lds_bytes<D>(1));
+    return p < 1 ? 1 : p;
+}
+
+// K = 256 * pages (PAGED): as many pages per launch as the LDS holds, launches merged in place (hsq_encode_pf.hip)
 template <int D>
 static int launch_pfd_paged(const float *grad, const float *codebook, int64_t M, int K, int32_t *codes, float *u, float *ws,
                             hipStream_t st) {
-    constexpr int KS = D > 16 ? D / 16 : 1;
-    constexpr int WAVES = D == 32 ? GQ_W32 : GQ_W8, THREADS = WAVES * 64;
-    constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
+    constexpr int WAVES = D == 32 ? GQ_W32 : (D == 16 ? 8 : GQ_W8), THREADS = WAVES * 64;
     auto kernel = hsq_encode_pfd_kernel<int32_t, D, false, false, true>;
+    const int per = pfd_pages_per_launch<D>(false), npages = K / 256;
     static const int bpc = [] {
+        const size_t lds = pfd_lds_bytes<D>(pfd_pages_per_launch<D>(false));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<int32_t, D, false, false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
         return resident_blocks_per_cu(hsq_encode_pfd_kernel<int32_t, D, false, false, true>, THREADS, lds);
     }();
     const int64_t blocks = pfd_grid((M + 63) / 64, bpc, WAVES);
-    for (int page = 0; page * 256 < K; ++page) {
+    for (int page = 0; page < npages; page += per) {
         PfdArgs a = {};
         a.grad = grad;
         a.M = M;
@@ -576,13 +622,14 @@ static int launch_pfd_paged(const float *grad, const float *codebook, int64_t M,
         a.u = u;
         a.cb = codebook + (size_t)page * 256 * D;
         a.ws = ws;
+        a.npages = npages - page < per ? npages - page : per;
         a.code_base = page * 256;
         a.merge = page > 0;
-        a.last_page = (page + 1) * 256 >= K;
+        a.last_page = page + a.npages >= npages;
         pfd_split(a, (M + 63) / 64, blocks);
-        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, st, a);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), pfd_lds_bytes<D>(a.npages), st, a);
     }
-    GQ_CHECK_LAUNCH("gq_hsq_encode (paged prefilter, d = 8 / 32)");
+    GQ_CHECK_LAUNCH("gq_hsq_encode (paged prefilter)");
     return GQ_OK;
 }
 
@@ -590,8 +637,9 @@ int launch_encode_pfd_paged(const float *grad, const float *codebook, int64_t M,
                             float *ws, hipStream_t st) {
     if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
     if (d == 8) return launch_pfd_paged<8>(grad, codebook, M, K, codes, u, ws, st);
+    if (d == 16) return launch_pfd_paged<16>(grad, codebook, M, K, codes, u, ws, st);
     if (d == 32) return launch_pfd_paged<32>(grad, codebook, M, K, codes, u, ws, st);
-    return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: the d = 8 / 32 prefilter kernel was asked for d = %d", d);
+    return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: the paged prefilter kernel was asked for d = %d", d);
 }
 
 template <typename CodeT>
@@ -612,10 +660,10 @@ template <int D>
 static int pfd_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                              const float *codebook, int K, int ef, float ef_scale, uint8_t *wire, float *u_flat,
                              uint32_t *seg_minmax, float *ws, hipStream_t st) {
-    constexpr int KS = D > 16 ? D / 16 : 1;
-    constexpr int WAVES = D == 32 ? GQ_W32 : GQ_W8, THREADS = WAVES * 64;
-    constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
+    constexpr int WAVES = D == 32 ? GQ_W32 : (D == 16 ? 8 : GQ_W8), THREADS = WAVES * 64;
+    const int per = pfd_pages_per_launch<D>(true), npages = K / 256;
     static const int bpc = [] {
+        const size_t lds = pfd_lds_bytes<D>(pfd_pages_per_launch<D>(true));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<int32_t, D, true, true, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<int32_t, D, true, false, true>),
@@ -624,7 +672,7 @@ static int pfd_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, 
         return resident_blocks_per_cu(hsq_encode_pfd_kernel<int32_t, D, true, true, true>, THREADS, lds);
     }();
     const int64_t blocks = pfd_grid(ntiles, bpc, WAVES);
-    for (int page = 0; page * 256 < K; ++page) {
+    for (int page = 0; page < npages; page += per) {
         PfdArgs a = {};
         a.M = ntiles * 64;
         a.u = u_flat;
@@ -637,16 +685,17 @@ static int pfd_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, 
         a.ntiles = ntiles;
         a.nseg = nseg;
         a.ef_scale = ef_scale;
+        a.npages = npages - page < per ? npages - page : per;
         a.code_base = page * 256;
         a.merge = page > 0;
-        a.last_page = (page + 1) * 256 >= K;
+        a.last_page = page + a.npages >= npages;
         pfd_split(a, ntiles, blocks);
         if (ef && page == 0)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<int32_t, D, true, true, true>), dim3((unsigned)blocks),
-                               dim3(THREADS), lds, st, a);
+                               dim3(THREADS), pfd_lds_bytes<D>(a.npages), st, a);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<int32_t, D, true, false, true>), dim3((unsigned)blocks),
-                               dim3(THREADS), lds, st, a);
+                               dim3(THREADS), pfd_lds_bytes<D>(a.npages), st, a);
     }
     GQ_CHECK_LAUNCH("gq_hsq_encode_batched_paged");
     return GQ_OK;
@@ -657,6 +706,8 @@ int launch_pfd_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, 
                              uint32_t *seg_minmax, float *ws, hipStream_t st) {
     if (d == 8)
         return pfd_batched_paged<8>(seg_table, tile_seg, nseg, ntiles, codebook, K, ef, ef_scale, wire, u_flat, seg_minmax, ws, st);
+    if (d == 16)
+        return pfd_batched_paged<16>(seg_table, tile_seg, nseg, ntiles, codebook, K, ef, ef_scale, wire, u_flat, seg_minmax, ws, st);
     return pfd_batched_paged<32>(seg_table, tile_seg, nseg, ntiles, codebook, K, ef, ef_scale, wire, u_flat, seg_minmax, ws, st);
 }
 
