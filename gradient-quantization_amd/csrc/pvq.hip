@@ -110,6 +110,17 @@ __global__ __launch_bounds__(PV_THREADS) void pvq_encode_kernel(const float *__r
 // subvector -- counts every term and lands on K-1 like the oracle); the selected projection is recomputed as
 // one explicit fmaf chain.  Padded codewords (K not a multiple of 32) score +0 and change neither sum.
 // ------------------------------------------------------------------------------------
+// Second stage of the ResidualCompressor (residual_compressor.py:15-24) without a residual tensor: the tile is
+// staged as  v - codebook1[code1] * norm1  -- stage 1's decode (nearest_neighbor_compressor.py:85-89: gather x norm,
+// the product rounded) subtracted from the gradient (`residuals -= decompressed`, :22), element by element, with the
+// reference's roundings.  norm1 is the de-quantised stage-1 norm per subvector (M floats: 1/d of the gradient).
+struct PvqResidual {
+    const void *codes1;     // null: plain encode of `grad`
+    int code1_bytes;        // 1 | 4
+    const float *norm1;
+    const float *cb1;       // stage 1's codebook [K1, d]
+};
+
 template <typename CodeT>
 __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float *__restrict__ grad,
                                                                     const float *__restrict__ cdag, int64_t M, int d,
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float
                                                                     const float *__restrict__ r, uint64_t seed,
                                                                     CodeT *__restrict__ codes, float *__restrict__ u,
                                                                     float *__restrict__ partials, int dpad,
-                                                                    int chunk_rows) {
+                                                                    int chunk_rows, PvqResidual rs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -143,7 +154,14 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float
         for (int i = lane; i < total; i += 64) {
             const int rr = (int)(((float)i + 0.5f) * inv_dpad);
             const int e = i - rr * dpad;
-            const float val = (sv0 + rr < M && e < d) ? grad[(sv0 + rr) * (int64_t)d + e] : 0.0f;
+            float val = (sv0 + rr < M && e < d) ? grad[(sv0 + rr) * (int64_t)d + e] : 0.0f;
+            if (rs.codes1 && sv0 + rr < M && e < d) {
+                const int64_t m = sv0 + rr;
+                const int c1 = rs.code1_bytes == 1 ? (int)static_cast<const uint8_t *>(rs.codes1)[m]
+                                                   : static_cast<const int32_t *>(rs.codes1)[m];
+                const float dec = rs.cb1[(int64_t)c1 * d + e] * rs.norm1[m];   // stage 1's decoded element (product rounded)
+                val = val - dec;
+            }
             s_v[rr * stride + (e & 1) * half + (e >> 1)] = val;
         }
     };
@@ -243,7 +261,8 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float
 
 template <typename CodeT>
 static int launch_pvq_lds(const float *grad, const float *cdag, int64_t M, int d, int K, int random_mode, const float *r,
-                          uint64_t seed, CodeT *codes, float *u, float *ws, hipStream_t st, bool *done) {
+                          uint64_t seed, CodeT *codes, float *u, float *ws, hipStream_t st, bool *done,
+                          PvqResidual rs = PvqResidual{nullptr, 0, nullptr, nullptr}) {
     int dpad = 0, chunk_rows = 0;
     size_t lds_bytes = 0;
     *done = false;
@@ -262,7 +281,7 @@ static int launch_pvq_lds(const float *grad, const float *cdag, int64_t M, int d
     if (cap > GQ_MAIN_PARTIALS) cap = GQ_MAIN_PARTIALS;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(pvq_encode_lds_kernel<CodeT>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds_bytes,
-                       st, grad, cdag, M, d, K, random_mode, r, seed, codes, u, ws, dpad, chunk_rows);
+                       st, grad, cdag, M, d, K, random_mode, r, seed, codes, u, ws, dpad, chunk_rows, rs);
     GQ_CHECK_LAUNCH("gq_pvq_encode (mfma)");
     *done = true;
     return GQ_OK;
@@ -333,4 +352,33 @@ GQ_API int gq_pvq_encode(const float *grad, const float *c_dagger, int64_t M, in
         return gq::dispatch_pvq<int32_t>(grad, c_dagger, M, d, K, random_mode, r, seed, static_cast<int32_t *>(codes), u,
                                          workspace, st);
     return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode: code_bytes must be 1 or 4");
+}
+
+GQ_API int gq_pvq_encode_residual(const float *grad, const void *codes1, int code1_bytes, const float *norm1,
+                                  const float *codebook1, const float *c_dagger, int64_t M, int d, int K, int random_mode,
+                                  const float *r, uint64_t seed, void *codes, int code_bytes, float *u, float *workspace,
+                                  void *stream) {
+    if (M < 1 || d < 1 || K < 1) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: bad sizes");
+    if (!grad || !codes1 || !norm1 || !codebook1 || !c_dagger || !codes || !u || !workspace)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: null pointer");
+    if (code1_bytes != 1 && code1_bytes != 4) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: code1_bytes must be 1 or 4");
+    if (random_mode != GQ_RANDOM_GIVEN && random_mode != GQ_RANDOM_DEVICE)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: random_mode must be GIVEN or DEVICE (the sampler needs draws)");
+    if (random_mode == GQ_RANDOM_GIVEN && !r) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: r is null");
+    if (code_bytes == 1 && K > 256) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: uint8 codes need K <= 256");
+    hipStream_t st = gq::as_stream(stream);
+    const gq::PvqResidual rs = {codes1, code1_bytes, norm1, codebook1};
+    bool done = false;
+    int rc;
+    if (code_bytes == 1)
+        rc = gq::launch_pvq_lds<uint8_t>(grad, c_dagger, M, d, K, random_mode, r, seed, static_cast<uint8_t *>(codes), u,
+                                         workspace, st, &done, rs);
+    else if (code_bytes == 4)
+        rc = gq::launch_pvq_lds<int32_t>(grad, c_dagger, M, d, K, random_mode, r, seed, static_cast<int32_t *>(codes), u,
+                                         workspace, st, &done, rs);
+    else
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: code_bytes must be 1 or 4");
+    if (rc != GQ_OK) return rc;
+    if (!done) return gq::fail(GQ_ERR_UNSUPPORTED, "gq_pvq_encode_residual: d = %d does not fit the LDS-staged kernel", d);
+    return GQ_OK;
 }

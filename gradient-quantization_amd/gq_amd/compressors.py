@@ -318,7 +318,9 @@ class ProbabilisticVectorCompressor(object):
             self.c_dagger = self.c_dagger.to(device)
         return self.codewords, self.c_dagger
 
-    def compress(self, vec):
+    def compress(self, vec, minus=None):
+        """minus = (codes1, norm1, codebook1): compress  vec - codebook1[codes1] * norm1  -- the residual of a first
+        stage (ResidualCompressor) -- computed inside the kernel's tile staging instead of as a tensor."""
         _require_device(vec, "ProbabilisticVectorCompressor.compress")
         dev = vec.device
         flat = vec.contiguous().view(-1)
@@ -326,11 +328,17 @@ class ProbabilisticVectorCompressor(object):
         codes = torch.empty(self.M, dtype=self.code_dtype, device=dev)
         u = torch.empty(self.M, dtype=torch.float32, device=dev)
         ws = native.new_workspace(dev, 0)
+        r, mode, seed = None, native.RANDOM_DEVICE, 0
         if self._rng == "reference":
-            r = torch.rand(self.M)       # CPU generator, as :52
-            native.pvq_encode(flat, cdag, codes, u, ws, native.RANDOM_GIVEN, r.to(dev), 0)
+            r, mode = torch.rand(self.M).to(dev), native.RANDOM_GIVEN       # CPU generator, as :52
         else:
-            native.pvq_encode(flat, cdag, codes, u, ws, native.RANDOM_DEVICE, None, _next_seed())
+            seed = _next_seed()
+        if minus is None:
+            native.pvq_encode(flat, cdag, codes, u, ws, mode, r, seed)
+        else:
+            codes1, norm1, cb1 = minus
+            native.pvq_encode_residual(flat, codes1.contiguous().view(-1), norm1.contiguous().view(-1).float(), cb1, cdag,
+                                       codes, u, ws, mode, r, seed)
         if not self.compressed_norm:
             return [u, codes]
         lb_ub = torch.empty(2, dtype=torch.float32, device=dev)
@@ -357,8 +365,14 @@ class ProbabilisticVectorCompressor(object):
 
 
 class ResidualCompressor(object):
-    """Two stages (residual_compressor.py:7-32): NearestNeighbor on the gradient, then the
-    probabilistic vector compressor on what is left; decode = sum of the stage decodes."""
+    """Two stages (residual_compressor.py:7-32): NearestNeighbor on the gradient, the probabilistic vector
+    compressor on what stage 1 leaves; decode = sum of the stage decodes.  The residual is never a tensor here:
+    stage 2's kernel stages its tiles as  v - codebook1[code1] * norm1  (gq_pvq_encode_residual), so compress is
+    stage 1's two launches + stage 2's, with two reads of the gradient instead of a clone, a decode, an in-place
+    subtraction and a second encode over a materialised residual.  Pinned against the reference's own output
+    (tests/golden/residual_*.npz)."""
+
+    FUSED_MAX_DIM = 104      # the LDS-staged second-stage kernel; wider subvectors take the tensor path
 
     def __init__(self, size, shape, args):
         self.compressors = [
@@ -367,17 +381,19 @@ class ResidualCompressor(object):
         ]
 
     def compress(self, vec):
-        residuals = vec.clone()
-        signatures = []
-        for compressor in self.compressors:
-            signature = compressor.compress(residuals)
-            decompressed = compressor.decompress(signature)
-            residuals -= decompressed
-            signatures.append(signature)
-        return signatures
+        first, second = self.compressors
+        sig1 = first.compress(vec)
+        if first.dim > self.FUSED_MAX_DIM or first.dim != second.dim:
+            residuals = vec.clone()
+            residuals -= first.decompress(sig1)
+            return [sig1, second.compress(residuals)]
+        norms, codes1 = sig1
+        norm1 = first.norm_compressor.decompress(norms) if first.compressed_norm else norms     # probabilistic_scalar_compressor.py:31-32
+        return [sig1, second.compress(vec, minus=(codes1, norm1, first._codebook_on(vec.device)))]
 
     def decompress(self, signatures):
-        decoded = [c.decompress(s) for s, c in zip(signatures, self.compressors)]
+        decoded = [c.decompress(sig) for sig, c in zip(signatures, self.compressors)]
+        # the reference's reduction, not `a + b`: sum() starts from +0, so two -0 entries give +0 (:26-32)
         return torch.stack(decoded, dim=0).sum(dim=0)
 
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "gq_hsq_encode_batched_any", "gq_hsq_levels_batched_any", "gq_hsq_decode_sum_batched_any", "gq_hsq_error_batched_any",
     "gq_hsq_batched_any_supported", "gq_hsq_encode_batched_paged", "gq_qsgd_wide_compress", "gq_qsgd_wide_decode_sum",
     "gq_profile_arm", "gq_profile_read", "gq_hsq_compress", "gq_hsq_given_draws",
-    "gq_pvq_encode", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
+    "gq_pvq_encode", "gq_pvq_encode_residual", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
 
@@ -457,6 +457,24 @@ def pvq_encode(grad, c_dagger, codes, u, workspace, random_mode, r, seed):
                              ctypes.c_int(_CODE_BYTES[codes.dtype]), _dev_ptr(u, torch.float32, "u"),
                              _dev_ptr(workspace, torch.float32, "workspace"), _stream())
     _check(rc, "gq_pvq_encode")
+
+
+def pvq_encode_residual(grad, codes1, norm1, codebook1, c_dagger, codes, u, workspace, random_mode, r, seed):
+    """PVQ encode of  grad - codebook1[codes1] * norm1  without materialising it (ResidualCompressor's second stage)."""
+    K, d = c_dagger.shape
+    M = grad.numel() // d
+    assert grad.numel() == M * d and codes.numel() == M and u.numel() == M and codes1.numel() == M and norm1.numel() == M
+    assert codebook1.shape[1] == d
+    rp = _dev_ptr(r, torch.float32, "r") if r is not None else ctypes.c_void_p(0)
+    rc = lib().gq_pvq_encode_residual(_dev_ptr(grad, torch.float32, "grad"), _dev_ptr(codes1, None, "codes1"),
+                                      ctypes.c_int(_CODE_BYTES[codes1.dtype]), _dev_ptr(norm1, torch.float32, "norm1"),
+                                      _dev_ptr(codebook1, torch.float32, "codebook1"),
+                                      _dev_ptr(c_dagger, torch.float32, "c_dagger"), ctypes.c_int64(M), ctypes.c_int(d),
+                                      ctypes.c_int(K), ctypes.c_int(random_mode), rp, ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                                      _dev_ptr(codes, None, "codes"), ctypes.c_int(_CODE_BYTES[codes.dtype]),
+                                      _dev_ptr(u, torch.float32, "u"), _dev_ptr(workspace, torch.float32, "workspace"),
+                                      _stream())
+    _check(rc, "gq_pvq_encode_residual")
 
 
 def qsgd_code_bits(n_bit, random_mode):

@@ -281,6 +281,14 @@ int gq_qsgd_decode_sum(const float *norm, const uint8_t *signs, const void *leve
  */
 int gq_pvq_encode(const float *grad, const float *c_dagger, int64_t M, int d, int K, int random_mode, const float *r,
                   uint64_t seed, void *codes, int code_bytes, float *u, float *workspace, void *stream);
+/* Second stage of the ResidualCompressor (compressors/residual_compressor.py:15-24) WITHOUT a residual tensor: the
+ * same encode applied to  grad - codebook1[codes1] * norm1  computed on the fly with the reference's roundings
+ * (stage 1's decode, nearest_neighbor_compressor.py:85-89, then `residuals -= decompressed`).  norm1 [M] f32 is stage
+ * 1's de-quantised norm per subvector.  GQ_ERR_UNSUPPORTED when d does not fit the LDS-staged kernel (d > 104). */
+int gq_pvq_encode_residual(const float *grad, const void *codes1, int code1_bytes, const float *norm1,
+                           const float *codebook1, const float *c_dagger, int64_t M, int d, int K, int random_mode,
+                           const float *r, uint64_t seed, void *codes, int code_bytes, float *u, float *workspace,
+                           void *stream);
 
 /*
  * QSGD on a packed wire, multi-tensor form (one launch for all tensors; same arithmetic as
