@@ -388,7 +388,9 @@ def run_qsgd(args, torch, np, dist, native, exchange, dev, rank, world, backend,
     params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
     os.environ["GQ_EXCHANGE"] = args.exchange
     torch.manual_seed(1234 + rank)
-    q = Quantizer(QSGDCompressor, params, qargs)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # the constructors report the reference's dimension repair on stdout
+        q = Quantizer(QSGDCompressor, params, qargs)
     grads = [[torch.randn(s, device=dev) * 1e-3 for s in shapes] for _ in range(3)]
 
     def step(i):

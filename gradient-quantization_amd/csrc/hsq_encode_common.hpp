@@ -103,7 +103,7 @@ __host__ __device__ inline int *ws_worklist(float *ws) { return reinterpret_cast
 // Per-block (min,max) of u -> partials[2*blockIdx.x], and block 0 pads the unused slots.  The level kernel
 // (gq_hsq_levels) folds the pairs into (lb, ub): every one of its workgroups reads the 8 KiB from L2, which costs it
 // ~0.3 us once -- less than a last-workgroup fold inside the encode did (ticket round trip + fold: ~1.8 us on the
-// encode's critical path; profiles/r02_pf_prologue_stamps.txt).
+// encode's critical path; profiles/r02_b_pf_prologue_stamps.txt).
 // sawnan (wave-uniform): a projection of this wave's tiles is NaN -> the workgroup's pair is (NaN, NaN) and the
 // level kernel's fold makes (lb, ub) NaN, as torch.min / torch.max do.
 template <int WAVES = ENC_WAVES>

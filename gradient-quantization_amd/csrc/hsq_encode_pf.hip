@@ -278,7 +278,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // the codebook (A fragments: every wave splits ONE of the 8 row blocks into bf16 hi / lo and shares it
     // through LDS -- each wave splitting all 8 cost 0.8 us of VALU time per SIMD), and the wave's first tile,
     // whose HBM latency then hides behind the staging.  One barrier.  (Before: staging, fragments, barrier,
-    // ||c||_1, barrier and only then the first tile's loads: 5.2 us; profiles/r02_pf_prologue_stamps.txt.)
+    // ||c||_1, barrier and only then the first tile's loads: 5.2 us; profiles/r02_b_pf_prologue_stamps.txt.)
     float cbv[256 * 16 / PF_THREADS];
 #pragma unroll
     for (int n = 0; n < 256 * 16 / PF_THREADS; ++n) cbv[n] = cb[threadIdx.x + n * PF_THREADS];
