@@ -36,13 +36,14 @@ extern "C" {
 
 /* Encode workspace (caller-allocated device memory, gq_hsq_workspace_bytes(M) bytes, 16-byte
  * aligned):
- *   [ (min,max) f32 pairs x GQ_MAX_PARTIALS | int32 x4: fix-up count, ticket, final flag, - | fix-up log int32[M] ]
+ *   [ (min,max) f32 pairs x GQ_MAX_PARTIALS | int32 x4: -, -, final flag, - | fix-up log int32[M] ]
  * The int32 x4 block (bytes [8*GQ_MAX_PARTIALS, +16)) must be ZERO before the first use; the
- * library keeps it consistent afterwards (no memset per call).  gq_hsq_encode leaves either the
- * per-workgroup (min,max) of u in the pairs (unused slots hold (+inf,-inf), final flag 0) or -- the
- * d16/K256 prefilter path, whose last workgroup folds them itself -- the final (lb, ub) at pair 0
- * with the final flag raised; gq_hsq_levels reads them.  The log lists the subvectors the prefilter
- * path recomputed exactly (diagnostics; valid until the next call). */
+ * library keeps it consistent afterwards (no memset per call).  gq_hsq_encode leaves the
+ * per-workgroup (min,max) of u in the pairs (unused slots hold (+inf,-inf); a workgroup that met a NaN
+ * projection leaves (NaN, NaN)), final flag 0, and gq_hsq_levels folds them into (lb, ub) -- NaN if any
+ * pair is NaN, as torch.min / torch.max propagate it (probabilistic_scalar_compressor.py:13-14).  (A caller
+ * may instead put the final pair at slot 0 and raise the flag.)  The log marks the subvectors the prefilter
+ * path recomputed exactly: entry i holds i (diagnostics; the caller fills it with -1 beforehand). */
 #define GQ_MAX_PARTIALS 1024
 #define GQ_FIXUP_PARTIALS 256 /* slots no grid writes: gq_hsq_encode fills them with (+inf,-inf) */
 size_t gq_hsq_workspace_bytes(int64_t M);
