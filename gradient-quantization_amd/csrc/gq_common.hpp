@@ -33,6 +33,45 @@ bool profile_take(hipEvent_t *start, hipEvent_t *stop);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// sum / R of the parameter-server mean (ps_quantizer.py:48: torch.stack(...).mean(0) divides the sum by R).  For R a power
+// of two -- 1, 2, 4, 8 ranks -- the division is an exact scaling: x * (1/R) is the same correctly rounded x * 2^-k, subnormal
+// results included, for ONE VALU operation instead of the ~10 of the IEEE division sequence (16 divisions per lane and
+// iteration were a quarter of the R = 8 decode's instructions).  Other R divide.
+struct MeanDiv {
+    float fR, inv;
+    bool pow2;
+};
+__host__ __device__ inline MeanDiv mean_div_of(int R) {
+    MeanDiv m;
+    m.fR = (float)R;
+    m.inv = 1.0f / (float)R;
+    m.pow2 = R > 0 && (R & (R - 1)) == 0;
+    return m;
+}
+template <class V>   // float or a vector of floats
+__device__ __forceinline__ V mean_div(V x, const MeanDiv &m) {
+    return m.pow2 ? x * m.inv : x / m.fR;
+}
+
+// max(mx, |a|, |b|) that PROPAGATES NaN (IEEE-754-2019 `maximum`; v_maximum3_f32 is new in gfx950), for the QSGD bucket
+// norms: torch.max(|v|, dim=1) makes a bucket's norm NaN when one of its elements is (qsgd_compressor.py:49), which fmaxf
+// would hide.  Same cost as v_max3_f32.
+__device__ __forceinline__ float absmax3_nan(float mx, float a, float b) {
+    float d;
+    asm("v_maximum3_f32 %0, |%1|, |%2|, %3" : "=v"(d) : "v"(a), "v"(b), "v"(mx));
+    return d;
+}
+__device__ __forceinline__ float max_nan(float a, float b) {
+    float d;
+    asm("v_maximum3_f32 %0, %1, %2, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float wave_max_nan(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max_nan(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_v4_kernel(
     const int q_per = d >> 2;
     const int64_t total = M * q_per;
     const float s = 1.0f / (float)(1 << (n_bit & 31));   // inv_s, see level_to_norm
-    const float fR = (float)R;
+    const MeanDiv md = mean_div_of(R);
     const int64_t stride = (int64_t)gridDim.x * DEC_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * DEC_THREADS + threadIdx.x; i < total; i += stride) {
         const int64_t m = i / q_per;
@@ -76,10 +76,10 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_v4_kernel(
             }
         }
         if (R > 1) {
-            acc[0] = acc[0] / fR;
-            acc[1] = acc[1] / fR;
-            acc[2] = acc[2] / fR;
-            acc[3] = acc[3] / fR;
+            acc[0] = mean_div(acc[0], md);
+            acc[1] = mean_div(acc[1], md);
+            acc[2] = mean_div(acc[2], md);
+            acc[3] = mean_div(acc[3], md);
         }
         *reinterpret_cast<f32x4 *>(out + 4 * i) = acc;
     }
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(DEC16_THREADS) void hsq_decode_sum_d16u8_kernel(
     }
     __syncthreads();
     const float inv_s = 1.0f / (float)(1 << (n_bit & 31));
-    const float fR = (float)R;
+    const MeanDiv md = mean_div_of(R);
     const int q = threadIdx.x & 3;
     const float *const my_cb = s_cb + ((threadIdx.x >> 3) & 3) * 16 + 4 * q;   // this lane's copy and quarter
     const int64_t total = ((M + 3) >> 2) * 4;   // (group of 4 subvectors, quarter) items
@@ -178,10 +178,10 @@ __global__ __launch_bounds__(DEC16_THREADS) void hsq_decode_sum_d16u8_kernel(
             if (k < nv) {
                 f32x4 a = acc[k];
                 if (R > 1) {
-                    a[0] = a[0] / fR;
-                    a[1] = a[1] / fR;
-                    a[2] = a[2] / fR;
-                    a[3] = a[3] / fR;
+                    a[0] = mean_div(a[0], md);
+                    a[1] = mean_div(a[1], md);
+                    a[2] = mean_div(a[2], md);
+                    a[3] = mean_div(a[3], md);
                 }
                 *reinterpret_cast<f32x4 *>(out + (m0 + k) * 16 + 4 * q) = a;
             }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_scalar_kernel(
     int d, int n_bit, float *__restrict__ out) {
     const int64_t total = M * d;
     const float s = 1.0f / (float)(1 << (n_bit & 31));   // inv_s, see level_to_norm
-    const float fR = (float)R;
+    const MeanDiv md = mean_div_of(R);
     const int64_t stride = (int64_t)gridDim.x * DEC_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * DEC_THREADS + threadIdx.x; i < total; i += stride) {
         const int64_t m = i / d;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_scalar_kernel(
             const float dec = cb[(int64_t)code * d + jj] * n;
             acc = (r == 0) ? dec : acc + dec;
         }
-        if (R > 1) acc = acc / fR;
+        if (R > 1) acc = mean_div(acc, md);
         out[i] = acc;
     }
 }

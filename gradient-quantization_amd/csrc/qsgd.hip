@@ -60,8 +60,8 @@ __global__ __launch_bounds__(QS_THREADS) void qsgd_compress_wave_kernel(const fl
     for (int64_t b = (int64_t)blockIdx.x * (QS_THREADS / 64) + (threadIdx.x >> 6); b < Mb; b += nw) {
         const float *v = grad + b * (int64_t)d;
         float mx = 0.0f;
-        for (int jj = lane; jj < d; jj += 64) mx = fmaxf(mx, fabsf(v[jj]));
-        mx = wave_max(mx);
+        for (int jj = lane; jj < d; jj += 64) mx = absmax3_nan(mx, v[jj], v[jj]);   // NaN-propagating, like torch.max
+        mx = wave_max_nan(mx);
         if (lane == 0) norm[b] = mx;
         for (int jj = lane; jj < d; jj += 64)
             qsgd_quantise_one<LevelT>(v[jj], mx, s, smax, random_mode, r, seed, b * (int64_t)d + jj, signs, levels);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(QS_THREADS) void qsgd_decode_sum_kernel(const float
     const int64_t total = Mb * (int64_t)d;
     const int64_t stride = (int64_t)gridDim.x * QS_THREADS;
     const float s = (float)(1 << n_bit);
-    const float fR = (float)R;
+    const MeanDiv md = mean_div_of(R);
     for (int64_t i = (int64_t)blockIdx.x * QS_THREADS + threadIdx.x; i < total; i += stride) {
         const int64_t b = i / d;
         float acc = 0.0f;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(QS_THREADS) void qsgd_decode_sum_kernel(const float
             t = t / s;
             acc = (r == 0) ? t : acc + t;
         }
-        if (R > 1) acc = acc / fR;
+        if (R > 1) acc = mean_div(acc, md);
         out[i] = acc;
     }
 }

@@ -66,9 +66,9 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
         float mx = 0.0f;
         for (int e = 2 * lane; e < d; e += 128) {
             const float2 p = load(e);
-            mx = fmaxf(mx, fmaxf(fabsf(p.x), fabsf(p.y)));
+            mx = absmax3_nan(mx, p.x, p.y);   // NaN-propagating, like torch.max (qsgd_compressor.py:49)
         }
-        mx = wave_max(mx);
+        mx = wave_max_nan(mx);
         if (lane == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = mx;
         const uint64_t g0 = (uint64_t)b << 20;  // RNG stream index: unique per (bucket, element)
         uint8_t *dst = wire + rec[4] + ((lb * d * bits) >> 3);
@@ -168,10 +168,10 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
             float m2 = 0.0f;
             for (int e = 2 * c0; e < d; e += 32) {
                 const float2 p = load(e);
-                m2 = fmaxf(m2, fmaxf(fabsf(p.x), fabsf(p.y)));
+                m2 = absmax3_nan(m2, p.x, p.y);   // NaN-propagating, like torch.max
             }
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o, 64));
+            for (int o = 8; o > 0; o >>= 1) m2 = max_nan(m2, __shfl_xor(m2, o, 64));
             if (c0 == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = m2;
             uint8_t *dst2 = wire + rec[4] + ((lb * d) >> 1);
             for (int e = 2 * c0; e < d; e += 32) {
@@ -208,11 +208,11 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
                     x[jc][1] = x[jc][1] + q1 * ef_scale;
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) mx = fmaxf(mx, fabsf(x[jc][k >> 2][k & 3]));
+                for (int k = 0; k < 8; k += 2) mx = absmax3_nan(mx, x[jc][k >> 2][k & 3], x[jc][(k + 1) >> 2][(k + 1) & 3]);   // NaN-propagating
             }
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));   // the bucket's 16 lanes
+        for (int o = 8; o > 0; o >>= 1) mx = max_nan(mx, __shfl_xor(mx, o, 64));   // the bucket's 16 lanes
         if (live && c0 == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = mx;
         const uint64_t g0 = (uint64_t)b << 20;  // RNG stream index: unique per (bucket, element)
         uint8_t *dst = wire + rec[4] + ((lb * d) >> 1);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched_kernel(
     const int lane = threadIdx.x & 63;
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float s = (float)(1 << n_bit);
-    const float fR = (float)R;
+    const MeanDiv md = mean_div_of(R);
     const unsigned lmask = (1u << (bits - 1)) - 1u;
     for (int64_t b = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); b < nbuckets; b += nw) {
         const int seg = __builtin_amdgcn_readfirstlane(bucket_seg[b]);
@@ -291,8 +291,8 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched_kernel(
                 a1 = (r == 0) ? t1 : a1 + t1;
             }
             if (R > 1) {
-                a0 = a0 / fR;
-                a1 = a1 / fR;
+                a0 = mean_div(a0, md);
+                a1 = mean_div(a1, md);
             }
             *reinterpret_cast<float2 *>(o + e) = make_float2(a0, a1);
         }
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_kernel(
     const int lane = threadIdx.x & 63, sub = lane >> 4, c0 = lane & 15;
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float inv_s = 1.0f / (float)(1 << n_bit);
-    const float fR = (float)R;
+    const MeanDiv md = mean_div_of(R);
     const int64_t nquads = (nbuckets + 3) >> 2;
     for (int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); qd < nquads; qd += nw) {
         const int64_t b = 4 * qd + sub;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_kernel(
                 for (int r = 1; r < R; ++r) payload(r, std::false_type{});
                 if (R > 1) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[k >> 2][k & 3] = acc[k >> 2][k & 3] / fR;
+                    for (int k = 0; k < 8; ++k) acc[k >> 2][k & 3] = mean_div(acc[k >> 2][k & 3], md);
                 }
                 *reinterpret_cast<f32x4 *>(o + 8 * c) = acc[0];
                 *reinterpret_cast<f32x4 *>(o + 8 * c + 4) = acc[1];
@@ -371,8 +371,8 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_kernel(
                     a1 = (r == 0) ? t1 : a1 + t1;
                 }
                 if (R > 1) {
-                    a0 = a0 / fR;
-                    a1 = a1 / fR;
+                    a0 = mean_div(a0, md);
+                    a1 = mean_div(a1, md);
                 }
                 *reinterpret_cast<float2 *>(o + e) = make_float2(a0, a1);
             }

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_absmax_kernel(const int6
     unsigned *cur = nullptr;     // the bucket word the running max belongs to
     float run_mx = 0.0f;
     auto flush = [&]() {
-        const float m = wave_max(run_mx);
+        const float m = wave_max_nan(run_mx);   // a NaN (positive: |.| cleared its sign) is the largest integer as well
         if (lane == 0 && cur) {
             // look before the atomic: the word only grows, so a value already as large makes ours redundant
             const unsigned mine = __float_as_uint(m);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_absmax_kernel(const int6
                         p[1] = p[1] + p1;
                         *reinterpret_cast<v2f *>(v + e) = p;
                     }
-                    mx = fmaxf(mx, fmaxf(fabsf(p[0]), fabsf(p[1])));
+                    mx = absmax3_nan(mx, p[0], p[1]);   // NaN-propagating; as an integer a NaN's bits also win the atomic max below
                 }
             }
         }
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_decode_kernel(const int6
                                                                      float *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const float inv_s = 1.0f / (float)(1 << n_bit);
-    const float fR = (float)R;
+    const MeanDiv md = mean_div_of(R);
     constexpr unsigned lmask = (1u << (BITS - 1)) - 1u;
     int64_t c_begin, c_end;
     wide_run(nchunks, c_begin, c_end);
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_decode_kernel(const int6
             }
             if (R > 1) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] = acc[k] / fR;
+                for (int k = 0; k < 8; ++k) acc[k] = mean_div(acc[k], md);
             }
             if (whole && dwords) {   // tensors start 16-byte aligned in `out` and at % 8 == 0: two 16-byte stores
                 *reinterpret_cast<f32x4 *>(o + e0) = f32x4{acc[0], acc[1], acc[2], acc[3]};
