@@ -259,12 +259,12 @@ def test_qsgd_matches_reference_golden(nat, name):
     r = torch.from_numpy(g["r"].reshape(-1)).to(dev) if random else None
     nat.qsgd_compress(x, d, n_bit, 1 if random else 0, r, 0, norm, signs, levels)
     torch.cuda.synchronize()
-    assert np.array_equal(_bits(norm.cpu().numpy()), _bits(g["norm"].reshape(-1)))
+    assert _same(norm.cpu().numpy(), g["norm"])          # a NaN element makes its bucket's norm NaN (torch.max)
     assert np.array_equal(signs.cpu().numpy().astype(bool), g["signs"].reshape(-1))
     assert np.array_equal(levels.cpu().numpy(), g["levels"].reshape(-1))
     out = torch.empty(Mb * d, dtype=torch.float32, device=dev)
     nat.qsgd_decode_sum(norm, signs, levels, d, n_bit, out, R=1)
-    assert np.array_equal(out.cpu().numpy(), g["decoded"].reshape(-1))
+    assert np.array_equal(out.cpu().numpy(), g["decoded"].reshape(-1), equal_nan=True)
 
 
 def test_full_size_properties(nat, oracle):
