@@ -173,17 +173,27 @@ class WireExchange(object):
         cuda = self.gathered.device.type == "cuda"
         res = {}
         for mode in MODES:
-            for _ in range(2):
-                step_fn(mode)
-            if cuda:
-                torch.cuda.synchronize()
-            dist.barrier(group=self.group)
-            t0 = time.perf_counter()
-            for _ in range(rounds):
-                step_fn(mode)
-            if cuda:
-                torch.cuda.synchronize()
-            res[mode] = (time.perf_counter() - t0) / rounds * 1e3
+            ok = 1.0
+            try:
+                for _ in range(2):
+                    step_fn(mode)
+                if cuda:
+                    torch.cuda.synchronize()
+                dist.barrier(group=self.group)
+                t0 = time.perf_counter()
+                for _ in range(rounds):
+                    step_fn(mode)
+                if cuda:
+                    torch.cuda.synchronize()
+                res[mode] = (time.perf_counter() - t0) / rounds * 1e3
+            except Exception as e:      # a transport the backend refuses is left out (all-gather is the one every backend has)
+                import sys
+                print("gq_amd.exchange: transport %r failed in autotune: %s" % (mode, e), file=sys.stderr)
+                ok, res[mode] = 0.0, float("inf")
+            flag = torch.tensor([ok], dtype=torch.float64, device=self.gathered.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            if float(flag.item()) == 0.0:
+                res[mode] = 1e30
         t = torch.tensor([res[m] for m in MODES], dtype=torch.float64, device=self.gathered.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         self.timings_ms = {m: float(v) for m, v in zip(MODES, t.tolist())}
