@@ -50,6 +50,8 @@ EXTRA = {
     # + MFMA results straight into VGPRs: with 512 registers available (d = 32 runs one wave per SIMD) the
     # compiler otherwise accumulates in AGPRs and pays 16 v_accvgpr_read per chain (69 -> 61 us)
     "hsq_encode_pfd.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    # every score of the f32 MFMA is read by the VALU (two sequential sums per subvector): keep them out of the AGPRs
+    "pvq.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 }
 
 

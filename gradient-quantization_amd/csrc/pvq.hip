@@ -19,6 +19,7 @@
 namespace gq {
 
 constexpr int PV_THREADS = 256;
+typedef float pv_f32x2 __attribute__((ext_vector_type(2)));
 
 template <typename CodeT, int D, bool LDS_CB>
 __global__ __launch_bounds__(PV_THREADS) void pvq_encode_kernel(const float *__restrict__ grad,
@@ -109,6 +110,32 @@ __global__ __launch_bounds__(PV_THREADS) void pvq_encode_kernel(const float *__r
 // threshold (the sums never decrease, so "first k with cum >= thr" == that count; NaN -- an all-zero
 // subvector -- counts every term and lands on K-1 like the oracle); the selected projection is recomputed as
 // one explicit fmaf chain.  Padded codewords (K not a multiple of 32) score +0 and change neither sum.
+// a / b for many a and ONE b, correctly rounded, in three operations: y = RN(1/b) is computed once (a true division);
+// q0 = RN(a y) is within an ulp of the quotient, r = a - q0 b is exact in one fma, RN(q0 + r y) is the correctly
+// rounded quotient (Markstein's correction step).  Valid while nothing on the way is subnormal: the caller checks
+// 2^-80 <= b <= 2^20 and 2^-102 <= a <= b (then a/b >= 2^-122, and r, a multiple of 2^-47 ulp-units of a, is
+// representable); a == 0 would be fine too but is not worth a test.  Checked against `a / b` on 5.9e9 (a, b) pairs
+// on the CPU (every mantissa of b; b with the 16 highest mantissas against every mantissa of a) and on the GPU by
+// the kernel-vs-oracle tests.  b == 0 with a == 0 gives 0 * inf = NaN like 0 / 0.
+__device__ __forceinline__ float shared_quotient(float a, float b, float y) {
+    const float q0 = __fmul_rn(a, y);
+    const float r = __fmaf_rn(-q0, b, a);
+    return __fmaf_rn(r, y, q0);
+}
+
+// The double T with  (float)x >= thr  <=>  x >= T  for every double x (round to nearest even): the midpoint between
+// thr and the float below it when the tie goes to thr (even mantissa), the next double above the midpoint otherwise.
+__device__ __forceinline__ double rounds_up_to_threshold(float thr) {
+    const uint32_t tb = __float_as_uint(thr);
+    if ((tb & 0x7F800000u) == 0x7F800000u) return (double)thr;   // +-inf, NaN: the comparison is the same in double
+    const float below = thr > 0.0f ? __uint_as_float(tb - 1u)
+                                   : (thr < 0.0f ? __uint_as_float(tb + 1u) : __uint_as_float(0x80000001u));
+    const double mid = 0.5 * ((double)thr + (double)below);
+    if ((tb & 1u) == 0) return mid;
+    const int64_t mb = __double_as_longlong(mid);
+    return __longlong_as_double(mid > 0.0 ? mb + 1 : mb - 1);
+}
+
 // ------------------------------------------------------------------------------------
 // Second stage of the ResidualCompressor (residual_compressor.py:15-24) without a residual tensor: the tile is
 // staged as  v - codebook1[code1] * norm1  -- stage 1's decode (nearest_neighbor_compressor.py:85-89: gather x norm,
@@ -165,6 +192,60 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float
             s_v[rr * stride + (e & 1) * half + (e >> 1)] = val;
         }
     };
+    // Rows that need no padding (d a multiple of 8, at most 32) are fetched as float4s, one tile AHEAD: the loads of
+    // the next tile are in flight while this one is swept, so the sweeps never wait for HBM (the element-wise loop
+    // above waits for every one of its loads).  Float4 q of a tile is row q / (d/4), elements 4 (q mod d/4) ...
+    const bool vec = d == dpad && d <= 32 && (reinterpret_cast<uintptr_t>(grad) & 15) == 0 &&
+                     (!rs.codes1 || (reinterpret_cast<uintptr_t>(rs.cb1) & 15) == 0);
+    const int nq = d >> 2;
+    const float inv_nq = 1.0f / (float)nq;
+    f32x4 pre[8];
+    int pre_c1[8];
+    float pre_n1[8];
+    auto fetch_tile = [&](int64_t t) {
+        const int64_t sv0 = t * 64;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i >= nq) break;
+            const int q = i * 64 + lane;
+            const int rr = (int)(((float)q + 0.5f) * inv_nq);
+            const int e0 = (q - rr * nq) * 4;
+            const int64_t m = sv0 + rr;
+            pre[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            pre_c1[i] = 0;
+            pre_n1[i] = 0.0f;
+            if (m < M) {
+                pre[i] = *reinterpret_cast<const f32x4 *>(grad + m * (int64_t)d + e0);
+                if (rs.codes1) {
+                    pre_c1[i] = rs.code1_bytes == 1 ? (int)static_cast<const uint8_t *>(rs.codes1)[m]
+                                                    : static_cast<const int32_t *>(rs.codes1)[m];
+                    pre_n1[i] = rs.norm1[m];
+                }
+            }
+        }
+    };
+    auto commit_tile = [&](int64_t t) {
+        const int64_t sv0 = t * 64;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i >= nq) break;
+            const int q = i * 64 + lane;
+            const int rr = (int)(((float)q + 0.5f) * inv_nq);
+            const int e0 = (q - rr * nq) * 4;
+            f32x4 val = pre[i];
+            if (rs.codes1 && sv0 + rr < M) {
+                const f32x4 c = *reinterpret_cast<const f32x4 *>(rs.cb1 + (int64_t)pre_c1[i] * d + e0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dec = c[e] * pre_n1[i];   // stage 1's decoded element (product rounded)
+                    val[e] = val[e] - dec;
+                }
+            }
+            float *row = s_v + rr * stride + (e0 >> 1);
+            *reinterpret_cast<pv_f32x2 *>(row) = pv_f32x2{val[0], val[2]};
+            *reinterpret_cast<pv_f32x2 *>(row + half) = pv_f32x2{val[1], val[3]};
+        }
+    };
     const int64_t ntiles = (M + 63) >> 6;
     const int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
     const int64_t rounds = (ntiles + nw - 1) / nw;   // the same for every wave: barriers stay uniform
@@ -173,20 +254,28 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float
         stage_codebook(0);
         __syncthreads();
     }
+    if (vec && (int64_t)blockIdx.x * ENC_WAVES + wave < ntiles) fetch_tile((int64_t)blockIdx.x * ENC_WAVES + wave);
     for (int64_t round = 0; round < rounds; ++round) {
         const int64_t t = round * nw + (int64_t)blockIdx.x * ENC_WAVES + wave;
         const bool active = t < ntiles;
         const int64_t sv = t * 64 + lane;           // this lane's subvector
-        if (active) stage_tile(t);
-        float l1 = 0.0f, thr = 0.0f;
+        if (active) {
+            if (vec) {
+                commit_tile(t);
+                if (t + nw < ntiles) fetch_tile(t + nw);
+            } else {
+                stage_tile(t);
+            }
+        }
+        float l1 = 0.0f, thr = 0.0f, amin = INFINITY;
         double cum = 0.0;   // torch.cumsum accumulates f32 input in double on the CPU; every output is rounded to f32
         int count = 0;
-        for (int sweep = 0; sweep < 2; ++sweep) {
-            if (sweep == 1) {
-                const float rr = (active && sv < M) ? ((random_mode == GQ_RANDOM_GIVEN) ? r[sv] : uniform01(seed, (uint64_t)sv))
-                                                    : 0.0f;
-                thr = rr - 1e-5f;
-            }
+        // Sweep 1 in its fast form (see shared_quotient below): y = RN(1/l1), T = the double threshold that stands for
+        // "(float)cum >= thr"; taken when every lane of the wave qualifies, otherwise the division is done term by term.
+        float y = 0.0f;
+        double T = 0.0;
+        bool fast = false;
+        auto sweep = [&](auto first, auto quick) {
             for (int chunk = 0; chunk < nchunks; ++chunk) {
                 const int row0 = chunk * chunk_rows;
                 if (nchunks > 1) {
@@ -203,8 +292,22 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float
                     const float *arow = s_cb + (rb * 32 + j) * stride + h * half;
                     const float *b0 = s_v + j * stride + h * half;
                     const float *b1 = s_v + (32 + j) * stride + h * half;
-                    f32x16 acc0 = {0}, acc1 = {0};
-                    for (int k4 = 0; k4 < half; k4 += 4) {
+                    // the first product of a chain takes a literal zero as its addend: no accumulator to clear
+                    f32x16 acc0, acc1;
+                    {
+                        const f32x16 zero = {0};
+                        const f32x4 a = *reinterpret_cast<const f32x4 *>(arow);
+                        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(b0);
+                        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(b1);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], x0[0], zero, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], x1[0], zero, 0, 0, 0);
+#pragma unroll
+                        for (int q = 1; q < 4; ++q) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], x0[q], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], x1[q], acc1, 0, 0, 0);
+                        }
+                    }
+                    for (int k4 = 4; k4 < half; k4 += 4) {
                         const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + k4);
                         const f32x4 x0 = *reinterpret_cast<const f32x4 *>(b0 + k4);
                         const f32x4 x1 = *reinterpret_cast<const f32x4 *>(b1 + k4);
@@ -215,12 +318,12 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float
                         }
                     }
                     // lane L <- the 32 scores of subvector L: x = rows acc_row(r), y = rows acc_row(r) + 4
-                    float x[16], y[16];
+                    float x[16], yv[16];
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         x[q] = acc0[q];
-                        y[q] = acc1[q];
-                        swap32(x[q], y[q]);
+                        yv[q] = acc1[q];
+                        swap32(x[q], yv[q]);
                     }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -228,9 +331,13 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float
                         for (int part = 0; part < 2; ++part) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float a = fabsf(part ? y[4 * g + e] : x[4 * g + e]);   // codeword 32 rb + 8 g + 4 part + e
-                                if (sweep == 0) {
+                                const float a = fabsf(part ? yv[4 * g + e] : x[4 * g + e]);   // codeword 32 rb + 8 g + 4 part + e
+                                if (decltype(first)::value) {
                                     l1 = l1 + a;
+                                    if (e & 1) amin = fminf(fminf(amin, a), fabsf(part ? yv[4 * g + e - 1] : x[4 * g + e - 1]));
+                                } else if (decltype(quick)::value) {
+                                    cum = cum + (double)shared_quotient(a, l1, y);
+                                    count += (cum >= T) ? 0 : 1;
                                 } else {
                                     cum = cum + (double)(a / l1);   // the reference divides first (:49,:57)
                                     count += ((float)cum >= thr) ? 0 : 1;
@@ -240,7 +347,23 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float
                     }
                 }
             }
+        };
+        sweep(std::true_type{}, std::false_type{});
+        {
+            const float rr = (active && sv < M) ? ((random_mode == GQ_RANDOM_GIVEN) ? r[sv] : uniform01(seed, (uint64_t)sv))
+                                                : 0.0f;
+            thr = rr - 1e-5f;
+            // An all-zero subvector (l1 == 0) needs no exemption: 0 * (1/0) is the NaN that 0/0 gives, every term counts.
+            const bool lane_ok = !active || sv >= M || l1 == 0.0f ||
+                                 (K == kpad && l1 >= 0x1p-80f && l1 <= 0x1p20f && amin >= 0x1p-102f);
+            fast = __builtin_amdgcn_ballot_w64(!lane_ok) == 0;
+            y = 1.0f / l1;
+            T = rounds_up_to_threshold(thr);
         }
+        if (fast)
+            sweep(std::false_type{}, std::true_type{});
+        else
+            sweep(std::false_type{}, std::false_type{});
         if (!active || sv >= M) continue;
         const int code = count < K - 1 ? count : K - 1;
         float sel = 0.0f;

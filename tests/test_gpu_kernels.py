@@ -342,6 +342,40 @@ def test_pvq_encode_on_the_matrix_cores_matches_the_oracle(nat, oracle, d, K, M)
     assert lb_ub[0].item() == float(ou.min()) and lb_ub[1].item() == float(ou.max())
 
 
+@pytest.mark.parametrize("K", [256, 250])
+def test_pvq_shared_quotient_walk_equals_the_division(nat, oracle, K):
+    """The inverse-CDF walk divides every |p_k| by the same l1: the kernel's three-operation quotient (pvq.hip,
+    shared_quotient) and its double threshold have to give what `a / l1` and `(float)cum >= thr` give.  Subvectors
+    scaled from 1e-30 to 1e8 (both sides of the range the fast form accepts, mixed within a wave), single-spike
+    subvectors (terms far below l1), whole zero tiles, draws on and next to 1e-5 (threshold 0 and its neighbours),
+    and K = 250 (padded codewords: always the term-by-term form)."""
+    d, M = 16, 64 * 700 + 5
+    rng = np.random.RandomState(K)
+    cdag = rng.standard_normal((K, d)).astype(np.float32) * 0.3
+    x = rng.standard_normal((M, d)).astype(np.float32)
+    scale = np.float32(10.0) ** rng.randint(-30, 9, size=M).astype(np.float32)
+    scale[: 64 * 200] = np.float32(1e-3)                       # plain waves: all lanes fast
+    x *= scale[:, None]
+    x[64 * 300: 64 * 302] = 0.0                                # two all-zero tiles
+    spikes = rng.randint(0, M, size=2000)
+    x[spikes, 1:] *= np.float32(1e-35)                         # one large element, the rest (nearly) underflown
+    r = rng.random_sample(M).astype(np.float32)
+    edge = np.float32(1e-5)
+    r[:8] = [0.0, edge, np.nextafter(edge, np.float32(1)), np.nextafter(edge, np.float32(0)), np.float32(2.0 ** -24),
+             np.float32(1.0) - np.float32(2.0 ** -24), np.float32(0.5), np.float32(1e-5) + np.float32(2.0 ** -40)]
+    x = x.reshape(-1)
+    dev = torch.device("cuda:0")
+    g, c, rt = torch.from_numpy(x).to(dev), torch.from_numpy(cdag).to(dev), torch.from_numpy(r).to(dev)
+    codes = torch.empty(M, dtype=torch.uint8, device=dev)
+    u = torch.empty(M, dtype=torch.float32, device=dev)
+    ws = nat.new_workspace(dev, M)
+    nat.pvq_encode(g, c, codes, u, ws, nat.RANDOM_GIVEN, rt, 0)
+    torch.cuda.synchronize()
+    oc, ou = oracle.pvq_encode(x, cdag, r)
+    assert np.array_equal(codes.cpu().numpy().astype(np.int64), oc.astype(np.int64))
+    assert np.array_equal(_bits(u.cpu().numpy()), _bits(ou))
+
+
 def test_full_size_compress_and_decode_mean_equal_the_oracle(nat, oracle):
     """BASELINE size, everything against the oracle bit for bit: three ranks' 25 M-element gradients compressed
     (codes, u, lb, ub, levels) and their decode-mean (R = 1 and R = 3) -- rare-event errors (one subvector in
