@@ -21,9 +21,9 @@ _u8p = ctypes.POINTER(ctypes.c_uint8)
 
 def build(force=False):
     """Compile oracle/gq_oracle.c with gcc (seconds)."""
-    src = os.path.join(_HERE, "gq_oracle.c")
+    srcs = [os.path.join(_HERE, "gq_oracle.c"), os.path.join(_HERE, "gq_cpu.c")]
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
         return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "-B", "libgq_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
