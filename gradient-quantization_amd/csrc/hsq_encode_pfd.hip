@@ -22,6 +22,11 @@
 #ifndef GQ_W8
 #define GQ_W8 12
 #endif
+// tiles at the end of a workgroup's run that the second wave of a SIMD leaves to the first (hsq_encode_pf.hip's tail rule):
+// D = 32 has only ~48 tiles of 5.5 us per workgroup -- 2 measured best (0: same, 4: +0.4 %, 6: +2 %); D = 8 is flat from 0 to 6
+#ifndef GQ_PFD_TAIL
+#define GQ_PFD_TAIL (D == 32 ? 2 : 6)
+#endif
 
 namespace gq {
 
@@ -92,58 +97,16 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : (D == 16 ? 8 : GQ_W8)) * 64, 1)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
 
-    // exact f32 codebook, groups of 4 codewords interleaved: s_cb[(k>>2)*QS + 4*e + (k&3)] = c[k][e]
     __shared__ int s_next;
-    if (threadIdx.x == 0) s_next = WAVES;
-    for (int i = threadIdx.x; i < npages * 256 * D; i += THREADS) {
-        const int k = i / D, e = i % D;
-        s_cb[(k >> 2) * QS + 4 * e + (k & 3)] = cb[i];
-    }
-    // A fragments of v_mfma_f32_32x32x16_bf16: lane (row j, half h) of k-step s holds
-    // c[rb*32 + j][16 s + 8 h .. + 7] (zeros beyond D), split into bf16 hi and lo
-    for (int i = threadIdx.x; i < npages * 8 * KS * 64; i += THREADS) {
-        const int l = i & 63, s = (i >> 6) % KS, rb = i / (64 * KS);
-        const int row = rb * 32 + (l & 31), e0 = 16 * s + 8 * (l >> 5);
-        f32x4 q0 = {0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0;
-        if (e0 < D) {
-            q0 = *reinterpret_cast<const f32x4 *>(cb + row * D + e0);
-            q1 = *reinterpret_cast<const f32x4 *>(cb + row * D + e0 + 4);
-        }
-        bf16x8 hi, lo;
-        split8(q0, q1, hi, lo);
-        s_a[((rb * KS + s) * 2 + 0) * 64 + l] = hi;
-        s_a[((rb * KS + s) * 2 + 1) * 64 + l] = lo;
-    }
     __shared__ int64_t s_seg[BATCHED ? PFD_LDS_SEGS * 8 : 1];
-    if (BATCHED) {
-        for (int i = threadIdx.x; i < a.nseg * 8; i += THREADS) s_seg[i] = a.seg_table[i];
-    }
-    __syncthreads();
-    // the error bound scales with max_k ||c_k||_1: measured, not assumed
     __shared__ float s_c1[WAVES];
-    {
-        float l1 = 0.0f;
-        for (int k = threadIdx.x & 255; k < npages * 256; k += 256) {
-            float rowsum = 0.0f;
-#pragma unroll
-            for (int e = 0; e < D; ++e) rowsum += fabsf(s_cb[(k >> 2) * QS + 4 * e + (k & 3)]);
-            l1 = fmaxf(l1, rowsum);
-        }
-        l1 = wave_max(l1);
-        if (lane == 0) s_c1[wave] = l1;
-    }
-    __syncthreads();
-    float c1 = s_c1[0];
-#pragma unroll
-    for (int w = 1; w < WAVES; ++w) c1 = fmaxf(c1, s_c1[w]);
-    const float err_scale = c1 * ERR_SCALE;  // E = max|v_j| * err_scale
 
     const int64_t ntiles = BATCHED ? a.ntiles : ((M + 63) >> 6);
     const int b = (int)blockIdx.x;
     const int64_t lo_tile = (int64_t)b * a.tiles_q + (b < a.tiles_r ? b : a.tiles_r);
     const int64_t tile_end = lo_tile + a.tiles_q + (b < a.tiles_r ? 1 : 0);
     // the slower wave of a SIMD (waves 4-7 of an 8-wave workgroup) leaves the last tiles of the run to the faster one
-    const int tail_from = (int)(tile_end - lo_tile) - ((WAVES >= 8 && wave >= 4) ? 6 : 0);
+    const int tail_from = (int)(tile_end - lo_tile) - ((WAVES >= 8 && wave >= 4) ? GQ_PFD_TAIL : 0);
     auto draw = [&]() {   // the next tile of this workgroup's run (may lie beyond tile_end)
         int k = 0x3FFFFFFF;
         if (lane == 0) {
@@ -284,13 +247,117 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : (D == 16 ? 8 : GQ_W8)) * 64, 1)
     f32x4 nxte[2][KS][2];   // EF: the error tile that goes with nxt (dead otherwise)
     bf16x8 vh[2][KS], vl[2][KS];
     Tile ti = {};
+    // ---- prologue.  K = 256 (one page): everything the workgroup needs from memory is requested first, in the order
+    // it is used -- the codebook words for the LDS image, this wave's row block of the codebook (every wave splits ONE
+    // of the 8 row blocks into bf16 hi / lo fragments and shares it through LDS; ||c||_1 comes from the same
+    // registers), the wave's first tile (single tensor), whose HBM latency then hides behind the staging -- and there
+    // is one barrier: hsq_encode_pf.hip's prologue (D = 32: 8.0 us before, encode 47.5 -> 44.2 us).  PAGED keeps the plain loops below.
+    bool first_loaded = false;
+    if constexpr (!PAGED) {
+        constexpr int NCB = (256 * D + THREADS - 1) / THREADS;
+        float cbv[NCB];
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) {
+            const int i = threadIdx.x + n * THREADS;
+            cbv[n] = (256 * D % THREADS == 0 || i < 256 * D) ? cb[i] : 0.0f;
+        }
+        f32x4 aq[KS][2];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            aq[s][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            aq[s][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (wave < 8 && 16 * s + 8 * h < D) {
+                aq[s][0] = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * D + 16 * s + 8 * h);
+                aq[s][1] = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * D + 16 * s + 8 * h + 4);
+            }
+        }
+        if (!BATCHED && t < tile_end) {
+            ti = tile_info(t, 0);
+            load_tile(ti, cur);
+            first_loaded = true;
+        }
+        if (threadIdx.x == 0) s_next = WAVES;
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) {
+            const int i = threadIdx.x + n * THREADS;
+            if (256 * D % THREADS == 0 || i < 256 * D) {
+                const int k = i / D, e = i % D;
+                s_cb[(k >> 2) * QS + 4 * e + (k & 3)] = cbv[n];
+            }
+        }
+        if (BATCHED) {
+            for (int i = threadIdx.x; i < a.nseg * 8; i += THREADS) s_seg[i] = a.seg_table[i];
+        }
+        float l1 = 0.0f;
+        if (wave < 8) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 hi, lo;
+                split8(aq[s][0], aq[s][1], hi, lo);
+                s_a[((wave * KS + s) * 2 + 0) * 64 + lane] = hi;
+                s_a[((wave * KS + s) * 2 + 1) * 64 + lane] = lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) l1 += fabsf(aq[s][0][e]) + fabsf(aq[s][1][e]);
+            }
+            l1 += __shfl_xor(l1, 32, 64);   // row wave*32 + j: this lane's elements + its partner's
+            l1 = wave_max(l1);
+        }
+        if (lane == 0) s_c1[wave] = l1;
+        __syncthreads();
+    } else {
+        // exact f32 codebook, groups of 4 codewords interleaved: s_cb[(k>>2)*QS + 4*e + (k&3)] = c[k][e]
+        if (threadIdx.x == 0) s_next = WAVES;
+        for (int i = threadIdx.x; i < npages * 256 * D; i += THREADS) {
+            const int k = i / D, e = i % D;
+            s_cb[(k >> 2) * QS + 4 * e + (k & 3)] = cb[i];
+        }
+        // A fragments of v_mfma_f32_32x32x16_bf16: lane (row j, half h) of k-step s holds
+        // c[rb*32 + j][16 s + 8 h .. + 7] (zeros beyond D), split into bf16 hi and lo
+        for (int i = threadIdx.x; i < npages * 8 * KS * 64; i += THREADS) {
+            const int l = i & 63, s = (i >> 6) % KS, rb = i / (64 * KS);
+            const int row = rb * 32 + (l & 31), e0 = 16 * s + 8 * (l >> 5);
+            f32x4 q0 = {0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0;
+            if (e0 < D) {
+                q0 = *reinterpret_cast<const f32x4 *>(cb + row * D + e0);
+                q1 = *reinterpret_cast<const f32x4 *>(cb + row * D + e0 + 4);
+            }
+            bf16x8 hi, lo;
+            split8(q0, q1, hi, lo);
+            s_a[((rb * KS + s) * 2 + 0) * 64 + l] = hi;
+            s_a[((rb * KS + s) * 2 + 1) * 64 + l] = lo;
+        }
+        if (BATCHED) {
+            for (int i = threadIdx.x; i < a.nseg * 8; i += THREADS) s_seg[i] = a.seg_table[i];
+        }
+        __syncthreads();
+        // the error bound scales with max_k ||c_k||_1: measured, not assumed
+        {
+            float l1 = 0.0f;
+            for (int k = threadIdx.x & 255; k < npages * 256; k += 256) {
+                float rowsum = 0.0f;
+#pragma unroll
+                for (int e = 0; e < D; ++e) rowsum += fabsf(s_cb[(k >> 2) * QS + 4 * e + (k & 3)]);
+                l1 = fmaxf(l1, rowsum);
+            }
+            l1 = wave_max(l1);
+            if (lane == 0) s_c1[wave] = l1;
+        }
+        __syncthreads();
+    }
+    float c1 = s_c1[0];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) c1 = fmaxf(c1, s_c1[w]);
+    const float err_scale = c1 * ERR_SCALE;  // E = max|v_j| * err_scale
+
     int64_t tn = draw();
     int seg_n = seg_of(tn);
     int seg_next = 0;
     if (t < tile_end) {
-        ti = tile_info(t, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[t]) : 0);
         seg_next = BATCHED ? __builtin_amdgcn_readfirstlane(seg_n) : 0;
-        load_tile(ti, cur);
+        if (!first_loaded) {
+            ti = tile_info(t, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[t]) : 0);
+            load_tile(ti, cur);
+        }
         load_err(ti, nxte);
         fold_err(ti, cur, nxte);
 #pragma unroll

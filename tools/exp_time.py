@@ -1,4 +1,4 @@
-"""Time gq_hsq_encode (25M elements) for one library build: GQ_LIB_PATH=... python tools/exp_time.py"""
+"""Time gq_hsq_encode (25M elements) for one library build: GQ_LIB_PATH=... [GQ_AB_D=8|16|32] python tools/exp_time.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gradient-quantization_amd"))
@@ -6,10 +6,11 @@ import torch
 from gq_amd import native
 from gq_amd.codebook import load_codebook
 dev = torch.device("cuda:0")
-cb = torch.from_numpy(load_codebook(16, 256)).to(dev)
+D = int(os.environ.get("GQ_AB_D", "16"))
+cb = torch.from_numpy(load_codebook(D, 256)).to(dev)
 torch.manual_seed(1234)
 g = torch.randn(25_000_000, device=dev)
-M = g.numel() // 16
+M = g.numel() // D
 codes = torch.empty(M, dtype=torch.uint8, device=dev)
 u = torch.empty(M, dtype=torch.float32, device=dev)
 ws = native.new_workspace(dev, M)
