@@ -324,6 +324,7 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
                                                                     int chunk_rows, LdsBatch bt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = (int)(blockDim.x >> 6);   // 4; 2 or 1 when a 4-wave workgroup's tiles do not fit the LDS (d > ~110)
     const int j = lane & 31, h = lane >> 5;
     const int stride = dpad + LDS_ROW_PAD, half = dpad >> 1;
     float *const s_cb = lds;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
     // rows [row0, row0 + chunk_rows) of the codebook -> s_cb (all threads)
     auto stage_codebook = [&](int row0) {
         const int total = chunk_rows * dpad;
-        for (int i = threadIdx.x; i < total; i += ENC_THREADS) {
+        for (int i = threadIdx.x; i < total; i += (int)blockDim.x) {
             const int r = (int)(((float)i + 0.5f) * inv_dpad);   // exact for these ranges (i < 2^20, dpad <= 128)
             const int e = i - r * dpad;
             const int row = row0 + r;
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
     };
 
     const int64_t ntiles = (M + 63) >> 6;
-    const int64_t nw = (int64_t)gridDim.x * ENC_WAVES;
+    const int64_t nw = (int64_t)gridDim.x * nwaves;
     const int64_t rounds = (ntiles + nw - 1) / nw;   // the same for every wave of the grid: barriers stay uniform
     float lmin = INFINITY, lmax = -INFINITY;
     bool sawnan = false;   // a projection of this wave is NaN (wave-uniform)
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
         // BATCHED: a wave takes ONE contiguous run of `rounds` tiles, so that its running (min,max) stays with a
         // tensor (visited round-robin every tile changed tensor and paid two atomics on the same few cache
         // lines: 46,000 tiles of the ResNet-50 list at d = 8 took 350 us, most of it queueing there)
-        const int64_t wid = (int64_t)blockIdx.x * ENC_WAVES + wave;
+        const int64_t wid = (int64_t)blockIdx.x * nwaves + wave;
         const int64_t t = BATCHED ? wid * rounds + round : round * nw + wid;
         const bool active = t < ntiles;
         if (active) stage_tile(t);
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_lds_kernel(const float
 }
 
 // LDS plan of hsq_encode_lds_kernel: false if (d, K) does not fit
-bool lds_plan(int d, int K, int *dpad, int *chunk_rows, size_t *bytes) {
+bool lds_plan(int d, int K, int *dpad, int *chunk_rows, size_t *bytes, int *waves) {
     static const int limit = [] {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, 0) != hipSuccess || v < 65536) v = 65536;
@@ -567,9 +568,14 @@ bool lds_plan(int d, int K, int *dpad, int *chunk_rows, size_t *bytes) {
     }();
     if (d > 128) return false;
     const int dp = (d + 7) & ~7, stride = dp + LDS_ROW_PAD;
-    const size_t tile = (size_t)ENC_WAVES * 64 * stride * sizeof(float);
     const size_t row = (size_t)stride * sizeof(float);
+    // waves per workgroup: 4; callers that pass `waves` accept 2 or 1 when four tiles of 64 rows do not fit next to 32
+    // codebook rows (d > ~110: d = 128 ran on the unstaged generic kernel before, 790 us per 25 M elements)
+    int w = ENC_WAVES;
+    while (w > 1 && waves && (size_t)w * 64 * row + 32 * row > (size_t)limit) w >>= 1;
+    const size_t tile = (size_t)w * 64 * row;
     if (tile + 32 * row > (size_t)limit) return false;
+    if (waves) *waves = w;
     const int kpad = (K + 31) & ~31;
     int rows = (int)(((size_t)limit - tile) / row) & ~31;
     // the whole codebook when it fits in half the LDS (two workgroups per CU); otherwise the largest chunk
@@ -646,7 +652,8 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
 
     int dpad = 0, chunk_rows = 0;
     size_t lds_bytes = 0;
-    const bool lds_ok = lds_plan(d, K, &dpad, &chunk_rows, &lds_bytes);
+    int lds_waves = ENC_WAVES;
+    const bool lds_ok = lds_plan(d, K, &dpad, &chunk_rows, &lds_bytes, &lds_waves);
     const bool pf_ok = K == 256 && (d == 8 || d == 16 || d == 32) && (reinterpret_cast<uintptr_t>(grad) & 15) == 0;
     // larger codebooks of the d = 16 family: the prefilter kernel once per page of 256 codewords
     const bool paged_ok = std::is_same<CodeT, int32_t>::value && (d == 8 || d == 16 || d == 32) && K > 256 &&
@@ -676,9 +683,13 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
             (void)hipGetLastError();
             attr_set = true;
         }
-        const int bpc = resident_blocks_per_cu(hsq_encode_lds_kernel<CodeT>, ENC_THREADS, lds_bytes);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_lds_kernel<CodeT>), dim3((unsigned)grid_for(bpc)),
-                           dim3(ENC_THREADS), lds_bytes, st, grad, codebook, M, d, K, codes, u, partials, dpad,
+        const int bpc = resident_blocks_per_cu(hsq_encode_lds_kernel<CodeT>, lds_waves * 64, lds_bytes);
+        int64_t lds_blocks = (ntiles + lds_waves - 1) / lds_waves;
+        int64_t lds_cap = (int64_t)cus * bpc;
+        if (lds_cap > GQ_MAIN_PARTIALS) lds_cap = GQ_MAIN_PARTIALS;
+        if (lds_blocks > lds_cap) lds_blocks = lds_cap;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_lds_kernel<CodeT>), dim3((unsigned)lds_blocks),
+                           dim3(lds_waves * 64), lds_bytes, st, grad, codebook, M, d, K, codes, u, partials, dpad,
                            chunk_rows, LdsBatch{});
         GQ_CHECK_LAUNCH("gq_hsq_encode (lds)");
         return GQ_OK;
@@ -733,7 +744,7 @@ static int launch_encode_lds_batched(const int64_t *seg_table, const int32_t *ti
                                      uint32_t *seg_minmax, hipStream_t st) {
     int dpad = 0, chunk_rows = 0;
     size_t lds_bytes = 0;
-    if (!lds_plan(d, K, &dpad, &chunk_rows, &lds_bytes))
+    if (!lds_plan(d, K, &dpad, &chunk_rows, &lds_bytes, nullptr))
         return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched_any: needs d <= 128 (d=%d K=%d)", d, K);
     auto kernel = hsq_encode_lds_kernel<CodeT, true, EF>;
     static bool attr_set = false;
@@ -760,7 +771,7 @@ static int launch_encode_lds_batched(const int64_t *seg_table, const int32_t *ti
 GQ_API int gq_hsq_batched_any_supported(int d, int K) {
     int dpad = 0, chunk_rows = 0;
     size_t bytes = 0;
-    return (d >= 1 && K >= 1 && K <= 65536 && gq::lds_plan(d, K, &dpad, &chunk_rows, &bytes)) ? 1 : 0;
+    return (d >= 1 && K >= 1 && K <= 65536 && gq::lds_plan(d, K, &dpad, &chunk_rows, &bytes, nullptr)) ? 1 : 0;
 }
 
 GQ_API int gq_hsq_encode_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,

@@ -122,8 +122,10 @@ __device__ __forceinline__ void write_minmax_partials(float lmin, float lmax, fl
     if (threadIdx.x == 0) {
         float a = s_min[0], b = s_max[0];
         bool anynan = nan_bits(a);
+        const int launched = (int)(blockDim.x >> 6);   // a kernel may run with fewer waves than it is built for
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) {
+            if (w >= launched) break;
             anynan = anynan || nan_bits(s_min[w]);
             a = fminf(a, s_min[w]);
             b = fmaxf(b, s_max[w]);
@@ -165,7 +167,7 @@ int launch_encode_pfd(const float *grad, const float *codebook, int64_t M, int d
 
 // LDS plan of the operand-staging kernels (hsq_encode_lds_kernel, pvq_encode_lds_kernel): false if (d, K) does not fit
 constexpr int LDS_ROW_PAD = 4;
-bool lds_plan(int d, int K, int *dpad, int *chunk_rows, size_t *bytes);
+bool lds_plan(int d, int K, int *dpad, int *chunk_rows, size_t *bytes, int *waves = nullptr);
 
 int launch_encode_pfd_paged(const float *grad, const float *codebook, int64_t M, int d, int K, int32_t *codes, float *u,
                             float *workspace, hipStream_t st);

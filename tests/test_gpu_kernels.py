@@ -124,10 +124,12 @@ def test_lds_staged_encode_chunked_codebook_in_a_small_lds_budget():
 
 
 @pytest.mark.parametrize("d,K,M", [(16, 4096, 5000), (64, 1024, 1000), (100, 512, 777), (96, 256, 300), (5, 5, 1234),
-                                   (3, 32, 64), (33, 2048, 129), (1, 64, 4097), (65, 4096, 200)])
+                                   (3, 32, 64), (33, 2048, 129), (1, 64, 4097), (65, 4096, 200), (128, 256, 3000), (120, 300, 700),
+                                   (112, 64, 129)])
 def test_lds_staged_encode_any_shape_matches_generic_and_oracle(nat, oracle, d, K, M):
     """The LDS-staged exact MFMA kernel (the default for everything but d16/K256): whole and chunked
-    codebooks, ragged tiles, K that is no multiple of 32, odd d -- bit-identical to the generic kernel
+    codebooks, ragged tiles, K that is no multiple of 32, odd d, d up to 128 (two-wave workgroups above ~110: four
+    tiles do not fit the LDS there) -- bit-identical to the generic kernel
     and to the oracle's fmaf chain (the reference's torch.mm arithmetic)."""
     rng = np.random.RandomState(d * 1000 + K)
     cb = rng.standard_normal((K, d)).astype(np.float32)
