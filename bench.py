@@ -67,6 +67,12 @@ def parse_args():
 
 def self_launch(args):
     """`bench.py --gpus N` from a bare shell: become the parent of N ranks.  Nothing here touches the GPU."""
+    import torch
+    have = torch.cuda.device_count()      # counting devices does not initialise the GPU
+    if os.environ.get("GQ_BENCH_BACKEND", "nccl") == "nccl" and have < args.gpus:
+        sys.exit("bench.py --gpus %d: this machine shows %d GPU(s); one rank per GPU is the contract.  For a functional run of "
+                 "the %d-rank code path on fewer GPUs: GQ_BENCH_BACKEND=gloo python bench.py --gpus %d (its times mean nothing)"
+                 % (args.gpus, have, args.gpus, args.gpus))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
