@@ -101,7 +101,6 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : (D == 16 ? 8 : GQ_W8)) * 64, 1)
     __shared__ int64_t s_seg[BATCHED ? PFD_LDS_SEGS * 8 : 1];
     __shared__ float s_c1[WAVES];
 
-    const int64_t ntiles = BATCHED ? a.ntiles : ((M + 63) >> 6);
     const int b = (int)blockIdx.x;
     const int64_t lo_tile = (int64_t)b * a.tiles_q + (b < a.tiles_r ? b : a.tiles_r);
     const int64_t tile_end = lo_tile + a.tiles_q + (b < a.tiles_r ? 1 : 0);
