@@ -286,6 +286,7 @@ class _BatchedBase(object):
         self._host = [host.clone().pin_memory() for _ in range(slots + 1)]
         self._host_np = [h[:self._table_words].view(self.nseg, 8).numpy() for h in self._host]   # views of the pinned tables
         self._zeros = [0] * self.nseg
+        self._resets = extra is not None    # the header also carries per-step reset values (min / max accumulators)
         self._last_ptrs = self._last_eptrs = None
         self._events = [None] * (slots + 1)
         self._dev = torch.empty_like(host, device=device)
@@ -314,12 +315,14 @@ class _BatchedBase(object):
     def _upload(self, tensors, slot, align, errs=None):
         """Column 0 of the segment table <- the tensors' device pointers; column 7 <- the error
         buffers' (error-feedback kernels) or 0.  False if any tensor cannot be addressed that way.
-        The header goes to the device every time (it also carries the reset values of the kernels' min / max
-        accumulators); when the pointers are the ones of the last upload (gradients that keep their storage from
+        A header that also carries the reset values of the kernels' min / max accumulators (HSQ, wide-bucket QSGD)
+        goes to the device every time; when the pointers are the ones of the last upload (gradients that keep their storage from
         step to step) the pinned copy is sent as it is, without checking and rewriting the table."""
         ptrs = [g.data_ptr() for g in tensors]
         eptrs = [e.data_ptr() for e in errs] if errs is not None else self._zeros
         if self.ready and ptrs == self._last_ptrs and eptrs == self._last_eptrs:
+            if not self._resets:
+                return True     # nothing but the table in this header, and the device copy still holds it
             self._dev.copy_(self._host[self._last_slot], non_blocking=True)     # unchanged since its last copy
             self._events[self._last_slot].record()     # a later rewrite of this pinned buffer waits for this copy too
             return True
