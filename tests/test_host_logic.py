@@ -249,9 +249,14 @@ def run_psq_digest_fixture(name, factory, device, signature_of):
     users, seed, scale = int(g["users"]), int(g["seed"]), float(g["scale_in"])
     shapes = [tuple(x) for x in json.loads(str(g["shapes"]))]
     params = [torch.nn.Parameter(torch.zeros(*sh, device=device)) for sh in shapes]
-    q = Quantizer(NearestNeighborCompressor, params, make_args(num_users=users, no_cuda=device == "cpu"), codec_factory=factory)
+    extra = json.loads(str(g["args"])) if "args" in g.files else {"random": 0}      # the reference's flags of this fixture
+    signatures = int(g["signatures"]) if "signatures" in g.files else 1
+    q = Quantizer(NearestNeighborCompressor, params,
+                  make_args(num_users=users, no_cuda=device == "cpu", gq_rng="reference", **extra), codec_factory=factory)
     rng = np.random.RandomState(seed)
     grads = []
+    if "seed_r" in g.files:      # args.random: the reference seeded the CPU generator right before the first record
+        torch.manual_seed(int(g["seed_r"]))
     for u in range(users):
         grads.append([(rng.standard_normal(sh) * scale).astype(np.float32) for sh in shapes])
         for p, x in zip(params, grads[u]):
@@ -260,7 +265,9 @@ def run_psq_digest_fixture(name, factory, device, signature_of):
     k = 0
     for u in range(users):
         for i, sh in enumerate(shapes):
-            if g["codes_sha"][k] != "":
+            if not signatures:
+                pass        # random draws: only the aggregates are pinned (make_golden.py)
+            elif g["codes_sha"][k] != "":
                 codes, levels, lb, ub = signature_of(q, u, i, grads[u][i])
                 assert _sha(codes.astype(np.uint8)) == str(g["codes_sha"][k]), (name, "codes", u, i)
                 assert _sha(levels.astype(np.int32)) == str(g["levels_sha"][k]), (name, "levels", u, i)
