@@ -40,16 +40,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct MeanDiv {
     float fR, inv;
     bool pow2;
+    bool apply;   // false: one payload, plain decompress -- the value is stored as decoded (a -0 stays -0)
 };
-__host__ __device__ inline MeanDiv mean_div_of(int R) {
+// mean = the call IS the parameter-server aggregate (every multi-tensor decode): torch's sum starts from +0, so an element
+// whose payloads all decode to -0 (a QSGD level 0 with a negative sign, a codeword element times a zero norm) comes out
+// as +0 even for one payload; the single-tensor entry points with R == 1 are the plain `decompress` and keep the -0.
+__host__ __device__ inline MeanDiv mean_div_of(int R, bool mean = false) {
     MeanDiv m;
     m.fR = (float)R;
     m.inv = 1.0f / (float)R;
     m.pow2 = R > 0 && (R & (R - 1)) == 0;
+    m.apply = mean || R > 1;
     return m;
 }
 template <class V>   // float or a vector of floats
 __device__ __forceinline__ V mean_div(V x, const MeanDiv &m) {
+    x = x + 0.0f;   // (+0) + sum, as torch.stack(...).mean(0) accumulates: -0 becomes +0, everything else is unchanged
     return m.pow2 ? x * m.inv : x / m.fR;
 }
 

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_kernel(
         *reinterpret_cast<f32x4 *>(s_cb + (i >> 2) * 20 + 4 * (i & 3)) = reinterpret_cast<const f32x4 *>(cb)[i];
     __syncthreads();
     const float s = (float)(1 << n_bit);
-    const MeanDiv md = mean_div_of(R);
+    const MeanDiv md = mean_div_of(R, true);   // the aggregate of R users (ps_quantizer.py:48)
     const int64_t total = ntiles * 64 * 4;
     const int64_t stride = (int64_t)gridDim.x * BT_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * BT_THREADS + threadIdx.x; i < total; i += stride) {
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_kernel(
                 acc[3] = acc[3] + dec[3];
             }
         }
-        if (R > 1) {
+        if (md.apply) {
             acc[0] = mean_div(acc[0], md);
             acc[1] = mean_div(acc[1], md);
             acc[2] = mean_div(acc[2], md);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
     }
     __syncthreads();
     const float inv_s = 1.0f / (float)(1 << n_bit);
-    const MeanDiv md = mean_div_of(R);
+    const MeanDiv md = mean_div_of(R, true);
     const int q = threadIdx.x & 3;
     const float *const my_cb = s_cb4 + ((threadIdx.x >> 3) & 3) * 16 + 4 * q;   // this lane's copy and quarter
     const int64_t total = ntiles * 64;   // (group of 4 padded subvectors, quarter) items
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
         for (int k = 0; k < 4; ++k) {
             if (k < nv) {
                 f32x4 a = acc[k];
-                if (R > 1) {
+                if (md.apply) {
                     a[0] = mean_div(a[0], md);
                     a[1] = mean_div(a[1], md);
                     a[2] = mean_div(a[2], md);
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_d_kernel(
         *reinterpret_cast<f32x4 *>(s_cb + (i / UPS) * RS + 4 * (i % UPS)) = reinterpret_cast<const f32x4 *>(cb)[i];
     __syncthreads();
     const float inv_s = 1.0f / (float)(1 << n_bit);
-    const MeanDiv md = mean_div_of(R);
+    const MeanDiv md = mean_div_of(R, true);
     const int64_t total = ntiles * 64 * UPS;
     const int64_t stride = (int64_t)gridDim.x * BT_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * BT_THREADS + threadIdx.x; i < total; i += stride) {
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_d_kernel(
         };
         payload(0, std::true_type{});
         for (int r = 1; r < R; ++r) payload(r, std::false_type{});
-        if (R > 1) {
+        if (md.apply) {
             acc[0] = mean_div(acc[0], md);
             acc[1] = mean_div(acc[1], md);
             acc[2] = mean_div(acc[2], md);
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_any_kernel(
     }
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
     const float inv_s = 1.0f / (float)(1u << n_bit);   // exact; n * inv_s == n / 2^n_bit
-    const MeanDiv md = mean_div_of(R);
+    const MeanDiv md = mean_div_of(R, !ERR);   // ERR: R = 1, the plain decode whose difference to grad is the residual
     const int ups = d / VEC, units = 64 * ups;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int seg = tile_seg[tile];
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_any_kernel(
                     acc = acc + dec;
                 }
             }
-            if (R > 1) acc = mean_div(acc, md);
+            if (md.apply) acc = mean_div(acc, md);
             const int64_t at = local * d + VEC * q;
             if (ERR) acc = *reinterpret_cast<const vec_t *>(grad + at) - acc;
             *reinterpret_cast<vec_t *>(dst + at) = acc;

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_v4_kernel(
                 acc[3] = acc[3] + dec[3];
             }
         }
-        if (R > 1) {
+        if (md.apply) {
             acc[0] = mean_div(acc[0], md);
             acc[1] = mean_div(acc[1], md);
             acc[2] = mean_div(acc[2], md);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(DEC16_THREADS) void hsq_decode_sum_d16u8_kernel(
         for (int k = 0; k < 4; ++k) {
             if (k < nv) {
                 f32x4 a = acc[k];
-                if (R > 1) {
+                if (md.apply) {
                     a[0] = mean_div(a[0], md);
                     a[1] = mean_div(a[1], md);
                     a[2] = mean_div(a[2], md);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_scalar_kernel(
             const float dec = cb[(int64_t)code * d + jj] * n;
             acc = (r == 0) ? dec : acc + dec;
         }
-        if (R > 1) acc = mean_div(acc, md);
+        if (md.apply) acc = mean_div(acc, md);
         out[i] = acc;
     }
 }

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(QS_THREADS) void qsgd_decode_sum_kernel(const float
             t = t / s;
             acc = (r == 0) ? t : acc + t;
         }
-        if (R > 1) acc = mean_div(acc, md);
+        if (md.apply) acc = mean_div(acc, md);
         out[i] = acc;
     }
 }

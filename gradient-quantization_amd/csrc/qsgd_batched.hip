@@ -253,7 +253,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched_kernel(
     const int lane = threadIdx.x & 63;
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float s = (float)(1 << n_bit);
-    const MeanDiv md = mean_div_of(R);
+    const MeanDiv md = mean_div_of(R, true);   // the aggregate of R users (ps_quantizer.py:48)
     const unsigned lmask = (1u << (bits - 1)) - 1u;
     for (int64_t b = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); b < nbuckets; b += nw) {
         const int seg = __builtin_amdgcn_readfirstlane(bucket_seg[b]);
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched_kernel(
                 a0 = (r == 0) ? t0 : a0 + t0;
                 a1 = (r == 0) ? t1 : a1 + t1;
             }
-            if (R > 1) {
+            if (md.apply) {
                 a0 = mean_div(a0, md);
                 a1 = mean_div(a1, md);
             }
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_kernel(
     const int lane = threadIdx.x & 63, sub = lane >> 4, c0 = lane & 15;
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float inv_s = 1.0f / (float)(1 << n_bit);
-    const MeanDiv md = mean_div_of(R);
+    const MeanDiv md = mean_div_of(R, true);   // the aggregate of R users (ps_quantizer.py:48)
     const int64_t nquads = (nbuckets + 3) >> 2;
     for (int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); qd < nquads; qd += nw) {
         const int64_t b = 4 * qd + sub;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_kernel(
                 };
                 payload(0, std::true_type{});
                 for (int r = 1; r < R; ++r) payload(r, std::false_type{});
-                if (R > 1) {
+                if (md.apply) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) acc[k >> 2][k & 3] = mean_div(acc[k >> 2][k & 3], md);
                 }
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_kernel(
                     a0 = (r == 0) ? t0 : a0 + t0;
                     a1 = (r == 0) ? t1 : a1 + t1;
                 }
-                if (R > 1) {
+                if (md.apply) {
                     a0 = mean_div(a0, md);
                     a1 = mean_div(a1, md);
                 }

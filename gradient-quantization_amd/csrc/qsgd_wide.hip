@@ -235,7 +235,7 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_decode_kernel(const int6
                                                                      float *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const float inv_s = 1.0f / (float)(1 << n_bit);
-    const MeanDiv md = mean_div_of(R);
+    const MeanDiv md = mean_div_of(R, true);   // the aggregate of R users (ps_quantizer.py:48)
     constexpr unsigned lmask = (1u << (BITS - 1)) - 1u;
     int64_t c_begin, c_end;
     wide_run(nchunks, c_begin, c_end);
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_decode_kernel(const int6
                     acc[k] = (r == 0) ? t : acc[k] + t;
                 }
             }
-            if (R > 1) {
+            if (md.apply) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] = mean_div(acc[k], md);
             }

@@ -177,6 +177,8 @@ class HSQCodec(object):
     def decode_mean(self, gathered, off, R):
         out = torch.empty(self.numel, dtype=torch.float32, device=gathered.device)
         self._decode(gathered, off, R, out)
+        if R == 1:
+            out.add_(0.0)   # one payload is the plain decompress (-0 kept); the aggregate is a sum that starts from +0
         return out.view(self.shape)
 
 
@@ -268,6 +270,8 @@ class QSGDCodec(object):
     def decode_mean(self, gathered, off, R):
         out = torch.empty(self.numel, dtype=torch.float32, device=gathered.device)
         self._decode_rows(gathered, off, R, out)
+        if R == 1:
+            out.add_(0.0)   # as HSQCodec.decode_mean: torch.stack(...).mean(0) of one payload turns -0 into +0
         return out.view(self.shape)
 
 

@@ -137,7 +137,10 @@ int gq_minmax_partials(const float *v, int64_t n, float *workspace, void *stream
  *     out[m,:] = ( sum_{r=0..R-1, ascending} codebook[codes_r[m],:] * n_r[m] ) / R
  * codes: [R][M], levels: [R][M], lb_ub: [R][2].  level_bytes == 0 means `levels`
  * holds f32 norms [R][M] (the n_bit == 32 signature) and lb_ub / n_bit are ignored.
- * R == 1 is the plain decompress.
+ * R == 1 is the plain decompress (a decoded -0 stays -0, as nearest_neighbor_compressor.py:85-90 returns it).  R > 1 is the
+ * aggregate: torch's sum starts from +0, so the sum is (+0 + p_0 + ... + p_{R-1}) and an element whose payloads are all -0
+ * comes out as +0.  The multi-tensor decodes (gq_*_decode_sum_batched*, gq_qsgd_wide_decode_sum) are always the aggregate,
+ * also for R == 1 (ps_quantizer.py:48 takes the mean of one user's stack as well).
  */
 int gq_hsq_decode_sum(const void *codes, int code_bytes, const void *levels, int level_bytes, const float *lb_ub,
                       const float *codebook, int R, int64_t M, int d, int K, int n_bit, float *out, void *stream);

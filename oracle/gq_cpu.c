@@ -152,7 +152,10 @@ GQ_EXPORT int gq_cpu_hsq_decode_sum(const void *codes, int code_bytes, const voi
         gq_oracle_hsq_decode(c, norms, codebook, M, d, dec + (size_t)r * (size_t)n);
         free(c);
     }
-    gq_oracle_mean_users(dec, R, n, out);
+    if (R == 1)
+        memcpy(out, dec, (size_t)n * sizeof(float));   /* the plain decompress: a -0 stays -0 */
+    else
+        gq_oracle_mean_users(dec, R, n, out);
     free(dec);
     free(norms);
     return GQ_OK;
@@ -197,7 +200,10 @@ GQ_EXPORT int gq_cpu_qsgd_decode_sum(const float *norm, const uint8_t *signs, co
                                   dec + (size_t)r * (size_t)n);
         free(l);
     }
-    gq_oracle_mean_users(dec, R, n, out);
+    if (R == 1)
+        memcpy(out, dec, (size_t)n * sizeof(float));
+    else
+        gq_oracle_mean_users(dec, R, n, out);
     free(dec);
     return GQ_OK;
 }

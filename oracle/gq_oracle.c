@@ -172,7 +172,7 @@ GQ_EXPORT void gq_oracle_hsq_compress(const float *grad, const float *codebook, 
  */
 GQ_EXPORT void gq_oracle_mean_users(const float *decoded, int U, int64_t n, float *out) {
     for (int64_t i = 0; i < n; ++i) {
-        float acc = decoded[i];
+        float acc = 0.0f + decoded[i];   /* torch's sum starts from +0: an all -0 column comes out as +0 */
         for (int k = 1; k < U; ++k) acc += decoded[(int64_t)k * n + i];
         out[i] = acc / (float)U;
     }

@@ -41,6 +41,18 @@ class OracleQSGDCodec(QSGDCodec):
 
     def encode_into(self, grad, wire_user, off, salt):
         c = self.c
+        if self.bits == 0:      # the plain signature form (norm | signs | levels): the reference's draws
+            assert not c.random or c._rng == "reference", "oracle codec: deterministic levels or the reference's draws"
+            r = torch.rand(self.Mb, self.d).numpy() if c.random else None      # qsgd_compressor.py:56
+            norm, signs, levels = oracle.qsgd_compress(grad.detach().cpu().numpy().reshape(-1), self.d, c.bit,
+                                                       1 if c.random else 0, r)
+            vn, vs, vl = self._views(wire_user, off)
+            vn.copy_(torch.from_numpy(norm))
+            vs.copy_(torch.from_numpy(signs))
+            if self.level_dtype == torch.uint8:
+                levels = np.where(levels < 0, 0, levels)      # INT_MIN (zero bucket) -> 0 in the byte form, decodes to 0
+            vl.copy_(torch.from_numpy(levels).to(self.level_dtype))
+            return
         assert not c.random and self.bits in (4, 8)
         norm, signs, levels = oracle.qsgd_compress(grad.detach().cpu().numpy().reshape(-1), self.d, c.bit, 0)
         lv = levels.copy()
@@ -53,6 +65,12 @@ class OracleQSGDCodec(QSGDCodec):
 
     def _decode_rows(self, gathered, off, R, out):
         decs = []
+        if self.bits == 0:
+            for r in range(R):
+                vn, vs, vl = self._views(gathered[r], off)
+                decs.append(oracle.qsgd_decompress(vn.numpy(), vs.numpy(), vl.numpy().astype(np.int32), self.d, self.c.bit))
+            out.copy_(torch.from_numpy(oracle.mean_users(np.stack(decs, 0))))
+            return
         nb = self.numel * self.bits // 8
         for r in range(R):
             norm = gathered[r, off + self.norm_off:off + self.norm_off + self.Mb * 4].view(torch.float32).numpy()

