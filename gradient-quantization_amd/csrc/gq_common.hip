@@ -124,6 +124,22 @@ GQ_API int gq_hsq_given_draws(const float *r_flat) {
     return GQ_OK;
 }
 
+// ---- plain (non-aggregate) semantics for the next multi-tensor decode (gq_decode_plain_next) ------------------
+namespace gq {
+static thread_local bool g_decode_plain = false;
+bool take_decode_plain() {
+    const bool p = g_decode_plain;
+    g_decode_plain = false;
+    return p;
+}
+}  // namespace gq
+
+GQ_API int gq_decode_plain_next(void) {
+    gq::g_decode_plain = true;
+    return GQ_OK;
+}
+
+
 GQ_API int gq_profile_arm(int slot) {
     if (slot < 0 || slot >= GQ_PROFILE_SLOTS) return gq::fail(GQ_ERR_INVALID_ARG, "gq_profile_arm: slot %d", slot);
     if (!gq::g_prof_created[slot]) {

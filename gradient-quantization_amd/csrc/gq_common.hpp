@@ -20,6 +20,8 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 int cu_count();
 // the draws handed over by gq_hsq_given_draws on this thread (once), or nullptr
 const float *take_given_draws();
+// gq_decode_plain_next was called on this thread since the last multi-tensor decode (once)
+bool take_decode_plain();
 // true (once) if gq_profile_arm was called on this thread: the events to attach to the next dispatch
 bool profile_take(hipEvent_t *start, hipEvent_t *stop);
 

@@ -146,14 +146,14 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_kernel(
 __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
-    float *__restrict__ out) {
+    float *__restrict__ out, int plain) {
     // rows 20 floats apart: an odd number of 16-byte units spreads the random-row gathers over the banks
     __shared__ __attribute__((aligned(16))) float s_cb[256 * 20];
     for (int i = threadIdx.x; i < 256 * 16 / 4; i += BT_THREADS)
         *reinterpret_cast<f32x4 *>(s_cb + (i >> 2) * 20 + 4 * (i & 3)) = reinterpret_cast<const f32x4 *>(cb)[i];
     __syncthreads();
     const float s = (float)(1 << n_bit);
-    const MeanDiv md = mean_div_of(R, true);   // the aggregate of R users (ps_quantizer.py:48)
+    const MeanDiv md = mean_div_of(R, !plain);   // the aggregate of R users (ps_quantizer.py:48) unless the caller asked for the plain decode
     const int64_t total = ntiles * 64 * 4;
     const int64_t stride = (int64_t)gridDim.x * BT_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * BT_THREADS + threadIdx.x; i < total; i += stride) {
@@ -207,7 +207,7 @@ constexpr int BT4_THREADS = 1024;
 __global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
-    float *__restrict__ out) {
+    float *__restrict__ out, int plain) {
     extern __shared__ float s_cb4[];   // [256][4 copies][16]
     for (int i = threadIdx.x; i < 256 * 16; i += BT4_THREADS) {   // (row, copy, quarter)
         const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
     }
     __syncthreads();
     const float inv_s = 1.0f / (float)(1 << n_bit);
-    const MeanDiv md = mean_div_of(R, true);
+    const MeanDiv md = mean_div_of(R, !plain);
     const int q = threadIdx.x & 3;
     const float *const my_cb = s_cb4 + ((threadIdx.x >> 3) & 3) * 16 + 4 * q;   // this lane's copy and quarter
     const int64_t total = ntiles * 64;   // (group of 4 padded subvectors, quarter) items
@@ -347,7 +347,7 @@ template <int D>
 __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_d_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
-    float *__restrict__ out) {
+    float *__restrict__ out, int plain) {
     constexpr int UPS = D / 4;                               // 16-byte units per subvector
     constexpr int RS = ((D / 4) & 1) ? D : D + 4;            // LDS row stride in floats
     __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_d_kernel(
         *reinterpret_cast<f32x4 *>(s_cb + (i / UPS) * RS + 4 * (i % UPS)) = reinterpret_cast<const f32x4 *>(cb)[i];
     __syncthreads();
     const float inv_s = 1.0f / (float)(1 << n_bit);
-    const MeanDiv md = mean_div_of(R, true);
+    const MeanDiv md = mean_div_of(R, !plain);
     const int64_t total = ntiles * 64 * UPS;
     const int64_t stride = (int64_t)gridDim.x * BT_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * BT_THREADS + threadIdx.x; i < total; i += stride) {
@@ -406,7 +406,7 @@ template <typename CodeT, typename LevelT, int VEC, bool ERR>
 __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_any_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int d, int K,
-    int n_bit, float *__restrict__ out, int cb_in_lds) {
+    int n_bit, float *__restrict__ out, int cb_in_lds, int plain) {
     extern __shared__ __attribute__((aligned(16))) float s_cb_any[];
     const float *cbp = cb;
     if (cb_in_lds) {
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_any_kernel(
     }
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
     const float inv_s = 1.0f / (float)(1u << n_bit);   // exact; n * inv_s == n / 2^n_bit
-    const MeanDiv md = mean_div_of(R, !ERR);   // ERR: R = 1, the plain decode whose difference to grad is the residual
+    const MeanDiv md = mean_div_of(R, !ERR && !plain);   // ERR: R = 1, the plain decode whose difference to grad is the residual
     const int ups = d / VEC, units = 64 * ups;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int seg = tile_seg[tile];
@@ -462,6 +462,7 @@ template <typename CodeT, typename LevelT, bool ERR>
 static int launch_decode_any(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
                              int64_t user_stride, int R, const float *cb, int d, int K, int n_bit, float *out,
                              hipStream_t st, const char *what) {
+    const int plain = (!ERR && take_decode_plain()) ? 1 : 0;   // gq_decode_plain_next: the ring's hop, not the aggregate
     const size_t cb_bytes = (size_t)K * d * sizeof(float);
     const int in_lds = cb_bytes <= 64 * 1024;
     const size_t lds = in_lds ? cb_bytes : 0;
@@ -471,11 +472,11 @@ static int launch_decode_any(const int64_t *seg_table, const int32_t *tile_seg, 
     if ((d & 3) == 0) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched_any_kernel<CodeT, LevelT, 4, ERR>),
                            dim3((unsigned)blocks), dim3(BT_THREADS), lds, st, seg_table, tile_seg, ntiles, gathered,
-                           user_stride, R, cb, d, K, n_bit, out, in_lds);
+                           user_stride, R, cb, d, K, n_bit, out, in_lds, plain);
     } else {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched_any_kernel<CodeT, LevelT, 1, ERR>),
                            dim3((unsigned)blocks), dim3(BT_THREADS), lds, st, seg_table, tile_seg, ntiles, gathered,
-                           user_stride, R, cb, d, K, n_bit, out, in_lds);
+                           user_stride, R, cb, d, K, n_bit, out, in_lds, plain);
     }
     GQ_CHECK_LAUNCH(what);
     return GQ_OK;
@@ -561,6 +562,7 @@ GQ_API int gq_hsq_decode_sum_batched(const int64_t *seg_table, const int32_t *ti
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: bad sizes");
     if (!seg_table || !tile_seg || !gathered || !codebook || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: null pointer");
+    const int plain = gq::take_decode_plain() ? 1 : 0;
     if ((user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0) {
         static const int bpc = [] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gq::hsq_decode_sum_batched4_kernel),
@@ -576,11 +578,11 @@ GQ_API int gq_hsq_decode_sum_batched(const int64_t *seg_table, const int32_t *ti
         if (blocks > (int64_t)gq::cu_count() * bpc) blocks = (int64_t)gq::cu_count() * bpc;
         hipLaunchKernelGGL(gq::hsq_decode_sum_batched4_kernel, dim3((unsigned)blocks), dim3(gq::BT4_THREADS),
                            (size_t)64 * 1024, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
-                           user_stride_bytes, R, codebook, n_bit, out);
+                           user_stride_bytes, R, codebook, n_bit, out, plain);
     } else {
         hipLaunchKernelGGL(gq::hsq_decode_sum_batched_kernel, dim3((unsigned)gq::bt_grid(ntiles * 256)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
-                           user_stride_bytes, R, codebook, n_bit, out);
+                           user_stride_bytes, R, codebook, n_bit, out, plain);
     }
     GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched");
     return GQ_OK;
@@ -596,14 +598,15 @@ GQ_API int gq_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched_d: bad sizes");
     if (!seg_table || !tile_seg || !gathered || !codebook || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched_d: null pointer");
+    const int plain = gq::take_decode_plain() ? 1 : 0;
     if (d == 8) {
         hipLaunchKernelGGL(gq::hsq_decode_sum_batched_d_kernel<8>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 2)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
-                           user_stride_bytes, R, codebook, n_bit, out);
+                           user_stride_bytes, R, codebook, n_bit, out, plain);
     } else if (d == 32) {
         hipLaunchKernelGGL(gq::hsq_decode_sum_batched_d_kernel<32>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 8)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
-                           user_stride_bytes, R, codebook, n_bit, out);
+                           user_stride_bytes, R, codebook, n_bit, out, plain);
     } else {
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched_d: d must be 8, 16 or 32 (K = 256)");
     }

@@ -249,11 +249,11 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
 // decode + mean over R users: one wave per bucket, out = ( sum_r (l * (2*sign-1)) * norm / 2^n_bit ) / R
 __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int n_bit,
-    int bits, const uint8_t *__restrict__ gathered, int64_t user_stride, int R, float *__restrict__ out) {
+    int bits, const uint8_t *__restrict__ gathered, int64_t user_stride, int R, float *__restrict__ out, int plain) {
     const int lane = threadIdx.x & 63;
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float s = (float)(1 << n_bit);
-    const MeanDiv md = mean_div_of(R, true);   // the aggregate of R users (ps_quantizer.py:48)
+    const MeanDiv md = mean_div_of(R, !plain);   // the aggregate of R users (ps_quantizer.py:48)
     const unsigned lmask = (1u << (bits - 1)) - 1u;
     for (int64_t b = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); b < nbuckets; b += nw) {
         const int seg = __builtin_amdgcn_readfirstlane(bucket_seg[b]);
@@ -307,11 +307,11 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched_kernel(
 // cleared sign bit decodes to -0 like the reference's 0 * -1), the division as an exact scaling.
 __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int n_bit,
-    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, float *__restrict__ out) {
+    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, float *__restrict__ out, int plain) {
     const int lane = threadIdx.x & 63, sub = lane >> 4, c0 = lane & 15;
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float inv_s = 1.0f / (float)(1 << n_bit);
-    const MeanDiv md = mean_div_of(R, true);   // the aggregate of R users (ps_quantizer.py:48)
+    const MeanDiv md = mean_div_of(R, !plain);   // the aggregate of R users (ps_quantizer.py:48)
     const int64_t nquads = (nbuckets + 3) >> 2;
     for (int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); qd < nquads; qd += nw) {
         const int64_t b = 4 * qd + sub;
@@ -447,15 +447,16 @@ GQ_API int gq_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *b
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: bad sizes");
     if (!seg_table || !bucket_seg || !gathered || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: null pointer");
+    const int plain = gq::take_decode_plain() ? 1 : 0;
     if (bits == 4 && (user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
         hipLaunchKernelGGL(gq::qsgd_decode_sum_batched4_kernel, dim3((unsigned)gq::qb_grid((nbuckets + 3) / 4)),
                            dim3(gq::QB_THREADS), 0, gq::as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit,
-                           gathered, user_stride_bytes, R, out);
+                           gathered, user_stride_bytes, R, out, plain);
     } else {
         hipLaunchKernelGGL(gq::qsgd_decode_sum_batched_kernel, dim3((unsigned)gq::qb_grid(nbuckets)),
                            dim3(gq::QB_THREADS), 0, gq::as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, bits,
-                           gathered, user_stride_bytes, R, out);
+                           gathered, user_stride_bytes, R, out, plain);
     }
     GQ_CHECK_LAUNCH("gq_qsgd_decode_sum_batched");
     return GQ_OK;

@@ -232,10 +232,10 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_decode_kernel(const int6
                                                                      int64_t nchunks, int n_bit,
                                                                      const uint8_t *__restrict__ gathered,
                                                                      int64_t user_stride, int R,
-                                                                     float *__restrict__ out) {
+                                                                     float *__restrict__ out, int plain) {
     const int lane = threadIdx.x & 63;
     const float inv_s = 1.0f / (float)(1 << n_bit);
-    const MeanDiv md = mean_div_of(R, true);   // the aggregate of R users (ps_quantizer.py:48)
+    const MeanDiv md = mean_div_of(R, !plain);   // the aggregate of R users (ps_quantizer.py:48)
     constexpr unsigned lmask = (1u << (BITS - 1)) - 1u;
     int64_t c_begin, c_end;
     wide_run(nchunks, c_begin, c_end);
@@ -361,16 +361,17 @@ GQ_API int gq_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chun
     if ((user_stride_bytes & 3) != 0 || (reinterpret_cast<uintptr_t>(gathered) & 3) != 0 ||
         (reinterpret_cast<uintptr_t>(out) & 15) != 0)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_wide_decode_sum: wires must be 4-byte, out 16-byte aligned");
+    const int plain = gq::take_decode_plain() ? 1 : 0;
     const dim3 grid((unsigned)gq::qw_grid(nchunks)), block(gq::QW_THREADS);
     if (bits == 4)
         hipLaunchKernelGGL(gq::qsgd_wide_decode_kernel<4>, grid, block, 0, gq::as_stream(stream), seg_table, chunk_seg,
-                           nchunks, n_bit, gathered, user_stride_bytes, R, out);
+                           nchunks, n_bit, gathered, user_stride_bytes, R, out, plain);
     else if (bits == 16)
         hipLaunchKernelGGL(gq::qsgd_wide_decode_kernel<16>, grid, block, 0, gq::as_stream(stream), seg_table, chunk_seg,
-                           nchunks, n_bit, gathered, user_stride_bytes, R, out);
+                           nchunks, n_bit, gathered, user_stride_bytes, R, out, plain);
     else
         hipLaunchKernelGGL(gq::qsgd_wide_decode_kernel<8>, grid, block, 0, gq::as_stream(stream), seg_table, chunk_seg,
-                           nchunks, n_bit, gathered, user_stride_bytes, R, out);
+                           nchunks, n_bit, gathered, user_stride_bytes, R, out, plain);
     GQ_CHECK_LAUNCH("gq_qsgd_wide_decode_sum");
     return GQ_OK;
 }

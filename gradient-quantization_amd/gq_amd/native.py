@@ -25,7 +25,7 @@ EXPORTS = [
     "gq_hsq_encode_batched_d", "gq_hsq_decode_sum_batched_d", "gq_hsq_encode_batched_d_ef", "gq_hsq_levels_batched_ef_d",
     "gq_hsq_encode_batched_any", "gq_hsq_levels_batched_any", "gq_hsq_decode_sum_batched_any", "gq_hsq_error_batched_any",
     "gq_hsq_batched_any_supported", "gq_hsq_encode_batched_paged", "gq_qsgd_wide_compress", "gq_qsgd_wide_decode_sum",
-    "gq_profile_arm", "gq_profile_read", "gq_hsq_compress", "gq_hsq_given_draws",
+    "gq_profile_arm", "gq_profile_read", "gq_hsq_compress", "gq_hsq_given_draws", "gq_decode_plain_next",
     "gq_pvq_encode", "gq_pvq_encode_residual", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
@@ -260,6 +260,12 @@ def hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat
                                      _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
                                      _dev_ptr(workspace, torch.float32, "workspace"), _stream())
     _check(rc, "gq_hsq_encode_batched")
+
+
+def decode_plain_next():
+    """The next multi-tensor decode of this thread is the plain decompress of its payload (a -0 stays -0), not the
+    aggregate (+0 + sum) / R: RingQuantizer's hop and final gradient (ring_quantizer.py:32,41-47)."""
+    _check(lib().gq_decode_plain_next(), "gq_decode_plain_next")
 
 
 def hsq_given_draws(r_flat):

@@ -53,9 +53,11 @@ class DenseCodec(object):
     def roundtrip(self, grad, salt):
         return grad.clone()
 
-    def decode_mean(self, gathered, off, R):
-        # [R, numel] view of the gathered wire; stack().mean(0) of the reference
+    def decode_mean(self, gathered, off, R, plain=False):
+        # [R, numel] view of the gathered wire; stack().mean(0) of the reference (plain: the one payload as it is)
         rows = gathered[:, off:off + self.numel * 4].view(torch.float32)
+        if plain and R == 1:
+            return rows[0].clone().view(self.shape)
         return rows.mean(dim=0).view(self.shape)
 
 
@@ -77,8 +79,10 @@ class GenericCodec(object):
     def encode_into(self, grad, wire_user, off, salt):
         wire_user[off:off + self.numel * 4].view(torch.float32).copy_(self.roundtrip(grad, salt).reshape(-1))
 
-    def decode_mean(self, gathered, off, R):
+    def decode_mean(self, gathered, off, R, plain=False):
         rows = gathered[:, off:off + self.numel * 4].view(torch.float32)
+        if plain and R == 1:
+            return rows[0].clone().view(self.shape)
         return rows.mean(dim=0).view(self.shape)
 
 
@@ -174,10 +178,10 @@ class HSQCodec(object):
         self.decode_wire(tmp, 0, out)
         return out.view(self.shape)
 
-    def decode_mean(self, gathered, off, R):
+    def decode_mean(self, gathered, off, R, plain=False):
         out = torch.empty(self.numel, dtype=torch.float32, device=gathered.device)
         self._decode(gathered, off, R, out)
-        if R == 1:
+        if R == 1 and not plain:
             out.add_(0.0)   # one payload is the plain decompress (-0 kept); the aggregate is a sum that starts from +0
         return out.view(self.shape)
 
@@ -242,11 +246,13 @@ class QSGDCodec(object):
             native.qsgd_compress(flat, self.d, c.bit, native.RANDOM_DEVICE, None, _next_seed() ^ salt, norm, signs,
                                  levels)
 
-    def _decode_rows(self, gathered, off, R, out):
+    def _decode_rows(self, gathered, off, R, out, plain=False):
         if self.bits:
             rows = gathered[:, off:off + self.nbytes]
             if not rows.is_contiguous():
                 rows = rows.contiguous()
+            if plain:
+                native.decode_plain_next()
             out.copy_(self._batched1(gathered.device).decode_mean(rows, R)[0].view(-1))
             return
         # the plain entry point takes dense [R][...] arrays: gather the three sections
@@ -261,16 +267,16 @@ class QSGDCodec(object):
         tmp = torch.empty(self.nbytes, dtype=torch.uint8, device=grad.device)
         self.encode_into(grad, tmp, 0, salt)
         out = torch.empty(self.numel, dtype=torch.float32, device=grad.device)
-        self._decode_rows(tmp.view(1, -1), 0, 1, out)
+        self._decode_rows(tmp.view(1, -1), 0, 1, out, plain=True)     # decompress(compress(g)): no aggregate
         return out.view(self.shape)
 
     def decode_wire(self, wire_user, off, out):
-        self._decode_rows(wire_user.view(1, -1), off, 1, out)
+        self._decode_rows(wire_user.view(1, -1), off, 1, out, plain=True)
 
-    def decode_mean(self, gathered, off, R):
+    def decode_mean(self, gathered, off, R, plain=False):
         out = torch.empty(self.numel, dtype=torch.float32, device=gathered.device)
-        self._decode_rows(gathered, off, R, out)
-        if R == 1:
+        self._decode_rows(gathered, off, R, out, plain=plain)
+        if R == 1 and not plain:
             out.add_(0.0)   # as HSQCodec.decode_mean: torch.stack(...).mean(0) of one payload turns -0 into +0
         return out.view(self.shape)
 
@@ -401,6 +407,7 @@ class _BatchedBase(object):
             self._tmp_wire = torch.zeros((1, self.user_bytes), dtype=torch.uint8, device=self.device)
         if not self.encode(tensors, self._tmp_wire[0], slot, salt, errs, ef_scale, draws=draws):
             return None
+        native.decode_plain_next()      # decompress(compress(t)) (ps_quantizer.py:52-61): the plain decode, a -0 stays -0
         return self.decode_mean(self._tmp_wire, 1)
 
 
@@ -839,7 +846,7 @@ class PSQuantizer(object):
         o = self._draw_off[i]
         return {"r": draws[0][o:o + self.codecs[i].M]}
 
-    def _decode_all(self, gathered, two_phase, pending=()):
+    def _decode_all(self, gathered, two_phase, pending=(), plain=False):
         """Mean of the R = gathered.shape[0] user payloads for every parameter (ps_quantizer.py:47-61),
         as a list of tensors in parameter order.  `pending`: the transfers that fill `gathered`
         (exchange.WireExchange.start) -- one, or two for a split exchange, in which case the tensors below
@@ -865,11 +872,13 @@ class PSQuantizer(object):
 
         def decode_part(part):
             for gi, (cls, idxs, obj) in enumerate(groups):
+                if plain:
+                    native.decode_plain_next()      # consumed by the launch inside decode_mean
                 group_views[gi] = obj.decode_mean(gathered, R, part if split else None, firsts[gi] if split else 0)
             for i in single:
                 if split and (self.offsets[i] < self.cut) != (part == "head"):
                     continue
-                done[i] = self.codecs[i].decode_mean(gathered, self.offsets[i], R)
+                done[i] = self.codecs[i].decode_mean(gathered, self.offsets[i], R, plain=plain)
 
         if pending:
             pending.pop(0).wait()
@@ -906,7 +915,10 @@ class PSQuantizer(object):
                     views.append(mean[o:o + n].view(self.codecs[i].shape))
                     o += n
                 self._dense_mean[k], self._dense_views[k] = mean, views
-            torch.mean(rows, dim=0, out=self._dense_mean[k])   # stack().mean(0) of the reference, all at once
+            if plain and R == 1:
+                self._dense_mean[k].copy_(rows[0])      # the ring's hop: the payload as it is (a -0 stays -0)
+            else:
+                torch.mean(rows, dim=0, out=self._dense_mean[k])   # stack().mean(0) of the reference, all at once
             for i, v in zip(self.dense_idx, self._dense_views[k]):
                 done[i] = v
         if two_phase:
@@ -982,12 +994,12 @@ class RingQuantizer(PSQuantizer):
                 self._inbox = torch.empty((1, self.user_bytes), dtype=torch.uint8, device=dev)
             dist.recv(self._inbox.view(-1), src=self._peer(rank - 1), group=self.process_group)
             self._ready_for_wire(dev)
-            self.running = self._decode_all(self._inbox, False)
+            self.running = self._decode_all(self._inbox, False, plain=True)
         if self.running is not None:     # ring_quantizer.py:31-32 (user != 0)
             torch._foreach_add_([p.grad.data for p in self.parameters], list(self.running))
         self.recorded = 0                # every user re-uses wire slot 0
         super().record(user, epoch)
-        self.running = self._decode_all(self._wire[:1], False)
+        self.running = self._decode_all(self._wire[:1], False, plain=True)
 
     def _peer(self, group_rank):
         import torch.distributed as dist
@@ -1014,7 +1026,7 @@ class RingQuantizer(PSQuantizer):
             final = self._wire[:1] if rank == world - 1 else self._inbox_for(dev)
             dist.broadcast(final.view(-1), src=self._peer(world - 1), group=self.process_group)
             if rank != world - 1:
-                self.running = self._decode_all(final, False)
+                self.running = self._decode_all(final, False, plain=True)
         if self.running is not None:     # ring_quantizer.py:45-46
             for param, g in zip(self.parameters, self.running):
                 param.grad.data = g

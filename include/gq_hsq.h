@@ -233,6 +233,15 @@ int gq_hsq_batched_any_supported(int d, int K);   /* 1 if gq_hsq_encode_batched_
  * gq_hsq_levels_batched* call on this thread with random_mode = GQ_RANDOM_GIVEN consumes it (compare is the
  * reference's strict `frac > r`). */
 int gq_hsq_given_draws(const float *r_flat);
+
+/*
+ * The NEXT multi-tensor decode issued by this thread (gq_hsq_decode_sum_batched*, gq_qsgd_decode_sum_batched,
+ * gq_qsgd_wide_decode_sum) is a plain decompress of its one payload instead of the parameter-server aggregate: a decoded
+ * -0 stays -0.  This is the ring's hop and its final gradient (ring_quantizer.py:32,41-43,47: grad.add_(decompress(...)),
+ * param.grad.data = the last decompress), where the aggregate's (+0 + sum) / R would turn those zeros positive.  Only the sign of
+ * zeros differs between the two.
+ */
+int gq_decode_plain_next(void);
 int gq_hsq_encode_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                               const float *codebook, int d, int K, int code_bytes, int ef, float ef_scale,
                               uint8_t *wire, float *u_flat, uint32_t *seg_minmax, void *stream);

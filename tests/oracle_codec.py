@@ -33,7 +33,7 @@ class OracleHSQCodec(HSQCodec):
             codes, levels, lb_ub = self._views(gathered[r], off)
             decs.append(oracle.hsq_decompress(codes.numpy().astype(np.int32), levels.numpy().astype(np.int32),
                                               np.float32(lb_ub[0].item()), np.float32(lb_ub[1].item()), cb, c.n_bit))
-        out.copy_(torch.from_numpy(oracle.mean_users(np.stack(decs, 0))))
+        out.copy_(torch.from_numpy(decs[0] if R == 1 else oracle.mean_users(np.stack(decs, 0))))   # one payload: the plain decompress
 
 
 class OracleQSGDCodec(QSGDCodec):
@@ -63,13 +63,13 @@ class OracleQSGDCodec(QSGDCodec):
         wire_user[off + self.norm_off:off + self.norm_off + self.Mb * 4].view(torch.float32).copy_(torch.from_numpy(norm))
         wire_user[off + self.codes_off:off + self.codes_off + codes.size].copy_(torch.from_numpy(codes))
 
-    def _decode_rows(self, gathered, off, R, out):
+    def _decode_rows(self, gathered, off, R, out, plain=False):
         decs = []
         if self.bits == 0:
             for r in range(R):
                 vn, vs, vl = self._views(gathered[r], off)
                 decs.append(oracle.qsgd_decompress(vn.numpy(), vs.numpy(), vl.numpy().astype(np.int32), self.d, self.c.bit))
-            out.copy_(torch.from_numpy(oracle.mean_users(np.stack(decs, 0))))
+            out.copy_(torch.from_numpy(decs[0] if R == 1 else oracle.mean_users(np.stack(decs, 0))))   # one payload: the plain decompress
             return
         nb = self.numel * self.bits // 8
         for r in range(R):
@@ -84,7 +84,7 @@ class OracleQSGDCodec(QSGDCodec):
             signs = codes >> (self.bits - 1)
             levels = (codes & ((1 << (self.bits - 1)) - 1)).astype(np.int32)
             decs.append(oracle.qsgd_decompress(norm, signs, levels, self.d, self.c.bit))
-        out.copy_(torch.from_numpy(oracle.mean_users(np.stack(decs, 0))))
+        out.copy_(torch.from_numpy(decs[0] if R == 1 else oracle.mean_users(np.stack(decs, 0))))   # one payload: the plain decompress
 
 
 def oracle_codec_factory(compressor, numel, shape):

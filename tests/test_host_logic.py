@@ -219,6 +219,11 @@ def run_psq_fixture(name, factory, device="cpu", tol=1e-6):
                     continue
             rel = np.linalg.norm((got - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-30)
             assert rel <= tol, (name, st, i, rel)
+            # zeros and their signs: the parameter-server mean is a sum that starts from +0, the ring's and the
+            # two-phase result are plain decompress outputs that keep a -0
+            z = ref == 0
+            assert np.array_equal(got[z] == 0, np.ones(int(z.sum()), bool)), (name, st, i, "zeros")
+            assert np.array_equal(np.signbit(got[z]), np.signbit(ref[z])), (name, st, i, "sign of zero")
     if args.ef:
         for i, p in enumerate(params):
             for u in range(U):
