@@ -108,6 +108,30 @@ GQ_API int gq_sub(const float *grad, const float *decoded, float *err, int64_t n
     return GQ_OK;
 }
 
+// ---- mean of R rows (the aggregate of identity-compressed tensors) -------------------------------------------
+namespace gq {
+__global__ __launch_bounds__(256) void mean_rows_kernel(const uint8_t *__restrict__ rows, int64_t row_stride_bytes, int R,
+                                                        int64_t n, float *__restrict__ out) {
+    const MeanDiv md = mean_div_of(R, true);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float acc = reinterpret_cast<const float *>(rows)[i];
+        for (int r = 1; r < R; ++r) acc = acc + reinterpret_cast<const float *>(rows + (int64_t)r * row_stride_bytes)[i];
+        out[i] = mean_div(acc, md);   // (+0 + row 0 + row 1 + ...) / R, rows ascending, a true division: torch's CPU mean
+    }
+}
+}  // namespace gq
+
+GQ_API int gq_mean_rows(const void *rows, int64_t row_stride_bytes, int R, int64_t n, float *out, void *stream) {
+    if (R < 1 || n < 0 || (n > 0 && (!rows || !out)) || (row_stride_bytes & 3) != 0)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_mean_rows: bad arguments");
+    if (n == 0) return GQ_OK;
+    hipLaunchKernelGGL(gq::mean_rows_kernel, dim3(gq::grid_for(n, 256)), dim3(256), 0, gq::as_stream(stream),
+                       static_cast<const uint8_t *>(rows), row_stride_bytes, R, n, out);
+    GQ_CHECK_LAUNCH("gq_mean_rows");
+    return GQ_OK;
+}
+
 // ---- caller-supplied draws for the multi-tensor level kernels (gq_hsq_given_draws) -------------------------
 namespace gq {
 static thread_local const float *g_given_draws = nullptr;

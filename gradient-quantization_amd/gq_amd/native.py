@@ -25,7 +25,7 @@ EXPORTS = [
     "gq_hsq_encode_batched_d", "gq_hsq_decode_sum_batched_d", "gq_hsq_encode_batched_d_ef", "gq_hsq_levels_batched_ef_d",
     "gq_hsq_encode_batched_any", "gq_hsq_levels_batched_any", "gq_hsq_decode_sum_batched_any", "gq_hsq_error_batched_any",
     "gq_hsq_batched_any_supported", "gq_hsq_encode_batched_paged", "gq_qsgd_wide_compress", "gq_qsgd_wide_decode_sum",
-    "gq_profile_arm", "gq_profile_read", "gq_hsq_compress", "gq_hsq_given_draws", "gq_decode_plain_next",
+    "gq_profile_arm", "gq_profile_read", "gq_hsq_compress", "gq_hsq_given_draws", "gq_decode_plain_next", "gq_mean_rows",
     "gq_pvq_encode", "gq_pvq_encode_residual", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
     "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
 ]
@@ -260,6 +260,18 @@ def hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat
                                      _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
                                      _dev_ptr(workspace, torch.float32, "workspace"), _stream())
     _check(rc, "gq_hsq_encode_batched")
+
+
+def mean_rows(rows, out):
+    """out[i] = (+0 + rows[0, i] + ... + rows[R-1, i]) / R for a [R, n] float32 view whose rows may be strided (the dense
+    region of the gathered wire): torch.stack(...).mean(0) with the CPU's arithmetic."""
+    assert rows.dtype == torch.float32 and rows.dim() == 2 and rows.stride(1) == 1
+    R, n = int(rows.shape[0]), int(rows.shape[1])
+    stride = int(rows.stride(0)) * 4 if R > 1 else n * 4
+    if rows.device.index != torch._C._cuda_getDevice():
+        raise GQNativeError("rows are on %s but the current device is cuda:%d" % (rows.device, torch._C._cuda_getDevice()))
+    _check(lib().gq_mean_rows(ctypes.c_void_p(rows.data_ptr()), ctypes.c_int64(stride), ctypes.c_int(R), ctypes.c_int64(n),
+                              _dev_ptr(out, torch.float32, "out"), _stream()), "gq_mean_rows")
 
 
 def decode_plain_next():

@@ -58,6 +58,10 @@ class DenseCodec(object):
         rows = gathered[:, off:off + self.numel * 4].view(torch.float32)
         if plain and R == 1:
             return rows[0].clone().view(self.shape)
+        if rows.device.type == "cuda":      # torch's GPU mean multiplies by 1/R and sums in its own order
+            out = torch.empty(self.numel, dtype=torch.float32, device=rows.device)
+            native.mean_rows(rows, out)
+            return out.view(self.shape)
         return rows.mean(dim=0).view(self.shape)
 
 
@@ -83,6 +87,10 @@ class GenericCodec(object):
         rows = gathered[:, off:off + self.numel * 4].view(torch.float32)
         if plain and R == 1:
             return rows[0].clone().view(self.shape)
+        if rows.device.type == "cuda":      # torch's GPU mean multiplies by 1/R and sums in its own order
+            out = torch.empty(self.numel, dtype=torch.float32, device=rows.device)
+            native.mean_rows(rows, out)
+            return out.view(self.shape)
         return rows.mean(dim=0).view(self.shape)
 
 
@@ -917,6 +925,8 @@ class PSQuantizer(object):
                 self._dense_mean[k], self._dense_views[k] = mean, views
             if plain and R == 1:
                 self._dense_mean[k].copy_(rows[0])      # the ring's hop: the payload as it is (a -0 stays -0)
+            elif rows.device.type == "cuda":
+                native.mean_rows(rows, self._dense_mean[k])     # stack().mean(0) with the CPU's arithmetic (true division)
             else:
                 torch.mean(rows, dim=0, out=self._dense_mean[k])   # stack().mean(0) of the reference, all at once
             for i, v in zip(self.dense_idx, self._dense_views[k]):

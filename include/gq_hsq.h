@@ -264,6 +264,14 @@ int gq_axpy_inplace(float *grad, const float *err, float scale, int64_t n, void 
 int gq_sub(const float *grad, const float *decoded, float *err, int64_t n, void *stream);
 
 /*
+ * The aggregate of tensors that travel uncompressed (IdenticalCompressor, ps_quantizer.py:18,48): out[i] =
+ * (+0 + rows_0[i] + ... + rows_{R-1}[i]) / R, rows ascending, a true division -- the arithmetic of torch.stack(...).mean(0)
+ * on the CPU.  (torch's GPU mean multiplies by 1/R and sums in another order: last-bit differences for R = 3, 5, 6, 7.)
+ * rows_r = (const float *)((const char *)rows + r * row_stride_bytes).
+ */
+int gq_mean_rows(const void *rows, int64_t row_stride_bytes, int R, int64_t n, float *out, void *stream);
+
+/*
  * QSGD compress -- replaces qsgd_compressor.py:47-64.  `grad` is Mb buckets of d floats.
  *     norm[b]  = max_j |v_j| ;  x = |v/norm| * 2^n_bit ;  l = trunc(clamp(x, 0, 2^n_bit-1))
  *     l += (x - l > r)  if random_mode ;  signs = v > 0
