@@ -13,7 +13,13 @@ from gq_amd.quantizers import DenseCodec, GenericCodec, HSQCodec, QSGDCodec
 class OracleHSQCodec(HSQCodec):
     def encode_into(self, grad, wire_user, off, salt, r=None):
         c = self.c
-        assert c.compressed_norm
+        cb = c.codewords.cpu().numpy()
+        if not c.compressed_norm:       # n_bit == 32: the projections travel as float32 (nearest_neighbor_compressor.py:75-78)
+            codes_, u_ = oracle.hsq_encode(grad.detach().cpu().numpy().reshape(-1), cb)
+            codes, norms, _ = self._views(wire_user, off)
+            codes.copy_(torch.from_numpy(codes_.astype(np.uint8 if self.code_dtype == torch.uint8 else np.int32)))
+            norms.copy_(torch.from_numpy(u_))
+            return
         random = bool(c.norm_compressor.random)
         if random:      # reference-parity draws only: handed in by the quantizer, or drawn here as the reference does
             assert c.norm_compressor._rng == "reference", "oracle codec: deterministic levels or the reference's draws"
@@ -31,6 +37,9 @@ class OracleHSQCodec(HSQCodec):
         decs = []
         for r in range(R):
             codes, levels, lb_ub = self._views(gathered[r], off)
+            if not c.compressed_norm:
+                decs.append(oracle.hsq_decode(codes.numpy().astype(np.int32), levels.numpy(), cb))
+                continue
             decs.append(oracle.hsq_decompress(codes.numpy().astype(np.int32), levels.numpy().astype(np.int32),
                                               np.float32(lb_ub[0].item()), np.float32(lb_ub[1].item()), cb, c.n_bit))
         out.copy_(torch.from_numpy(decs[0] if R == 1 else oracle.mean_users(np.stack(decs, 0))))   # one payload: the plain decompress

@@ -181,6 +181,16 @@ def _psq_args(name, users):
         kw["scale"] = "0.5"
     if "qsgd" in name:
         kw.update(c_dim=128, n_bit=2)
+    if "terngrad" in name:
+        kw.update(c_dim=0, n_bit=1)
+    if "_d32" in name:
+        kw.update(c_dim=32, n_bit=8)
+    if "_d8" in name:
+        kw.update(c_dim=8)
+    if "_d12_k9" in name:
+        kw.update(c_dim=12, k_bit=9)
+    if "_n32" in name:
+        kw.update(n_bit=32)
     if name.startswith("ring_"):
         kw["mode"] = "ring"
     if "_rand" in name:      # the reference's stochastic rounding with its own CPU draws
@@ -196,7 +206,7 @@ def run_psq_fixture(name, factory, device="cpu", tol=1e-6):
     args = _psq_args(name, U)
     shapes = [g["grad_s0_u0_p%d" % i].shape for i in range(P)]
     params = [torch.nn.Parameter(torch.zeros(*s, device=device)) for s in shapes]
-    q = Quantizer(QSGDCompressor if "qsgd" in name else NearestNeighborCompressor, params, args,
+    q = Quantizer(QSGDCompressor if ("qsgd" in name or "terngrad" in name) else NearestNeighborCompressor, params, args,
                   codec_factory=factory)
     if "seed_r" in g.files:
         torch.manual_seed(int(g["seed_r"]))
