@@ -181,6 +181,12 @@ def _psq_args(name, users):
         kw["scale"] = "0.5"
     if "qsgd" in name:
         kw.update(c_dim=128, n_bit=2)
+    if "qsgd_n4" in name:
+        kw.update(n_bit=4)
+    if "qsgd_n8" in name:
+        kw.update(c_dim=64, n_bit=8)
+    if "_k5" in name:
+        kw.update(k_bit=5)
     if "terngrad" in name:
         kw.update(c_dim=0, n_bit=1)
     if "_d32" in name:
