@@ -65,6 +65,37 @@ def test_hsq_compress_matches_reference(oracle, name):
     assert _same(dec, g["decoded"]), "decoded tensor differs bitwise"
 
 
+HSQD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "hsqd_*.npz")))
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", HSQD)
+def test_hsq_compress_at_baseline_size_matches_reference_digests(oracle, name):
+    """BASELINE configs[1] (25 M float32, c_dim 16 / k_bit 8 / n_bit 6): the oracle's codes, levels, (lb, ub) and decoded
+    tensor hash to the digests of the reference's own output (tests/golden/make_golden.py: hsq_digest_case)."""
+    import torch
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    x = (np.random.RandomState(int(g["seed"])).standard_normal(int(g["n"])) * float(g["scale_in"])).astype(np.float32)
+    assert _sha(x) == str(g["x_sha"])
+    d, K, n_bit, random = int(g["dim"]), int(g["K"]), int(g["n_bit"]), int(g["random"])
+    cb = _cb(d, K)
+    r = None
+    if random:
+        torch.manual_seed(int(g["seed_r"]))
+        r = torch.rand(x.size // d).numpy()
+    res = oracle.hsq_compress(x, cb, n_bit, random, r)
+    assert np.array_equal(res["codes"][:64], g["codes_head"])
+    assert _sha(res["codes"].astype(np.uint8)) == str(g["codes_sha"])
+    assert _sha(res["levels"].astype(np.int32)) == str(g["levels_sha"])
+    assert _same(np.array([res["lb"], res["ub"]], np.float32), g["lbub"])
+    dec = oracle.hsq_decompress(res["codes"], res["levels"], res["lb"], res["ub"], cb, n_bit)
+    assert _sha(dec) == str(g["decoded_sha"])
+
+
 def test_hsq_level_range_quirk():
     """random=1 lets the top element reach level 2^n_bit."""
     g = np.load(os.path.join(GOLDEN, "hsq_randn_s1_rand.npz"))
