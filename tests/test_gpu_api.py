@@ -878,6 +878,35 @@ def test_probabilistic_vector_compressor_matches_reference(name):
     assert np.array_equal(_bits(comp.decompress(sig).cpu().numpy()), _bits(g["decoded"]))
 
 
+PVQD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "pvqd_*.npz")))
+
+
+@pytest.mark.parametrize("name", PVQD)
+def test_probabilistic_vector_compressor_at_size_matches_reference_digests(name):
+    """a12 on 4 M elements through the MFMA kernel (shared-divisor quotient, double threshold: pvq.hip): codes, magnitudes /
+    levels, (lb, ub) and the decode hash to the digests of the reference's own output."""
+    import hashlib
+    from gq_amd.compressors import ProbabilisticVectorCompressor
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    x = (np.random.RandomState(int(g["seed"])).standard_normal(int(g["n"])) * float(g["scale_in"])).astype(np.float32)
+    assert sha(x) == str(g["x_sha"])
+    d, K, n_bit = int(g["dim"]), int(g["K"]), int(g["n_bit"])
+    comp = ProbabilisticVectorCompressor(x.size, x.shape, make_args(c_dim=d, k_bit=int(np.log2(K)), n_bit=n_bit, random=0,
+                                                                    gq_rng="reference"))
+    _inject(comp, g["codewords"], g["c_dagger"])
+    torch.manual_seed(int(g["seed_r"]))
+    norms, codes = comp.compress(torch.from_numpy(x).cuda())
+    assert sha(codes.cpu().numpy().astype(np.int32)) == str(g["codes_sha"])
+    if n_bit == 32:
+        assert sha(norms.cpu().numpy()) == str(g["u_sha"])
+    else:
+        lb, ub, l = norms
+        assert sha(l.cpu().numpy().astype(np.int32)) == str(g["levels_sha"])
+        assert _same(np.array([lb.item(), ub.item()], np.float32), g["lbub"])
+    assert sha(comp.decompress([norms, codes]).cpu().numpy()) == str(g["decoded_sha"])
+
+
 @pytest.mark.parametrize("name", RESIDUAL_CASES)
 def test_residual_compressor_matches_reference(name):
     """a11 against the reference's own output (tests/golden/residual_*.npz): both stage signatures and the summed

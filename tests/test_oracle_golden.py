@@ -273,6 +273,31 @@ def test_pvq_matches_reference(oracle, name):
     assert np.array_equal(_bits(oracle.pvq_decompress(sig, g["codewords"], n_bit)), _bits(g["decoded"].reshape(-1)))
 
 
+PVQD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "pvqd_*.npz")))
+
+
+@pytest.mark.parametrize("name", PVQD)
+def test_pvq_at_size_matches_reference_digests(oracle, name):
+    """ProbabilisticVectorCompressor on 4 M elements (250,000 inverse-CDF walks of 256 terms): the oracle's codes,
+    magnitudes / levels and decode hash to the digests of the reference's own output."""
+    import torch
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    x = (np.random.RandomState(int(g["seed"])).standard_normal(int(g["n"])) * float(g["scale_in"])).astype(np.float32)
+    assert _sha(x) == str(g["x_sha"])
+    d, n_bit = int(g["dim"]), int(g["n_bit"])
+    torch.manual_seed(int(g["seed_r"]))
+    r = torch.rand(x.size // d).numpy()
+    sig = oracle.pvq_compress(x, g["c_dagger"], r, n_bit)
+    assert np.array_equal(sig["codes"][:64], g["codes_head"])
+    assert _sha(sig["codes"].astype(np.int32)) == str(g["codes_sha"])
+    if n_bit == 32:
+        assert _sha(sig["u"]) == str(g["u_sha"])
+    else:
+        assert _sha(sig["levels"].astype(np.int32)) == str(g["levels_sha"])
+        assert _same(np.array([sig["lb"], sig["ub"]], np.float32), g["lbub"])
+    assert _sha(oracle.pvq_decompress(sig, g["codewords"], n_bit)) == str(g["decoded_sha"])
+
+
 @pytest.mark.parametrize("name", RESIDUAL_CASES)
 def test_residual_compressor_matches_reference(oracle, name):
     """ResidualCompressor.compress / decompress of the reference (same generator): both stage signatures, the stage
