@@ -927,6 +927,34 @@ def test_residual_compressor_matches_reference(name):
     assert np.array_equal(_bits(comp.decompress(sigs).cpu().numpy()), _bits(g["decoded"]))
 
 
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "residuald_*.npz"))))
+def test_residual_compressor_at_size_matches_reference_digests(name):
+    """a11 on 4 M elements: stage 1 (prefilter encode), stage 2 on `grad - decode(stage 1)` inside the kernel
+    (gq_pvq_encode_residual) and the summed decode hash to the digests of the reference's own output."""
+    import hashlib
+    from gq_amd.compressors import ResidualCompressor
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    x = (np.random.RandomState(int(g["seed"])).standard_normal(int(g["n"])) * float(g["scale_in"])).astype(np.float32)
+    assert sha(x) == str(g["x_sha"])
+    d, K, n_bit = int(g["dim"]), int(g["K"]), int(g["n_bit"])
+    np.random.seed(0)
+    comp = ResidualCompressor(x.size, x.shape, make_args(c_dim=d, k_bit=int(np.log2(K)), n_bit=n_bit, random=0, gq_rng="reference"))
+    _inject(comp.compressors[0], g["codewords1"], None)
+    _inject(comp.compressors[1], g["codewords2"], g["c_dagger"])
+    torch.manual_seed(int(g["seed_r"]))
+    sigs = comp.compress(torch.from_numpy(x).cuda())
+    for k, (norms, codes) in enumerate(sigs, 1):
+        assert sha(codes.cpu().numpy().astype(np.int32)) == str(g["s%d_codes_sha" % k]), k
+        if n_bit == 32:
+            assert sha(norms.cpu().numpy()) == str(g["s%d_u_sha" % k]), k
+        else:
+            lb, ub, l = norms
+            assert sha(l.cpu().numpy().astype(np.int32)) == str(g["s%d_levels_sha" % k]), k
+            assert _same(np.array([lb.item(), ub.item()], np.float32), g["s%d_lbub" % k]), k
+    assert sha(comp.decompress(sigs).cpu().numpy()) == str(g["decoded_sha"])
+
+
 def test_residual_compressor_two_stages():
     """a11: stage 1 (nearest neighbour) + stage 2 (probabilistic vector) on the residual."""
     from gq_amd.compressors import ResidualCompressor, NearestNeighborCompressor
