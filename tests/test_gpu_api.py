@@ -190,21 +190,23 @@ HSQD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "
 
 @pytest.mark.parametrize("name", HSQD)
 def test_compressor_at_baseline_size_matches_reference_digests(name):
-    """BASELINE configs[1] through the compressor class on the GPU: 25 M float32, c_dim 16 / k_bit 8 / n_bit 6, one of the
-    two with the reference's stochastic rounding draws -- codes, levels, (lb, ub) and the decompressed tensor hash to the
-    digests of the reference's own output."""
+    """BASELINE configs[1] through the compressor class on the GPU: 25 M float32, c_dim 16 / k_bit 8 / n_bit 6 (with and
+    without the reference's stochastic rounding draws), and K = 1024 / 4096 on 4 M / 2 M elements (the fused paged
+    prefilter) -- codes, levels, (lb, ub) and the decompressed tensor hash to the digests of the reference's own output."""
     import hashlib
     from gq_amd.compressors import NearestNeighborCompressor
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     x = (np.random.RandomState(int(g["seed"])).standard_normal(int(g["n"])) * float(g["scale_in"])).astype(np.float32)
     assert sha(x) == str(g["x_sha"])
-    comp = NearestNeighborCompressor(x.size, x.shape, make_args(n_bit=int(g["n_bit"]), random=int(g["random"]), gq_rng="reference"))
+    K = int(g["K"])
+    comp = NearestNeighborCompressor(x.size, x.shape, make_args(n_bit=int(g["n_bit"]), random=int(g["random"]), gq_rng="reference",
+                                                                k_bit=int(np.log2(K))))
     if "seed_r" in g.files:
         torch.manual_seed(int(g["seed_r"]))
     (lb, ub, l), codes = comp.compress(torch.from_numpy(x).cuda())
     dec = comp.decompress([(lb, ub, l), codes])
-    assert sha(codes.cpu().numpy().astype(np.uint8)) == str(g["codes_sha"])
+    assert sha(codes.cpu().numpy().astype(np.uint8 if K <= 256 else np.int32)) == str(g["codes_sha"])
     assert sha(l.cpu().numpy().astype(np.int32)) == str(g["levels_sha"])
     assert _same(np.array([lb.item(), ub.item()], np.float32), g["lbub"])
     assert sha(dec.cpu().numpy()) == str(g["decoded_sha"])
