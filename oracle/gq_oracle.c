@@ -32,7 +32,20 @@
 
 #define GQ_EXPORT __attribute__((visibility("default")))
 
+/* A thread that has run AVX / AVX-512 code without a closing vzeroupper keeps the upper halves of its vector registers
+ * dirty, and every legacy-SSE instruction it executes afterwards (this file's scalar loops are built for baseline x86-64)
+ * pays a merge with that state.  torch's CPU kernels do leave such threads behind, and they share the OpenMP pool with this
+ * library: measured after one strided torch.mean, ONE worker of the team ran its share 60x slower (6.9 s against 0.12 s for
+ * the same slice), the parallel region waited for it, and a pytest run of the whole CPU suite took 11 minutes instead of 3.
+ * Every exported function and every thread of every parallel region therefore starts with vzeroupper. */
+static inline void gq_clean_vector_state(void) {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx")) __asm__ volatile("vzeroupper" ::: "memory");
+#endif
+}
+
 GQ_EXPORT int gq_oracle_num_threads(void) {
+    gq_clean_vector_state();
 #ifdef _OPENMP
     return omp_get_max_threads();
 #else
@@ -41,6 +54,7 @@ GQ_EXPORT int gq_oracle_num_threads(void) {
 }
 
 GQ_EXPORT void gq_oracle_set_num_threads(int n) {
+    gq_clean_vector_state();
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);
 #else
@@ -58,7 +72,11 @@ GQ_EXPORT void gq_oracle_set_num_threads(int n) {
  */
 GQ_EXPORT void gq_oracle_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, int K,
                                     int32_t *codes, float *u) {
-#pragma omp parallel for schedule(static)
+    gq_clean_vector_state();
+#pragma omp parallel
+    {
+        gq_clean_vector_state();   /* per thread: see the comment at its definition */
+#pragma omp for schedule(static)
     for (int64_t m = 0; m < M; ++m) {
         const float *v = grad + m * (int64_t)d;
         float best_abs = -1.0f, best_p = 0.0f;
@@ -78,11 +96,13 @@ GQ_EXPORT void gq_oracle_hsq_encode(const float *grad, const float *codebook, in
         codes[m] = best_k;
         u[m] = best_p;
     }
+    }
 }
 
 /* torch.min / torch.max over the whole tensor
  * (compressors/probabilistic_scalar_compressor.py:13-14).  lb_ub[0]=min, [1]=max. */
 GQ_EXPORT void gq_oracle_minmax(const float *u, int64_t M, float *lb_ub) {
+    gq_clean_vector_state();
     float lo = INFINITY, hi = -INFINITY;
     int has_nan = 0;
     for (int64_t i = 0; i < M; ++i) {
@@ -107,13 +127,17 @@ GQ_EXPORT void gq_oracle_minmax(const float *u, int64_t M, float *lb_ub) {
  */
 GQ_EXPORT void gq_oracle_scalar_levels(const float *u, int64_t M, int n_bit, int random, const float *r,
                                        float lb, float ub, int32_t *levels) {
+    gq_clean_vector_state();
     const float s = (float)(1 << n_bit);
     if (lb - ub == 0.0f) {
         memset(levels, 0, (size_t)M * sizeof(int32_t));
         return;
     }
     const float range = ub - lb;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel
+    {
+        gq_clean_vector_state();   /* per thread: see the comment at its definition */
+#pragma omp for schedule(static)
     for (int64_t i = 0; i < M; ++i) {
         float q = (u[i] - lb) / range;
         float x = fabsf(q) * s;
@@ -125,12 +149,14 @@ GQ_EXPORT void gq_oracle_scalar_levels(const float *u, int64_t M, int n_bit, int
         }
         levels[i] = l;
     }
+    }
 }
 
 /* Scalar de-quantiser, probabilistic_scalar_compressor.py:29-33:
  *   n = float(l) * (ub - lb) / s + lb      -- mul, then /s, then add; nothing fused */
 GQ_EXPORT void gq_oracle_scalar_decode(const int32_t *levels, int64_t M, int n_bit, float lb, float ub,
                                        float *norms) {
+    gq_clean_vector_state();
     const float s = (float)(1 << n_bit);
     const float range = ub - lb;
     for (int64_t i = 0; i < M; ++i) {
@@ -144,12 +170,17 @@ GQ_EXPORT void gq_oracle_scalar_decode(const int32_t *levels, int64_t M, int n_b
  *   out[m,:] = codewords[codes[m],:] * norms[m] */
 GQ_EXPORT void gq_oracle_hsq_decode(const int32_t *codes, const float *norms, const float *codebook, int64_t M,
                                     int d, float *out) {
-#pragma omp parallel for schedule(static)
+    gq_clean_vector_state();
+#pragma omp parallel
+    {
+        gq_clean_vector_state();   /* per thread: see the comment at its definition */
+#pragma omp for schedule(static)
     for (int64_t m = 0; m < M; ++m) {
         const float *c = codebook + (int64_t)codes[m] * d;
         const float n = norms[m];
         float *o = out + m * (int64_t)d;
         for (int j = 0; j < d; ++j) o[j] = c[j] * n;
+    }
     }
 }
 
@@ -160,6 +191,7 @@ GQ_EXPORT void gq_oracle_hsq_decode(const int32_t *codes, const float *norms, co
 GQ_EXPORT void gq_oracle_hsq_compress(const float *grad, const float *codebook, int64_t M, int d, int K, int n_bit,
                                       int random, const float *r, int32_t *codes, float *u, float *lb_ub,
                                       int32_t *levels) {
+    gq_clean_vector_state();
     gq_oracle_hsq_encode(grad, codebook, M, d, K, codes, u);
     gq_oracle_minmax(u, M, lb_ub);
     gq_oracle_scalar_levels(u, M, n_bit, random, r, lb_ub[0], lb_ub[1], levels);
@@ -171,6 +203,7 @@ GQ_EXPORT void gq_oracle_hsq_compress(const float *grad, const float *codebook, 
  * decoded: [U][n] contiguous.  Sum in user order, then divide by U.
  */
 GQ_EXPORT void gq_oracle_mean_users(const float *decoded, int U, int64_t n, float *out) {
+    gq_clean_vector_state();
     for (int64_t i = 0; i < n; ++i) {
         float acc = 0.0f + decoded[i];   /* torch's sum starts from +0: an all -0 column comes out as +0 */
         for (int k = 1; k < U; ++k) acc += decoded[(int64_t)k * n + i];
@@ -191,8 +224,12 @@ GQ_EXPORT void gq_oracle_mean_users(const float *decoded, int U, int64_t n, floa
  */
 GQ_EXPORT void gq_oracle_qsgd_compress(const float *grad, int64_t Mb, int d, int n_bit, int random, const float *r,
                                        float *norm, uint8_t *signs, int32_t *levels) {
+    gq_clean_vector_state();
     const float s = (float)(1 << n_bit);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel
+    {
+        gq_clean_vector_state();   /* per thread: see the comment at its definition */
+#pragma omp for schedule(static)
     for (int64_t b = 0; b < Mb; ++b) {
         const float *v = grad + b * (int64_t)d;
         float mx = 0.0f;
@@ -218,12 +255,14 @@ GQ_EXPORT void gq_oracle_qsgd_compress(const float *grad, int64_t Mb, int d, int
             signs[i] = v[j] > 0.0f ? 1 : 0;
         }
     }
+    }
 }
 
 /* QSGD decompress, qsgd_compressor.py:66-71:
  *   out = (float(l) * (2*signs - 1)) * norm / s */
 GQ_EXPORT void gq_oracle_qsgd_decompress(const float *norm, const uint8_t *signs, const int32_t *levels, int64_t Mb,
                                          int d, int n_bit, float *out) {
+    gq_clean_vector_state();
     const float s = (float)(1 << n_bit);
     for (int64_t b = 0; b < Mb; ++b) {
         for (int j = 0; j < d; ++j) {
@@ -256,7 +295,11 @@ GQ_EXPORT void gq_oracle_qsgd_decompress(const float *norm, const uint8_t *signs
 GQ_EXPORT void gq_oracle_pvq_encode_ex(const float *grad, const float *cdag, int64_t M, int d, int K, const float *r,
                                        int32_t *codes, float *u, float *l1_out, float *p_out, float *cum_out,
                                        int64_t cum_rows) {
-#pragma omp parallel for schedule(static)
+    gq_clean_vector_state();
+#pragma omp parallel
+    {
+        gq_clean_vector_state();   /* per thread: see the comment at its definition */
+#pragma omp for schedule(static)
     for (int64_t m = 0; m < M; ++m) {
         const float *v = grad + m * (int64_t)d;
         float l1 = 0.0f;
@@ -288,9 +331,11 @@ GQ_EXPORT void gq_oracle_pvq_encode_ex(const float *grad, const float *cdag, int
         codes[m] = code;
         u[m] = (sel > 0.0f ? 1.0f : (sel < 0.0f ? -1.0f : 0.0f)) * l1;
     }
+    }
 }
 
 GQ_EXPORT void gq_oracle_pvq_encode(const float *grad, const float *cdag, int64_t M, int d, int K, const float *r,
                                     int32_t *codes, float *u) {
+    gq_clean_vector_state();
     gq_oracle_pvq_encode_ex(grad, cdag, M, d, K, r, codes, u, 0, 0, 0, 0);
 }
