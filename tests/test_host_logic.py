@@ -212,7 +212,10 @@ def run_psq_fixture(name, factory, device="cpu", tol=1e-6):
     args = _psq_args(name, U)
     shapes = [g["grad_s0_u0_p%d" % i].shape for i in range(P)]
     params = [torch.nn.Parameter(torch.zeros(*s, device=device)) for s in shapes]
-    q = Quantizer(QSGDCompressor if ("qsgd" in name or "terngrad" in name) else NearestNeighborCompressor, params, args,
+    from gq_amd.compressors import IdenticalCompressor
+    comp = IdenticalCompressor if name.endswith("_sgd") else (QSGDCompressor if ("qsgd" in name or "terngrad" in name)
+                                                              else NearestNeighborCompressor)
+    q = Quantizer(comp, params, args,
                   codec_factory=factory)
     if "seed_r" in g.files:
         torch.manual_seed(int(g["seed_r"]))
