@@ -558,11 +558,11 @@ GQ_API int gq_hsq_levels_batched_ef(const int64_t *seg_table, const int32_t *til
 GQ_API int gq_hsq_decode_sum_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                      const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                      const float *codebook, int n_bit, float *out, void *stream) {
+    const int plain = gq::take_decode_plain() ? 1 : 0;   // consumed even when the call is refused below
     if (nseg < 1 || ntiles < 1 || R < 1 || n_bit < 1 || n_bit > 8)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: bad sizes");
     if (!seg_table || !tile_seg || !gathered || !codebook || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: null pointer");
-    const int plain = gq::take_decode_plain() ? 1 : 0;
     if ((user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0) {
         static const int bpc = [] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gq::hsq_decode_sum_batched4_kernel),
@@ -594,11 +594,11 @@ GQ_API int gq_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *
     if (d == 16)
         return gq_hsq_decode_sum_batched(seg_table, tile_seg, nseg, ntiles, gathered, user_stride_bytes, R, codebook,
                                          n_bit, out, stream);
+    const int plain = gq::take_decode_plain() ? 1 : 0;   // consumed even when the call is refused below
     if (nseg < 1 || ntiles < 1 || R < 1 || n_bit < 1 || n_bit > 8)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched_d: bad sizes");
     if (!seg_table || !tile_seg || !gathered || !codebook || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched_d: null pointer");
-    const int plain = gq::take_decode_plain() ? 1 : 0;
     if (d == 8) {
         hipLaunchKernelGGL(gq::hsq_decode_sum_batched_d_kernel<8>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 2)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,

@@ -443,11 +443,11 @@ GQ_API int gq_qsgd_compress_batched_ef(const int64_t *seg_table, const int32_t *
 GQ_API int gq_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
                                       int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                       float *out, void *stream) {
+    const int plain = gq::take_decode_plain() ? 1 : 0;   // consumed even when the call is refused below
     if (nseg < 1 || nbuckets < 1 || n_bit < 1 || R < 1 || (bits != 4 && bits != 8 && bits != 16))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: bad sizes");
     if (!seg_table || !bucket_seg || !gathered || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: null pointer");
-    const int plain = gq::take_decode_plain() ? 1 : 0;
     if (bits == 4 && (user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
         hipLaunchKernelGGL(gq::qsgd_decode_sum_batched4_kernel, dim3((unsigned)gq::qb_grid((nbuckets + 3) / 4)),

@@ -354,6 +354,7 @@ GQ_API int gq_qsgd_wide_compress(const int64_t *seg_table, const int32_t *chunk_
 GQ_API int gq_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks,
                                    int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                    float *out, void *stream) {
+    const int plain = gq::take_decode_plain() ? 1 : 0;   // consumed even when the call is refused below
     if (nseg < 1 || nchunks < 1 || n_bit < 1 || R < 1 || (bits != 4 && bits != 8 && bits != 16))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_wide_decode_sum: bad sizes");
     if (!seg_table || !chunk_seg || !gathered || !out)
@@ -361,7 +362,6 @@ GQ_API int gq_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chun
     if ((user_stride_bytes & 3) != 0 || (reinterpret_cast<uintptr_t>(gathered) & 3) != 0 ||
         (reinterpret_cast<uintptr_t>(out) & 15) != 0)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_wide_decode_sum: wires must be 4-byte, out 16-byte aligned");
-    const int plain = gq::take_decode_plain() ? 1 : 0;
     const dim3 grid((unsigned)gq::qw_grid(nchunks)), block(gq::QW_THREADS);
     if (bits == 4)
         hipLaunchKernelGGL(gq::qsgd_wide_decode_kernel<4>, grid, block, 0, gq::as_stream(stream), seg_table, chunk_seg,
