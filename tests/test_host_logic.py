@@ -283,11 +283,16 @@ def run_psq_digest_fixture(name, factory, device, signature_of):
     grads = []
     if "seed_r" in g.files:      # args.random: the reference seeded the CPU generator right before the first record
         torch.manual_seed(int(g["seed_r"]))
-    for u in range(users):
-        grads.append([(rng.standard_normal(sh) * scale).astype(np.float32) for sh in shapes])
-        for p, x in zip(params, grads[u]):
-            p.grad = torch.from_numpy(x.copy()).to(device)
-        q.record(u, epoch=1)
+    steps = int(g["steps"]) if "steps" in g.files else 1
+    for st in range(steps):
+        grads = []
+        for u in range(users):
+            grads.append([(rng.standard_normal(sh) * scale).astype(np.float32) for sh in shapes])
+            for p, x in zip(params, grads[u]):
+                p.grad = torch.from_numpy(x.copy()).to(device)
+            q.record(u, epoch=st + 1)
+        if st + 1 < steps:
+            q.apply()
     k = 0
     for u in range(users):
         for i, sh in enumerate(shapes):
@@ -304,6 +309,12 @@ def run_psq_digest_fixture(name, factory, device, signature_of):
     q.apply()
     for i, p in enumerate(params):
         assert _sha(p.grad.data.cpu().numpy()) == str(g["agg_sha"][i]), (name, "aggregate", i, tuple(p.shape))
+    if "err_sha" in g.files:      # error feedback: the users' residual buffers after the last step
+        k = 0
+        for i, p in enumerate(params):
+            for u in range(users):
+                assert _sha(p.error[u].cpu().numpy()) == str(g["err_sha"][k]), (name, "error", i, u)
+                k += 1
     return q
 
 
