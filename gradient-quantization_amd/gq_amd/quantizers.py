@@ -259,9 +259,7 @@ class QSGDCodec(object):
             rows = gathered[:, off:off + self.nbytes]
             if not rows.is_contiguous():
                 rows = rows.contiguous()
-            if plain:
-                native.decode_plain_next()
-            out.copy_(self._batched1(gathered.device).decode_mean(rows, R)[0].view(-1))
+            out.copy_(self._batched1(gathered.device).decode_mean(rows, R, plain=plain)[0].view(-1))
             return
         # the plain entry point takes dense [R][...] arrays: gather the three sections
         lb = torch.empty(0, dtype=self.level_dtype).element_size()
@@ -383,18 +381,24 @@ class _BatchedBase(object):
             self._tail = (first_seg, first_item, tab.view(-1).to(self.device), items)
         return self._tail[2], self._tail[3], self.nseg - first_seg, self._nitems - first_item
 
-    def decode_mean(self, gathered, R, part=None, first_seg=0):
+    def decode_mean(self, gathered, R, part=None, first_seg=0, plain=False):
         """Mean of the R payloads of `gathered` for every tensor of the group (views of one output buffer).
         part = "head" / "tail": only the tensors before / from segment `first_seg` (the two halves of a split
-        exchange land in the same buffer: "head" first, then "tail")."""
+        exchange land in the same buffer: "head" first, then "tail").  plain: the decompress of ONE payload as the
+        reference returns it (a -0 stays -0) instead of the aggregate -- the flag is raised right before the launch
+        that consumes it."""
         if not self.ready:      # a rank that decodes before it has encoded anything (ring hop, late joiner)
             self.upload_layout()
         out, views = self._out_buffer(gathered.device, advance=part != "tail")
         if part is None:
+            if plain:
+                native.decode_plain_next()
             self._launch_decode(self._dev[:self._table_words], self._item_seg, self.nseg, self._nitems, gathered, R, out)
         else:
             tabs = self._part(part, first_seg)
             if tabs is not None:
+                if plain:
+                    native.decode_plain_next()
                 self._launch_decode(tabs[0], tabs[1], tabs[2], tabs[3], gathered, R, out)
         return views
 
@@ -415,8 +419,7 @@ class _BatchedBase(object):
             self._tmp_wire = torch.zeros((1, self.user_bytes), dtype=torch.uint8, device=self.device)
         if not self.encode(tensors, self._tmp_wire[0], slot, salt, errs, ef_scale, draws=draws):
             return None
-        native.decode_plain_next()      # decompress(compress(t)) (ps_quantizer.py:52-61): the plain decode, a -0 stays -0
-        return self.decode_mean(self._tmp_wire, 1)
+        return self.decode_mean(self._tmp_wire, 1, plain=True)     # decompress(compress(t)) (ps_quantizer.py:52-61): a -0 stays -0
 
 
 class BatchedHSQ(_BatchedBase):
@@ -880,9 +883,7 @@ class PSQuantizer(object):
 
         def decode_part(part):
             for gi, (cls, idxs, obj) in enumerate(groups):
-                if plain:
-                    native.decode_plain_next()      # consumed by the launch inside decode_mean
-                group_views[gi] = obj.decode_mean(gathered, R, part if split else None, firsts[gi] if split else 0)
+                group_views[gi] = obj.decode_mean(gathered, R, part if split else None, firsts[gi] if split else 0, plain=plain)
             for i in single:
                 if split and (self.offsets[i] < self.cut) != (part == "head"):
                     continue
