@@ -110,18 +110,6 @@ __global__ __launch_bounds__(PV_THREADS) void pvq_encode_kernel(const float *__r
 // threshold (the sums never decrease, so "first k with cum >= thr" == that count; NaN -- an all-zero
 // subvector -- counts every term and lands on K-1 like the oracle); the selected projection is recomputed as
 // one explicit fmaf chain.  Padded codewords (K not a multiple of 32) score +0 and change neither sum.
-// a / b for many a and ONE b, correctly rounded, in three operations: y = RN(1/b) is computed once (a true division);
-// q0 = RN(a y) is within an ulp of the quotient, r = a - q0 b is exact in one fma, RN(q0 + r y) is the correctly
-// rounded quotient (Markstein's correction step).  Valid while nothing on the way is subnormal: the caller checks
-// 2^-80 <= b <= 2^20 and 2^-102 <= a <= b (then a/b >= 2^-122, and r, a multiple of 2^-47 ulp-units of a, is
-// representable); a == 0 would be fine too but is not worth a test.  Checked against `a / b` on 5.9e9 (a, b) pairs
-// on the CPU (every mantissa of b; b with the 16 highest mantissas against every mantissa of a) and on the GPU by
-// the kernel-vs-oracle tests.  b == 0 with a == 0 gives 0 * inf = NaN like 0 / 0.
-__device__ __forceinline__ float shared_quotient(float a, float b, float y) {
-    const float q0 = __fmul_rn(a, y);
-    const float r = __fmaf_rn(-q0, b, a);
-    return __fmaf_rn(r, y, q0);
-}
 
 // The double T with  (float)x >= thr  <=>  x >= T  for every double x (round to nearest even): the midpoint between
 // thr and the float below it when the tie goes to thr (even mantissa), the next double above the midpoint otherwise.

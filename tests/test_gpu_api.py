@@ -696,6 +696,46 @@ def test_batched_packed_qsgd_equals_per_tensor_and_reference_arithmetic(kw, orac
         assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n_bit", [2, 4, 7])
+def test_qsgd_extreme_bucket_scales_match_the_oracle(n_bit, oracle):
+    """The packed QSGD compress on bucket scales from 1e-38 (subnormal elements) to 1e30, elements 30 orders of magnitude
+    below their bucket's norm, zero and single-spike buckets, NaN / inf buckets: levels, signs and norms equal the
+    oracle's (the reference's `v / norm`).  (A three-operation shared-divisor quotient like pvq.hip's was tried here: the
+    per-element domain check it needs costs what it saves, 34 us either way.)"""
+    from gq_amd.compressors import QSGDCompressor
+    from gq_amd.quantizers import QSGDCodec
+    rng = np.random.RandomState(n_bit)
+    B, d = 4096, 128
+    x = rng.standard_normal((B, d)).astype(np.float32)
+    scale = (np.float32(10.0) ** rng.randint(-38, 31, size=B)).astype(np.float32)
+    scale[:1024] = np.float32(1e-3)                                   # plain waves: every lane on the quick path
+    x *= scale[:, None]
+    tiny = rng.randint(0, B, size=600)
+    x[tiny, 3:40] *= np.float32(1e-35)                                 # elements far below the bucket's norm (some underflow)
+    x[7] = 0.0
+    x[9, 1:] = 0.0                                                     # one spike, the rest exact zeros
+    x[11, 5] = np.float32("nan")
+    x[13, 6] = np.float32("inf")
+    x[15] = np.float32(1e-45)                                          # a bucket of the smallest subnormal
+    xt = torch.from_numpy(x).cuda()
+    codec = QSGDCodec(QSGDCompressor(x.size, x.shape, make_args(c_dim=d, n_bit=n_bit, random=0)), x.size, x.shape)
+    assert codec.bits in (4, 8)
+    wire = torch.zeros(codec.nbytes, dtype=torch.uint8, device="cuda")
+    codec.encode_into(xt, wire, 0, 0)
+    norm, signs, levels = oracle.qsgd_compress(x.reshape(-1), d, n_bit, 0)
+    got_norm = wire[codec.norm_off:codec.norm_off + 4 * B].view(torch.float32).cpu().numpy()
+    assert _same(got_norm, norm)
+    raw = wire[codec.codes_off:codec.codes_off + x.size * codec.bits // 8].cpu().numpy()
+    if codec.bits == 4:
+        codes = np.empty(x.size, np.uint8)
+        codes[0::2], codes[1::2] = raw & 15, raw >> 4
+    else:
+        codes = raw
+    lv = np.where(levels < 0, 0, levels)                               # INT_MIN (NaN quotient) is level 0 on the packed wire
+    assert np.array_equal(codes & ((1 << (codec.bits - 1)) - 1), lv.astype(np.uint8))
+    assert np.array_equal(codes >> (codec.bits - 1), signs)
+
+
 @pytest.mark.parametrize("kw", [dict(c_dim=128, n_bit=2), dict(c_dim=0, n_bit=1), dict(c_dim=512, n_bit=8)],
                          ids=lambda k: "d%d_n%d" % (k["c_dim"], k["n_bit"]))
 def test_qsgd_large_tensors_match_the_oracle(kw, oracle):
