@@ -398,19 +398,23 @@ def run_qsgd(args, torch, np, dist, native, exchange, dev, rank, world, backend,
     with contextlib.redirect_stdout(sys.stderr):     # the constructors report the reference's dimension repair on stdout
         q = Quantizer(QSGDCompressor, params, qargs)
     grads = [[torch.randn(s, device=dev) * 1e-3 for s in shapes] for _ in range(3)]
+    prewarm = 200
+    # apply() rebinds `param.grad.data` like the reference (ps_quantizer.py:63): a tensor object that was handed in as a
+    # gradient points at the decoded mean afterwards.  Every step therefore gets its own alias objects of the three input
+    # lists (made here, outside the timed region), and the inputs stay N(0,1) * 1e-3 for the whole run.
+    fresh = [[g.view(g.shape) for g in grads[i % 3]] for i in range(prewarm + args.warmup + args.steps)]
 
     def step(i):
-        for p, g in zip(params, grads[i % 3]):
+        for p, g in zip(params, fresh[i]):
             p.grad = g
         q.record(0, epoch=1)
         q.apply()
 
-    prewarm = 200
     for i in range(prewarm + args.warmup):
         step(i)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(prewarm + args.warmup, prewarm + args.warmup + args.steps):
         step(i)
     barrier()
     dt = time.perf_counter() - t0
@@ -423,9 +427,8 @@ def run_qsgd(args, torch, np, dist, native, exchange, dev, rank, world, backend,
     # the dominant kernel alone: the multi-tensor 4-bit compress, back to back between two HIP events on the
     # stream it is launched on (torch's current stream)
     grp = [g[2] for g in q._groups if isinstance(g[2], BatchedQSGD) and not g[2].wide][0]
-    gl = [params[i].grad.data for i in grp.idxs]
     for p, g in zip(params, grads[0]):
-        p.grad = g
+        p.grad = g.view(g.shape)
     gl = [params[i].grad.data for i in grp.idxs]
     wire0 = q._wire[0]
     k_ms = event_ms(torch, lambda: grp.encode(gl, wire0, 0, 0))
