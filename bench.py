@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: gradient elements quantised per second, HSQ d=16 k=8 n=6.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hsq|qsgd] [--exchange MODE]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hsq|resnet50|qsgd] [--exchange MODE]
 
 `--gpus N` with N > 1 from a bare shell launches its own N ranks (a child `python -m torch.distributed.run
 --nproc-per-node N ... bench.py ...`, started BEFORE anything touches the GPU); under torch.distributed.run
@@ -17,14 +17,22 @@ never finds its input in the 256 MiB Infinity Cache):
 (encode + levels, SURVEY 8d's definition of the metric) is in `compress_only`.  Weak scaling: every rank
 owns a full-size gradient (it is one of the reference's `num_users`).
 
-Workload qsgd (BASELINE configs[4]): the ResNet-50/CIFAR parameter list (161 tensors, 23.5 M elements) through
-PSQuantizer.record + apply with QSGDCompressor c_dim=128 n_bit=2 (packed 4-bit wire, multi-tensor kernels).
+Workload resnet50 (BASELINE configs[2]): the ResNet-50/CIFAR parameter list (161 tensors, 23.5 M elements; 76 go through
+the codebook, 85 small ones travel as f32) through PSQuantizer.record + apply with NearestNeighborCompressor c_dim=16
+k_bit=8 n_bit=6 (quantizers/ps_quantizer.py:27-65): one multi-tensor encode, one level launch, one decode-mean per step.
+Workload qsgd (BASELINE configs[4]): the same list with QSGDCompressor c_dim=128 n_bit=2 (packed 4-bit wire).
+Both hand every step fresh tensor objects of three input lists (apply() rebinds .grad.data like the reference).
 
 Extra objects on the JSON line:
   roofline      dominant kernel: algorithmic bytes per launch / its average launch duration, measured with HIP
-                events inside the run; peak = 8 TB/s HBM3E.
-  cpu_baseline  the CPU oracle (oracle/gq_oracle.c, OpenMP, scalar code) timed on a bounded sample of
-                the same gradient on this box's host cores (rank 0, N=1 only).
+                events attached to its dispatches inside the timed region; peak = 8 TB/s HBM3E.  `frac` is that kernel
+                alone, `frac_compress` SURVEY 8(d)'s own definition: 4.125 B x size / t(encode + levels).
+                `traffic`: HBM bytes per launch from PMC counters (FETCH_SIZE, WRITE_SIZE in separate rocprofv3
+                passes of a short child run of this script, gfx950 corrections of MI355X_MICROARCH.md), measured
+                in this run when rocprofv3 is present (--traffic live|auto), else the committed figure.
+  cpu_baseline  the CPU oracle (oracle/gq_oracle.c: OpenMP, hardware FMA, eight codeword chains per AVX2 register)
+                timed on a bounded sample of the same gradient on this box's host cores (rank 0, N=1 only), with
+                the per-thread rate and the Python reference's own figures (other machine) beside it.
   exchange      N > 1: backend, ranks, the transport used and the per-transport times measured before the timed
                 region (all-gather / direct all-pairs / split with overlapped decode).
 """
@@ -55,11 +63,18 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="hsq", choices=["hsq", "qsgd"])
+    ap.add_argument("--workload", default="hsq", choices=["hsq", "resnet50", "qsgd"])
     ap.add_argument("--random", type=int, default=0, choices=[0, 2],
                     help="hsq: 0 = deterministic levels (the bit-exact configuration); 2 = on-device stochastic rounding")
-    ap.add_argument("--exchange", default=os.environ.get("GQ_EXCHANGE", "auto"),
-                    choices=["auto", "allgather", "direct", "split"], help="N > 1: how the wire travels")
+    ap.add_argument("--exchange", default=os.environ.get("GQ_EXCHANGE", "allgather"),
+                    choices=["auto", "allgather", "direct", "split"],
+                    help="N > 1: how the wire travels.  Default: the in-place all-gather (the one collective every backend has); "
+                         "auto = time all three before the timed region and keep the fastest (opt-in: direct / split have not "
+                         "met RCCL with more than one rank yet)")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "off"],
+                    help="roofline.traffic: live = two short child runs under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE); "
+                         "auto = live at N=1 when rocprofv3 is on PATH, else the committed profiles/hbm_traffic.json")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the untimed random=2 / 1e-3-scale side measurements")
     return ap.parse_args()
@@ -84,25 +99,101 @@ def self_launch(args):
 
 
 def cpu_baseline(g_host, cb):
-    """Time the CPU oracle's whole compress (encode + min/max + levels) on the rank-0 gradient,
-    repeated until about 10 s of wall time have been spent (bounded sample, all host cores)."""
+    """Time the CPU oracle's whole compress (encode + min/max + levels) on the rank-0 gradient, repeated until about
+    10 s of wall time have been spent (bounded sample), on all host cores and on ONE thread."""
     import oracle
     oracle.build()
     threads = oracle.num_threads()
     oracle.hsq_compress(g_host[:16 * 20000], cb, N_BIT, 0)       # warm the thread pool
     n = SIZE
     reps, spent = 0, 0.0
-    while spent < 10.0 and reps < 64:
+    while spent < 10.0 and reps < 4000:
         t0 = time.perf_counter()
         oracle.hsq_compress(g_host[:n], cb, N_BIT, 0)
         spent += time.perf_counter() - t0
         reps += 1
-    return {"value": n * reps / spent, "unit": "elements/s", "cores": threads, "kind": "port", "vectorised": False,
+    oracle.set_num_threads(1)
+    n1 = 16 * 500_000
+    oracle.hsq_compress(g_host[:n1], cb, N_BIT, 0)
+    reps1, spent1 = 0, 0.0
+    while spent1 < 4.0 and reps1 < 200:
+        t0 = time.perf_counter()
+        oracle.hsq_compress(g_host[:n1], cb, N_BIT, 0)
+        spent1 += time.perf_counter() - t0
+        reps1 += 1
+    oracle.set_num_threads(threads)
+    value = n * reps / spent
+    return {"value": value, "unit": "elements/s", "cores": threads, "kind": "port", "vectorised": True,
+            "per_thread": value / threads, "one_thread": {"value": n1 * reps1 / spent1, "unit": "elements/s",
+                                                          "sample": "%d elements x %d repetitions, 1 thread" % (n1, reps1)},
             "sample": "the full 25,000,000-element rank-0 gradient, HSQ compress (encode+min/max+levels), "
-                      "%d repetitions in %.1f s wall, OpenMP %d threads (%.0f core-seconds); scalar C restatement of "
-                      "the reference (no SIMD intrinsics): a stated baseline, not a tuned CPU implementation"
+                      "%d repetitions in %.1f s wall, OpenMP %d threads (%.0f core-seconds); C restatement of the "
+                      "reference built with -mavx2 -mfma: every score is the reference's ascending fmaf chain, eight "
+                      "codewords per 256-bit register (oracle/gq_oracle.c); min/max single-threaded like torch's"
                       % (reps, spent, threads, spent * threads),
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(),
+            "reference_python": {"value_8_threads": 2.17e7, "value_1_thread": 5.2e6, "unit": "elements/s",
+                                 "note": "the reference itself (PyTorch CPU ops), measured in the survey container, not on "
+                                         "this box (BASELINE.md section 2); it cannot travel to the GPU box"}}
+
+
+def live_traffic(workload, kernel_match):
+    """HBM bytes per launch of the kernels whose name contains `kernel_match`, from PMC counters collected NOW: two
+    child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE do not fit one pass), a few steps each.
+    FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports half the bytes of a 16-B-per-lane streaming read, so the
+    read side is doubled (MI355X_MICROARCH.md, HBM section).  Returns (bytes or None, how)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="gq_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.abspath(__file__), "--traffic-child", "--workload", workload, "--steps", "6", "--warmup", "2",
+               "--no-cpu-baseline", "--no-variants", "--traffic", "off"]
+        try:
+            # a child process (never an exec from this GPU-initialised process); the profiler's own program is python itself
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=300, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == counter and kernel_match in r.get("Kernel_Name", ""):
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, "rocprofv3 --pmc %s produced no rows for %s" % (counter, kernel_match)
+            got[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception as e:      # a box without counter access: fall back to the committed figure
+            return None, "rocprofv3 --pmc %s failed: %s" % (counter, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    rd, wr = got["FETCH_SIZE"][0] * 1024 * 2, got["WRITE_SIZE"][0] * 1024
+    return rd + wr, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate child runs of bench.py "
+                     "(%d / %d launches of %s); KiB counters, read side doubled (gfx950 wide-read correction): "
+                     "%.1f MB read + %.1f MB written" % (got["FETCH_SIZE"][1], got["WRITE_SIZE"][1], kernel_match,
+                                                         rd / 1e6, wr / 1e6))
+
+
+def traffic_for(args, world, workload, kernel_match, file_key):
+    """roofline.traffic and where it came from."""
+    if args.traffic == "off" or args.traffic_child:
+        return None, "not collected (--traffic off)"
+    why = "--traffic file"
+    if args.traffic in ("auto", "live") and world == 1:
+        t, why = live_traffic(workload, kernel_match)
+        if t is not None:
+            return t, why
+    if file_key and os.path.exists(os.path.join(ROOT, TRAFFIC_FILE)):
+        try:
+            t = json.load(open(os.path.join(ROOT, TRAFFIC_FILE))).get(file_key)
+            return t, TRAFFIC_FILE + " (committed figure of an earlier rocprofv3 --pmc run, NOT measured in this run: %s)" % why
+        except Exception:
+            pass
+    return None, why
 
 
 def event_ms(torch, fn, n=50, warm=10):
@@ -154,8 +245,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.workload == "qsgd":
-        line = run_qsgd(args, torch, np, dist, native, exchange, dev, rank, world, backend, barrier)
+    if args.workload in ("qsgd", "resnet50"):
+        line = run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend, barrier)
     else:
         line = run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, barrier)
     if rank == 0:
@@ -252,7 +343,8 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
                     exchange_decode_split()
                 else:
                     decode(ex.run(m))
-            mode = ex.autotune(probe)
+            mode = ex.autotune(probe, preflight=lambda m: (sex.start("split", cut=swire.cut, dry_run=True) if m == "split"
+                                                           else ex.start(m, dry_run=True)))
         else:
             mode = args.exchange
 
@@ -260,7 +352,7 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     # per step over the first 60 steps, 74 us in steady state), so the W warm-up steps are preceded by an
     # untimed pre-warm of PREWARM_STEPS of the same steps (~0.25 s at N=1); the timed region is untouched and
     # the JSON line says so (`prewarm_steps`).
-    prewarm = PREWARM_STEPS if world == 1 else 300
+    prewarm = 20 if args.traffic_child else (PREWARM_STEPS if world == 1 else 300)
     for i in range(prewarm):          # a fixed count: every rank issues the same collectives
         step(i, mode)
         if i % 100 == 99:
@@ -324,12 +416,8 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     ms_per_step = dt / args.steps * 1e3
     value = world * SIZE * args.steps / dt
     achieved = ALGO_BYTES_PER_ELEM * SIZE / (enc_ms * 1e-3) / 1e9
-    traffic = None
-    if os.path.exists(os.path.join(ROOT, TRAFFIC_FILE)):
-        try:
-            traffic = json.load(open(os.path.join(ROOT, TRAFFIC_FILE))).get("hsq_encode_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    achieved_compress = ALGO_BYTES_PER_ELEM * SIZE / (cmp_ms * 1e-3) / 1e9
+    traffic, traffic_source = traffic_for(args, world, "hsq", "hsq_encode_pf_kernel", "hsq_encode_hbm_bytes_per_launch")
     line = {
         "metric": "gradient elements quantized/sec (HSQ d=16 k=8)", "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -343,9 +431,13 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
                    "elements_per_rank": SIZE, "random": args.random, "ranks": world,
                    "inputs": "3 gradients of 100 MB used in turn (never Infinity-Cache resident)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this kernel, separate "
-                                       "runs of tools/hbm_traffic.sh; not measured in this run)",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "algorithmic_bytes": ALGO_BYTES_PER_ELEM * SIZE,
+                     "frac_compress": achieved_compress / HBM_PEAK_GBS, "achieved_compress": achieved_compress,
+                     "compress_ms": cmp_ms,
+                     "frac_is": "frac = the dominant kernel alone (4.125 B x 25e6 / kernel_ms / peak); frac_compress = SURVEY 8(d)'s "
+                                "definition, the whole compress: 4.125 B x 25e6 / (encode + levels, HIP events around "
+                                "back-to-back pairs on rotating inputs) / peak",
                      "kernel": "gq_hsq_encode = hsq_encode_pf_kernel (one launch: prefilter, exact rescoring, in-place exact fix-up, final lb/ub)",
                      "kernel_ms": enc_ms, "kernel_ms_back_to_back": enc_b2b_ms,
                      "kernel_ms_recorded_bracket": enc_bracket_ms, "empty_recorded_bracket_ms": ev_overhead_ms,
@@ -379,26 +471,33 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
 
 
 # ------------------------------------------------------------------------------------------------------
-# workload qsgd: ResNet-50 parameter list through the quantizer (BASELINE configs[4])
+# workloads resnet50 / qsgd: the ResNet-50 parameter list through the quantizer (BASELINE configs[2] / [4])
 # ------------------------------------------------------------------------------------------------------
-def run_qsgd(args, torch, np, dist, native, exchange, dev, rank, world, backend, barrier):
+def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend, barrier):
     from argparse import Namespace
-    from gq_amd.compressors import QSGDCompressor
+    from gq_amd.compressors import NearestNeighborCompressor, QSGDCompressor
     from gq_amd.driver import ResNet50
-    from gq_amd.quantizers import BatchedQSGD, Quantizer
+    from gq_amd.quantizers import BatchedHSQ, BatchedQSGD, Quantizer
 
+    hsq = args.workload == "resnet50"
     shapes = [tuple(p.shape) for p in ResNet50(num_classes=10).parameters()]
     n = sum(int(np.prod(s)) for s in shapes)
-    qargs = Namespace(c_dim=128, k_bit=8, n_bit=2, no_cuda=False, random=1, ef=False, two_phase=False, scale="exp",
-                      num_users=1, mode="ps", cr=256)
+    if hsq:     # README: --quantizer hsq --network resnet50 --c-dim 16 --k-bit 8 --n-bit 6 (--random defaults to True)
+        qargs = Namespace(c_dim=C_DIM, k_bit=K_BIT, n_bit=N_BIT, no_cuda=False, random=1, ef=False, two_phase=False,
+                          scale="exp", num_users=1, mode="ps", cr=256)
+        Comp = NearestNeighborCompressor
+    else:       # README: --quantizer qsgd --c-dim 128 --n-bit 2
+        qargs = Namespace(c_dim=128, k_bit=8, n_bit=2, no_cuda=False, random=1, ef=False, two_phase=False, scale="exp",
+                          num_users=1, mode="ps", cr=256)
+        Comp = QSGDCompressor
     params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
     os.environ["GQ_EXCHANGE"] = args.exchange
     torch.manual_seed(1234 + rank)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # the constructors report the reference's dimension repair on stdout
-        q = Quantizer(QSGDCompressor, params, qargs)
+        q = Quantizer(Comp, params, qargs)
     grads = [[torch.randn(s, device=dev) * 1e-3 for s in shapes] for _ in range(3)]
-    prewarm = 200
+    prewarm = 10 if args.traffic_child else 200
     # apply() rebinds `param.grad.data` like the reference (ps_quantizer.py:63): a tensor object that was handed in as a
     # gradient points at the decoded mean afterwards.  Every step therefore gets its own alias objects of the three input
     # lists (made here, outside the timed region), and the inputs stay N(0,1) * 1e-3 for the whole run.
@@ -410,11 +509,18 @@ def run_qsgd(args, torch, np, dist, native, exchange, dev, rank, world, backend,
         q.record(0, epoch=1)
         q.apply()
 
-    for i in range(prewarm + args.warmup):
+    for i in range(prewarm + args.warmup):      # (--exchange auto: the first apply() times the transports)
         step(i)
+    # HIP events attached to the dominant kernel's dispatch on up to 16 of the timed steps (HSQ: the multi-tensor
+    # prefilter encode takes them, gq_profile_arm; the first launch after arming is that encode)
+    stride = max(1, -(-args.steps // 16))
+    armed = list(range(0, args.steps, stride))[:16] if hsq else []
+    slot_of = {prewarm + args.warmup + i: k for k, i in enumerate(armed)}
     barrier()
     t0 = time.perf_counter()
     for i in range(prewarm + args.warmup, prewarm + args.warmup + args.steps):
+        if i in slot_of:
+            native.profile_arm(slot_of[i])
         step(i)
     barrier()
     dt = time.perf_counter() - t0
@@ -424,43 +530,73 @@ def run_qsgd(args, torch, np, dist, native, exchange, dev, rank, world, backend,
         dt = float(t.item())
     identical = ranks_agree(torch, dist, world, [p.grad.data for p in params if p.numel() > 1000][:8])
 
-    # the dominant kernel alone: the multi-tensor 4-bit compress, back to back between two HIP events on the
-    # stream it is launched on (torch's current stream)
-    grp = [g[2] for g in q._groups if isinstance(g[2], BatchedQSGD) and not g[2].wide][0]
+    # untimed: the kernels of the step alone, back to back between two HIP events on the stream they are launched on
+    Grp = BatchedHSQ if hsq else BatchedQSGD
+    grp = [g[2] for g in q._groups if isinstance(g[2], Grp) and not getattr(g[2], "wide", False)][0]
     for p, g in zip(params, grads[0]):
         p.grad = g.view(g.shape)
     gl = [params[i].grad.data for i in grp.idxs]
     wire0 = q._wire[0]
-    k_ms = event_ms(torch, lambda: grp.encode(gl, wire0, 0, 0))
+    cmp_ms = event_ms(torch, lambda: grp.encode(gl, wire0, 0, 0))       # HSQ: encode + levels; QSGD: the one compress launch
     k_elems = sum(cd.numel for cd in grp.codecs)
     dec_ms = event_ms(torch, lambda: grp.decode_mean(q._wire[:1], 1))
+    exch_ms = None
+    if world > 1 and q._ex is not None:
+        mode = q.exchange_mode
+
+        def only_exchange():
+            for pnd in q._ex.start(mode, 1, q.cut)[1]:
+                pnd.wait()
+        exch_ms = event_ms(torch, only_exchange)
     if rank != 0:
         return None
-    achieved = QSGD_ALGO_BYTES_PER_ELEM * k_elems / (k_ms * 1e-3) / 1e9
+    if hsq:
+        k_ms = float(np.mean([native.profile_read(k) for k in range(len(armed))]))
+        algo = ALGO_BYTES_PER_ELEM * k_elems
+        kernel = ("gq_hsq_encode_batched = hsq_encode_pf_kernel<uint8_t, BATCHED> (ONE launch for the 76 codebook-compressed "
+                  "tensors: prefilter, exact rescoring, in-place fix-up, per-tensor lb/ub by atomics)")
+        match, metric = "hsq_encode_pf_kernel", "gradient elements quantized/sec (HSQ d=16 k=8, ResNet-50 list)"
+        cfg = ("ResNet-50/CIFAR parameter list (161 tensors, %d elements) per rank through PSQuantizer.record + apply, HSQ c_dim=16 "
+               "k_bit=8 n_bit=6 random=1 on-device draws (BASELINE configs[2]; the README's hsq command), byte wire, multi-tensor kernels" % n)
+        note = ("kernel_ms: HIP start/stop events attached to the encode's dispatch on %d of the timed steps; compress_ms = encode + "
+                "levels launches back to back after the timed region; the step itself is host-bound (per-parameter Python)" % len(armed))
+    else:
+        k_ms = cmp_ms
+        algo = QSGD_ALGO_BYTES_PER_ELEM * k_elems
+        kernel = "gq_qsgd_compress_batched = qsgd_compress_batched4_kernel"
+        match, metric = "qsgd_compress_batched4_kernel", "gradient elements quantized/sec (QSGD c_dim=128 n_bit=2, ResNet-50 list)"
+        cfg = ("ResNet-50/CIFAR parameter list (161 tensors, %d elements) per rank, QSGD c_dim=128 n_bit=2 "
+               "random=1 (BASELINE configs[4]), packed 4-bit wire, multi-tensor kernels" % n)
+        note = ("HIP events around 50 back-to-back launches after the timed region (the step itself is host-bound: "
+                "~0.09 ms of kernels in a ~0.15 ms step)")
+    achieved = algo / (k_ms * 1e-3) / 1e9
+    achieved_compress = algo / (cmp_ms * 1e-3) / 1e9
+    traffic, traffic_source = traffic_for(args, world, args.workload, match, None)
     line = {
-        "metric": "gradient elements quantized/sec (QSGD c_dim=128 n_bit=2, ResNet-50 list)", "value": world * n * args.steps / dt,
+        "metric": metric, "value": world * n * args.steps / dt,
         "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "value_is": "end_to_end: PSQuantizer.record + apply per step (compress, " + ("exchange, " if world > 1 else "")
                     + "decode-mean, small tensors dense), host launch time included",
         "prewarm_steps": prewarm,
-        "config": {"workload": "ResNet-50/CIFAR parameter list (161 tensors, %d elements) per rank, QSGD c_dim=128 n_bit=2 "
-                               "random=1 (BASELINE configs[4]), packed 4-bit wire, multi-tensor kernels" % n,
-                   "elements_per_rank": n, "ranks": world, "wire_bytes_per_rank": q.wire_bytes_per_user(),
-                   "inputs": "3 gradient lists used in turn, N(0,1)*1e-3"},
+        "config": {"workload": cfg, "elements_per_rank": n, "ranks": world, "wire_bytes_per_rank": q.wire_bytes_per_user(),
+                   "inputs": "3 gradient lists used in turn through fresh tensor objects, N(0,1)*1e-3"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "gq_qsgd_compress_batched = qsgd_compress_batched4_kernel",
-                     "kernel_ms": k_ms, "kernel_elements": k_elems,
-                     "note": "HIP events around 20 back-to-back launches after the timed region (the step itself is "
-                             "host-bound: ~0.09 ms of kernels in a ~0.25 ms step)"},
-        "phases_ms": {"compress_kernel": k_ms, "decode_mean_kernel_R1": dec_ms},
+                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": algo,
+                     "frac_compress": achieved_compress / HBM_PEAK_GBS, "compress_ms": cmp_ms,
+                     "kernel": kernel, "kernel_ms": k_ms, "kernel_elements": k_elems, "note": note},
+        "phases_ms": {"compress_kernels": cmp_ms, "decode_mean_kernel_R1": dec_ms, "exchange": exch_ms},
+        "compress_only": {"value": world * k_elems / (cmp_ms * 1e-3), "unit": "elements/s"},
         "ranks_bit_identical": identical,
     }
     if world > 1:
         line["exchange"] = {"backend": "rccl" if backend == "nccl" else backend,
                             "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "ranks": world,
-                            "transport": q.exchange_mode, "requested": args.exchange,
-                            "autotune_ms": q._ex.timings_ms if q._ex is not None else None}
+                            "transport": q.exchange_mode, "requested": args.exchange, "ms": exch_ms,
+                            "wire_bytes_per_rank": q.wire_bytes_per_user(),
+                            "autotune_ms": q._ex.timings_ms if q._ex is not None else None,
+                            "note": "ms = the chosen transport alone (no decode), HIP events, untimed pass; autotune_ms = exchange + "
+                                    "decode-mean per transport (max over ranks), only with --exchange auto"}
     return line
 
 

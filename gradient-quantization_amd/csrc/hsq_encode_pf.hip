@@ -657,7 +657,11 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
     hipStream_t st = as_stream(stream);
     const int64_t blocks = pf16_grid(ntiles, bpc);
     pf_split(a, ntiles, blocks);
-    if (nseg <= PF_LDS_SEGS) {
+    hipEvent_t ev_start, ev_stop;
+    if (nseg <= PF_LDS_SEGS && profile_take(&ev_start, &ev_stop)) {   // gq_profile_arm: events attached to this dispatch
+        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, true, EF, true>), dim3((unsigned)blocks),
+                              dim3(PF_THREADS), 0, st, ev_start, ev_stop, 0, a);
+    } else if (nseg <= PF_LDS_SEGS) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, true, EF, true>), dim3((unsigned)blocks),
                            dim3(PF_THREADS), 0, st, a);
     } else {

@@ -17,8 +17,9 @@ of the exchange.  Three ways to fill the other ranks' rows, all bit-identical in
                  caller decodes the first range while the second is still in flight (needs one user per
                  rank so that a row's byte range is contiguous; otherwise it degrades to "direct").
 
-`GQ_EXCHANGE` selects the mode ("auto": time all of them on the first exchange and keep the fastest,
-every rank taking the same decision from the all-reduced maxima).  Collectives run on the process
+`GQ_EXCHANGE` selects the mode; the default is "allgather", the one collective every backend has ("auto" is
+opt-in: time all of them on the first exchange and keep the fastest, every rank taking the same decision from the
+all-reduced maxima -- "direct" and "split" have not run on RCCL with more than one rank yet).  Collectives run on the process
 group's own stream; `Work.wait()` makes torch's current stream wait for them without blocking the host.
 """
 import os
@@ -80,7 +81,7 @@ class WireExchange(object):
         return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
 
     # ---- the three transports ---------------------------------------------------------------
-    def _allgather(self, rows):
+    def _allgather(self, rows, dry=False):
         import torch.distributed as dist
         n = rows * self.user_bytes
         flat = self.gathered.view(-1)
@@ -90,6 +91,9 @@ class WireExchange(object):
         else:   # fewer records than slots this step: gather the used rows of every rank, rank-major
             out = self._partial_buffer(rows).view(-1)
             inp = self.local[:rows].reshape(-1)
+        if dry:
+            assert out.numel() == self.world * inp.numel() and out.is_contiguous() and inp.is_contiguous()
+            return None
         w = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
         return _Pending([w])
 
@@ -100,13 +104,14 @@ class WireExchange(object):
                                               device=self.gathered.device)
         return buf
 
-    def _direct(self, rows, lo, hi):
-        """Grouped point-to-point transfers of bytes [lo, hi) of the first `rows` rows of every rank."""
+    def _direct(self, rows, lo, hi, dry=False):
+        """Grouped point-to-point transfers of bytes [lo, hi) of the first `rows` rows of every rank.
+        dry: build and validate every operation (views, peers, host buffers) but queue nothing."""
         import torch.distributed as dist
         ops, after = [], []
         whole = lo == 0 and hi == self.user_bytes
         target = self.gathered if rows == self.users else self._partial_buffer(rows)
-        if rows != self.users:
+        if rows != self.users and not dry:
             target[self.rank * rows:(self.rank + 1) * rows].copy_(self.local[:rows])
         for step in range(1, self.world):
             # peers in a rotated order: at step s every rank sends to rank+s and receives from rank-s, so
@@ -123,12 +128,15 @@ class WireExchange(object):
             if self._staged:
                 if step == 1:     # one host copy of the outgoing bytes serves every peer
                     out_h = self._host_buffer(("out", lo, hi), send_t.numel())
-                    out_h.copy_(send_t)           # synchronous: the kernels that wrote the wire have finished
+                    if not dry:
+                        out_h.copy_(send_t)       # synchronous: the kernels that wrote the wire have finished
                 in_h = self._host_buffer(("in", src, lo, hi), recv_t.numel())
                 after.append((recv_t, in_h))
                 send_t, recv_t = out_h, in_h
             ops.append(dist.P2POp(dist.isend, send_t, self._peer(dst), group=self.group))
             ops.append(dist.P2POp(dist.irecv, recv_t, self._peer(src), group=self.group))
+        if dry:
+            return None
         return _Pending(dist.batch_isend_irecv(ops) if ops else [], after)
 
     def _host_buffer(self, key, n):
@@ -138,9 +146,11 @@ class WireExchange(object):
         return buf
 
     # ---- public -----------------------------------------------------------------------------
-    def start(self, mode, rows=None, cut=None):
+    def start(self, mode, rows=None, cut=None, dry_run=False):
         """Queue the exchange of the first `rows` rows per rank.  Returns (buffer, [pending...]): one pending
-        transfer for "allgather" / "direct", two for "split" (bytes [0, cut) then [cut, user_bytes))."""
+        transfer for "allgather" / "direct", two for "split" (bytes [0, cut) then [cut, user_bytes)).
+        dry_run: everything but the transfers themselves -- the buffers, views and operation lists are built and
+        checked, nothing is queued and no peer is engaged (autotune's preflight); returns (buffer, [])."""
         rows = self.users if rows is None else rows
         buf = self.gathered if rows == self.users else self._partial_buffer(rows)
         if self.world == 1:
@@ -148,14 +158,14 @@ class WireExchange(object):
         if mode == "split" and (rows != 1 or not cut or cut <= 0 or cut >= self.user_bytes):
             mode = "direct"
         if mode == "allgather":
-            return buf, [self._allgather(rows)]
-        if mode == "direct":
-            return buf, [self._direct(rows, 0, self.user_bytes)]
-        if mode == "split":
-            first = self._direct(rows, 0, cut)
-            second = self._direct(rows, cut, self.user_bytes)
-            return buf, [first, second]
-        raise ValueError(mode)
+            pend = [self._allgather(rows, dry_run)]
+        elif mode == "direct":
+            pend = [self._direct(rows, 0, self.user_bytes, dry_run)]
+        elif mode == "split":
+            pend = [self._direct(rows, 0, cut, dry_run), self._direct(rows, cut, self.user_bytes, dry_run)]
+        else:
+            raise ValueError(mode)
+        return buf, ([] if dry_run else pend)
 
     def run(self, mode, rows=None):
         """Exchange and wait (stream-ordered): the whole gathered buffer is valid for kernels queued next."""
@@ -164,37 +174,56 @@ class WireExchange(object):
             p.wait()
         return buf
 
-    def autotune(self, step_fn, rounds=10):
+    def autotune(self, step_fn, rounds=10, preflight=None):
         """Time step_fn(mode) -- the caller's exchange (+ decode) for that transport; it is idempotent -- for
-        every mode and return the fastest.  Times are maxima over ranks: every rank returns the same mode."""
+        every mode and return the fastest.  Times are maxima over ranks: every rank returns the same mode.
+
+        Every rank issues the SAME sequence of collectives whatever happens locally.  Per mode:
+          1. preflight(mode) -- by default start(mode, dry_run=True): the transport's buffers, views and operation
+             lists are built and checked, NOTHING is queued and no peer is engaged.  A rank on which this raises
+             (a transport its backend or its arguments refuse) reports ok = 0.
+          2. ONE all-reduce(MIN) of the ok-flags, outside any try, on every rank.  If any rank failed, the transport
+             is dropped on ALL ranks: nobody calls step_fn for it, nobody enters its barrier.
+          3. otherwise, on every rank: two untimed calls, barrier, the timed loop.
+        An error in step 3 is NOT caught: once a rank has queued its half of a transfer its peers are waiting in
+        theirs, an RCCL failure is asynchronous and poisons the communicator -- the exception propagates, the process
+        exits non-zero and the launcher ends the job.  (Round 2 caught it per rank and went on to an all-reduce
+        while the healthy ranks sat in a barrier: mismatched collectives, a hang.)"""
+        import sys
         import torch.distributed as dist
         if self.world == 1:
             return "allgather"
-        cuda = self.gathered.device.type == "cuda"
+        dev = self.gathered.device
+        cuda = dev.type == "cuda"
+        if preflight is None:
+            def preflight(mode):
+                self.start(mode, cut=self.user_bytes // 2 // 16 * 16, dry_run=True)
         res = {}
         for mode in MODES:
             ok = 1.0
             try:
-                for _ in range(2):
-                    step_fn(mode)
-                if cuda:
-                    torch.cuda.synchronize()
-                dist.barrier(group=self.group)
-                t0 = time.perf_counter()
-                for _ in range(rounds):
-                    step_fn(mode)
-                if cuda:
-                    torch.cuda.synchronize()
-                res[mode] = (time.perf_counter() - t0) / rounds * 1e3
-            except Exception as e:      # a transport the backend refuses is left out (all-gather is the one every backend has)
-                import sys
-                print("gq_amd.exchange: transport %r failed in autotune: %s" % (mode, e), file=sys.stderr)
-                ok, res[mode] = 0.0, float("inf")
-            flag = torch.tensor([ok], dtype=torch.float64, device=self.gathered.device)
+                preflight(mode)
+            except Exception as e:
+                print("gq_amd.exchange: rank %d: transport %r failed its preflight and is dropped on every rank: %s"
+                      % (self.rank, mode, e), file=sys.stderr)
+                ok = 0.0
+            flag = torch.tensor([ok], dtype=torch.float64, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
             if float(flag.item()) == 0.0:
                 res[mode] = 1e30
-        t = torch.tensor([res[m] for m in MODES], dtype=torch.float64, device=self.gathered.device)
+                continue
+            for _ in range(2):
+                step_fn(mode)
+            if cuda:
+                torch.cuda.synchronize()
+            dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            for _ in range(rounds):
+                step_fn(mode)
+            if cuda:
+                torch.cuda.synchronize()
+            res[mode] = (time.perf_counter() - t0) / rounds * 1e3
+        t = torch.tensor([res[m] for m in MODES], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         self.timings_ms = {m: float(v) for m, v in zip(MODES, t.tolist())}
         return min(MODES, key=lambda m: (self.timings_ms[m], MODES.index(m)))

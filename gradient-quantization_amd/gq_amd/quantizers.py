@@ -958,7 +958,8 @@ class PSQuantizer(object):
                 def step(mode):
                     buf, pend = ex.start(mode, self.recorded, self.cut)
                     self._decode_all(buf, False, pend)
-                self.exchange_mode = ex.autotune(step)
+                self.exchange_mode = ex.autotune(
+                    step, preflight=lambda mode: ex.start(mode, self.recorded, self.cut, dry_run=True))
             gathered, pending = ex.start(self.exchange_mode, self.recorded, self.cut)
         else:
             gathered, pending = self._wire[:self.recorded], ()

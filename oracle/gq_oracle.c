@@ -20,9 +20,14 @@
  * (re-verified by the golden tests).  Compile with
  * -ffp-contract=off so that nothing else is fused.
  *
- * Build:  gcc -O2 -fPIC -shared -fopenmp -ffp-contract=off -o libgq_oracle.so gq_oracle.c -lm
+ * -mavx2 -mfma: fmaf() becomes one vfmadd instruction (the same correctly rounded fused operation as libm's fmaf,
+ * without the PLT call per multiply-add that a baseline x86-64 build makes).
+ *
+ * Build:  gcc -O2 -mavx2 -mfma -fPIC -shared -fopenmp -ffp-contract=off -o libgq_oracle.so gq_oracle.c gq_cpu.c -lm
  */
+#include <immintrin.h>
 #include <math.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 #include <limits.h>
@@ -40,7 +45,11 @@
  * Every exported function and every thread of every parallel region therefore starts with vzeroupper. */
 static inline void gq_clean_vector_state(void) {
 #if defined(__x86_64__)
-    if (__builtin_cpu_supports("avx")) __asm__ volatile("vzeroupper" ::: "memory");
+    /* the clobber list matters since this file holds 256-bit values of its own: without it the compiler may keep a
+     * ymm constant live across the instruction and find its upper half zeroed */
+    if (__builtin_cpu_supports("avx"))
+        __asm__ volatile("vzeroupper" ::: "memory", "xmm0", "xmm1", "xmm2", "xmm3", "xmm4", "xmm5", "xmm6", "xmm7", "xmm8",
+                         "xmm9", "xmm10", "xmm11", "xmm12", "xmm13", "xmm14", "xmm15");
 #endif
 }
 
@@ -69,34 +78,105 @@ GQ_EXPORT void gq_oracle_set_num_threads(int n) {
  *   u     = p.gather(1, codes)   -- SIGNED projection (:73)
  * grad: [M*d] f32, codebook: [K*d] f32 row-major (already row-normalised),
  * codes: [M] int32, u: [M] f32.
+ *
+ * hsq_encode_one_scalar is the literal restatement (one subvector, codewords in turn).  gq_oracle_hsq_encode runs the
+ * SAME arithmetic eight codewords at a time: lane i of a 256-bit register carries codeword kb+i's own accumulator
+ * through the same ascending chain acc = fma(c[j], v[j], acc), j = 0..d-1 (vfmadd231ps is the fused operation fmaf()
+ * is; a lane never sees another lane's value), four such registers per pass so that one broadcast of v[j] feeds 32
+ * chains.  The first-maximum rule is kept per lane by a strict `>` over ascending blocks and across lanes by taking
+ * the lowest index among equal maxima.  A subvector with any NaN score (NaN or infinite input) is redone by the
+ * scalar form, whose NaN ranking is torch.argmax's.  tests/test_oracle_golden.py holds both forms to the reference's
+ * fixtures bit for bit; gq_oracle_hsq_encode_scalar stays exported for that comparison.
  */
+static inline void hsq_encode_one_scalar(const float *v, const float *codebook, int d, int K, int32_t *code, float *u) {
+    float best_abs = -1.0f, best_p = 0.0f;
+    int32_t best_k = 0;
+    for (int k = 0; k < K; ++k) {
+        const float *c = codebook + (int64_t)k * d;
+        float acc = 0.0f;
+        for (int j = 0; j < d; ++j) acc = fmaf(c[j], v[j], acc);
+        float a = fabsf(acc);
+        /* torch.argmax: first index of the maximum; a NaN counts as the maximum */
+        if (a > best_abs || (isnan(a) && !isnan(best_abs))) {
+            best_abs = a;
+            best_p = acc;
+            best_k = k;
+        }
+    }
+    *code = best_k;
+    *u = best_p;
+}
+
+GQ_EXPORT void gq_oracle_hsq_encode_scalar(const float *grad, const float *codebook, int64_t M, int d, int K,
+                                           int32_t *codes, float *u) {
+    gq_clean_vector_state();
+#pragma omp parallel
+    {
+        gq_clean_vector_state();   /* per thread: see the comment at its definition */
+#pragma omp for schedule(static)
+    for (int64_t m = 0; m < M; ++m) hsq_encode_one_scalar(grad + m * (int64_t)d, codebook, d, K, codes + m, u + m);
+    }
+}
+
 GQ_EXPORT void gq_oracle_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, int K,
                                     int32_t *codes, float *u) {
     gq_clean_vector_state();
+    /* transposed image [d][Kp], Kp = K rounded up to 32, padded with zero codewords: a padded lane scores +0 (or NaN
+     * for a non-finite input, which sends the subvector to the scalar form) and its index is above every real one,
+     * so it never wins a tie */
+    const int Kp = (K + 31) & ~31;
+    float *cT = (float *)aligned_alloc(32, (size_t)Kp * (size_t)d * sizeof(float));
+    if (!cT) { gq_oracle_hsq_encode_scalar(grad, codebook, M, d, K, codes, u); return; }
+    for (int j = 0; j < d; ++j)
+        for (int k = 0; k < Kp; ++k) cT[(size_t)j * Kp + k] = k < K ? codebook[(int64_t)k * d + j] : 0.0f;
+    const __m256 absmask = _mm256_castsi256_ps(_mm256_set1_epi32(0x7fffffff));
+    const __m256i lane_id = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
 #pragma omp parallel
     {
         gq_clean_vector_state();   /* per thread: see the comment at its definition */
 #pragma omp for schedule(static)
     for (int64_t m = 0; m < M; ++m) {
         const float *v = grad + m * (int64_t)d;
-        float best_abs = -1.0f, best_p = 0.0f;
-        int32_t best_k = 0;
-        for (int k = 0; k < K; ++k) {
-            const float *c = codebook + (int64_t)k * d;
-            float acc = 0.0f;
-            for (int j = 0; j < d; ++j) acc = fmaf(c[j], v[j], acc);
-            float a = fabsf(acc);
-            /* torch.argmax: first index of the maximum; a NaN counts as the maximum */
-            if (a > best_abs || (isnan(a) && !isnan(best_abs))) {
-                best_abs = a;
-                best_p = acc;
-                best_k = k;
+        __m256 best_abs = _mm256_set1_ps(-1.0f), best_p = _mm256_setzero_ps(), unord = _mm256_setzero_ps();
+        __m256i best_k = _mm256_setzero_si256();
+        for (int kb = 0; kb < Kp; kb += 32) {
+            __m256 a0 = _mm256_setzero_ps(), a1 = a0, a2 = a0, a3 = a0;
+            const float *c = cT + kb;
+            for (int j = 0; j < d; ++j, c += Kp) {
+                const __m256 vj = _mm256_broadcast_ss(v + j);
+                a0 = _mm256_fmadd_ps(_mm256_load_ps(c), vj, a0);
+                a1 = _mm256_fmadd_ps(_mm256_load_ps(c + 8), vj, a1);
+                a2 = _mm256_fmadd_ps(_mm256_load_ps(c + 16), vj, a2);
+                a3 = _mm256_fmadd_ps(_mm256_load_ps(c + 24), vj, a3);
+            }
+            const __m256 acc[4] = {a0, a1, a2, a3};
+            for (int b = 0; b < 4; ++b) {
+                const __m256 ab = _mm256_and_ps(acc[b], absmask);
+                const __m256 gt = _mm256_cmp_ps(ab, best_abs, _CMP_GT_OQ);
+                best_abs = _mm256_blendv_ps(best_abs, ab, gt);
+                best_p = _mm256_blendv_ps(best_p, acc[b], gt);
+                best_k = _mm256_castps_si256(_mm256_blendv_ps(_mm256_castsi256_ps(best_k),
+                             _mm256_castsi256_ps(_mm256_add_epi32(lane_id, _mm256_set1_epi32(kb + 8 * b))), gt));
+                unord = _mm256_or_ps(unord, _mm256_cmp_ps(acc[b], acc[b], _CMP_UNORD_Q));
             }
         }
-        codes[m] = best_k;
-        u[m] = best_p;
+        if (_mm256_movemask_ps(unord)) {
+            hsq_encode_one_scalar(v, codebook, d, K, codes + m, u + m);
+            continue;
+        }
+        float fa[8], fp[8];
+        int32_t fk[8];
+        _mm256_storeu_ps(fa, best_abs);
+        _mm256_storeu_ps(fp, best_p);
+        _mm256_storeu_si256((__m256i *)fk, best_k);
+        int w = 0;
+        for (int i = 1; i < 8; ++i)
+            if (fa[i] > fa[w] || (fa[i] == fa[w] && fk[i] < fk[w])) w = i;
+        codes[m] = fk[w];
+        u[m] = fp[w];
     }
     }
+    free(cT);
 }
 
 /* torch.min / torch.max over the whole tensor

@@ -69,6 +69,20 @@ def hsq_encode(grad, codebook):
     return codes, u
 
 
+def hsq_encode_scalar(grad, codebook):
+    """The literal one-codeword-at-a-time form of hsq_encode (what the blocked form must equal bit for bit)."""
+    codebook = _f32(codebook)
+    K, d = codebook.shape
+    g = _f32(grad).reshape(-1)
+    assert g.size % d == 0
+    M = g.size // d
+    codes = np.empty(M, np.int32)
+    u = np.empty(M, np.float32)
+    lib().gq_oracle_hsq_encode_scalar(_p(g, _f32p), _p(codebook, _f32p), ctypes.c_int64(M), ctypes.c_int(d),
+                                      ctypes.c_int(K), _p(codes, _i32p), _p(u, _f32p))
+    return codes, u
+
+
 def minmax(u):
     u = _f32(u).reshape(-1)
     out = np.empty(2, np.float32)

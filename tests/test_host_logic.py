@@ -420,6 +420,44 @@ def test_quantizer_ranks_gloo_fewer_records_than_slots(tmp_path, oracle, exchang
         assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
 
 
+@pytest.mark.parametrize("world,bad_rank,bad_modes,expect", [
+    (2, 1, "direct,split", "allgather"), (4, 2, "direct,split", "allgather"), (8, 5, "direct,split", "allgather"),
+    (2, 0, "allgather", None)])
+def test_autotune_drops_a_transport_that_fails_on_one_rank(tmp_path, world, bad_rank, bad_modes, expect):
+    """exchange.autotune: a transport that raises on ONE rank must not desynchronise the collectives (round-2 advisor:
+    the failing rank skipped a barrier its peers sat in).  The preflight catches it before any peer is engaged, the
+    all-reduced flag drops the transport on every rank, nobody runs or times it, all ranks return the same surviving
+    mode, and the job ends (a hang fails the timeout)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() + 17 * world + bad_rank) % 2000))
+    out = str(tmp_path / "at")
+    script = os.path.join(HERE, "_autotune_worker.py")
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), out, str(bad_rank), bad_modes], env=env,
+                              stderr=subprocess.DEVNULL) for r in range(world)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=120) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    got = [open(out + "_rank%d.txt" % r).read().split("\n") for r in range(world)]
+    modes = set(g[0] for g in got)
+    assert len(modes) == 1, "ranks disagree: %r" % modes
+    assert len(set(g[1] for g in got)) == 1, "ranks hold different timing tables"
+    mode = modes.pop()
+    assert mode not in bad_modes.split(",")
+    if expect:
+        assert mode == expect
+    for r, g in enumerate(got):
+        calls = g[2].split(",")
+        for m in bad_modes.split(","):
+            assert m not in calls, "rank %d ran dropped transport %r" % (r, m)
+            assert "(%r, 1e+30)" % m in g[1]
+        for m in ("allgather", "direct", "split"):
+            if m not in bad_modes.split(","):
+                assert calls.count(m) == 5      # two untimed + three timed, on every rank alike
+
+
 def test_run_reference_launcher_shadows_the_reference_packages(tmp_path):
     """the launcher puts this implementation's `compressors` / `quantizers`
     ahead of the ones that sit next to the reference's main.py, keeps the script's other local

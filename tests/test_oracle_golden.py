@@ -65,6 +65,42 @@ def test_hsq_compress_matches_reference(oracle, name):
     assert _same(dec, g["decoded"]), "decoded tensor differs bitwise"
 
 
+@pytest.mark.parametrize("name", HSQ_CASES)
+def test_hsq_encode_scalar_form_matches_reference(oracle, name):
+    """The one-codeword-at-a-time restatement (the blocked form's own checker) against the same fixtures."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cb = _cb(int(g["dim"]), int(g["K"]))
+    codes, u = oracle.hsq_encode_scalar(g["x"], cb)
+    assert np.array_equal(codes, g["codes"].astype(np.int32))
+    if codes.size > 1:
+        assert _same(u, g["u"])
+
+
+@pytest.mark.parametrize("d,K", [(16, 256), (8, 256), (32, 256), (12, 512), (8, 32), (16, 16), (10, 40), (16, 1024)])
+def test_hsq_encode_blocked_form_equals_scalar_form(oracle, d, K):
+    """Eight independent fmaf chains per register == the chains one after the other: ties (first index), signed
+    zeros, NaN / Inf subvectors, K not a multiple of 32, unnormalised codebooks."""
+    rng = np.random.RandomState(d * 1000 + K)
+    cb = rng.standard_normal((K, d)).astype(np.float32)
+    cb[K // 3] = cb[1]                      # exact duplicate rows: ties between lanes and between blocks
+    cb[K - 1] = -cb[0]
+    M = 4096
+    x = rng.standard_normal((M, d)).astype(np.float32)
+    x[10] = 0.0
+    x[11] = -0.0
+    x[12, 3] = np.nan
+    x[13, 0] = np.inf
+    x[14, d - 1] = -np.inf
+    x[15] = cb[1] * 3.0
+    x[16:200] = np.round(x[16:200])         # small integers: many exact ties
+    x[200:300] *= 1e-30
+    x[300:400] *= 1e30
+    a = oracle.hsq_encode(x, cb)
+    b = oracle.hsq_encode_scalar(x, cb)
+    assert np.array_equal(a[0], b[0])
+    assert _same(a[1], b[1])
+
+
 HSQD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "hsqd_*.npz")))
 
 
