@@ -98,12 +98,35 @@ def self_launch(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def usable_cpus():
+    """CPUs this process may actually keep busy: the scheduler affinity, capped by the cgroup's CPU quota.  (The GPU
+    boxes show 256 host CPUs under a quota of 16: 128 OpenMP threads run a 25 M-element compress in bursts at 5.6e9
+    elements/s and, sustained, get throttled to 3.7e8 -- a fifth of what 16 threads sustain.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    why = "sched_getaffinity"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(quota) // int(period) >= 1 and int(quota) // int(period) < n:
+            n, why = int(quota) // int(period), "cgroup cpu.max %s/%s" % (quota, period)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and 1 <= q // per < n:
+                n, why = q // per, "cgroup cfs quota %d/%d" % (q, per)
+        except Exception:
+            pass
+    return n, why
+
+
 def cpu_baseline(g_host, cb):
     """Time the CPU oracle's whole compress (encode + min/max + levels) on the rank-0 gradient, repeated until about
     10 s of wall time have been spent (bounded sample), on all host cores and on ONE thread."""
     import oracle
     oracle.build()
-    threads = oracle.num_threads()
+    avail, why = usable_cpus()
+    threads = max(1, min(oracle.num_threads(), avail))
+    oracle.set_num_threads(threads)
     oracle.hsq_compress(g_host[:16 * 20000], cb, N_BIT, 0)       # warm the thread pool
     n = SIZE
     reps, spent = 0, 0.0
@@ -131,7 +154,7 @@ def cpu_baseline(g_host, cb):
                       "reference built with -mavx2 -mfma: every score is the reference's ascending fmaf chain, eight "
                       "codewords per 256-bit register (oracle/gq_oracle.c); min/max single-threaded like torch's"
                       % (reps, spent, threads, spent * threads),
-            "host_cpus": os.cpu_count(),
+            "host_cpus": os.cpu_count(), "usable_cpus": avail, "usable_cpus_from": why,
             "reference_python": {"value_8_threads": 2.17e7, "value_1_thread": 5.2e6, "unit": "elements/s",
                                  "note": "the reference itself (PyTorch CPU ops), measured in the survey container, not on "
                                          "this box (BASELINE.md section 2); it cannot travel to the GPU box"}}
@@ -299,8 +322,8 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     out = torch.empty(SIZE, dtype=torch.float32, device=dev)
     seed = 1234 + rank
 
-    def compress(g):
-        native.hsq_encode(g, cb, codes, u, partials)
+    def compress(g, profile_slot=-1):
+        native.hsq_encode(g, cb, codes, u, partials, profile_slot=profile_slot)
         native.hsq_levels(u, N_BIT, args.random, None, seed, partials, lb_ub, levels)
 
     def decode(buf):
@@ -309,8 +332,8 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     if world > 1:
         s_codes, s_la, s_lb, s_lbub = swire.views(sex.local[0])
 
-        def compress_split(g):
-            native.hsq_encode(g, cb, s_codes, u, partials)
+        def compress_split(g, profile_slot=-1):
+            native.hsq_encode(g, cb, s_codes, u, partials, profile_slot=profile_slot)
             native.hsq_levels(u[:swire.MA], N_BIT, args.random, None, seed, partials, s_lbub, s_la)
             native.hsq_levels(u[swire.MA:], N_BIT, args.random, None, seed + 7919, partials, s_lbub, s_lb)
 
@@ -323,13 +346,13 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
             native.hsq_decode_sum_packed(buf, swire.MB, cb, N_BIT, out[swire.MA * C_DIM:], world,
                                          swire.codes_off + swire.MA, swire.levels_b_off, swire.lbub_off)
 
-    def step(i, mode):
+    def step(i, mode, profile_slot=-1):
         g = grads[i % 3]
         if mode == "split":
-            compress_split(g)
+            compress_split(g, profile_slot)
             exchange_decode_split()
         else:
-            compress(g)
+            compress(g, profile_slot)
             decode(ex.run(mode) if world > 1 else ex.gathered)
 
     # ---- transport: requested, or the fastest of the three (exchange + decode, max over ranks) ----------
@@ -361,7 +384,7 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
         step(i, mode)
 
     # HIP events on the dominant kernel, live in the timed region: a start/stop pair ATTACHED to the encode's
-    # dispatch (hipExtLaunchKernelGGL through gq_profile_arm) on up to 16 of the steps.  An event bracket
+    # dispatch (hipExtLaunchKernelGGL: gq_hsq_encode_ex's profile_slot) on up to 16 of the steps.  An event bracket
     # recorded around the call would also measure 5-8 us of queue bubbles and put them into the timed
     # region (calibrated below for reference).
     stride = max(1, -(-args.steps // 16))          # at most 16 armed steps: an armed dispatch costs a few us of its own
@@ -370,9 +393,7 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i in slot_of:
-            native.profile_arm(slot_of[i])
-        step(i, mode)
+        step(i, mode, slot_of.get(i, -1))
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -512,15 +533,17 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
     for i in range(prewarm + args.warmup):      # (--exchange auto: the first apply() times the transports)
         step(i)
     # HIP events attached to the dominant kernel's dispatch on up to 16 of the timed steps (HSQ: the multi-tensor
-    # prefilter encode takes them, gq_profile_arm; the first launch after arming is that encode)
+    # prefilter encode takes them: gq_hsq_batch.profile_slot)
     stride = max(1, -(-args.steps // 16))
     armed = list(range(0, args.steps, stride))[:16] if hsq else []
     slot_of = {prewarm + args.warmup + i: k for k, i in enumerate(armed)}
+    Grp = BatchedHSQ if hsq else BatchedQSGD
+    grp = [g[2] for g in q._groups if isinstance(g[2], Grp) and not getattr(g[2], "wide", False)][0]
     barrier()
     t0 = time.perf_counter()
     for i in range(prewarm + args.warmup, prewarm + args.warmup + args.steps):
         if i in slot_of:
-            native.profile_arm(slot_of[i])
+            grp.profile_slot = slot_of[i]
         step(i)
     barrier()
     dt = time.perf_counter() - t0
@@ -531,8 +554,6 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
     identical = ranks_agree(torch, dist, world, [p.grad.data for p in params if p.numel() > 1000][:8])
 
     # untimed: the kernels of the step alone, back to back between two HIP events on the stream they are launched on
-    Grp = BatchedHSQ if hsq else BatchedQSGD
-    grp = [g[2] for g in q._groups if isinstance(g[2], Grp) and not getattr(g[2], "wide", False)][0]
     for p, g in zip(params, grads[0]):
         p.grad = g.view(g.shape)
     gl = [params[i].grad.data for i in grp.idxs]

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgq_hsq.so")
-SOURCES = ["gq_common.hip", "hsq_encode.hip", "hsq_encode_pf.hip", "hsq_encode_pfd.hip", "hsq_levels.hip", "hsq_batched.hip", "hsq_decode.hip", "qsgd.hip", "qsgd_batched.hip", "qsgd_wide.hip", "pvq.hip"]
+SOURCES = ["gq_common.hip", "gq_api.hip", "hsq_encode.hip", "hsq_encode_pf.hip", "hsq_encode_pfd.hip", "hsq_levels.hip", "hsq_batched.hip", "hsq_decode.hip", "qsgd.hip", "qsgd_batched.hip", "qsgd_wide.hip", "pvq.hip"]
 # -ffp-contract=off: the reference's elementwise ops are separately rounded; hipcc's
 # default ("fast") would fuse the decode's mul/add and the level quantiser's sub/div.
 # -packed-fp32-ops (target feature off): no v_pk_{fma,mul,add}_f32.  One instantiation of the encode kernel came out

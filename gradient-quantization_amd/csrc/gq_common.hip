@@ -19,32 +19,33 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
-// ---- per-dispatch timing (gq_profile_arm / gq_profile_read) -------------------------------------------
-static thread_local int g_armed_slot = -1;
+// ---- per-dispatch timing (profile_slot of the encode entry points / gq_profile_read) -----------------------
 static hipEvent_t g_prof_events[GQ_PROFILE_SLOTS][2];
 static bool g_prof_created[GQ_PROFILE_SLOTS];
 
-bool profile_take(hipEvent_t *start, hipEvent_t *stop) {
-    const int slot = g_armed_slot;
-    if (slot < 0) return false;
-    g_armed_slot = -1;
+bool profile_events(int slot, hipEvent_t *start, hipEvent_t *stop) {
+    if (slot < 0 || slot >= GQ_PROFILE_SLOTS) return false;
+    if (!g_prof_created[slot]) {
+        if (hipEventCreate(&g_prof_events[slot][0]) != hipSuccess || hipEventCreate(&g_prof_events[slot][1]) != hipSuccess)
+            return false;
+        g_prof_created[slot] = true;
+    }
     *start = g_prof_events[slot][0];
     *stop = g_prof_events[slot][1];
     return true;
 }
 
 int cu_count() {
-    static thread_local int cached_dev = -1;
-    static thread_local int cached_cus = 0;
+    // compute units per device, looked up once per device (a plain table: a racing first use writes the same value)
+    static int cus[64];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (dev != cached_dev) {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cached_dev = dev;
-        cached_cus = n;
+        cus[dev] = n;
     }
-    return cached_cus;
+    return cus[dev];
 }
 
 __global__ void axpy_inplace_kernel(float *__restrict__ y, const float *__restrict__ x, float a, int64_t n) {
@@ -74,7 +75,7 @@ static inline int grid_for(int64_t n, int block) {
 
 }  // namespace gq
 
-GQ_API int gq_abi_version(void) { return 1; }
+GQ_API int gq_abi_version(void) { return 2; }
 
 GQ_API const char *gq_last_error(void) { return gq::last_error_buf(); }
 
@@ -129,49 +130,6 @@ GQ_API int gq_mean_rows(const void *rows, int64_t row_stride_bytes, int R, int64
     hipLaunchKernelGGL(gq::mean_rows_kernel, dim3(gq::grid_for(n, 256)), dim3(256), 0, gq::as_stream(stream),
                        static_cast<const uint8_t *>(rows), row_stride_bytes, R, n, out);
     GQ_CHECK_LAUNCH("gq_mean_rows");
-    return GQ_OK;
-}
-
-// ---- caller-supplied draws for the multi-tensor level kernels (gq_hsq_given_draws) -------------------------
-namespace gq {
-static thread_local const float *g_given_draws = nullptr;
-const float *take_given_draws() {
-    const float *r = g_given_draws;
-    g_given_draws = nullptr;
-    return r;
-}
-}  // namespace gq
-
-GQ_API int gq_hsq_given_draws(const float *r_flat) {
-    if (!r_flat) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_given_draws: null pointer");
-    gq::g_given_draws = r_flat;
-    return GQ_OK;
-}
-
-// ---- plain (non-aggregate) semantics for the next multi-tensor decode (gq_decode_plain_next) ------------------
-namespace gq {
-static thread_local bool g_decode_plain = false;
-bool take_decode_plain() {
-    const bool p = g_decode_plain;
-    g_decode_plain = false;
-    return p;
-}
-}  // namespace gq
-
-GQ_API int gq_decode_plain_next(void) {
-    gq::g_decode_plain = true;
-    return GQ_OK;
-}
-
-
-GQ_API int gq_profile_arm(int slot) {
-    if (slot < 0 || slot >= GQ_PROFILE_SLOTS) return gq::fail(GQ_ERR_INVALID_ARG, "gq_profile_arm: slot %d", slot);
-    if (!gq::g_prof_created[slot]) {
-        if (hipEventCreate(&gq::g_prof_events[slot][0]) != hipSuccess || hipEventCreate(&gq::g_prof_events[slot][1]) != hipSuccess)
-            return gq::fail(GQ_ERR_HIP, "gq_profile_arm: hipEventCreate failed");
-        gq::g_prof_created[slot] = true;
-    }
-    gq::g_armed_slot = slot;
     return GQ_OK;
 }
 

@@ -7,6 +7,8 @@
 #include "gq_hsq.h"
 
 #define GQ_API extern "C" __attribute__((visibility("default")))
+// per-variant launchers behind the exported entry points of gq_api.hip (gq_internal.h): C names, not exported
+#define GQ_INTERNAL extern "C" __attribute__((visibility("hidden")))
 
 namespace gq {
 
@@ -18,12 +20,9 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 // Number of compute units of the current device (cached).
 int cu_count();
-// the draws handed over by gq_hsq_given_draws on this thread (once), or nullptr
-const float *take_given_draws();
-// gq_decode_plain_next was called on this thread since the last multi-tensor decode (once)
-bool take_decode_plain();
-// true (once) if gq_profile_arm was called on this thread: the events to attach to the next dispatch
-bool profile_take(hipEvent_t *start, hipEvent_t *stop);
+// the start / stop events of a gq_profile_read slot (created on first use); false for slot < 0 or a failure:
+// the caller then launches plainly
+bool profile_events(int slot, hipEvent_t *start, hipEvent_t *stop);
 
 #define GQ_CHECK_LAUNCH(what)                                                              \
     do {                                                                                   \
@@ -101,6 +100,22 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// GQ_LEVELS_PACKED6: four 6-bit levels per three bytes (include/gq_hsq.h)
+struct Packed6 {};
+__device__ __forceinline__ void store_packed6(uint8_t *dst, int l0, int l1, int l2, int l3) {   // dst = section + 3 * group
+    const unsigned w = (unsigned)(l0 & 63) | ((unsigned)(l1 & 63) << 6) | ((unsigned)(l2 & 63) << 12) | ((unsigned)(l3 & 63) << 18);
+    dst[0] = (uint8_t)w;
+    dst[1] = (uint8_t)(w >> 8);
+    dst[2] = (uint8_t)(w >> 16);
+}
+// the four levels of group g as one word: three bytes at section + 3g (an unaligned dword read; the fourth byte is the
+// next group's, or padding / the next section of the wire: every section is followed by at least one more byte)
+__device__ __forceinline__ unsigned load_packed6(const uint8_t *src) {
+    unsigned w;
+    __builtin_memcpy(&w, src, 4);
+    return w;
 }
 
 // Counter-based uniform [0,1) generator for GQ_RANDOM_DEVICE: a 32-bit avalanche hash (two

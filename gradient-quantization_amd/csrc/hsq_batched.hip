@@ -46,7 +46,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
         const float range = ub - lb;
         const bool flat = (lb - ub) == 0.0f;
         const f32x4 uu = *reinterpret_cast<const f32x4 *>(u_flat + 4 * i);
-        LevelT out[4];
+        typename std::conditional<std::is_same<LevelT, Packed6>::value, int, LevelT>::type out[4];   // Packed6: past-the-end slots stay 0
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if constexpr (std::is_same<LevelT, float>::value) {   // n_bit == 32: the projections travel as they are
@@ -65,8 +65,15 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
                     l += (prob > rr) ? 1 : 0;
                 }
             }
-            out[e] = (LevelT)l;
+            if constexpr (std::is_same<LevelT, Packed6>::value)
+                out[e] = local + e < m ? l : 0;
+            else
+                out[e] = (LevelT)l;
         }
+        if constexpr (std::is_same<LevelT, Packed6>::value) {
+            store_packed6(wire + rec[4] + 3 * (local >> 2), out[0], out[1], out[2], out[3]);   // `local` is a multiple of 4
+            continue;
+        } else {
         LevelT *dst = reinterpret_cast<LevelT *>(wire + rec[4]) + local;   // sections start 16-byte aligned
         if (local + 3 < m) {
             typedef LevelT L4 __attribute__((ext_vector_type(4)));
@@ -74,6 +81,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
             *reinterpret_cast<L4 *>(dst) = o4;
         } else {
             for (int e = 0; e < 4 && local + e < m; ++e) dst[e] = out[e];
+        }
         }
     }
 }
@@ -84,6 +92,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
 // into the error buffer named by seg_table[seg][7] (skipped when 0).  `grad` is what the EF encode
 // left there (grad + scale*error_old).  One thread per (padded subvector, quarter); the four
 // threads of a subvector compute the same level, quarter 0 stores it.
+template <bool PACKED6>
 __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
@@ -118,12 +127,23 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_kernel(
             }
         }
         if (q == 0) {
-            wire[rec[4] + local] = (uint8_t)l;
+            if constexpr (!PACKED6) wire[rec[4] + local] = (uint8_t)l;
             if (local == 0) {
                 float *lbub = reinterpret_cast<float *>(wire + rec[5]);
                 lbub[0] = lb;
                 lbub[1] = ub;
             }
+        }
+        if constexpr (PACKED6) {
+            // the four subvectors of a group sit in 16 consecutive lanes (4 quarters each; groups never straddle a
+            // tile); the group's first lane collects their levels.  Lanes of subvectors past the tensor's end have left
+            // the loop (`continue` above), so their levels are read as 0 through the ballot.
+            const int lane = threadIdx.x & 63, base = lane & ~15;
+            const int l1 = __shfl(l, base + 4, 64), l2 = __shfl(l, base + 8, 64), l3 = __shfl(l, base + 12, 64);
+            const int64_t m = rec[1];
+            if ((lane & 15) == 0)
+                store_packed6(wire + rec[4] + 3 * (local >> 2), l, local + 1 < m ? l1 : 0, local + 2 < m ? l2 : 0,
+                              local + 3 < m ? l3 : 0);
         }
         float *err = reinterpret_cast<float *>(rec[7]);
         if (!err) continue;
@@ -204,6 +224,46 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_kernel(
 // and the four 4-lane teams of every ds_read_b128 lane group read copies 0..3.
 constexpr int BT4_THREADS = 1024;
 
+constexpr int BT4_CHUNK = 8;   // payloads whose words are requested together (see hsq_decode_sum_d16u8_kernel)
+
+// LDS byte address of a codebook row for this lane: [0, 0, code_k, lane_const] by one v_perm_b32
+template <int K4>
+__device__ __forceinline__ unsigned bt4_row_addr(unsigned c4, unsigned lane_const) {
+    return __builtin_amdgcn_perm(c4, lane_const, 0x0c0c0000u | ((4u + K4) << 8));
+}
+
+template <bool FIRST, bool PACKED6>
+__device__ __forceinline__ void bt4_payload(f32x4 (&acc)[4], unsigned c4, unsigned l4, float lb, float ub, float inv_s, int q,
+                                            const char *cb_bytes, unsigned lane_const) {
+    const float range = ub - lb;
+    // lane q of a team works out the norm of subvector q; the team shares them by quad-permute DPP moves
+    const unsigned lq = PACKED6 ? ((l4 >> (6 * q)) & 63u) : ((l4 >> (8 * q)) & 255u);
+    float n_own = (float)lq * range;   // prob_scalar:31-32, unfused
+    n_own = n_own * inv_s;                                   // == / 2^n_bit exactly
+    n_own = n_own + lb;
+    const int n_bits = __builtin_bit_cast(int, n_own);
+    const float n_team[4] = {
+        __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0x00, 0xF, 0xF, true)),
+        __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0x55, 0xF, 0xF, true)),
+        __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xAA, 0xF, 0xF, true)),
+        __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xFF, 0xF, 0xF, true))};
+    const unsigned a[4] = {bt4_row_addr<0>(c4, lane_const), bt4_row_addr<1>(c4, lane_const), bt4_row_addr<2>(c4, lane_const),
+                           bt4_row_addr<3>(c4, lane_const)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float n = n_team[k];
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(cb_bytes + a[k]);
+        const f32x4 n4 = {n, n, n, n};
+        const f32x4 dec = c * n4;
+        if constexpr (FIRST) {
+            acc[k] = dec;
+        } else {
+            acc[k] = acc[k] + dec;
+        }
+    }
+}
+
+template <bool PACKED6>   // levels as four 6-bit values per three bytes (GQ_LEVELS_PACKED6) instead of a byte each
 __global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
@@ -217,7 +277,8 @@ __global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
     const float inv_s = 1.0f / (float)(1 << n_bit);
     const MeanDiv md = mean_div_of(R, !plain);
     const int q = threadIdx.x & 3;
-    const float *const my_cb = s_cb4 + ((threadIdx.x >> 3) & 3) * 16 + 4 * q;   // this lane's copy and quarter
+    const unsigned lane_const = (unsigned)(((threadIdx.x >> 3) & 3) * 64 + 16 * q);   // this lane's copy and quarter, bytes
+    const char *const cb_bytes = reinterpret_cast<const char *>(s_cb4);
     const int64_t total = ntiles * 64;   // (group of 4 padded subvectors, quarter) items
     const int64_t stride = (int64_t)gridDim.x * BT4_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * BT4_THREADS + threadIdx.x; i < total; i += stride) {
@@ -229,39 +290,37 @@ __global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
         const int64_t left = rec[1] - local;
         if (left <= 0) continue;
         const int nv = left < 4 ? (int)left : 4;
-        const int64_t code_off = rec[3] + local, level_off = rec[4] + local, lbub_off = rec[5];
+        const int64_t code_off = rec[3] + local, level_off = rec[4] + (PACKED6 ? 3 * (local >> 2) : local), lbub_off = rec[5];
         f32x4 acc[4];
-        auto payload = [&](int r, auto first) {   // first: payload 0 initialises, the others accumulate
-            const uint8_t *p = gathered + (int64_t)r * user_stride;
-            const unsigned c4 = *reinterpret_cast<const unsigned *>(p + code_off);    // sections are padded to 16 B:
-            const unsigned l4 = *reinterpret_cast<const unsigned *>(p + level_off);   // reading past M stays inside
-            const float *lbub = reinterpret_cast<const float *>(p + lbub_off);
-            const float lb = lbub[0], range = lbub[1] - lb;
-            // lane q of a team works out the norm of subvector q; the team shares them by quad-permute DPP moves
-            float n_own = (float)((l4 >> (8 * q)) & 255u) * range;   // prob_scalar:31-32, unfused
-            n_own = n_own * inv_s;                                   // == / 2^n_bit exactly
-            n_own = n_own + lb;
-            const int n_bits = __builtin_bit_cast(int, n_own);
-            const float n_team[4] = {
-                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0x00, 0xF, 0xF, true)),
-                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0x55, 0xF, 0xF, true)),
-                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xAA, 0xF, 0xF, true)),
-                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xFF, 0xF, 0xF, true))};
+        // a chunk's words (codes, levels, lb, ub of up to BT4_CHUNK payloads) are all requested before the first is
+        // used: fetched inside the payload loop, every payload waited out its own round trip to memory
+        const uint8_t *p = gathered;
+        for (int r0 = 0; r0 < R; r0 += BT4_CHUNK) {
+            unsigned c4[BT4_CHUNK], l4[BT4_CHUNK];
+            float lb[BT4_CHUNK], ub[BT4_CHUNK];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float n = n_team[k];
-                const f32x4 c = *reinterpret_cast<const f32x4 *>(my_cb + ((c4 >> (8 * k)) & 255u) * 64);
-                const f32x4 n4 = {n, n, n, n};
-                const f32x4 dec = c * n4;
-                if constexpr (decltype(first)::value) {
-                    acc[k] = dec;
-                } else {
-                    acc[k] = acc[k] + dec;
+            for (int jj = 0; jj < BT4_CHUNK; ++jj) {
+                if (r0 + jj < R) {
+                    const uint8_t *pj = p + (int64_t)jj * user_stride;
+                    c4[jj] = *reinterpret_cast<const unsigned *>(pj + code_off);    // sections are padded to 16 B:
+                    l4[jj] = PACKED6 ? load_packed6(pj + level_off)
+                                     : *reinterpret_cast<const unsigned *>(pj + level_off);   // reading past M stays inside
+                    const float *lbub = reinterpret_cast<const float *>(pj + lbub_off);
+                    lb[jj] = lbub[0];
+                    ub[jj] = lbub[1];
                 }
             }
-        };
-        payload(0, std::true_type{});
-        for (int r = 1; r < R; ++r) payload(r, std::false_type{});
+            p += (int64_t)BT4_CHUNK * user_stride;
+#pragma unroll
+            for (int jj = 0; jj < BT4_CHUNK; ++jj) {
+                if (r0 + jj < R) {
+                    if (jj == 0 && r0 == 0)
+                        bt4_payload<true, PACKED6>(acc, c4[jj], l4[jj], lb[jj], ub[jj], inv_s, q, cb_bytes, lane_const);
+                    else
+                        bt4_payload<false, PACKED6>(acc, c4[jj], l4[jj], lb[jj], ub[jj], inv_s, q, cb_bytes, lane_const);
+                }
+            }
+        }
         float *o = out + rec[6] + local * 16 + 4 * q;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -461,8 +520,8 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_any_kernel(
 template <typename CodeT, typename LevelT, bool ERR>
 static int launch_decode_any(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
                              int64_t user_stride, int R, const float *cb, int d, int K, int n_bit, float *out,
-                             hipStream_t st, const char *what) {
-    const int plain = (!ERR && take_decode_plain()) ? 1 : 0;   // gq_decode_plain_next: the ring's hop, not the aggregate
+                             hipStream_t st, const char *what, int plain_arg) {
+    const int plain = (!ERR && plain_arg) ? 1 : 0;   // the ring's hop / a round trip, not the aggregate
     const size_t cb_bytes = (size_t)K * d * sizeof(float);
     const int in_lds = cb_bytes <= 64 * 1024;
     const size_t lds = in_lds ? cb_bytes : 0;
@@ -485,7 +544,7 @@ static int launch_decode_any(const int64_t *seg_table, const int32_t *tile_seg, 
 template <bool ERR>
 static int decode_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                       const uint8_t *gathered, int64_t user_stride, int R, const float *cb, int d, int K,
-                      int code_bytes, int level_bytes, int n_bit, float *out, void *stream, const char *what) {
+                      int code_bytes, int level_bytes, int n_bit, float *out, void *stream, const char *what, int plain) {
     if (nseg < 1 || ntiles < 1 || R < 1 || d < 1 || K < 1 || n_bit < 1 || (n_bit > 30 && level_bytes != 0))
         return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes", what);
     if (level_bytes == 0) n_bit = 1;   // f32 norms: no level scaling
@@ -495,7 +554,7 @@ static int decode_any(const int64_t *seg_table, const int32_t *tile_seg, int nse
 #define GQ_ANY_CASE(CB, LB, CT, LT)                                                                                  \
     if (code_bytes == CB && level_bytes == LB)                                                                      \
         return launch_decode_any<CT, LT, ERR>(seg_table, tile_seg, ntiles, gathered, user_stride, R, cb, d, K, n_bit, \
-                                              out, st, what);
+                                              out, st, what, plain);
     GQ_ANY_CASE(1, 0, uint8_t, float)
     GQ_ANY_CASE(4, 0, int32_t, float)
     GQ_ANY_CASE(1, 1, uint8_t, uint8_t)
@@ -517,68 +576,71 @@ static inline int64_t bt_grid(int64_t items) {
 
 }  // namespace gq
 
-GQ_API int gq_hsq_levels_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                 const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                                 uint64_t seed, uint8_t *wire, void *stream) {
+GQ_INTERNAL int gqi_hsq_levels_batched_d16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                           const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
+                                           uint64_t seed, const float *r_flat, const float *ef_codebook, int packed6,
+                                           uint8_t *wire, void *stream) {
+    // ef_codebook != NULL: additionally error = v - decode(wire) for the rows that have an error buffer (d = 16)
     if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > 8)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: bad sizes");
     if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !wire)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: null pointer");
-    const float *r_flat = random_mode == GQ_RANDOM_GIVEN ? gq::take_given_draws() : nullptr;
     if (random_mode == GQ_RANDOM_GIVEN && !r_flat)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: GQ_RANDOM_GIVEN needs gq_hsq_given_draws() on this thread first");
-    if (((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > 255)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: levels do not fit uint8");
-    hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<uint8_t>, dim3((unsigned)gq::bt_grid(ntiles * 16)), dim3(gq::BT_THREADS), 0,
-                       gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed,
-                       r_flat, wire);
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: GQ_RANDOM_GIVEN needs r_flat");
+    if (((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > (packed6 ? 63 : 255))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: levels do not fit %s", packed6 ? "6 bits" : "uint8");
+    const dim3 block(gq::BT_THREADS);
+    hipStream_t st = gq::as_stream(stream);
+    if (ef_codebook && packed6)
+        hipLaunchKernelGGL(gq::hsq_levels_ef_batched_kernel<true>, dim3((unsigned)gq::bt_grid(ntiles * 256)), block, 0, st,
+                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, wire);
+    else if (ef_codebook)
+        hipLaunchKernelGGL(gq::hsq_levels_ef_batched_kernel<false>, dim3((unsigned)gq::bt_grid(ntiles * 256)), block, 0, st,
+                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, wire);
+    else if (packed6)
+        hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<gq::Packed6>, dim3((unsigned)gq::bt_grid(ntiles * 16)), block, 0, st,
+                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, wire);
+    else
+        hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<uint8_t>, dim3((unsigned)gq::bt_grid(ntiles * 16)), block, 0, st,
+                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, wire);
     GQ_CHECK_LAUNCH("gq_hsq_levels_batched");
     return GQ_OK;
 }
 
-GQ_API int gq_hsq_levels_batched_ef(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                    const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                                    uint64_t seed, const float *codebook, uint8_t *wire, void *stream) {
-    if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > 8)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef: bad sizes");
-    if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !codebook || !wire)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef: null pointer");
-    const float *r_flat = random_mode == GQ_RANDOM_GIVEN ? gq::take_given_draws() : nullptr;
-    if (random_mode == GQ_RANDOM_GIVEN && !r_flat)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef: GQ_RANDOM_GIVEN needs gq_hsq_given_draws() on this thread first");
-    if (((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > 255)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef: levels do not fit uint8");
-    hipLaunchKernelGGL(gq::hsq_levels_ef_batched_kernel, dim3((unsigned)gq::bt_grid(ntiles * 256)), dim3(gq::BT_THREADS),
-                       0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed,
-                       r_flat, codebook, wire);
-    GQ_CHECK_LAUNCH("gq_hsq_levels_batched_ef");
-    return GQ_OK;
-}
-
-GQ_API int gq_hsq_decode_sum_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                     const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                     const float *codebook, int n_bit, float *out, void *stream) {
-    const int plain = gq::take_decode_plain() ? 1 : 0;   // consumed even when the call is refused below
+GQ_INTERNAL int gqi_hsq_decode_sum_batched_d16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                               const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                               const float *codebook, int n_bit, int packed6, float *out, int plain,
+                                               void *stream) {
     if (nseg < 1 || ntiles < 1 || R < 1 || n_bit < 1 || n_bit > 8)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: bad sizes");
     if (!seg_table || !tile_seg || !gathered || !codebook || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: null pointer");
+    plain = plain ? 1 : 0;
     if ((user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0) {
         static const int bpc = [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gq::hsq_decode_sum_batched4_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gq::hsq_decode_sum_batched4_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gq::hsq_decode_sum_batched4_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
             (void)hipGetLastError();
             int n = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gq::hsq_decode_sum_batched4_kernel, gq::BT4_THREADS,
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gq::hsq_decode_sum_batched4_kernel<false>, gq::BT4_THREADS,
                                                              (size_t)64 * 1024) != hipSuccess || n < 1)
                 n = 1;
             return n;
         }();
         int64_t blocks = (ntiles * 64 + gq::BT4_THREADS - 1) / gq::BT4_THREADS;
         if (blocks > (int64_t)gq::cu_count() * bpc) blocks = (int64_t)gq::cu_count() * bpc;
-        hipLaunchKernelGGL(gq::hsq_decode_sum_batched4_kernel, dim3((unsigned)blocks), dim3(gq::BT4_THREADS),
-                           (size_t)64 * 1024, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
-                           user_stride_bytes, R, codebook, n_bit, out, plain);
+        if (packed6)
+            hipLaunchKernelGGL(gq::hsq_decode_sum_batched4_kernel<true>, dim3((unsigned)blocks), dim3(gq::BT4_THREADS),
+                               (size_t)64 * 1024, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
+                               user_stride_bytes, R, codebook, n_bit, out, plain);
+        else
+            hipLaunchKernelGGL(gq::hsq_decode_sum_batched4_kernel<false>, dim3((unsigned)blocks), dim3(gq::BT4_THREADS),
+                               (size_t)64 * 1024, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
+                               user_stride_bytes, R, codebook, n_bit, out, plain);
+    } else if (packed6) {
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched: packed levels need 4-byte aligned wires");
     } else {
         hipLaunchKernelGGL(gq::hsq_decode_sum_batched_kernel, dim3((unsigned)gq::bt_grid(ntiles * 256)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
@@ -588,17 +650,15 @@ GQ_API int gq_hsq_decode_sum_batched(const int64_t *seg_table, const int32_t *ti
     return GQ_OK;
 }
 
-GQ_API int gq_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                       const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                       const float *codebook, int d, int n_bit, float *out, void *stream) {
-    if (d == 16)
-        return gq_hsq_decode_sum_batched(seg_table, tile_seg, nseg, ntiles, gathered, user_stride_bytes, R, codebook,
-                                         n_bit, out, stream);
-    const int plain = gq::take_decode_plain() ? 1 : 0;   // consumed even when the call is refused below
+// K = 256, d = 8 or 32, byte codes and levels
+GQ_INTERNAL int gqi_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                             const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                             const float *codebook, int d, int n_bit, float *out, int plain, void *stream) {
     if (nseg < 1 || ntiles < 1 || R < 1 || n_bit < 1 || n_bit > 8)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched_d: bad sizes");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: bad sizes");
     if (!seg_table || !tile_seg || !gathered || !codebook || !out)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched_d: null pointer");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: null pointer");
+    plain = plain ? 1 : 0;
     if (d == 8) {
         hipLaunchKernelGGL(gq::hsq_decode_sum_batched_d_kernel<8>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 2)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
@@ -608,27 +668,25 @@ GQ_API int gq_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
                            user_stride_bytes, R, codebook, n_bit, out, plain);
     } else {
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched_d: d must be 8, 16 or 32 (K = 256)");
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched: this path serves d = 8 or 32 (K = 256)");
     }
-    GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched_d");
+    GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched");
     return GQ_OK;
 }
 
-GQ_API int gq_hsq_levels_batched_ef_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                      const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                                      uint64_t seed, const float *codebook, int d, uint8_t *wire, void *stream) {
-    if (d == 16)
-        return gq_hsq_levels_batched_ef(seg_table, tile_seg, nseg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed,
-                                        codebook, wire, stream);
+// error-feedback level kernel of d = 8 / 32 (K = 256): levels + error = v - decode(wire) in one launch
+GQ_INTERNAL int gqi_hsq_levels_batched_ef_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                            const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
+                                            uint64_t seed, const float *r_flat, const float *codebook, int d, uint8_t *wire,
+                                            void *stream) {
     if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > 8)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef_d: bad sizes");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: bad sizes");
     if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !codebook || !wire)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef_d: null pointer");
-    const float *r_flat = random_mode == GQ_RANDOM_GIVEN ? gq::take_given_draws() : nullptr;
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: null pointer");
     if (random_mode == GQ_RANDOM_GIVEN && !r_flat)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef_d: GQ_RANDOM_GIVEN needs gq_hsq_given_draws() on this thread first");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: GQ_RANDOM_GIVEN needs r_flat");
     if (((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > 255)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_ef_d: levels do not fit uint8");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: levels do not fit uint8");
     if (d == 8) {
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_d_kernel<8>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 2)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
@@ -638,32 +696,32 @@ GQ_API int gq_hsq_levels_batched_ef_d(const int64_t *seg_table, const int32_t *t
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
                            n_bit, random_mode, seed, r_flat, codebook, wire);
     } else {
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched_ef_d: d must be 8, 16 or 32 (K = 256)");
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched: the fused error-feedback form serves d = 8, 16 or 32 (K = 256)");
     }
-    GQ_CHECK_LAUNCH("gq_hsq_levels_batched_ef_d");
+    GQ_CHECK_LAUNCH("gq_hsq_levels_batched");
     return GQ_OK;
 }
 
-GQ_API int gq_hsq_levels_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                     const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                                     uint64_t seed, int level_bytes, uint8_t *wire, void *stream) {
+// any level width (1 / 2 / 4 bytes, or 0: the f32 projections travel); independent of (d, K)
+GQ_INTERNAL int gqi_hsq_levels_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                           const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
+                                           uint64_t seed, const float *r_flat, int level_bytes, uint8_t *wire, void *stream) {
     if (nseg < 1 || ntiles < 1 || n_bit < 1 || (n_bit > 30 && level_bytes != 0))
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: bad sizes");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: bad sizes");
     if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !wire)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: null pointer");
-    const float *r_flat = random_mode == GQ_RANDOM_GIVEN ? gq::take_given_draws() : nullptr;
-    if (random_mode == GQ_RANDOM_GIVEN && !r_flat)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: GQ_RANDOM_GIVEN needs gq_hsq_given_draws() on this thread first");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: null pointer");
+    if (random_mode == GQ_RANDOM_GIVEN && !r_flat && level_bytes != 0)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: GQ_RANDOM_GIVEN needs r_flat");
     if (level_bytes == 0) {   // n_bit == 32 (nearest_neighbor_compressor.py:14,75-76): u itself is the payload
         hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<float>, dim3((unsigned)gq::bt_grid(ntiles * 16)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
                            1, GQ_RANDOM_OFF, (uint64_t)0, (const float *)nullptr, wire);
-        GQ_CHECK_LAUNCH("gq_hsq_levels_batched_any");
+        GQ_CHECK_LAUNCH("gq_hsq_levels_batched");
         return GQ_OK;
     }
     const int64_t top = ((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0);
     if ((level_bytes == 1 && top > 255) || (level_bytes == 2 && top > 32767))
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: levels up to %lld do not fit %d byte(s)",
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: levels up to %lld do not fit %d byte(s)",
                         (long long)top, level_bytes);
     const dim3 grid((unsigned)gq::bt_grid(ntiles * 16)), block(gq::BT_THREADS);
     hipStream_t st = gq::as_stream(stream);
@@ -677,22 +735,23 @@ GQ_API int gq_hsq_levels_batched_any(const int64_t *seg_table, const int32_t *ti
         hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<int32_t>, grid, block, 0, st, seg_table, tile_seg, ntiles, u_flat,
                            seg_minmax, n_bit, random_mode, seed, r_flat, wire);
     else
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched_any: level_bytes must be 1, 2 or 4");
-    GQ_CHECK_LAUNCH("gq_hsq_levels_batched_any");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: level_bytes must be 0, 1, 2 or 4");
+    GQ_CHECK_LAUNCH("gq_hsq_levels_batched");
     return GQ_OK;
 }
 
-GQ_API int gq_hsq_decode_sum_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                         const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                         const float *codebook, int d, int K, int code_bytes, int level_bytes,
-                                         int n_bit, float *out, void *stream) {
+GQ_INTERNAL int gqi_hsq_decode_sum_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                               const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                               const float *codebook, int d, int K, int code_bytes, int level_bytes,
+                                               int n_bit, float *out, int plain, void *stream) {
     return gq::decode_any<false>(seg_table, tile_seg, nseg, ntiles, gathered, user_stride_bytes, R, codebook, d, K,
-                                 code_bytes, level_bytes, n_bit, out, stream, "gq_hsq_decode_sum_batched_any");
+                                 code_bytes, level_bytes, n_bit, out, stream, "gq_hsq_decode_sum_batched", plain);
 }
 
-GQ_API int gq_hsq_error_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                    const uint8_t *wire, const float *codebook, int d, int K, int code_bytes,
-                                    int level_bytes, int n_bit, void *stream) {
+// error = grad - decode(wire) for the rows that have an error buffer (ps_quantizer.py:39), any widths
+GQ_INTERNAL int gqi_hsq_error_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                          const uint8_t *wire, const float *codebook, int d, int K, int code_bytes,
+                                          int level_bytes, int n_bit, void *stream) {
     return gq::decode_any<true>(seg_table, tile_seg, nseg, ntiles, wire, 0, 1, codebook, d, K, code_bytes, level_bytes,
-                                n_bit, nullptr, stream, "gq_hsq_error_batched_any");
+                                n_bit, nullptr, stream, "gq_hsq_levels_batched (error feedback)", 0);
 }

@@ -98,8 +98,56 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_v4_kernel(
 // Same arithmetic and summation order as the kernels above.
 constexpr int DEC16_THREADS = 1024;
 constexpr int DEC16_LBUB = 64;
+#ifndef GQ_DEC16_CHUNK
+#define GQ_DEC16_CHUNK 3
+#endif
+#ifndef GQ_DEC16_WAVES
+#define GQ_DEC16_WAVES 8
+#endif
+constexpr int DEC16_CHUNK = GQ_DEC16_CHUNK;   // payloads whose words are requested together
 
-__global__ __launch_bounds__(DEC16_THREADS) void hsq_decode_sum_d16u8_kernel(
+// LDS byte address of a codebook row for this lane: code * 256 + (copy * 64 + quarter * 16), built by ONE v_perm_b32
+// from byte k of the packed codes and the lane's constant (< 256): [0, 0, code_k, lane_const].
+template <int K4>
+__device__ __forceinline__ unsigned row_addr(unsigned c4, unsigned lane_const) {
+    return __builtin_amdgcn_perm(c4, lane_const, 0x0c0c0000u | ((4u + K4) << 8));
+}
+
+// One payload's contribution to the four subvectors of a team (see the kernel): norms by lane q, shared through
+// quad-permute DPP moves; probabilistic_scalar_compressor.py:31-32 unfused, nearest_neighbor_compressor.py:88.
+template <bool FIRST, bool PACKED6>
+__device__ __forceinline__ void dec16_payload(f32x4 (&acc)[4], unsigned c4, unsigned l4, float lb, float range, float inv_s,
+                                              int q, const char *cb_bytes, unsigned lane_const) {
+    const float n_own = level_to_norm<unsigned>(PACKED6 ? ((l4 >> (6 * q)) & 63u) : ((l4 >> (8 * q)) & 255u), lb, range, inv_s);
+    const int n_bits = __builtin_bit_cast(int, n_own);
+    const float n_team[4] = {   // quad_perm [k,k,k,k]: lane k of the team broadcasts
+        __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0x00, 0xF, 0xF, true)),
+        __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0x55, 0xF, 0xF, true)),
+        __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xAA, 0xF, 0xF, true)),
+        __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xFF, 0xF, 0xF, true))};
+    const unsigned a[4] = {row_addr<0>(c4, lane_const), row_addr<1>(c4, lane_const), row_addr<2>(c4, lane_const),
+                           row_addr<3>(c4, lane_const)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float n = n_team[k];
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(cb_bytes + a[k]);
+        const f32x4 n4 = {n, n, n, n};
+        const f32x4 dec = c * n4;
+        if constexpr (FIRST) {
+            acc[k] = dec;
+        } else {
+            acc[k] = acc[k] + dec;
+        }
+    }
+}
+
+// Payloads are taken DEC16_CHUNK at a time: the 2 x DEC16_CHUNK dwords of a chunk are requested back to back and
+// only then consumed.  (Round 2 fetched a payload's two words inside the payload loop: every payload waited out its
+// own round trip to HBM, R of them in a row per item, and the kernel's time was write time PLUS R x 2.1 us --
+// latency, not arithmetic.)
+template <bool PACKED6>   // levels: a byte each, or four 6-bit values per three bytes (GQ_LEVELS_PACKED6; level_stride in bytes either way)
+__global__ __launch_bounds__(DEC16_THREADS) __attribute__((amdgpu_waves_per_eu(GQ_DEC16_WAVES, GQ_DEC16_WAVES)))
+void hsq_decode_sum_d16u8_kernel(
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ levels, const float *__restrict__ lb_ub,
     int64_t code_stride, int64_t level_stride, int64_t lbub_stride, const float *__restrict__ cb, int R, int64_t M,
     int K, int n_bit, float *__restrict__ out) {
@@ -119,60 +167,71 @@ __global__ __launch_bounds__(DEC16_THREADS) void hsq_decode_sum_d16u8_kernel(
     const float inv_s = 1.0f / (float)(1 << (n_bit & 31));
     const MeanDiv md = mean_div_of(R);
     const int q = threadIdx.x & 3;
-    const float *const my_cb = s_cb + ((threadIdx.x >> 3) & 3) * 16 + 4 * q;   // this lane's copy and quarter
+    const unsigned lane_const = (unsigned)(((threadIdx.x >> 3) & 3) * 64 + 16 * q);   // this lane's copy and quarter, bytes
+    const char *const cb_bytes = reinterpret_cast<const char *>(s_cb);
+    auto lbub_of = [&](int r, float &lb, float &range) {
+        if (r < DEC16_LBUB) {
+            const float2 lr = s_lbub[r];
+            lb = lr.x;
+            range = lr.y;
+        } else {
+            lb = lb_ub[r * lbub_stride];
+            range = lb_ub[r * lbub_stride + 1] - lb;
+        }
+    };
     const int64_t total = ((M + 3) >> 2) * 4;   // (group of 4 subvectors, quarter) items
     const int64_t stride = (int64_t)gridDim.x * DEC16_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * DEC16_THREADS + threadIdx.x; i < total; i += stride) {
         const int64_t m0 = (i >> 2) * 4;
         const int nv = (M - m0) < 4 ? (int)(M - m0) : 4;
         f32x4 acc[4];
-        auto payload = [&](int r, auto first) {   // first: payload 0 initialises, the others accumulate
-            const uint8_t *cp = codes + (int64_t)r * code_stride + m0;
-            const uint8_t *lp = levels + (int64_t)r * level_stride + m0;
-            unsigned c4, l4;
-            if (nv == 4) {
-                c4 = *reinterpret_cast<const unsigned *>(cp);
-                l4 = *reinterpret_cast<const unsigned *>(lp);
-            } else {
-                c4 = l4 = 0;
-                for (int k = 0; k < nv; ++k) {
-                    c4 |= (unsigned)cp[k] << (8 * k);
-                    l4 |= (unsigned)lp[k] << (8 * k);
-                }
-            }
-            float lb, range;
-            if (r < DEC16_LBUB) {
-                const float2 lr = s_lbub[r];
-                lb = lr.x;
-                range = lr.y;
-            } else {
-                lb = lb_ub[r * lbub_stride];
-                range = lb_ub[r * lbub_stride + 1] - lb;
-            }
-            // the four lanes of a team (quarters 0..3 of the same four subvectors) need the same four norms:
-            // lane q works out the norm of subvector q only and the team exchanges them by quad-permute DPP moves
-            const float n_own = level_to_norm<unsigned>((l4 >> (8 * q)) & 255u, lb, range, inv_s);
-            const int n_bits = __builtin_bit_cast(int, n_own);
-            const float n_team[4] = {   // quad_perm [k,k,k,k]: lane k of the team broadcasts
-                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0x00, 0xF, 0xF, true)),
-                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0x55, 0xF, 0xF, true)),
-                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xAA, 0xF, 0xF, true)),
-                __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xFF, 0xF, 0xF, true))};
+        if (nv == 4) {
+            const unsigned off = (unsigned)m0;      // M < 2^31 subvectors (checked by the launcher): a 32-bit lane offset
+            const unsigned loff = PACKED6 ? 3u * (unsigned)(m0 >> 2) : off;
+            const uint8_t *cp = codes, *lp = levels;   // uniform: advance on the scalar unit
+            for (int r0 = 0; r0 < R; r0 += DEC16_CHUNK) {
+                unsigned c4[DEC16_CHUNK], l4[DEC16_CHUNK];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float n = n_team[k];
-                const f32x4 c = *reinterpret_cast<const f32x4 *>(my_cb + ((c4 >> (8 * k)) & 255u) * 64);
-                const f32x4 n4 = {n, n, n, n};
-                const f32x4 dec = c * n4;
-                if constexpr (decltype(first)::value) {
-                    acc[k] = dec;
-                } else {
-                    acc[k] = acc[k] + dec;
+                for (int jj = 0; jj < DEC16_CHUNK; ++jj) {
+                    if (r0 + jj < R) {
+                        c4[jj] = *reinterpret_cast<const unsigned *>(cp + (int64_t)jj * code_stride + off);
+                        l4[jj] = PACKED6 ? load_packed6(lp + (int64_t)jj * level_stride + loff)
+                                         : *reinterpret_cast<const unsigned *>(lp + (int64_t)jj * level_stride + off);
+                    }
+                }
+                cp += (int64_t)DEC16_CHUNK * code_stride;
+                lp += (int64_t)DEC16_CHUNK * level_stride;
+#pragma unroll
+                for (int jj = 0; jj < DEC16_CHUNK; ++jj) {
+                    if (r0 + jj < R) {
+                        float lb, range;
+                        lbub_of(r0 + jj, lb, range);
+                        if (jj == 0 && r0 == 0)
+                            dec16_payload<true, PACKED6>(acc, c4[jj], l4[jj], lb, range, inv_s, q, cb_bytes, lane_const);
+                        else
+                            dec16_payload<false, PACKED6>(acc, c4[jj], l4[jj], lb, range, inv_s, q, cb_bytes, lane_const);
+                    }
                 }
             }
-        };
-        payload(0, std::true_type{});
-        for (int r = 1; r < R; ++r) payload(r, std::false_type{});
+        } else {   // the last, partial group of a tensor whose M is not a multiple of 4: byte loads
+            for (int r = 0; r < R; ++r) {
+                const uint8_t *cp = codes + (int64_t)r * code_stride + m0;
+                const uint8_t *lp = levels + (int64_t)r * level_stride + (PACKED6 ? 3 * (m0 >> 2) : m0);
+                unsigned c4 = 0, l4 = 0;
+                for (int k = 0; k < nv; ++k) c4 |= (unsigned)cp[k] << (8 * k);
+                if (PACKED6) {   // a group is always stored whole (slots past M hold 0)
+                    l4 = (unsigned)lp[0] | ((unsigned)lp[1] << 8) | ((unsigned)lp[2] << 16);
+                } else {
+                    for (int k = 0; k < nv; ++k) l4 |= (unsigned)lp[k] << (8 * k);
+                }
+                float lb, range;
+                lbub_of(r, lb, range);
+                if (r == 0)
+                    dec16_payload<true, PACKED6>(acc, c4, l4, lb, range, inv_s, q, cb_bytes, lane_const);
+                else
+                    dec16_payload<false, PACKED6>(acc, c4, l4, lb, range, inv_s, q, cb_bytes, lane_const);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < nv) {
@@ -221,32 +280,37 @@ static int launch_decode(const CodeT *codes, const LevelT *levels, const float *
                          int64_t bs, const float *cb, int R, int64_t M, int d, int K, int n_bit, float *out,
                          hipStream_t st) {
     const int64_t cap = (int64_t)cu_count() * 8;
-    if constexpr (sizeof(CodeT) == 1 && sizeof(LevelT) == 1) {
-        const uintptr_t align = reinterpret_cast<uintptr_t>(codes) | reinterpret_cast<uintptr_t>(levels) |
-                                (uintptr_t)cs | (uintptr_t)ls;
+    if constexpr (sizeof(CodeT) == 1 && (std::is_same<LevelT, uint8_t>::value || std::is_same<LevelT, Packed6>::value)) {
+        constexpr bool P6 = std::is_same<LevelT, Packed6>::value;
+        const uintptr_t align = reinterpret_cast<uintptr_t>(codes) | (uintptr_t)cs |
+                                (P6 ? 0 : (reinterpret_cast<uintptr_t>(levels) | (uintptr_t)ls));
         if (d == 16 && K <= 256 && lb_ub && (align & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
-            (reinterpret_cast<uintptr_t>(cb) & 15) == 0 && M >= (int64_t)K) {
+            (reinterpret_cast<uintptr_t>(cb) & 15) == 0 && (M >= (int64_t)K || P6)) {
             const int64_t total = ((M + 3) >> 2) * 4;
             const size_t lds = (size_t)K * 64 * sizeof(float);   // four copies of every row
             static const int bpc = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_d16u8_kernel),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_d16u8_kernel<P6>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
                 (void)hipGetLastError();
                 int n = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hsq_decode_sum_d16u8_kernel, DEC16_THREADS,
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hsq_decode_sum_d16u8_kernel<P6>, DEC16_THREADS,
                                                                  (size_t)256 * 64 * sizeof(float)) != hipSuccess || n < 1)
                     n = 1;
                 return n;
             }();
             int64_t blocks = (total + DEC16_THREADS - 1) / DEC16_THREADS;
             if (blocks > (int64_t)cu_count() * bpc) blocks = (int64_t)cu_count() * bpc;
-            hipLaunchKernelGGL(hsq_decode_sum_d16u8_kernel, dim3((unsigned)blocks), dim3(DEC16_THREADS), lds, st,
+            hipLaunchKernelGGL(hsq_decode_sum_d16u8_kernel<P6>, dim3((unsigned)blocks), dim3(DEC16_THREADS), lds, st,
                                reinterpret_cast<const uint8_t *>(codes), reinterpret_cast<const uint8_t *>(levels),
                                lb_ub, cs, ls, bs, cb, R, M, K, n_bit, out);
             GQ_CHECK_LAUNCH("gq_hsq_decode_sum");
             return GQ_OK;
         }
     }
+    if constexpr (std::is_same<LevelT, Packed6>::value) {
+        return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum: GQ_LEVELS_PACKED6 is served for d = 16, K <= 256, byte codes, "
+                                        "4-byte aligned codes and 16-byte aligned out / codebook");
+    } else {
     if ((d & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(cb) & 15) == 0) {
         const int64_t total = M * (d >> 2);
         int64_t blocks = (total + DEC_THREADS - 1) / DEC_THREADS;
@@ -271,6 +335,7 @@ static int launch_decode(const CodeT *codes, const LevelT *levels, const float *
     }
     GQ_CHECK_LAUNCH("gq_hsq_decode_sum");
     return GQ_OK;
+    }
 }
 
 template <typename CodeT>
@@ -290,8 +355,13 @@ static int dispatch_levels(const CodeT *codes, int64_t cs, const void *levels, i
         case 4:
             return launch_decode<CodeT, int32_t>(codes, static_cast<const int32_t *>(levels), lb_ub, cs, ls, bs, cb, R,
                                                  M, d, K, n_bit, out, st);
+        case GQ_LEVELS_PACKED6:
+            if constexpr (sizeof(CodeT) == 1)
+                return launch_decode<CodeT, Packed6>(codes, static_cast<const Packed6 *>(levels), lb_ub, cs, ls, bs, cb, R, M,
+                                                     d, K, n_bit, out, st);
+            return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum: GQ_LEVELS_PACKED6 goes with byte codes");
         default:
-            return fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: level_bytes must be 0, 1, 2 or 4");
+            return fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: level_bytes must be 0, 1, 2, 4 or GQ_LEVELS_PACKED6");
     }
 }
 
@@ -306,7 +376,9 @@ GQ_API int gq_hsq_decode_sum_strided(const void *codes, int code_bytes, int64_t 
     if (!codes || !levels || !codebook || !out) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: null pointer");
     if (level_bytes != 0 && (!lb_ub || n_bit < 1 || n_bit > 30))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: lb_ub / n_bit required with integer levels");
-    const int lsz = level_bytes == 0 ? 4 : level_bytes;
+    const int lsz = level_bytes == 0 ? 4 : (level_bytes == GQ_LEVELS_PACKED6 ? 1 : level_bytes);
+    if (level_bytes == GQ_LEVELS_PACKED6 && (n_bit > 6 || code_bytes != 1))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: GQ_LEVELS_PACKED6 holds levels up to 63 and goes with byte codes");
     if ((code_bytes != 1 && code_bytes != 4) || code_stride_bytes % code_bytes || level_stride_bytes % lsz ||
         lbub_stride_bytes % 4)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: strides must be multiples of the element size");
@@ -323,6 +395,9 @@ GQ_API int gq_hsq_decode_sum(const void *codes, int code_bytes, const void *leve
                              const float *lb_ub, const float *codebook, int R, int64_t M, int d, int K, int n_bit,
                              float *out, void *stream) {
     const int lsz = level_bytes == 0 ? 4 : level_bytes;
+    if (level_bytes == GQ_LEVELS_PACKED6)   // contiguous payloads: a section is 3 * ceil(M / 4) bytes
+        return gq_hsq_decode_sum_strided(codes, code_bytes, M * (int64_t)code_bytes, levels, level_bytes, 3 * ((M + 3) / 4),
+                                         lb_ub, 8, codebook, R, M, d, K, n_bit, out, stream);
     return gq_hsq_decode_sum_strided(codes, code_bytes, M * (int64_t)code_bytes, levels, level_bytes, M * (int64_t)lsz,
                                      lb_ub, 8, codebook, R, M, d, K, n_bit, out, stream);
 }

@@ -636,7 +636,7 @@ __global__ __launch_bounds__(ENC_THREADS) void hsq_encode_valu_kernel(const floa
 
 template <typename CodeT>
 static int launch_encode(const float *grad, const float *codebook, int64_t M, int d, int K, CodeT *codes, float *u,
-                         float *partials, int impl, hipStream_t st) {
+                         float *partials, int impl, hipStream_t st, int profile_slot) {
     const int cus = cu_count();
     const int64_t ntiles = (M + 63) / 64;
     static const int bpc_d16 = resident_blocks_per_cu(hsq_encode_d16k256_kernel<CodeT>, ENC_THREADS, 0);
@@ -698,7 +698,7 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
         if (d != 16 || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 4 needs K=256 and d in {8, 16, 32}");
         if ((reinterpret_cast<uintptr_t>(grad) & 15) != 0)
             return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: grad must be 16-byte aligned");
-        return launch_encode_pf<CodeT>(grad, codebook, M, codes, u, partials, st);
+        return launch_encode_pf<CodeT>(grad, codebook, M, codes, u, partials, st, profile_slot);
     }
     if (impl == 1) {
         if (d != 16 || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 1 needs d=16, K=256");
@@ -745,7 +745,7 @@ static int launch_encode_lds_batched(const int64_t *seg_table, const int32_t *ti
     int dpad = 0, chunk_rows = 0;
     size_t lds_bytes = 0;
     if (!lds_plan(d, K, &dpad, &chunk_rows, &lds_bytes, nullptr))
-        return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched_any: needs d <= 128 (d=%d K=%d)", d, K);
+        return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched (exact): needs d <= 128 (d=%d K=%d)", d, K);
     auto kernel = hsq_encode_lds_kernel<CodeT, true, EF>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -768,24 +768,24 @@ static int launch_encode_lds_batched(const int64_t *seg_table, const int32_t *ti
 
 }  // namespace gq
 
-GQ_API int gq_hsq_batched_any_supported(int d, int K) {
+GQ_INTERNAL int gqi_hsq_batched_any_supported(int d, int K) {
     int dpad = 0, chunk_rows = 0;
     size_t bytes = 0;
     return (d >= 1 && K >= 1 && K <= 65536 && gq::lds_plan(d, K, &dpad, &chunk_rows, &bytes, nullptr)) ? 1 : 0;
 }
 
-GQ_API int gq_hsq_encode_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+GQ_INTERNAL int gqi_hsq_encode_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                      const float *codebook, int d, int K, int code_bytes, int ef, float ef_scale,
                                      uint8_t *wire, float *u_flat, uint32_t *seg_minmax, void *stream) {
     if (nseg < 1 || ntiles < 1 || ntiles * 64 > 0x7FFFFFFFLL || d < 1 || K < 1 || K > 65536)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_any: bad sizes nseg=%d ntiles=%lld d=%d K=%d", nseg,
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched (exact): bad sizes nseg=%d ntiles=%lld d=%d K=%d", nseg,
                         (long long)ntiles, d, K);
     if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_any: null pointer");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched (exact): null pointer");
     if (code_bytes != 1 && code_bytes != 4)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_any: code_bytes must be 1 or 4");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched (exact): code_bytes must be 1 or 4");
     if (code_bytes == 1 && K > 256)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_any: uint8 codes need K <= 256");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched (exact): uint8 codes need K <= 256");
     hipStream_t st = gq::as_stream(stream);
     if (code_bytes == 1)
         return ef ? gq::launch_encode_lds_batched<uint8_t, true>(seg_table, tile_seg, ntiles, codebook, d, K, ef_scale,
@@ -803,24 +803,25 @@ GQ_API size_t gq_hsq_workspace_bytes(int64_t M) {
     return (size_t)(2 * GQ_MAX_PARTIALS) * sizeof(float) + 16 + (size_t)M * sizeof(int32_t);
 }
 
-GQ_API int gq_hsq_encode_impl(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes,
-                              int code_bytes, float *u, float *minmax_partials, int impl, void *stream) {
+GQ_API int gq_hsq_encode_ex(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes,
+                            int code_bytes, float *u, float *minmax_partials, int impl, int profile_slot, void *stream) {
     if (M < 1 || d < 1 || d > 512 || K < 1 || K > 65536)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: bad sizes M=%lld d=%d K=%d", (long long)M, d, K);
     if (!grad || !codebook || !codes || !u || !minmax_partials)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: null pointer");
+    if (profile_slot >= GQ_PROFILE_SLOTS) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_ex: profile_slot %d", profile_slot);
     if (code_bytes == 1) {
         if (K > 256) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: uint8 codes need K <= 256");
         return gq::launch_encode<uint8_t>(grad, codebook, M, d, K, static_cast<uint8_t *>(codes), u, minmax_partials,
-                                          impl, gq::as_stream(stream));
+                                          impl, gq::as_stream(stream), profile_slot);
     }
     if (code_bytes == 4)
         return gq::launch_encode<int32_t>(grad, codebook, M, d, K, static_cast<int32_t *>(codes), u, minmax_partials,
-                                          impl, gq::as_stream(stream));
+                                          impl, gq::as_stream(stream), profile_slot);
     return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: code_bytes must be 1 or 4");
 }
 
 GQ_API int gq_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes,
                          int code_bytes, float *u, float *minmax_partials, void *stream) {
-    return gq_hsq_encode_impl(grad, codebook, M, d, K, codes, code_bytes, u, minmax_partials, 0, stream);
+    return gq_hsq_encode_ex(grad, codebook, M, d, K, codes, code_bytes, u, minmax_partials, GQ_ENCODE_AUTO, -1, stream);
 }

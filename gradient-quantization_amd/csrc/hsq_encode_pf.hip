@@ -41,6 +41,10 @@ namespace gq {
 
 // The d = 16 kernels run ONE workgroup of 8 waves per CU (two waves per SIMD, as before, but in one workgroup):
 // the waves of a workgroup share their tiles through an LDS counter (see the kernel).
+#ifndef GQ_PF_GROUP
+#define GQ_PF_GROUP 4     // codewords per key of the top-2 scan (4 or 8); see the scan in the kernel.  8 was built in round 3
+                          // (13 VALU operations per chain instead of 18, an 8-codeword exact rescoring): 42.4 us against 40.3 us
+#endif
 constexpr int PF_WAVES = 8;
 constexpr int PF_THREADS = PF_WAVES * 64;
 constexpr int PF_TAIL = 6;   // swept 2..12 (52.3 us at 4..8, 54 at 2 and 12)
@@ -151,6 +155,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     struct Tile {
         gcf_ptr base;
         int64_t m, sv0;
+        int rem;       // index of the tile's last valid subvector (0..63): m - 1 - sv0, capped at 63
         int seg;
         gcode_ptr codes;
         gcf_ptr err;   // EF: this tensor's error buffer or nullptr
@@ -192,6 +197,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             ti.sv0 = (tile - uniform64(r2)) * 64;
             ti.codes = (gcode_ptr)((uintptr_t)a.wire + (uintptr_t)uniform64(r3));
             ti.err = EF ? (gcf_ptr)(uintptr_t)uniform64(r7) : (gcf_ptr)0;
+            const int64_t rem = ti.m - 1 - ti.sv0;
+            ti.rem = rem > 63 ? 63 : (int)rem;
         } else {
             ti.seg = 0;
             ti.base = (gcf_ptr)a.grad;
@@ -199,26 +206,34 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             ti.sv0 = tile * 64;
             ti.codes = (gcode_ptr)static_cast<CodeT *>(a.codes);
             ti.err = (gcf_ptr)0;
+            const int64_t rem = M - 1 - ti.sv0;
+            ti.rem = rem > 63 ? 63 : (int)rem;
         }
         return ti;
     };
+    // Addresses inside a tile: a wave-uniform 64-bit base (the tile's first subvector: scalar arithmetic) plus a 32-bit
+    // lane offset, so that the loads and stores take an SGPR base and the per-lane part is two VALU operations per
+    // block (clamp, scale) instead of ~10 of 64-bit compare / select / shift / add.  lane_sv: this lane's subvector of
+    // each block, clamped to the tile's last valid one (tail: re-read it, the result is masked).
+    auto lane_off = [&](const Tile &ti, int blk) {   // float offset of v[8h..] of subvector blk*32+j from the tile's first float
+        const unsigned li = min((unsigned)(blk * 32 + j), (unsigned)ti.rem);
+        return li * 16u + 8u * (unsigned)h;
+    };
     auto load_tile = [&](const Tile &ti, f32x4(&dst)[4]) {
+        const gcf_ptr tb = ti.base + ti.sv0 * 16;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
-            int64_t sv = ti.sv0 + blk * 32 + j;
-            sv = sv < ti.m ? sv : ti.m - 1;  // tail: re-read the last subvector, result is masked
-            const gcv_ptr p = (gcv_ptr)(ti.base + sv * 16 + 8 * h);
+            const gcv_ptr p = (gcv_ptr)(tb + lane_off(ti, blk));
             dst[2 * blk] = p[0];
             dst[2 * blk + 1] = p[1];
         }
     };
     auto load_err = [&](const Tile &ti, f32x4(&dst)[4]) {
         if (EF && ti.err) {
+            const gcf_ptr tb = ti.err + ti.sv0 * 16;
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
-                int64_t sv = ti.sv0 + blk * 32 + j;
-                sv = sv < ti.m ? sv : ti.m - 1;
-                const gcv_ptr p = (gcv_ptr)(ti.err + sv * 16 + 8 * h);
+                const gcv_ptr p = (gcv_ptr)(tb + lane_off(ti, blk));
                 dst[2 * blk] = p[0];
                 dst[2 * blk + 1] = p[1];
             }
@@ -227,6 +242,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // v = grad + scale*error, written back over grad (valid subvectors only)
     auto fold_err = [&](const Tile &ti, f32x4(&g)[4], const f32x4(&e)[4]) {
         if (EF && ti.err) {
+            const gf_ptr tb = (gf_ptr)(ti.base + ti.sv0 * 16);
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
@@ -239,9 +255,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
                         x[c] = x[c] + prod;
                     }
                 }
-                const int64_t sv = ti.sv0 + blk * 32 + j;
-                if (sv < ti.m) {
-                    const gv_ptr p = (gv_ptr)(gf_ptr)(ti.base + sv * 16 + 8 * h);
+                if (blk * 32 + j <= ti.rem) {
+                    const gv_ptr p = (gv_ptr)(tb + (unsigned)((blk * 32 + j) * 16 + 8 * h));
                     p[0] = g[2 * blk];
                     p[1] = g[2 * blk + 1];
                 }
@@ -355,15 +370,71 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         // PAGED: what the earlier pages left for this lane's subvector, requested a whole tile before its use
         float prev_u = 0.0f;
         int prev_idx = 0;
-        if (PAGED && a.merge && ti.sv0 + lane < ti.m) {
-            prev_u = u[BATCHED ? t * 64 + lane : ti.sv0 + lane];
-            prev_idx = (int)ti.codes[ti.sv0 + lane];
+        if (PAGED && a.merge && lane <= ti.rem) {
+            prev_u = (u + (BATCHED ? t * 64 : ti.sv0))[(unsigned)lane];
+            prev_idx = (int)(ti.codes + ti.sv0)[(unsigned)lane];
         }
 
         // ---- prefilter: 16 (block, row block) chains; top-2 GROUP keys per (block, row-block half) ----
         // The three MFMAs of chain c+1 depend on each other and issue is in order, so they are
         // placed one by one BETWEEN the key operations of chain c (sched_barrier pins the order):
         // the matrix pipe runs under the VALU stream.
+#if GQ_PF_GROUP == 8
+        // Keys over GROUPS OF 8 codewords (registers 8g..8g+7 of a chain = rows {0..3} and {8..11} (+16g, +4h) of
+        // its row block): per 16 scores 2 keys instead of 4 and ONE top-2 step per chain instead of two -- 13 VALU
+        // operations per chain against 18 -- with one tracker per block (16 group ids).  The price is an exact
+        // rescoring of 8 codewords instead of 4 (64 more plain FMAs, which issue at half the cost of the max / med3 /
+        // and_or operations the scan is made of).
+        unsigned best[2] = {0, 0}, second[2] = {0, 0};
+        unsigned vmask = KEY_MASK;
+        asm volatile("" : "+v"(vmask));  // keep the mask in a VGPR: v_and_or with an SGPR operand issues slower
+        auto group_key = [&](const f32x16 &a, int rb, int g) {
+            const float m = fmaxf(absmax4(a[8 * g], a[8 * g + 1], a[8 * g + 2], a[8 * g + 3]),
+                                  absmax4(a[8 * g + 4], a[8 * g + 5], a[8 * g + 6], a[8 * g + 7]));
+            return and_or(__float_as_uint(m), vmask, (unsigned)(rb * 2 + g));
+        };
+        auto track = [&](int blk, unsigned k0, unsigned k1) {
+            second[blk] = max(second[blk], med3u(best[blk], k0, k1));
+            best[blk] = max3u(best[blk], k0, k1);
+        };
+        f32x16 acc = {0};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[0], vh[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[0], vl[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[0], vh[0], acc, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int rb = c & 7, blk = c >> 3;
+            if (c + 1 < 16) {
+                const int nb = (c + 1) >> 3, nr = (c + 1) & 7;
+                f32x16 nacc = {0};
+                __builtin_amdgcn_sched_barrier(0);
+                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[nr], vh[nb], nacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned k0 = group_key(acc, rb, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vl[nb], nacc, 0, 0, 0);
+                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vh[nb], nacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                track(blk, k0, group_key(acc, rb, 1));
+                __builtin_amdgcn_sched_barrier(0);
+                acc = nacc;
+            } else {
+                track(blk, group_key(acc, rb, 0), group_key(acc, rb, 1));
+            }
+        }
+
+        // ---- per block: the best group's first codeword and the bound on the rest ----
+        int k1[2];
+        unsigned s2[2], bk[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const unsigned bw = best[blk];
+            const int gid = (int)(bw & 31u);
+            k1[blk] = (gid >> 1) * 32 + 16 * (gid & 1) + 4 * h;   // rows k1 .. k1+3 and k1+8 .. k1+11
+            s2[blk] = second[blk] | 31u;                          // upper end of its bucket
+            bk[blk] = bw;
+        }
+#else
         unsigned best[4] = {0, 0, 0, 0}, second[4] = {0, 0, 0, 0};
         unsigned vmask = KEY_MASK;
         asm volatile("" : "+v"(vmask));  // keep the mask in a VGPR: v_and_or with an SGPR operand issues slower
@@ -371,9 +442,20 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             return and_or(__float_as_uint(absmax4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3])), vmask,
                           (unsigned)((rb & 3) * 4 + q));
         };
-        auto track = [&](int trk, unsigned k0, unsigned k1) {
-            second[trk] = max(second[trk], med3u(best[trk], k0, k1));
-            best[trk] = max3u(best[trk], k0, k1);
+        // Top-2 of the tracker and the FOUR keys of a chain in five operations (two steps of three were six):
+        //   t = max3(best, k0, k1)   a = med3(best, k0, k1)      -- first and second of {best, k0, k1}
+        //   b = med3(t, k2, k3)      best' = max3(t, k2, k3)     -- second of {t, k2, k3}: k2 / k3 if they stay below t, else t or the smaller of them
+        //   second' = max3(second, a, b)
+        // (the second largest of {best, k0..k3} is max(a, b): both of the top two lie in {t, a, k2, k3}.)
+        unsigned trk_t = 0, trk_a = 0;
+        auto track_lo = [&](int trk, unsigned k0, unsigned k1) {
+            trk_t = max3u(best[trk], k0, k1);
+            trk_a = med3u(best[trk], k0, k1);
+        };
+        auto track_hi = [&](int trk, unsigned k2, unsigned k3) {
+            const unsigned b = med3u(trk_t, k2, k3);
+            best[trk] = max3u(trk_t, k2, k3);
+            second[trk] = max3u(second[trk], trk_a, b);
         };
         f32x16 acc = {0};
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[0], vh[0], acc, 0, 0, 0);
@@ -388,17 +470,17 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
                 __builtin_amdgcn_sched_barrier(0);
                 nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[nr], vh[nb], nacc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                track(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
+                track_lo(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
                 __builtin_amdgcn_sched_barrier(0);
                 nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vl[nb], nacc, 0, 0, 0);
                 nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vh[nb], nacc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                track(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
+                track_hi(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
                 __builtin_amdgcn_sched_barrier(0);
                 acc = nacc;
             } else {
-#pragma unroll
-                for (int p2 = 0; p2 < 4; p2 += 2) track(trk, group_key(acc, rb, p2), group_key(acc, rb, p2 + 1));
+                track_lo(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
+                track_hi(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
             }
         }
 
@@ -415,6 +497,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             s2[blk] = max3u(second[2 * blk], second[2 * blk + 1], bl) | 31u;         // upper end of its bucket
             bk[blk] = bw;
         }
+#endif
 
         // ---- this lane's own full subvector (tile subvector `lane`): 8 swaps of the B loads ----
         float vf[16];
@@ -445,12 +528,21 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         const bool pick1 = (bk[1] & KEY_MASK) > (bk[0] & KEY_MASK);
         const int kc = pick1 ? k1[1] : k1[0];
         const unsigned rest = max3u(s2[0], s2[1], (pick1 ? bk[0] : bk[1]) | 31u);
-        const f32x4 p4 = exact_score_quad<16>(s_cb + (kc >> 2) * QUAD_STRIDE, vf);   // kc is a multiple of 4: one group
+        const f32x4 p4 = exact_score_quad<16>(s_cb + (kc >> 2) * QUAD_STRIDE, vf);   // kc is a multiple of 4: one quad
         float val = p4[0];
         int idx = kc;
         take_if_greater(val, idx, p4[1], kc + 1);
         take_if_greater(val, idx, p4[2], kc + 2);
         take_if_greater(val, idx, p4[3], kc + 3);
+#if GQ_PF_GROUP == 8
+        {   // the group's second quad, rows kc+8 .. kc+11 (two quads further in the LDS image), ascending index: first maximum
+            const f32x4 q4 = exact_score_quad<16>(s_cb + ((kc >> 2) + 2) * QUAD_STRIDE, vf);
+            take_if_greater(val, idx, q4[0], kc + 8);
+            take_if_greater(val, idx, q4[1], kc + 9);
+            take_if_greater(val, idx, q4[2], kc + 10);
+            take_if_greater(val, idx, q4[3], kc + 11);
+        }
+#endif
 
         float vmax = 0.0f;
 #pragma unroll
@@ -468,9 +560,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         }
         // NaN anywhere makes the comparisons false -> not safe -> exact fix-up path
 
-        const int64_t sv = ti.sv0 + lane;          // index inside this tile's tensor
-        const bool valid = sv < ti.m;
-        const int64_t gsv = BATCHED ? t * 64 + lane : sv;   // index into u / the worklist
+        const bool valid = lane <= ti.rem;         // this lane's subvector exists (the tensor's last tile may be short)
 
         // Consume the prefetched tile (convert it to the next B fragments) BEFORE this tile's
         // stores are issued: the wait for the prefetch then sees only long-finished memory ops.
@@ -548,9 +638,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
                 atomicMax(a.seg_minmax + 2 * ti.seg + 1, MAPPED_NAN_HI);
             }
         }
-        if (valid) {
-            ti.codes[sv] = (CodeT)idx;
-            u[gsv] = val;
+        if (valid) {   // uniform bases (the tile's first code / projection) + the lane index
+            (ti.codes + ti.sv0)[(unsigned)lane] = (CodeT)idx;
+            ((gf_ptr)u + (BATCHED ? t * 64 : ti.sv0))[(unsigned)lane] = val;
             if (!PAGED || a.last_page) {   // (min,max) of the FINAL projections only: earlier pages' values may be replaced
                 lmin = fminf(lmin, val);
                 lmax = fmaxf(lmax, val);
@@ -578,7 +668,7 @@ static int64_t pf16_grid(int64_t ntiles, int bpc) {
 
 template <typename CodeT>
 int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *ws,
-                     hipStream_t st) {
+                     hipStream_t st, int profile_slot) {
     if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
     static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<CodeT, false>, PF_THREADS, 0);
     PfArgs a = {};
@@ -591,7 +681,7 @@ int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT 
     const int64_t blocks = pf16_grid((M + 63) / 64, bpc);
     pf_split(a, (M + 63) / 64, blocks);
     hipEvent_t ev_start, ev_stop;
-    if (profile_take(&ev_start, &ev_stop)) {   // gq_profile_arm: events attached to this dispatch
+    if (profile_events(profile_slot, &ev_start, &ev_stop)) {   // events attached to this dispatch (gq_profile_read)
         hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, false>), dim3((unsigned)blocks),
                               dim3(PF_THREADS), 0, st, ev_start, ev_stop, 0, a);
     } else {
@@ -627,8 +717,8 @@ int launch_encode_pf_paged(const float *grad, const float *codebook, int64_t M, 
     return GQ_OK;
 }
 
-template int launch_encode_pf<uint8_t>(const float *, const float *, int64_t, uint8_t *, float *, float *, hipStream_t);
-template int launch_encode_pf<int32_t>(const float *, const float *, int64_t, int32_t *, float *, float *, hipStream_t);
+template int launch_encode_pf<uint8_t>(const float *, const float *, int64_t, uint8_t *, float *, float *, hipStream_t, int);
+template int launch_encode_pf<int32_t>(const float *, const float *, int64_t, int32_t *, float *, float *, hipStream_t, int);
 
 }  // namespace gq
 
@@ -636,7 +726,7 @@ namespace gq {
 template <bool EF>
 static int encode_batched(const char *what, const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                           const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax, float *workspace,
-                          float ef_scale, void *stream) {
+                          float ef_scale, int profile_slot, void *stream) {
     if (nseg < 1 || ntiles < 1 || ntiles * 64 > 0x7FFFFFFFLL)
         return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes nseg=%d ntiles=%lld", what, nseg, (long long)ntiles);
     if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
@@ -658,7 +748,7 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
     const int64_t blocks = pf16_grid(ntiles, bpc);
     pf_split(a, ntiles, blocks);
     hipEvent_t ev_start, ev_stop;
-    if (nseg <= PF_LDS_SEGS && profile_take(&ev_start, &ev_stop)) {   // gq_profile_arm: events attached to this dispatch
+    if (nseg <= PF_LDS_SEGS && profile_events(profile_slot, &ev_start, &ev_stop)) {   // events attached to this dispatch
         hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, true, EF, true>), dim3((unsigned)blocks),
                               dim3(PF_THREADS), 0, st, ev_start, ev_stop, 0, a);
     } else if (nseg <= PF_LDS_SEGS) {
@@ -713,46 +803,29 @@ static int encode_batched_paged16(const int64_t *seg_table, const int32_t *tile_
 }
 }  // namespace gq
 
-GQ_API int gq_hsq_encode_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+GQ_INTERNAL int gqi_hsq_encode_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                        const float *codebook, int d, int K, int ef, float ef_scale, uint8_t *wire,
                                        float *u_flat, uint32_t *seg_minmax, float *workspace, void *stream) {
     if (nseg < 1 || ntiles < 1 || ntiles * 64 > 0x7FFFFFFFLL)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_paged: bad sizes nseg=%d ntiles=%lld", nseg,
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched (paged): bad sizes nseg=%d ntiles=%lld", nseg,
                         (long long)ntiles);
     if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched_paged: null pointer");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched (paged): null pointer");
     if ((d != 8 && d != 16 && d != 32) || K <= 256 || (K & 255) != 0 || K > 65536)
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched_paged: d must be 8, 16 or 32 and K a multiple of 256 above 256");
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched (paged): d must be 8, 16 or 32 and K a multiple of 256 above 256");
     if (nseg > (d == 16 ? gq::PF_LDS_SEGS : 384))
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched_paged: at most 384 tensors per launch");
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode_batched (paged): at most 384 tensors per launch");
     hipStream_t st = gq::as_stream(stream);
     return gq::launch_pfd_batched_paged(seg_table, tile_seg, nseg, ntiles, codebook, d, K, ef, ef_scale, wire, u_flat,
                                         seg_minmax, workspace, st);
 }
 
-GQ_API int gq_hsq_encode_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                 const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax,
-                                 float *workspace, void *stream) {
+GQ_INTERNAL int gqi_hsq_encode_batched_d16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                           const float *codebook, int ef, float ef_scale, uint8_t *wire, float *u_flat,
+                                           uint32_t *seg_minmax, float *workspace, int profile_slot, void *stream) {
+    if (ef)
+        return gq::encode_batched<true>("gq_hsq_encode_batched", seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat,
+                                        seg_minmax, workspace, ef_scale, profile_slot, stream);
     return gq::encode_batched<false>("gq_hsq_encode_batched", seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat,
-                                     seg_minmax, workspace, 0.0f, stream);
+                                     seg_minmax, workspace, 0.0f, profile_slot, stream);
 }
-
-GQ_API int gq_hsq_encode_batched_ef(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                    const float *codebook, float ef_scale, uint8_t *wire, float *u_flat,
-                                    uint32_t *seg_minmax, float *workspace, void *stream) {
-    return gq::encode_batched<true>("gq_hsq_encode_batched_ef", seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat,
-                                    seg_minmax, workspace, ef_scale, stream);
-}
-
-// Whole compress (nearest_neighbor_compressor.py:63-78 = encode + probabilistic_scalar_compressor.py:12-27) in one
-// call: gq_hsq_encode followed by gq_hsq_levels on the same stream.  (Doing both in ONE launch -- every workgroup
-// quantising its own tiles once the last one has published the final (lb, ub) -- was built and measured: 64 us with
-// a plain launch, 77 us with the cooperative launch the grid barrier needs, against 56.5 us for the two launches.)
-GQ_API int gq_hsq_compress(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes, int code_bytes,
-                           float *u, float *workspace, int n_bit, int random_mode, const float *r, uint64_t seed,
-                           float *lb_ub, void *levels, int level_bytes, void *stream) {
-    const int rc = gq_hsq_encode(grad, codebook, M, d, K, codes, code_bytes, u, workspace, stream);
-    if (rc != GQ_OK) return rc;
-    return gq_hsq_levels(u, M, n_bit, random_mode, r, seed, workspace, lb_ub, levels, level_bytes, stream);
-}
-

@@ -829,21 +829,12 @@ static int encode_batched_d(const char *what, const int64_t *seg_table, const in
 }
 }  // namespace gq
 
-GQ_API int gq_hsq_encode_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                   const float *codebook, int d, uint8_t *wire, float *u_flat, uint32_t *seg_minmax,
-                                   float *workspace, void *stream) {
-    if (d == 16)
-        return gq_hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace, stream);
-    return gq::encode_batched_d<false>("gq_hsq_encode_batched_d", seg_table, tile_seg, nseg, ntiles, codebook, d, 0.0f, wire,
+GQ_INTERNAL int gqi_hsq_encode_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                         const float *codebook, int d, int ef, float ef_scale, uint8_t *wire, float *u_flat,
+                                         uint32_t *seg_minmax, float *workspace, void *stream) {
+    if (ef)
+        return gq::encode_batched_d<true>("gq_hsq_encode_batched", seg_table, tile_seg, nseg, ntiles, codebook, d, ef_scale,
+                                          wire, u_flat, seg_minmax, workspace, stream);
+    return gq::encode_batched_d<false>("gq_hsq_encode_batched", seg_table, tile_seg, nseg, ntiles, codebook, d, 0.0f, wire,
                                        u_flat, seg_minmax, workspace, stream);
-}
-
-GQ_API int gq_hsq_encode_batched_d_ef(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                      const float *codebook, int d, float ef_scale, uint8_t *wire, float *u_flat,
-                                      uint32_t *seg_minmax, float *workspace, void *stream) {
-    if (d == 16)
-        return gq_hsq_encode_batched_ef(seg_table, tile_seg, nseg, ntiles, codebook, ef_scale, wire, u_flat, seg_minmax,
-                                        workspace, stream);
-    return gq::encode_batched_d<true>("gq_hsq_encode_batched_d_ef", seg_table, tile_seg, nseg, ntiles, codebook, d, ef_scale,
-                                      wire, u_flat, seg_minmax, workspace, stream);
 }

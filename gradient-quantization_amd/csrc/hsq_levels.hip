@@ -7,6 +7,7 @@
 // Built with -ffp-contract=off: sub, IEEE divide, exact *2^n_bit, truncation -- the
 // same roundings as the reference's separate elementwise ops.
 #include "hsq_encode_common.hpp"
+#include <type_traits>
 
 namespace gq {
 
@@ -77,6 +78,25 @@ __global__ __launch_bounds__(LV_THREADS) void hsq_levels_kernel(const float *__r
         }
         return l;
     };
+    if constexpr (std::is_same<LevelT, Packed6>::value) {
+        // four levels per thread and iteration -> one 24-bit group (a NaN quotient's INT_MIN is stored as 0, like the byte form)
+        uint8_t *const sec = reinterpret_cast<uint8_t *>(levels);
+        const int64_t groups = (M + 3) >> 2;
+        const bool vec = (reinterpret_cast<uintptr_t>(u) & 15) == 0;
+        const int64_t stride = (int64_t)gridDim.x * LV_THREADS;
+        for (int64_t i = (int64_t)blockIdx.x * LV_THREADS + threadIdx.x; i < groups; i += stride) {
+            int l[4] = {0, 0, 0, 0};
+            if (vec && 4 * i + 3 < M) {
+                const f32x4 uu = reinterpret_cast<const f32x4 *>(u)[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) l[e] = level_of(uu[e], 4 * i + e);
+            } else {
+                for (int e = 0; e < 4 && 4 * i + e < M; ++e) l[e] = level_of(u[4 * i + e], 4 * i + e);
+            }
+            store_packed6(sec + 3 * i, l[0], l[1], l[2], l[3]);
+        }
+        return;
+    } else {
     // four levels per thread and iteration: one dwordx4 load, one packed store
     const int64_t M4 = ((reinterpret_cast<uintptr_t>(u) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(levels) & (4 * sizeof(LevelT) - 1)) == 0)
@@ -95,6 +115,7 @@ __global__ __launch_bounds__(LV_THREADS) void hsq_levels_kernel(const float *__r
     }
     for (int64_t i = 4 * M4 + (int64_t)blockIdx.x * LV_THREADS + threadIdx.x; i < M; i += stride)
         levels[i] = (LevelT)level_of(u[i], i);
+    }
 }
 
 }  // namespace gq
@@ -108,7 +129,7 @@ GQ_API int gq_hsq_levels(const float *u, int64_t M, int n_bit, int random_mode, 
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels: random_mode %d", random_mode);
     if (random_mode == GQ_RANDOM_GIVEN && !r) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels: r is null");
     const int64_t top = ((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0);
-    if ((level_bytes == 1 && top > 255) || (level_bytes == 2 && top > 65535))
+    if ((level_bytes == 1 && top > 255) || (level_bytes == 2 && top > 65535) || (level_bytes == GQ_LEVELS_PACKED6 && top > 63))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels: level_bytes=%d cannot hold level %lld", level_bytes,
                         (long long)top);
     int64_t blocks = (M + gq::LV_THREADS * 8 - 1) / (gq::LV_THREADS * 8);
@@ -125,8 +146,10 @@ GQ_API int gq_hsq_levels(const float *u, int64_t M, int n_bit, int random_mode, 
         GQ_LAUNCH_LEVELS(uint16_t);
     else if (level_bytes == 4)
         GQ_LAUNCH_LEVELS(int32_t);
+    else if (level_bytes == GQ_LEVELS_PACKED6)
+        GQ_LAUNCH_LEVELS(gq::Packed6);
     else
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels: level_bytes must be 1, 2 or 4");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels: level_bytes must be 1, 2, 4 or GQ_LEVELS_PACKED6");
 #undef GQ_LAUNCH_LEVELS
     GQ_CHECK_LAUNCH("gq_hsq_levels");
     return GQ_OK;

@@ -447,49 +447,37 @@ static int dispatch_pvq(const float *grad, const float *cdag, int64_t M, int d, 
 
 GQ_API int gq_pvq_encode(const float *grad, const float *c_dagger, int64_t M, int d, int K, int random_mode,
                          const float *r, uint64_t seed, void *codes, int code_bytes, float *u, float *workspace,
-                         void *stream) {
+                         const gq_pvq_stage1 *stage1, void *stream) {
     if (M < 1 || d < 1 || K < 1) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode: bad sizes");
     if (!grad || !c_dagger || !codes || !u || !workspace) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode: null pointer");
     if (random_mode != GQ_RANDOM_GIVEN && random_mode != GQ_RANDOM_DEVICE)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode: random_mode must be GIVEN or DEVICE (the sampler needs draws)");
     if (random_mode == GQ_RANDOM_GIVEN && !r) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode: r is null");
+    if (code_bytes != 1 && code_bytes != 4) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode: code_bytes must be 1 or 4");
+    if (code_bytes == 1 && K > 256) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode: uint8 codes need K <= 256");
     hipStream_t st = gq::as_stream(stream);
-    if (code_bytes == 1) {
-        if (K > 256) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode: uint8 codes need K <= 256");
-        return gq::dispatch_pvq<uint8_t>(grad, c_dagger, M, d, K, random_mode, r, seed, static_cast<uint8_t *>(codes), u,
-                                         workspace, st);
-    }
-    if (code_bytes == 4)
+    if (!stage1) {
+        if (code_bytes == 1)
+            return gq::dispatch_pvq<uint8_t>(grad, c_dagger, M, d, K, random_mode, r, seed, static_cast<uint8_t *>(codes), u,
+                                             workspace, st);
         return gq::dispatch_pvq<int32_t>(grad, c_dagger, M, d, K, random_mode, r, seed, static_cast<int32_t *>(codes), u,
                                          workspace, st);
-    return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode: code_bytes must be 1 or 4");
-}
-
-GQ_API int gq_pvq_encode_residual(const float *grad, const void *codes1, int code1_bytes, const float *norm1,
-                                  const float *codebook1, const float *c_dagger, int64_t M, int d, int K, int random_mode,
-                                  const float *r, uint64_t seed, void *codes, int code_bytes, float *u, float *workspace,
-                                  void *stream) {
-    if (M < 1 || d < 1 || K < 1) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: bad sizes");
-    if (!grad || !codes1 || !norm1 || !codebook1 || !c_dagger || !codes || !u || !workspace)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: null pointer");
-    if (code1_bytes != 1 && code1_bytes != 4) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: code1_bytes must be 1 or 4");
-    if (random_mode != GQ_RANDOM_GIVEN && random_mode != GQ_RANDOM_DEVICE)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: random_mode must be GIVEN or DEVICE (the sampler needs draws)");
-    if (random_mode == GQ_RANDOM_GIVEN && !r) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: r is null");
-    if (code_bytes == 1 && K > 256) return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: uint8 codes need K <= 256");
-    hipStream_t st = gq::as_stream(stream);
-    const gq::PvqResidual rs = {codes1, code1_bytes, norm1, codebook1};
+    }
+    // second stage of the ResidualCompressor: the tile is staged as grad - codebook1[codes1] * norm1
+    if (!stage1->codes1 || !stage1->norm1 || !stage1->codebook1)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode: stage1 holds a null pointer");
+    if (stage1->code1_bytes != 1 && stage1->code1_bytes != 4)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode: stage1->code1_bytes must be 1 or 4");
+    const gq::PvqResidual rs = {stage1->codes1, stage1->code1_bytes, stage1->norm1, stage1->codebook1};
     bool done = false;
     int rc;
     if (code_bytes == 1)
         rc = gq::launch_pvq_lds<uint8_t>(grad, c_dagger, M, d, K, random_mode, r, seed, static_cast<uint8_t *>(codes), u,
                                          workspace, st, &done, rs);
-    else if (code_bytes == 4)
+    else
         rc = gq::launch_pvq_lds<int32_t>(grad, c_dagger, M, d, K, random_mode, r, seed, static_cast<int32_t *>(codes), u,
                                          workspace, st, &done, rs);
-    else
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_pvq_encode_residual: code_bytes must be 1 or 4");
     if (rc != GQ_OK) return rc;
-    if (!done) return gq::fail(GQ_ERR_UNSUPPORTED, "gq_pvq_encode_residual: d = %d does not fit the LDS-staged kernel", d);
+    if (!done) return gq::fail(GQ_ERR_UNSUPPORTED, "gq_pvq_encode: d = %d does not fit the LDS-staged kernel (stage1 form)", d);
     return GQ_OK;
 }

@@ -427,23 +427,20 @@ static int qsgd_compress_batched(const char *what, const int64_t *seg_table, con
 }
 }  // namespace gq
 
-GQ_API int gq_qsgd_compress_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
-                                    int n_bit, int random_mode, uint64_t seed, uint8_t *wire, void *stream) {
+GQ_INTERNAL int gqi_qsgd_compress_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
+                                          int n_bit, int random_mode, uint64_t seed, int ef, float ef_scale, uint8_t *wire,
+                                          void *stream) {
+    if (ef)
+        return gq::qsgd_compress_batched<true>("gq_qsgd_compress_batched", seg_table, bucket_seg, nseg, nbuckets, n_bit,
+                                               random_mode, seed, ef_scale, wire, stream);
     return gq::qsgd_compress_batched<false>("gq_qsgd_compress_batched", seg_table, bucket_seg, nseg, nbuckets, n_bit,
                                             random_mode, seed, 0.0f, wire, stream);
 }
 
-GQ_API int gq_qsgd_compress_batched_ef(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
-                                       int n_bit, int random_mode, uint64_t seed, float ef_scale, uint8_t *wire,
-                                       void *stream) {
-    return gq::qsgd_compress_batched<true>("gq_qsgd_compress_batched_ef", seg_table, bucket_seg, nseg, nbuckets, n_bit,
-                                           random_mode, seed, ef_scale, wire, stream);
-}
-
-GQ_API int gq_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
-                                      int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                      float *out, void *stream) {
-    const int plain = gq::take_decode_plain() ? 1 : 0;   // consumed even when the call is refused below
+GQ_INTERNAL int gqi_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
+                                            int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                            float *out, int plain, void *stream) {
+    plain = plain ? 1 : 0;
     if (nseg < 1 || nbuckets < 1 || n_bit < 1 || R < 1 || (bits != 4 && bits != 8 && bits != 16))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: bad sizes");
     if (!seg_table || !bucket_seg || !gathered || !out)

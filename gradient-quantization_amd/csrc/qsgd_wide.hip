@@ -319,16 +319,16 @@ static inline int64_t qw_grid(int64_t nchunks) {
 
 }  // namespace gq
 
-GQ_API int gq_qsgd_wide_compress(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks,
+GQ_INTERNAL int gqi_qsgd_wide_compress(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks,
                                  int n_bit, int random_mode, uint64_t seed, int ef, float ef_scale,
                                  uint32_t *norm_bits, uint8_t *wire, void *stream) {
-    if (nseg < 1 || nchunks < 1 || n_bit < 1) return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_wide_compress: bad sizes");
+    if (nseg < 1 || nchunks < 1 || n_bit < 1) return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched (wide): bad sizes");
     if (!seg_table || !chunk_seg || !norm_bits || !wire)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_wide_compress: null pointer");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched (wide): null pointer");
     if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_wide_compress: random_mode must be OFF or DEVICE");
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched (wide): random_mode must be OFF or DEVICE");
     const int bits = gq_qsgd_code_bits(n_bit, random_mode);
-    if (!bits) return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_wide_compress: n_bit %d has no packed format", n_bit);
+    if (!bits) return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched (wide): n_bit %d has no packed format", n_bit);
     hipStream_t st = gq::as_stream(stream);
     const dim3 grid((unsigned)gq::qw_grid(nchunks)), block(gq::QW_THREADS);
     if (ef)
@@ -347,21 +347,21 @@ GQ_API int gq_qsgd_wide_compress(const int64_t *seg_table, const int32_t *chunk_
     else if (bits == 8) GQ_QW_LAUNCH(false, 8);
     else GQ_QW_LAUNCH(false, 16);
 #undef GQ_QW_LAUNCH
-    GQ_CHECK_LAUNCH("gq_qsgd_wide_compress");
+    GQ_CHECK_LAUNCH("gq_qsgd_compress_batched (wide)");
     return GQ_OK;
 }
 
-GQ_API int gq_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks,
-                                   int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                   float *out, void *stream) {
-    const int plain = gq::take_decode_plain() ? 1 : 0;   // consumed even when the call is refused below
+GQ_INTERNAL int gqi_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks,
+                                         int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                         float *out, int plain, void *stream) {
+    plain = plain ? 1 : 0;
     if (nseg < 1 || nchunks < 1 || n_bit < 1 || R < 1 || (bits != 4 && bits != 8 && bits != 16))
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_wide_decode_sum: bad sizes");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched (wide): bad sizes");
     if (!seg_table || !chunk_seg || !gathered || !out)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_wide_decode_sum: null pointer");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched (wide): null pointer");
     if ((user_stride_bytes & 3) != 0 || (reinterpret_cast<uintptr_t>(gathered) & 3) != 0 ||
         (reinterpret_cast<uintptr_t>(out) & 15) != 0)
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_wide_decode_sum: wires must be 4-byte, out 16-byte aligned");
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched (wide): wires must be 4-byte, out 16-byte aligned");
     const dim3 grid((unsigned)gq::qw_grid(nchunks)), block(gq::QW_THREADS);
     if (bits == 4)
         hipLaunchKernelGGL(gq::qsgd_wide_decode_kernel<4>, grid, block, 0, gq::as_stream(stream), seg_table, chunk_seg,
@@ -372,6 +372,6 @@ GQ_API int gq_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chun
     else
         hipLaunchKernelGGL(gq::qsgd_wide_decode_kernel<8>, grid, block, 0, gq::as_stream(stream), seg_table, chunk_seg,
                            nchunks, n_bit, gathered, user_stride_bytes, R, out, plain);
-    GQ_CHECK_LAUNCH("gq_qsgd_wide_decode_sum");
+    GQ_CHECK_LAUNCH("gq_qsgd_decode_sum_batched (wide)");
     return GQ_OK;
 }

@@ -18,17 +18,14 @@ GQ_FIXUP_PARTIALS = 256
 RANDOM_OFF, RANDOM_GIVEN, RANDOM_DEVICE = 0, 1, 2
 ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFILTER_D16K256 = 0, 1, 2, 3, 4
 
-EXPORTS = [
-    "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_workspace_bytes", "gq_hsq_encode", "gq_hsq_encode_impl", "gq_hsq_levels",
-    "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched",
-    "gq_hsq_encode_batched_ef", "gq_hsq_levels_batched_ef", "gq_qsgd_compress_batched_ef",
-    "gq_hsq_encode_batched_d", "gq_hsq_decode_sum_batched_d", "gq_hsq_encode_batched_d_ef", "gq_hsq_levels_batched_ef_d",
-    "gq_hsq_encode_batched_any", "gq_hsq_levels_batched_any", "gq_hsq_decode_sum_batched_any", "gq_hsq_error_batched_any",
-    "gq_hsq_batched_any_supported", "gq_hsq_encode_batched_paged", "gq_qsgd_wide_compress", "gq_qsgd_wide_decode_sum",
-    "gq_profile_arm", "gq_profile_read", "gq_hsq_compress", "gq_hsq_given_draws", "gq_decode_plain_next", "gq_mean_rows",
-    "gq_pvq_encode", "gq_pvq_encode_residual", "gq_qsgd_code_bits", "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched",
-    "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided", "gq_axpy_inplace", "gq_sub", "gq_qsgd_compress", "gq_qsgd_decode_sum",
+EXPORTS = [     # every entry point include/gq_hsq.h declares (tests/test_host_logic.py compares the two lists)
+    "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_workspace_bytes", "gq_profile_read",
+    "gq_hsq_encode", "gq_hsq_encode_ex", "gq_hsq_levels", "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided",
+    "gq_hsq_batched_path", "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched",
+    "gq_axpy_inplace", "gq_sub", "gq_mean_rows", "gq_qsgd_compress", "gq_qsgd_decode_sum", "gq_qsgd_code_bits",
+    "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched", "gq_pvq_encode",
 ]
+ABI_VERSION = 2
 
 _lib = None
 
@@ -51,6 +48,9 @@ def lib():
         L.gq_hsq_workspace_bytes.restype = ctypes.c_size_t
         for name in EXPORTS:
             getattr(L, name)  # AttributeError if the library is stale
+        if L.gq_abi_version() != ABI_VERSION:
+            raise GQNativeError("%s has ABI version %d, this binding is written for %d: rebuild it"
+                                % (LIB_PATH, L.gq_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 
@@ -112,13 +112,8 @@ def mark_worklist(workspace, M):
     workspace[2 * GQ_MAX_PARTIALS + 4:2 * GQ_MAX_PARTIALS + 4 + M].view(torch.int32).fill_(-1)
 
 
-def profile_arm(slot):
-    """The next d16/K256 hsq_encode on this thread carries a start/stop event pair on its dispatch."""
-    _check(lib().gq_profile_arm(ctypes.c_int(slot)), "gq_profile_arm")
-
-
 def profile_read(slot):
-    """Duration (ms) of the dispatch armed under `slot`; waits for it."""
+    """Duration (ms) of the encode dispatch that was handed `slot` (hsq_encode(profile_slot=...), HSQBatch.encode); waits for it."""
     ms = ctypes.c_float(0.0)
     _check(lib().gq_profile_read(ctypes.c_int(slot), ctypes.byref(ms)), "gq_profile_read")
     return ms.value
@@ -131,34 +126,25 @@ def device_info(device=0):
     return cus.value, arch.value.decode()
 
 
-def hsq_encode(grad, codebook, codes, u, partials, impl=ENCODE_AUTO):
-    """grad f32 [M*d] -> codes (uint8|int32 [M]), u f32 [M]; `partials` = new_workspace(device, M)."""
+def hsq_encode(grad, codebook, codes, u, partials, impl=ENCODE_AUTO, profile_slot=-1):
+    """grad f32 [M*d] -> codes (uint8|int32 [M]), u f32 [M]; `partials` = new_workspace(device, M).
+    profile_slot >= 0: the d16/K256 prefilter kernel's dispatch carries that slot's start/stop events (profile_read)."""
     K, d = codebook.shape
     M = grad.numel() // d
     assert grad.numel() == M * d and codes.numel() == M and u.numel() == M
     assert partials.numel() >= workspace_floats(M), "encode workspace too small: use native.new_workspace(device, M)"
-    rc = lib().gq_hsq_encode_impl(_dev_ptr(grad, torch.float32, "grad"), _dev_ptr(codebook, torch.float32, "codebook"),
-                                  ctypes.c_int64(M), ctypes.c_int(d), ctypes.c_int(K), _dev_ptr(codes, None, "codes"),
-                                  ctypes.c_int(_CODE_BYTES[codes.dtype]), _dev_ptr(u, torch.float32, "u"),
-                                  _dev_ptr(partials, torch.float32, "partials"), ctypes.c_int(impl), _stream())
+    rc = lib().gq_hsq_encode_ex(_dev_ptr(grad, torch.float32, "grad"), _dev_ptr(codebook, torch.float32, "codebook"),
+                                ctypes.c_int64(M), ctypes.c_int(d), ctypes.c_int(K), _dev_ptr(codes, None, "codes"),
+                                ctypes.c_int(_CODE_BYTES[codes.dtype]), _dev_ptr(u, torch.float32, "u"),
+                                _dev_ptr(partials, torch.float32, "partials"), ctypes.c_int(impl), ctypes.c_int(profile_slot),
+                                _stream())
     _check(rc, "gq_hsq_encode")
 
 
 def hsq_compress(grad, codebook, codes, u, workspace, n_bit, random_mode, r, seed, lb_ub, levels):
-    """encode + level quantiser (gq_hsq_compress: one cooperative launch for d16/K256 with byte levels)."""
-    K, d = codebook.shape
-    M = grad.numel() // d
-    assert grad.numel() == M * d and codes.numel() == M and u.numel() == M and levels.numel() == M
-    assert workspace.numel() >= workspace_floats(M)
-    rc = lib().gq_hsq_compress(_dev_ptr(grad, torch.float32, "grad"), _dev_ptr(codebook, torch.float32, "codebook"),
-                               ctypes.c_int64(M), ctypes.c_int(d), ctypes.c_int(K), _dev_ptr(codes, None, "codes"),
-                               ctypes.c_int(_CODE_BYTES[codes.dtype]), _dev_ptr(u, torch.float32, "u"),
-                               _dev_ptr(workspace, torch.float32, "workspace"), ctypes.c_int(n_bit),
-                               ctypes.c_int(random_mode),
-                               _dev_ptr(r, torch.float32, "r") if r is not None else ctypes.c_void_p(0),
-                               ctypes.c_uint64(seed & (2 ** 64 - 1)), _dev_ptr(lb_ub, torch.float32, "lb_ub"),
-                               _dev_ptr(levels, None, "levels"), ctypes.c_int(_LEVEL_BYTES[levels.dtype]), _stream())
-    _check(rc, "gq_hsq_compress")
+    """The whole compress (nearest_neighbor_compressor.py:63-78): gq_hsq_encode, then gq_hsq_levels, on the same stream."""
+    hsq_encode(grad, codebook, codes, u, workspace)
+    hsq_levels(u, n_bit, random_mode, r, seed, workspace, lb_ub, levels)
 
 
 def hsq_levels(u, n_bit, random_mode, r, seed, partials, lb_ub, levels):
@@ -218,48 +204,85 @@ def hsq_decode_sum_packed(wire, M, codebook, n_bit, out, R, codes_off=0, levels_
     _check(rc, "gq_hsq_decode_sum_strided")
 
 
-def hsq_encode_batched(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace, ef_scale=None):
-    """ef_scale given: the error-feedback form (seg_table[:, 7] = error buffers, grads updated in place).
-    The codebook's sub-dimension picks the kernel (K = 256; d = 16, or 8 / 32 without error feedback)."""
-    assert workspace.numel() >= workspace_floats(ntiles * 64)
-    d = int(codebook.shape[1])
-    if d != 16 and ef_scale is not None:
-        rc = lib().gq_hsq_encode_batched_d_ef(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                              _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                              ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
-                                              ctypes.c_int(d), ctypes.c_float(ef_scale), _dev_ptr(wire, torch.uint8, "wire"),
-                                              _dev_ptr(u_flat, torch.float32, "u_flat"),
-                                              _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
-                                              _dev_ptr(workspace, torch.float32, "workspace"), _stream())
-        _check(rc, "gq_hsq_encode_batched_d_ef")
-        return
-    if d != 16:
-        rc = lib().gq_hsq_encode_batched_d(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                           _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                           ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
-                                           ctypes.c_int(d), _dev_ptr(wire, torch.uint8, "wire"),
-                                           _dev_ptr(u_flat, torch.float32, "u_flat"),
-                                           _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
-                                           _dev_ptr(workspace, torch.float32, "workspace"), _stream())
-        _check(rc, "gq_hsq_encode_batched_d")
-        return
-    if ef_scale is not None:
-        rc = lib().gq_hsq_encode_batched_ef(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                            _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                            ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
-                                            ctypes.c_float(ef_scale), _dev_ptr(wire, torch.uint8, "wire"),
-                                            _dev_ptr(u_flat, torch.float32, "u_flat"),
-                                            _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
-                                            _dev_ptr(workspace, torch.float32, "workspace"), _stream())
-        _check(rc, "gq_hsq_encode_batched_ef")
-        return
-    rc = lib().gq_hsq_encode_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                     _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                     ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
-                                     _dev_ptr(wire, torch.uint8, "wire"), _dev_ptr(u_flat, torch.float32, "u_flat"),
-                                     _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
-                                     _dev_ptr(workspace, torch.float32, "workspace"), _stream())
-    _check(rc, "gq_hsq_encode_batched")
+class _HSQBatchStruct(ctypes.Structure):      # gq_hsq_batch (include/gq_hsq.h)
+    _fields_ = [("struct_bytes", ctypes.c_uint32), ("d", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("code_bytes", ctypes.c_int32), ("level_bytes", ctypes.c_int32), ("n_bit", ctypes.c_int32),
+                ("nseg", ctypes.c_int32), ("profile_slot", ctypes.c_int32), ("ntiles", ctypes.c_int64),
+                ("seg_table", ctypes.c_void_p), ("tile_seg", ctypes.c_void_p), ("codebook", ctypes.c_void_p),
+                ("u_flat", ctypes.c_void_p), ("seg_minmax", ctypes.c_void_p), ("workspace", ctypes.c_void_p)]
+
+
+_NAN = float("nan")
+BATCH_PREFILTER, BATCH_PAGED, BATCH_EXACT = 1, 2, 3
+
+
+class HSQBatch(object):
+    """The multi-tensor HSQ launches of one group of tensors that share a codebook: the gq_hsq_batch descriptor is
+    filled ONCE (every pointer and size that does not change from step to step), a step's calls only hand over the
+    wire and the stream -- ~3 us of marshalling per launch (the quantizer step is host-bound).  Which kernels serve
+    the shape is the library's decision (gq_hsq_batched_path); `path` is 0 when none does."""
+
+    def __init__(self, seg_table, tile_seg, nseg, ntiles, codebook, code_dtype, level_dtype, n_bit, u_flat=None,
+                 seg_minmax=None, workspace=None):
+        self.L = lib()
+        self.keep = (seg_table, tile_seg, codebook, u_flat, seg_minmax, workspace)     # the pointers below stay valid
+        self.device = seg_table.device.index
+        K, d = int(codebook.shape[0]), int(codebook.shape[1])
+        if workspace is not None:
+            assert workspace.numel() >= workspace_floats(ntiles * 64)
+        opt = lambda t, dt, nm: _dev_ptr(t, dt, nm).value if t is not None else None
+        self.s = _HSQBatchStruct(ctypes.sizeof(_HSQBatchStruct), d, K, _CODE_BYTES[code_dtype], _LEVEL_BYTES[level_dtype],
+                                 int(n_bit), int(nseg), -1, int(ntiles), _dev_ptr(seg_table, torch.int64, "seg_table").value,
+                                 _dev_ptr(tile_seg, torch.int32, "tile_seg").value,
+                                 _dev_ptr(codebook, torch.float32, "codebook").value, opt(u_flat, torch.float32, "u_flat"),
+                                 opt(seg_minmax, torch.int32, "seg_minmax"), opt(workspace, torch.float32, "workspace"))
+        self.ref = ctypes.byref(self.s)
+        self.path = int(self.L.gq_hsq_batched_path(self.ref))
+
+    def part(self, seg_table, tile_seg, nseg, ntiles):
+        """The same configuration over another table (the head / tail of a split decode)."""
+        codebook = self.keep[2]
+        code_dtype = {v: k for k, v in _CODE_BYTES.items()}[self.s.code_bytes]
+        level_dtype = {v: k for k, v in _LEVEL_BYTES.items()}[self.s.level_bytes]
+        return HSQBatch(seg_table, tile_seg, nseg, ntiles, codebook, code_dtype, level_dtype, self.s.n_bit)
+
+    def _wire(self, wire):
+        if wire.device.index != self.device or wire.device.index != torch._C._cuda_getDevice():
+            raise GQNativeError("wire is on %s, this batch's launches are for cuda:%d (the current device must match)"
+                                % (wire.device, self.device))
+        return ctypes.c_void_p(wire.data_ptr())
+
+    def encode(self, wire, ef_scale=None, profile_slot=-1):
+        """ef_scale given: the error-feedback form (seg_table[:, 7] = error buffers, grads updated in place)."""
+        self.s.profile_slot = profile_slot
+        rc = self.L.gq_hsq_encode_batched(self.ref, self._wire(wire), ctypes.c_float(_NAN if ef_scale is None else ef_scale),
+                                          _stream())
+        self.s.profile_slot = -1
+        _check(rc, "gq_hsq_encode_batched")
+
+    def levels(self, wire, random_mode, seed, r_flat=None, write_error=False):
+        """r_flat: the reference's draws laid out like u_flat (random_mode = RANDOM_GIVEN).  write_error: also
+        error = grad - decode(wire) into the buffers of seg_table[:, 7] (after an encode with ef_scale)."""
+        rp = _dev_ptr(r_flat, torch.float32, "r_flat") if r_flat is not None else ctypes.c_void_p(0)
+        rc = self.L.gq_hsq_levels_batched(self.ref, self._wire(wire), ctypes.c_int(random_mode),
+                                          ctypes.c_uint64(seed & (2 ** 64 - 1)), rp, ctypes.c_int(1 if write_error else 0),
+                                          _stream())
+        _check(rc, "gq_hsq_levels_batched")
+
+    def decode(self, gathered, R, out, plain=False):
+        """Mean of the R payloads (plain: the decompress of ONE payload as the reference returns it, a -0 stays -0)."""
+        assert gathered.dtype == torch.uint8 and gathered.dim() == 2 and gathered.shape[0] == R and gathered.stride(1) == 1
+        stride = int(gathered.stride(0)) if R > 1 else int(gathered.shape[1])
+        rc = self.L.gq_hsq_decode_sum_batched(self.ref, self._wire(gathered), ctypes.c_int64(stride), ctypes.c_int(R),
+                                              _dev_ptr(out, torch.float32, "out"), ctypes.c_int(1 if plain else 0), _stream())
+        _check(rc, "gq_hsq_decode_sum_batched")
+
+
+def hsq_batched_path(d, K, code_dtype, nseg=1):
+    """Which multi-tensor encode serves (d, K, code width, number of tensors): BATCH_PREFILTER / PAGED / EXACT or 0."""
+    s = _HSQBatchStruct(ctypes.sizeof(_HSQBatchStruct), int(d), int(K), _CODE_BYTES[code_dtype], 1, 6, int(nseg), -1, 1, 1, 1, 1,
+                        None, None, None)      # the path depends on the shape only; the (non-null) pointers are not read
+    return int(lib().gq_hsq_batched_path(ctypes.byref(s)))
 
 
 def mean_rows(rows, out):
@@ -274,283 +297,79 @@ def mean_rows(rows, out):
                               _dev_ptr(out, torch.float32, "out"), _stream()), "gq_mean_rows")
 
 
-def decode_plain_next():
-    """The next multi-tensor decode of this thread is the plain decompress of its payload (a -0 stays -0), not the
-    aggregate (+0 + sum) / R: RingQuantizer's hop and final gradient (ring_quantizer.py:32,41-47)."""
-    _check(lib().gq_decode_plain_next(), "gq_decode_plain_next")
+
+class _QSGDBatchStruct(ctypes.Structure):     # gq_qsgd_batch (include/gq_hsq.h)
+    _fields_ = [("struct_bytes", ctypes.c_uint32), ("n_bit", ctypes.c_int32), ("bits", ctypes.c_int32),
+                ("wide", ctypes.c_int32), ("nseg", ctypes.c_int32), ("reserved", ctypes.c_int32), ("nitems", ctypes.c_int64),
+                ("seg_table", ctypes.c_void_p), ("item_seg", ctypes.c_void_p), ("norm_bits", ctypes.c_void_p)]
 
 
-def hsq_given_draws(r_flat):
-    """The reference's draws (laid out like u_flat) for the next hsq_levels_batched* call with RANDOM_GIVEN."""
-    _check(lib().gq_hsq_given_draws(_dev_ptr(r_flat, torch.float32, "r_flat")), "gq_hsq_given_draws")
+class QSGDBatch(object):
+    """The multi-tensor QSGD launches on the packed wire (buckets, or chunks of wide buckets: `wide`)."""
 
-
-class PreparedHSQ16(object):
-    """The three multi-tensor launches of the default configuration (d = 16, K = 256, byte codes and levels) with
-    every argument that does not change from step to step converted to its ctypes form ONCE: the per-step cost of a
-    launch drops from ~12 us of argument marshalling to ~3 us (the quantizer step is host-bound)."""
-
-    def __init__(self, seg_table, tile_seg, nseg, ntiles, codebook, u_flat, seg_minmax, workspace, n_bit):
+    def __init__(self, seg_table, item_seg, nseg, nitems, n_bit, bits, wide=False, norm_bits=None):
         self.L = lib()
-        self.keep = (seg_table, tile_seg, codebook, u_flat, seg_minmax, workspace)     # the pointers below stay valid
-        self.device = seg_table.device.index
-        self.seg = _dev_ptr(seg_table, torch.int64, "seg_table")
-        self.tile = _dev_ptr(tile_seg, torch.int32, "tile_seg")
-        self.cb = _dev_ptr(codebook, torch.float32, "codebook")
-        self.u = _dev_ptr(u_flat, torch.float32, "u_flat")
-        self.mm = _dev_ptr(seg_minmax, torch.int32, "seg_minmax")
-        self.ws = _dev_ptr(workspace, torch.float32, "workspace")
-        self.nseg, self.ntiles, self.n_bit = ctypes.c_int(nseg), ctypes.c_int64(ntiles), ctypes.c_int(n_bit)
+        self.keep = (seg_table, item_seg, norm_bits)
+        self.s = _QSGDBatchStruct(ctypes.sizeof(_QSGDBatchStruct), int(n_bit), int(bits), 1 if wide else 0, int(nseg), 0,
+                                  int(nitems), _dev_ptr(seg_table, torch.int64, "seg_table").value,
+                                  _dev_ptr(item_seg, torch.int32, "item_seg").value,
+                                  _dev_ptr(norm_bits, torch.int32, "norm_bits").value if norm_bits is not None else None)
+        self.ref = ctypes.byref(self.s)
 
-    def _wire(self, wire):
-        if wire.device.index != self.device or wire.device.index != torch._C._cuda_getDevice():
-            raise GQNativeError("wire is on %s, the prepared launches are for cuda:%d (the current device must match)"
-                                % (wire.device, self.device))
-        return ctypes.c_void_p(wire.data_ptr())
+    def part(self, seg_table, item_seg, nseg, nitems):
+        return QSGDBatch(seg_table, item_seg, nseg, nitems, self.s.n_bit, self.s.bits, bool(self.s.wide), self.keep[2])
 
-    def encode(self, wire, ef_scale=None):
-        w, st = self._wire(wire), _stream()
-        if ef_scale is None:
-            rc = self.L.gq_hsq_encode_batched(self.seg, self.tile, self.nseg, self.ntiles, self.cb, w, self.u, self.mm, self.ws, st)
-        else:
-            rc = self.L.gq_hsq_encode_batched_ef(self.seg, self.tile, self.nseg, self.ntiles, self.cb, ctypes.c_float(ef_scale),
-                                                 w, self.u, self.mm, self.ws, st)
-        _check(rc, "gq_hsq_encode_batched")
+    def compress(self, wire, random_mode, seed, ef_scale=None):
+        """ef_scale given: error feedback in the same pass (seg_table[:, 7] = error buffers)."""
+        rc = self.L.gq_qsgd_compress_batched(self.ref, _dev_ptr(wire, torch.uint8, "wire"), ctypes.c_int(random_mode),
+                                             ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                                             ctypes.c_float(_NAN if ef_scale is None else ef_scale), _stream())
+        _check(rc, "gq_qsgd_compress_batched")
 
-    def levels(self, wire, random_mode, seed, ef=False):
-        w, st = self._wire(wire), _stream()
-        sd = ctypes.c_uint64(seed & (2 ** 64 - 1))
-        if ef:
-            rc = self.L.gq_hsq_levels_batched_ef(self.seg, self.tile, self.nseg, self.ntiles, self.u, self.mm, self.n_bit,
-                                                 ctypes.c_int(random_mode), sd, self.cb, w, st)
-        else:
-            rc = self.L.gq_hsq_levels_batched(self.seg, self.tile, self.nseg, self.ntiles, self.u, self.mm, self.n_bit,
-                                              ctypes.c_int(random_mode), sd, w, st)
-        _check(rc, "gq_hsq_levels_batched")
-
-    def decode(self, gathered, R, out):
+    def decode(self, gathered, R, out, plain=False):
         assert gathered.dtype == torch.uint8 and gathered.dim() == 2 and gathered.shape[0] == R and gathered.is_contiguous()
-        rc = self.L.gq_hsq_decode_sum_batched(self.seg, self.tile, self.nseg, self.ntiles, self._wire(gathered),
-                                              ctypes.c_int64(gathered.shape[1]), ctypes.c_int(R), self.cb, self.n_bit,
-                                              _dev_ptr(out, torch.float32, "out"), _stream())
-        _check(rc, "gq_hsq_decode_sum_batched")
-
-
-def hsq_batched_any_supported(d, K):
-    """True if gq_hsq_encode_batched_any serves sub-dimension d with K codewords (a tile and 32 codebook rows fit the LDS)."""
-    return bool(lib().gq_hsq_batched_any_supported(ctypes.c_int(int(d)), ctypes.c_int(int(K))))
-
-
-def hsq_encode_batched_any(seg_table, tile_seg, nseg, ntiles, codebook, code_dtype, wire, u_flat, seg_minmax,
-                           ef_scale=None):
-    """Any (d <= 128, K): exact scoring; ef_scale given = tiles are read as grad + ef_scale*error, written back."""
-    K, d = int(codebook.shape[0]), int(codebook.shape[1])
-    rc = lib().gq_hsq_encode_batched_any(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                         _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                         ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
-                                         ctypes.c_int(d), ctypes.c_int(K), ctypes.c_int(_CODE_BYTES[code_dtype]),
-                                         ctypes.c_int(0 if ef_scale is None else 1),
-                                         ctypes.c_float(0.0 if ef_scale is None else ef_scale),
-                                         _dev_ptr(wire, torch.uint8, "wire"), _dev_ptr(u_flat, torch.float32, "u_flat"),
-                                         _dev_ptr(seg_minmax, torch.int32, "seg_minmax"), _stream())
-    _check(rc, "gq_hsq_encode_batched_any")
-
-
-def hsq_encode_batched_paged(seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, workspace,
-                             ef_scale=None):
-    """d in {8, 16, 32}, K = 256 * pages, int32 codes: the prefilter kernel once per page of 256 codewords."""
-    K, d = int(codebook.shape[0]), int(codebook.shape[1])
-    assert workspace.numel() >= workspace_floats(ntiles * 64)
-    rc = lib().gq_hsq_encode_batched_paged(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                           _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                           ctypes.c_int64(ntiles), _dev_ptr(codebook, torch.float32, "codebook"),
-                                           ctypes.c_int(d), ctypes.c_int(K), ctypes.c_int(0 if ef_scale is None else 1),
-                                           ctypes.c_float(0.0 if ef_scale is None else ef_scale),
-                                           _dev_ptr(wire, torch.uint8, "wire"), _dev_ptr(u_flat, torch.float32, "u_flat"),
-                                           _dev_ptr(seg_minmax, torch.int32, "seg_minmax"),
-                                           _dev_ptr(workspace, torch.float32, "workspace"), _stream())
-    _check(rc, "gq_hsq_encode_batched_paged")
-
-
-def hsq_levels_batched_any(seg_table, tile_seg, nseg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, level_dtype,
-                           wire):
-    rc = lib().gq_hsq_levels_batched_any(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                         _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                         ctypes.c_int64(ntiles), _dev_ptr(u_flat, torch.float32, "u_flat"),
-                                         _dev_ptr(seg_minmax, torch.int32, "seg_minmax"), ctypes.c_int(n_bit),
-                                         ctypes.c_int(random_mode), ctypes.c_uint64(seed & (2 ** 64 - 1)),
-                                         ctypes.c_int(_LEVEL_BYTES[level_dtype]), _dev_ptr(wire, torch.uint8, "wire"),
-                                         _stream())
-    _check(rc, "gq_hsq_levels_batched_any")
-
-
-def hsq_decode_sum_batched_any(seg_table, tile_seg, nseg, ntiles, gathered, codebook, code_dtype, level_dtype, n_bit, out,
-                               R):
-    assert gathered.dim() == 2 and gathered.shape[0] == R and gathered.stride(1) == 1
-    rc = lib().gq_hsq_decode_sum_batched_any(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                             _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                             ctypes.c_int64(ntiles), ctypes.c_void_p(gathered.data_ptr()),
-                                             ctypes.c_int64(gathered.stride(0)), ctypes.c_int(R),
-                                             _dev_ptr(codebook, torch.float32, "codebook"),
-                                             ctypes.c_int(int(codebook.shape[1])), ctypes.c_int(int(codebook.shape[0])),
-                                             ctypes.c_int(_CODE_BYTES[code_dtype]), ctypes.c_int(_LEVEL_BYTES[level_dtype]),
-                                             ctypes.c_int(n_bit), _dev_ptr(out, torch.float32, "out"), _stream())
-    _check(rc, "gq_hsq_decode_sum_batched_any")
-
-
-def hsq_error_batched_any(seg_table, tile_seg, nseg, ntiles, wire, codebook, code_dtype, level_dtype, n_bit):
-    """error = grad - decode(wire) for every row of the table that names an error buffer (column 7)."""
-    rc = lib().gq_hsq_error_batched_any(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                        _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                        ctypes.c_int64(ntiles), _dev_ptr(wire, torch.uint8, "wire"),
-                                        _dev_ptr(codebook, torch.float32, "codebook"),
-                                        ctypes.c_int(int(codebook.shape[1])), ctypes.c_int(int(codebook.shape[0])),
-                                        ctypes.c_int(_CODE_BYTES[code_dtype]), ctypes.c_int(_LEVEL_BYTES[level_dtype]),
-                                        ctypes.c_int(n_bit), _stream())
-    _check(rc, "gq_hsq_error_batched_any")
-
-
-def hsq_levels_batched(seg_table, tile_seg, nseg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, wire,
-                       ef_codebook=None):
-    """ef_codebook given: also writes error = grad - decoded into the buffers of seg_table[:, 7]."""
-    if ef_codebook is not None and int(ef_codebook.shape[1]) != 16:
-        rc = lib().gq_hsq_levels_batched_ef_d(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                              _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                              ctypes.c_int64(ntiles), _dev_ptr(u_flat, torch.float32, "u_flat"),
-                                              _dev_ptr(seg_minmax, torch.int32, "seg_minmax"), ctypes.c_int(n_bit),
-                                              ctypes.c_int(random_mode), ctypes.c_uint64(seed & (2 ** 64 - 1)),
-                                              _dev_ptr(ef_codebook, torch.float32, "codebook"),
-                                              ctypes.c_int(int(ef_codebook.shape[1])),
-                                              _dev_ptr(wire, torch.uint8, "wire"), _stream())
-        _check(rc, "gq_hsq_levels_batched_ef_d")
-        return
-    if ef_codebook is not None:
-        rc = lib().gq_hsq_levels_batched_ef(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                            _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                            ctypes.c_int64(ntiles), _dev_ptr(u_flat, torch.float32, "u_flat"),
-                                            _dev_ptr(seg_minmax, torch.int32, "seg_minmax"), ctypes.c_int(n_bit),
-                                            ctypes.c_int(random_mode), ctypes.c_uint64(seed & (2 ** 64 - 1)),
-                                            _dev_ptr(ef_codebook, torch.float32, "codebook"),
-                                            _dev_ptr(wire, torch.uint8, "wire"), _stream())
-        _check(rc, "gq_hsq_levels_batched_ef")
-        return
-    rc = lib().gq_hsq_levels_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                     _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                     ctypes.c_int64(ntiles), _dev_ptr(u_flat, torch.float32, "u_flat"),
-                                     _dev_ptr(seg_minmax, torch.int32, "seg_minmax"), ctypes.c_int(n_bit),
-                                     ctypes.c_int(random_mode), ctypes.c_uint64(seed & (2 ** 64 - 1)),
-                                     _dev_ptr(wire, torch.uint8, "wire"), _stream())
-    _check(rc, "gq_hsq_levels_batched")
-
-
-def hsq_decode_sum_batched(seg_table, tile_seg, nseg, ntiles, gathered, codebook, n_bit, out, R):
-    assert gathered.dtype == torch.uint8 and gathered.dim() == 2 and gathered.shape[0] == R and gathered.is_contiguous()
-    d = int(codebook.shape[1])
-    if d != 16:
-        rc = lib().gq_hsq_decode_sum_batched_d(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                               _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                               ctypes.c_int64(ntiles), _dev_ptr(gathered, torch.uint8, "gathered"),
+        rc = self.L.gq_qsgd_decode_sum_batched(self.ref, _dev_ptr(gathered, torch.uint8, "gathered"),
                                                ctypes.c_int64(gathered.shape[1]), ctypes.c_int(R),
-                                               _dev_ptr(codebook, torch.float32, "codebook"), ctypes.c_int(d),
-                                               ctypes.c_int(n_bit), _dev_ptr(out, torch.float32, "out"), _stream())
-        _check(rc, "gq_hsq_decode_sum_batched_d")
-        return
-    rc = lib().gq_hsq_decode_sum_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                         _dev_ptr(tile_seg, torch.int32, "tile_seg"), ctypes.c_int(nseg),
-                                         ctypes.c_int64(ntiles), _dev_ptr(gathered, torch.uint8, "gathered"),
-                                         ctypes.c_int64(gathered.shape[1]), ctypes.c_int(R),
-                                         _dev_ptr(codebook, torch.float32, "codebook"), ctypes.c_int(n_bit),
-                                         _dev_ptr(out, torch.float32, "out"), _stream())
-    _check(rc, "gq_hsq_decode_sum_batched")
+                                               _dev_ptr(out, torch.float32, "out"), ctypes.c_int(1 if plain else 0), _stream())
+        _check(rc, "gq_qsgd_decode_sum_batched")
 
 
-def pvq_encode(grad, c_dagger, codes, u, workspace, random_mode, r, seed):
+class _PVQStage1(ctypes.Structure):           # gq_pvq_stage1
+    _fields_ = [("codes1", ctypes.c_void_p), ("code1_bytes", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("norm1", ctypes.c_void_p), ("codebook1", ctypes.c_void_p)]
+
+
+def pvq_encode(grad, c_dagger, codes, u, workspace, random_mode, r, seed, stage1=None):
+    """stage1 = (codes1, norm1, codebook1): the encode of  grad - codebook1[codes1] * norm1  without materialising it
+    (the ResidualCompressor's second stage)."""
     K, d = c_dagger.shape
     M = grad.numel() // d
     assert grad.numel() == M * d and codes.numel() == M and u.numel() == M
     rp = _dev_ptr(r, torch.float32, "r") if r is not None else ctypes.c_void_p(0)
+    st1 = ctypes.c_void_p(0)
+    if stage1 is not None:
+        codes1, norm1, codebook1 = stage1
+        assert codes1.numel() == M and norm1.numel() == M and codebook1.shape[1] == d
+        st1 = ctypes.byref(_PVQStage1(_dev_ptr(codes1, None, "codes1").value, _CODE_BYTES[codes1.dtype], 0,
+                                      _dev_ptr(norm1, torch.float32, "norm1").value,
+                                      _dev_ptr(codebook1, torch.float32, "codebook1").value))
     rc = lib().gq_pvq_encode(_dev_ptr(grad, torch.float32, "grad"), _dev_ptr(c_dagger, torch.float32, "c_dagger"),
                              ctypes.c_int64(M), ctypes.c_int(d), ctypes.c_int(K), ctypes.c_int(random_mode), rp,
                              ctypes.c_uint64(seed & (2 ** 64 - 1)), _dev_ptr(codes, None, "codes"),
                              ctypes.c_int(_CODE_BYTES[codes.dtype]), _dev_ptr(u, torch.float32, "u"),
-                             _dev_ptr(workspace, torch.float32, "workspace"), _stream())
+                             _dev_ptr(workspace, torch.float32, "workspace"), st1, _stream())
     _check(rc, "gq_pvq_encode")
 
 
 def pvq_encode_residual(grad, codes1, norm1, codebook1, c_dagger, codes, u, workspace, random_mode, r, seed):
-    """PVQ encode of  grad - codebook1[codes1] * norm1  without materialising it (ResidualCompressor's second stage)."""
-    K, d = c_dagger.shape
-    M = grad.numel() // d
-    assert grad.numel() == M * d and codes.numel() == M and u.numel() == M and codes1.numel() == M and norm1.numel() == M
-    assert codebook1.shape[1] == d
-    rp = _dev_ptr(r, torch.float32, "r") if r is not None else ctypes.c_void_p(0)
-    rc = lib().gq_pvq_encode_residual(_dev_ptr(grad, torch.float32, "grad"), _dev_ptr(codes1, None, "codes1"),
-                                      ctypes.c_int(_CODE_BYTES[codes1.dtype]), _dev_ptr(norm1, torch.float32, "norm1"),
-                                      _dev_ptr(codebook1, torch.float32, "codebook1"),
-                                      _dev_ptr(c_dagger, torch.float32, "c_dagger"), ctypes.c_int64(M), ctypes.c_int(d),
-                                      ctypes.c_int(K), ctypes.c_int(random_mode), rp, ctypes.c_uint64(seed & (2 ** 64 - 1)),
-                                      _dev_ptr(codes, None, "codes"), ctypes.c_int(_CODE_BYTES[codes.dtype]),
-                                      _dev_ptr(u, torch.float32, "u"), _dev_ptr(workspace, torch.float32, "workspace"),
-                                      _stream())
-    _check(rc, "gq_pvq_encode_residual")
+    pvq_encode(grad, c_dagger, codes, u, workspace, random_mode, r, seed, stage1=(codes1, norm1, codebook1))
 
 
 def qsgd_code_bits(n_bit, random_mode):
     return int(lib().gq_qsgd_code_bits(ctypes.c_int(n_bit), ctypes.c_int(random_mode)))
 
 
-def qsgd_compress_batched(seg_table, bucket_seg, nseg, nbuckets, n_bit, random_mode, seed, wire, ef_scale=None):
-    """ef_scale given: error feedback in the same pass (seg_table[:, 7] = error buffers)."""
-    if ef_scale is not None:
-        rc = lib().gq_qsgd_compress_batched_ef(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                               _dev_ptr(bucket_seg, torch.int32, "bucket_seg"), ctypes.c_int(nseg),
-                                               ctypes.c_int64(nbuckets), ctypes.c_int(n_bit), ctypes.c_int(random_mode),
-                                               ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_float(ef_scale),
-                                               _dev_ptr(wire, torch.uint8, "wire"), _stream())
-        _check(rc, "gq_qsgd_compress_batched_ef")
-        return
-    rc = lib().gq_qsgd_compress_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                        _dev_ptr(bucket_seg, torch.int32, "bucket_seg"), ctypes.c_int(nseg),
-                                        ctypes.c_int64(nbuckets), ctypes.c_int(n_bit), ctypes.c_int(random_mode),
-                                        ctypes.c_uint64(seed & (2 ** 64 - 1)), _dev_ptr(wire, torch.uint8, "wire"),
-                                        _stream())
-    _check(rc, "gq_qsgd_compress_batched")
-
-
-def qsgd_decode_sum_batched(seg_table, bucket_seg, nseg, nbuckets, n_bit, bits, gathered, out, R):
-    assert gathered.dtype == torch.uint8 and gathered.dim() == 2 and gathered.shape[0] == R and gathered.is_contiguous()
-    rc = lib().gq_qsgd_decode_sum_batched(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                          _dev_ptr(bucket_seg, torch.int32, "bucket_seg"), ctypes.c_int(nseg),
-                                          ctypes.c_int64(nbuckets), ctypes.c_int(n_bit), ctypes.c_int(bits),
-                                          _dev_ptr(gathered, torch.uint8, "gathered"),
-                                          ctypes.c_int64(gathered.shape[1]), ctypes.c_int(R),
-                                          _dev_ptr(out, torch.float32, "out"), _stream())
-    _check(rc, "gq_qsgd_decode_sum_batched")
-
-
 QSGD_WIDE_CHUNK = 1024     # GQ_QSGD_WIDE_CHUNK (include/gq_hsq.h)
-
-
-def qsgd_wide_compress(seg_table, chunk_seg, nseg, nchunks, n_bit, random_mode, seed, norm_bits, wire, ef_scale=None):
-    """Wide buckets (TernGrad: the tensor is one bucket): bucket norms, then codes; ef_scale given = error feedback."""
-    rc = lib().gq_qsgd_wide_compress(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                     _dev_ptr(chunk_seg, torch.int32, "chunk_seg"), ctypes.c_int(nseg),
-                                     ctypes.c_int64(nchunks), ctypes.c_int(n_bit), ctypes.c_int(random_mode),
-                                     ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_int(0 if ef_scale is None else 1),
-                                     ctypes.c_float(0.0 if ef_scale is None else ef_scale),
-                                     _dev_ptr(norm_bits, torch.int32, "norm_bits"), _dev_ptr(wire, torch.uint8, "wire"),
-                                     _stream())
-    _check(rc, "gq_qsgd_wide_compress")
-
-
-def qsgd_wide_decode_sum(seg_table, chunk_seg, nseg, nchunks, n_bit, bits, gathered, out, R):
-    assert gathered.dtype == torch.uint8 and gathered.dim() == 2 and gathered.shape[0] == R and gathered.is_contiguous()
-    rc = lib().gq_qsgd_wide_decode_sum(_dev_ptr(seg_table, torch.int64, "seg_table"),
-                                       _dev_ptr(chunk_seg, torch.int32, "chunk_seg"), ctypes.c_int(nseg),
-                                       ctypes.c_int64(nchunks), ctypes.c_int(n_bit), ctypes.c_int(bits),
-                                       _dev_ptr(gathered, torch.uint8, "gathered"), ctypes.c_int64(gathered.shape[1]),
-                                       ctypes.c_int(R), _dev_ptr(out, torch.float32, "out"), _stream())
-    _check(rc, "gq_qsgd_wide_decode_sum")
 
 
 def axpy_inplace(grad, err, scale):

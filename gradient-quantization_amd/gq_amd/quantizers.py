@@ -310,7 +310,7 @@ class _BatchedBase(object):
         self.ready = False      # the device header has been written at least once
         self._outs, self._out_views, self._out_turn = [None, None], [None, None], 0
         self._layout = table.clone()    # host copy of the segment table without pointers (decode needs no pointers)
-        self._tail = None               # (first segment, first item, table, item->segment) of a split decode's second part
+        self._head = self._tail = None  # (first segment, launch descriptor) of the two parts of a split decode
 
     def _out_buffer(self, device, advance=True):
         """Decode target + its per-tensor views.  Two buffers used in turn (the mean and its two-phase
@@ -363,43 +363,37 @@ class _BatchedBase(object):
         return True
 
     def _part(self, part, first_seg):
-        """Tables of one part of a split decode (PSQuantizer.apply under GQ_EXCHANGE=split): "head" = the
+        """Launch descriptor of one part of a split decode (PSQuantizer.apply under GQ_EXCHANGE=split): "head" = the
         tensors before segment `first_seg` (the same device table, fewer items), "tail" = the others (a table
-        of their own, built once: segment and item indices restart at zero).  Returns (table, item->segment,
-        nseg, nitems) or None when the part is empty."""
+        of their own, built once: segment and item indices restart at zero).  None when the part is empty."""
         first_item = int(self._layout[first_seg, 2]) if first_seg < self.nseg else self._nitems
         if part == "head":
             if first_seg == 0:
                 return None
-            return self._dev[:self._table_words], self._item_seg, first_seg, first_item
+            if self._head is None or self._head[0] != first_seg:
+                self._head = (first_seg, self._batch.part(self._dev[:self._table_words], self._item_seg, first_seg, first_item))
+            return self._head[1]
         if first_seg >= self.nseg:
             return None
         if self._tail is None or self._tail[0] != first_seg:
             tab = self._layout[first_seg:].clone()
             tab[:, 2] -= first_item
             items = (self._item_seg[first_item:] - first_seg).contiguous()
-            self._tail = (first_seg, first_item, tab.view(-1).to(self.device), items)
-        return self._tail[2], self._tail[3], self.nseg - first_seg, self._nitems - first_item
+            self._tail = (first_seg, self._batch.part(tab.view(-1).to(self.device), items, self.nseg - first_seg,
+                                                      self._nitems - first_item))
+        return self._tail[1]
 
     def decode_mean(self, gathered, R, part=None, first_seg=0, plain=False):
         """Mean of the R payloads of `gathered` for every tensor of the group (views of one output buffer).
         part = "head" / "tail": only the tensors before / from segment `first_seg` (the two halves of a split
         exchange land in the same buffer: "head" first, then "tail").  plain: the decompress of ONE payload as the
-        reference returns it (a -0 stays -0) instead of the aggregate -- the flag is raised right before the launch
-        that consumes it."""
+        reference returns it (a -0 stays -0) instead of the aggregate."""
         if not self.ready:      # a rank that decodes before it has encoded anything (ring hop, late joiner)
             self.upload_layout()
         out, views = self._out_buffer(gathered.device, advance=part != "tail")
-        if part is None:
-            if plain:
-                native.decode_plain_next()
-            self._launch_decode(self._dev[:self._table_words], self._item_seg, self.nseg, self._nitems, gathered, R, out)
-        else:
-            tabs = self._part(part, first_seg)
-            if tabs is not None:
-                if plain:
-                    native.decode_plain_next()
-                self._launch_decode(tabs[0], tabs[1], tabs[2], tabs[3], gathered, R, out)
+        batch = self._batch if part is None else self._part(part, first_seg)
+        if batch is not None:
+            batch.decode(gathered, R, out, plain=plain)
         return views
 
     def upload_layout(self):
@@ -426,21 +420,16 @@ class BatchedHSQ(_BatchedBase):
     """All NearestNeighborCompressor tensors that share a codebook are encoded by ONE encode + ONE levels
     launch and decoded by ONE decode-mean launch (per-tensor lb / ub, identical results).  The reference
     walks the parameter list in Python (ps_quantizer.py:33,47); ResNet-50 has 76 such tensors.
-    K = 256, d in DIMS with byte-sized codes and levels take the prefilter encode and the specialised
-    levels / decode kernels; every other shape the exact multi-tensor kernels (gq_hsq_*_batched_any)."""
-
-    DIMS = (16, 8, 32)       # sub-dimensions with a multi-tensor prefilter encode (K = 256)
-
-    @staticmethod
-    def _prefilter(codec):
-        return codec.c.K == 256 and codec.c.dim in BatchedHSQ.DIMS and codec.code_dtype == torch.uint8
+    The library decides which kernels serve the group's shape (include/gq_hsq.h, gq_hsq_batched_path): K = 256 with
+    d = 8 / 16 / 32 and byte-sized codes the prefilter encode and the specialised levels / decode kernels, larger
+    codebooks of those dimensions the paged prefilter, every other shape exact scoring."""
 
     @staticmethod
     def eligible(codec):
         c = getattr(codec, "c", None)
         if type(codec) is not HSQCodec or c.K == c.dim:   # K == d: a random codebook per tensor
             return False
-        return BatchedHSQ._prefilter(codec) or native.hsq_batched_any_supported(c.dim, c.K)
+        return native.hsq_batched_path(c.dim, c.K, codec.code_dtype) != 0
 
     @staticmethod
     def group_key(codec):
@@ -480,18 +469,14 @@ class BatchedHSQ(_BatchedBase):
         self.u_flat = torch.empty(self.ntiles * 64, dtype=torch.float32, device=device)
         cd0 = self.codecs[0]
         self.code_dtype, self.level_dtype = cd0.code_dtype, cd0.level_dtype
-        self.prefilter = BatchedHSQ._prefilter(cd0)                                   # which encode
-        # larger codebooks of the prefilter dimensions: the prefilter kernel once per page of 256 codewords
-        self.paged = (c0.dim in BatchedHSQ.DIMS and c0.K > 256 and c0.K % 256 == 0 and self.code_dtype == torch.int32
-                      and nseg <= 384)
-        self.bytes = self.prefilter and self.level_dtype == torch.uint8               # which levels / decode
         self.align = 16 if c0.dim % 4 == 0 else 4
-        self.ws = native.new_workspace(device, self.ntiles * 64) if (self.prefilter or self.paged) else None
-        # the default configuration's launches with their constant arguments marshalled once
-        self._fast = None
-        if self.prefilter and self.bytes and c0.dim == 16:
-            self._fast = native.PreparedHSQ16(self._dev[:self._table_words], self.tile_seg, self.nseg, self.ntiles, self.codebook,
-                                              self.u_flat, self._dev[self._table_words:].view(torch.int32), self.ws, self.n_bit)
+        self.ws = native.new_workspace(device, self.ntiles * 64)
+        # ONE launch descriptor for the group (gq_hsq_batch): the library picks the kernels -- prefilter (K = 256,
+        # d = 8 / 16 / 32), the same with the pages of a larger codebook resident, or exact scoring for every other shape
+        self._batch = native.HSQBatch(self._dev[:self._table_words], self.tile_seg, self.nseg, self.ntiles, self.codebook,
+                                      self.code_dtype, self.level_dtype, self.n_bit, self.u_flat,
+                                      self._dev[self._table_words:].view(torch.int32), self.ws)
+        self.profile_slot = -1      # measurement hook (bench.py): the NEXT encode's dispatch is timed into this slot
 
     def _given_draws(self, draws):
         """draws = (r_all on the device, {parameter index: offset of its M draws}): the reference's
@@ -516,57 +501,23 @@ class BatchedHSQ(_BatchedBase):
         t += ef_scale*err (in place, before encoding) and err = t - decoded (in place, after)."""
         if self.reference_draws and draws is None:
             return False
-        if self.prefilter and self.codebook.shape[1] != 16 and self.nseg > 384:
-            return False    # d = 8 / 32: at most 384 tensors per launch
+        if self._batch.path == 0:       # e.g. more than 384 tensors of d = 8 / 32 and no exact kernel for the shape
+            return False
         if not self._upload(tensors, slot, self.align, errs):
             return False
         ef = ef_scale if errs is not None else None
-        if self._fast is not None:
-            self._fast.encode(wire_user, ef)
-            if self.reference_draws:
-                native.hsq_given_draws(self._given_draws(draws))
-                self._fast.levels(wire_user, native.RANDOM_GIVEN, 0, errs is not None)
-            elif self.random:
-                self._fast.levels(wire_user, native.RANDOM_DEVICE, _next_seed() ^ salt, errs is not None)
-            else:
-                self._fast.levels(wire_user, native.RANDOM_OFF, 0, errs is not None)
-            return True
-        seg_table = self._dev[:self._table_words]
-        minmax = self._dev[self._table_words:].view(torch.int32)
-        if self.prefilter:
-            native.hsq_encode_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.codebook, wire_user,
-                                      self.u_flat, minmax, self.ws, ef_scale=ef)
-        elif self.paged:
-            native.hsq_encode_batched_paged(seg_table, self.tile_seg, self.nseg, self.ntiles, self.codebook, wire_user,
-                                            self.u_flat, minmax, self.ws, ef_scale=ef)
+        self._batch.encode(wire_user, ef, self.profile_slot)
+        self.profile_slot = -1
+        if self.n_bit == 32:
+            mode, seed, r_flat = native.RANDOM_OFF, 0, None
+        elif self.reference_draws:
+            mode, seed, r_flat = native.RANDOM_GIVEN, 0, self._given_draws(draws)
+        elif self.random:
+            mode, seed, r_flat = native.RANDOM_DEVICE, _next_seed() ^ salt, None
         else:
-            native.hsq_encode_batched_any(seg_table, self.tile_seg, self.nseg, self.ntiles, self.codebook, self.code_dtype,
-                                          wire_user, self.u_flat, minmax, ef_scale=ef)
-        mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
-        seed = (_next_seed() ^ salt) if self.random else 0
-        if self.reference_draws:
-            mode, seed = native.RANDOM_GIVEN, 0
-            native.hsq_given_draws(self._given_draws(draws))      # consumed by the level launch below
-        if self.bytes:
-            native.hsq_levels_batched(seg_table, self.tile_seg, self.nseg, self.ntiles, self.u_flat, minmax, self.n_bit,
-                                      mode, seed, wire_user, ef_codebook=self.codebook if errs is not None else None)
-            return True
-        native.hsq_levels_batched_any(seg_table, self.tile_seg, self.nseg, self.ntiles, self.u_flat, minmax, self.n_bit,
-                                      mode, seed, self.level_dtype, wire_user)
-        if errs is not None:
-            native.hsq_error_batched_any(seg_table, self.tile_seg, self.nseg, self.ntiles, wire_user, self.codebook,
-                                         self.code_dtype, self.level_dtype, self.n_bit)
+            mode, seed, r_flat = native.RANDOM_OFF, 0, None
+        self._batch.levels(wire_user, mode, seed, r_flat, write_error=errs is not None)
         return True
-
-    def _launch_decode(self, table, tile_seg, nseg, ntiles, gathered, R, out):
-        if self._fast is not None and nseg == self.nseg and ntiles == self.ntiles and table.data_ptr() == self._dev.data_ptr():
-            self._fast.decode(gathered, R, out)
-            return
-        if self.bytes:
-            native.hsq_decode_sum_batched(table, tile_seg, nseg, ntiles, gathered, self.codebook, self.n_bit, out, R)
-        else:
-            native.hsq_decode_sum_batched_any(table, tile_seg, nseg, ntiles, gathered, self.codebook, self.code_dtype,
-                                              self.level_dtype, self.n_bit, out, R)
 
 
 class BatchedQSGD(_BatchedBase):
@@ -616,6 +567,9 @@ class BatchedQSGD(_BatchedBase):
         # wide: max |v| per bucket is folded into words that the per-step header resets to zero
         extra = torch.zeros((word + 1) // 2, dtype=torch.int64) if self.wide else None
         self._setup(table, extra, device, slots, user_bytes)
+        self._batch = native.QSGDBatch(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets, self.n_bit,
+                                       self.bits, self.wide,
+                                       self._dev[self._table_words:].view(torch.int32) if self.wide else None)
 
     def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None):
         """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place)."""
@@ -623,18 +577,8 @@ class BatchedQSGD(_BatchedBase):
             return False
         mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
         seed = (_next_seed() ^ salt) if self.random else 0
-        ef = ef_scale if errs is not None else None
-        if self.wide:
-            native.qsgd_wide_compress(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets, self.n_bit,
-                                      mode, seed, self._dev[self._table_words:].view(torch.int32), wire_user, ef_scale=ef)
-        else:
-            native.qsgd_compress_batched(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets,
-                                         self.n_bit, mode, seed, wire_user, ef_scale=ef)
+        self._batch.compress(wire_user, mode, seed, ef_scale if errs is not None else None)
         return True
-
-    def _launch_decode(self, table, bucket_seg, nseg, nbuckets, gathered, R, out):
-        fn = native.qsgd_wide_decode_sum if self.wide else native.qsgd_decode_sum_batched
-        fn(table, bucket_seg, nseg, nbuckets, self.n_bit, self.bits, gathered, out, R)
 
 
 def default_codec_factory(compressor, numel, shape):

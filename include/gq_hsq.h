@@ -55,22 +55,30 @@ size_t gq_hsq_workspace_bytes(int64_t M);
 #define GQ_RANDOM_DEVICE 2 /* stochastic rounding against an on-device counter-based generator
                               seeded by `seed` (same distribution, not the same draws)          */
 
-/* Library / device identification. */
-int gq_abi_version(void);
-const char *gq_last_error(void);
-/*
- * Per-dispatch timing of the dominant kernel (bench.py's roofline object): gq_profile_arm(slot) makes the next
- * d16/K256 gq_hsq_encode issued by this thread attach a start / stop HIP event pair to its kernel dispatch
- * (hipExtLaunchKernelGGL), so that the pair measures the kernel alone -- an event bracket recorded around the call
- * also measures ~5-8 us of queue bubbles.  gq_profile_read(slot, &ms) waits for that dispatch and returns its
- * duration.  Nothing else changes; unarmed calls are not affected.
- */
-#define GQ_PROFILE_SLOTS 64
-int gq_profile_arm(int slot);
-int gq_profile_read(int slot, float *kernel_ms);
+/* level_bytes of the level / decode entry points: 1 | 2 | 4 = one uint8 / uint16 / int32 per level, 0 = the f32
+ * projections travel instead of levels (--n-bit 32), and
+ * GQ_LEVELS_PACKED6 = four 6-bit levels per three bytes: group g (subvectors 4g .. 4g+3) is the 24-bit little-endian word
+ *     l[4g] | l[4g+1] << 6 | l[4g+2] << 12 | l[4g+3] << 18      at byte 3g of the section (3 * ceil(M / 4) bytes),
+ * for configurations whose top level is <= 63 (n_bit <= 6 without stochastic rounding, <= 5 with).  A byte per level
+ * spends 8 bits on 6: this form takes 12.5 % off the (codes, levels) payload of the BASELINE configuration.  Served
+ * for d = 16, K <= 256 with byte codes; the decode is the same arithmetic on the same integers (bit-identical). */
+#define GQ_LEVELS_PACKED6 (-6)
 
+/* Library / device identification. */
+int gq_abi_version(void);            /* 2 since the round-3 descriptor form of the multi-tensor entry points */
+const char *gq_last_error(void);     /* text of the calling thread's last failure (the library's only per-thread state) */
 /* Fills CU count and the gcnArchName (e.g. "gfx950:sramecc+:xnack-") of `device`. */
 int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
+
+/*
+ * Per-dispatch timing of the dominant kernel (bench.py's roofline object).  An encode entry point that is handed
+ * profile_slot >= 0 (gq_hsq_encode_ex; gq_hsq_batch.profile_slot) attaches a start / stop HIP event pair of that
+ * slot to its d16/K256 prefilter kernel's dispatch (hipExtLaunchKernelGGL), so that the pair measures the kernel
+ * alone -- an event bracket recorded around the call also measures ~5-8 us of queue bubbles.
+ * gq_profile_read(slot, &ms) waits for that dispatch and returns its duration.  profile_slot = -1: a plain launch.
+ */
+#define GQ_PROFILE_SLOTS 64
+int gq_profile_read(int slot, float *kernel_ms);
 
 /*
  * HSQ encode -- replaces nearest_neighbor_compressor.py:65-73 (view(-1,d); mm;
@@ -86,30 +94,21 @@ int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
 int gq_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes, int code_bytes,
                   float *u, float *workspace, void *stream);
 
-/*
- * The whole compress of NearestNeighborCompressor (nearest_neighbor_compressor.py:63-78: the encode above, then
- * probabilistic_scalar_compressor.py:12-27 on u) in one call: gq_hsq_encode followed by gq_hsq_levels (declared
- * below) on the same stream, same outputs.
- */
-int gq_hsq_compress(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes, int code_bytes,
-                    float *u, float *workspace, int n_bit, int random_mode, const float *r, uint64_t seed,
-                    float *lb_ub, void *levels, int level_bytes, void *stream);
-
 /* Same, with the kernel chosen explicitly (diagnostics / cross-checks; results are
  * identical for every impl):  0 = auto, 1 = exact f32 MFMA, d16/K256, register-resident
  * codebook, 2 = exact f32 MFMA generic (any d, K), 3 = VALU fmaf chain with the codebook in
  * LDS, 4 = bf16x3 MFMA prefilter + exact f32 rescoring + exact fix-up for K = 256 and d in
  * {8, 16, 32} (the default for those shapes; bit-identical output), 5 = exact f32 MFMA with the codebook (chunked when it
  * does not fit) and the subvector tiles staged in LDS, any d <= 128 and any K (the default for
- * every other shape; 2 remains the fallback for d > 128). */
+ * every other shape; 2 remains the fallback for d > 128).  profile_slot: see gq_profile_read. */
 #define GQ_ENCODE_AUTO 0
 #define GQ_ENCODE_MFMA_D16K256 1
 #define GQ_ENCODE_MFMA_GENERIC 2
 #define GQ_ENCODE_VALU 3
 #define GQ_ENCODE_PREFILTER_D16K256 4
 #define GQ_ENCODE_MFMA_LDS 5
-int gq_hsq_encode_impl(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes,
-                       int code_bytes, float *u, float *workspace, int impl, void *stream);
+int gq_hsq_encode_ex(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes, int code_bytes,
+                     float *u, float *workspace, int impl, int profile_slot, void *stream);
 
 /*
  * Scalar level quantiser -- replaces probabilistic_scalar_compressor.py:12-27.
@@ -117,8 +116,10 @@ int gq_hsq_encode_impl(const float *grad, const float *codebook, int64_t M, int 
  *     levels = 0                                   if lb - ub == 0
  *     x = |(u-lb)/(ub-lb)| * 2^n_bit ;  l = trunc(clamp(x, 0, 2^n_bit - 1))
  *     l += (x - l > r)                             if random_mode != GQ_RANDOM_OFF
- * Outputs lb_ub[2] (f32) and levels[M] (level_bytes 1/2/4 -> uint8/uint16/int32;
- * the value range is [0, 2^n_bit] with stochastic rounding, [0, 2^n_bit - 1] without).
+ * Outputs lb_ub[2] (f32) and levels[M] (level_bytes 1/2/4 -> uint8/uint16/int32, GQ_LEVELS_PACKED6 -> 3 * ceil(M/4)
+ * bytes; the value range is [0, 2^n_bit] with stochastic rounding, [0, 2^n_bit - 1] without).
+ * The whole compress of NearestNeighborCompressor (nearest_neighbor_compressor.py:63-78) is gq_hsq_encode followed
+ * by gq_hsq_levels on the same stream.
  */
 int gq_hsq_levels(const float *u, int64_t M, int n_bit, int random_mode, const float *r, uint64_t seed,
                   const float *workspace, float *lb_ub, void *levels, int level_bytes, void *stream);
@@ -139,8 +140,7 @@ int gq_minmax_partials(const float *v, int64_t n, float *workspace, void *stream
  * holds f32 norms [R][M] (the n_bit == 32 signature) and lb_ub / n_bit are ignored.
  * R == 1 is the plain decompress (a decoded -0 stays -0, as nearest_neighbor_compressor.py:85-90 returns it).  R > 1 is the
  * aggregate: torch's sum starts from +0, so the sum is (+0 + p_0 + ... + p_{R-1}) and an element whose payloads are all -0
- * comes out as +0.  The multi-tensor decodes (gq_*_decode_sum_batched*, gq_qsgd_wide_decode_sum) are always the aggregate,
- * also for R == 1 (ps_quantizer.py:48 takes the mean of one user's stack as well).
+ * comes out as +0.  The multi-tensor decodes take the choice as an argument (`plain`).
  */
 int gq_hsq_decode_sum(const void *codes, int code_bytes, const void *levels, int level_bytes, const float *lb_ub,
                       const float *codebook, int R, int64_t M, int d, int K, int n_bit, float *out, void *stream);
@@ -154,109 +154,80 @@ int gq_hsq_decode_sum_strided(const void *codes, int code_bytes, int64_t code_st
                               int n_bit, float *out, void *stream);
 
 /*
- * Multi-tensor (batched) forms for d = 16, K = 256, uint8 codes and levels: ONE launch serves every
- * tensor of a model that shares the codebook (the reference loops over parameters in Python,
- * ps_quantizer.py:33,47).  lb / ub stay per tensor.  Every tensor is padded to whole
- * 64-subvector tiles in a common index space of `ntiles` tiles:
- *   tile_seg   int32[ntiles]       tensor ("segment") of each tile, ascending
- *   seg_table  int64[nseg][8]      { grad pointer (16-byte aligned), M subvectors, first tile,
- *                                    byte offset of codes / of levels / of (lb,ub) inside ONE
- *                                    user's wire, float offset of the tensor in `out`, reserved }
- *   seg_minmax uint32[nseg][2]     order-mapped (min,max) of u; the caller resets it before each
- *                                  encode to { 0xFFFFFFFF, 0 }
- *   u_flat     float[ntiles*64]    projection spill, padded index space
- *   workspace  gq_hsq_workspace_bytes(ntiles*64) bytes (same contract as gq_hsq_encode)
- * gq_hsq_encode_batched writes codes into `wire`, u into u_flat and folds (min,max) into
- * seg_minmax; gq_hsq_levels_batched writes levels and (lb,ub) into `wire`;
- * gq_hsq_decode_sum_batched averages R users' wires (`gathered` + r*user_stride_bytes) into `out`.
- * Results are identical to the per-tensor entry points.
+ * Multi-tensor forms: ONE launch per step and operation serves every tensor of a model that shares a codebook (the
+ * reference loops over parameters in Python, ps_quantizer.py:33,47).  lb / ub stay per tensor.  The tensors and the
+ * configuration are described by ONE struct that the caller fills once (round 2 had six spellings of the encode and
+ * two per-thread "next call" flags; all of that is a field or an argument now):
  *
- * Error-feedback forms (ps_quantizer.py:34-39 for all tensors at once): seg_table[seg][7] is the
- * tensor's error buffer (float*, 16-byte aligned; 0 = no feedback for this tensor).
- * gq_hsq_encode_batched_ef reads every tile as v = grad + ef_scale*error (product rounded, then the
- * add), writes v back over grad like the reference's in-place add_, and encodes v;
- * gq_hsq_levels_batched_ef additionally writes error = v - decoded (the decode of the wire it has just
- * completed) over the old error.  Same results as gq_axpy_inplace + encode + levels + decode + gq_sub.
+ *   Every tensor is padded to whole 64-subvector tiles in a common index space of `ntiles` tiles:
+ *   tile_seg   int32[ntiles]       tensor ("segment") of each tile, ascending
+ *   seg_table  int64[nseg][8]      { grad pointer (16-byte aligned when d % 4 == 0, else 4), M subvectors, first tile,
+ *                                    byte offset of codes / of levels / of (lb,ub) inside ONE user's wire (sections
+ *                                    16-byte aligned), float offset of the tensor in `out`,
+ *                                    error buffer (float *, aligned like grad; 0 = no error feedback for this tensor) }
+ *   seg_minmax uint32[nseg][2]     order-mapped (min,max) of u; the caller resets it before each encode to
+ *                                  { 0xFFFFFFFF, 0 }
+ *   u_flat     float[ntiles*64]    projection spill, padded index space
+ *   workspace  gq_hsq_workspace_bytes(ntiles*64) bytes (same contract as gq_hsq_encode); may be NULL when
+ *              gq_hsq_batched_path() says GQ_BATCH_EXACT
+ *
+ * gq_hsq_batched_path(b): which kernels serve (d, K, code_bytes, level_bytes, nseg) --
+ *   GQ_BATCH_PREFILTER  K = 256, d in {8, 16, 32}, byte codes: bf16x3 prefilter + exact rescoring (d = 8 / 32: <= 384 tensors)
+ *   GQ_BATCH_PAGED      d in {8, 16, 32}, K = 512, 768, ... 65536, int32 codes, <= 384 tensors: the prefilter with the
+ *                       pages of 256 codewords resident in LDS (an earlier page keeps a tie: the first maximum)
+ *   GQ_BATCH_EXACT      any other d <= 104 and K: exact f32 MFMA scoring, codebook chunked in LDS when large
+ *   0                   not served (the caller takes the per-tensor entry points); gq_last_error() says why
+ * Results are identical to the per-tensor entry points on every path.
  */
-int gq_hsq_encode_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                          const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax,
-                          float *workspace, void *stream);
-int gq_hsq_levels_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                          const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                          uint64_t seed, uint8_t *wire, void *stream);
-int gq_hsq_encode_batched_ef(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                             const float *codebook, float ef_scale, uint8_t *wire, float *u_flat,
-                             uint32_t *seg_minmax, float *workspace, void *stream);
-int gq_hsq_levels_batched_ef(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                             const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                             uint64_t seed, const float *codebook, uint8_t *wire, void *stream);
-int gq_hsq_decode_sum_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                              const uint8_t *gathered, int64_t user_stride_bytes, int R, const float *codebook,
-                              int n_bit, float *out, void *stream);
-/* The same for the other sub-dimensions that have a prefilter encode (K = 256, d = 8, 16 or 32; d = 16
- * forwards to the entry points above); the _ef forms as gq_hsq_encode_batched_ef / gq_hsq_levels_batched_ef. */
-int gq_hsq_encode_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                            const float *codebook, int d, uint8_t *wire, float *u_flat, uint32_t *seg_minmax,
-                            float *workspace, void *stream);
-int gq_hsq_encode_batched_d_ef(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                               const float *codebook, int d, float ef_scale, uint8_t *wire, float *u_flat,
-                               uint32_t *seg_minmax, float *workspace, void *stream);
-int gq_hsq_levels_batched_ef_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                               const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                               uint64_t seed, const float *codebook, int d, uint8_t *wire, void *stream);
-int gq_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                const uint8_t *gathered, int64_t user_stride_bytes, int R, const float *codebook,
-                                int d, int n_bit, float *out, void *stream);
+#define GQ_BATCH_PREFILTER 1
+#define GQ_BATCH_PAGED 2
+#define GQ_BATCH_EXACT 3
+typedef struct gq_hsq_batch {
+    uint32_t struct_bytes;     /* sizeof(gq_hsq_batch): a caller built against another layout is refused */
+    int32_t d, K;              /* nearest_neighbor_compressor.py:23-43 */
+    int32_t code_bytes;        /* 1 (K <= 256) | 4 */
+    int32_t level_bytes;       /* 1 | 2 | 4, GQ_LEVELS_PACKED6, or 0: the f32 projections travel (--n-bit 32, nearest_neighbor_compressor.py:14,75-76) */
+    int32_t n_bit;             /* probabilistic_scalar_compressor.py:7 */
+    int32_t nseg;
+    int32_t profile_slot;      /* -1, or the gq_profile_read slot the d16/K256 encode's dispatch is timed into */
+    int64_t ntiles;
+    const int64_t *seg_table;
+    const int32_t *tile_seg;
+    const float *codebook;     /* [K, d] f32, row-normalised by the caller (utils/vec_np.py:4-10) */
+    float *u_flat;
+    uint32_t *seg_minmax;
+    float *workspace;
+} gq_hsq_batch;
+int gq_hsq_batched_path(const gq_hsq_batch *b);
 
-/* The same multi-tensor launches for ANY other shape the reference can be configured to
- * (nearest_neighbor_compressor.py:23-57: d from --c-dim and its repair loop, K = 2^k_bit or d, int32 codes when
- * k_bit > 8; probabilistic_scalar_compressor.py:20-25: n_bit = 8 with stochastic rounding reaches level 256):
- * code_bytes 1 | 4, level_bytes 1 | 2 | 4, sections of the wire 16-byte aligned.  Exact f32 scoring (the LDS
- * kernel of gq_hsq_encode, d <= 128).  gq_hsq_encode_batched_any: `ef` != 0 reads every tile as
- * grad + ef_scale*error (seg_table[seg][7]) and writes it back;  gq_hsq_error_batched_any then writes
- * error = grad - decode(wire) for the rows that have an error buffer (ps_quantizer.py:39).
- * gq_hsq_levels_batched_any is independent of (d, K) and also serves the prefilter encodes above. */
-/* Multi-tensor prefilter encode for the larger codebooks of the prefilter dimensions (d = 8, 16 or 32; K = 512,
- * 768, ... : `--k-bit 9` and up, int32 codes): one launch per page of 256 codewords, a page's exact winner merged
- * into the (code, u) the earlier pages left in `wire` / `u_flat` (an earlier page keeps a tie: the first maximum);
- * same table, workspace and results as gq_hsq_encode_batched_any, 3-4x faster.  ef != 0: error feedback (in the
- * first page's launch).  At most 384 tensors per launch. */
-int gq_hsq_encode_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                const float *codebook, int d, int K, int ef, float ef_scale, uint8_t *wire,
-                                float *u_flat, uint32_t *seg_minmax, float *workspace, void *stream);
-int gq_hsq_batched_any_supported(int d, int K);   /* 1 if gq_hsq_encode_batched_any serves (d, K) */
-/* Stochastic rounding with the REFERENCE's draws in the multi-tensor level kernels
- * (probabilistic_scalar_compressor.py:23-26: r = torch.rand(M) per tensor, CPU generator): the caller draws them --
- * torch.rand is one sequential stream, so ONE torch.rand(sum of M) per record() equals the reference's per-tensor
- * calls in parameter order -- lays them out like u_flat (r_flat[tile * 64 + i] belongs to subvector i of tile
- * `tile`; padding slots are not read) and hands the device pointer over with gq_hsq_given_draws; the NEXT
- * gq_hsq_levels_batched* call on this thread with random_mode = GQ_RANDOM_GIVEN consumes it (compare is the
- * reference's strict `frac > r`). */
-int gq_hsq_given_draws(const float *r_flat);
+/* Encode of every tensor into ONE user's `wire` (codes), u into u_flat, (min,max) into seg_minmax --
+ * nearest_neighbor_compressor.py:65-73 per tensor.  ef_scale: NaN = no error feedback; otherwise every tile is read as
+ * v = grad + ef_scale*error (ps_quantizer.py:35: product rounded, then the add), v is written back over grad like the
+ * reference's in-place add_, and v is encoded (rows whose seg_table[seg][7] is 0 are encoded as they are). */
+int gq_hsq_encode_batched(const gq_hsq_batch *b, uint8_t *wire, float ef_scale, void *stream);
+
+/* Levels and (lb, ub) of every tensor into `wire` -- probabilistic_scalar_compressor.py:12-27 per tensor.
+ * r_flat: the caller's draws for random_mode = GQ_RANDOM_GIVEN, laid out like u_flat (r_flat[tile * 64 + i] belongs to
+ * subvector i of tile `tile`; padding slots are not read), NULL otherwise.  Reference parity: r = torch.rand(M) per
+ * tensor from the CPU generator (probabilistic_scalar_compressor.py:23-26) is one sequential stream, so ONE
+ * torch.rand(sum of M) per record() equals the reference's per-tensor calls in parameter order PROVIDED every tensor
+ * draws -- the reference returns before torch.rand when lb == ub (:15-16), see DESIGN.md.
+ * write_error != 0 (after an encode with error feedback): additionally error = v - decode(wire) over the old error,
+ * ps_quantizer.py:37-39, for the rows that have an error buffer. */
+int gq_hsq_levels_batched(const gq_hsq_batch *b, uint8_t *wire, int random_mode, uint64_t seed, const float *r_flat,
+                          int write_error, void *stream);
+
+/* Decode + mean of R users' wires (`gathered` + r*user_stride_bytes) into `out` -- ps_quantizer.py:47-48.
+ * plain != 0: the plain decompress of ONE payload as the reference returns it (a -0 stays -0) -- the ring's hop and
+ * final gradient (ring_quantizer.py:32,41-47), the two-phase / error-feedback round trips (ps_quantizer.py:37,52-61);
+ * plain == 0: the aggregate (+0 + sum) / R, also for R == 1.  Only the sign of zeros differs.
+ * Only d, K, the widths, n_bit, nseg, ntiles, seg_table, tile_seg and codebook of `b` are read: a decode of a PART of
+ * the tensors (split exchange) passes a copy of the struct with another table. */
+int gq_hsq_decode_sum_batched(const gq_hsq_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                              float *out, int plain, void *stream);
 
 /*
- * The NEXT multi-tensor decode issued by this thread (gq_hsq_decode_sum_batched*, gq_qsgd_decode_sum_batched,
- * gq_qsgd_wide_decode_sum) is a plain decompress of its one payload instead of the parameter-server aggregate: a decoded
- * -0 stays -0.  This is the ring's hop and its final gradient (ring_quantizer.py:32,41-43,47: grad.add_(decompress(...)),
- * param.grad.data = the last decompress), where the aggregate's (+0 + sum) / R would turn those zeros positive.  Only the sign of
- * zeros differs between the two.
- */
-int gq_decode_plain_next(void);
-int gq_hsq_encode_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                              const float *codebook, int d, int K, int code_bytes, int ef, float ef_scale,
-                              uint8_t *wire, float *u_flat, uint32_t *seg_minmax, void *stream);
-int gq_hsq_levels_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                              const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                              uint64_t seed, int level_bytes, uint8_t *wire, void *stream);
-int gq_hsq_decode_sum_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                  const uint8_t *gathered, int64_t user_stride_bytes, int R, const float *codebook,
-                                  int d, int K, int code_bytes, int level_bytes, int n_bit, float *out, void *stream);
-int gq_hsq_error_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                             const uint8_t *wire, const float *codebook, int d, int K, int code_bytes,
-                             int level_bytes, int n_bit, void *stream);
-
-/*
- * Error-feedback helpers fused around the codec (ps_quantizer.py:35,39):
+ * Error-feedback helpers around the per-tensor codec (ps_quantizer.py:35,39):
  *     gq_axpy_inplace:   grad += scale * err
  *     gq_sub:            err   = grad - decoded
  */
@@ -290,8 +261,50 @@ int gq_qsgd_decode_sum(const float *norm, const uint8_t *signs, const void *leve
                        int d, int n_bit, float *out, void *stream);
 
 /*
- * ProbabilisticVectorCompressor encode -- the INTENDED semantics of
- * probabilistic_vector_compressor.py:42-63 (the reference's own code cannot run):
+ * QSGD on a packed wire, multi-tensor form (one launch for all tensors; same arithmetic as
+ * gq_qsgd_compress / gq_qsgd_decode_sum).  Per element one code = sign<<(bits-1) | level with
+ * bits = gq_qsgd_code_bits(n_bit, random_mode): 4 (two codes per byte, element 2i in the low nibble)
+ * when the top level is <= 7, 8 when it is <= 127, 16 (little-endian) when it is <= 32767, 0 = no packed format.
+ * A zero bucket is written as level 0 (the reference's NaN level also decodes to 0).
+ *
+ * wide == 0: the unit of work is a bucket; buckets are numbered across tensors: item_seg int32[nitems] names the
+ *   tensor of each bucket; seg_table int64[nseg][8] = { grad pointer (8-byte aligned), d (even, <= 65536), first
+ *   bucket, byte offset of the f32 norms / of the codes inside ONE user's wire, float offset of the tensor in `out`
+ *   (a multiple of 4), buckets, error buffer (float *, 0 = none) }.
+ * wide != 0: WIDE buckets -- the reference's TernGrad command (`--quantizer qsgd --c-dim 0 --n-bit 1`: one bucket
+ *   spans the tensor, qsgd_compressor.py:15-16) or any c_dim of a few thousand and more.  The unit of work is a chunk
+ *   of GQ_QSGD_WIDE_CHUNK consecutive elements of one bucket (the last chunk of a bucket may be shorter; d must be
+ *   even): item_seg names the tensor of each chunk, ascending; seg_table int64[nseg][8] = { grad pointer, d, first
+ *   chunk, byte offset of the norms / of the codes, float offset in `out`, first word of the tensor's buckets in
+ *   norm_bits, error buffer }.  norm_bits (one uint32 per bucket; give every tensor its own 128-byte line: the words
+ *   are targets of atomics) must be zero before each compress (max |v| is folded into it with integer atomics); the
+ *   compress is two launches (bucket norms, then codes).
+ * ef_scale: NaN = none; otherwise error feedback in the same pass (ps_quantizer.py:35-39): the bucket is read as
+ *   v = grad + ef_scale*error, v is written back over grad and error = v - decode(code) over error.
+ * plain: as gq_hsq_decode_sum_batched.
+ */
+#define GQ_QSGD_WIDE_CHUNK 1024
+typedef struct gq_qsgd_batch {
+    uint32_t struct_bytes;     /* sizeof(gq_qsgd_batch) */
+    int32_t n_bit;             /* qsgd_compressor.py:10 */
+    int32_t bits;              /* gq_qsgd_code_bits(n_bit, random_mode) */
+    int32_t wide;
+    int32_t nseg;
+    int32_t reserved;
+    int64_t nitems;
+    const int64_t *seg_table;
+    const int32_t *item_seg;
+    uint32_t *norm_bits;       /* wide only */
+} gq_qsgd_batch;
+int gq_qsgd_code_bits(int n_bit, int random_mode);
+int gq_qsgd_compress_batched(const gq_qsgd_batch *b, uint8_t *wire, int random_mode, uint64_t seed, float ef_scale,
+                             void *stream);
+int gq_qsgd_decode_sum_batched(const gq_qsgd_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                               float *out, int plain, void *stream);
+
+/*
+ * ProbabilisticVectorCompressor encode -- probabilistic_vector_compressor.py:42-63 (pinned by the reference's own
+ * output):
  *     p = c_dagger . v   (c_dagger = pinv(codewords^T), [K,d]) ;  l1 = sum_k |p_k|
  *     code = first k with cumsum_k(|p|/l1) >= r - 1e-5 ;  u = sign(p_code) * l1
  * r: one uniform draw per subvector (GQ_RANDOM_GIVEN: caller-supplied r[M]; GQ_RANDOM_DEVICE: in-kernel).
@@ -299,61 +312,22 @@ int gq_qsgd_decode_sum(const float *norm, const uint8_t *signs, const void *leve
  * bytes suffice) so that gq_hsq_levels / gq_hsq_decode_sum finish the compress / decompress
  * exactly as for the NearestNeighbor compressor.  Any d <= 104 and any K on the matrix cores (exact f32 MFMA, the
  * two sequential sums lane-local); beyond that d in {4,8,12,16,24,32,64} on the VALU kernel.
+ * stage1 != NULL: the second stage of the ResidualCompressor (compressors/residual_compressor.py:15-24) WITHOUT a
+ * residual tensor -- the same encode applied to  grad - codebook1[codes1] * norm1  computed on the fly with the
+ * reference's roundings (stage 1's decode, nearest_neighbor_compressor.py:85-89, then `residuals -= decompressed`);
+ * norm1 [M] f32 is stage 1's de-quantised norm per subvector.  GQ_ERR_UNSUPPORTED when d does not fit the
+ * LDS-staged kernel (d > 104).
  */
+typedef struct gq_pvq_stage1 {
+    const void *codes1;
+    int32_t code1_bytes;
+    int32_t reserved;
+    const float *norm1;
+    const float *codebook1;
+} gq_pvq_stage1;
 int gq_pvq_encode(const float *grad, const float *c_dagger, int64_t M, int d, int K, int random_mode, const float *r,
-                  uint64_t seed, void *codes, int code_bytes, float *u, float *workspace, void *stream);
-/* Second stage of the ResidualCompressor (compressors/residual_compressor.py:15-24) WITHOUT a residual tensor: the
- * same encode applied to  grad - codebook1[codes1] * norm1  computed on the fly with the reference's roundings
- * (stage 1's decode, nearest_neighbor_compressor.py:85-89, then `residuals -= decompressed`).  norm1 [M] f32 is stage
- * 1's de-quantised norm per subvector.  GQ_ERR_UNSUPPORTED when d does not fit the LDS-staged kernel (d > 104). */
-int gq_pvq_encode_residual(const float *grad, const void *codes1, int code1_bytes, const float *norm1,
-                           const float *codebook1, const float *c_dagger, int64_t M, int d, int K, int random_mode,
-                           const float *r, uint64_t seed, void *codes, int code_bytes, float *u, float *workspace,
-                           void *stream);
-
-/*
- * QSGD on a packed wire, multi-tensor form (one launch for all tensors; same arithmetic as
- * gq_qsgd_compress / gq_qsgd_decode_sum).  Per element one code = sign<<(bits-1) | level with
- * bits = gq_qsgd_code_bits(n_bit, random_mode): 4 (two codes per byte, element 2i in the low nibble)
- * when the top level is <= 7, 8 when it is <= 127, 16 (little-endian) when it is <= 32767, 0 = no packed
- * format.  Buckets are numbered across
- * tensors: bucket_seg int32[nbuckets]; seg_table int64[nseg][8] = { grad pointer (8-byte aligned),
- * d (even, <= 65536), first bucket, byte offset of the f32 norms / of the codes inside ONE user's wire,
- * float offset of the tensor in `out` (a multiple of 4), buckets, reserved }.  A zero bucket is written as level 0
- * (the reference's NaN level also decodes to 0).
- * gq_qsgd_compress_batched_ef: error feedback in the same pass (ps_quantizer.py:35-39):
- * seg_table[seg][7] = the tensor's error buffer (float*, 8-byte aligned; 0 = none); the bucket is read
- * as v = grad + ef_scale*error, v is written back over grad and error = v - decode(code) over error.
- */
-int gq_qsgd_code_bits(int n_bit, int random_mode);
-int gq_qsgd_compress_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
-                             int n_bit, int random_mode, uint64_t seed, uint8_t *wire, void *stream);
-int gq_qsgd_compress_batched_ef(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
-                                int n_bit, int random_mode, uint64_t seed, float ef_scale, uint8_t *wire,
-                                void *stream);
-int gq_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
-                               int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                               float *out, void *stream);
-
-/*
- * The same packed wire for WIDE buckets -- the reference's TernGrad command (`--quantizer qsgd --c-dim 0
- * --n-bit 1`: one bucket spans the tensor, qsgd_compressor.py:15-16) or any c_dim of a few thousand and more.
- * The unit of work is a chunk of GQ_QSGD_WIDE_CHUNK consecutive elements of one bucket (the last chunk of a
- * bucket may be shorter; d must be even): chunk_seg int32[nchunks] names the tensor of each chunk, ascending;
- * seg_table int64[nseg][8] = { grad pointer (8-byte aligned), d, first chunk, byte offset of the norms / of the
- * codes inside ONE user's wire, float offset of the tensor in `out` (a multiple of 4), first word of the tensor's buckets in
- * norm_bits, error buffer (float*, 0 = none) }.  norm_bits (one uint32 per bucket; give every tensor its own
- * 128-byte line: the words are targets of atomics) must be zero before each
- * compress (max |v| is folded into it with integer atomics).  gq_qsgd_wide_compress = two launches (bucket
- * norms, then codes); ef != 0: error feedback as in gq_qsgd_compress_batched_ef.
- */
-#define GQ_QSGD_WIDE_CHUNK 1024
-int gq_qsgd_wide_compress(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks, int n_bit,
-                          int random_mode, uint64_t seed, int ef, float ef_scale, uint32_t *norm_bits, uint8_t *wire,
-                          void *stream);
-int gq_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks, int n_bit,
-                            int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R, float *out,
-                            void *stream);
+                  uint64_t seed, void *codes, int code_bytes, float *u, float *workspace, const gq_pvq_stage1 *stage1,
+                  void *stream);
 
 #ifdef __cplusplus
 }

@@ -111,16 +111,6 @@ GQ_EXPORT int gq_cpu_hsq_levels(const float *u, int64_t M, int n_bit, int random
     return GQ_OK;
 }
 
-/* gq_hsq_compress: nearest_neighbor_compressor.py:63-78 */
-GQ_EXPORT int gq_cpu_hsq_compress(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes,
-                                  int code_bytes, float *u, float *workspace, int n_bit, int random_mode,
-                                  const float *r, uint64_t seed, float *lb_ub, void *levels, int level_bytes,
-                                  void *stream) {
-    const int rc = gq_cpu_hsq_encode(grad, codebook, M, d, K, codes, code_bytes, u, workspace, stream);
-    if (rc != GQ_OK) return rc;
-    return gq_cpu_hsq_levels(u, M, n_bit, random_mode, r, seed, workspace, lb_ub, levels, level_bytes, stream);
-}
-
 /* gq_hsq_decode_sum: probabilistic_scalar_compressor.py:29-33, nearest_neighbor_compressor.py:80-90,
  * ps_quantizer.py:48 */
 GQ_EXPORT int gq_cpu_hsq_decode_sum(const void *codes, int code_bytes, const void *levels, int level_bytes,

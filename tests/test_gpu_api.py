@@ -164,7 +164,7 @@ def test_psquantizer_on_gpu_matches_reference(name):
     from test_host_logic import run_psq_fixture
     q = run_psq_fixture(name, None, device="cuda", tol=0.0)
     assert q.codecs[0].__class__.__name__ in ("HSQCodec", "QSGDCodec") or name.endswith("_sgd")
-    if "_rand" in name and "qsgd" not in name:     # the reference's own draws, through the multi-tensor kernels (gq_hsq_given_draws)
+    if "_rand" in name and "qsgd" not in name:     # the reference's own draws, through the multi-tensor kernels (gq_hsq_levels_batched's r_flat)
         assert q._groups and q._groups[0][2].ready and q._groups[0][2].reference_draws
 
 
@@ -1165,7 +1165,7 @@ def test_bench_two_rank_code_path_on_one_gpu():
 
 
 
-@pytest.mark.parametrize("extra", [[], ["--exchange", "split"], ["--workload", "qsgd"]])
+@pytest.mark.parametrize("extra", [[], ["--exchange", "split"], ["--exchange", "auto"], ["--workload", "qsgd"], ["--workload", "resnet50"]])
 def test_bench_launches_its_own_ranks(extra):
     """`python bench.py --gpus 2` from a bare shell (no RANK / WORLD_SIZE): bench.py starts its own two ranks before
     anything touches the GPU and rank 0 prints the one JSON line (GQ_BENCH_BACKEND=gloo: both ranks share this GPU)."""
@@ -1184,6 +1184,10 @@ def test_bench_launches_its_own_ranks(extra):
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["ranks_bit_identical"] is True
     assert d["exchange"]["ranks"] == 2 and d["exchange"]["backend"] == "gloo"
     if extra[:1] == ["--exchange"]:
-        assert d["exchange"]["transport"] == "split"
-    elif not extra:
-        assert d["exchange"]["transport"] in ("allgather", "direct", "split") and set(d["exchange"]["autotune_ms"]) == {"allgather", "direct", "split"}
+        assert d["exchange"]["transport"] == ("split" if extra[1] == "split" else d["exchange"]["transport"])
+        if extra[1] == "auto":     # opt-in: every transport timed before the timed region, all ranks decide alike
+            assert d["exchange"]["transport"] in ("allgather", "direct", "split")
+            assert set(d["exchange"]["autotune_ms"]) == {"allgather", "direct", "split"}
+    elif not extra:     # the default is the in-place all-gather, nothing is auto-tuned
+        assert d["exchange"]["transport"] == "allgather" and d["exchange"]["autotune_ms"] is None
+        assert d["exchange"]["ms"] > 0

@@ -504,27 +504,3 @@ def test_prefilter_fuzz_against_exact_kernels():
     assert "120 rounds, 0 mismatching" in r.stdout
 
 
-@pytest.mark.parametrize("M,mode", [(1, 0), (65, 2), (4099, 1), (200001, 0)])
-def test_compress_entry_point_equals_encode_plus_levels(nat, M, mode):
-    """gq_hsq_compress = gq_hsq_encode + gq_hsq_levels in one C call (nearest_neighbor_compressor.py:63-78)."""
-    dev = torch.device("cuda:0")
-    cb = torch.from_numpy(_cb(16, 256)).to(dev)
-    torch.manual_seed(M)
-    g = torch.randn(M * 16, device=dev) * 0.01
-    r = torch.rand(M, device=dev) if mode == 1 else None
-    outs = []
-    for one_call in (False, True):
-        codes = torch.empty(M, dtype=torch.uint8, device=dev)
-        u = torch.empty(M, dtype=torch.float32, device=dev)
-        ws = nat.new_workspace(dev, M)
-        lbub = torch.empty(2, dtype=torch.float32, device=dev)
-        lv = torch.empty(M, dtype=torch.uint8, device=dev)
-        if one_call:
-            nat.hsq_compress(g, cb, codes, u, ws, 6, mode, r, 99, lbub, lv)
-        else:
-            nat.hsq_encode(g, cb, codes, u, ws)
-            nat.hsq_levels(u, 6, mode, r, 99, ws, lbub, lv)
-        torch.cuda.synchronize()
-        outs.append((codes, u.view(torch.int32), lbub.view(torch.int32), lv))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)

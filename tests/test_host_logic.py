@@ -55,9 +55,27 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 12
     for n in names:
         assert hasattr(lib, n), "libgq_hsq.so does not export %s declared in include/gq_hsq.h" % n
-    assert set(native.EXPORTS) <= set(names)
+    assert set(native.EXPORTS) == set(names), "the binding's list and the header differ"
+    assert len(names) <= 25, "the ABI was collapsed to <= 25 entry points in round 3 (descriptor structs instead of variants)"
     lib.gq_abi_version.restype = ctypes.c_int
-    assert lib.gq_abi_version() == 1
+    assert lib.gq_abi_version() == native.ABI_VERSION == 2
+    # nothing but the declared entry points leaves the library (the per-variant launchers are hidden)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("gq"))
+    assert exported == names, "exported but not declared: %s" % sorted(set(exported) - set(names))
+
+
+def test_the_library_keeps_no_per_thread_call_state():
+    """Round 2 armed `the next call` through thread-local flags (plain decode, given draws, profile slot); they are
+    arguments / descriptor fields now.  The only thread_local left is gq_last_error's text buffer."""
+    csrc = os.path.join(PKG, "csrc")
+    hits = []
+    for f in sorted(os.listdir(csrc)):
+        for n, ln in enumerate(open(os.path.join(csrc, f)), 1):
+            if "thread_local" in ln:
+                hits.append((f, n))
+    assert len(hits) == 1 and hits[0][0] == "gq_common.hip", hits
 
 
 def test_no_oracle_or_cpu_fallback_in_product():
