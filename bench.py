@@ -71,6 +71,8 @@ def parse_args():
                     help="N > 1: how the wire travels.  Default: the in-place all-gather (the one collective every backend has); "
                          "auto = time all three before the timed region and keep the fastest (opt-in: direct / split have not "
                          "met RCCL with more than one rank yet)")
+    ap.add_argument("--wire-levels", default=os.environ.get("GQ_WIRE_LEVELS", "bytes"), choices=["bytes", "packed6"],
+                    help="how the 6-bit levels travel: a byte each, or four per three bytes (12.5 %% less wire; same decode bits)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "off"],
                     help="roofline.traffic: live = two short child runs under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE); "
                          "auto = live at N=1 when rocprofv3 is on PATH, else the committed profiles/hbm_traffic.json")
@@ -313,7 +315,10 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     # three gradients in turn: 300 MB of inputs + the 100 MB decode target between two uses of the same bytes
     grads = [torch.randn(SIZE, device=dev, generator=gen) for _ in range(3)]
     M = SIZE // C_DIM
-    wire, swire = HSQWire(M), SplitHSQWire(M)
+    packed6 = args.wire_levels == "packed6" and args.random == 0      # top level 63 (n_bit 6 without stochastic rounding)
+    if packed6 and args.exchange in ("split", "auto"):
+        sys.exit("bench.py: --wire-levels packed6 goes with --exchange allgather or direct (the split arrangement keeps byte levels)")
+    wire, swire = HSQWire(M, packed6), SplitHSQWire(M)
     ex = exchange.WireExchange(world, rank, 1, wire.nbytes, dev)
     sex = exchange.WireExchange(world, rank, 1, swire.nbytes, dev) if world > 1 else None
     codes, levels, lb_ub = wire.views(ex.local[0])
@@ -324,10 +329,11 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
 
     def compress(g, profile_slot=-1):
         native.hsq_encode(g, cb, codes, u, partials, profile_slot=profile_slot)
-        native.hsq_levels(u, N_BIT, args.random, None, seed, partials, lb_ub, levels)
+        native.hsq_levels(u, N_BIT, args.random, None, seed, partials, lb_ub, levels, packed6)
 
     def decode(buf):
-        native.hsq_decode_sum_packed(buf, M, cb, N_BIT, out, world, wire.codes_off, wire.levels_off, wire.lbub_off)
+        native.hsq_decode_sum_packed(buf, M, cb, N_BIT, out, world, wire.codes_off, wire.levels_off, wire.lbub_off,
+                                     level_dtype=native.PACKED6 if packed6 else torch.uint8)
 
     if world > 1:
         s_codes, s_la, s_lb, s_lbub = swire.views(sex.local[0])
@@ -424,7 +430,7 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
         b.record()
     torch.cuda.synchronize()
     enc_bracket_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))
-    lv_ms = event_ms(torch, lambda: native.hsq_levels(u, N_BIT, args.random, None, seed, partials, lb_ub, levels))
+    lv_ms = event_ms(torch, lambda: native.hsq_levels(u, N_BIT, args.random, None, seed, partials, lb_ub, levels, packed6))
     cmp_ms = event_ms(torch, lambda: compress(next_grad()))
     dec_ms = event_ms(torch, lambda: decode(ex.gathered))
     exch_ms = None
@@ -450,6 +456,7 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
                                "n_bit=6 (BASELINE configs[%d]), step = encode+levels" % (1 if world == 1 else 3)
                                + ("+exchange(%s)" % mode if world > 1 else "") + "+decode-mean",
                    "elements_per_rank": SIZE, "random": args.random, "ranks": world,
+                   "wire_levels": "packed6" if packed6 else "bytes", "wire_bytes_per_rank": wire.nbytes,
                    "inputs": "3 gradients of 100 MB used in turn (never Infinity-Cache resident)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -513,6 +520,7 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
         Comp = QSGDCompressor
     params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
     os.environ["GQ_EXCHANGE"] = args.exchange
+    os.environ["GQ_WIRE_LEVELS"] = args.wire_levels      # packed6 applies where the top level is <= 63 (not with the README's --random 1 at n_bit 6)
     torch.manual_seed(1234 + rank)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # the constructors report the reference's dimension repair on stdout

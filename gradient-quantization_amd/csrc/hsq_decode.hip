@@ -194,7 +194,8 @@ void hsq_decode_sum_d16u8_kernel(
 #pragma unroll
                 for (int jj = 0; jj < DEC16_CHUNK; ++jj) {
                     if (r0 + jj < R) {
-                        c4[jj] = *reinterpret_cast<const unsigned *>(cp + (int64_t)jj * code_stride + off);
+                        c4[jj] = PACKED6 ? load_packed6(cp + (int64_t)jj * code_stride + off)      // (an alignment-free dword load)
+                                         : *reinterpret_cast<const unsigned *>(cp + (int64_t)jj * code_stride + off);
                         l4[jj] = PACKED6 ? load_packed6(lp + (int64_t)jj * level_stride + loff)
                                          : *reinterpret_cast<const unsigned *>(lp + (int64_t)jj * level_stride + off);
                     }
@@ -282,8 +283,9 @@ static int launch_decode(const CodeT *codes, const LevelT *levels, const float *
     const int64_t cap = (int64_t)cu_count() * 8;
     if constexpr (sizeof(CodeT) == 1 && (std::is_same<LevelT, uint8_t>::value || std::is_same<LevelT, Packed6>::value)) {
         constexpr bool P6 = std::is_same<LevelT, Packed6>::value;
-        const uintptr_t align = reinterpret_cast<uintptr_t>(codes) | (uintptr_t)cs |
-                                (P6 ? 0 : (reinterpret_cast<uintptr_t>(levels) | (uintptr_t)ls));
+        // the packed form reads codes and levels with alignment-free dword loads (a group of levels starts at any byte)
+        const uintptr_t align = P6 ? 0 : (reinterpret_cast<uintptr_t>(codes) | (uintptr_t)cs |
+                                          reinterpret_cast<uintptr_t>(levels) | (uintptr_t)ls);
         if (d == 16 && K <= 256 && lb_ub && (align & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(cb) & 15) == 0 && (M >= (int64_t)K || P6)) {
             const int64_t total = ((M + 3) >> 2) * 4;
@@ -309,7 +311,7 @@ static int launch_decode(const CodeT *codes, const LevelT *levels, const float *
     }
     if constexpr (std::is_same<LevelT, Packed6>::value) {
         return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum: GQ_LEVELS_PACKED6 is served for d = 16, K <= 256, byte codes, "
-                                        "4-byte aligned codes and 16-byte aligned out / codebook");
+                                        "16-byte aligned out / codebook");
     } else {
     if ((d & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(cb) & 15) == 0) {
         const int64_t total = M * (d >> 2);

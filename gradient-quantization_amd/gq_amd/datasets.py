@@ -115,16 +115,29 @@ class OnDiskClassification(object):
         return (xb - self.mean) / self.std                 # transforms.Normalize
 
     def batches(self, batch, epoch_seed, rank=0, world=1, shuffle=True):
-        """Batches of `batch` samples for this rank (a global batch is world * batch consecutive entries of the
-        epoch's permutation, as the reference's loader yields batch_size * num_users and main.py:189-193 splits it).
-        The last short global batch is dropped in training order and kept when shuffle is False (evaluation)."""
+        """This rank's share of every global batch (world * batch consecutive entries of the epoch's permutation, as the
+        reference's loader yields batch_size * num_users and main.py:189-193 splits it).  The loader's drop_last is False
+        (dataloaders.py: DataLoader defaults): the short last batch is kept and split the same way -- see rank_slice."""
         gen = torch.Generator().manual_seed(epoch_seed)
         order = torch.randperm(self.n, generator=gen) if shuffle else torch.arange(self.n)
         order = order.to(self.x.device)
-        per = batch * world
-        stop = self.n - per + 1 if shuffle else self.n
-        for i in range(0, max(stop, 1 if not shuffle else 0), per):
-            idx = order[i + rank * batch:i + (rank + 1) * batch]
-            if idx.numel() == 0:
-                continue
+        for lo, hi in rank_slices(self.n, batch, rank, world):
+            idx = order[lo:hi]
             yield self._prepare(self.x[idx], gen), self.y[idx]
+
+
+def rank_slices(n, batch, rank, world):
+    """[lo, hi) of this rank's samples in every global batch of `world * batch` consecutive entries.  A full batch gives
+    every rank `batch`.  The short last one (n % (world * batch) samples; DataLoader keeps it, drop_last=False) is split
+    like main.py:189-193 splits a batch over its users: every rank but the last gets len // world, the last rank the
+    rest; when it holds fewer samples than ranks it is skipped on every rank (a rank without samples could not take
+    part in the step's collectives)."""
+    per = batch * world
+    for i in range(0, n, per):
+        size = min(per, n - i)
+        share = size // world
+        if share == 0:
+            continue
+        lo = i + rank * share
+        hi = i + size if rank == world - 1 else lo + share
+        yield lo, hi

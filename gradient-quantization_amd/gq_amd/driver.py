@@ -132,13 +132,13 @@ class SyntheticClassification(object):
                 SyntheticClassification(None, 0, 0, self.x.device, 0, self.x[k:], self.y[k:]))
 
     def batches(self, batch, epoch_seed, rank=0, world=1, shuffle=True):
+        """As OnDiskClassification.batches: the short last batch is kept (the reference's loader has drop_last=False)."""
+        from .datasets import rank_slices
         g = torch.Generator().manual_seed(epoch_seed)
         perm = (torch.randperm(self.n, generator=g) if shuffle else torch.arange(self.n)).to(self.x.device)
-        per = batch * world
-        for i in range(0, (self.n - per + 1) if shuffle else self.n, per):
-            idx = perm[i + rank * batch:i + (rank + 1) * batch]
-            if idx.numel():
-                yield self.x[idx], self.y[idx]
+        for lo, hi in rank_slices(self.n, batch, rank, world):
+            idx = perm[lo:hi]
+            yield self.x[idx], self.y[idx]
 
 
 def build_parser():
@@ -243,6 +243,8 @@ def train(args, log=None):
             optimizer = optim.SGD(model.parameters(), lr=steps[epoch], momentum=momentum, weight_decay=5e-4)
         # the loader yields num_users*batch_size samples per rank; split across users as main.py:189-193
         for x, y in data.batches(args.batch_size * args.num_users, 1000 * args.seed + epoch, rank, world):
+            if x.shape[0] < args.num_users:      # a last batch too short to give every user a sample (the reference would average an empty batch)
+                continue
             ub = x.shape[0] // args.num_users
             users = [(x[u * ub:(u + 1) * ub], y[u * ub:(u + 1) * ub]) for u in range(args.num_users - 1)]
             users.append((x[(args.num_users - 1) * ub:], y[(args.num_users - 1) * ub:]))
@@ -252,7 +254,7 @@ def train(args, log=None):
             if it % args.log_interval == 0 or it == 1:
                 rec = {"iter": it, "epoch": epoch, "loss": float(loss), "ms_per_iter": (time.perf_counter() - t0) * 1e3,
                        "ranks": world, "users_per_rank": args.num_users}
-                if test_data is not None:      # main.py:197-211: loss and test accuracy are logged together
+                if test_data is not None and rank == 0:      # main.py:197-211: loss and test accuracy are logged together (once: rank 0)
                     acc, tl = test(model, loss_func, test_data, getattr(args, "test_batch_size", 1000))
                     rec["accuracy(%)"] = 100.0 * acc
                     rec["test_loss"] = tl

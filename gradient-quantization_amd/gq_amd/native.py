@@ -86,7 +86,13 @@ def _stream():
 
 
 _CODE_BYTES = {torch.uint8: 1, torch.int32: 4}
-_LEVEL_BYTES = {torch.uint8: 1, torch.int16: 2, torch.int32: 4, torch.float32: 0}
+LEVELS_PACKED6 = -6     # GQ_LEVELS_PACKED6: four 6-bit levels per three bytes (include/gq_hsq.h)
+PACKED6 = "packed6"     # stands in for a level dtype wherever one is passed: the section is uint8[3 * ceil(M / 4)]
+_LEVEL_BYTES = {torch.uint8: 1, torch.int16: 2, torch.int32: 4, torch.float32: 0, PACKED6: LEVELS_PACKED6}
+
+
+def packed6_bytes(M):
+    return 3 * ((int(M) + 3) // 4)
 
 
 def workspace_floats(M):
@@ -141,22 +147,28 @@ def hsq_encode(grad, codebook, codes, u, partials, impl=ENCODE_AUTO, profile_slo
     _check(rc, "gq_hsq_encode")
 
 
-def hsq_compress(grad, codebook, codes, u, workspace, n_bit, random_mode, r, seed, lb_ub, levels):
+def hsq_compress(grad, codebook, codes, u, workspace, n_bit, random_mode, r, seed, lb_ub, levels, packed6=False):
     """The whole compress (nearest_neighbor_compressor.py:63-78): gq_hsq_encode, then gq_hsq_levels, on the same stream."""
     hsq_encode(grad, codebook, codes, u, workspace)
-    hsq_levels(u, n_bit, random_mode, r, seed, workspace, lb_ub, levels)
+    hsq_levels(u, n_bit, random_mode, r, seed, workspace, lb_ub, levels, packed6)
 
 
-def hsq_levels(u, n_bit, random_mode, r, seed, partials, lb_ub, levels):
+def hsq_levels(u, n_bit, random_mode, r, seed, partials, lb_ub, levels, packed6=False):
+    """packed6: `levels` is the uint8 section of 3 * ceil(M / 4) bytes (four 6-bit levels per three bytes)."""
     M = u.numel()
-    assert levels.numel() == M and lb_ub.numel() == 2
+    assert lb_ub.numel() == 2
+    if packed6:
+        assert levels.dtype == torch.uint8 and levels.numel() >= packed6_bytes(M)
+    else:
+        assert levels.numel() == M
     rp = _dev_ptr(r, torch.float32, "r") if r is not None else ctypes.c_void_p(0)
     if r is not None:
         assert r.numel() == M
     rc = lib().gq_hsq_levels(_dev_ptr(u, torch.float32, "u"), ctypes.c_int64(M), ctypes.c_int(n_bit),
                              ctypes.c_int(random_mode), rp, ctypes.c_uint64(seed & (2 ** 64 - 1)),
                              _dev_ptr(partials, torch.float32, "partials"), _dev_ptr(lb_ub, torch.float32, "lb_ub"),
-                             _dev_ptr(levels, None, "levels"), ctypes.c_int(_LEVEL_BYTES[levels.dtype]), _stream())
+                             _dev_ptr(levels, None, "levels"),
+                             ctypes.c_int(LEVELS_PACKED6 if packed6 else _LEVEL_BYTES[levels.dtype]), _stream())
     _check(rc, "gq_hsq_levels")
 
 

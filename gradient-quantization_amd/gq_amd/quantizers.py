@@ -23,6 +23,8 @@ library (gq_amd.native).  `codec_factory` exists so that the host logic above ca
 exercised without a GPU by the tests (with the CPU oracle as the checker codec).
 """
 import math
+import operator
+import os
 
 import torch
 
@@ -94,31 +96,55 @@ class GenericCodec(object):
         return rows.mean(dim=0).view(self.shape)
 
 
+def wire_levels_mode(args=None):
+    """How byte-sized levels travel: "bytes" (one per level) or "packed6" (four 6-bit levels per three bytes, for the
+    configurations whose top level is <= 63 with d = 16, K <= 256).  args.gq_wire_levels, else $GQ_WIRE_LEVELS."""
+    mode = getattr(args, "gq_wire_levels", None) or os.environ.get("GQ_WIRE_LEVELS", "bytes")
+    if mode not in ("bytes", "packed6"):
+        raise ValueError("gq_wire_levels / GQ_WIRE_LEVELS must be 'bytes' or 'packed6', got %r" % (mode,))
+    return mode
+
+
 class HSQCodec(object):
     """NearestNeighborCompressor on the HIP kernels.  Wire per user:
-    codes[M] (uint8 | int32) | levels[M] (uint8/int16/int32, or f32 u when n_bit == 32) | lb, ub."""
+    codes[M] (uint8 | int32) | levels[M] (uint8/int16/int32, or f32 u when n_bit == 32; packed6: 3 * ceil(M/4) bytes) | lb, ub."""
 
-    def __init__(self, compressor, numel, shape):
+    def __init__(self, compressor, numel, shape, packed6=False):
         self.c, self.numel, self.shape = compressor, numel, shape
         M = compressor.M
         self.M = M
         self.code_dtype = compressor.code_dtype
         self.level_dtype = compressor.wire_level_dtype() if compressor.compressed_norm else torch.float32
+        self.packed6 = bool(packed6) and self.can_pack6(compressor)
         cb = torch.empty(0, dtype=self.code_dtype).element_size()
-        lb = torch.empty(0, dtype=self.level_dtype).element_size()
+        self._level_bytes = native.packed6_bytes(M) if self.packed6 else M * torch.empty(0, dtype=self.level_dtype).element_size()
         self.codes_off = 0
         self.levels_off = _up(M * cb)
-        self.lbub_off = self.levels_off + _up(M * lb)
+        self.lbub_off = self.levels_off + _up(self._level_bytes)
         self.nbytes = self.lbub_off + 16
         self._u = None
         self._partials = None
 
+    @staticmethod
+    def can_pack6(compressor):
+        """GQ_LEVELS_PACKED6 serves d = 16, K <= 256 (byte codes) when no level exceeds 63: n_bit <= 6 without stochastic
+        rounding (probabilistic_scalar_compressor.py:18: levels up to 2^n_bit - 1), n_bit <= 5 with it (:25: up to 2^n_bit)."""
+        if not compressor.compressed_norm or compressor.dim != 16 or compressor.K > 256:
+            return False
+        nc = compressor.norm_compressor
+        return (1 << nc.n_bit) - (0 if nc.random else 1) <= 63
+
+    def wire_level_kind(self):
+        """What the native calls take as the level type of this codec's wire."""
+        return native.PACKED6 if self.packed6 else self.level_dtype
+
     def _views(self, wire_user, off):
         M = self.M
         cb = torch.empty(0, dtype=self.code_dtype).element_size()
-        lb = torch.empty(0, dtype=self.level_dtype).element_size()
         codes = wire_user[off + self.codes_off:off + self.codes_off + M * cb].view(self.code_dtype)
-        levels = wire_user[off + self.levels_off:off + self.levels_off + M * lb].view(self.level_dtype)
+        levels = wire_user[off + self.levels_off:off + self.levels_off + self._level_bytes]
+        if not self.packed6:
+            levels = levels.view(self.level_dtype)
         lb_ub = wire_user[off + self.lbub_off:off + self.lbub_off + 8].view(torch.float32)
         return codes, levels, lb_ub
 
@@ -137,13 +163,13 @@ class HSQCodec(object):
     def _levels(self, u, partials, levels, lb_ub, salt, r=None):
         nc = self.c.norm_compressor
         if not nc.random:
-            native.hsq_levels(u, nc.n_bit, native.RANDOM_OFF, None, 0, partials, lb_ub, levels)
+            native.hsq_levels(u, nc.n_bit, native.RANDOM_OFF, None, 0, partials, lb_ub, levels, self.packed6)
         elif nc._rng == "reference":
             if r is None:       # the quantizer hands over its slice of ONE torch.rand per record (same stream)
                 r = torch.rand(self.M).to(u.device)
-            native.hsq_levels(u, nc.n_bit, native.RANDOM_GIVEN, r, 0, partials, lb_ub, levels)
+            native.hsq_levels(u, nc.n_bit, native.RANDOM_GIVEN, r, 0, partials, lb_ub, levels, self.packed6)
         else:
-            native.hsq_levels(u, nc.n_bit, native.RANDOM_DEVICE, None, _next_seed() ^ salt, partials, lb_ub, levels)
+            native.hsq_levels(u, nc.n_bit, native.RANDOM_DEVICE, None, _next_seed() ^ salt, partials, lb_ub, levels, self.packed6)
 
     def encode_into(self, grad, wire_user, off, salt, r=None):
         _require_device(grad, "HSQCodec.encode_into")
@@ -160,7 +186,7 @@ class HSQCodec(object):
             else:   # encode + levels in one library call (gq_hsq_compress)
                 mode = native.RANDOM_DEVICE if nc.random else native.RANDOM_OFF
                 native.hsq_compress(flat, cbk, codes, u, partials, nc.n_bit, mode, None,
-                                    (_next_seed() ^ salt) if nc.random else 0, lb_ub, levels)
+                                    (_next_seed() ^ salt) if nc.random else 0, lb_ub, levels, self.packed6)
         else:
             _, partials = self._scratch(dev)
             native.hsq_encode(flat, cbk, codes, levels, partials)  # `levels` section holds f32 u
@@ -175,7 +201,7 @@ class HSQCodec(object):
         native.hsq_decode_sum_packed(gathered, self.M, cbk, self.c.n_bit if self.c.compressed_norm else 32, out, R,
                                      codes_off=off + self.codes_off, levels_off=off + self.levels_off,
                                      lbub_off=off + self.lbub_off, code_dtype=self.code_dtype,
-                                     level_dtype=self.level_dtype)
+                                     level_dtype=self.wire_level_kind())
         assert P == gathered.stride(0)
 
     def roundtrip(self, grad, salt, r=None):
@@ -287,6 +313,12 @@ class QSGDCodec(object):
         return out.view(self.shape)
 
 
+_DATA_PTR = torch.Tensor.data_ptr
+_IS_CONTIGUOUS = torch.Tensor.is_contiguous
+_DTYPE_OF = operator.attrgetter("dtype")
+_F32_ONLY = {torch.float32}
+
+
 class _BatchedBase(object):
     """Shared plumbing of the multi-tensor kernels: a per-step header (segment table with the
     tensors' current device pointers, plus kernel-specific reset values) goes to the device in ONE
@@ -334,9 +366,14 @@ class _BatchedBase(object):
         A header that also carries the reset values of the kernels' min / max accumulators (HSQ, wide-bucket QSGD)
         goes to the device every time; when the pointers are the ones of the last upload (gradients that keep their storage from
         step to step) the pinned copy is sent as it is, without checking and rewriting the table."""
-        ptrs = [g.data_ptr() for g in tensors]
-        eptrs = [e.data_ptr() for e in errs] if errs is not None else self._zeros
-        if self.ready and ptrs == self._last_ptrs and eptrs == self._last_eptrs:
+        ptrs = list(map(_DATA_PTR, tensors))
+        eptrs = list(map(_DATA_PTR, errs)) if errs is not None else self._zeros
+        # the fast path still checks what the kernels assume about every tensor: a gradient replaced by a strided view or
+        # another dtype AT THE SAME ADDRESS (channels_last, the caching allocator handing the block out again) must not
+        # ride on the last upload's validation.  (map() over the C-level accessors: ~6 us for 76 tensors; a Python-level
+        # list of (dtype, is_contiguous) tuples cost 20.)
+        if (self.ready and ptrs == self._last_ptrs and eptrs == self._last_eptrs
+                and all(map(_IS_CONTIGUOUS, tensors)) and set(map(_DTYPE_OF, tensors)) == _F32_ONLY):
             if not self._resets:
                 return True     # nothing but the table in this header, and the device copy still holds it
             self._dev.copy_(self._host[self._last_slot], non_blocking=True)     # unchanged since its last copy
@@ -433,7 +470,7 @@ class BatchedHSQ(_BatchedBase):
 
     @staticmethod
     def group_key(codec):
-        return (codec.c.dim, codec.c.K, _esize(codec.code_dtype), _esize(codec.level_dtype), int(codec.c.n_bit))
+        return (codec.c.dim, codec.c.K, _esize(codec.code_dtype), _esize(codec.level_dtype), int(codec.c.n_bit), int(codec.packed6))
 
     def __init__(self, codecs, offsets, idxs, device, slots, user_bytes):
         self.idxs = list(idxs)
@@ -474,7 +511,7 @@ class BatchedHSQ(_BatchedBase):
         # ONE launch descriptor for the group (gq_hsq_batch): the library picks the kernels -- prefilter (K = 256,
         # d = 8 / 16 / 32), the same with the pages of a larger codebook resident, or exact scoring for every other shape
         self._batch = native.HSQBatch(self._dev[:self._table_words], self.tile_seg, self.nseg, self.ntiles, self.codebook,
-                                      self.code_dtype, self.level_dtype, self.n_bit, self.u_flat,
+                                      self.code_dtype, cd0.wire_level_kind(), self.n_bit, self.u_flat,
                                       self._dev[self._table_words:].view(torch.int32), self.ws)
         self.profile_slot = -1      # measurement hook (bench.py): the NEXT encode's dispatch is timed into this slot
 
@@ -581,11 +618,11 @@ class BatchedQSGD(_BatchedBase):
         return True
 
 
-def default_codec_factory(compressor, numel, shape):
+def default_codec_factory(compressor, numel, shape, packed6=False):
     if isinstance(compressor, IdenticalCompressor):
         return DenseCodec(compressor, numel, shape)
     if isinstance(compressor, NearestNeighborCompressor):
-        return HSQCodec(compressor, numel, shape)
+        return HSQCodec(compressor, numel, shape, packed6)
     if isinstance(compressor, QSGDCompressor):
         return QSGDCodec(compressor, numel, shape)
     return GenericCodec(compressor, numel, shape)
@@ -617,6 +654,10 @@ class PSQuantizer(object):
         self.two_phase = args.two_phase
         self.process_group = process_group
         factory = codec_factory or default_codec_factory
+        self.wire_levels = wire_levels_mode(args)      # "bytes" | "packed6" (6-bit levels where the configuration allows)
+        if self.wire_levels == "packed6":
+            base_factory = factory
+            factory = lambda comp, n, shape: base_factory(comp, n, shape, packed6=True)
         self.compressors = []
         self.codecs = []
         for param in self.parameters:

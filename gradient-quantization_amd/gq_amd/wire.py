@@ -8,6 +8,8 @@ subvectors with k_bit <= 8 and levels that fit a byte:
 
 All sections are 16-byte aligned so the kernels can write them in place (the encode
 and level kernels write straight into views of this buffer; nothing is repacked).
+`packed6=True`: the levels travel as four 6-bit values per three bytes (GQ_LEVELS_PACKED6, include/gq_hsq.h:
+top level <= 63), 3 * ceil(M / 4) bytes instead of M -- 12.5 % off the payload of the BASELINE configuration.
 
 `SplitHSQWire` is the same payload arranged for a two-part exchange (gq_amd/exchange.py,
 "split"): bytes [0, cut) hold everything the first MA subvectors need,
@@ -27,11 +29,13 @@ def _up(x, a=16):
 class HSQWire:
     """Offsets of the sections of one rank's payload."""
 
-    def __init__(self, M):
+    def __init__(self, M, packed6=False):
         self.M = M
+        self.packed6 = packed6
+        self.level_bytes = 3 * ((M + 3) // 4) if packed6 else M
         self.codes_off = 0
         self.levels_off = _up(M)
-        self.lbub_off = self.levels_off + _up(M)
+        self.lbub_off = self.levels_off + _up(self.level_bytes)
         self.nbytes = self.lbub_off + 16
 
     def alloc(self, device, ranks=None):
@@ -39,10 +43,10 @@ class HSQWire:
         return torch.empty(shape, dtype=torch.uint8, device=device)
 
     def views(self, buf):
-        """(codes u8[M], levels u8[M], lb_ub f32[2]) views into a 1-D payload buffer."""
+        """(codes u8[M], levels u8[M] -- or the packed section u8[3 * ceil(M / 4)] --, lb_ub f32[2]) views into a 1-D payload buffer."""
         assert buf.dim() == 1 and buf.numel() == self.nbytes
         codes = buf[self.codes_off:self.codes_off + self.M]
-        levels = buf[self.levels_off:self.levels_off + self.M]
+        levels = buf[self.levels_off:self.levels_off + self.level_bytes]
         lb_ub = buf[self.lbub_off:self.lbub_off + 8].view(torch.float32)
         return codes, levels, lb_ub
 

@@ -92,6 +92,31 @@ GQ_EXPORT int gq_cpu_minmax_partials(const float *v, int64_t n, float *workspace
     return GQ_OK;
 }
 
+/* GQ_LEVELS_PACKED6 (include/gq_hsq.h): four 6-bit levels per three bytes; a NaN quotient's INT_MIN travels as 0 like in the byte form */
+#define GQ_LEVELS_PACKED6 (-6)
+static void store_packed6(const int32_t *l, int64_t M, uint8_t *dst) {
+    for (int64_t g = 0; 4 * g < M; ++g) {
+        uint32_t w = 0;
+        for (int k = 0; k < 4 && 4 * g + k < M; ++k) {
+            const int32_t v = l[4 * g + k];
+            w |= ((uint32_t)(v < 0 ? 0 : v) & 63u) << (6 * k);
+        }
+        dst[3 * g] = (uint8_t)w;
+        dst[3 * g + 1] = (uint8_t)(w >> 8);
+        dst[3 * g + 2] = (uint8_t)(w >> 16);
+    }
+}
+static int32_t *load_packed6(const uint8_t *src, int64_t M) {
+    int32_t *l = (int32_t *)malloc((size_t)M * 4);
+    if (!l) return 0;
+    for (int64_t m = 0; m < M; ++m) {
+        const uint8_t *p = src + 3 * (m >> 2);
+        const uint32_t w = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+        l[m] = (int32_t)((w >> (6 * (m & 3))) & 63u);
+    }
+    return l;
+}
+
 /* gq_hsq_levels: probabilistic_scalar_compressor.py:12-27 */
 GQ_EXPORT int gq_cpu_hsq_levels(const float *u, int64_t M, int n_bit, int random_mode, const float *r, uint64_t seed,
                                 const float *workspace, float *lb_ub, void *levels, int level_bytes, void *stream) {
@@ -99,14 +124,18 @@ GQ_EXPORT int gq_cpu_hsq_levels(const float *u, int64_t M, int n_bit, int random
     (void)seed;
     (void)workspace;   /* the oracle recomputes min / max from u; the pair at the head of the workspace is the same */
     if (M < 1 || !u || !lb_ub || !levels || n_bit < 1 || n_bit > 30) return GQ_ERR_INVALID_ARG;
-    if (level_bytes != 1 && level_bytes != 2 && level_bytes != 4) return GQ_ERR_INVALID_ARG;
+    if (level_bytes != 1 && level_bytes != 2 && level_bytes != 4 && level_bytes != GQ_LEVELS_PACKED6) return GQ_ERR_INVALID_ARG;
+    if (level_bytes == GQ_LEVELS_PACKED6 && (1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > 63) return GQ_ERR_INVALID_ARG;
     if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_GIVEN) return GQ_ERR_INVALID_ARG;
     if (random_mode == GQ_RANDOM_GIVEN && !r) return GQ_ERR_INVALID_ARG;
     int32_t *l = (int32_t *)malloc((size_t)M * 4);
     if (!l) return GQ_ERR_UNSUPPORTED;
     gq_oracle_minmax(u, M, lb_ub);
     gq_oracle_scalar_levels(u, M, n_bit, random_mode == GQ_RANDOM_GIVEN, r, lb_ub[0], lb_ub[1], l);
-    store_codes(l, M, levels, level_bytes);
+    if (level_bytes == GQ_LEVELS_PACKED6)
+        store_packed6(l, M, (uint8_t *)levels);
+    else
+        store_codes(l, M, levels, level_bytes);
     free(l);
     return GQ_OK;
 }
@@ -120,7 +149,8 @@ GQ_EXPORT int gq_cpu_hsq_decode_sum(const void *codes, int code_bytes, const voi
     (void)K;
     if (R < 1 || M < 1 || d < 1 || !codes || !levels || !codebook || !out) return GQ_ERR_INVALID_ARG;
     if (code_bytes != 1 && code_bytes != 4) return GQ_ERR_INVALID_ARG;
-    if (level_bytes != 0 && level_bytes != 1 && level_bytes != 2 && level_bytes != 4) return GQ_ERR_INVALID_ARG;
+    if (level_bytes != 0 && level_bytes != 1 && level_bytes != 2 && level_bytes != 4 && level_bytes != GQ_LEVELS_PACKED6)
+        return GQ_ERR_INVALID_ARG;
     if (level_bytes != 0 && !lb_ub) return GQ_ERR_INVALID_ARG;
     const int64_t n = M * (int64_t)d;
     float *dec = (float *)malloc((size_t)R * (size_t)n * sizeof(float));
@@ -135,7 +165,9 @@ GQ_EXPORT int gq_cpu_hsq_decode_sum(const void *codes, int code_bytes, const voi
         if (level_bytes == 0) {
             memcpy(norms, (const float *)levels + (size_t)r * (size_t)M, (size_t)M * sizeof(float));
         } else {
-            int32_t *l = load_codes((const char *)levels + (size_t)r * (size_t)M * (size_t)level_bytes, M, level_bytes);
+            int32_t *l = level_bytes == GQ_LEVELS_PACKED6
+                             ? load_packed6((const uint8_t *)levels + (size_t)r * (size_t)(3 * ((M + 3) / 4)), M)
+                             : load_codes((const char *)levels + (size_t)r * (size_t)M * (size_t)level_bytes, M, level_bytes);
             gq_oracle_scalar_decode(l, M, n_bit, lb_ub[2 * r], lb_ub[2 * r + 1], norms);
             free(l);
         }

@@ -10,6 +10,20 @@ from gq_amd.compressors import IdenticalCompressor, NearestNeighborCompressor, Q
 from gq_amd.quantizers import DenseCodec, GenericCodec, HSQCodec, QSGDCodec
 
 
+def pack6(levels):
+    """GQ_LEVELS_PACKED6 (include/gq_hsq.h): four 6-bit levels per three bytes, little-endian 24-bit groups."""
+    l = np.zeros((levels.size + 3) // 4 * 4, np.uint32)
+    l[:levels.size] = np.where(levels < 0, 0, levels).astype(np.uint32) & 63      # a NaN quotient's INT_MIN travels as 0, like the byte form
+    w = l[0::4] | (l[1::4] << 6) | (l[2::4] << 12) | (l[3::4] << 18)
+    return np.stack([w & 255, (w >> 8) & 255, (w >> 16) & 255], 1).astype(np.uint8).reshape(-1)
+
+
+def unpack6(raw, M):
+    b = raw.astype(np.uint32).reshape(-1, 3)
+    w = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+    return np.stack([(w >> (6 * k)) & 63 for k in range(4)], 1).reshape(-1)[:M].astype(np.int32)
+
+
 class OracleHSQCodec(HSQCodec):
     def encode_into(self, grad, wire_user, off, salt, r=None):
         c = self.c
@@ -28,7 +42,10 @@ class OracleHSQCodec(HSQCodec):
         res = oracle.hsq_compress(grad.detach().cpu().numpy().reshape(-1), cb, c.n_bit, 1 if random else 0, r)
         codes, levels, lb_ub = self._views(wire_user, off)
         codes.copy_(torch.from_numpy(res["codes"].astype(np.uint8 if self.code_dtype == torch.uint8 else np.int32)))
-        levels.copy_(torch.from_numpy(res["levels"]).to(self.level_dtype))
+        if self.packed6:
+            levels.copy_(torch.from_numpy(pack6(res["levels"])))
+        else:
+            levels.copy_(torch.from_numpy(res["levels"]).to(self.level_dtype))
         lb_ub.copy_(torch.tensor([res["lb"], res["ub"]], dtype=torch.float32))
 
     def _decode(self, gathered, off, R, out):
@@ -40,7 +57,8 @@ class OracleHSQCodec(HSQCodec):
             if not c.compressed_norm:
                 decs.append(oracle.hsq_decode(codes.numpy().astype(np.int32), levels.numpy(), cb))
                 continue
-            decs.append(oracle.hsq_decompress(codes.numpy().astype(np.int32), levels.numpy().astype(np.int32),
+            lv = unpack6(levels.numpy(), self.M) if self.packed6 else levels.numpy().astype(np.int32)
+            decs.append(oracle.hsq_decompress(codes.numpy().astype(np.int32), lv,
                                               np.float32(lb_ub[0].item()), np.float32(lb_ub[1].item()), cb, c.n_bit))
         out.copy_(torch.from_numpy(decs[0] if R == 1 else oracle.mean_users(np.stack(decs, 0))))   # one payload: the plain decompress
 
@@ -96,11 +114,11 @@ class OracleQSGDCodec(QSGDCodec):
         out.copy_(torch.from_numpy(decs[0] if R == 1 else oracle.mean_users(np.stack(decs, 0))))   # one payload: the plain decompress
 
 
-def oracle_codec_factory(compressor, numel, shape):
+def oracle_codec_factory(compressor, numel, shape, packed6=False):
     if isinstance(compressor, IdenticalCompressor):
         return DenseCodec(compressor, numel, shape)
     if isinstance(compressor, NearestNeighborCompressor):
-        return OracleHSQCodec(compressor, numel, shape)
+        return OracleHSQCodec(compressor, numel, shape, packed6)
     if isinstance(compressor, QSGDCompressor):
         return OracleQSGDCodec(compressor, numel, shape)
     return GenericCodec(compressor, numel, shape)

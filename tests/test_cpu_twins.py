@@ -37,8 +37,9 @@ class Boundary(object):
         rc = getattr(self.lib, self.prefix + name)(*args)
         assert rc == 0, "%s%s returned %d" % (self.prefix, name, rc)
 
-    def hsq_compress_decode(self, x, cb, n_bit, random, r, code_bytes, R=1):
-        """-> codes, u, lb_ub, levels, decoded mean of R copies of the payload (level_bytes 4)."""
+    def hsq_compress_decode(self, x, cb, n_bit, random, r, code_bytes, R=1, level_bytes=4):
+        """-> codes, u, lb_ub, levels, decoded mean of R copies of the payload (level_bytes 4, or GQ_LEVELS_PACKED6 = -6:
+        the levels come back as the packed section, three bytes per four levels)."""
         d, K = cb.shape[1], cb.shape[0]
         M = x.size // d
         P = self.ptr
@@ -48,17 +49,18 @@ class Boundary(object):
         nws = getattr(self.lib, self.prefix + "hsq_workspace_bytes")(ctypes.c_int64(M)) // 4 + 1
         ws = self.new(np.zeros(nws, np.float32))
         lb_ub = self.new(np.zeros(2, np.float32))
-        levels = self.new(np.zeros(M, np.int32))
+        levels = self.new(np.zeros(M, np.int32) if level_bytes == 4 else np.zeros(3 * ((M + 3) // 4) + 1, np.uint8))
         rr = self.new(np.ascontiguousarray(r, np.float32)) if random else None
         self._call("hsq_encode", P(grad), P(cbk), ctypes.c_int64(M), d, K, P(codes), code_bytes, P(u), P(ws), None)
         self._call("hsq_levels", P(u), ctypes.c_int64(M), n_bit, 1 if random else 0, P(rr) if random else None,
-                   ctypes.c_uint64(0), P(ws), P(lb_ub), P(levels), 4, None)
+                   ctypes.c_uint64(0), P(ws), P(lb_ub), P(levels), level_bytes, None)
         out = self.new(np.zeros(M * d, np.float32))
         h = self.to_host
         cR = self.new(np.concatenate([h(codes)] * R))
-        lR = self.new(np.concatenate([h(levels)] * R))
+        lv = h(levels) if level_bytes == 4 else h(levels)[:3 * ((M + 3) // 4)]       # contiguous payloads: no slack between sections
+        lR = self.new(np.concatenate([lv] * R + [np.zeros(4, lv.dtype)]))           # (+ the byte the last group's dword read touches)
         bR = self.new(np.concatenate([h(lb_ub)] * R))
-        self._call("hsq_decode_sum", P(cR), code_bytes, P(lR), 4, P(bR), P(cbk), R, ctypes.c_int64(M), d, K, n_bit,
+        self._call("hsq_decode_sum", P(cR), code_bytes, P(lR), level_bytes, P(bR), P(cbk), R, ctypes.c_int64(M), d, K, n_bit,
                    P(out), None)
         self.sync()
         return h(codes), h(u), h(lb_ub), h(levels), h(out)
@@ -165,6 +167,42 @@ def test_the_same_ctypes_calls_on_the_hip_library_and_on_the_cpu_twins(d, K, n_b
             assert _same(p, q), name
         else:
             assert np.array_equal(p, q), name
+
+
+@pytest.mark.parametrize("name", [n for n in HSQ_CASES if "_d16_" in n or n.startswith("hsq_randn") or n.startswith("hsq_small")])
+def test_cpu_twins_packed6_levels_decode_like_byte_levels(name):
+    """GQ_LEVELS_PACKED6 (four 6-bit levels per three bytes) through the twins: the packed section unpacks to the
+    reference's levels and the decode of the packed payload is the reference's decoded tensor, bit for bit."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d, K, n_bit, random = int(g["dim"]), int(g["K"]), int(g["n_bit"]), int(g["random"])
+    if d != 16 or K > 256 or n_bit == 32 or (1 << n_bit) - (0 if random else 1) > 63 or g["codes"].size == 1:
+        pytest.skip("the packed form serves d = 16, K <= 256, top level <= 63")
+    cb = np.load(os.path.join(GOLDEN, "codebook_d%d_k%d_normalized.npy" % (d, K)))
+    sys.path.insert(0, HERE)
+    from oracle_codec import unpack6
+    b = cpu_boundary()
+    codes, u, lb_ub, packed, dec = b.hsq_compress_decode(g["x"], cb, n_bit, random, g["r"] if random else None, 1, 1, -6)
+    assert np.array_equal(unpack6(packed[:3 * ((codes.size + 3) // 4)], codes.size), np.where(g["levels"] < 0, 0, g["levels"]))
+    assert _same(dec, g["decoded"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_bit,random,R,M", [(6, 0, 1, 64 * 97 + 13), (6, 0, 8, 100003), (5, 1, 3, 4098), (2, 0, 2, 7), (6, 0, 4, 256)])
+def test_packed6_levels_on_the_hip_library_and_on_the_cpu_twins(n_bit, random, R, M):
+    """The same ctypes calls with level_bytes = GQ_LEVELS_PACKED6 on both libraries: packed section and decoded mean
+    byte-identical (d = 16, K = 256)."""
+    rng = np.random.RandomState(n_bit * 31 + R)
+    x = (rng.standard_normal(M * 16) * 0.02).astype(np.float32)
+    cb = np.load(os.path.join(GOLDEN, "codebook_d16_k256_normalized.npy"))
+    r = rng.random_sample(M).astype(np.float32)
+    a = cpu_boundary().hsq_compress_decode(x, cb, n_bit, random, r, 1, R, -6)
+    b = gpu_boundary().hsq_compress_decode(x, cb, n_bit, random, r, 1, R, -6)
+    nb = 3 * ((M + 3) // 4)
+    assert np.array_equal(a[0], b[0]) and _same(a[1], b[1]) and _same(a[2], b[2])
+    assert np.array_equal(a[3][:nb], b[3][:nb]), "packed level sections differ"
+    assert _same(a[4], b[4]), "decoded mean of the packed payloads differs"
+    c = gpu_boundary().hsq_compress_decode(x, cb, n_bit, random, r, 1, R, 4)
+    assert _same(b[4], c[4]), "packed and int32 levels decode differently"
 
 
 @pytest.mark.gpu

@@ -145,3 +145,22 @@ def test_driver_one_epoch_on_disk_data_logs_loss_and_accuracy(tmp_path, dataset)
     assert type(q.codecs[0]).__name__ == "HSQCodec"
     if dataset == "mnist":
         assert lines[-1]["accuracy(%)"] > 80.0, lines[-1]
+
+
+def test_rank_slices_keep_the_short_last_batch_like_the_reference_loader():
+    """The reference's DataLoader has drop_last=False and main.py:189-193 gives every user len // num_users samples, the
+    last user the rest.  rank_slices does the same over ranks: every sample of the epoch is used exactly once, all ranks
+    take the same number of steps, a last batch with fewer samples than ranks is skipped everywhere."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gradient-quantization_amd"))
+    from gq_amd.datasets import rank_slices
+    for n, batch, world in ((1000, 32, 4), (1003, 32, 4), (96, 32, 3), (97, 32, 3), (130, 64, 2), (10, 4, 1), (9, 4, 4)):
+        per_rank = [list(rank_slices(n, batch, r, world)) for r in range(world)]
+        assert len(set(len(p) for p in per_rank)) == 1, "ranks would take different numbers of steps"
+        seen = sorted(i for p in per_rank for lo, hi in p for i in range(lo, hi))
+        full, rest = divmod(n, batch * world)
+        expect = n if rest == 0 or rest // world > 0 else full * batch * world
+        assert seen == list(range(expect)), (n, batch, world)
+        for step in range(len(per_rank[0])):
+            sizes = [per_rank[r][step][1] - per_rank[r][step][0] for r in range(world)]
+            assert len(set(sizes[:-1])) <= 1 and sizes[-1] >= sizes[0] and sizes[-1] - sizes[0] < world

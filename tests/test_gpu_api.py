@@ -168,6 +168,52 @@ def test_psquantizer_on_gpu_matches_reference(name):
         assert q._groups and q._groups[0][2].ready and q._groups[0][2].reference_draws
 
 
+@pytest.mark.parametrize("name", PSQ)
+def test_psquantizer_on_gpu_with_packed6_levels_matches_reference(name, monkeypatch):
+    """GQ_WIRE_LEVELS=packed6: wherever the configuration allows it (d = 16, K <= 256, top level <= 63) the levels travel
+    as four 6-bit values per three bytes; the aggregates (and error-feedback residuals) still equal the reference's
+    fixtures at tolerance 0 -- record, error feedback, two-phase round trips, the ring's plain decodes."""
+    from test_host_logic import run_psq_fixture
+    monkeypatch.setenv("GQ_WIRE_LEVELS", "packed6")
+    q = run_psq_fixture(name, None, device="cuda", tol=0.0)
+    packed = [c for c in q.codecs if getattr(c, "packed6", False)]
+    if name in ("psq_fcn_u4_det", "psq_fcn_u4_ef", "psq_fcn_u4_ef_twophase", "psq_fcn_u4_twophase"):      # d16 k8 n6, deterministic levels
+        assert packed, "no tensor of %s took the packed form" % name
+    for c in packed:
+        assert c.nbytes < c.M * 2 + 16 + 32
+
+
+def test_resnet50_list_with_packed6_levels_equals_the_byte_wire(monkeypatch):
+    """The ResNet-50 parameter list (76 codebook-compressed tensors) through the multi-tensor kernels, two users, with
+    and without packed levels: same aggregates bit for bit, 12 % fewer wire bytes; error feedback + two-phase too."""
+    import json
+    from gq_amd.compressors import NearestNeighborCompressor
+    from gq_amd.quantizers import Quantizer
+    shapes = json.load(open(os.path.join(GOLDEN, "resnet50_cifar_shapes.json")))["parameter_shapes"]
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    grads = [[torch.randn(s, device=dev) * 1e-3 for s in shapes] for _ in range(2)]
+    for ef, two_phase in ((False, False), (True, True)):
+        outs, sizes = [], []
+        for mode in ("bytes", "packed6"):
+            monkeypatch.setenv("GQ_WIRE_LEVELS", mode)
+            params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
+            q = Quantizer(NearestNeighborCompressor, params, make_args(c_dim=16, k_bit=8, n_bit=6, random=0, num_users=2, ef=ef,
+                                                                       two_phase=two_phase))
+            for step in range(2):
+                for u in range(2):
+                    for p, gr in zip(params, grads[u]):
+                        p.grad = gr.clone()
+                    q.record(u, epoch=1)
+                q.apply()
+            assert q._groups and q._groups[0][2].ready
+            outs.append([p.grad.data.clone() for p in params] + ([e.clone() for p in params for e in p.error] if ef else []))
+            sizes.append(q.wire_bytes_per_user())
+        assert sizes[1] < 0.9 * sizes[0], sizes
+        for a, b in zip(*outs):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "psqd_*.npz"))))
 def test_psquantizer_full_parameter_lists_match_reference_digests_on_gpu(name):
     """The real FCN / ResNet-50 parameter lists (161 tensors, 23.5 M elements, two users) through the multi-tensor HIP
@@ -470,8 +516,10 @@ def test_batched_quantizer_any_shape_equals_per_tensor_path(case, tmp_path, monk
     assert qb._groups and qb._groups[0][2] is not None and qb._groups[0][2].ready and not qp._groups
     grp = qb._groups[0][2]
     assert grp.codebook.shape == (K, d) and len(qb.batch_idx) == sum(int(np.prod(s)) > 1000 for s in shapes) >= 5
-    assert grp.prefilter == (K == 256 and d in (8, 16, 32)) and not grp.bytes
-    assert grp.paged == (K > 256 and K % 256 == 0 and d in (8, 16, 32))
+    from gq_amd import native
+    want = (native.BATCH_PREFILTER if (K == 256 and d in (8, 16, 32)) else
+            native.BATCH_PAGED if (K > 256 and K % 256 == 0 and d in (8, 16, 32)) else native.BATCH_EXACT)
+    assert grp._batch.path == want      # the library's choice of kernels for this shape (gq_hsq_batched_path)
     for a, b, s in zip(gb, gp, shapes):
         assert a.shape == torch.Size(s)
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), s
@@ -497,8 +545,9 @@ def test_batched_quantizer_reference_default_flags():
     q, g = _run_quantizer(shapes, 2, 9, c_dim=32, n_bit=8, random=1)
     det, gd = _run_quantizer(shapes, 2, 9, c_dim=32, n_bit=8, random=0)
     grp = q._groups[0][2]
-    assert grp.ready and grp.prefilter and not grp.bytes and grp.level_dtype == torch.int16
-    assert det._groups[0][2].bytes
+    from gq_amd import native
+    assert grp.ready and grp._batch.path == native.BATCH_PREFILTER and grp.level_dtype == torch.int16
+    assert det._groups[0][2].level_dtype == torch.uint8
     for a, b, p in zip(g, gd, q.parameters):
         if p.numel() > 1000:
             assert not torch.equal(a, b)
@@ -508,12 +557,15 @@ def test_batched_quantizer_reference_default_flags():
 @pytest.mark.parametrize("c_dim", [16, 32])
 def test_batched_quantizer_long_tensor_lists(c_dim):
     """More tensors than the kernels keep segment records for in LDS (384): d = 16 switches to the instantiation
-    that reads the records from global memory, d = 32 falls back to per-tensor launches; same results either way."""
+    that reads the records from global memory, d = 32 is served by the exact multi-tensor kernels instead of the
+    prefilter (the library's choice, gq_hsq_batched_path); same results as per-tensor launches either way."""
     shapes = [(1024,)] * 300 + [(32, 64)] * 100 + [(10,)] * 3
     qb, gb = _run_quantizer(shapes, 1, 4, c_dim=c_dim)
     qp, gp = _run_quantizer(shapes, 1, 4, c_dim=c_dim, gq_no_batch=True)
     assert qb._groups and len(qb._groups[0][1]) == 400
-    assert qb._groups[0][2].ready == (c_dim == 16)
+    from gq_amd import native
+    assert qb._groups[0][2].ready
+    assert qb._groups[0][2]._batch.path == (native.BATCH_PREFILTER if c_dim == 16 else native.BATCH_EXACT)
     for a, b in zip(gb, gp):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     assert torch.equal(qb._wire, qp._wire)
@@ -1191,3 +1243,39 @@ def test_bench_launches_its_own_ranks(extra):
     elif not extra:     # the default is the in-place all-gather, nothing is auto-tuned
         assert d["exchange"]["transport"] == "allgather" and d["exchange"]["autotune_ms"] is None
         assert d["exchange"]["ms"] > 0
+
+
+def test_a_gradient_replaced_at_the_same_address_is_revalidated():
+    """Round-2 advisor: the pointer-table fast path returned before the dtype / contiguity checks.  A gradient that comes
+    back at the SAME address as a strided view must not be read as if it were contiguous: the group refuses it and the
+    step takes the per-tensor path (which makes it contiguous), with the reference's result."""
+    from gq_amd.compressors import NearestNeighborCompressor
+    from gq_amd.quantizers import Quantizer
+    dev = torch.device("cuda:0")
+    shapes = [(64, 64), (64, 64), (32, 64)]
+    params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
+    q = Quantizer(NearestNeighborCompressor, params, make_args(num_users=1))
+    torch.manual_seed(11)
+    store = [torch.randn(s, device=dev) for s in shapes]
+
+    def step(grads):
+        for p, g in zip(params, grads):
+            p.grad = g
+        q.record(0, epoch=1)
+        q.apply()
+        return [p.grad.data.clone() for p in params]
+    first = step([g.view(g.shape) for g in store])
+    assert q._groups[0][2].ready
+    # same storage, same data_ptr, but a transposed (non-contiguous) view for tensor 0
+    t0 = store[0].t()
+    assert t0.data_ptr() == store[0].data_ptr() and not t0.is_contiguous()
+    second = step([t0, store[1].view(shapes[1]), store[2].view(shapes[2])])
+    qp = Quantizer(NearestNeighborCompressor, [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes],
+                   make_args(num_users=1, gq_no_batch=True))
+    for p, g in zip(qp.parameters, [t0.contiguous(), store[1], store[2]]):
+        p.grad = g.clone()
+    qp.record(0, epoch=1)
+    qp.apply()
+    for a, p in zip(second, qp.parameters):
+        assert torch.equal(a.view(torch.int32), p.grad.data.view(torch.int32))
+    assert not torch.equal(first[0], second[0])

@@ -30,6 +30,10 @@ obj = q._groups[0][2]
 obj._upload = timed("upload (pointers -> pinned header -> H2D)", obj._upload)
 obj.encode = timed("group.encode (incl. upload)", obj.encode)
 obj.decode_mean = timed("group.decode_mean", obj.decode_mean)
+obj._batch.decode = timed("  native decode call", obj._batch.decode)
+obj._batch.encode = timed("  native encode call", obj._batch.encode)
+obj._batch.levels = timed("  native levels call", obj._batch.levels)
+obj._out_buffer = timed("  _out_buffer", obj._out_buffer)
 q.record = timed("record", q.record)
 q.apply = timed("apply", q.apply)
 q._decode_all = timed("_decode_all", q._decode_all)
