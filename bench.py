@@ -466,7 +466,7 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
                      "frac_is": "frac = the dominant kernel alone (4.125 B x 25e6 / kernel_ms / peak); frac_compress = SURVEY 8(d)'s "
                                 "definition, the whole compress: 4.125 B x 25e6 / (encode + levels, HIP events around "
                                 "back-to-back pairs on rotating inputs) / peak",
-                     "kernel": "gq_hsq_encode = hsq_encode_pf_kernel (one launch: prefilter, exact rescoring, in-place exact fix-up, final lb/ub)",
+                     "kernel": "gq_hsq_encode = hsq_encode_pf_kernel (one launch: prefilter, exact rescoring, in-place exact fix-up; levels: a second launch)",
                      "kernel_ms": enc_ms, "kernel_ms_back_to_back": enc_b2b_ms,
                      "kernel_ms_recorded_bracket": enc_bracket_ms, "empty_recorded_bracket_ms": ev_overhead_ms,
                      "note": "exact f32 scoring would need 512 flop/element (81 us at 157.3 TFLOP/s); the "
@@ -474,7 +474,9 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
                              "start/stop events attached to the kernel's dispatch inside the timed region "
                              "(agrees with rocprofv3, profiles/); a bracket RECORDED around the call reads "
                              "kernel_ms_recorded_bracket, an empty one empty_recorded_bracket_ms"},
-        "phases_ms": {"encode": enc_ms, "levels": lv_ms, "compress": cmp_ms, "decode_mean": dec_ms, "exchange": exch_ms},
+        "phases_ms": {"encode": enc_ms, "levels": lv_ms, "compress": cmp_ms, "decode_mean": dec_ms, "exchange": exch_ms,
+                      "note": "encode: HIP events attached to the dispatch in the timed region; levels / compress / decode_mean: HIP events "
+                              "around back-to-back calls on rotating inputs (untimed pass)"},
         "compress_only": {"value": world * SIZE / (cmp_ms * 1e-3), "unit": "elements/s"},
         "ranks_bit_identical": identical,
     }

@@ -1266,14 +1266,16 @@ def test_a_gradient_replaced_at_the_same_address_is_revalidated():
         return [p.grad.data.clone() for p in params]
     first = step([g.view(g.shape) for g in store])
     assert q._groups[0][2].ready
-    # same storage, same data_ptr, but a transposed (non-contiguous) view for tensor 0
+    # same storage, same data_ptr, but a transposed (non-contiguous) view for tensor 0.  (apply() rebinds .data of the
+    # tensor objects it was given, like the reference's `param.grad.data = g`: the expected input is copied first.)
     t0 = store[0].t()
     assert t0.data_ptr() == store[0].data_ptr() and not t0.is_contiguous()
+    expect_in = [t0.contiguous().clone(), store[1].clone(), store[2].clone()]
     second = step([t0, store[1].view(shapes[1]), store[2].view(shapes[2])])
     qp = Quantizer(NearestNeighborCompressor, [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes],
                    make_args(num_users=1, gq_no_batch=True))
-    for p, g in zip(qp.parameters, [t0.contiguous(), store[1], store[2]]):
-        p.grad = g.clone()
+    for p, g in zip(qp.parameters, expect_in):
+        p.grad = g
     qp.record(0, epoch=1)
     qp.apply()
     for a, p in zip(second, qp.parameters):
