@@ -663,9 +663,7 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
         if constexpr (std::is_same<CodeT, int32_t>::value) {
             if (!paged_ok)
                 return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 4 with K > 256 needs d in {8, 16, 32}, K %% 256 == 0, aligned grad");
-            static const bool per_page = getenv("GQ_PAGED_PER_LAUNCH") != nullptr;   // tests / A-B: the old page-per-launch form
-            if (d != 16 || !per_page) return launch_encode_pfd_paged(grad, codebook, M, d, K, codes, u, partials, st);
-            return launch_encode_pf_paged(grad, codebook, M, K, codes, u, partials, st);
+            return launch_encode_pfd_paged(grad, codebook, M, d, K, codes, u, partials, st);
         } else {
             return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: K > 256 needs int32 codes");
         }

@@ -157,9 +157,6 @@ static int resident_blocks_per_cu(KernelT kernel, int threads, size_t lds) {
 template <typename CodeT>
 int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *workspace,
                      hipStream_t st, int profile_slot = -1);
-// the same for d = 16 and K = 512, 768, ... (a launch per page of 256 codewords, results merged in place)
-int launch_encode_pf_paged(const float *grad, const float *codebook, int64_t M, int K, int32_t *codes, float *u,
-                           float *workspace, hipStream_t st);
 // hsq_encode_pfd.hip: the same for d = 8 and d = 32 (K = 256).
 template <typename CodeT>
 int launch_encode_pfd(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u,

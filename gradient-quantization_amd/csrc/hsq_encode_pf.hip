@@ -41,10 +41,6 @@ namespace gq {
 
 // The d = 16 kernels run ONE workgroup of 8 waves per CU (two waves per SIMD, as before, but in one workgroup):
 // the waves of a workgroup share their tiles through an LDS counter (see the kernel).
-#ifndef GQ_PF_GROUP
-#define GQ_PF_GROUP 4     // codewords per key of the top-2 scan (4 or 8); see the scan in the kernel.  8 was built in round 3
-                          // (13 VALU operations per chain instead of 18, an 8-codeword exact rescoring): 42.4 us against 40.3 us
-#endif
 constexpr int PF_WAVES = 8;
 constexpr int PF_THREADS = PF_WAVES * 64;
 constexpr int PF_TAIL = 6;   // swept 2..12 (52.3 us at 4..8, 54 at 2 and 12)
@@ -69,9 +65,6 @@ struct PfArgs {
     int64_t ntiles;
     int nseg;                 // batched: segments in seg_table
     float ef_scale;           // EF kernels: grad <- grad + ef_scale * error (error pointer = seg_table[seg][7], 0 = none)
-    int code_base;            // PAGED: index of this page's first codeword (a multiple of 256)
-    int merge;                // PAGED: keep the (code, u) already in the output unless this page beats it
-    int last_page;            // PAGED: this launch produces the final projections (fold their min / max)
     int tiles_q, tiles_r;     // tiles per workgroup: the first tiles_r workgroups take tiles_q + 1, the others tiles_q
 };
 
@@ -85,10 +78,7 @@ static void pf_split(PfArgs &a, int64_t ntiles, int64_t blocks) {
 // SEGLDS (batched only): the segment records are read from their LDS copy (nseg <= PF_LDS_SEGS) or, for
 // longer tensor lists, from global memory -- as two instantiations, because a run-time choice between
 // the two sources turns the record pointer into a flat pointer (see tile_info).
-// PAGED (single tensor, K a multiple of 256 above 256): one launch per page of 256 codewords, a.cb = the page; a
-// page's winner is exact, so max |u| over the pages -- an earlier page keeps a tie: the first maximum -- is the
-// exact argmax over the whole codebook.  The merge reads the (code, u) the previous pages left in the output.
-template <typename CodeT, bool BATCHED, bool EF = false, bool SEGLDS = true, bool PAGED = false>
+template <typename CodeT, bool BATCHED, bool EF = false, bool SEGLDS = true>
 __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfArgs a) {
     const float *__restrict__ cb = a.cb;
     float *__restrict__ ws = a.ws;
@@ -367,74 +357,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             flush_minmax();
             cur_seg = ti.seg;
         }
-        // PAGED: what the earlier pages left for this lane's subvector, requested a whole tile before its use
-        float prev_u = 0.0f;
-        int prev_idx = 0;
-        if (PAGED && a.merge && lane <= ti.rem) {
-            prev_u = (u + (BATCHED ? t * 64 : ti.sv0))[(unsigned)lane];
-            prev_idx = (int)(ti.codes + ti.sv0)[(unsigned)lane];
-        }
-
         // ---- prefilter: 16 (block, row block) chains; top-2 GROUP keys per (block, row-block half) ----
         // The three MFMAs of chain c+1 depend on each other and issue is in order, so they are
         // placed one by one BETWEEN the key operations of chain c (sched_barrier pins the order):
         // the matrix pipe runs under the VALU stream.
-#if GQ_PF_GROUP == 8
-        // Keys over GROUPS OF 8 codewords (registers 8g..8g+7 of a chain = rows {0..3} and {8..11} (+16g, +4h) of
-        // its row block): per 16 scores 2 keys instead of 4 and ONE top-2 step per chain instead of two -- 13 VALU
-        // operations per chain against 18 -- with one tracker per block (16 group ids).  The price is an exact
-        // rescoring of 8 codewords instead of 4 (64 more plain FMAs, which issue at half the cost of the max / med3 /
-        // and_or operations the scan is made of).
-        unsigned best[2] = {0, 0}, second[2] = {0, 0};
-        unsigned vmask = KEY_MASK;
-        asm volatile("" : "+v"(vmask));  // keep the mask in a VGPR: v_and_or with an SGPR operand issues slower
-        auto group_key = [&](const f32x16 &a, int rb, int g) {
-            const float m = fmaxf(absmax4(a[8 * g], a[8 * g + 1], a[8 * g + 2], a[8 * g + 3]),
-                                  absmax4(a[8 * g + 4], a[8 * g + 5], a[8 * g + 6], a[8 * g + 7]));
-            return and_or(__float_as_uint(m), vmask, (unsigned)(rb * 2 + g));
-        };
-        auto track = [&](int blk, unsigned k0, unsigned k1) {
-            second[blk] = max(second[blk], med3u(best[blk], k0, k1));
-            best[blk] = max3u(best[blk], k0, k1);
-        };
-        f32x16 acc = {0};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[0], vh[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[0], vl[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[0], vh[0], acc, 0, 0, 0);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int rb = c & 7, blk = c >> 3;
-            if (c + 1 < 16) {
-                const int nb = (c + 1) >> 3, nr = (c + 1) & 7;
-                f32x16 nacc = {0};
-                __builtin_amdgcn_sched_barrier(0);
-                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[nr], vh[nb], nacc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned k0 = group_key(acc, rb, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vl[nb], nacc, 0, 0, 0);
-                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vh[nb], nacc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                track(blk, k0, group_key(acc, rb, 1));
-                __builtin_amdgcn_sched_barrier(0);
-                acc = nacc;
-            } else {
-                track(blk, group_key(acc, rb, 0), group_key(acc, rb, 1));
-            }
-        }
-
-        // ---- per block: the best group's first codeword and the bound on the rest ----
-        int k1[2];
-        unsigned s2[2], bk[2];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const unsigned bw = best[blk];
-            const int gid = (int)(bw & 31u);
-            k1[blk] = (gid >> 1) * 32 + 16 * (gid & 1) + 4 * h;   // rows k1 .. k1+3 and k1+8 .. k1+11
-            s2[blk] = second[blk] | 31u;                          // upper end of its bucket
-            bk[blk] = bw;
-        }
-#else
         unsigned best[4] = {0, 0, 0, 0}, second[4] = {0, 0, 0, 0};
         unsigned vmask = KEY_MASK;
         asm volatile("" : "+v"(vmask));  // keep the mask in a VGPR: v_and_or with an SGPR operand issues slower
@@ -497,7 +423,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             s2[blk] = max3u(second[2 * blk], second[2 * blk + 1], bl) | 31u;         // upper end of its bucket
             bk[blk] = bw;
         }
-#endif
 
         // ---- this lane's own full subvector (tile subvector `lane`): 8 swaps of the B loads ----
         float vf[16];
@@ -534,15 +459,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         take_if_greater(val, idx, p4[1], kc + 1);
         take_if_greater(val, idx, p4[2], kc + 2);
         take_if_greater(val, idx, p4[3], kc + 3);
-#if GQ_PF_GROUP == 8
-        {   // the group's second quad, rows kc+8 .. kc+11 (two quads further in the LDS image), ascending index: first maximum
-            const f32x4 q4 = exact_score_quad<16>(s_cb + ((kc >> 2) + 2) * QUAD_STRIDE, vf);
-            take_if_greater(val, idx, q4[0], kc + 8);
-            take_if_greater(val, idx, q4[1], kc + 9);
-            take_if_greater(val, idx, q4[2], kc + 10);
-            take_if_greater(val, idx, q4[3], kc + 11);
-        }
-#endif
 
         float vmax = 0.0f;
 #pragma unroll
@@ -624,27 +540,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             if (!BATCHED && lane == 0) worklist[ti.sv0 + fl] = (int)(ti.sv0 + fl);   // diagnostics only: which subvectors took this path
         }
 
-        if (PAGED && valid) {
-            idx += a.code_base;
-            if (a.merge && !(nan_rank(val) > nan_rank(prev_u))) {   // strict: ties (and an earlier NaN) stay with the earlier page
-                val = prev_u;
-                idx = prev_idx;
-            }
-        }
-        if (PAGED && __ballot(valid && nan_bits(val)) != 0) {   // a NaN kept from an earlier page counts as well
-            sawnan = true;
-            if (BATCHED && lane == 0) {
-                atomicMin(a.seg_minmax + 2 * ti.seg, MAPPED_NAN_LO);
-                atomicMax(a.seg_minmax + 2 * ti.seg + 1, MAPPED_NAN_HI);
-            }
-        }
         if (valid) {   // uniform bases (the tile's first code / projection) + the lane index
             (ti.codes + ti.sv0)[(unsigned)lane] = (CodeT)idx;
             ((gf_ptr)u + (BATCHED ? t * 64 : ti.sv0))[(unsigned)lane] = val;
-            if (!PAGED || a.last_page) {   // (min,max) of the FINAL projections only: earlier pages' values may be replaced
-                lmin = fminf(lmin, val);
-                lmax = fmaxf(lmax, val);
-            }
+            lmin = fminf(lmin, val);
+            lmax = fmaxf(lmax, val);
         }
         ti = tin;
         t = tn;
@@ -689,31 +589,6 @@ int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT 
                            dim3(PF_THREADS), 0, st, a);
     }
     GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter)");
-    return GQ_OK;
-}
-
-// K = 256 * pages, d = 16: one launch per page (see PAGED)
-int launch_encode_pf_paged(const float *grad, const float *codebook, int64_t M, int K, int32_t *codes, float *u, float *ws,
-                           hipStream_t st) {
-    if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
-    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<int32_t, false, false, true, true>, PF_THREADS, 0);
-    const int64_t blocks = pf16_grid((M + 63) / 64, bpc);
-    for (int page = 0; page * 256 < K; ++page) {
-        PfArgs a = {};
-        a.grad = grad;
-        a.M = M;
-        a.codes = codes;
-        a.u = u;
-        a.cb = codebook + (size_t)page * 256 * 16;
-        a.ws = ws;
-        a.code_base = page * 256;
-        a.merge = page > 0;
-        a.last_page = (page + 1) * 256 >= K;
-        pf_split(a, (M + 63) / 64, blocks);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<int32_t, false, false, true, true>), dim3((unsigned)blocks),
-                           dim3(PF_THREADS), 0, st, a);
-    }
-    GQ_CHECK_LAUNCH("gq_hsq_encode (paged prefilter)");
     return GQ_OK;
 }
 
@@ -768,39 +643,6 @@ int launch_pfd_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, 
                              const float *codebook, int d, int K, int ef, float ef_scale, uint8_t *wire, float *u_flat,
                              uint32_t *seg_minmax, float *ws, hipStream_t st);   // hsq_encode_pfd.hip
 
-// multi-tensor, K = 256 * pages, int32 codes: one launch per page (PAGED); error feedback rides in page 0
-static int encode_batched_paged16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                  const float *codebook, int K, int ef, float ef_scale, uint8_t *wire, float *u_flat,
-                                  uint32_t *seg_minmax, float *workspace, hipStream_t st) {
-    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<int32_t, true, true, true, true>, PF_THREADS, 0);
-    const int64_t blocks = pf16_grid(ntiles, bpc);
-    for (int page = 0; page * 256 < K; ++page) {
-        PfArgs a = {};
-        a.M = ntiles * 64;
-        a.u = u_flat;
-        a.cb = codebook + (size_t)page * 256 * 16;
-        a.ws = workspace;
-        a.seg_table = seg_table;
-        a.tile_seg = tile_seg;
-        a.wire = wire;
-        a.seg_minmax = seg_minmax;
-        a.ntiles = ntiles;
-        a.nseg = nseg;
-        a.ef_scale = ef_scale;
-        a.code_base = page * 256;
-        a.merge = page > 0;
-        a.last_page = (page + 1) * 256 >= K;
-        pf_split(a, ntiles, blocks);
-        if (ef && page == 0)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<int32_t, true, true, true, true>), dim3((unsigned)blocks),
-                               dim3(PF_THREADS), 0, st, a);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<int32_t, true, false, true, true>), dim3((unsigned)blocks),
-                               dim3(PF_THREADS), 0, st, a);
-    }
-    GQ_CHECK_LAUNCH("gq_hsq_encode_batched_paged");
-    return GQ_OK;
-}
 }  // namespace gq
 
 GQ_INTERNAL int gqi_hsq_encode_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,

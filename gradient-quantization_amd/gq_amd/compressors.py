@@ -280,12 +280,14 @@ class QSGDCompressor(object):
 
 
 class ProbabilisticVectorCompressor(object):
-    """Unbiased vector quantiser (probabilistic_vector_compressor.py:8-77), INTENDED semantics:
-    sample the codeword with probability |p_k| / ||p||_1, p = pinv(C^T) v, magnitude sign(p_k)*||p||_1,
-    so that E[decode] = v.  The reference's own class cannot run: it opens
-    ./codebook/... (the tree has ./codebooks/learned_codebook/..., which is what is used here) and
-    takes argmin of a bool tensor; its inverse-CDF intent -- first index whose cumulative
-    probability reaches r - 1e-5 -- is what gq_pvq_encode implements."""
+    """Unbiased vector quantiser (probabilistic_vector_compressor.py:8-77): sample the codeword with probability
+    |p_k| / ||p||_1, p = pinv(C^T) v, magnitude sign(p_k) * ||p||_1, so that E[decode] = v.
+    Pinned by the reference's own output (tests/golden/pvq_*.npz, residual_*.npz): the class as it
+    stands opens ./codebook/... (the tree has ./codebooks/learned_codebook/..., which is what is used here) and calls
+    torch.argmin on a bool tensor (:58), which no torch with bool tensors implements; the fixtures were produced with
+    that one operation defined as (index of the first True) - 1 -- the inverse-CDF sample the line's `+ 1` is written
+    for -- and every other line running unedited.  gq_pvq_encode reproduces them bit for bit, including torch.cumsum's
+    double accumulation of the cumulative probabilities."""
 
     def __init__(self, size, shape, args):
         c_dim, k_bit, n_bit = args.c_dim, args.k_bit, args.n_bit
