@@ -488,10 +488,11 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
         # side measurements asked for by SURVEY 8d: stochastic rounding with the in-kernel generator, and a
         # gradient of realistic magnitude (N(0,1) * 1e-3); compress only, HIP events over 20 launches
         small = grads[1] * 1e-3
+        lv_b = torch.empty(M, dtype=torch.uint8, device=dev)      # byte levels of their own (stochastic rounding reaches level 64)
         r2 = event_ms(torch, lambda: (native.hsq_encode(next_grad(), cb, codes, u, partials),
-                                      native.hsq_levels(u, N_BIT, 2, None, seed, partials, lb_ub, levels)))
+                                      native.hsq_levels(u, N_BIT, 2, None, seed, partials, lb_ub, lv_b)))
         sc = event_ms(torch, lambda: (native.hsq_encode(small, cb, codes, u, partials),
-                                      native.hsq_levels(u, N_BIT, 0, None, seed, partials, lb_ub, levels)))
+                                      native.hsq_levels(u, N_BIT, 0, None, seed, partials, lb_ub, lv_b)))
         line["variants"] = {"compress_random2": {"ms": r2, "value": SIZE / (r2 * 1e-3), "unit": "elements/s"},
                             "compress_scale_1e-3": {"ms": sc, "value": SIZE / (sc * 1e-3), "unit": "elements/s"}}
         del small
