@@ -174,6 +174,8 @@ def live_traffic(workload, kernel_match):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself being profiled: no nested rocprofv3"
     got = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="gq_pmc_", dir="/tmp")
@@ -182,7 +184,7 @@ def live_traffic(workload, kernel_match):
                "--no-cpu-baseline", "--no-variants", "--traffic", "off"]
         try:
             # a child process (never an exec from this GPU-initialised process); the profiler's own program is python itself
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=300, stdout=subprocess.DEVNULL,
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=150, stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL)
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
