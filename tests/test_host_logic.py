@@ -546,3 +546,49 @@ def test_codebooks_are_found_in_a_reference_checkout_cwd(tmp_path):
     out = subprocess.run([sys.executable, "-B", os.path.join(PKG, "run_reference.py"), str(script)],
                          cwd="/root/reference", env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_batch_descriptor_is_validated_before_anything_is_launched():
+    """The multi-tensor entry points refuse a descriptor they cannot serve with an error code and a text -- checked here
+    without a GPU: every refusal below happens before the first HIP call."""
+    import torch
+    from gq_amd import native
+    L = native.lib()
+    S = native._HSQBatchStruct
+
+    def desc(**kw):
+        f = dict(struct_bytes=ctypes.sizeof(S), d=16, K=256, code_bytes=1, level_bytes=1, n_bit=6, nseg=3, profile_slot=-1, ntiles=7,
+                 seg_table=64, tile_seg=64, codebook=64, u_flat=64, seg_minmax=64, workspace=64)
+        f.update(kw)
+        return S(**f)
+    path = lambda **kw: L.gq_hsq_batched_path(ctypes.byref(desc(**kw)))
+    assert path() == native.BATCH_PREFILTER and path(d=8) == native.BATCH_PREFILTER and path(d=32, nseg=384) == native.BATCH_PREFILTER
+    assert path(K=1024, code_bytes=4) == native.BATCH_PAGED and path(d=32, K=4096, code_bytes=4) == native.BATCH_PAGED
+    assert path(d=12, K=512, code_bytes=4) == native.BATCH_EXACT and path(d=24, K=64) == native.BATCH_EXACT
+    assert path(d=32, nseg=385) == native.BATCH_EXACT            # more tensors than the d = 32 prefilter keeps records for
+    assert path(K=1024, code_bytes=4, nseg=500) == native.BATCH_EXACT
+    assert path(d=600, K=256) == 0 and b"no multi-tensor kernel" in L.gq_last_error()
+    # refused descriptors
+    assert path(struct_bytes=8) == 0 and b"struct_bytes" in L.gq_last_error()
+    assert path(K=512, code_bytes=1) == 0 and b"uint8 codes need K <= 256" in L.gq_last_error()
+    assert path(level_bytes=3) == 0 and path(code_bytes=2) == 0 and path(nseg=0) == 0 and path(codebook=None) == 0
+    assert path(level_bytes=native.LEVELS_PACKED6) == native.BATCH_PREFILTER
+    assert path(level_bytes=native.LEVELS_PACKED6, d=32) == 0 and b"GQ_LEVELS_PACKED6" in L.gq_last_error()
+    nan = ctypes.c_float(float("nan"))
+    for fn, args in ((L.gq_hsq_encode_batched, (ctypes.c_void_p(64), nan, None)),
+                     (L.gq_hsq_levels_batched, (ctypes.c_void_p(64), 0, ctypes.c_uint64(0), None, 0, None)),
+                     (L.gq_hsq_decode_sum_batched, (ctypes.c_void_p(64), ctypes.c_int64(128), 1, ctypes.c_void_p(64), 0, None))):
+        assert fn(None, *args) == -1 and b"null descriptor" in L.gq_last_error()
+        assert fn(ctypes.byref(desc(struct_bytes=4)), *args) == -1
+        assert fn(ctypes.byref(desc(code_bytes=1, K=300)), *args) == -1
+    assert L.gq_hsq_encode_batched(ctypes.byref(desc(d=600)), ctypes.c_void_p(64), nan, None) == -2      # no kernel serves the shape
+    assert L.gq_hsq_encode_batched(ctypes.byref(desc()), None, nan, None) == -1          # null wire
+    assert L.gq_hsq_levels_batched(ctypes.byref(desc()), ctypes.c_void_p(64), 7, ctypes.c_uint64(0), None, 0, None) == -1   # random_mode
+    Q = native._QSGDBatchStruct
+    q = Q(ctypes.sizeof(Q), 2, 4, 0, 3, 0, 10, 64, 64, None)
+    assert L.gq_qsgd_compress_batched(None, ctypes.c_void_p(64), 0, ctypes.c_uint64(0), nan, None) == -1
+    q.bits = 8
+    assert L.gq_qsgd_compress_batched(ctypes.byref(q), ctypes.c_void_p(64), 0, ctypes.c_uint64(0), nan, None) == -1 and b"packs to 4" in L.gq_last_error()
+    q.bits, q.wide = 4, 1
+    assert L.gq_qsgd_compress_batched(ctypes.byref(q), ctypes.c_void_p(64), 0, ctypes.c_uint64(0), nan, None) == -1 and b"norm_bits" in L.gq_last_error()
+    assert native.hsq_batched_path(16, 256, torch.uint8) == native.BATCH_PREFILTER and native.hsq_batched_path(200, 64, torch.uint8) == 0
