@@ -71,8 +71,9 @@ def parse_args():
                     help="N > 1: how the wire travels.  Default: the in-place all-gather (the one collective every backend has); "
                          "auto = time all three before the timed region and keep the fastest (opt-in: direct / split have not "
                          "met RCCL with more than one rank yet)")
-    ap.add_argument("--wire-levels", default=os.environ.get("GQ_WIRE_LEVELS", "bytes"), choices=["bytes", "packed6"],
-                    help="how the 6-bit levels travel: a byte each, or four per three bytes (12.5 %% less wire; same decode bits)")
+    ap.add_argument("--wire-levels", default=os.environ.get("GQ_WIRE_LEVELS", "auto"), choices=["auto", "bytes", "packed6"],
+                    help="how the 6-bit levels travel: a byte each, or four per three bytes (12.5 %% less wire; same decode bits); "
+                         "auto = packed6 when there is an exchange (N > 1, all-gather / direct), bytes at N = 1")
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "off"],
                     help="roofline.traffic: live = two short child runs under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE); "
                          "auto = live at N=1 when rocprofv3 is on PATH, else the committed profiles/hbm_traffic.json")
@@ -317,6 +318,8 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     # three gradients in turn: 300 MB of inputs + the 100 MB decode target between two uses of the same bytes
     grads = [torch.randn(SIZE, device=dev, generator=gen) for _ in range(3)]
     M = SIZE // C_DIM
+    if args.wire_levels == "auto":
+        args.wire_levels = "packed6" if (world > 1 and args.exchange in ("allgather", "direct")) else "bytes"
     packed6 = args.wire_levels == "packed6" and args.random == 0      # top level 63 (n_bit 6 without stochastic rounding)
     if packed6 and args.exchange in ("split", "auto"):
         sys.exit("bench.py: --wire-levels packed6 goes with --exchange allgather or direct (the split arrangement keeps byte levels)")
@@ -525,7 +528,7 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
         Comp = QSGDCompressor
     params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
     os.environ["GQ_EXCHANGE"] = args.exchange
-    os.environ["GQ_WIRE_LEVELS"] = args.wire_levels      # packed6 applies where the top level is <= 63 (not with the README's --random 1 at n_bit 6)
+    os.environ["GQ_WIRE_LEVELS"] = args.wire_levels      # (auto: packed6 for N > 1.)  packed6 applies where the top level is <= 63 (not with the README's --random 1 at n_bit 6)
     torch.manual_seed(1234 + rank)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # the constructors report the reference's dimension repair on stdout

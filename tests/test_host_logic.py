@@ -426,12 +426,14 @@ def test_quantizer_ranks_gloo(tmp_path, oracle, world, users, mode, exchange):
         assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
 
 
-@pytest.mark.parametrize("world,users,mode,exchange", [(2, 2, "ps", "allgather"), (4, 1, "ps", "split"), (8, 1, "ps", "direct"),
-                                                       (2, 2, "ring", "allgather")])
-def test_quantizer_ranks_gloo_packed6_levels(tmp_path, oracle, world, users, mode, exchange):
+@pytest.mark.parametrize("world,users,mode,exchange,levels", [(2, 2, "ps", "allgather", "packed6"), (4, 1, "ps", "split", "packed6"),
+                                                              (8, 1, "ps", "direct", "packed6"), (2, 2, "ring", "allgather", "packed6"),
+                                                              (2, 1, "ps", "allgather", "auto")])
+def test_quantizer_ranks_gloo_packed6_levels(tmp_path, oracle, world, users, mode, exchange, levels):
     """GQ_WIRE_LEVELS=packed6: the levels travel as four 6-bit values per three bytes (12 % less wire); R ranks over gloo
     still equal the same users in one process on the BYTE wire, bitwise -- the decode sees the same integers."""
-    r0 = _run_ranks(tmp_path, world, mode, users, exchange, tag=300 + world * 10 + users + len(exchange), wire_levels="packed6")
+    # ("auto", the default: packed where there is an exchange -- more than one rank -- and bytes on a single rank)
+    r0 = _run_ranks(tmp_path, world, mode, users, exchange, tag=300 + world * 10 + users + len(exchange) + len(levels), wire_levels=levels)
     assert int(r0["wire_bytes"]) < int(r0["byte_wire_bytes"]), "the packed wire is not smaller"
     sys.path.insert(0, HERE)
     import _dist_worker as w
