@@ -20,8 +20,8 @@ static int check_batch(const gq_hsq_batch *b, const char *what) {
     if (b->level_bytes != 0 && b->level_bytes != 1 && b->level_bytes != 2 && b->level_bytes != 4 &&
         b->level_bytes != GQ_LEVELS_PACKED6)
         return fail(GQ_ERR_INVALID_ARG, "%s: level_bytes must be 0 (f32 projections), 1, 2, 4 or GQ_LEVELS_PACKED6", what);
-    if (b->level_bytes == GQ_LEVELS_PACKED6 && !(b->d == 16 && b->K <= 256 && b->code_bytes == 1))
-        return fail(GQ_ERR_UNSUPPORTED, "%s: GQ_LEVELS_PACKED6 is served for d = 16, K <= 256 with byte codes", what);
+    if (b->level_bytes == GQ_LEVELS_PACKED6 && !(b->d == 16 && b->K == 256 && b->code_bytes == 1 && b->n_bit <= 6))
+        return fail(GQ_ERR_UNSUPPORTED, "%s: the multi-tensor kernels take GQ_LEVELS_PACKED6 for d = 16, K = 256, byte codes, n_bit <= 6", what);
     if (!b->seg_table || !b->tile_seg || !b->codebook) return fail(GQ_ERR_INVALID_ARG, "%s: null pointer in the descriptor", what);
     if (b->profile_slot >= GQ_PROFILE_SLOTS) return fail(GQ_ERR_INVALID_ARG, "%s: profile_slot %d", what, b->profile_slot);
     return GQ_OK;

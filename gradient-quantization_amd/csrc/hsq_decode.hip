@@ -115,7 +115,10 @@ __device__ __forceinline__ unsigned row_addr(unsigned c4, unsigned lane_const) {
 
 // One payload's contribution to the four subvectors of a team (see the kernel): norms by lane q, shared through
 // quad-permute DPP moves; probabilistic_scalar_compressor.py:31-32 unfused, nearest_neighbor_compressor.py:88.
-template <bool FIRST, bool PACKED6>
+// ABS0: the codebook image starts at LDS address 0 (a kernel whose only LDS is its dynamic array) and the v_perm_b32
+// result IS the address; through a pointer the compiler adds the array's link-time base (0) to every row address.
+typedef const f32x4 __attribute__((address_space(3))) lds_f32x4;
+template <bool FIRST, bool PACKED6, bool ABS0 = false>
 __device__ __forceinline__ void dec16_payload(f32x4 (&acc)[4], unsigned c4, unsigned l4, float lb, float range, float inv_s,
                                               int q, const char *cb_bytes, unsigned lane_const) {
     const float n_own = level_to_norm<unsigned>(PACKED6 ? ((l4 >> (6 * q)) & 63u) : ((l4 >> (8 * q)) & 255u), lb, range, inv_s);
@@ -130,7 +133,8 @@ __device__ __forceinline__ void dec16_payload(f32x4 (&acc)[4], unsigned c4, unsi
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float n = n_team[k];
-        const f32x4 c = *reinterpret_cast<const f32x4 *>(cb_bytes + a[k]);
+        const f32x4 c = ABS0 ? *reinterpret_cast<lds_f32x4 *>((uintptr_t)a[k])
+                             : *reinterpret_cast<const f32x4 *>(cb_bytes + a[k]);
         const f32x4 n4 = {n, n, n, n};
         const f32x4 dec = c * n4;
         if constexpr (FIRST) {
@@ -249,6 +253,175 @@ void hsq_decode_sum_d16u8_kernel(
     }
 }
 
+// The same decode for a compile-time payload count R <= DEC16_RMAX, software-pipelined ACROSS items.  In the kernel above
+// every wave runs load -> R payloads of arithmetic -> 4 stores, and all waves of the chip do so in step (each has ~3 items):
+// the payload words of an item are requested behind the stores of the previous one in the CU's memory pipeline and come
+// back once that burst has drained, HBM writes pause while everybody computes -- T(R) = write time + R x compute time.
+// Here the R (code, level) word pairs of an item live in registers and each pair is re-requested for the wave's NEXT item
+// as soon as it has been consumed, i.e. before the current item's stores are queued; the loop body is straight-line for
+// the compiler's vmcnt bookkeeping (a payload's words wait with R + 3 younger operations outstanding, the stores among
+// them), so the stores drain under the next item's arithmetic.  (lb, ub - lb) sit in scalar registers.
+constexpr int DEC16_RMAX = 8;
+#ifndef GQ_DEC16R_WAVES
+#define GQ_DEC16R_WAVES 8
+#endif
+
+template <int R, bool PACKED6>
+__global__ __launch_bounds__(DEC16_THREADS) __attribute__((amdgpu_waves_per_eu(GQ_DEC16R_WAVES, GQ_DEC16R_WAVES)))
+void hsq_decode_sum_d16u8_r_kernel(
+    const uint8_t *__restrict__ codes, const uint8_t *__restrict__ levels, const float *__restrict__ lb_ub,
+    int64_t code_stride, int64_t level_stride, int64_t lbub_stride, const float *__restrict__ cb, int64_t M, int K,
+    int n_bit, float *__restrict__ out) {
+    extern __shared__ float s_cb[];   // [K][4 copies][16] at LDS address 0: a row address is the v_perm_b32 result itself
+    for (int i = threadIdx.x; i < K * 16; i += DEC16_THREADS) {   // (row, copy, quarter)
+        const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
+        *reinterpret_cast<f32x4 *>(s_cb + row * 64 + c * 16 + 4 * q) = *reinterpret_cast<const f32x4 *>(cb + row * 16 + 4 * q);
+    }
+    float lb[R], range[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float l = lb_ub[r * lbub_stride], u = lb_ub[r * lbub_stride + 1];
+        lb[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, l)));
+        range[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, u - l)));
+    }
+    __syncthreads();
+    const float inv_s = 1.0f / (float)(1 << (n_bit & 31));
+    const MeanDiv md = mean_div_of(R);
+    const int q = threadIdx.x & 3;
+    const unsigned lane_const = (unsigned)(((threadIdx.x >> 3) & 3) * 64 + 16 * q);
+    const char *const cb_bytes = reinterpret_cast<const char *>(s_cb);
+    const unsigned full = (unsigned)(M >> 2) * 4u;   // items of whole groups; M < 2^31 - 2^21 (launcher): 32-bit item numbers
+    const unsigned stride = gridDim.x * DEC16_THREADS;
+    unsigned i = blockIdx.x * DEC16_THREADS + threadIdx.x;
+    unsigned c4[R], l4[R];
+    // per-payload bases pinned in scalar registers: the loads then take the (scalar base + 32-bit lane offset) form,
+    // left to itself the compiler re-associates base + r * stride + offset into a 64-bit VALU add per load
+    typedef const uint8_t __attribute__((address_space(1))) gbyte;   // global address space kept through the integer round trip
+    gbyte *cbase[R], *lbase[R];
+    auto pin = [](const uint8_t *p) {
+        const uint64_t v = reinterpret_cast<uint64_t>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<gbyte *>(((uint64_t)hi << 32) | lo);
+    };
+    typedef unsigned __attribute__((aligned(1))) word_any;   // the packed form reads words at any byte (see load_packed6)
+    auto ldw = [](gbyte *p) {
+        return PACKED6 ? (unsigned)*reinterpret_cast<const word_any __attribute__((address_space(1))) *>(p)
+                       : *reinterpret_cast<const unsigned __attribute__((address_space(1))) *>(p);
+    };
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        cbase[r] = pin(codes + (int64_t)r * code_stride);
+        lbase[r] = pin(levels + (int64_t)r * level_stride);
+    }
+    auto request = [&](unsigned item) {
+        const unsigned off = item & ~3u;                           // first subvector of the group
+        const unsigned loff = PACKED6 ? 3u * (item >> 2) : off;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            c4[r] = ldw(cbase[r] + off);
+            l4[r] = ldw(lbase[r] + loff);
+        }
+    };
+    if (i < full) request(i);
+    while (i < full) {
+        const unsigned nxt = i + stride;
+        const unsigned pre = nxt < full ? nxt : i;   // the last item re-requests itself: no branch around the loads
+        const unsigned poff = pre & ~3u, ploff = PACKED6 ? 3u * (pre >> 2) : poff;
+        f32x4 acc[4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (r == 0)
+                dec16_payload<true, PACKED6, true>(acc, c4[r], l4[r], lb[r], range[r], inv_s, q, cb_bytes, lane_const);
+            else
+                dec16_payload<false, PACKED6, true>(acc, c4[r], l4[r], lb[r], range[r], inv_s, q, cb_bytes, lane_const);
+            c4[r] = ldw(cbase[r] + poff);
+            l4[r] = ldw(lbase[r] + ploff);
+        }
+        float *o = out + (int64_t)(i & ~3u) * 16 + 4 * q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x4 a = acc[k];
+            if (md.apply) {
+                a[0] = mean_div(a[0], md);
+                a[1] = mean_div(a[1], md);
+                a[2] = mean_div(a[2], md);
+                a[3] = mean_div(a[3], md);
+            }
+            *reinterpret_cast<f32x4 *>(o + 16 * k) = a;
+        }
+        i = nxt;
+    }
+    // the last, partial group of a tensor whose M is not a multiple of 4 (byte loads), by the first team of workgroup 0
+    const int nv = (int)(M & 3);
+    if (nv != 0 && blockIdx.x == 0 && threadIdx.x < 4) {
+        const int64_t m0 = (int64_t)full;
+        f32x4 acc[4];
+#pragma unroll 1
+        for (int r = 0; r < R; ++r) {   // a plain loop: (lb, ub) from memory, nothing of the main loop's register set kept
+            const uint8_t *cp = codes + (int64_t)r * code_stride + m0;
+            const uint8_t *lp = levels + (int64_t)r * level_stride + (PACKED6 ? 3 * (m0 >> 2) : m0);
+            unsigned c = 0, l = 0;
+            for (int k = 0; k < nv; ++k) c |= (unsigned)cp[k] << (8 * k);
+            if (PACKED6) {   // a group is always stored whole (slots past M hold 0)
+                l = (unsigned)lp[0] | ((unsigned)lp[1] << 8) | ((unsigned)lp[2] << 16);
+            } else {
+                for (int k = 0; k < nv; ++k) l |= (unsigned)lp[k] << (8 * k);
+            }
+            const float tl = lb_ub[r * lbub_stride], tr = lb_ub[r * lbub_stride + 1] - tl;
+            if (r == 0)
+                dec16_payload<true, PACKED6, true>(acc, c, l, tl, tr, inv_s, q, cb_bytes, lane_const);
+            else
+                dec16_payload<false, PACKED6, true>(acc, c, l, tl, tr, inv_s, q, cb_bytes, lane_const);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < nv) {
+                f32x4 a = acc[k];
+                if (md.apply) {
+                    a[0] = mean_div(a[0], md);
+                    a[1] = mean_div(a[1], md);
+                    a[2] = mean_div(a[2], md);
+                    a[3] = mean_div(a[3], md);
+                }
+                *reinterpret_cast<f32x4 *>(out + (m0 + k) * 16 + 4 * q) = a;
+            }
+        }
+    }
+}
+
+template <int R, bool P6>
+static void launch_dec16_r(const uint8_t *codes, const uint8_t *levels, const float *lb_ub, int64_t cs, int64_t ls, int64_t bs,
+                           const float *cb, int64_t M, int K, int n_bit, float *out, hipStream_t st) {
+    static const int bpc = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_d16u8_r_kernel<R, P6>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipGetLastError();
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hsq_decode_sum_d16u8_r_kernel<R, P6>, DEC16_THREADS,
+                                                         (size_t)256 * 64 * sizeof(float)) != hipSuccess || n < 1)
+            n = 1;
+        return n;
+    }();
+    const int64_t total = ((M + 3) >> 2) * 4;
+    int64_t blocks = (total + DEC16_THREADS - 1) / DEC16_THREADS;
+    if (blocks > (int64_t)cu_count() * bpc) blocks = (int64_t)cu_count() * bpc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_d16u8_r_kernel<R, P6>), dim3((unsigned)blocks), dim3(DEC16_THREADS),
+                       (size_t)K * 64 * sizeof(float), st, codes, levels, lb_ub, cs, ls, bs, cb, M, K, n_bit, out);
+}
+
+template <bool P6>
+static bool launch_dec16_fixed_r(int R, const uint8_t *codes, const uint8_t *levels, const float *lb_ub, int64_t cs, int64_t ls,
+                                 int64_t bs, const float *cb, int64_t M, int K, int n_bit, float *out, hipStream_t st) {
+    if (M >= ((int64_t)1 << 31) - ((int64_t)1 << 21)) return false;
+    switch (R) {
+#define GQ_DEC16_CASE(N) case N: launch_dec16_r<N, P6>(codes, levels, lb_ub, cs, ls, bs, cb, M, K, n_bit, out, st); return true;
+        GQ_DEC16_CASE(1) GQ_DEC16_CASE(2) GQ_DEC16_CASE(3) GQ_DEC16_CASE(4)
+        GQ_DEC16_CASE(5) GQ_DEC16_CASE(6) GQ_DEC16_CASE(7) GQ_DEC16_CASE(8)
+#undef GQ_DEC16_CASE
+        default: return false;
+    }
+}
+
 // any d: one thread per output float.
 template <typename CodeT, typename LevelT>
 __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_scalar_kernel(
@@ -288,6 +461,11 @@ static int launch_decode(const CodeT *codes, const LevelT *levels, const float *
                                           reinterpret_cast<uintptr_t>(levels) | (uintptr_t)ls);
         if (d == 16 && K <= 256 && lb_ub && (align & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(cb) & 15) == 0 && (M >= (int64_t)K || P6)) {
+            if (launch_dec16_fixed_r<P6>(R, reinterpret_cast<const uint8_t *>(codes), reinterpret_cast<const uint8_t *>(levels),
+                                         lb_ub, cs, ls, bs, cb, M, K, n_bit, out, st)) {
+                GQ_CHECK_LAUNCH("gq_hsq_decode_sum");
+                return GQ_OK;
+            }
             const int64_t total = ((M + 3) >> 2) * 4;
             const size_t lds = (size_t)K * 64 * sizeof(float);   // four copies of every row
             static const int bpc = [] {

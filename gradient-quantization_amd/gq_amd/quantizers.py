@@ -98,7 +98,7 @@ class GenericCodec(object):
 
 def wire_levels_mode(args=None, world=1):
     """How byte-sized levels travel: "bytes" (one per level) or "packed6" (four 6-bit levels per three bytes, for the
-    configurations whose top level is <= 63 with d = 16, K <= 256).  args.gq_wire_levels, else $GQ_WIRE_LEVELS, else
+    configurations whose top level is <= 63 with d = 16, K = 256).  args.gq_wire_levels, else $GQ_WIRE_LEVELS, else
     "auto": packed6 when there is an exchange to shorten (more than one rank), bytes on a single rank -- the packed form is
     bit-identical in its result and costs < 1 % of a single-rank step."""
     mode = getattr(args, "gq_wire_levels", None) or os.environ.get("GQ_WIRE_LEVELS", "auto")
@@ -131,9 +131,11 @@ class HSQCodec(object):
 
     @staticmethod
     def can_pack6(compressor):
-        """GQ_LEVELS_PACKED6 serves d = 16, K <= 256 (byte codes) when no level exceeds 63: n_bit <= 6 without stochastic
-        rounding (probabilistic_scalar_compressor.py:18: levels up to 2^n_bit - 1), n_bit <= 5 with it (:25: up to 2^n_bit)."""
-        if not compressor.compressed_norm or compressor.dim != 16 or compressor.K > 256:
+        """The packed form is used for d = 16, K = 256 (what the multi-tensor level / decode kernels with packed levels are
+        built for; the per-tensor entry points would take any K <= 256) when no level exceeds 63: n_bit <= 6 without
+        stochastic rounding (probabilistic_scalar_compressor.py:18: levels up to 2^n_bit - 1), n_bit <= 5 with it (:25: up
+        to 2^n_bit).  Every other configuration keeps one byte (or more) per level."""
+        if not compressor.compressed_norm or compressor.dim != 16 or compressor.K != 256:
             return False
         nc = compressor.norm_compressor
         return (1 << nc.n_bit) - (0 if nc.random else 1) <= 63

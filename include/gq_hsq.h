@@ -61,7 +61,8 @@ size_t gq_hsq_workspace_bytes(int64_t M);
  *     l[4g] | l[4g+1] << 6 | l[4g+2] << 12 | l[4g+3] << 18      at byte 3g of the section (3 * ceil(M / 4) bytes),
  * for configurations whose top level is <= 63 (n_bit <= 6 without stochastic rounding, <= 5 with).  A byte per level
  * spends 8 bits on 6: this form takes 12.5 % off the (codes, levels) payload of the BASELINE configuration.  Served
- * for d = 16, K <= 256 with byte codes; the decode is the same arithmetic on the same integers (bit-identical). */
+ * for d = 16 with byte codes: K <= 256 by the per-tensor entry points, K = 256 by the multi-tensor ones; the decode is
+ * the same arithmetic on the same integers (bit-identical). */
 #define GQ_LEVELS_PACKED6 (-6)
 
 /* Library / device identification. */

@@ -1,6 +1,6 @@
 """Randomised check of the multi-tensor kernels against the per-tensor path: random (d, K) with synthetic
 codebooks, random tensor lists (ragged tiles, tiny and large tensors), users, error feedback, two-phase, ring;
-HSQ and QSGD (incl. wide buckets).  Every aggregate, wire and residual must match bit for bit.
+HSQ (byte and 6-bit packed levels) and QSGD (incl. wide buckets).  Every aggregate, wire and residual must match bit for bit.
     python tools/fuzz_batched.py [seconds] [seed]"""
 import contextlib, gc, io, os, sys, tempfile, time
 from argparse import Namespace
@@ -61,6 +61,11 @@ while time.time() - t0 < budget:
             continue
         codebook(d, 2 ** k_bit)
         kw = dict(c_dim=d, k_bit=k_bit, n_bit=n_bit)
+        if d == 16 and rng.random() < 0.5:      # GQ_LEVELS_PACKED6 wherever the configuration allows it (else it falls back to bytes)
+            kw.update(gq_wire_levels="packed6")
+            if rng.random() < 0.7:
+                kw.update(k_bit=8, n_bit=int(rng.choice([2, 5, 6])))
+                codebook(16, 256)
         comp = NearestNeighborCompressor
     else:
         d = int(rng.choice([0, 128, 64, 512, 4098, 8192, 2]))
