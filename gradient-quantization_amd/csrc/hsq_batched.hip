@@ -232,7 +232,8 @@ __device__ __forceinline__ unsigned bt4_row_addr(unsigned c4, unsigned lane_cons
     return __builtin_amdgcn_perm(c4, lane_const, 0x0c0c0000u | ((4u + K4) << 8));
 }
 
-template <bool FIRST, bool PACKED6>
+typedef const f32x4 __attribute__((address_space(3))) bt4_lds_f32x4;
+template <bool FIRST, bool PACKED6, bool ABS0 = false>   // ABS0: the image starts at LDS address 0 (see dec16_payload)
 __device__ __forceinline__ void bt4_payload(f32x4 (&acc)[4], unsigned c4, unsigned l4, float lb, float ub, float inv_s, int q,
                                             const char *cb_bytes, unsigned lane_const) {
     const float range = ub - lb;
@@ -252,7 +253,8 @@ __device__ __forceinline__ void bt4_payload(f32x4 (&acc)[4], unsigned c4, unsign
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float n = n_team[k];
-        const f32x4 c = *reinterpret_cast<const f32x4 *>(cb_bytes + a[k]);
+        const f32x4 c = ABS0 ? *reinterpret_cast<bt4_lds_f32x4 *>((uintptr_t)a[k])
+                             : *reinterpret_cast<const f32x4 *>(cb_bytes + a[k]);
         const f32x4 n4 = {n, n, n, n};
         const f32x4 dec = c * n4;
         if constexpr (FIRST) {
@@ -335,6 +337,172 @@ __global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
                 *reinterpret_cast<f32x4 *>(o + 16 * k) = a;
             }
         }
+    }
+}
+
+// The same for a compile-time payload count R <= BT4_RMAX, software-pipelined across a wave's tiles like
+// hsq_decode_sum_d16u8_r_kernel (hsq_decode.hip): a wave's 64 items are exactly one tile, so the segment record of a tile
+// is wave-uniform -- it is fetched by scalar loads two tiles ahead, the (code, level) words and (lb, ub) of the NEXT tile
+// are re-requested into the registers of the payload just consumed, and the stores of a tile drain under the next
+// tile's arithmetic.  In the kernel above every item walks tile_seg -> segment record -> payload words -> stores as one
+// dependent chain per lane, behind the previous item's stores.
+constexpr int BT4_RMAX = 8;
+
+struct Bt4Tile {          // wave-uniform: where a tile's bytes are
+    uint64_t code_off;    // byte offset of the tile's first code inside a payload
+    uint64_t level_off;   // ... of its first level (byte or packed group)
+    uint64_t lbub_off;    // ... of the segment's (lb, ub)
+    int64_t out_off;      // float offset of the tile's first output
+    int left;             // subvectors of the segment from the tile's start on (>= 1), capped at 64
+};
+
+template <bool PACKED6>
+__device__ __forceinline__ Bt4Tile bt4_tile(const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t tile) {
+    const int seg = tile_seg[tile];
+    const int64_t *rec = seg_table + 8 * (int64_t)seg;
+    const int64_t local0 = (tile - rec[2]) * 64;
+    const int64_t left = rec[1] - local0;
+    Bt4Tile t;
+    t.code_off = (uint64_t)(rec[3] + local0);
+    t.level_off = (uint64_t)(rec[4] + (PACKED6 ? 3 * (local0 >> 2) : local0));
+    t.lbub_off = (uint64_t)rec[5];
+    t.out_off = rec[6] + local0 * 16;
+    t.left = left < 64 ? (int)left : 64;
+    return t;
+}
+
+// R >= BT4_R_NARROW: 16 word registers + 16 sums + the rows in flight do not fit the 64 registers of 8 waves per SIMD
+// (the compiler spilled 12-13 dwords per lane and trip); those run 768-thread workgroups, 6 waves per SIMD, 80 registers.
+#ifndef GQ_BT4_R_NARROW
+#define GQ_BT4_R_NARROW 7
+#endif
+constexpr int bt4r_threads(int R) { return R >= GQ_BT4_R_NARROW ? 768 : 1024; }
+constexpr int bt4r_waves(int R) { return R >= GQ_BT4_R_NARROW ? 6 : 8; }
+
+template <int R, bool PACKED6>
+__global__ __launch_bounds__(bt4r_threads(R)) __attribute__((amdgpu_waves_per_eu(bt4r_waves(R), bt4r_waves(R))))
+void hsq_decode_sum_batched4_r_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
+    const uint8_t *__restrict__ gathered, int64_t user_stride, const float *__restrict__ cb, int n_bit,
+    float *__restrict__ out, int plain) {
+    extern __shared__ float s_cb4[];   // [256][4 copies][16] at LDS address 0 (bt4_payload<.., ABS0>)
+    constexpr int THREADS = bt4r_threads(R);
+    for (int i = threadIdx.x; i < 256 * 16; i += THREADS) {   // (row, copy, quarter)
+        const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
+        *reinterpret_cast<f32x4 *>(s_cb4 + row * 64 + c * 16 + 4 * q) = *reinterpret_cast<const f32x4 *>(cb + row * 16 + 4 * q);
+    }
+    __syncthreads();
+    const float inv_s = 1.0f / (float)(1 << n_bit);
+    const MeanDiv md = mean_div_of(R, !plain);
+    const int q = threadIdx.x & 3;
+    const unsigned lane_const = (unsigned)(((threadIdx.x >> 3) & 3) * 64 + 16 * q);
+    const char *const cb_bytes = reinterpret_cast<const char *>(s_cb4);
+    const unsigned g = (unsigned)(threadIdx.x & 63) & ~3u;   // this lane's first subvector inside a tile
+    const unsigned out_lane = (g * 16 + 4 * q) * 4;          // bytes
+    // one tile per wave and trip; the wave's tile number is uniform by construction, told to the compiler
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6)));
+    const int64_t wstride = (int64_t)gridDim.x * (THREADS / 64);
+    typedef const uint8_t __attribute__((address_space(1))) gbyte;
+    typedef const unsigned __attribute__((address_space(1))) gword;
+    typedef const unsigned __attribute__((address_space(1), aligned(1))) gword_any;   // packed levels start at any byte
+    const uint64_t wire0 = reinterpret_cast<uint64_t>(gathered);
+    unsigned c4[R], l4[R];
+    float lb[R], ub[R];
+    // requests of tile t for payload r: (scalar base) + (32-bit lane offset) loads; lanes past the segment's end re-read
+    // the tile's first group
+    auto request = [&](const Bt4Tile &t, unsigned gl, int r) {
+        const uint64_t base = wire0 + (uint64_t)r * (uint64_t)user_stride;
+        c4[r] = *reinterpret_cast<gword *>(reinterpret_cast<gbyte *>(base + t.code_off) + gl);
+        l4[r] = PACKED6 ? (unsigned)*reinterpret_cast<gword_any *>(reinterpret_cast<gbyte *>(base + t.level_off) + 3u * (gl >> 2))
+                        : *reinterpret_cast<gword *>(reinterpret_cast<gbyte *>(base + t.level_off) + gl);
+        const float *lbub = reinterpret_cast<const float *>(gathered + (int64_t)r * user_stride + (int64_t)t.lbub_off);
+        lb[r] = lbub[0];
+        ub[r] = lbub[1];
+    };
+    int64_t tile = wave0;
+    if (tile >= ntiles) return;
+    Bt4Tile cur = bt4_tile<PACKED6>(seg_table, tile_seg, tile);
+    int64_t tn = tile + wstride < ntiles ? tile + wstride : tile;
+    Bt4Tile nxt = bt4_tile<PACKED6>(seg_table, tile_seg, tn);
+    {
+        const unsigned gl = (int)g < cur.left ? g : 0u;
+#pragma unroll
+        for (int r = 0; r < R; ++r) request(cur, gl, r);
+    }
+    while (true) {
+        const int64_t t2 = tn + wstride < ntiles ? tn + wstride : tn;
+        const Bt4Tile aft = bt4_tile<PACKED6>(seg_table, tile_seg, t2);   // scalar loads, two tiles ahead
+        unsigned gl = (int)g < nxt.left ? g : 0u;
+        f32x4 acc[4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (r == 0)
+                bt4_payload<true, PACKED6, true>(acc, c4[r], l4[r], lb[r], ub[r], inv_s, q, cb_bytes, lane_const);
+            else
+                bt4_payload<false, PACKED6, true>(acc, c4[r], l4[r], lb[r], ub[r], inv_s, q, cb_bytes, lane_const);
+            // keep each re-request behind the payload it replaces (hoisted to the top of the trip, the new words were
+            // spilled until their registers came free): the lane offset is made to "depend" on the payload's last sum.
+            // No instruction; a sched_barrier or a volatile asm counts as a store and turns the scalar (lb, ub) loads into vector loads
+            asm("" : "+v"(gl) : "v"(acc[3][3]));
+            request(nxt, gl, r);
+        }
+        if (md.apply) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[k][0] = mean_div(acc[k][0], md);
+                acc[k][1] = mean_div(acc[k][1], md);
+                acc[k][2] = mean_div(acc[k][2], md);
+                acc[k][3] = mean_div(acc[k][3], md);
+            }
+        }
+        f32x4 *o = reinterpret_cast<f32x4 *>(out + cur.out_off + (out_lane >> 2));   // through `out` itself: a pointer rebuilt from an
+                                                                                   // integer may alias the wire as far as the compiler knows,
+                                                                                   // and the uniform (lb, ub) loads stop being scalar loads
+        if (cur.left == 64) {   // wave-uniform: the whole tile belongs to the segment
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[4 * k] = acc[k];
+        } else {
+            const int nv = cur.left - (int)g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nv) o[4 * k] = acc[k];
+        }
+        if (tile + wstride >= ntiles) break;
+        tile += wstride;
+        cur = nxt;
+        nxt = aft;
+        tn = t2;
+    }
+}
+
+template <int R, bool P6>
+static void launch_bt4_r(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
+                         int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st) {
+    static const int bpc = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_batched4_r_kernel<R, P6>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipGetLastError();
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hsq_decode_sum_batched4_r_kernel<R, P6>, bt4r_threads(R),
+                                                         (size_t)64 * 1024) != hipSuccess || n < 1)
+            n = 1;
+        return n;
+    }();
+    int64_t blocks = (ntiles * 64 + bt4r_threads(R) - 1) / bt4r_threads(R);
+    if (blocks > (int64_t)cu_count() * bpc) blocks = (int64_t)cu_count() * bpc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched4_r_kernel<R, P6>), dim3((unsigned)blocks), dim3(bt4r_threads(R)),
+                       (size_t)64 * 1024, st, seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain);
+}
+
+template <bool P6>
+static bool launch_bt4_fixed_r(int R, const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
+                               int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st) {
+    switch (R) {
+#define GQ_BT4_CASE(N) case N: launch_bt4_r<N, P6>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st); return true;
+        GQ_BT4_CASE(1) GQ_BT4_CASE(2) GQ_BT4_CASE(3) GQ_BT4_CASE(4)
+        GQ_BT4_CASE(5) GQ_BT4_CASE(6) GQ_BT4_CASE(7) GQ_BT4_CASE(8)
+#undef GQ_BT4_CASE
+        default: return false;
     }
 }
 
@@ -629,6 +797,13 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_d16(const int64_t *seg_table, const i
                 n = 1;
             return n;
         }();
+        if (packed6 ? gq::launch_bt4_fixed_r<true>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, n_bit, out,
+                                                   plain, gq::as_stream(stream))
+                    : gq::launch_bt4_fixed_r<false>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, n_bit,
+                                                    out, plain, gq::as_stream(stream))) {
+            GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched");
+            return GQ_OK;
+        }
         int64_t blocks = (ntiles * 64 + gq::BT4_THREADS - 1) / gq::BT4_THREADS;
         if (blocks > (int64_t)gq::cu_count() * bpc) blocks = (int64_t)gq::cu_count() * bpc;
         if (packed6)
