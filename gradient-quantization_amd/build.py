@@ -39,7 +39,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != "gq_host.cpp"] + [os.path.join(ROOT, "include", "gq_hsq.h"), __file__]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "gq_hsq.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -55,32 +55,7 @@ EXTRA = {
 }
 
 
-HOST_SRC = os.path.join(CSRC, "gq_host.cpp")
-HOST_LIB = os.path.join(HERE, "gq_amd", "_gq_host.so")
-
-
-def build_host(force=False, verbose=False):
-    """gq_amd/_gq_host.so: the per-parameter host loops of the quantizer step in C++ (a torch extension, g++ only).
-    Optional: gq_amd.quantizers falls back to its Python loops without it."""
-    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= max(os.path.getmtime(HOST_SRC), os.path.getmtime(__file__)):
-        return HOST_LIB
-    import sysconfig
-    import torch
-    from torch.utils import cpp_extension
-    inc = cpp_extension.include_paths() + [sysconfig.get_paths()["include"]]
-    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
-    cmd = (["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-DTORCH_EXTENSION_NAME=_gq_host",
-            "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
-           + ["-isystem" + i for i in inc] + [HOST_SRC, "-o", HOST_LIB, "-L" + libdir, "-Wl,-rpath," + libdir,
-                                              "-lc10", "-ltorch_cpu", "-ltorch", "-ltorch_python"])
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return HOST_LIB
-
-
 def build(force=False, verbose=False):
-    build_host(force, verbose)
     if not force and not needs_build():
         return LIB
     objdir = os.path.join(HERE, "build")
