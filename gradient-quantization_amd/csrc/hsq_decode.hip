@@ -389,6 +389,142 @@ void hsq_decode_sum_d16u8_r_kernel(
     }
 }
 
+// Any R above DEC16_RMAX with the same pipelining, in chunks of DEC16_RMAX payloads: the words of (item, chunk) sit in
+// registers, each pair is re-requested for the NEXT chunk -- of the same item, or the first chunk of the wave's next item --
+// as soon as it has been consumed.  Every trip of the chunk loop issues its 2 x DEC16_RMAX loads unconditionally (a chunk
+// with fewer payloads re-reads its last one), so the compiler's vmcnt bookkeeping stays exact and no wait lands on the
+// previous item's stores.  The sums start from +0: only reached with R > 1, where the mean adds +0 anyway (mean_div).
+template <bool PACKED6>
+__global__ __launch_bounds__(DEC16_THREADS) __attribute__((amdgpu_waves_per_eu(GQ_DEC16R_WAVES, GQ_DEC16R_WAVES)))
+void hsq_decode_sum_d16u8_rc_kernel(
+    const uint8_t *__restrict__ codes, const uint8_t *__restrict__ levels, const float *__restrict__ lb_ub,
+    int64_t code_stride, int64_t level_stride, int64_t lbub_stride, const float *__restrict__ cb, int R, int64_t M, int K,
+    int n_bit, float *__restrict__ out) {
+    constexpr int C = DEC16_RMAX;
+    extern __shared__ float s_cb[];   // [K][4 copies][16] at LDS address 0, then (lb, ub - lb) of the R payloads
+    for (int i = threadIdx.x; i < K * 16; i += DEC16_THREADS) {   // (row, copy, quarter)
+        const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
+        *reinterpret_cast<f32x4 *>(s_cb + row * 64 + c * 16 + 4 * q) = *reinterpret_cast<const f32x4 *>(cb + row * 16 + 4 * q);
+    }
+    float2 *const s_lbub = reinterpret_cast<float2 *>(s_cb + K * 64);
+    for (int r = threadIdx.x; r < R; r += DEC16_THREADS) {
+        const float lb = lb_ub[r * lbub_stride];
+        s_lbub[r] = make_float2(lb, lb_ub[r * lbub_stride + 1] - lb);
+    }
+    __syncthreads();
+    const float inv_s = 1.0f / (float)(1 << (n_bit & 31));
+    const MeanDiv md = mean_div_of(R);
+    const int q = threadIdx.x & 3;
+    const unsigned lane_const = (unsigned)(((threadIdx.x >> 3) & 3) * 64 + 16 * q);
+    const char *const cb_bytes = reinterpret_cast<const char *>(s_cb);
+    const unsigned full = (unsigned)(M >> 2) * 4u;
+    const unsigned stride = gridDim.x * DEC16_THREADS;
+    const int nchunks = (R + C - 1) / C;
+    typedef const uint8_t __attribute__((address_space(1))) gbyte;
+    typedef unsigned __attribute__((aligned(1))) word_any;
+    auto ldw = [](gbyte *p) {
+        return PACKED6 ? (unsigned)*reinterpret_cast<const word_any __attribute__((address_space(1))) *>(p)
+                       : *reinterpret_cast<const unsigned __attribute__((address_space(1))) *>(p);
+    };
+    const uint64_t codes0 = reinterpret_cast<uint64_t>(codes), levels0 = reinterpret_cast<uint64_t>(levels);
+    unsigned c4[C], l4[C];
+    // requests for slot jj of chunk `chunk` of item `item` (payload min(chunk * C + jj, R - 1))
+    auto request = [&](unsigned item, int chunk, int jj) {
+        const unsigned off = item & ~3u, loff = PACKED6 ? 3u * (item >> 2) : off;
+        int r = chunk * C + jj;
+        r = r < R ? r : R - 1;
+        c4[jj] = ldw(reinterpret_cast<gbyte *>(codes0 + (uint64_t)r * (uint64_t)code_stride) + off);
+        l4[jj] = ldw(reinterpret_cast<gbyte *>(levels0 + (uint64_t)r * (uint64_t)level_stride) + loff);
+    };
+    unsigned i = blockIdx.x * DEC16_THREADS + threadIdx.x;
+    if (i < full) {
+#pragma unroll
+        for (int jj = 0; jj < C; ++jj) request(i, 0, jj);
+    }
+    while (i < full) {
+        const unsigned nxt = i + stride;
+        const unsigned pre = nxt < full ? nxt : i;
+        f32x4 acc[4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const bool last = chunk + 1 == nchunks;
+            const unsigned ni = last ? pre : i;
+            const int nc = last ? 0 : chunk + 1;
+#pragma unroll
+            for (int jj = 0; jj < C; ++jj) {
+                const int r = chunk * C + jj;
+                if (r < R) {
+                    const float2 lr = s_lbub[r];
+                    dec16_payload<false, PACKED6, true>(acc, c4[jj], l4[jj], lr.x, lr.y, inv_s, q, cb_bytes, lane_const);
+                }
+                request(ni, nc, jj);
+            }
+        }
+        float *o = out + (int64_t)(i & ~3u) * 16 + 4 * q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x4 a = acc[k];
+            a[0] = mean_div(a[0], md);
+            a[1] = mean_div(a[1], md);
+            a[2] = mean_div(a[2], md);
+            a[3] = mean_div(a[3], md);
+            *reinterpret_cast<f32x4 *>(o + 16 * k) = a;
+        }
+        i = nxt;
+    }
+    const int nv = (int)(M & 3);   // the last, partial group (byte loads), by the first team of workgroup 0
+    if (nv != 0 && blockIdx.x == 0 && threadIdx.x < 4) {
+        const int64_t m0 = (int64_t)full;
+        f32x4 acc[4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll 1
+        for (int r = 0; r < R; ++r) {
+            const uint8_t *cp = codes + (int64_t)r * code_stride + m0;
+            const uint8_t *lp = levels + (int64_t)r * level_stride + (PACKED6 ? 3 * (m0 >> 2) : m0);
+            unsigned c = 0, l = 0;
+            for (int k = 0; k < nv; ++k) c |= (unsigned)cp[k] << (8 * k);
+            if (PACKED6) {
+                l = (unsigned)lp[0] | ((unsigned)lp[1] << 8) | ((unsigned)lp[2] << 16);
+            } else {
+                for (int k = 0; k < nv; ++k) l |= (unsigned)lp[k] << (8 * k);
+            }
+            const float2 lr = s_lbub[r];
+            dec16_payload<false, PACKED6, true>(acc, c, l, lr.x, lr.y, inv_s, q, cb_bytes, lane_const);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < nv) {
+                f32x4 a = acc[k];
+                a[0] = mean_div(a[0], md);
+                a[1] = mean_div(a[1], md);
+                a[2] = mean_div(a[2], md);
+                a[3] = mean_div(a[3], md);
+                *reinterpret_cast<f32x4 *>(out + (m0 + k) * 16 + 4 * q) = a;
+            }
+        }
+    }
+}
+
+constexpr int DEC16_RC_MAX = 1024;   // payloads whose (lb, ub - lb) fit behind the codebook image (8 KB)
+
+template <bool P6>
+static void launch_dec16_rc(int R, const uint8_t *codes, const uint8_t *levels, const float *lb_ub, int64_t cs, int64_t ls,
+                            int64_t bs, const float *cb, int64_t M, int K, int n_bit, float *out, hipStream_t st) {
+    static const int bpc = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_d16u8_rc_kernel<P6>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 8 * DEC16_RC_MAX);
+        (void)hipGetLastError();
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hsq_decode_sum_d16u8_rc_kernel<P6>, DEC16_THREADS,
+                                                         (size_t)256 * 64 * sizeof(float) + 8 * 64) != hipSuccess || n < 1)
+            n = 1;
+        return n;
+    }();
+    const int64_t total = ((M + 3) >> 2) * 4;
+    int64_t blocks = (total + DEC16_THREADS - 1) / DEC16_THREADS;
+    if (blocks > (int64_t)cu_count() * bpc) blocks = (int64_t)cu_count() * bpc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_d16u8_rc_kernel<P6>), dim3((unsigned)blocks), dim3(DEC16_THREADS),
+                       (size_t)K * 64 * sizeof(float) + 8 * (size_t)R, st, codes, levels, lb_ub, cs, ls, bs, cb, R, M, K, n_bit, out);
+}
+
 template <int R, bool P6>
 static void launch_dec16_r(const uint8_t *codes, const uint8_t *levels, const float *lb_ub, int64_t cs, int64_t ls, int64_t bs,
                            const float *cb, int64_t M, int K, int n_bit, float *out, hipStream_t st) {
@@ -418,7 +554,10 @@ static bool launch_dec16_fixed_r(int R, const uint8_t *codes, const uint8_t *lev
         GQ_DEC16_CASE(1) GQ_DEC16_CASE(2) GQ_DEC16_CASE(3) GQ_DEC16_CASE(4)
         GQ_DEC16_CASE(5) GQ_DEC16_CASE(6) GQ_DEC16_CASE(7) GQ_DEC16_CASE(8)
 #undef GQ_DEC16_CASE
-        default: return false;
+        default:
+            if (R > DEC16_RC_MAX) return false;
+            launch_dec16_rc<P6>(R, codes, levels, lb_ub, cs, ls, bs, cb, M, K, n_bit, out, st);
+            return true;
     }
 }
 

@@ -187,7 +187,8 @@ def test_cpu_twins_packed6_levels_decode_like_byte_levels(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_bit,random,R,M", [(6, 0, 1, 64 * 97 + 13), (6, 0, 8, 100003), (5, 1, 3, 4098), (2, 0, 2, 7), (6, 0, 4, 256)])
+@pytest.mark.parametrize("n_bit,random,R,M", [(6, 0, 1, 64 * 97 + 13), (6, 0, 8, 100003), (5, 1, 3, 4098), (2, 0, 2, 7), (6, 0, 4, 256),
+                                               (6, 0, 12, 4099), (6, 0, 3, 1_200_001), (4, 0, 17, 530_000)])
 def test_packed6_levels_on_the_hip_library_and_on_the_cpu_twins(n_bit, random, R, M):
     """The same ctypes calls with level_bytes = GQ_LEVELS_PACKED6 on both libraries: packed section and decoded mean
     byte-identical (d = 16, K = 256)."""

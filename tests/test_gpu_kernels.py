@@ -226,11 +226,13 @@ def test_hsq_device_rng_is_stochastic_rounding(nat, oracle):
     assert not torch.equal(res["levels"], res3["levels"])
 
 
-@pytest.mark.parametrize("R", [1, 2, 3, 8])
-def test_hsq_decode_sum_matches_oracle_mean(nat, oracle, R):
+@pytest.mark.parametrize("R,M", [(1, 3000), (2, 3000), (3, 3000), (8, 3000), (5, 3001), (7, 2999), (9, 3000), (16, 3002),
+                                 (19, 3003), (2, 1_100_003), (8, 600_001), (11, 600_002)])
+def test_hsq_decode_sum_matches_oracle_mean(nat, oracle, R, M):
+    """R <= 8: the fixed-R pipelined kernels; above: the chunked one; M % 4 != 0: the partial last group; the large M give
+    every lane several items (the words of the next item are requested while the current one is summed)."""
     rng = np.random.RandomState(40 + R)
     cb = _cb(16, 256)
-    M = 3000
     dev = torch.device("cuda:0")
     codes, levels, lbub, decs = [], [], [], []
     for r in range(R):
