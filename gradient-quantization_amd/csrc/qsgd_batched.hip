@@ -380,11 +380,202 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_kernel(
     }
 }
 
+// The same for a compile-time payload count R <= QB4_RMAX and a segment table that fits in LDS, software-pipelined across
+// a wave's items like hsq_decode_sum_d16u8_r_kernel (hsq_decode.hip): the kernel above walks bucket -> segment record ->
+// (norm, code word) of payload 0 .. R-1 as one chain of dependent round trips per item, each behind the previous item's
+// stores.  Here an item's R (code word, norm) pairs live in registers and each pair is re-requested for the wave's NEXT
+// item right after it has been consumed, the bucket -> segment word is fetched two items ahead and the record comes from
+// the LDS copy of the table.  Buckets wider than 128 elements (more than one 8-element unit per lane) and widths that are
+// not a multiple of 8 finish through the plain code inside the item.
+constexpr int QB4_RMAX = 8;
+
+template <int R>
+__global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_r_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int nseg, int n_bit,
+    const uint8_t *__restrict__ gathered, int64_t user_stride, float *__restrict__ out, int plain) {
+    __shared__ int64_t s_seg[QB_LDS_SEGS * 8];
+    for (int i = threadIdx.x; i < nseg * 8; i += QB_THREADS) s_seg[i] = seg_table[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, sub = lane >> 4, c0 = lane & 15;
+    const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
+    const float inv_s = 1.0f / (float)(1 << n_bit);
+    const MeanDiv md = mean_div_of(R, !plain);
+    const int64_t nquads = (nbuckets + 3) >> 2;
+    typedef const uint8_t __attribute__((address_space(1))) gbyte;
+    typedef const unsigned __attribute__((address_space(1))) gword;
+    typedef const float __attribute__((address_space(1))) gfloat;
+    const uint64_t wire0 = reinterpret_cast<uint64_t>(gathered);
+    struct Item {
+        unsigned norm_off, code_off;   // bytes inside one payload: this bucket's norm, this lane's code word
+        int64_t out_off;               // floats: this lane's first output
+        int64_t lb;                    // bucket index inside its tensor
+        int d;                         // bucket width
+        int seg;
+    };
+    auto bucket_of = [&](int64_t qd) {   // lanes past the last bucket redo it (nothing is stored for them)
+        const int64_t b = 4 * qd + sub;
+        return b < nbuckets ? b : nbuckets - 1;
+    };
+    auto item_of = [&](int64_t b, int seg) {
+        const int64_t *rec = s_seg + 8 * seg;
+        Item it;
+        it.seg = seg;
+        it.d = (int)rec[1];
+        it.lb = b - rec[2];
+        it.norm_off = (unsigned)(rec[3] + 4 * it.lb);
+        it.code_off = (unsigned)(rec[4] + ((it.lb * it.d) >> 1) + 4 * c0);
+        it.out_off = rec[5] + it.lb * it.d + 8 * c0;
+        return it;
+    };
+    unsigned w[R];
+    float nm[R];
+    auto request = [&](const Item &it, unsigned guard, int r) {
+        const uint64_t base = wire0 + (uint64_t)r * (uint64_t)user_stride;
+        // a lane without a unit in this bucket (8 * c0 >= d) reads the bucket's first word instead of one past its codes
+        const unsigned co = (8 * c0 < it.d ? it.code_off : it.code_off - 4u * (unsigned)c0) + guard;
+        w[r] = *reinterpret_cast<gword *>(reinterpret_cast<gbyte *>(base) + co);
+        nm[r] = *reinterpret_cast<gfloat *>(reinterpret_cast<gbyte *>(base) + (it.norm_off + guard));
+    };
+    int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6);
+    if (qd >= nquads) return;
+    int64_t qn = qd + nw < nquads ? qd + nw : qd;
+    Item cur = item_of(bucket_of(qd), bucket_seg[bucket_of(qd)]);
+    int seg_n = bucket_seg[bucket_of(qn)];
+#pragma unroll
+    for (int r = 0; r < R; ++r) request(cur, 0u, r);
+    while (true) {
+        const int64_t q2 = qn + nw < nquads ? qn + nw : qn;
+        const int seg_2 = bucket_seg[bucket_of(q2)];            // consumed a whole item later
+        const Item nxt = item_of(bucket_of(qn), seg_n);
+        const bool mine = 4 * qd + sub < nbuckets;
+        f32x4 acc[2];
+        unsigned guard = 0;
+        auto payload = [&](unsigned ww, float norm, auto first) {
+            const unsigned nw_ = ~ww;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float lf = (float)((ww >> (4 * k)) & 7u);
+                const unsigned sgn = (nw_ >> (4 * k + 3)) & 1u;          // 1: negative
+                float t = __uint_as_float(__float_as_uint(lf) | (sgn << 31));
+                t = t * norm;
+                t = t * inv_s;
+                if constexpr (decltype(first)::value) {
+                    acc[k >> 2][k & 3] = t;
+                } else {
+                    acc[k >> 2][k & 3] = acc[k >> 2][k & 3] + t;
+                }
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (r == 0)
+                payload(w[r], nm[r], std::true_type{});
+            else
+                payload(w[r], nm[r], std::false_type{});
+            // each re-request stays behind the payload it replaces: its offset "depends" on the payload's last sum
+            // (an empty non-volatile asm: no instruction, and not a store as far as the compiler's alias analysis goes)
+            asm("" : "+v"(guard) : "v"(acc[1][3]));
+            request(nxt, guard, r);
+        }
+        if (md.apply) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k >> 2][k & 3] = mean_div(acc[k >> 2][k & 3], md);
+        }
+        float *o = out + cur.out_off;
+        if ((cur.d & 7) == 0) {
+            if (mine && 8 * c0 < cur.d) {
+                *reinterpret_cast<f32x4 *>(o) = acc[0];
+                *reinterpret_cast<f32x4 *>(o + 4) = acc[1];
+            }
+            if (cur.d > 128 && mine) {   // further units of a wide bucket: the plain form
+                for (int c = c0 + 16; 8 * c < cur.d; c += 16) {
+                    f32x4 a2[2];
+                    for (int r = 0; r < R; ++r) {
+                        const uint8_t *p = gathered + (int64_t)r * user_stride;
+                        const float norm = *reinterpret_cast<const float *>(p + cur.norm_off);
+                        const unsigned ww = *reinterpret_cast<const unsigned *>(p + cur.code_off + 4 * (c - c0));
+                        const unsigned nw_ = ~ww;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float lf = (float)((ww >> (4 * k)) & 7u);
+                            const unsigned sgn = (nw_ >> (4 * k + 3)) & 1u;
+                            float t = __uint_as_float(__float_as_uint(lf) | (sgn << 31));
+                            t = t * norm;
+                            t = t * inv_s;
+                            a2[k >> 2][k & 3] = r == 0 ? t : a2[k >> 2][k & 3] + t;
+                        }
+                    }
+                    if (md.apply) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) a2[k >> 2][k & 3] = mean_div(a2[k >> 2][k & 3], md);
+                    }
+                    *reinterpret_cast<f32x4 *>(o + 8 * (c - c0)) = a2[0];
+                    *reinterpret_cast<f32x4 *>(o + 8 * (c - c0) + 4) = a2[1];
+                }
+            }
+        } else if (mine) {   // odd bucket widths: an element pair (one byte) at a time, as in the kernel above
+            const int64_t code0 = (int64_t)cur.code_off - 4 * c0;
+            float *ob = o - 8 * c0;
+            for (int e = 2 * c0; e < cur.d; e += 32) {
+                float a0 = 0.0f, a1 = 0.0f;
+                for (int r = 0; r < R; ++r) {
+                    const uint8_t *p = gathered + (int64_t)r * user_stride;
+                    const float norm = *reinterpret_cast<const float *>(p + cur.norm_off);
+                    const unsigned byte = p[code0 + (e >> 1)];
+                    const unsigned c0_ = byte & 15u, c1_ = byte >> 4;
+                    float t0 = (float)(c0_ & 7u) * (2.0f * (float)(c0_ >> 3) - 1.0f);
+                    float t1 = (float)(c1_ & 7u) * (2.0f * (float)(c1_ >> 3) - 1.0f);
+                    t0 = t0 * norm;
+                    t1 = t1 * norm;
+                    t0 = t0 * inv_s;
+                    t1 = t1 * inv_s;
+                    a0 = (r == 0) ? t0 : a0 + t0;
+                    a1 = (r == 0) ? t1 : a1 + t1;
+                }
+                if (md.apply) {
+                    a0 = mean_div(a0, md);
+                    a1 = mean_div(a1, md);
+                }
+                *reinterpret_cast<float2 *>(ob + e) = make_float2(a0, a1);
+            }
+        }
+        if (qd + nw >= nquads) break;
+        qd += nw;
+        cur = nxt;
+        qn = q2;
+        seg_n = seg_2;
+    }
+}
+
+template <int R>
+static void launch_qb4_r(const int64_t *seg_table, const int32_t *bucket_seg, int64_t nbuckets, int nseg, int n_bit,
+                         const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st);
+
 static inline int64_t qb_grid(int64_t nbuckets) {
     int64_t blocks = (nbuckets + (QB_THREADS / 64) - 1) / (QB_THREADS / 64);
     const int64_t cap = (int64_t)cu_count() * 8;
     if (blocks > cap) blocks = cap;
     return blocks < 1 ? 1 : blocks;
+}
+
+template <int R>
+static void launch_qb4_r(const int64_t *seg_table, const int32_t *bucket_seg, int64_t nbuckets, int nseg, int n_bit,
+                         const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_decode_sum_batched4_r_kernel<R>), dim3((unsigned)qb_grid((nbuckets + 3) / 4)),
+                       dim3(QB_THREADS), 0, st, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride, out, plain);
+}
+
+static bool launch_qb4_fixed_r(int R, const int64_t *seg_table, const int32_t *bucket_seg, int64_t nbuckets, int nseg, int n_bit,
+                               const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st) {
+    // byte offsets inside a payload are 32-bit in this kernel, the table sits in LDS
+    if (nseg > QB_LDS_SEGS || user_stride >= ((int64_t)1 << 31)) return false;
+    switch (R) {
+#define GQ_QB4_CASE(N) case N: launch_qb4_r<N>(seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride, out, plain, st); return true;
+        GQ_QB4_CASE(1) GQ_QB4_CASE(2) GQ_QB4_CASE(3) GQ_QB4_CASE(4)
+        GQ_QB4_CASE(5) GQ_QB4_CASE(6) GQ_QB4_CASE(7) GQ_QB4_CASE(8)
+#undef GQ_QB4_CASE
+        default: return false;
+    }
 }
 
 }  // namespace gq
@@ -447,6 +638,11 @@ GQ_INTERNAL int gqi_qsgd_decode_sum_batched(const int64_t *seg_table, const int3
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: null pointer");
     if (bits == 4 && (user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        if (gq::launch_qb4_fixed_r(R, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride_bytes, out, plain,
+                                   gq::as_stream(stream))) {
+            GQ_CHECK_LAUNCH("gq_qsgd_decode_sum_batched");
+            return GQ_OK;
+        }
         hipLaunchKernelGGL(gq::qsgd_decode_sum_batched4_kernel, dim3((unsigned)gq::qb_grid((nbuckets + 3) / 4)),
                            dim3(gq::QB_THREADS), 0, gq::as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit,
                            gathered, user_stride_bytes, R, out, plain);
