@@ -506,3 +506,41 @@ def test_prefilter_fuzz_against_exact_kernels():
     assert "120 rounds, 0 mismatching" in r.stdout
 
 
+
+
+def test_compress_and_decode_replay_from_a_hip_graph(nat):
+    """The C ABI keeps no per-thread call state and its kernels reset their own counters: encode + levels + decode-mean
+    captured ONCE into a HIP graph (torch.cuda.graph: stream capture of the launches) give, on every replay with new
+    contents in the same input buffer, the bits of the eager calls."""
+    dev = torch.device("cuda:0")
+    cb = torch.from_numpy(_cb(16, 256)).to(dev)
+    M = 70_001
+    x = torch.empty(M * 16, dtype=torch.float32, device=dev)
+
+    def buffers():
+        return dict(codes=torch.empty(M, dtype=torch.uint8, device=dev), u=torch.empty(M, dtype=torch.float32, device=dev),
+                    ws=nat.new_workspace(dev, M), lb_ub=torch.empty(2, dtype=torch.float32, device=dev),
+                    levels=torch.empty(M, dtype=torch.uint8, device=dev), out=torch.empty(M * 16, dtype=torch.float32, device=dev))
+
+    def run(b):
+        nat.hsq_encode(x, cb, b["codes"], b["u"], b["ws"])
+        nat.hsq_levels(b["u"], 6, 0, None, 0, b["ws"], b["lb_ub"], b["levels"])
+        nat.hsq_decode_sum(b["codes"], b["levels"], b["lb_ub"], cb, 6, b["out"], R=1)
+
+    captured, eager = buffers(), buffers()
+    torch.manual_seed(5)
+    x.copy_(torch.randn(M * 16, device=dev))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):      # the first calls set kernel attributes: not inside a capture
+        run(captured)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run(captured)
+    for trial in range(3):
+        x.copy_(torch.randn(M * 16, device=dev) * (10.0 ** -trial))
+        graph.replay()
+        run(eager)
+        torch.cuda.synchronize()
+        for k in ("codes", "levels", "lb_ub", "out"):
+            assert torch.equal(captured[k].view(torch.uint8), eager[k].view(torch.uint8)), (trial, k)
