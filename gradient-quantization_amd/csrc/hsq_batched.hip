@@ -270,7 +270,7 @@ __global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
     float *__restrict__ out, int plain) {
-    extern __shared__ float s_cb4[];   // [256][4 copies][16]
+    extern __shared__ __attribute__((aligned(16))) float s_cb4[];   // [256][4 copies][16]
     for (int i = threadIdx.x; i < 256 * 16; i += BT4_THREADS) {   // (row, copy, quarter)
         const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
         *reinterpret_cast<f32x4 *>(s_cb4 + row * 64 + c * 16 + 4 * q) = *reinterpret_cast<const f32x4 *>(cb + row * 16 + 4 * q);
@@ -371,10 +371,10 @@ __device__ __forceinline__ Bt4Tile bt4_tile(const int64_t *__restrict__ seg_tabl
     return t;
 }
 
-// R >= BT4_R_NARROW: 16 word registers + 16 sums + the rows in flight do not fit the 64 registers of 8 waves per SIMD
+// R >= BT4_R_NARROW: 2R word registers + 16 sums + the rows in flight do not fit the 64 registers of 8 waves per SIMD
 // (the compiler spilled 12-13 dwords per lane and trip); those run 768-thread workgroups, 6 waves per SIMD, 80 registers.
 #ifndef GQ_BT4_R_NARROW
-#define GQ_BT4_R_NARROW 7
+#define GQ_BT4_R_NARROW 6
 #endif
 constexpr int bt4r_threads(int R) { return R >= GQ_BT4_R_NARROW ? 768 : 1024; }
 constexpr int bt4r_waves(int R) { return R >= GQ_BT4_R_NARROW ? 6 : 8; }
@@ -385,13 +385,8 @@ void hsq_decode_sum_batched4_r_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, const float *__restrict__ cb, int n_bit,
     float *__restrict__ out, int plain) {
-    extern __shared__ float s_cb4[];   // [256][4 copies][16] at LDS address 0 (bt4_payload<.., ABS0>)
+    extern __shared__ __attribute__((aligned(16))) float s_cb4[];   // [256][4 copies][16] at LDS address 0 (bt4_payload<.., ABS0>)
     constexpr int THREADS = bt4r_threads(R);
-    for (int i = threadIdx.x; i < 256 * 16; i += THREADS) {   // (row, copy, quarter)
-        const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
-        *reinterpret_cast<f32x4 *>(s_cb4 + row * 64 + c * 16 + 4 * q) = *reinterpret_cast<const f32x4 *>(cb + row * 16 + 4 * q);
-    }
-    __syncthreads();
     const float inv_s = 1.0f / (float)(1 << n_bit);
     const MeanDiv md = mean_div_of(R, !plain);
     const int q = threadIdx.x & 3;
@@ -419,8 +414,10 @@ void hsq_decode_sum_batched4_r_kernel(
         lb[r] = lbub[0];
         ub[r] = lbub[1];
     };
-    int64_t tile = wave0;
-    if (tile >= ntiles) return;
+    // the first tile's record and payload words are requested BEFORE the codebook image is staged: their round trips run
+    // under the staging.  (A wave without a tile still takes part in the barrier.)
+    const bool active = wave0 < ntiles;
+    int64_t tile = active ? wave0 : ntiles - 1;
     Bt4Tile cur = bt4_tile<PACKED6>(seg_table, tile_seg, tile);
     int64_t tn = tile + wstride < ntiles ? tile + wstride : tile;
     Bt4Tile nxt = bt4_tile<PACKED6>(seg_table, tile_seg, tn);
@@ -429,6 +426,23 @@ void hsq_decode_sum_batched4_r_kernel(
 #pragma unroll
         for (int r = 0; r < R; ++r) request(cur, gl, r);
     }
+    {
+        constexpr int STAGE = (256 * 16 + THREADS - 1) / THREADS;
+        f32x4 stage[STAGE];
+#pragma unroll
+        for (int n = 0; n < STAGE; ++n) {
+            const int e = threadIdx.x + n * THREADS;   // (row, copy, quarter)
+            if (e < 256 * 16) stage[n] = *reinterpret_cast<const f32x4 *>(cb + (e >> 4) * 16 + 4 * (e & 3));
+        }
+#pragma unroll
+        for (int n = 0; n < STAGE; ++n) {
+            const int e = threadIdx.x + n * THREADS;
+            const int row = e >> 4, c = (e >> 2) & 3, qq = e & 3;
+            if (e < 256 * 16) *reinterpret_cast<f32x4 *>(s_cb4 + row * 64 + c * 16 + 4 * qq) = stage[n];
+        }
+    }
+    __syncthreads();
+    if (!active) return;
     while (true) {
         const int64_t t2 = tn + wstride < ntiles ? tn + wstride : tn;
         const Bt4Tile aft = bt4_tile<PACKED6>(seg_table, tile_seg, t2);   // scalar loads, two tiles ahead

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_v4_kernel(
     const CodeT *__restrict__ codes, const LevelT *__restrict__ levels, const float *__restrict__ lb_ub,
     int64_t code_stride, int64_t level_stride, int64_t lbub_stride, const float *__restrict__ cb, int R, int64_t M,
     int d, int K, int n_bit, float *__restrict__ out) {
-    extern __shared__ float s_cb[];
+    extern __shared__ __attribute__((aligned(16))) float s_cb[];
     if (LDS_CB) {
         const int rs = cb_row_stride(d);
         for (int i = threadIdx.x; i < K * d; i += DEC_THREADS) s_cb[(i / d) * rs + (i % d)] = cb[i];
@@ -155,7 +155,7 @@ void hsq_decode_sum_d16u8_kernel(
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ levels, const float *__restrict__ lb_ub,
     int64_t code_stride, int64_t level_stride, int64_t lbub_stride, const float *__restrict__ cb, int R, int64_t M,
     int K, int n_bit, float *__restrict__ out) {
-    extern __shared__ float s_cb[];   // [K][4 copies][16]
+    extern __shared__ __attribute__((aligned(16))) float s_cb[];   // [K][4 copies][16]
     for (int i = threadIdx.x; i < K * 16; i += DEC16_THREADS) {   // (row, copy, quarter)
         const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
         *reinterpret_cast<f32x4 *>(s_cb + row * 64 + c * 16 + 4 * q) = *reinterpret_cast<const f32x4 *>(cb + row * 16 + 4 * q);
@@ -272,24 +272,9 @@ void hsq_decode_sum_d16u8_r_kernel(
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ levels, const float *__restrict__ lb_ub,
     int64_t code_stride, int64_t level_stride, int64_t lbub_stride, const float *__restrict__ cb, int64_t M, int K,
     int n_bit, float *__restrict__ out) {
-    extern __shared__ float s_cb[];   // [K][4 copies][16] at LDS address 0: a row address is the v_perm_b32 result itself
-    for (int i = threadIdx.x; i < K * 16; i += DEC16_THREADS) {   // (row, copy, quarter)
-        const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
-        *reinterpret_cast<f32x4 *>(s_cb + row * 64 + c * 16 + 4 * q) = *reinterpret_cast<const f32x4 *>(cb + row * 16 + 4 * q);
-    }
-    float lb[R], range[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float l = lb_ub[r * lbub_stride], u = lb_ub[r * lbub_stride + 1];
-        lb[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, l)));
-        range[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, u - l)));
-    }
-    __syncthreads();
-    const float inv_s = 1.0f / (float)(1 << (n_bit & 31));
-    const MeanDiv md = mean_div_of(R);
-    const int q = threadIdx.x & 3;
-    const unsigned lane_const = (unsigned)(((threadIdx.x >> 3) & 3) * 64 + 16 * q);
-    const char *const cb_bytes = reinterpret_cast<const char *>(s_cb);
+    extern __shared__ __attribute__((aligned(16))) float s_cb[];   // [K][4 copies][16] at LDS address 0: a row address is the v_perm_b32 result itself
+    // Everything the workgroup needs before its first sum is requested up front, the first item's payload words first:
+    // their trip to HBM then runs under the staging of the codebook image.
     const unsigned full = (unsigned)(M >> 2) * 4u;   // items of whole groups; M < 2^31 - 2^21 (launcher): 32-bit item numbers
     const unsigned stride = gridDim.x * DEC16_THREADS;
     unsigned i = blockIdx.x * DEC16_THREADS + threadIdx.x;
@@ -323,35 +308,34 @@ void hsq_decode_sum_d16u8_r_kernel(
         }
     };
     if (i < full) request(i);
-    while (i < full) {
-        const unsigned nxt = i + stride;
-        const unsigned pre = nxt < full ? nxt : i;   // the last item re-requests itself: no branch around the loads
-        const unsigned poff = pre & ~3u, ploff = PACKED6 ? 3u * (pre >> 2) : poff;
-        f32x4 acc[4];
+    constexpr int STAGE = 256 * 16 / DEC16_THREADS;   // K <= 256 rows of four 16-byte quarters
+    f32x4 stage[STAGE];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (r == 0)
-                dec16_payload<true, PACKED6, true>(acc, c4[r], l4[r], lb[r], range[r], inv_s, q, cb_bytes, lane_const);
-            else
-                dec16_payload<false, PACKED6, true>(acc, c4[r], l4[r], lb[r], range[r], inv_s, q, cb_bytes, lane_const);
-            c4[r] = ldw(cbase[r] + poff);
-            l4[r] = ldw(lbase[r] + ploff);
-        }
-        float *o = out + (int64_t)(i & ~3u) * 16 + 4 * q;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            f32x4 a = acc[k];
-            if (md.apply) {
-                a[0] = mean_div(a[0], md);
-                a[1] = mean_div(a[1], md);
-                a[2] = mean_div(a[2], md);
-                a[3] = mean_div(a[3], md);
-            }
-            *reinterpret_cast<f32x4 *>(o + 16 * k) = a;
-        }
-        i = nxt;
+    for (int n = 0; n < STAGE; ++n) {
+        const int e = threadIdx.x + n * DEC16_THREADS;   // (row, copy, quarter)
+        if (e < K * 16) stage[n] = *reinterpret_cast<const f32x4 *>(cb + (e >> 4) * 16 + 4 * (e & 3));
     }
-    // the last, partial group of a tensor whose M is not a multiple of 4 (byte loads), by the first team of workgroup 0
+    float lb[R], range[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float l = lb_ub[r * lbub_stride], u = lb_ub[r * lbub_stride + 1];
+        lb[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, l)));
+        range[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, u - l)));
+    }
+#pragma unroll
+    for (int n = 0; n < STAGE; ++n) {
+        const int e = threadIdx.x + n * DEC16_THREADS;
+        const int row = e >> 4, c = (e >> 2) & 3, q = e & 3;
+        if (e < K * 16) *reinterpret_cast<f32x4 *>(s_cb + row * 64 + c * 16 + 4 * q) = stage[n];
+    }
+    __syncthreads();
+    const float inv_s = 1.0f / (float)(1 << (n_bit & 31));
+    const MeanDiv md = mean_div_of(R);
+    const int q = threadIdx.x & 3;
+    const unsigned lane_const = (unsigned)(((threadIdx.x >> 3) & 3) * 64 + 16 * q);
+    const char *const cb_bytes = reinterpret_cast<const char *>(s_cb);
+    // the last, partial group of a tensor whose M is not a multiple of 4 (byte loads), by the first team of workgroup 0 --
+    // BEFORE the pipelined loop, so that nothing of it stays in registers across the loop
     const int nv = (int)(M & 3);
     if (nv != 0 && blockIdx.x == 0 && threadIdx.x < 4) {
         const int64_t m0 = (int64_t)full;
@@ -387,6 +371,35 @@ void hsq_decode_sum_d16u8_r_kernel(
             }
         }
     }
+#pragma clang loop unroll(disable)
+    while (i < full) {
+        const unsigned nxt = i + stride;
+        const unsigned pre = nxt < full ? nxt : i;   // the last item re-requests itself: no branch around the loads
+        const unsigned poff = pre & ~3u, ploff = PACKED6 ? 3u * (pre >> 2) : poff;
+        f32x4 acc[4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (r == 0)
+                dec16_payload<true, PACKED6, true>(acc, c4[r], l4[r], lb[r], range[r], inv_s, q, cb_bytes, lane_const);
+            else
+                dec16_payload<false, PACKED6, true>(acc, c4[r], l4[r], lb[r], range[r], inv_s, q, cb_bytes, lane_const);
+            c4[r] = ldw(cbase[r] + poff);
+            l4[r] = ldw(lbase[r] + ploff);
+        }
+        float *o = out + (int64_t)(i & ~3u) * 16 + 4 * q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x4 a = acc[k];
+            if (md.apply) {
+                a[0] = mean_div(a[0], md);
+                a[1] = mean_div(a[1], md);
+                a[2] = mean_div(a[2], md);
+                a[3] = mean_div(a[3], md);
+            }
+            *reinterpret_cast<f32x4 *>(o + 16 * k) = a;
+        }
+        i = nxt;
+    }
 }
 
 // Any R above DEC16_RMAX with the same pipelining, in chunks of DEC16_RMAX payloads: the words of (item, chunk) sit in
@@ -401,7 +414,7 @@ void hsq_decode_sum_d16u8_rc_kernel(
     int64_t code_stride, int64_t level_stride, int64_t lbub_stride, const float *__restrict__ cb, int R, int64_t M, int K,
     int n_bit, float *__restrict__ out) {
     constexpr int C = DEC16_RMAX;
-    extern __shared__ float s_cb[];   // [K][4 copies][16] at LDS address 0, then (lb, ub - lb) of the R payloads
+    extern __shared__ __attribute__((aligned(16))) float s_cb[];   // [K][4 copies][16] at LDS address 0, then (lb, ub - lb) of the R payloads
     for (int i = threadIdx.x; i < K * 16; i += DEC16_THREADS) {   // (row, copy, quarter)
         const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
         *reinterpret_cast<f32x4 *>(s_cb + row * 64 + c * 16 + 4 * q) = *reinterpret_cast<const f32x4 *>(cb + row * 16 + 4 * q);
