@@ -66,13 +66,23 @@ struct PfArgs {
     int nseg;                 // batched: segments in seg_table
     float ef_scale;           // EF kernels: grad <- grad + ef_scale * error (error pointer = seg_table[seg][7], 0 = none)
     int tiles_q, tiles_r;     // tiles per workgroup: the first tiles_r workgroups take tiles_q + 1, the others tiles_q
+    int tiles_skew, skew_blocks;   // ... and of the first skew_blocks (even) workgroups the even ones take tiles_skew more, the odd ones as many fewer
 };
 
 // The split of the tiles over the grid is made on the host: dividing 64-bit integers in the kernel's prologue was
 // ~300 scalar instructions (0.8 us) in front of the first load.
+#ifndef GQ_PF_SKEW_PERMILLE
+#define GQ_PF_SKEW_PERMILLE 10
+#endif
 static void pf_split(PfArgs &a, int64_t ntiles, int64_t blocks) {
     a.tiles_q = (int)(ntiles / blocks);
     a.tiles_r = (int)(ntiles % blocks);
+    // Workgroups go to the eight XCDs in turn, and on every MI355X measured (six boxes, profiles/r0*_pf_kernel_stamps.txt)
+    // the odd XCDs finish the same number of tiles 1.2-1.5 us later than the even ones (same cycles per tile: a lower
+    // clock).  The odd workgroups hand ~1 % of their tiles to their even neighbours.
+    a.skew_blocks = (int)(blocks & ~(int64_t)1);
+    a.tiles_skew = (int)((a.tiles_q * (int64_t)GQ_PF_SKEW_PERMILLE + 500) / 1000);
+    if (a.tiles_skew >= a.tiles_q) a.tiles_skew = 0;
 }
 
 // SEGLDS (batched only): the segment records are read from their LDS copy (nseg <= PF_LDS_SEGS) or, for
@@ -110,8 +120,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // trip per tile, ~0.7 us, and commit a wave two tiles ahead: measured slower than the static split.)
     // Contiguous runs also keep a wave's running (min,max) with one tensor for many tiles in the batched form.
     const int b = (int)blockIdx.x;
-    const int64_t lo_tile = (int64_t)b * a.tiles_q + (b < a.tiles_r ? b : a.tiles_r);
-    const int64_t tile_end = lo_tile + a.tiles_q + (b < a.tiles_r ? 1 : 0);
+    const bool skewed = b < a.skew_blocks;
+    const int64_t lo_tile = (int64_t)b * a.tiles_q + (b < a.tiles_r ? b : a.tiles_r) + ((skewed && (b & 1)) ? a.tiles_skew : 0);
+    const int64_t tile_end = lo_tile + a.tiles_q + (b < a.tiles_r ? 1 : 0) + (skewed ? ((b & 1) ? -a.tiles_skew : a.tiles_skew) : 0);
     // The second wave of a SIMD (waves 4-7: the slower of the pair) leaves the last PF_TAIL tiles of the run to
     // the first one: a tile it started that late would finish ~1.5 us after everybody else.
     const int tail_from = (int)(tile_end - lo_tile) - (wave >= PF_WAVES / 2 ? PF_TAIL : 0);
