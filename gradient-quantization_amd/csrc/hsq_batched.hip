@@ -508,6 +508,137 @@ static void launch_bt4_r(const int64_t *seg_table, const int32_t *tile_seg, int6
                        (size_t)64 * 1024, st, seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain);
 }
 
+// Any R above BT4_RMAX: the same pipeline in chunks of BT4_RMAX payloads (see hsq_decode_sum_d16u8_rc_kernel): the words of
+// (tile, chunk) sit in registers and each pair is re-requested for the next chunk -- of the same tile, or the first chunk
+// of the wave's next tile -- as soon as it has been consumed; every trip issues its loads unconditionally (a short last
+// chunk re-reads the last payload), which keeps the compiler's vmcnt bookkeeping exact.  (lb, ub) per payload by scalar
+// loads at consumption (they were vector loads per lane before).  Sums start from +0 (R > 1: the mean adds +0 anyway).
+constexpr int BT4_RC_THREADS = 1024;
+template <bool PACKED6>
+__global__ __launch_bounds__(BT4_RC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))   // 16 word registers + 16 sums + rows + two tile records: ~90 VGPRs
+void hsq_decode_sum_batched4_rc_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
+    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
+    float *__restrict__ out, int plain) {
+    extern __shared__ __attribute__((aligned(16))) float s_cb4[];   // [256][4 copies][16] at LDS address 0
+    constexpr int THREADS = BT4_RC_THREADS, C = BT4_RMAX;
+    const float inv_s = 1.0f / (float)(1 << n_bit);
+    const MeanDiv md = mean_div_of(R, !plain);
+    const int q = threadIdx.x & 3;
+    const unsigned lane_const = (unsigned)(((threadIdx.x >> 3) & 3) * 64 + 16 * q);
+    const char *const cb_bytes = reinterpret_cast<const char *>(s_cb4);
+    const unsigned g = (unsigned)(threadIdx.x & 63) & ~3u;
+    const unsigned out_lane = (g * 16 + 4 * q) * 4;
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6)));
+    const int64_t wstride = (int64_t)gridDim.x * (THREADS / 64);
+    const int nchunks = (R + C - 1) / C;
+    typedef const uint8_t __attribute__((address_space(1))) gbyte;
+    typedef const unsigned __attribute__((address_space(1))) gword;
+    typedef const unsigned __attribute__((address_space(1), aligned(1))) gword_any;
+    const uint64_t wire0 = reinterpret_cast<uint64_t>(gathered);
+    unsigned c4[C], l4[C];
+    auto request = [&](const Bt4Tile &t, unsigned gl, int chunk, int jj) {
+        int r = chunk * C + jj;
+        r = r < R ? r : R - 1;
+        const uint64_t base = wire0 + (uint64_t)r * (uint64_t)user_stride;
+        c4[jj] = *reinterpret_cast<gword *>(reinterpret_cast<gbyte *>(base + t.code_off) + gl);
+        l4[jj] = PACKED6 ? (unsigned)*reinterpret_cast<gword_any *>(reinterpret_cast<gbyte *>(base + t.level_off) + 3u * (gl >> 2))
+                         : *reinterpret_cast<gword *>(reinterpret_cast<gbyte *>(base + t.level_off) + gl);
+    };
+    const bool active = wave0 < ntiles;
+    int64_t tile = active ? wave0 : ntiles - 1;
+    Bt4Tile cur = bt4_tile<PACKED6>(seg_table, tile_seg, tile);
+    int64_t tn = tile + wstride < ntiles ? tile + wstride : tile;
+    Bt4Tile nxt = bt4_tile<PACKED6>(seg_table, tile_seg, tn);
+    {
+        const unsigned gl = (int)g < cur.left ? g : 0u;
+#pragma unroll
+        for (int jj = 0; jj < C; ++jj) request(cur, gl, 0, jj);
+    }
+    {
+        constexpr int STAGE = (256 * 16 + THREADS - 1) / THREADS;
+        f32x4 stage[STAGE];
+#pragma unroll
+        for (int n = 0; n < STAGE; ++n) {
+            const int e = threadIdx.x + n * THREADS;
+            if (e < 256 * 16) stage[n] = *reinterpret_cast<const f32x4 *>(cb + (e >> 4) * 16 + 4 * (e & 3));
+        }
+#pragma unroll
+        for (int n = 0; n < STAGE; ++n) {
+            const int e = threadIdx.x + n * THREADS;
+            const int row = e >> 4, c = (e >> 2) & 3, qq = e & 3;
+            if (e < 256 * 16) *reinterpret_cast<f32x4 *>(s_cb4 + row * 64 + c * 16 + 4 * qq) = stage[n];
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    while (true) {
+        const int64_t t2 = tn + wstride < ntiles ? tn + wstride : tn;
+        const Bt4Tile aft = bt4_tile<PACKED6>(seg_table, tile_seg, t2);
+        const unsigned gl_cur = (int)g < cur.left ? g : 0u, gl_nxt = (int)g < nxt.left ? g : 0u;
+        f32x4 acc[4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const bool last = chunk + 1 == nchunks;
+            const int nc = last ? 0 : chunk + 1;
+#pragma unroll
+            for (int jj = 0; jj < C; ++jj) {
+                const int r = chunk * C + jj;
+                if (r < R) {
+                    const float *lbub = reinterpret_cast<const float *>(gathered + (int64_t)r * user_stride + (int64_t)cur.lbub_off);
+                    bt4_payload<false, PACKED6, true>(acc, c4[jj], l4[jj], lbub[0], lbub[1], inv_s, q, cb_bytes, lane_const);
+                }
+                if (last)
+                    request(nxt, gl_nxt, 0, jj);
+                else
+                    request(cur, gl_cur, nc, jj);
+            }
+        }
+        if (md.apply) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[k][0] = mean_div(acc[k][0], md);
+                acc[k][1] = mean_div(acc[k][1], md);
+                acc[k][2] = mean_div(acc[k][2], md);
+                acc[k][3] = mean_div(acc[k][3], md);
+            }
+        }
+        f32x4 *o = reinterpret_cast<f32x4 *>(out + cur.out_off + (out_lane >> 2));
+        if (cur.left == 64) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[4 * k] = acc[k];
+        } else {
+            const int nv = cur.left - (int)g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nv) o[4 * k] = acc[k];
+        }
+        if (tile + wstride >= ntiles) break;
+        tile += wstride;
+        cur = nxt;
+        nxt = aft;
+        tn = t2;
+    }
+}
+
+template <bool P6>
+static void launch_bt4_rc(int R, const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
+                          int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st) {
+    static const int bpc = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_batched4_rc_kernel<P6>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipGetLastError();
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hsq_decode_sum_batched4_rc_kernel<P6>, BT4_RC_THREADS, (size_t)64 * 1024) != hipSuccess ||
+            n < 1)
+            n = 1;
+        return n;
+    }();
+    int64_t blocks = (ntiles * 64 + BT4_RC_THREADS - 1) / BT4_RC_THREADS;
+    if (blocks > (int64_t)cu_count() * bpc) blocks = (int64_t)cu_count() * bpc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched4_rc_kernel<P6>), dim3((unsigned)blocks), dim3(BT4_RC_THREADS), (size_t)64 * 1024, st,
+                       seg_table, tile_seg, ntiles, gathered, user_stride, R, cb, n_bit, out, plain);
+}
+
 template <bool P6>
 static bool launch_bt4_fixed_r(int R, const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
                                int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st) {
@@ -516,7 +647,9 @@ static bool launch_bt4_fixed_r(int R, const int64_t *seg_table, const int32_t *t
         GQ_BT4_CASE(1) GQ_BT4_CASE(2) GQ_BT4_CASE(3) GQ_BT4_CASE(4)
         GQ_BT4_CASE(5) GQ_BT4_CASE(6) GQ_BT4_CASE(7) GQ_BT4_CASE(8)
 #undef GQ_BT4_CASE
-        default: return false;
+        default:
+            launch_bt4_rc<P6>(R, seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st);
+            return true;
     }
 }
 

@@ -261,10 +261,21 @@ void hsq_decode_sum_d16u8_kernel(
 // as soon as it has been consumed, i.e. before the current item's stores are queued; the loop body is straight-line for
 // the compiler's vmcnt bookkeeping (a payload's words wait with R + 3 younger operations outstanding, the stores among
 // them), so the stores drain under the next item's arithmetic.  (lb, ub - lb) sit in scalar registers.
-constexpr int DEC16_RMAX = 8;
+constexpr int DEC16_RMAX = 16;
 #ifndef GQ_DEC16R_WAVES
 #define GQ_DEC16R_WAVES 8
 #endif
+
+// lane t of every team of four broadcasts its word (quad_perm [t, t, t, t])
+__device__ __forceinline__ unsigned team_word(unsigned w, int t) {
+    const int x = (int)w;
+    switch (t) {
+        case 0: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0x00, 0xF, 0xF, true);
+        case 1: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0x55, 0xF, 0xF, true);
+        case 2: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0xAA, 0xF, 0xF, true);
+        default: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0xFF, 0xF, 0xF, true);
+    }
+}
 
 template <int R, bool PACKED6>
 __global__ __launch_bounds__(DEC16_THREADS) __attribute__((amdgpu_waves_per_eu(GQ_DEC16R_WAVES, GQ_DEC16R_WAVES)))
@@ -278,11 +289,19 @@ void hsq_decode_sum_d16u8_r_kernel(
     const unsigned full = (unsigned)(M >> 2) * 4u;   // items of whole groups; M < 2^31 - 2^21 (launcher): 32-bit item numbers
     const unsigned stride = gridDim.x * DEC16_THREADS;
     unsigned i = blockIdx.x * DEC16_THREADS + threadIdx.x;
-    unsigned c4[R], l4[R];
-    // per-payload bases pinned in scalar registers: the loads then take the (scalar base + 32-bit lane offset) form,
-    // left to itself the compiler re-associates base + r * stride + offset into a 64-bit VALU add per load
+    // The four lanes of a team need the same word pair of every payload.  Each lane fetches the pair of ONE payload in four
+    // -- lane q of a team: payloads q, 4 + q, 8 + q, ... -- and a payload's pair reaches the team by a quad-permute DPP move
+    // when its turn comes: ceil(R / 4) x 2 wave-wide loads per item instead of 2 R (a wave-wide dword load keeps the CU's
+    // address path busy for ~16 cycles whatever it fetches: at R = 16 that path, not the arithmetic, set the time) and as
+    // many word registers, so that R = 16 fits the 64 registers of 8 waves per SIMD.
+    constexpr int NW = (R + 3) / 4;           // word pairs per lane
+    constexpr int LASTN = R - 4 * (NW - 1);   // payloads in the last group (1..4)
+    const int q = threadIdx.x & 3;
+    unsigned cw[NW], lw[NW];
+    // group bases pinned in scalar registers (+ 4 j payload strides), the lane's own payload inside the group goes into the
+    // 32-bit offset: q strides (launcher: 3 strides + the section fit 32 bits); lanes past R in the last group repeat payload R - 1
     typedef const uint8_t __attribute__((address_space(1))) gbyte;   // global address space kept through the integer round trip
-    gbyte *cbase[R], *lbase[R];
+    gbyte *cbase[NW], *lbase[NW];
     auto pin = [](const uint8_t *p) {
         const uint64_t v = reinterpret_cast<uint64_t>(p);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -294,20 +313,24 @@ void hsq_decode_sum_d16u8_r_kernel(
                        : *reinterpret_cast<const unsigned __attribute__((address_space(1))) *>(p);
     };
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        cbase[r] = pin(codes + (int64_t)r * code_stride);
-        lbase[r] = pin(levels + (int64_t)r * level_stride);
+    for (int j = 0; j < NW; ++j) {
+        cbase[j] = pin(codes + (int64_t)(4 * j) * code_stride);
+        lbase[j] = pin(levels + (int64_t)(4 * j) * level_stride);
     }
-    auto request = [&](unsigned item) {
-        const unsigned off = item & ~3u;                           // first subvector of the group
+    const unsigned qc = (unsigned)q * (unsigned)code_stride, ql = (unsigned)q * (unsigned)level_stride;
+    const int ql_last = q < LASTN ? q : LASTN - 1;
+    const unsigned qc_last = (unsigned)ql_last * (unsigned)code_stride, qll_last = (unsigned)ql_last * (unsigned)level_stride;
+    auto request_group = [&](unsigned item, int j) {
+        const unsigned off = item & ~3u;                           // first subvector of the group of four
         const unsigned loff = PACKED6 ? 3u * (item >> 2) : off;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            c4[r] = ldw(cbase[r] + off);
-            l4[r] = ldw(lbase[r] + loff);
-        }
+        const bool last = LASTN != 4 && j == NW - 1;
+        cw[j] = ldw(cbase[j] + (off + (last ? qc_last : qc)));
+        lw[j] = ldw(lbase[j] + (loff + (last ? qll_last : ql)));
     };
-    if (i < full) request(i);
+    if (i < full) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) request_group(i, j);
+    }
     constexpr int STAGE = 256 * 16 / DEC16_THREADS;   // K <= 256 rows of four 16-byte quarters
     f32x4 stage[STAGE];
 #pragma unroll
@@ -331,7 +354,6 @@ void hsq_decode_sum_d16u8_r_kernel(
     __syncthreads();
     const float inv_s = 1.0f / (float)(1 << (n_bit & 31));
     const MeanDiv md = mean_div_of(R);
-    const int q = threadIdx.x & 3;
     const unsigned lane_const = (unsigned)(((threadIdx.x >> 3) & 3) * 64 + 16 * q);
     const char *const cb_bytes = reinterpret_cast<const char *>(s_cb);
     // the last, partial group of a tensor whose M is not a multiple of 4 (byte loads), by the first team of workgroup 0 --
@@ -375,16 +397,16 @@ void hsq_decode_sum_d16u8_r_kernel(
     while (i < full) {
         const unsigned nxt = i + stride;
         const unsigned pre = nxt < full ? nxt : i;   // the last item re-requests itself: no branch around the loads
-        const unsigned poff = pre & ~3u, ploff = PACKED6 ? 3u * (pre >> 2) : poff;
         f32x4 acc[4];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+            const int j = r >> 2;
+            const unsigned c4 = team_word(cw[j], r & 3), l4 = team_word(lw[j], r & 3);
             if (r == 0)
-                dec16_payload<true, PACKED6, true>(acc, c4[r], l4[r], lb[r], range[r], inv_s, q, cb_bytes, lane_const);
+                dec16_payload<true, PACKED6, true>(acc, c4, l4, lb[r], range[r], inv_s, q, cb_bytes, lane_const);
             else
-                dec16_payload<false, PACKED6, true>(acc, c4[r], l4[r], lb[r], range[r], inv_s, q, cb_bytes, lane_const);
-            c4[r] = ldw(cbase[r] + poff);
-            l4[r] = ldw(lbase[r] + ploff);
+                dec16_payload<false, PACKED6, true>(acc, c4, l4, lb[r], range[r], inv_s, q, cb_bytes, lane_const);
+            if ((r & 3) == 3 || r == R - 1) request_group(pre, j);   // the group's four payloads are summed: its registers take the next item's
         }
         float *o = out + (int64_t)(i & ~3u) * 16 + 4 * q;
 #pragma unroll
@@ -413,7 +435,7 @@ void hsq_decode_sum_d16u8_rc_kernel(
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ levels, const float *__restrict__ lb_ub,
     int64_t code_stride, int64_t level_stride, int64_t lbub_stride, const float *__restrict__ cb, int R, int64_t M, int K,
     int n_bit, float *__restrict__ out) {
-    constexpr int C = DEC16_RMAX;
+    constexpr int C = 8;   // payloads per chunk
     extern __shared__ __attribute__((aligned(16))) float s_cb[];   // [K][4 copies][16] at LDS address 0, then (lb, ub - lb) of the R payloads
     for (int i = threadIdx.x; i < K * 16; i += DEC16_THREADS) {   // (row, copy, quarter)
         const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
@@ -562,10 +584,14 @@ template <bool P6>
 static bool launch_dec16_fixed_r(int R, const uint8_t *codes, const uint8_t *levels, const float *lb_ub, int64_t cs, int64_t ls,
                                  int64_t bs, const float *cb, int64_t M, int K, int n_bit, float *out, hipStream_t st) {
     if (M >= ((int64_t)1 << 31) - ((int64_t)1 << 21)) return false;
+    // the lane's payload inside a group of four travels in the 32-bit offset of its loads: up to 3 strides + the section
+    if (cs < 0 || ls < 0 || 3 * (cs > ls ? cs : ls) + M + 64 >= ((int64_t)1 << 32)) return false;
     switch (R) {
 #define GQ_DEC16_CASE(N) case N: launch_dec16_r<N, P6>(codes, levels, lb_ub, cs, ls, bs, cb, M, K, n_bit, out, st); return true;
         GQ_DEC16_CASE(1) GQ_DEC16_CASE(2) GQ_DEC16_CASE(3) GQ_DEC16_CASE(4)
         GQ_DEC16_CASE(5) GQ_DEC16_CASE(6) GQ_DEC16_CASE(7) GQ_DEC16_CASE(8)
+        GQ_DEC16_CASE(9) GQ_DEC16_CASE(10) GQ_DEC16_CASE(11) GQ_DEC16_CASE(12)
+        GQ_DEC16_CASE(13) GQ_DEC16_CASE(14) GQ_DEC16_CASE(15) GQ_DEC16_CASE(16)
 #undef GQ_DEC16_CASE
         default:
             if (R > DEC16_RC_MAX) return false;

@@ -446,6 +446,20 @@ def test_batched_quantizer_equals_per_tensor_path():
     assert torch.equal(qb._wire, qp._wire)
 
 
+@pytest.mark.parametrize("users,kw", [(5, {}), (8, {}), (8, dict(gq_wire_levels="packed6")), (11, {}), (16, dict(gq_wire_levels="packed6")),
+                                      (19, {})])
+def test_batched_quantizer_many_users_equal_per_tensor_path(users, kw):
+    """The multi-tensor decode-mean for every payload count: compile-time-R pipelined kernels up to 8 (768-thread workgroups
+    from 6 on), the chunked form above, byte and packed 6-bit levels -- against the per-tensor kernels, bit for bit."""
+    shapes = RESNET50_COMPRESSED[:10] + RESNET50_SMALL[:3]
+    qb, gb = _run_quantizer(shapes, users, 23, **kw)
+    qp, gp = _run_quantizer(shapes, users, 23, gq_no_batch=True, **kw)
+    assert qb._groups and qb._groups[0][2].ready and not qp._groups
+    for a, b, s in zip(gb, gp, shapes):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), s
+    assert torch.equal(qb._wire, qp._wire)
+
+
 @pytest.mark.parametrize("c_dim", [32, 8])
 def test_batched_quantizer_other_subdimensions_equal_per_tensor_path(c_dim):
     """The multi-tensor kernels for the other prefilter sub-dimensions (main.py's default --c-dim 32, and 8):
