@@ -340,13 +340,24 @@ __global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
     }
 }
 
+// lane t of every team of four broadcasts its word (quad_perm [t, t, t, t])
+__device__ __forceinline__ unsigned bt4_team_word(unsigned w, int t) {
+    const int x = (int)w;
+    switch (t) {
+        case 0: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0x00, 0xF, 0xF, true);
+        case 1: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0x55, 0xF, 0xF, true);
+        case 2: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0xAA, 0xF, 0xF, true);
+        default: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0xFF, 0xF, 0xF, true);
+    }
+}
+
 // The same for a compile-time payload count R <= BT4_RMAX, software-pipelined across a wave's tiles like
 // hsq_decode_sum_d16u8_r_kernel (hsq_decode.hip): a wave's 64 items are exactly one tile, so the segment record of a tile
 // is wave-uniform -- it is fetched by scalar loads two tiles ahead, the (code, level) words and (lb, ub) of the NEXT tile
 // are re-requested into the registers of the payload just consumed, and the stores of a tile drain under the next
 // tile's arithmetic.  In the kernel above every item walks tile_seg -> segment record -> payload words -> stores as one
 // dependent chain per lane, behind the previous item's stores.
-constexpr int BT4_RMAX = 8;
+constexpr int BT4_RMAX = 16;
 
 struct Bt4Tile {          // wave-uniform: where a tile's bytes are
     uint64_t code_off;    // byte offset of the tile's first code inside a payload
@@ -376,8 +387,10 @@ __device__ __forceinline__ Bt4Tile bt4_tile(const int64_t *__restrict__ seg_tabl
 #ifndef GQ_BT4_R_NARROW
 #define GQ_BT4_R_NARROW 6
 #endif
-constexpr int bt4r_threads(int R) { return R >= GQ_BT4_R_NARROW ? 768 : 1024; }
-constexpr int bt4r_waves(int R) { return R >= GQ_BT4_R_NARROW ? 6 : 8; }
+// R > 8: (lb, ub) of 9..16 payloads in flight for two tiles push the kernel past 80 registers: one 1024-thread workgroup
+// per CU, 4 waves per SIMD (the arithmetic of that many payloads outweighs the stores anyway).
+constexpr int bt4r_threads(int R) { return R > 8 ? 1024 : (R >= GQ_BT4_R_NARROW ? 768 : 1024); }
+constexpr int bt4r_waves(int R) { return R > 8 ? 4 : (R >= GQ_BT4_R_NARROW ? 6 : 8); }
 
 template <int R, bool PACKED6>
 __global__ __launch_bounds__(bt4r_threads(R)) __attribute__((amdgpu_waves_per_eu(bt4r_waves(R), bt4r_waves(R))))
@@ -401,15 +414,26 @@ void hsq_decode_sum_batched4_r_kernel(
     typedef const unsigned __attribute__((address_space(1))) gword;
     typedef const unsigned __attribute__((address_space(1), aligned(1))) gword_any;   // packed levels start at any byte
     const uint64_t wire0 = reinterpret_cast<uint64_t>(gathered);
-    unsigned c4[R], l4[R];
+    // Each lane of a team of four fetches the word pair of ONE payload in four (lane q: payloads q, 4 + q, ...) and a
+    // payload's pair reaches the team by a quad-permute DPP move when its turn comes (hsq_decode_sum_d16u8_r_kernel): a
+    // quarter of the wave-wide loads and of the word registers.  The lane's payload inside a group of four goes into the 32-bit
+    // lane offset (launcher: 3 payload strides fit); lanes past R in the last group repeat payload R - 1.
+    constexpr int NW = (R + 3) / 4;
+    constexpr int LASTN = R - 4 * (NW - 1);
+    unsigned cw[NW], lw[NW];
     float lb[R], ub[R];
-    // requests of tile t for payload r: (scalar base) + (32-bit lane offset) loads; lanes past the segment's end re-read
-    // the tile's first group
-    auto request = [&](const Bt4Tile &t, unsigned gl, int r) {
-        const uint64_t base = wire0 + (uint64_t)r * (uint64_t)user_stride;
-        c4[r] = *reinterpret_cast<gword *>(reinterpret_cast<gbyte *>(base + t.code_off) + gl);
-        l4[r] = PACKED6 ? (unsigned)*reinterpret_cast<gword_any *>(reinterpret_cast<gbyte *>(base + t.level_off) + 3u * (gl >> 2))
-                        : *reinterpret_cast<gword *>(reinterpret_cast<gbyte *>(base + t.level_off) + gl);
+    const unsigned qs = (unsigned)q * (unsigned)user_stride;
+    const unsigned qs_last = (unsigned)(q < LASTN ? q : LASTN - 1) * (unsigned)user_stride;
+    // requests of tile t for the payloads of group j: (scalar base) + (32-bit lane offset) loads; lanes past the segment's
+    // end re-read the tile's first group of subvectors
+    auto request_group = [&](const Bt4Tile &t, unsigned gl, int j) {
+        const uint64_t base = wire0 + (uint64_t)(4 * j) * (uint64_t)user_stride;
+        const unsigned qo = (LASTN != 4 && j == NW - 1) ? qs_last : qs;
+        cw[j] = *reinterpret_cast<gword *>(reinterpret_cast<gbyte *>(base + t.code_off) + (gl + qo));
+        lw[j] = PACKED6 ? (unsigned)*reinterpret_cast<gword_any *>(reinterpret_cast<gbyte *>(base + t.level_off) + (3u * (gl >> 2) + qo))
+                        : *reinterpret_cast<gword *>(reinterpret_cast<gbyte *>(base + t.level_off) + (gl + qo));
+    };
+    auto request_lbub = [&](const Bt4Tile &t, int r) {
         const float *lbub = reinterpret_cast<const float *>(gathered + (int64_t)r * user_stride + (int64_t)t.lbub_off);
         lb[r] = lbub[0];
         ub[r] = lbub[1];
@@ -424,7 +448,9 @@ void hsq_decode_sum_batched4_r_kernel(
     {
         const unsigned gl = (int)g < cur.left ? g : 0u;
 #pragma unroll
-        for (int r = 0; r < R; ++r) request(cur, gl, r);
+        for (int j = 0; j < NW; ++j) request_group(cur, gl, j);
+#pragma unroll
+        for (int r = 0; r < R; ++r) request_lbub(cur, r);
     }
     {
         constexpr int STAGE = (256 * 16 + THREADS - 1) / THREADS;
@@ -450,15 +476,17 @@ void hsq_decode_sum_batched4_r_kernel(
         f32x4 acc[4];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+            const unsigned c4 = bt4_team_word(cw[r >> 2], r & 3), l4 = bt4_team_word(lw[r >> 2], r & 3);
             if (r == 0)
-                bt4_payload<true, PACKED6, true>(acc, c4[r], l4[r], lb[r], ub[r], inv_s, q, cb_bytes, lane_const);
+                bt4_payload<true, PACKED6, true>(acc, c4, l4, lb[r], ub[r], inv_s, q, cb_bytes, lane_const);
             else
-                bt4_payload<false, PACKED6, true>(acc, c4[r], l4[r], lb[r], ub[r], inv_s, q, cb_bytes, lane_const);
+                bt4_payload<false, PACKED6, true>(acc, c4, l4, lb[r], ub[r], inv_s, q, cb_bytes, lane_const);
             // keep each re-request behind the payload it replaces (hoisted to the top of the trip, the new words were
             // spilled until their registers came free): the lane offset is made to "depend" on the payload's last sum.
             // No instruction; a sched_barrier or a volatile asm counts as a store and turns the scalar (lb, ub) loads into vector loads
             asm("" : "+v"(gl) : "v"(acc[3][3]));
-            request(nxt, gl, r);
+            request_lbub(nxt, r);
+            if ((r & 3) == 3 || r == R - 1) request_group(nxt, gl, r >> 2);   // the group's payloads are summed: its registers take the next tile's
         }
         if (md.apply) {
 #pragma unroll
@@ -521,7 +549,7 @@ void hsq_decode_sum_batched4_rc_kernel(
     const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
     float *__restrict__ out, int plain) {
     extern __shared__ __attribute__((aligned(16))) float s_cb4[];   // [256][4 copies][16] at LDS address 0
-    constexpr int THREADS = BT4_RC_THREADS, C = BT4_RMAX;
+    constexpr int THREADS = BT4_RC_THREADS, C = 8;
     const float inv_s = 1.0f / (float)(1 << n_bit);
     const MeanDiv md = mean_div_of(R, !plain);
     const int q = threadIdx.x & 3;
@@ -642,10 +670,14 @@ static void launch_bt4_rc(int R, const int64_t *seg_table, const int32_t *tile_s
 template <bool P6>
 static bool launch_bt4_fixed_r(int R, const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
                                int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st) {
+    // (the lane's payload inside a group of four travels in the 32-bit offset of its loads: 3 strides + a payload must fit)
+    if (user_stride < 0 || 4 * user_stride >= ((int64_t)1 << 32)) R = BT4_RMAX + 1;
     switch (R) {
 #define GQ_BT4_CASE(N) case N: launch_bt4_r<N, P6>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st); return true;
         GQ_BT4_CASE(1) GQ_BT4_CASE(2) GQ_BT4_CASE(3) GQ_BT4_CASE(4)
         GQ_BT4_CASE(5) GQ_BT4_CASE(6) GQ_BT4_CASE(7) GQ_BT4_CASE(8)
+        GQ_BT4_CASE(9) GQ_BT4_CASE(10) GQ_BT4_CASE(11) GQ_BT4_CASE(12)
+        GQ_BT4_CASE(13) GQ_BT4_CASE(14) GQ_BT4_CASE(15) GQ_BT4_CASE(16)
 #undef GQ_BT4_CASE
         default:
             launch_bt4_rc<P6>(R, seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st);
