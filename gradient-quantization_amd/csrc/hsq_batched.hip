@@ -218,13 +218,10 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_kernel(
     }
 }
 
-// The same with the decode kernel's conflict-free gather (hsq_decode.hip, hsq_decode_sum_d16u8_kernel): a
-// thread produces one quarter of FOUR consecutive padded subvectors (they share a tile, hence a tensor),
-// two dword loads per payload; the codebook is staged four times (row r, copy c at byte r*256 + c*64)
-// and the four 4-lane teams of every ds_read_b128 lane group read copies 0..3.
-constexpr int BT4_THREADS = 1024;
-
-constexpr int BT4_CHUNK = 8;   // payloads whose words are requested together (see hsq_decode_sum_d16u8_kernel)
+// The d = 16 / K = 256 multi-tensor decode-mean is built like the per-tensor one (hsq_decode.hip,
+// hsq_decode_sum_d16u8_r_kernel): a thread produces one quarter of FOUR consecutive padded subvectors (they share a
+// tile, hence a tensor); the codebook is staged four times (row r, copy c at byte r*256 + c*64) and the four 4-lane
+// teams of every ds_read_b128 lane group read copies 0..3.  Helpers first, the kernels below.
 
 // LDS byte address of a codebook row for this lane: [0, 0, code_k, lane_const] by one v_perm_b32
 template <int K4>
@@ -261,81 +258,6 @@ __device__ __forceinline__ void bt4_payload(f32x4 (&acc)[4], unsigned c4, unsign
             acc[k] = dec;
         } else {
             acc[k] = acc[k] + dec;
-        }
-    }
-}
-
-template <bool PACKED6>   // levels as four 6-bit values per three bytes (GQ_LEVELS_PACKED6) instead of a byte each
-__global__ __launch_bounds__(BT4_THREADS) void hsq_decode_sum_batched4_kernel(
-    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
-    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
-    float *__restrict__ out, int plain) {
-    extern __shared__ __attribute__((aligned(16))) float s_cb4[];   // [256][4 copies][16]
-    for (int i = threadIdx.x; i < 256 * 16; i += BT4_THREADS) {   // (row, copy, quarter)
-        const int row = i >> 4, c = (i >> 2) & 3, q = i & 3;
-        *reinterpret_cast<f32x4 *>(s_cb4 + row * 64 + c * 16 + 4 * q) = *reinterpret_cast<const f32x4 *>(cb + row * 16 + 4 * q);
-    }
-    __syncthreads();
-    const float inv_s = 1.0f / (float)(1 << n_bit);
-    const MeanDiv md = mean_div_of(R, !plain);
-    const int q = threadIdx.x & 3;
-    const unsigned lane_const = (unsigned)(((threadIdx.x >> 3) & 3) * 64 + 16 * q);   // this lane's copy and quarter, bytes
-    const char *const cb_bytes = reinterpret_cast<const char *>(s_cb4);
-    const int64_t total = ntiles * 64;   // (group of 4 padded subvectors, quarter) items
-    const int64_t stride = (int64_t)gridDim.x * BT4_THREADS;
-    for (int64_t i = (int64_t)blockIdx.x * BT4_THREADS + threadIdx.x; i < total; i += stride) {
-        const int64_t g0 = (i >> 2) * 4;
-        const int64_t tile = g0 >> 6;
-        const int seg = tile_seg[tile];
-        const int64_t *rec = seg_table + 8 * (int64_t)seg;
-        const int64_t local = (tile - rec[2]) * 64 + (g0 & 63);
-        const int64_t left = rec[1] - local;
-        if (left <= 0) continue;
-        const int nv = left < 4 ? (int)left : 4;
-        const int64_t code_off = rec[3] + local, level_off = rec[4] + (PACKED6 ? 3 * (local >> 2) : local), lbub_off = rec[5];
-        f32x4 acc[4];
-        // a chunk's words (codes, levels, lb, ub of up to BT4_CHUNK payloads) are all requested before the first is
-        // used: fetched inside the payload loop, every payload waited out its own round trip to memory
-        const uint8_t *p = gathered;
-        for (int r0 = 0; r0 < R; r0 += BT4_CHUNK) {
-            unsigned c4[BT4_CHUNK], l4[BT4_CHUNK];
-            float lb[BT4_CHUNK], ub[BT4_CHUNK];
-#pragma unroll
-            for (int jj = 0; jj < BT4_CHUNK; ++jj) {
-                if (r0 + jj < R) {
-                    const uint8_t *pj = p + (int64_t)jj * user_stride;
-                    c4[jj] = *reinterpret_cast<const unsigned *>(pj + code_off);    // sections are padded to 16 B:
-                    l4[jj] = PACKED6 ? load_packed6(pj + level_off)
-                                     : *reinterpret_cast<const unsigned *>(pj + level_off);   // reading past M stays inside
-                    const float *lbub = reinterpret_cast<const float *>(pj + lbub_off);
-                    lb[jj] = lbub[0];
-                    ub[jj] = lbub[1];
-                }
-            }
-            p += (int64_t)BT4_CHUNK * user_stride;
-#pragma unroll
-            for (int jj = 0; jj < BT4_CHUNK; ++jj) {
-                if (r0 + jj < R) {
-                    if (jj == 0 && r0 == 0)
-                        bt4_payload<true, PACKED6>(acc, c4[jj], l4[jj], lb[jj], ub[jj], inv_s, q, cb_bytes, lane_const);
-                    else
-                        bt4_payload<false, PACKED6>(acc, c4[jj], l4[jj], lb[jj], ub[jj], inv_s, q, cb_bytes, lane_const);
-                }
-            }
-        }
-        float *o = out + rec[6] + local * 16 + 4 * q;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k < nv) {
-                f32x4 a = acc[k];
-                if (md.apply) {
-                    a[0] = mean_div(a[0], md);
-                    a[1] = mean_div(a[1], md);
-                    a[2] = mean_div(a[2], md);
-                    a[3] = mean_div(a[3], md);
-                }
-                *reinterpret_cast<f32x4 *>(o + 16 * k) = a;
-            }
         }
     }
 }
@@ -668,12 +590,12 @@ static void launch_bt4_rc(int R, const int64_t *seg_table, const int32_t *tile_s
 }
 
 template <bool P6>
-static bool launch_bt4_fixed_r(int R, const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
+static void launch_bt4_fixed_r(int R, const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
                                int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st) {
     // (the lane's payload inside a group of four travels in the 32-bit offset of its loads: 3 strides + a payload must fit)
     if (user_stride < 0 || 4 * user_stride >= ((int64_t)1 << 32)) R = BT4_RMAX + 1;
     switch (R) {
-#define GQ_BT4_CASE(N) case N: launch_bt4_r<N, P6>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st); return true;
+#define GQ_BT4_CASE(N) case N: launch_bt4_r<N, P6>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st); return;
         GQ_BT4_CASE(1) GQ_BT4_CASE(2) GQ_BT4_CASE(3) GQ_BT4_CASE(4)
         GQ_BT4_CASE(5) GQ_BT4_CASE(6) GQ_BT4_CASE(7) GQ_BT4_CASE(8)
         GQ_BT4_CASE(9) GQ_BT4_CASE(10) GQ_BT4_CASE(11) GQ_BT4_CASE(12)
@@ -681,7 +603,7 @@ static bool launch_bt4_fixed_r(int R, const int64_t *seg_table, const int32_t *t
 #undef GQ_BT4_CASE
         default:
             launch_bt4_rc<P6>(R, seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st);
-            return true;
+            return;
     }
 }
 
@@ -964,35 +886,13 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_d16(const int64_t *seg_table, const i
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: null pointer");
     plain = plain ? 1 : 0;
     if ((user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0) {
-        static const int bpc = [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gq::hsq_decode_sum_batched4_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gq::hsq_decode_sum_batched4_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            (void)hipGetLastError();
-            int n = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gq::hsq_decode_sum_batched4_kernel<false>, gq::BT4_THREADS,
-                                                             (size_t)64 * 1024) != hipSuccess || n < 1)
-                n = 1;
-            return n;
-        }();
-        if (packed6 ? gq::launch_bt4_fixed_r<true>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, n_bit, out,
-                                                   plain, gq::as_stream(stream))
-                    : gq::launch_bt4_fixed_r<false>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, n_bit,
-                                                    out, plain, gq::as_stream(stream))) {
-            GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched");
-            return GQ_OK;
-        }
-        int64_t blocks = (ntiles * 64 + gq::BT4_THREADS - 1) / gq::BT4_THREADS;
-        if (blocks > (int64_t)gq::cu_count() * bpc) blocks = (int64_t)gq::cu_count() * bpc;
+        // compile-time-R kernels up to BT4_RMAX payloads, the chunked one above: every R is served
         if (packed6)
-            hipLaunchKernelGGL(gq::hsq_decode_sum_batched4_kernel<true>, dim3((unsigned)blocks), dim3(gq::BT4_THREADS),
-                               (size_t)64 * 1024, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
-                               user_stride_bytes, R, codebook, n_bit, out, plain);
+            gq::launch_bt4_fixed_r<true>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, n_bit, out, plain,
+                                         gq::as_stream(stream));
         else
-            hipLaunchKernelGGL(gq::hsq_decode_sum_batched4_kernel<false>, dim3((unsigned)blocks), dim3(gq::BT4_THREADS),
-                               (size_t)64 * 1024, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
-                               user_stride_bytes, R, codebook, n_bit, out, plain);
+            gq::launch_bt4_fixed_r<false>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, n_bit, out, plain,
+                                          gq::as_stream(stream));
     } else if (packed6) {
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched: packed levels need 4-byte aligned wires");
     } else {
