@@ -228,11 +228,12 @@ def test_hsq_device_rng_is_stochastic_rounding(nat, oracle):
 
 @pytest.mark.parametrize("R,M", [(1, 3000), (2, 3000), (3, 3000), (8, 3000), (5, 3001), (7, 2999), (9, 3000), (16, 3002),
                                  (19, 3003), (2, 1_100_003), (8, 600_001), (11, 600_002)])
-def test_hsq_decode_sum_matches_oracle_mean(nat, oracle, R, M):
-    """R <= 8: the fixed-R pipelined kernels; above: the chunked one; M % 4 != 0: the partial last group; the large M give
-    every lane several items (the words of the next item are requested while the current one is summed)."""
+def test_hsq_decode_sum_matches_oracle_mean(nat, oracle, R, M, K=256):
+    """R <= 16: the compile-time-R pipelined kernels (a team's lanes fetch different payloads' words); above: the chunked
+    one; M % 4 != 0: the partial last group; the large M give every lane several items (the words of the next item are
+    requested while the current one is summed)."""
     rng = np.random.RandomState(40 + R)
-    cb = _cb(16, 256)
+    cb = np.ascontiguousarray(_cb(16, 256)[:K])     # (any unit-norm rows do: the oracle takes the same codebook)
     dev = torch.device("cuda:0")
     codes, levels, lbub, decs = [], [], [], []
     for r in range(R):
@@ -544,3 +545,9 @@ def test_compress_and_decode_replay_from_a_hip_graph(nat):
         torch.cuda.synchronize()
         for k in ("codes", "levels", "lb_ub", "out"):
             assert torch.equal(captured[k].view(torch.uint8), eager[k].view(torch.uint8)), (trial, k)
+
+
+@pytest.mark.parametrize("R,M,K", [(1, 5003, 64), (6, 5002, 64), (13, 5001, 32)])
+def test_hsq_decode_sum_smaller_codebooks(nat, oracle, R, M, K):
+    """d = 16 with fewer than 256 codewords goes through the same kernels (the LDS image holds K rows)."""
+    test_hsq_decode_sum_matches_oracle_mean(nat, oracle, R, M, K)
