@@ -438,6 +438,17 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     lv_ms = event_ms(torch, lambda: native.hsq_levels(u, N_BIT, args.random, None, seed, partials, lb_ub, levels, packed6))
     cmp_ms = event_ms(torch, lambda: compress(next_grad()))
     dec_ms = event_ms(torch, lambda: decode(ex.gathered))
+    # the decode-mean an 8-rank step runs after its exchange (R = 8: the kernel that grows with N), on 8 copies of this
+    # rank's payload; untimed, N = 1 only (with N > 1 the step's own decode already runs over R = N payloads)
+    dec8_ms = None
+    if world == 1:
+        g8 = wire.alloc(dev, ranks=8)
+        for r in range(8):
+            g8[r].copy_(ex.gathered[0])
+        dec8_ms = event_ms(torch, lambda: native.hsq_decode_sum_packed(
+            g8, M, cb, N_BIT, out, 8, wire.codes_off, wire.levels_off, wire.lbub_off,
+            level_dtype=native.PACKED6 if packed6 else torch.uint8))
+        del g8
     exch_ms = None
     if world > 1:
         exch_ms = event_ms(torch, (lambda: [p.wait() for p in sex.start("split", cut=swire.cut)[1]]) if mode == "split"
@@ -479,7 +490,8 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
                              "start/stop events attached to the kernel's dispatch inside the timed region "
                              "(agrees with rocprofv3, profiles/); a bracket RECORDED around the call reads "
                              "kernel_ms_recorded_bracket, an empty one empty_recorded_bracket_ms"},
-        "phases_ms": {"encode": enc_ms, "levels": lv_ms, "compress": cmp_ms, "decode_mean": dec_ms, "exchange": exch_ms,
+        "phases_ms": {"encode": enc_ms, "levels": lv_ms, "compress": cmp_ms, "decode_mean": dec_ms, "decode_mean_R8": dec8_ms,
+                      "exchange": exch_ms,
                       "note": "encode: HIP events attached to the dispatch in the timed region; levels / compress / decode_mean: HIP events "
                               "around back-to-back calls on rotating inputs (untimed pass)"},
         "compress_only": {"value": world * SIZE / (cmp_ms * 1e-3), "unit": "elements/s"},
