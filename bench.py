@@ -79,6 +79,8 @@ def parse_args():
                          "auto = live at N=1 when rocprofv3 is on PATH, else the committed profiles/hbm_traffic.json")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-launches", action="store_true",
+                    help="N = 1: levels and decode as two launches (as with N > 1) instead of gq_hsq_levels_decode")
     ap.add_argument("--no-variants", action="store_true", help="skip the untimed random=2 / 1e-3-scale side measurements")
     return ap.parse_args()
 
@@ -357,11 +359,23 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
             native.hsq_decode_sum_packed(buf, swire.MB, cb, N_BIT, out[swire.MA * C_DIM:], world,
                                          swire.codes_off + swire.MA, swire.levels_b_off, swire.lbub_off)
 
+    def roundtrip(g, profile_slot=-1):
+        """One rank: decompress(compress(g)) = the encode, then level quantiser + decode as ONE launch (gq_hsq_levels_decode:
+        the same (codes, lb, ub, levels) in the wire and the same decoded tensor as the two calls, bit for bit)."""
+        native.hsq_encode(g, cb, codes, u, partials, profile_slot=profile_slot)
+        if not native.hsq_levels_decode(u, N_BIT, args.random, None, seed, partials, lb_ub, levels, codes, cb, out, packed6):
+            native.hsq_levels(u, N_BIT, args.random, None, seed, partials, lb_ub, levels, packed6)
+            decode(ex.gathered)
+
+    fused = world == 1 and not args.two_launches
+
     def step(i, mode, profile_slot=-1):
         g = grads[i % 3]
         if mode == "split":
             compress_split(g, profile_slot)
             exchange_decode_split()
+        elif fused:
+            roundtrip(g, profile_slot)
         else:
             compress(g, profile_slot)
             decode(ex.run(mode) if world > 1 else ex.gathered)
@@ -440,6 +454,8 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     dec_ms = event_ms(torch, lambda: decode(ex.gathered))
     # the decode-mean an 8-rank step runs after its exchange (R = 8: the kernel that grows with N), on 8 copies of this
     # rank's payload; untimed, N = 1 only (with N > 1 the step's own decode already runs over R = N payloads)
+    lvdec_ms = event_ms(torch, lambda: native.hsq_levels_decode(u, N_BIT, args.random, None, seed, partials, lb_ub, levels, codes, cb,
+                                                                 out, packed6)) if world == 1 else None
     dec8_ms = None
     if world == 1:
         g8 = wire.alloc(dev, ranks=8)
@@ -490,8 +506,10 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
                              "start/stop events attached to the kernel's dispatch inside the timed region "
                              "(agrees with rocprofv3, profiles/); a bracket RECORDED around the call reads "
                              "kernel_ms_recorded_bracket, an empty one empty_recorded_bracket_ms"},
-        "phases_ms": {"encode": enc_ms, "levels": lv_ms, "compress": cmp_ms, "decode_mean": dec_ms, "decode_mean_R8": dec8_ms,
-                      "exchange": exch_ms,
+        "phases_ms": {"encode": enc_ms, "levels": lv_ms, "compress": cmp_ms, "decode_mean": dec_ms, "levels_decode_fused": lvdec_ms,
+                      "decode_mean_R8": dec8_ms, "exchange": exch_ms,
+                      "step": ("encode + gq_hsq_levels_decode (level quantiser and decode of the rank's own payload in one launch)" if fused
+                               else "encode + levels + " + ("exchange + " if world > 1 else "") + "decode-mean"),
                       "note": "encode: HIP events attached to the dispatch in the timed region; levels / compress / decode_mean: HIP events "
                               "around back-to-back calls on rotating inputs (untimed pass)"},
         "compress_only": {"value": world * SIZE / (cmp_ms * 1e-3), "unit": "elements/s"},

@@ -8,6 +8,8 @@
 // Write-bound: 4 B per output element + 2R/d B of payload reads; the codebook is
 // staged in LDS once per workgroup.  -ffp-contract=off keeps mul / div / add unfused.
 #include "gq_common.hpp"
+#include "hsq_encode_common.hpp"
+#include "hsq_levels_common.hpp"
 #include <type_traits>
 
 namespace gq {
@@ -600,6 +602,134 @@ static bool launch_dec16_fixed_r(int R, const uint8_t *codes, const uint8_t *lev
     }
 }
 
+// Levels + decode of ONE payload in a single launch: decompress(compress(g)) given the encode's codes and projections
+// (nearest_neighbor_compressor.py:74-90 after the argmax; what PSQuantizer.record does for a user, ps_quantizer.py:37, and
+// what a single-rank step runs: the level kernel's 5 us are launch and round-trip latency, not work).  The kernel is
+// hsq_decode_sum_d16u8_r_kernel<1> whose level word is not loaded but worked out from the team's four projections with
+// the level kernel's own arithmetic (LevelQuant), written to the wire like the level kernel writes it, and decoded.
+// (lb, ub): every workgroup folds the encode's (min,max) partials in its prologue, under the staging of the codebook image.
+template <bool PACKED6>
+__global__ __launch_bounds__(DEC16_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void hsq_levels_decode_d16u8_kernel(
+    const float *__restrict__ u, const uint8_t *__restrict__ codes, const float *__restrict__ partials,
+    float *__restrict__ lb_ub, uint8_t *__restrict__ levels, int n_bit, int random_mode, const float *__restrict__ r,
+    uint64_t seed, const float *__restrict__ cb, int64_t M, int K, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float s_cb[];   // [K][4 copies][16] at LDS address 0, then the fold's 2 x 16 floats
+    static_assert(GQ_MAX_PARTIALS == DEC16_THREADS, "one (min,max) pair per thread");
+    const unsigned full = (unsigned)(M >> 2) * 4u;
+    const unsigned stride = gridDim.x * DEC16_THREADS;
+    unsigned i = blockIdx.x * DEC16_THREADS + threadIdx.x;
+    const int q = threadIdx.x & 3;
+    // first item's code word and projection, the partials and the codebook: one round trip for all of it
+    unsigned c4 = 0;
+    float uq = 0.0f;
+    if (i < full) {
+        c4 = *reinterpret_cast<const unsigned *>(codes + (i & ~3u));
+        uq = u[i];                 // item i = (group i >> 2, quarter q): the group's subvector q is number (i & ~3) + q = i
+    }
+    const int final_flag = ws_counter(partials)[2];
+    const float2 part = reinterpret_cast<const float2 *>(partials)[threadIdx.x];
+    constexpr int STAGE = 256 * 16 / DEC16_THREADS;
+    f32x4 stage[STAGE];
+#pragma unroll
+    for (int n = 0; n < STAGE; ++n) {
+        const int e = threadIdx.x + n * DEC16_THREADS;
+        if (e < K * 16) stage[n] = *reinterpret_cast<const f32x4 *>(cb + (e >> 4) * 16 + 4 * (e & 3));
+    }
+    float *const s_red = s_cb + K * 64;
+    {
+        float lo = wave_min(part.x), hi = wave_max(part.y);
+        if (__ballot(part.x != part.x) != 0) lo = hi = __uint_as_float(0x7FC00000u);   // a (NaN, NaN) pair: lb = ub = NaN
+        if ((threadIdx.x & 63) == 0) {
+            s_red[threadIdx.x >> 6] = lo;
+            s_red[16 + (threadIdx.x >> 6)] = hi;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < STAGE; ++n) {
+        const int e = threadIdx.x + n * DEC16_THREADS;
+        const int row = e >> 4, c = (e >> 2) & 3, qq = e & 3;
+        if (e < K * 16) *reinterpret_cast<f32x4 *>(s_cb + row * 64 + c * 16 + 4 * qq) = stage[n];
+    }
+    __syncthreads();
+    float lb, ub;
+    if (final_flag != 0) {   // the caller's final pair (gq_hsq.h)
+        lb = partials[0];
+        ub = partials[1];
+    } else {
+        lb = s_red[0];
+        ub = s_red[16];
+        bool nan = lb != lb;
+#pragma unroll
+        for (int w = 1; w < DEC16_THREADS / 64; ++w) {
+            nan = nan || (s_red[w] != s_red[w]);
+            lb = fminf(lb, s_red[w]);
+            ub = fmaxf(ub, s_red[16 + w]);
+        }
+        if (nan) lb = ub = __uint_as_float(0x7FC00000u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        lb_ub[0] = lb;
+        lb_ub[1] = ub;
+    }
+    const LevelQuant lq(lb, ub, n_bit, random_mode, r, seed);
+    const float range = ub - lb;
+    const float inv_s = 1.0f / (float)(1 << (n_bit & 31));
+    const unsigned lane_const = (unsigned)(((threadIdx.x >> 3) & 3) * 64 + 16 * q);
+    const char *const cb_bytes = reinterpret_cast<const char *>(s_cb);
+    // the four levels of a team as the word the decode reads: a byte (or 6 bits) each, OR-ed over the team by two quad-permute steps
+    auto team_levels = [&](int l) {
+        int w = PACKED6 ? ((l & 63) << (6 * q)) : ((l & 255) << (8 * q));
+        w |= __builtin_amdgcn_mov_dpp(w, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+        w |= __builtin_amdgcn_mov_dpp(w, 0x4E, 0xF, 0xF, true);   // quad_perm [2, 3, 0, 1]
+        return (unsigned)w;
+    };
+    // the last, partial group of a tensor whose M is not a multiple of 4, by the first team of workgroup 0, before the loop
+    const int nv = (int)(M & 3);
+    if (nv != 0 && blockIdx.x == 0 && threadIdx.x < 4) {
+        const int64_t m0 = (int64_t)full;
+        unsigned c = 0;
+        for (int k = 0; k < nv; ++k) c |= (unsigned)codes[m0 + k] << (8 * k);
+        const int l = q < nv ? lq.level(u[m0 + q], m0 + q) : 0;
+        const unsigned l4 = team_levels(l);
+        if (q == 0) {
+            if (PACKED6) {   // a group is always stored whole (slots past M hold 0)
+                uint8_t *dst = levels + 3 * (m0 >> 2);
+                dst[0] = (uint8_t)l4;
+                dst[1] = (uint8_t)(l4 >> 8);
+                dst[2] = (uint8_t)(l4 >> 16);
+            } else {
+                for (int k = 0; k < nv; ++k) levels[m0 + k] = (uint8_t)(l4 >> (8 * k));
+            }
+        }
+        f32x4 acc[4];
+        dec16_payload<true, PACKED6, true>(acc, c, l4, lb, range, inv_s, q, cb_bytes, lane_const);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nv) *reinterpret_cast<f32x4 *>(out + (m0 + k) * 16 + 4 * q) = acc[k];
+    }
+#pragma clang loop unroll(disable)
+    while (i < full) {
+        const unsigned nxt = i + stride;
+        const unsigned pre = nxt < full ? nxt : i;
+        const unsigned m0 = i & ~3u;
+        const unsigned l4 = team_levels(lq.level(uq, (int64_t)i));
+        if (PACKED6) {   // the group's three bytes by lanes 0..2 of the team: one byte-store instruction
+            if (q < 3) levels[3 * (m0 >> 2) + q] = (uint8_t)(l4 >> (8 * q));
+        } else if (q == 0) {
+            *reinterpret_cast<unsigned *>(levels + m0) = l4;
+        }
+        f32x4 acc[4];
+        dec16_payload<true, PACKED6, true>(acc, c4, l4, lb, range, inv_s, q, cb_bytes, lane_const);
+        c4 = *reinterpret_cast<const unsigned *>(codes + (pre & ~3u));
+        uq = u[pre];
+        float *o = out + (int64_t)m0 * 16 + 4 * q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4 *>(o + 16 * k) = acc[k];
+        i = nxt;
+    }
+}
+
 // any d: one thread per output float.
 template <typename CodeT, typename LevelT>
 __global__ __launch_bounds__(DEC_THREADS) void hsq_decode_sum_scalar_kernel(
@@ -758,4 +888,52 @@ GQ_API int gq_hsq_decode_sum(const void *codes, int code_bytes, const void *leve
                                          lb_ub, 8, codebook, R, M, d, K, n_bit, out, stream);
     return gq_hsq_decode_sum_strided(codes, code_bytes, M * (int64_t)code_bytes, levels, level_bytes, M * (int64_t)lsz,
                                      lb_ub, 8, codebook, R, M, d, K, n_bit, out, stream);
+}
+
+GQ_API int gq_hsq_levels_decode(const float *u, int64_t M, int n_bit, int random_mode, const float *r, uint64_t seed,
+                                const float *minmax_partials, float *lb_ub, void *levels, int level_bytes, const void *codes,
+                                const float *codebook, int K, float *out, void *stream) {
+    if (M < 1 || n_bit < 1 || n_bit > 8 || K < 1)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode: bad sizes M=%lld n_bit=%d K=%d", (long long)M, n_bit, K);
+    if (!u || !minmax_partials || !lb_ub || !levels || !codes || !codebook || !out)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode: null pointer");
+    if (random_mode < GQ_RANDOM_OFF || random_mode > GQ_RANDOM_DEVICE || (random_mode == GQ_RANDOM_GIVEN && !r))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode: random_mode %d", random_mode);
+    const int64_t top = ((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0);
+    if ((level_bytes == 1 && top > 255) || (level_bytes == GQ_LEVELS_PACKED6 && top > 63))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode: level_bytes=%d cannot hold level %lld", level_bytes, (long long)top);
+    const uintptr_t a4 = reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(codes) |
+                         (level_bytes == 1 ? reinterpret_cast<uintptr_t>(levels) : 0);
+    const uintptr_t a16 = reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(codebook);
+    if ((level_bytes != 1 && level_bytes != GQ_LEVELS_PACKED6) || K > 256 || (a4 & 3) || (a16 & 15) ||
+        M >= ((int64_t)1 << 31) - ((int64_t)1 << 21))
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_decode: served for d = 16, K <= 256, byte codes, byte or packed 6-bit levels, "
+                                            "4-byte aligned u / codes / levels, 16-byte aligned out / codebook (use gq_hsq_levels + gq_hsq_decode_sum)");
+    hipStream_t st = gq::as_stream(stream);
+    const size_t lds = (size_t)K * 64 * sizeof(float) + 32 * sizeof(float);
+    auto launch = [&](auto p6) {
+        constexpr bool P6 = decltype(p6)::value;
+        static const int bpc = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gq::hsq_levels_decode_d16u8_kernel<P6>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 128);
+            (void)hipGetLastError();
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gq::hsq_levels_decode_d16u8_kernel<P6>, gq::DEC16_THREADS,
+                                                             (size_t)64 * 1024 + 128) != hipSuccess || n < 1)
+                n = 1;
+            return n;
+        }();
+        const int64_t total = ((M + 3) >> 2) * 4;
+        int64_t blocks = (total + gq::DEC16_THREADS - 1) / gq::DEC16_THREADS;
+        if (blocks > (int64_t)gq::cu_count() * bpc) blocks = (int64_t)gq::cu_count() * bpc;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gq::hsq_levels_decode_d16u8_kernel<P6>), dim3((unsigned)blocks), dim3(gq::DEC16_THREADS), lds,
+                           st, u, static_cast<const uint8_t *>(codes), minmax_partials, lb_ub, static_cast<uint8_t *>(levels), n_bit,
+                           random_mode, r, seed, codebook, M, K, out);
+    };
+    if (level_bytes == GQ_LEVELS_PACKED6)
+        launch(std::true_type{});
+    else
+        launch(std::false_type{});
+    GQ_CHECK_LAUNCH("gq_hsq_levels_decode");
+    return GQ_OK;
 }

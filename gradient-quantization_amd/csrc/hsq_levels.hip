@@ -7,6 +7,7 @@
 // Built with -ffp-contract=off: sub, IEEE divide, exact *2^n_bit, truncation -- the
 // same roundings as the reference's separate elementwise ops.
 #include "hsq_encode_common.hpp"
+#include "hsq_levels_common.hpp"
 #include <type_traits>
 
 namespace gq {
@@ -80,23 +81,8 @@ __global__ __launch_bounds__(LV_THREADS) void hsq_levels_kernel(const float *__r
         lb_ub[1] = ub;
     }
 
-    const float s = (float)(1 << n_bit);
-    const float smax = s - 1.0f;
-    const float range = ub - lb;
-    const bool flat = (lb - ub) == 0.0f;  // prob_scalar:15-16 -> all zeros
-    auto level_of = [&](float uu, int64_t i) -> int {
-        if (flat) return 0;
-        const float q = (uu - lb) / range;
-        const float x = fabsf(q) * s;
-        const float c = fminf(fmaxf(x, 0.0f), smax);
-        int l = (x != x) ? INT32_MIN : (int)c;   // clamp(NaN) stays NaN and NaN -> int32 is INT_MIN in the reference (x86)
-        if (random_mode != GQ_RANDOM_OFF) {
-            const float prob = x - (float)l;
-            const float rr = (random_mode == GQ_RANDOM_GIVEN) ? r[i] : uniform01(seed, (uint64_t)i);
-            l += (prob > rr) ? 1 : 0;
-        }
-        return l;
-    };
+    const LevelQuant lq(lb, ub, n_bit, random_mode, r, seed);
+    auto level_of = [&](float uu, int64_t i) -> int { return lq.level(uu, i); };
     if constexpr (std::is_same<LevelT, Packed6>::value) {
         // four levels per thread and iteration -> one 24-bit group (a NaN quotient's INT_MIN is stored as 0, like the byte form)
         uint8_t *const sec = reinterpret_cast<uint8_t *>(levels);

@@ -21,11 +21,13 @@ ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFI
 EXPORTS = [     # every entry point include/gq_hsq.h declares (tests/test_host_logic.py compares the two lists)
     "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_workspace_bytes", "gq_profile_read",
     "gq_hsq_encode", "gq_hsq_encode_ex", "gq_hsq_levels", "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided",
+    "gq_hsq_levels_decode",
     "gq_hsq_batched_path", "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched",
     "gq_axpy_inplace", "gq_sub", "gq_mean_rows", "gq_qsgd_compress", "gq_qsgd_decode_sum", "gq_qsgd_code_bits",
     "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched", "gq_pvq_encode",
 ]
 ABI_VERSION = 2
+ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3      # GQ_ERR_* of include/gq_hsq.h
 
 _lib = None
 
@@ -170,6 +172,36 @@ def hsq_levels(u, n_bit, random_mode, r, seed, partials, lb_ub, levels, packed6=
                              _dev_ptr(levels, None, "levels"),
                              ctypes.c_int(LEVELS_PACKED6 if packed6 else _LEVEL_BYTES[levels.dtype]), _stream())
     _check(rc, "gq_hsq_levels")
+
+
+def hsq_levels_decode(u, n_bit, random_mode, r, seed, partials, lb_ub, levels, codes, codebook, out, packed6=False):
+    """gq_hsq_levels followed by gq_hsq_decode_sum (R = 1) as ONE launch: decompress(compress(g)) from the encode's
+    codes and projections.  True when the library served it (d = 16, K <= 256, byte codes, byte or packed levels, aligned
+    buffers); False -- nothing launched -- when the caller has to make the two calls."""
+    M = u.numel()
+    K, d = codebook.shape
+    if (d != 16 or K > 256 or codes.dtype != torch.uint8 or (not packed6 and levels.dtype != torch.uint8)
+            or u.data_ptr() % 4 or codes.data_ptr() % 4 or (not packed6 and levels.data_ptr() % 4) or out.data_ptr() % 16
+            or codebook.data_ptr() % 16):
+        return False
+    assert lb_ub.numel() == 2 and codes.numel() == M and out.numel() == M * d
+    if packed6:
+        assert levels.dtype == torch.uint8 and levels.numel() >= packed6_bytes(M)
+    else:
+        assert levels.numel() == M
+    rp = _dev_ptr(r, torch.float32, "r") if r is not None else ctypes.c_void_p(0)
+    if r is not None:
+        assert r.numel() == M
+    rc = lib().gq_hsq_levels_decode(_dev_ptr(u, torch.float32, "u"), ctypes.c_int64(M), ctypes.c_int(n_bit),
+                                    ctypes.c_int(random_mode), rp, ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                                    _dev_ptr(partials, torch.float32, "partials"), _dev_ptr(lb_ub, torch.float32, "lb_ub"),
+                                    _dev_ptr(levels, None, "levels"), ctypes.c_int(LEVELS_PACKED6 if packed6 else 1),
+                                    _dev_ptr(codes, None, "codes"), _dev_ptr(codebook, torch.float32, "codebook"),
+                                    ctypes.c_int(K), _dev_ptr(out, torch.float32, "out"), _stream())
+    if rc == ERR_UNSUPPORTED:
+        return False
+    _check(rc, "gq_hsq_levels_decode")
+    return True
 
 
 def minmax_partials(v, partials):

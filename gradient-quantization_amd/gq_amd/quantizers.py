@@ -201,6 +201,33 @@ class HSQCodec(object):
         """Decode this user's own payload (error feedback residual)."""
         self._decode(wire_user.view(1, -1), off, 1, out)
 
+    def encode_decode_into(self, grad, wire_user, off, salt, out, r=None):
+        """encode_into + decode_wire: decompress(compress(grad)) with the payload left in the wire (ps_quantizer.py:37).
+        Where the library serves it (d = 16, byte codes, byte or packed levels) the level quantiser and the decode are ONE
+        launch (gq_hsq_levels_decode); same bits either way."""
+        nc = getattr(self.c, "norm_compressor", None)
+        if self.c.compressed_norm and self.c.dim == 16 and self.code_dtype == torch.uint8 and grad.device.type == "cuda":
+            dev = grad.device
+            flat = grad.contiguous().view(-1)
+            codes, levels, lb_ub = self._views(wire_user, off)
+            if self.packed6 or levels.dtype == torch.uint8:
+                cbk = self.c._codebook_on(dev)
+                u, partials = self._scratch(dev)
+                if not nc.random:
+                    mode, rr, seed = native.RANDOM_OFF, None, 0
+                elif nc._rng == "reference":
+                    mode, rr, seed = native.RANDOM_GIVEN, (r if r is not None else torch.rand(self.M).to(dev)), 0
+                else:
+                    mode, rr, seed = native.RANDOM_DEVICE, None, _next_seed() ^ salt
+                native.hsq_encode(flat, cbk, codes, u, partials)
+                if native.hsq_levels_decode(u, nc.n_bit, mode, rr, seed, partials, lb_ub, levels, codes, cbk, out, self.packed6):
+                    return
+                native.hsq_levels(u, nc.n_bit, mode, rr, seed, partials, lb_ub, levels, self.packed6)
+                self.decode_wire(wire_user, off, out)
+                return
+        self.encode_into(grad, wire_user, off, salt, r)
+        self.decode_wire(wire_user, off, out)
+
     def _decode(self, gathered, off, R, out):
         P = gathered.shape[1]
         cbk = self.c._codebook_on(gathered.device)
@@ -213,9 +240,8 @@ class HSQCodec(object):
     def roundtrip(self, grad, salt, r=None):
         dev = grad.device
         tmp = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
-        self.encode_into(grad, tmp, 0, salt, r)
         out = torch.empty(self.numel, dtype=torch.float32, device=dev)
-        self.decode_wire(tmp, 0, out)
+        self.encode_decode_into(grad, tmp, 0, salt, out, r)
         return out.view(self.shape)
 
     def decode_mean(self, gathered, off, R, plain=False):
@@ -833,8 +859,12 @@ class PSQuantizer(object):
                     native.axpy_inplace(grad, param.error[user].contiguous(), scale)
                 else:
                     grad.add_(scale * param.error[user])
-                codec.encode_into(grad, wire, off, salt, **self._slice(draws, i))
-                if hasattr(codec, "decode_wire"):
+                if hasattr(codec, "encode_decode_into"):
+                    decoded = torch.empty(grad.numel(), dtype=torch.float32, device=grad.device)
+                    codec.encode_decode_into(grad, wire, off, salt, decoded, **self._slice(draws, i))
+                    decoded = decoded.view(param.shape)
+                elif hasattr(codec, "decode_wire"):
+                    codec.encode_into(grad, wire, off, salt, **self._slice(draws, i))
                     decoded = torch.empty(grad.numel(), dtype=torch.float32, device=grad.device)
                     codec.decode_wire(wire, off, decoded)
                     decoded = decoded.view(param.shape)

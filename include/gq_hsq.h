@@ -154,6 +154,16 @@ int gq_hsq_decode_sum_strided(const void *codes, int code_bytes, int64_t code_st
                               int64_t lbub_stride_bytes, const float *codebook, int R, int64_t M, int d, int K,
                               int n_bit, float *out, void *stream);
 
+/* Levels + decode of ONE payload in a single launch: decompress(compress(g)) from the encode's outputs --
+ * nearest_neighbor_compressor.py:74-78 (u -> ProbabilisticScalarCompressor.compress, probabilistic_scalar_compressor.py:12-27)
+ * followed by :80-90 (decompress), i.e. what PSQuantizer.record computes for a user (ps_quantizer.py:37) and what a
+ * single-rank step runs after its encode.  Same results as gq_hsq_levels followed by gq_hsq_decode_sum with R = 1 (lb_ub,
+ * the level section and out, bit for bit); one launch less.  d = 16 with byte codes; level_bytes 1 or GQ_LEVELS_PACKED6;
+ * K <= 256; u / codes / levels 4-byte aligned, out / codebook 16-byte aligned -- GQ_ERR_UNSUPPORTED otherwise (use the two calls). */
+int gq_hsq_levels_decode(const float *u, int64_t M, int n_bit, int random_mode, const float *r, uint64_t seed,
+                         const float *minmax_partials, float *lb_ub, void *levels, int level_bytes, const void *codes,
+                         const float *codebook, int K, float *out, void *stream);
+
 /*
  * Multi-tensor forms: ONE launch per step and operation serves every tensor of a model that shares a codebook (the
  * reference loops over parameters in Python, ps_quantizer.py:33,47).  lb / ub stay per tensor.  The tensors and the

@@ -183,6 +183,16 @@ GQ_EXPORT int gq_cpu_hsq_decode_sum(const void *codes, int code_bytes, const voi
     return GQ_OK;
 }
 
+/* gq_hsq_levels_decode: the two calls above, one after the other (R = 1, d = 16, byte codes) */
+GQ_EXPORT int gq_cpu_hsq_levels_decode(const float *u, int64_t M, int n_bit, int random_mode, const float *r, uint64_t seed,
+                                       const float *minmax_partials, float *lb_ub, void *levels, int level_bytes, const void *codes,
+                                       const float *codebook, int K, float *out, void *stream) {
+    if (level_bytes != 1 && level_bytes != GQ_LEVELS_PACKED6) return GQ_ERR_UNSUPPORTED;
+    int rc = gq_cpu_hsq_levels(u, M, n_bit, random_mode, r, seed, minmax_partials, lb_ub, levels, level_bytes, stream);
+    if (rc != GQ_OK) return rc;
+    return gq_cpu_hsq_decode_sum(codes, 1, levels, level_bytes, lb_ub, codebook, 1, M, 16, K, n_bit, out, stream);
+}
+
 /* gq_qsgd_compress: qsgd_compressor.py:47-64 */
 GQ_EXPORT int gq_cpu_qsgd_compress(const float *grad, int64_t Mb, int d, int n_bit, int random_mode, const float *r,
                                    uint64_t seed, float *norm, uint8_t *signs, void *levels, int level_bytes,

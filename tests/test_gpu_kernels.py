@@ -551,3 +551,48 @@ def test_compress_and_decode_replay_from_a_hip_graph(nat):
 def test_hsq_decode_sum_smaller_codebooks(nat, oracle, R, M, K):
     """d = 16 with fewer than 256 codewords goes through the same kernels (the LDS image holds K rows)."""
     test_hsq_decode_sum_matches_oracle_mean(nat, oracle, R, M, K)
+
+
+@pytest.mark.parametrize("n_bit,random,packed6,M", [(6, 0, False, 70_003), (6, 2, False, 4098), (5, 1, True, 100_001), (6, 0, True, 1_300_002),
+                                                    (2, 1, False, 5), (8, 0, False, 64 * 1000), (7, 1, False, 9_999), (6, 0, False, 3)])
+def test_fused_levels_decode_equals_the_two_calls(nat, n_bit, random, packed6, M):
+    """gq_hsq_levels_decode == gq_hsq_levels followed by gq_hsq_decode_sum (R = 1): lb_ub, the level section and the decoded
+    tensor bit for bit -- deterministic, given draws, device draws; byte and packed levels; ragged and multi-item M."""
+    dev = torch.device("cuda:0")
+    cb = torch.from_numpy(_cb(16, 256)).to(dev)
+    torch.manual_seed(n_bit * 100 + random)
+    x = torch.randn(M * 16, device=dev) * 0.03
+    codes = torch.empty(M, dtype=torch.uint8, device=dev)
+    u = torch.empty(M, dtype=torch.float32, device=dev)
+    ws = nat.new_workspace(dev, M)
+    nat.hsq_encode(x, cb, codes, u, ws)
+    r = torch.rand(M, device=dev) if random == 1 else None
+    nlev = nat.packed6_bytes(M) + 4 if packed6 else M
+    res = []
+    for fused in (False, True):
+        lb_ub = torch.zeros(2, dtype=torch.float32, device=dev)
+        levels = torch.zeros(nlev, dtype=torch.uint8, device=dev)
+        out = torch.full((M * 16,), 7.0, dtype=torch.float32, device=dev)
+        if fused:
+            assert nat.hsq_levels_decode(u, n_bit, random, r, 99, ws, lb_ub, levels, codes, cb, out, packed6)
+        else:
+            nat.hsq_levels(u, n_bit, random, r, 99, ws, lb_ub, levels, packed6)
+            if packed6:
+                _decode_packed_unaligned(nat, codes, levels, lb_ub, cb, n_bit, out, M)
+            else:
+                nat.hsq_decode_sum(codes, levels, lb_ub, cb, n_bit, out, R=1)
+        torch.cuda.synchronize()
+        res.append((lb_ub.clone(), levels.clone(), out.clone()))
+    for a, b, name in zip(res[0], res[1], ("lb_ub", "levels", "out")):
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), name
+
+
+def _decode_packed_unaligned(nat, codes, levels, lb_ub, cb, n_bit, out, M):
+    """gq_hsq_decode_sum_strided with level_bytes = GQ_LEVELS_PACKED6 on separate buffers."""
+    import ctypes
+    L = nat.lib()
+    rc = L.gq_hsq_decode_sum_strided(ctypes.c_void_p(codes.data_ptr()), 1, ctypes.c_int64(M), ctypes.c_void_p(levels.data_ptr()),
+                                     nat.LEVELS_PACKED6, ctypes.c_int64(levels.numel()), ctypes.c_void_p(lb_ub.data_ptr()),
+                                     ctypes.c_int64(8), ctypes.c_void_p(cb.data_ptr()), 1, ctypes.c_int64(M), 16, 256, n_bit,
+                                     ctypes.c_void_p(out.data_ptr()), None)
+    assert rc == 0, L.gq_last_error()
