@@ -51,6 +51,8 @@ while time.time() - t0 < budget:
     rounds += 1
     hsq = rng.random() < 0.6
     users, steps = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    if rng.random() < 0.15:      # every decode-mean kernel: compile-time R up to 16, the chunked form above
+        users = int(rng.choice([4, 5, 7, 8, 9, 12, 16, 17, 21]))
     extra = [{}, {"ef": True}, {"ef": True, "two_phase": True}, {"two_phase": True}, {"mode": "ring"},
              {"mode": "ring", "ef": True}][int(rng.integers(0, 6))]
     if hsq:
