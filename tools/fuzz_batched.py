@@ -80,6 +80,9 @@ while time.time() - t0 < budget:
         shapes.append((m * d,) if rng.random() < 0.5 else (m, d))
     shapes.append((10,))
     kw.update(extra)
+    total = sum(int(np.prod(sh)) for sh in shapes)
+    if total * 4 * (users + 8) * 2 > 120e9:      # both quantizers alive at once: parameters, gradients, residuals per user, two
+        continue                                  # output buffers, clones -- a round of 4 GB tensors does not fit the 288 GB
     try:
         qb, gb = run(comp, shapes, users, rounds, steps, **kw)
         qp, gp = run(comp, shapes, users, rounds, steps, gq_no_batch=True, **kw)
