@@ -79,6 +79,7 @@ def parse_args():
                          "auto = live at N=1 when rocprofv3 is on PATH, else the committed profiles/hbm_traffic.json")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scaling", action="store_true", help="print the CPU oracle's thread scaling on this host and exit (no GPU work)")
     ap.add_argument("--two-launches", action="store_true",
                     help="N = 1: levels and decode as two launches (as with N > 1) instead of gq_hsq_levels_decode")
     ap.add_argument("--no-variants", action="store_true", help="skip the untimed random=2 / 1e-3-scale side measurements")
@@ -165,6 +166,31 @@ def cpu_baseline(g_host, cb):
                                          "this box (BASELINE.md section 2); it cannot travel to the GPU box"}}
 
 
+def cpu_scaling(g_host, cb):
+    """`--cpu-scaling`: the cpu_baseline leg's thread sweep (what the oracle makes of 1 .. all host threads on this box),
+    printed as a table instead of the JSON line.  Part of the CPU-baseline leg: the only place besides it that runs the oracle."""
+    import oracle
+    oracle.build()
+    print("os.cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)), "usable", usable_cpus())
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        if os.path.exists(f):
+            print(f, open(f).read().strip())
+    for th in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+        if th > os.cpu_count():
+            break
+        oracle.set_num_threads(th)
+        oracle.hsq_compress(g_host[:16 * 100000], cb, N_BIT, 0)
+        best_e = best_c = 1e9
+        for _ in range(3):
+            t = time.perf_counter()
+            oracle.hsq_encode(g_host, cb)
+            best_e = min(best_e, time.perf_counter() - t)
+            t = time.perf_counter()
+            oracle.hsq_compress(g_host, cb, N_BIT, 0)
+            best_c = min(best_c, time.perf_counter() - t)
+        print("threads %3d  encode %8.1f M elements/s  compress %8.1f M elements/s" % (th, SIZE / 1e6 / best_e, SIZE / 1e6 / best_c))
+
+
 def live_traffic(workload, kernel_match):
     """HBM bytes per launch of the kernels whose name contains `kernel_match`, from PMC counters collected NOW: two
     child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE do not fit one pass), a few steps each.
@@ -248,6 +274,11 @@ def main():
     args.gpus = world
 
     import numpy as np
+    if args.cpu_scaling:     # the CPU-baseline leg's thread sweep: host only
+        sys.path.insert(0, os.path.join(ROOT, "gradient-quantization_amd"))
+        from gq_amd.codebook import load_codebook
+        cpu_scaling(np.random.RandomState(1234).standard_normal(SIZE).astype(np.float32), load_codebook(C_DIM, 1 << K_BIT))
+        return
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback)")
