@@ -526,9 +526,13 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
                      "algorithmic_bytes": ALGO_BYTES_PER_ELEM * SIZE,
                      "frac_compress": achieved_compress / HBM_PEAK_GBS, "achieved_compress": achieved_compress,
                      "compress_ms": cmp_ms,
+                     # the whole timed step against the roofline: compress (4.125 B/element) + decode-mean over `world` payloads
+                     # ((2 * world / 16 + 4) B per output element), exchange bytes not counted
+                     "frac_step": (ALGO_BYTES_PER_ELEM + 2.0 * world / 16 + 4.0) * SIZE / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "frac_is": "frac = the dominant kernel alone (4.125 B x 25e6 / kernel_ms / peak); frac_compress = SURVEY 8(d)'s "
                                 "definition, the whole compress: 4.125 B x 25e6 / (encode + levels, HIP events around "
-                                "back-to-back pairs on rotating inputs) / peak",
+                                "back-to-back pairs on rotating inputs) / peak; frac_step = (4.125 + 2 R / 16 + 4) B x 25e6 / ms_per_step "
+                                "/ peak, the timed step's algorithmic bytes (compress + decode-mean of R = n_gpus payloads)",
                      "kernel": "gq_hsq_encode = hsq_encode_pf_kernel (one launch: prefilter, exact rescoring, in-place exact fix-up; levels: a second launch)",
                      "kernel_ms": enc_ms, "kernel_ms_back_to_back": enc_b2b_ms,
                      "kernel_ms_recorded_bracket": enc_bracket_ms, "empty_recorded_bracket_ms": ev_overhead_ms,
