@@ -596,3 +596,8 @@ def _decode_packed_unaligned(nat, codes, levels, lb_ub, cb, n_bit, out, M):
                                      ctypes.c_int64(8), ctypes.c_void_p(cb.data_ptr()), 1, ctypes.c_int64(M), 16, 256, n_bit,
                                      ctypes.c_void_p(out.data_ptr()), None)
     assert rc == 0, L.gq_last_error()
+
+
+def test_hsq_decode_sum_more_than_1024_payloads(nat, oracle):
+    """R above what the pipelined kernels hold (lb, ub) for in LDS goes through the generic d = 16 kernel."""
+    test_hsq_decode_sum_matches_oracle_mean(nat, oracle, 1025, 260)
