@@ -555,13 +555,19 @@ def test_hsq_decode_sum_smaller_codebooks(nat, oracle, R, M, K):
 
 @pytest.mark.parametrize("n_bit,random,packed6,M", [(6, 0, False, 70_003), (6, 2, False, 4098), (5, 1, True, 100_001), (6, 0, True, 1_300_002),
                                                     (2, 1, False, 5), (8, 0, False, 64 * 1000), (7, 1, False, 9_999), (6, 0, False, 3)])
-def test_fused_levels_decode_equals_the_two_calls(nat, n_bit, random, packed6, M):
+def test_fused_levels_decode_equals_the_two_calls(nat, n_bit, random, packed6, M, special=None):
     """gq_hsq_levels_decode == gq_hsq_levels followed by gq_hsq_decode_sum (R = 1): lb_ub, the level section and the decoded
     tensor bit for bit -- deterministic, given draws, device draws; byte and packed levels; ragged and multi-item M."""
     dev = torch.device("cuda:0")
     cb = torch.from_numpy(_cb(16, 256)).to(dev)
     torch.manual_seed(n_bit * 100 + random)
     x = torch.randn(M * 16, device=dev) * 0.03
+    if special == "zeros":          # lb == ub: probabilistic_scalar_compressor.py:15-16, all levels 0
+        x.zero_()
+    elif special == "nan":          # a NaN projection: lb = ub = NaN, every level the byte of INT_MIN, the decode NaN
+        x[16 * (M // 2) + 3] = float("nan")
+    elif special == "inf":
+        x[5] = float("inf")
     codes = torch.empty(M, dtype=torch.uint8, device=dev)
     u = torch.empty(M, dtype=torch.float32, device=dev)
     ws = nat.new_workspace(dev, M)
@@ -601,3 +607,10 @@ def _decode_packed_unaligned(nat, codes, levels, lb_ub, cb, n_bit, out, M):
 def test_hsq_decode_sum_more_than_1024_payloads(nat, oracle):
     """R above what the pipelined kernels hold (lb, ub) for in LDS goes through the generic d = 16 kernel."""
     test_hsq_decode_sum_matches_oracle_mean(nat, oracle, 1025, 260)
+
+
+@pytest.mark.parametrize("special", ["zeros", "nan", "inf"])
+@pytest.mark.parametrize("packed6", [False, True])
+def test_fused_levels_decode_degenerate_inputs(nat, special, packed6):
+    """All-zero gradient (lb == ub), a NaN and an infinite element: the fused launch and the two calls still agree on every bit."""
+    test_fused_levels_decode_equals_the_two_calls(nat, 6, 0, packed6, 4099, special)
