@@ -118,6 +118,17 @@ __device__ __forceinline__ unsigned load_packed6(const uint8_t *src) {
     return w;
 }
 
+// lane t of every aligned team of four lanes broadcasts its word to the team (quad_perm [t, t, t, t]); all four lanes active
+__device__ __forceinline__ unsigned team_word(unsigned w, int t) {
+    const int x = (int)w;
+    switch (t) {
+        case 0: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0x00, 0xF, 0xF, true);
+        case 1: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0x55, 0xF, 0xF, true);
+        case 2: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0xAA, 0xF, 0xF, true);
+        default: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0xFF, 0xF, 0xF, true);
+    }
+}
+
 // Counter-based uniform [0,1) generator for GQ_RANDOM_DEVICE: a 32-bit avalanche hash (two
 // multiply-xorshift rounds, then a third round that folds in the upper halves) of (seed, index); the top
 // 24 bits -> k * 2^-24, the same grid of values torch.rand produces for float32.  ~12 VALU operations --

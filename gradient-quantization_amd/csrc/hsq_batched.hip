@@ -262,17 +262,6 @@ __device__ __forceinline__ void bt4_payload(f32x4 (&acc)[4], unsigned c4, unsign
     }
 }
 
-// lane t of every team of four broadcasts its word (quad_perm [t, t, t, t])
-__device__ __forceinline__ unsigned bt4_team_word(unsigned w, int t) {
-    const int x = (int)w;
-    switch (t) {
-        case 0: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0x00, 0xF, 0xF, true);
-        case 1: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0x55, 0xF, 0xF, true);
-        case 2: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0xAA, 0xF, 0xF, true);
-        default: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0xFF, 0xF, 0xF, true);
-    }
-}
-
 // The same for a compile-time payload count R <= BT4_RMAX, software-pipelined across a wave's tiles like
 // hsq_decode_sum_d16u8_r_kernel (hsq_decode.hip): a wave's 64 items are exactly one tile, so the segment record of a tile
 // is wave-uniform -- it is fetched by scalar loads two tiles ahead, the (code, level) words and (lb, ub) of the NEXT tile
@@ -398,7 +387,7 @@ void hsq_decode_sum_batched4_r_kernel(
         f32x4 acc[4];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const unsigned c4 = bt4_team_word(cw[r >> 2], r & 3), l4 = bt4_team_word(lw[r >> 2], r & 3);
+            const unsigned c4 = team_word(cw[r >> 2], r & 3), l4 = team_word(lw[r >> 2], r & 3);
             if (r == 0)
                 bt4_payload<true, PACKED6, true>(acc, c4, l4, lb[r], ub[r], inv_s, q, cb_bytes, lane_const);
             else
@@ -592,9 +581,10 @@ static void launch_bt4_rc(int R, const int64_t *seg_table, const int32_t *tile_s
 template <bool P6>
 static void launch_bt4_fixed_r(int R, const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
                                int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st) {
-    // (the lane's payload inside a group of four travels in the 32-bit offset of its loads: 3 strides + a payload must fit)
-    if (user_stride < 0 || 4 * user_stride >= ((int64_t)1 << 32)) R = BT4_RMAX + 1;
-    switch (R) {
+    // (the lane's payload inside a group of four travels in the 32-bit offset of its loads: 3 strides + a payload must fit;
+    // wires of a gigabyte and more per user take the chunked kernel, whose bases are 64-bit)
+    const bool fits32 = user_stride >= 0 && 4 * user_stride < ((int64_t)1 << 32);
+    switch (fits32 ? R : 0) {
 #define GQ_BT4_CASE(N) case N: launch_bt4_r<N, P6>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st); return;
         GQ_BT4_CASE(1) GQ_BT4_CASE(2) GQ_BT4_CASE(3) GQ_BT4_CASE(4)
         GQ_BT4_CASE(5) GQ_BT4_CASE(6) GQ_BT4_CASE(7) GQ_BT4_CASE(8)

@@ -268,17 +268,6 @@ constexpr int DEC16_RMAX = 16;
 #define GQ_DEC16R_WAVES 8
 #endif
 
-// lane t of every team of four broadcasts its word (quad_perm [t, t, t, t])
-__device__ __forceinline__ unsigned team_word(unsigned w, int t) {
-    const int x = (int)w;
-    switch (t) {
-        case 0: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0x00, 0xF, 0xF, true);
-        case 1: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0x55, 0xF, 0xF, true);
-        case 2: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0xAA, 0xF, 0xF, true);
-        default: return (unsigned)__builtin_amdgcn_mov_dpp(x, 0xFF, 0xF, 0xF, true);
-    }
-}
-
 template <int R, bool PACKED6>
 __global__ __launch_bounds__(DEC16_THREADS) __attribute__((amdgpu_waves_per_eu(GQ_DEC16R_WAVES, GQ_DEC16R_WAVES)))
 void hsq_decode_sum_d16u8_r_kernel(
