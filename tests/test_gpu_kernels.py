@@ -614,3 +614,39 @@ def test_hsq_decode_sum_more_than_1024_payloads(nat, oracle):
 def test_fused_levels_decode_degenerate_inputs(nat, special, packed6):
     """All-zero gradient (lb == ub), a NaN and an infinite element: the fused launch and the two calls still agree on every bit."""
     test_fused_levels_decode_equals_the_two_calls(nat, 6, 0, packed6, 4099, special)
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 63, 4097, 70_002])
+@pytest.mark.parametrize("R", [1, 3, 8, 13])
+def test_decode_and_fused_kernels_write_nothing_past_their_buffers(nat, M, R):
+    """Canaries right behind `out` (and behind the level section of the fused launch): the partial last group and the
+    re-requests of the last item must not reach past M subvectors."""
+    dev = torch.device("cuda:0")
+    cb = torch.from_numpy(_cb(16, 256)).to(dev)
+    torch.manual_seed(M + R)
+    x = torch.randn(M * 16, device=dev) * 0.1
+    codes = torch.empty(M, dtype=torch.uint8, device=dev)
+    u = torch.empty(M, dtype=torch.float32, device=dev)
+    ws = nat.new_workspace(dev, M)
+    nat.hsq_encode(x, cb, codes, u, ws)
+    CAN = 256
+    big_out = torch.full((M * 16 + CAN,), 12345.0, dtype=torch.float32, device=dev)
+    out = big_out[:M * 16]
+    for packed6 in (False, True):
+        nlev = nat.packed6_bytes(M) if packed6 else M
+        big_lv = torch.full((nlev + CAN,), 0xA5, dtype=torch.uint8, device=dev)
+        lb_ub = torch.zeros(2, dtype=torch.float32, device=dev)
+        if R == 1:
+            assert nat.hsq_levels_decode(u, 6, 0, None, 0, ws, lb_ub, big_lv[:nlev + (4 if packed6 else 0)] if packed6 else big_lv[:nlev],
+                                         codes, cb, out, packed6)
+            torch.cuda.synchronize()
+            assert bool((big_lv[nlev:] == 0xA5).all()), "fused launch wrote past the level section"
+            assert bool((big_out[M * 16:] == 12345.0).all()), "fused launch wrote past out"
+        if not packed6:
+            levels = torch.empty(M, dtype=torch.uint8, device=dev)
+            nat.hsq_levels(u, 6, 0, None, 0, ws, lb_ub, levels)
+            cR, lR, bR = codes.repeat(R), levels.repeat(R), lb_ub.repeat(R)
+            big_out.fill_(12345.0)
+            nat.hsq_decode_sum(cR, lR, bR, cb, 6, out, R=R)
+            torch.cuda.synchronize()
+            assert bool((big_out[M * 16:] == 12345.0).all()), "decode-mean wrote past out"
