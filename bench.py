@@ -545,8 +545,10 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
                       "decode_mean_R8": dec8_ms, "exchange": exch_ms,
                       "step": ("encode + gq_hsq_levels_decode (level quantiser and decode of the rank's own payload in one launch)" if fused
                                else "encode + levels + " + ("exchange + " if world > 1 else "") + "decode-mean"),
-                      "note": "encode: HIP events attached to the dispatch in the timed region; levels / compress / decode_mean: HIP events "
-                              "around back-to-back calls on rotating inputs (untimed pass)"},
+                      "note": "encode: HIP events attached to the dispatch in the timed region; levels / compress / decode_mean / "
+                              "levels_decode_fused: HIP events around back-to-back calls on rotating inputs (untimed pass), i.e. launch to "
+                              "launch; in the step the start of a kernel overlaps the drain of the one before it, so the phases of a step "
+                              "can add up to ~1 us more than ms_per_step"},
         "compress_only": {"value": world * SIZE / (cmp_ms * 1e-3), "unit": "elements/s"},
         "ranks_bit_identical": identical,
     }
