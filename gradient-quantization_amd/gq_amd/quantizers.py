@@ -736,6 +736,8 @@ class PSQuantizer(object):
                 if len(idx) >= 2 and not getattr(args, "gq_no_batch", False):
                     self._groups.append([cls, idx, None])
         self.batch_idx = [i for g in self._groups for i in g[1]]
+        self._pick_dense = operator.itemgetter(*self.dense_idx) if len(self.dense_idx) >= 2 else None
+        self._pick_group = {}
         # gq_rng = "reference": the reference draws r = torch.rand(M) per compressed tensor, in parameter order, from
         # the CPU generator (probabilistic_scalar_compressor.py:23).  torch.rand is one sequential stream, so ONE
         # torch.rand(sum of M) per record (and one per two-phase apply) gives every tensor the same numbers; the
@@ -822,7 +824,10 @@ class PSQuantizer(object):
             cls, idxs, obj = grp
             if obj is None:
                 obj = grp[2] = cls(self.codecs, self.offsets, idxs, dev, self.capacity, self.user_bytes)
-            grads = [all_grads[i] for i in idxs]
+            pick = self._pick_group.get(id(grp))      # operator.itemgetter over the group's indices, built once
+            if pick is None:
+                pick = self._pick_group[id(grp)] = operator.itemgetter(*idxs)     # (a group has at least two tensors)
+            grads = list(pick(all_grads))
             # error feedback (ps_quantizer.py:35,39) rides in the same launches: grad += scale*error
             # before the encode, error = grad - decoded after it, both in place
             errs = [self.parameters[i].error[user] for i in idxs] if self.error_feedback else None
@@ -843,7 +848,7 @@ class PSQuantizer(object):
                 self._dense_in = {k: v for k, v in self._dense_in.items() if k[0] == key[0]}   # drop a replaced wire's
                 self._dense_in[key] = views
             with torch.no_grad():
-                torch._foreach_copy_(views, [all_grads[i] for i in self.dense_idx])
+                torch._foreach_copy_(views, list(self._pick_dense(all_grads)))
             skip.update(self.dense_idx)
         if len(skip) == self.num_layers:     # the usual case: everything went through the multi-tensor launches
             self.recorded += 1
