@@ -79,6 +79,9 @@ def parse_args():
                          "auto = live at N=1 when rocprofv3 is on PATH, else the committed profiles/hbm_traffic.json")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="--workload resnet50 / qsgd: record()'s device work replays from a HIP graph per set of gradient addresses "
+                         "(gq_graph; stochastic rounding with draws keyed by each tensor's (lb, ub), gq_rng='keyed')")
     ap.add_argument("--cpu-scaling", action="store_true", help="print the CPU oracle's thread scaling on this host and exit (no GPU work)")
     ap.add_argument("--two-launches", action="store_true",
                     help="N = 1: levels and decode as two launches (as with N > 1) instead of gq_hsq_levels_decode")
@@ -588,11 +591,14 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
     if hsq:     # README: --quantizer hsq --network resnet50 --c-dim 16 --k-bit 8 --n-bit 6 (--random defaults to True)
         qargs = Namespace(c_dim=C_DIM, k_bit=K_BIT, n_bit=N_BIT, no_cuda=False, random=1, ef=False, two_phase=False,
                           scale="exp", num_users=1, mode="ps", cr=256)
+
         Comp = NearestNeighborCompressor
     else:       # README: --quantizer qsgd --c-dim 128 --n-bit 2
         qargs = Namespace(c_dim=128, k_bit=8, n_bit=2, no_cuda=False, random=1, ef=False, two_phase=False, scale="exp",
                           num_users=1, mode="ps", cr=256)
         Comp = QSGDCompressor
+    if args.graph:      # stochastic rounding with draws keyed by each tensor's (lb, ub) / each bucket's norm: launches that never change
+        qargs.gq_graph, qargs.gq_rng = True, "keyed"
     params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
     os.environ["GQ_EXCHANGE"] = args.exchange
     os.environ["GQ_WIRE_LEVELS"] = args.wire_levels      # (auto: packed6 for N > 1.)  packed6 applies where the top level is <= 63 (not with the README's --random 1 at n_bit 6)
@@ -618,7 +624,7 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
     # HIP events attached to the dominant kernel's dispatch on up to 16 of the timed steps (HSQ: the multi-tensor
     # prefilter encode takes them: gq_hsq_batch.profile_slot)
     stride = max(1, -(-args.steps // 16))
-    armed = list(range(0, args.steps, stride))[:16] if hsq else []
+    armed = list(range(0, args.steps, stride))[:16] if (hsq and not args.graph) else []     # (a replayed graph has no armed dispatch)
     slot_of = {prewarm + args.warmup + i: k for k, i in enumerate(armed)}
     Grp = BatchedHSQ if hsq else BatchedQSGD
     grp = [g[2] for g in q._groups if isinstance(g[2], Grp) and not getattr(g[2], "wide", False)][0]
@@ -642,6 +648,12 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
     gl = [params[i].grad.data for i in grp.idxs]
     wire0 = q._wire[0]
     cmp_ms = event_ms(torch, lambda: grp.encode(gl, wire0, 0, 0))       # HSQ: encode + levels; QSGD: the one compress launch
+    if hsq and args.graph:      # the encode's own time from armed dispatches of eager calls after the timed region
+        armed = list(range(8))
+        for k in armed:
+            grp.profile_slot = k
+            grp.encode(gl, wire0, 0, 0)
+        torch.cuda.synchronize()
     k_elems = sum(cd.numel for cd in grp.codecs)
     dec_ms = event_ms(torch, lambda: grp.decode_mean(q._wire[:1], 1))
     exch_ms = None

@@ -118,6 +118,12 @@ __device__ __forceinline__ unsigned load_packed6(const uint8_t *src) {
     return w;
 }
 
+// GQ_RANDOM_DEVICE_KEYED: the seed of a tensor's stream from the caller's seed and the bits of the tensor's (lb, ub)
+__device__ __forceinline__ uint64_t keyed_seed(uint64_t seed, float lb, float ub) {
+    const uint64_t k = ((uint64_t)__float_as_uint(lb) << 32) | (uint64_t)__float_as_uint(ub);
+    return seed ^ (k * 0x9E3779B97F4A7C15ull) ^ (k >> 29);
+}
+
 // lane t of every aligned team of four lanes broadcasts its word to the team (quad_perm [t, t, t, t]); all four lanes active
 __device__ __forceinline__ unsigned team_word(unsigned w, int t) {
     const int x = (int)w;

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
         }
         const float range = ub - lb;
         const bool flat = (lb - ub) == 0.0f;
+        const uint64_t sd = random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, lb, ub) : seed;
         const f32x4 uu = *reinterpret_cast<const f32x4 *>(u_flat + 4 * i);
         typename std::conditional<std::is_same<LevelT, Packed6>::value, int, LevelT>::type out[4];   // Packed6: past-the-end slots stay 0
 #pragma unroll
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
                 l = (x != x) ? INT32_MIN : (int)c;   // clamp(NaN) stays NaN and NaN -> int32 is INT_MIN in the reference (x86)
                 if (random_mode != GQ_RANDOM_OFF) {   // GIVEN: the reference's draws, laid out like u_flat
                     const float prob = x - (float)l;
-                    const float rr = random_mode == GQ_RANDOM_GIVEN ? r_flat[4 * i + e] : uniform01(seed, (uint64_t)(4 * i + e));
+                    const float rr = random_mode == GQ_RANDOM_GIVEN ? r_flat[4 * i + e] : uniform01(sd, (uint64_t)(4 * i + e));
                     l += (prob > rr) ? 1 : 0;
                 }
             }
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_kernel(
             l = (x != x) ? INT32_MIN : (int)c;   // clamp(NaN) stays NaN and NaN -> int32 is INT_MIN in the reference (x86)
             if (random_mode != GQ_RANDOM_OFF) {   // GIVEN: the reference's draws, laid out like u_flat
                 const float prob = x - (float)l;
-                const float rr = random_mode == GQ_RANDOM_GIVEN ? r_flat[g] : uniform01(seed, (uint64_t)g);
+                const float rr = random_mode == GQ_RANDOM_GIVEN ? r_flat[g] : uniform01(random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, lb, ub) : seed, (uint64_t)g);
                 l += (prob > rr) ? 1 : 0;
             }
         }
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_d_kernel(
             l = (x != x) ? INT32_MIN : (int)c;   // clamp(NaN) stays NaN and NaN -> int32 is INT_MIN in the reference (x86)
             if (random_mode != GQ_RANDOM_OFF) {   // GIVEN: the reference's draws, laid out like u_flat
                 const float prob = x - (float)l;
-                const float rr = random_mode == GQ_RANDOM_GIVEN ? r_flat[g] : uniform01(seed, (uint64_t)g);
+                const float rr = random_mode == GQ_RANDOM_GIVEN ? r_flat[g] : uniform01(random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, lb, ub) : seed, (uint64_t)g);
                 l += (prob > rr) ? 1 : 0;
             }
         }

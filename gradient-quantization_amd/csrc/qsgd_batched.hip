@@ -25,7 +25,7 @@ __device__ __forceinline__ unsigned qsgd_code(float v, float norm, float s, floa
     if (x == x) {  // NaN (zero bucket) -> level 0
         const float c = fminf(fmaxf(x, 0.0f), smax);
         l = (unsigned)(int)c;
-        if (random_mode == GQ_RANDOM_DEVICE) {
+        if (random_mode >= GQ_RANDOM_DEVICE) {   // DEVICE, or DEVICE_KEYED with the bucket's keyed seed handed in
             const float prob = x - (float)l;
             l += (prob > uniform01(seed, gidx)) ? 1u : 0u;
         }
@@ -71,11 +71,12 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
         mx = wave_max_nan(mx);
         if (lane == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = mx;
         const uint64_t g0 = (uint64_t)b << 20;  // RNG stream index: unique per (bucket, element)
+        const uint64_t sd = random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, mx, mx) : seed;   // keyed by the bucket's norm
         uint8_t *dst = wire + rec[4] + ((lb * d * bits) >> 3);
         for (int e = 2 * lane; e < d; e += 128) {
             const float2 p = load(e);
-            const unsigned c0 = qsgd_code(p.x, mx, s, smax, random_mode, seed, g0 + e, bits);
-            const unsigned c1 = qsgd_code(p.y, mx, s, smax, random_mode, seed, g0 + e + 1, bits);
+            const unsigned c0 = qsgd_code(p.x, mx, s, smax, random_mode, sd, g0 + e, bits);
+            const unsigned c1 = qsgd_code(p.y, mx, s, smax, random_mode, sd, g0 + e + 1, bits);
             if (bits == 4) {
                 dst[e >> 1] = (uint8_t)(c0 | (c1 << 4));
             } else if (bits == 8) {
@@ -174,10 +175,11 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
             for (int o = 8; o > 0; o >>= 1) m2 = max_nan(m2, __shfl_xor(m2, o, 64));
             if (c0 == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = m2;
             uint8_t *dst2 = wire + rec[4] + ((lb * d) >> 1);
+            const uint64_t sd2 = random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, m2, m2) : seed;
             for (int e = 2 * c0; e < d; e += 32) {
                 const float2 p = load(e);
-                const unsigned k0 = qsgd_code(p.x, m2, s, smax, random_mode, seed, ((uint64_t)b << 20) + e, 4);
-                const unsigned k1 = qsgd_code(p.y, m2, s, smax, random_mode, seed, ((uint64_t)b << 20) + e + 1, 4);
+                const unsigned k0 = qsgd_code(p.x, m2, s, smax, random_mode, sd2, ((uint64_t)b << 20) + e, 4);
+                const unsigned k1 = qsgd_code(p.y, m2, s, smax, random_mode, sd2, ((uint64_t)b << 20) + e + 1, 4);
                 dst2[e >> 1] = (uint8_t)(k0 | (k1 << 4));
                 if (EF && err) {
                     float t0 = (float)(k0 & 7u) * (2.0f * (float)(k0 >> 3) - 1.0f);
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
         for (int o = 8; o > 0; o >>= 1) mx = max_nan(mx, __shfl_xor(mx, o, 64));   // the bucket's 16 lanes
         if (live && c0 == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = mx;
         const uint64_t g0 = (uint64_t)b << 20;  // RNG stream index: unique per (bucket, element)
+        const uint64_t sd = random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, mx, mx) : seed;   // keyed by the bucket's norm
         uint8_t *dst = wire + rec[4] + ((lb * d) >> 1);
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc) {
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const float val = x[jc][k >> 2][k & 3];
-                    const unsigned c = qsgd_code(val, mx, s, smax, random_mode, seed, g0 + e + k, 4);
+                    const unsigned c = qsgd_code(val, mx, s, smax, random_mode, sd, g0 + e + k, 4);
                     word |= c << (4 * k);
                     if (EF) {
                         // qsgd_compressor.py:69-70 on this element's own code (sign on the float's sign bit)
@@ -596,8 +599,8 @@ static int qsgd_compress_batched(const char *what, const int64_t *seg_table, con
                                  uint8_t *wire, void *stream) {
     if (nseg < 1 || nbuckets < 1 || n_bit < 1) return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes", what);
     if (!seg_table || !bucket_seg || !wire) return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
-    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
-        return fail(GQ_ERR_UNSUPPORTED, "%s: random_mode must be OFF or DEVICE", what);
+    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE && random_mode != GQ_RANDOM_DEVICE_KEYED)
+        return fail(GQ_ERR_UNSUPPORTED, "%s: random_mode must be OFF, DEVICE or DEVICE_KEYED", what);
     const int bits = gq_qsgd_code_bits(n_bit, random_mode);
     if (!bits) return fail(GQ_ERR_UNSUPPORTED, "%s: n_bit %d has no packed format", what, n_bit);
     if (bits == 4 && nseg <= QB_LDS_SEGS) {

@@ -121,7 +121,7 @@ __device__ __forceinline__ unsigned wide_code(float v, float norm, float s, floa
     if (x == x) {  // NaN (zero bucket) -> level 0
         const float c = fminf(fmaxf(x, 0.0f), smax);
         l = (unsigned)(int)c;
-        if (random_mode == GQ_RANDOM_DEVICE) {
+        if (random_mode >= GQ_RANDOM_DEVICE) {   // DEVICE, or DEVICE_KEYED with the keyed seed handed in
             const float prob = x - (float)l;
             l += (prob > uniform01(seed, gidx)) ? 1u : 0u;
         }
@@ -152,6 +152,7 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_quantise_kernel(
         uint8_t *dst = wire + it.rec[4] + ((at * BITS) >> 3);
         const bool dwords = ((at & 7) == 0);                       // code dwords of whole 8-element groups are aligned
         const uint64_t g0 = ((uint64_t)(it.rec[6] + it.b) << 32) + (uint64_t)it.first;   // RNG index: (bucket, element)
+        const uint64_t sd = random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, norm, norm) : seed;   // keyed by the bucket's norm
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e0 = 8 * lane + 512 * i;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_quantise_kernel(
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                code[k] = wide_code(val[k], norm, s, smax, random_mode, seed, g0 + (uint64_t)(e0 + k), BITS);
+                code[k] = wide_code(val[k], norm, s, smax, random_mode, sd, g0 + (uint64_t)(e0 + k), BITS);
             const bool whole = e0 + 8 <= it.n;
             if (BITS == 4) {
                 if (whole && dwords) {
@@ -325,8 +326,8 @@ GQ_INTERNAL int gqi_qsgd_wide_compress(const int64_t *seg_table, const int32_t *
     if (nseg < 1 || nchunks < 1 || n_bit < 1) return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched (wide): bad sizes");
     if (!seg_table || !chunk_seg || !norm_bits || !wire)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched (wide): null pointer");
-    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE)
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched (wide): random_mode must be OFF or DEVICE");
+    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE && random_mode != GQ_RANDOM_DEVICE_KEYED)
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched (wide): random_mode must be OFF, DEVICE or DEVICE_KEYED");
     const int bits = gq_qsgd_code_bits(n_bit, random_mode);
     if (!bits) return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched (wide): n_bit %d has no packed format", n_bit);
     hipStream_t st = gq::as_stream(stream);

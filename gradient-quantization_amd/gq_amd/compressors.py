@@ -18,7 +18,10 @@ call (probabilistic_scalar_compressor.py:23-25).  `args.gq_rng` (or $GQ_RNG) sel
     "device"     (default) counter-based generator inside the kernel: same distribution,
                  no host round trip, different draws than the reference;
     "reference"  torch.rand on the CPU generator + H2D copy: bit-identical to the
-                 reference for the same torch seed.
+                 reference for the same torch seed;
+    "keyed"      as "device", but in the multi-tensor level kernels the stream of a tensor is keyed by the bits of
+                 its (lb, ub) instead of a per-call seed: nothing in the launch changes from step to step, which is
+                 what lets a quantizer step replay from a HIP graph (gq_graph, quantizers.py).
 """
 import os
 
@@ -33,8 +36,8 @@ _seed_counter = [0]
 
 def _rng_mode(args):
     mode = getattr(args, "gq_rng", None) or os.environ.get("GQ_RNG", "device")
-    if mode not in ("device", "reference"):
-        raise ValueError("gq_rng must be 'device' or 'reference', got %r" % (mode,))
+    if mode not in ("device", "reference", "keyed"):
+        raise ValueError("gq_rng must be 'device', 'reference' or 'keyed', got %r" % (mode,))
     return mode
 
 

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GQ_LIB_PATH") or os.path.join(_PKG_DIR, "libgq_hsq.so
 
 GQ_MAX_PARTIALS = 1024
 GQ_FIXUP_PARTIALS = 256
-RANDOM_OFF, RANDOM_GIVEN, RANDOM_DEVICE = 0, 1, 2
+RANDOM_OFF, RANDOM_GIVEN, RANDOM_DEVICE, RANDOM_DEVICE_KEYED = 0, 1, 2, 3
 ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFILTER_D16K256 = 0, 1, 2, 3, 4
 
 EXPORTS = [     # every entry point include/gq_hsq.h declares (tests/test_host_logic.py compares the two lists)

@@ -262,7 +262,7 @@ class QSGDCodec(object):
         self.Mb, self.d = compressor.M, compressor.dim
         mode = native.RANDOM_DEVICE if compressor.random else native.RANDOM_OFF
         self.bits = 0
-        if self.d % 2 == 0 and (not compressor.random or compressor._rng == "device"):
+        if self.d % 2 == 0 and (not compressor.random or compressor._rng != "reference"):
             top = 2 ** compressor.bit - (0 if compressor.random else 1)
             self.bits = 4 if top <= 7 else (8 if top <= 127 else (16 if top <= 32767 else 0))
         self.norm_off = 0
@@ -516,6 +516,7 @@ class BatchedHSQ(_BatchedBase):
         c0 = self.codecs[0].c
         self.n_bit = c0.n_bit                                  # 32: the projections travel as f32 (no level quantiser)
         self.random = bool(c0.compressed_norm and c0.norm_compressor.random)
+        self.keyed = bool(self.random and c0.norm_compressor._rng == "keyed")   # draws keyed by (lb, ub): a launch that never changes
         self.reference_draws = self.codecs[0].uses_reference_draws()     # the reference's CPU draws, handed in per record
         self._r_index = self._r_flat = None
         self.codebook = c0._codebook_on(device)
@@ -568,17 +569,26 @@ class BatchedHSQ(_BatchedBase):
         torch.index_select(r_all, 0, self._r_index, out=self._r_flat)
         return self._r_flat
 
-    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None):
+    def graphable(self):
+        """True when nothing in this group's launches changes from record to record for fixed gradient addresses (no
+        per-call seed, no host-side draws): the launches can be nodes of a HIP graph (PSQuantizer, gq_graph)."""
+        return (not self.random or self.keyed) and not self.reference_draws and self._batch.path != 0
+
+    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None):
         """Compress `tensors` (one per batched parameter, in order) into one user's wire.
         Returns False (nothing launched) when a tensor is not a contiguous, 16-byte aligned f32
         tensor on this device: the caller then takes the per-tensor path for this step.
         With `errs` (error feedback, ps_quantizer.py:34-39) the same launches also do
-        t += ef_scale*err (in place, before encoding) and err = t - decoded (in place, after)."""
+        t += ef_scale*err (in place, before encoding) and err = t - decoded (in place, after).
+        graph_header (stream capture): a pinned copy of the header of exactly these tensors that nobody rewrites; it is
+        copied instead of the shared pinned buffers (no events, no validation: the caller has just run the same call eagerly)."""
         if self.reference_draws and draws is None:
             return False
         if self._batch.path == 0:       # e.g. more than 384 tensors of d = 8 / 32 and no exact kernel for the shape
             return False
-        if not self._upload(tensors, slot, self.align, errs):
+        if graph_header is not None:
+            self._dev.copy_(graph_header, non_blocking=True)
+        elif not self._upload(tensors, slot, self.align, errs):
             return False
         ef = ef_scale if errs is not None else None
         self._batch.encode(wire_user, ef, self.profile_slot)
@@ -587,6 +597,8 @@ class BatchedHSQ(_BatchedBase):
             mode, seed, r_flat = native.RANDOM_OFF, 0, None
         elif self.reference_draws:
             mode, seed, r_flat = native.RANDOM_GIVEN, 0, self._given_draws(draws)
+        elif self.keyed:
+            mode, seed, r_flat = native.RANDOM_DEVICE_KEYED, (salt * 0x2545F4914F6CDD1D + 0x5851F42D4C957F2D) & (2 ** 63 - 1), None
         elif self.random:
             mode, seed, r_flat = native.RANDOM_DEVICE, _next_seed() ^ salt, None
         else:
@@ -615,6 +627,7 @@ class BatchedQSGD(_BatchedBase):
         self.codecs = [codecs[i] for i in self.idxs]
         c0 = self.codecs[0]
         self.n_bit, self.bits, self.random = c0.c.bit, c0.bits, bool(c0.c.random)
+        self.keyed = bool(self.random and c0.c._rng == "keyed")
         self.wide = c0.d > self.WIDE_MIN
         assert all(cd.bits == self.bits and cd.c.bit == self.n_bit and (cd.d > self.WIDE_MIN) == self.wide
                    for cd in self.codecs)
@@ -646,12 +659,23 @@ class BatchedQSGD(_BatchedBase):
                                        self.bits, self.wide,
                                        self._dev[self._table_words:].view(torch.int32) if self.wide else None)
 
-    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None):
-        """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place)."""
-        if not self._upload(tensors, slot, 8, errs):
+    def graphable(self):
+        """The compress launch takes a fresh seed per record when it rounds stochastically: only the deterministic form
+        can be a HIP graph node (see BatchedHSQ.graphable)."""
+        return not self.random or self.keyed
+
+    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None):
+        """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place).
+        graph_header: see BatchedHSQ.encode."""
+        if graph_header is not None:
+            self._dev.copy_(graph_header, non_blocking=True)
+        elif not self._upload(tensors, slot, 8, errs):
             return False
-        mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
-        seed = (_next_seed() ^ salt) if self.random else 0
+        if self.keyed:      # gq_rng = "keyed": every bucket's draws keyed by its norm, the seed never changes
+            mode, seed = native.RANDOM_DEVICE_KEYED, (salt * 0x2545F4914F6CDD1D + 0x5851F42D4C957F2D) & (2 ** 63 - 1)
+        else:
+            mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
+            seed = (_next_seed() ^ salt) if self.random else 0
         self._batch.compress(wire_user, mode, seed, ef_scale if errs is not None else None)
         return True
 
@@ -738,6 +762,13 @@ class PSQuantizer(object):
         self.batch_idx = [i for g in self._groups for i in g[1]]
         self._pick_dense = operator.itemgetter(*self.dense_idx) if len(self.dense_idx) >= 2 else None
         self._pick_group = {}
+        # gq_graph (args.gq_graph or $GQ_GRAPH=1): the device work of a record() for a set of gradient addresses seen before
+        # is replayed as ONE HIP graph launch (the step is a launch-bound loop: ten launches and copies against ~85 us of
+        # kernels).  Needs launches whose arguments do not change between records: deterministic rounding or gq_rng="keyed".
+        g = getattr(args, "gq_graph", None)
+        self.use_graphs = bool(int(os.environ.get("GQ_GRAPH", "0"))) if g is None else bool(g)
+        self._rec_graphs = {}        # (slot, user, scale, gradient addresses) -> [sightings, graph or None, keep-alive]
+        self._apply_graphs = {}      # (users recorded, wire, output-buffer turns) -> [sightings, graph or None, decoded list]
         # gq_rng = "reference": the reference draws r = torch.rand(M) per compressed tensor, in parameter order, from
         # the CPU generator (probabilistic_scalar_compressor.py:23).  torch.rand is one sequential stream, so ONE
         # torch.rand(sum of M) per record (and one per two-phase apply) gives every tensor the same numbers; the
@@ -820,38 +851,31 @@ class PSQuantizer(object):
         draws = self._draws(dev)
         all_grads = [p.grad for p in self.parameters]     # (p.grad.data builds an alias tensor per access: ~1 us each)
         self._grad_objs = all_grads      # apply() rebinds .data of these very objects (161 fewer `param.grad` look-ups)
-        for grp in (self._groups if dev.type == "cuda" else []):
-            cls, idxs, obj = grp
-            if obj is None:
-                obj = grp[2] = cls(self.codecs, self.offsets, idxs, dev, self.capacity, self.user_bytes)
-            pick = self._pick_group.get(id(grp))      # operator.itemgetter over the group's indices, built once
-            if pick is None:
-                pick = self._pick_group[id(grp)] = operator.itemgetter(*idxs)     # (a group has at least two tensors)
-            grads = list(pick(all_grads))
-            # error feedback (ps_quantizer.py:35,39) rides in the same launches: grad += scale*error
-            # before the encode, error = grad - decoded after it, both in place
-            errs = [self.parameters[i].error[user] for i in idxs] if self.error_feedback else None
-            if obj.encode(grads, wire, slot, salt, errs, scale, draws=draws):
-                skip.update(idxs)
-        if len(self.dense_idx) >= 2:
-            # all small tensors with one concatenation straight into the packed wire region.  Under
-            # error feedback their residual is identically zero (decoded == grad), so nothing else to do.
-            key = (self._wire.data_ptr(), slot)
-            views = self._dense_in.get(key)
-            if views is None:       # parameter-shaped views of this slot's dense region, built once
-                region = wire[self.dense_off:self.dense_off + self.dense_bytes].view(torch.float32)
-                views, o = [], 0
-                for i in self.dense_idx:
-                    n = self.codecs[i].numel
-                    views.append(region[o:o + n].view(self.codecs[i].shape))
-                    o += n
-                self._dense_in = {k: v for k, v in self._dense_in.items() if k[0] == key[0]}   # drop a replaced wire's
-                self._dense_in[key] = views
-            with torch.no_grad():
-                torch._foreach_copy_(views, list(self._pick_dense(all_grads)))
-            skip.update(self.dense_idx)
+        # gq_graph: a record whose gradient addresses were seen before replays its device work as ONE graph launch
+        graph_key = None
+        if (self.use_graphs and dev.type == "cuda" and not self._draw_total and world == 1
+                and all(g[2] is not None and g[2].ready and g[2].graphable() for g in self._groups)):
+            graph_key = (slot, user, scale if self.error_feedback else None, self._wire.data_ptr(), tuple(map(_DATA_PTR, all_grads)))
+            ent = self._rec_graphs.get(graph_key)
+            if (ent is not None and ent[1] is not None and all(map(_IS_CONTIGUOUS, all_grads))
+                    and set(map(_DTYPE_OF, all_grads)) == _F32_ONLY):
+                ent[1].replay()
+                for g in self._groups:
+                    g[2]._last_ptrs = None      # the device header now holds this graph's table: the next eager call re-sends its own
+                self.recorded += 1
+                return
+        skip = self._record_launches(all_grads, wire, slot, user, salt, scale, draws, dev)
         if len(skip) == self.num_layers:     # the usual case: everything went through the multi-tensor launches
             self.recorded += 1
+            if graph_key is not None:
+                ent = self._rec_graphs.get(graph_key)
+                if ent is None:
+                    if len(self._rec_graphs) >= 16:     # a few address sets recur (the allocator hands the same blocks out again)
+                        self._rec_graphs.pop(next(iter(self._rec_graphs)))
+                    ent = self._rec_graphs[graph_key] = [0, None, None]
+                ent[0] += 1
+                if ent[0] >= 2 and ent[1] is None:      # the second sighting: worth a capture
+                    self._capture_record(ent, all_grads, wire, slot, user, salt, scale, dev)
             return
         for i, param in enumerate(self.parameters):
             if i in skip:
@@ -884,6 +908,58 @@ class PSQuantizer(object):
             else:
                 codec.encode_into(grad, wire, off, salt, **self._slice(draws, i))
         self.recorded += 1
+
+    def _record_launches(self, all_grads, wire, slot, user, salt, scale, draws, dev, headers=None):
+        """The multi-tensor launches of a record (+ the dense tensors' copy into the wire) -> the set of parameters served.
+        headers (stream capture): one pinned header per group, see BatchedHSQ.encode."""
+        skip = set()
+        skip_groups = []
+        for grp in (self._groups if dev.type == "cuda" else []):
+            cls, idxs, obj = grp
+            if obj is None:
+                obj = grp[2] = cls(self.codecs, self.offsets, idxs, dev, self.capacity, self.user_bytes)
+            pick = self._pick_group.get(id(grp))      # operator.itemgetter over the group's indices, built once
+            if pick is None:
+                pick = self._pick_group[id(grp)] = operator.itemgetter(*idxs)     # (a group has at least two tensors)
+            grads = list(pick(all_grads))
+            # error feedback (ps_quantizer.py:35,39) rides in the same launches: grad += scale*error
+            # before the encode, error = grad - decoded after it, both in place
+            errs = [self.parameters[i].error[user] for i in idxs] if self.error_feedback else None
+            hdr = headers[len(skip_groups)] if headers is not None else None
+            skip_groups.append(obj)
+            if obj.encode(grads, wire, slot, salt, errs, scale, draws=draws, graph_header=hdr):
+                skip.update(idxs)
+        if len(self.dense_idx) >= 2:
+            # all small tensors with one concatenation straight into the packed wire region.  Under
+            # error feedback their residual is identically zero (decoded == grad), so nothing else to do.
+            key = (self._wire.data_ptr(), slot)
+            views = self._dense_in.get(key)
+            if views is None:       # parameter-shaped views of this slot's dense region, built once
+                region = wire[self.dense_off:self.dense_off + self.dense_bytes].view(torch.float32)
+                views, o = [], 0
+                for i in self.dense_idx:
+                    n = self.codecs[i].numel
+                    views.append(region[o:o + n].view(self.codecs[i].shape))
+                    o += n
+                self._dense_in = {k: v for k, v in self._dense_in.items() if k[0] == key[0]}   # drop a replaced wire's
+                self._dense_in[key] = views
+            with torch.no_grad():
+                torch._foreach_copy_(views, list(self._pick_dense(all_grads)))
+            skip.update(self.dense_idx)
+        return skip
+
+    def _capture_record(self, ent, all_grads, wire, slot, user, salt, scale, dev):
+        """Stream-capture the launches the record just made eagerly, with pinned copies of the headers it has just sent
+        (the shared pinned buffers are rewritten by later records, a graph's memcpy node reads its source at every replay)."""
+        try:
+            headers = [g[2]._host[g[2]._last_slot].clone().pin_memory() for g in self._groups]
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers)
+        except Exception:      # a capture that fails leaves the eager path as it was
+            self.use_graphs = False
+            raise
+        ent[1], ent[2] = graph, headers
 
     def _slice(self, draws, i):
         """This parameter's share of the record's draws as a keyword for the codec (nothing for the other codecs)."""
@@ -1016,7 +1092,45 @@ class PSQuantizer(object):
             gathered, pending = ex.start(self.exchange_mode, self.recorded, self.cut)
         else:
             gathered, pending = self._wire[:self.recorded], ()
-        decoded = self._decode_all(gathered, self.two_phase, pending)
+        decoded = None
+        graph_key = None
+        if (self.use_graphs and world == 1 and not self.two_phase and gathered.device.type == "cuda"
+                and all(g[2] is not None and g[2].ready for g in self._groups)):
+            # gq_graph: the decode-mean launches (+ the dense tensors' mean) of an apply that has been seen with these buffers
+            # before replay as ONE graph launch; the two output buffers are used in turn, so two graphs alternate
+            graph_key = (self.recorded, self._wire.data_ptr(), tuple(g[2]._out_turn for g in self._groups), self._dense_turn)
+            ent = self._apply_graphs.get(graph_key)
+            if ent is not None and ent[1] is not None:
+                ent[1].replay()
+                for g in self._groups:
+                    g[2]._out_turn ^= 1
+                if len(self.dense_idx) >= 2:
+                    self._dense_turn ^= 1
+                decoded = ent[2]
+        if decoded is None:
+            decoded = self._decode_all(gathered, self.two_phase, pending)
+            if graph_key is not None and self._plan is not None and not self._plan[2]:     # (no per-tensor decodes in the plan)
+                ent = self._apply_graphs.get(graph_key)
+                if ent is None:
+                    if len(self._apply_graphs) >= 8:
+                        self._apply_graphs.pop(next(iter(self._apply_graphs)))
+                    ent = self._apply_graphs[graph_key] = [0, None, None]
+                ent[0] += 1
+                if ent[0] >= 2 and ent[1] is None:
+                    after = ([g[2]._out_turn for g in self._groups], self._dense_turn)
+                    try:
+                        for g, t in zip(self._groups, graph_key[2]):      # the capture re-issues the launches of THIS apply
+                            g[2]._out_turn = t
+                        self._dense_turn = graph_key[3]
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph):
+                            again = self._decode_all(gathered, False, ())
+                        if len(again) == len(decoded) and all(a is b for a, b in zip(again, decoded)):
+                            ent[1], ent[2] = graph, decoded
+                    finally:
+                        for g, t in zip(self._groups, after[0]):
+                            g[2]._out_turn = t
+                        self._dense_turn = after[1]
         # ps_quantizer.py:63 `param.grad.data = g`: the tensor OBJECT that is the parameter's gradient keeps its identity and
         # gets the mean as its data.  The objects are the ones the last record() read (nobody touches `param.grad` between
         # the last record and apply in the reference's loop, main.py:230-232); a parameter whose gradient was replaced in

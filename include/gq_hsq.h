@@ -54,6 +54,10 @@ size_t gq_hsq_workspace_bytes(int64_t M);
                               r = torch.rand(M) from the CPU generator, prob_scalar:23-25)       */
 #define GQ_RANDOM_DEVICE 2 /* stochastic rounding against an on-device counter-based generator
                               seeded by `seed` (same distribution, not the same draws)          */
+#define GQ_RANDOM_DEVICE_KEYED 3 /* gq_hsq_levels_batched / gq_qsgd_compress_batched only: as GQ_RANDOM_DEVICE, with every
+                              tensor's (QSGD: bucket's) stream keyed by the bits of its (lb, ub) (QSGD: norm) besides
+                              `seed`: new draws for every new gradient although `seed` stays what it was -- a
+                              launch whose arguments never change (a HIP graph node)                              */
 
 /* level_bytes of the level / decode entry points: 1 | 2 | 4 = one uint8 / uint16 / int32 per level, 0 = the f32
  * projections travel instead of levels (--n-bit 32), and

@@ -1295,3 +1295,50 @@ def test_a_gradient_replaced_at_the_same_address_is_revalidated():
     for a, p in zip(second, qp.parameters):
         assert torch.equal(a.view(torch.int32), p.grad.data.view(torch.int32))
     assert not torch.equal(first[0], second[0])
+
+
+@pytest.mark.parametrize("kw", [dict(random=0), dict(random=1, gq_rng="keyed"), dict(random=0, ef=True, scale="0.5"),
+                                dict(random=1, gq_rng="keyed", gq_wire_levels="packed6", n_bit=5),
+                                dict(qsgd=True, c_dim=128, n_bit=2, random=1, gq_rng="keyed"),
+                                dict(qsgd=True, c_dim=0, n_bit=1, random=1, gq_rng="keyed", ef=True, scale="0.5")])
+def test_record_replayed_from_a_hip_graph_equals_the_eager_launches(kw):
+    """gq_graph: from the second sighting of a set of gradient addresses on, record() replays its device work (header copy,
+    encode, levels, the dense tensors' copy) as ONE graph launch, and apply() its decode-mean launches (one graph per output
+    buffer).  Same aggregates, wire and residuals as the eager launches, over steps that alternate between two address sets
+    and then move to a third."""
+    from gq_amd.compressors import NearestNeighborCompressor, QSGDCompressor
+    from gq_amd.quantizers import Quantizer
+    kw = dict(kw)
+    Comp = QSGDCompressor if kw.pop("qsgd", False) else NearestNeighborCompressor
+    shapes = RESNET50_COMPRESSED[:12] + RESNET50_SMALL[:4]
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    store = [[torch.randn(s, device=dev) * 1e-2 for s in shapes] for _ in range(3)]      # three address sets
+    fills = [[torch.randn(s, device=dev) * 1e-2 for s in shapes] for _ in range(9)]      # what the gradients hold, step by step
+    order = [0, 1, 0, 1, 0, 1, 2, 2, 2]
+
+    def run(graph):
+        params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
+        q = Quantizer(Comp, params, make_args(num_users=1, gq_graph=graph, **kw))
+        outs = []
+        for step, k in enumerate(order):
+            for t, f in zip(store[k], fills[step]):
+                t.copy_(f)
+            for p, t in zip(params, store[k]):
+                p.grad = t.view(t.shape)      # a fresh object at the same address (apply() rebinds .data of the object)
+            q.record(0, epoch=1)
+            q.apply()
+            outs.append([p.grad.data.clone() for p in params])
+        return q, outs
+
+    qg, og = run(True)
+    qe, oe = run(False)
+    assert sum(1 for e in qg._rec_graphs.values() if e[1] is not None) == 3 and not qe._rec_graphs
+    assert sum(1 for e in qg._apply_graphs.values() if e[1] is not None) == 2 and not qe._apply_graphs     # the two output buffers in turn
+    for a, b in zip(og, oe):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    assert torch.equal(qg._wire, qe._wire)
+    if kw.get("ef"):
+        for pg, pe in zip(qg.parameters, qe.parameters):
+            assert torch.equal(pg.error[0], pe.error[0])
