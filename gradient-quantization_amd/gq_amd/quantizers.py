@@ -855,7 +855,9 @@ class PSQuantizer(object):
         graph_key = None
         if (self.use_graphs and dev.type == "cuda" and not self._draw_total and world == 1
                 and all(g[2] is not None and g[2].ready and g[2].graphable() for g in self._groups)):
-            graph_key = (slot, user, scale if self.error_feedback else None, self._wire.data_ptr(), tuple(map(_DATA_PTR, all_grads)))
+            graph_key = (slot, user, self._wire.data_ptr(), tuple(map(_DATA_PTR, all_grads)))
+            if self.error_feedback:     # the residual buffers' addresses are in the header too (a per-tensor step replaces them)
+                graph_key += (scale, tuple(p.error[user].data_ptr() for p in self.parameters))
             ent = self._rec_graphs.get(graph_key)
             if (ent is not None and ent[1] is not None and all(map(_IS_CONTIGUOUS, all_grads))
                     and set(map(_DTYPE_OF, all_grads)) == _F32_ONLY):
@@ -956,9 +958,11 @@ class PSQuantizer(object):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers)
-        except Exception:      # a capture that fails leaves the eager path as it was
+        except Exception as e:      # a capture that fails leaves the eager path as it was (this record has already run eagerly)
             self.use_graphs = False
-            raise
+            import warnings
+            warnings.warn("gq_graph: capturing a record failed (%s); continuing with eager launches" % (e,))
+            return
         ent[1], ent[2] = graph, headers
 
     def _slice(self, draws, i):
@@ -1098,7 +1102,9 @@ class PSQuantizer(object):
                 and all(g[2] is not None and g[2].ready for g in self._groups)):
             # gq_graph: the decode-mean launches (+ the dense tensors' mean) of an apply that has been seen with these buffers
             # before replay as ONE graph launch; the two output buffers are used in turn, so two graphs alternate
-            graph_key = (self.recorded, self._wire.data_ptr(), tuple(g[2]._out_turn for g in self._groups), self._dense_turn)
+            graph_key = (self.recorded, self._wire.data_ptr(), tuple(g[2]._out_turn for g in self._groups), self._dense_turn,
+                         tuple(0 if o is None else o.data_ptr() for g in self._groups for o in g[2]._outs),
+                         tuple(0 if m is None else m.data_ptr() for m in self._dense_mean))
             ent = self._apply_graphs.get(graph_key)
             if ent is not None and ent[1] is not None:
                 ent[1].replay()
@@ -1127,6 +1133,10 @@ class PSQuantizer(object):
                             again = self._decode_all(gathered, False, ())
                         if len(again) == len(decoded) and all(a is b for a, b in zip(again, decoded)):
                             ent[1], ent[2] = graph, decoded
+                    except Exception as e:      # this apply has already run eagerly
+                        self.use_graphs = False
+                        import warnings
+                        warnings.warn("gq_graph: capturing an apply failed (%s); continuing with eager launches" % (e,))
                     finally:
                         for g, t in zip(self._groups, after[0]):
                             g[2]._out_turn = t
