@@ -1342,3 +1342,39 @@ def test_record_replayed_from_a_hip_graph_equals_the_eager_launches(kw):
     if kw.get("ef"):
         for pg, pe in zip(qg.parameters, qe.parameters):
             assert torch.equal(pg.error[0], pe.error[0])
+
+
+def test_keyed_draws_are_new_for_every_gradient_and_round_without_bias():
+    """gq_rng = "keyed" (GQ_RANDOM_DEVICE_KEYED): the seed never changes, every tensor's stream is keyed by its (lb, ub).
+    The same gradient gives the same levels, another gradient other draws, and the rounding is unbiased: against the
+    truncated levels the stochastic ones are half a level higher on average."""
+    from gq_amd.compressors import NearestNeighborCompressor
+    from gq_amd.quantizers import Quantizer
+    dev = torch.device("cuda:0")
+    shapes = [(40000, 16), (30000, 16)]
+
+    def levels_of(grads, **kw):
+        params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
+        q = Quantizer(NearestNeighborCompressor, params, make_args(num_users=1, **kw))
+        for p, g in zip(params, grads):
+            p.grad = g.clone()
+        q.record(0, epoch=1)
+        torch.cuda.synchronize()
+        grp = q._groups[0][2]
+        out = []
+        for i, cd in zip(grp.idxs, grp.codecs):
+            off = q.offsets[i]
+            out.append(q._wire[0, off + cd.levels_off:off + cd.levels_off + cd.M].clone().to(torch.int32))
+        return out
+    torch.manual_seed(21)
+    g1 = [torch.randn(s, device=dev) * 1e-2 for s in shapes]
+    g2 = [g + 1e-6 * torch.randn_like(g) for g in g1]
+    a = levels_of(g1, random=1, gq_rng="keyed")
+    b = levels_of(g1, random=1, gq_rng="keyed")
+    c = levels_of(g2, random=1, gq_rng="keyed")
+    t = levels_of(g1, random=0)
+    for x, y, z, w in zip(a, b, c, t):
+        assert torch.equal(x, y)                                  # same gradient, same draws
+        assert (x != z).float().mean() > 0.2                       # another gradient (1e-4 relative away): other draws
+        d = (x - w).float()
+        assert bool(((d == 0) | (d == 1)).all()) and 0.47 < float(d.mean()) < 0.53
