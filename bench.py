@@ -696,7 +696,13 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
                     + "decode-mean, small tensors dense), host launch time included",
         "prewarm_steps": prewarm,
         "config": {"workload": cfg, "elements_per_rank": n, "ranks": world, "wire_bytes_per_rank": q.wire_bytes_per_user(),
-                   "inputs": "3 gradient lists used in turn through fresh tensor objects, N(0,1)*1e-3"},
+                   "inputs": "3 gradient lists used in turn through fresh tensor objects, N(0,1)*1e-3",
+                   "launches": ("gq_graph: record() and apply() replay their device work from HIP graphs (one per set of gradient "
+                                "addresses / output buffer; %d + %d captured), stochastic rounding with draws keyed by each tensor's "
+                                "(lb, ub) / each bucket's norm (gq_rng = 'keyed')" % (
+                                    sum(1 for e in q._rec_graphs.values() if e[1] is not None),
+                                    sum(1 for e in q._apply_graphs.values() if e[1] is not None))) if args.graph
+                               else "eager: ten launches and copies per record + apply; per-call seeds for the on-device draws"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": algo,
                      "frac_compress": achieved_compress / HBM_PEAK_GBS, "compress_ms": cmp_ms,

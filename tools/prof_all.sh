@@ -14,6 +14,8 @@ mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --workload resnet50 > $O/bench_resnet50.json 2> $O/bench_resnet50.err
 python bench.py --workload qsgd > $O/bench_qsgd.json 2> /dev/null
+python bench.py --workload resnet50 --graph --traffic off > $O/bench_resnet50_graph.json 2> /dev/null
+python bench.py --workload qsgd --graph --traffic off > $O/bench_qsgd_graph.json 2> /dev/null
 python bench.py --wire-levels packed6 --no-cpu-baseline --traffic off > $O/bench_packed6.json 2> /dev/null
 GQ_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --exchange auto > $O/bench_2ranks_gloo.json 2> /dev/null
 # 3. SQ counters of the encode (three passes) and the in-kernel stamps
