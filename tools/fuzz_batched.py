@@ -50,7 +50,7 @@ t0, rounds = time.time(), 0
 while time.time() - t0 < budget:
     rounds += 1
     hsq = rng.random() < 0.6
-    users, steps = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    users, steps = int(rng.integers(1, 4)), int(rng.integers(1, 3)) + (3 if rng.random() < 0.2 else 0)
     if rng.random() < 0.15:      # every decode-mean kernel: compile-time R up to 16, the chunked form above
         users = int(rng.choice([4, 5, 7, 8, 9, 12, 16, 17, 21]))
     extra = [{}, {"ef": True}, {"ef": True, "two_phase": True}, {"two_phase": True}, {"mode": "ring"},
@@ -80,6 +80,8 @@ while time.time() - t0 < budget:
         shapes.append((m * d,) if rng.random() < 0.5 else (m, d))
     shapes.append((10,))
     kw.update(extra)
+    if rng.random() < 0.3 and kw.get("mode", "ps") == "ps":     # the batched quantizer replays recurring steps from HIP graphs (the reference path stays eager)
+        kw.update(gq_graph=True)
     total = sum(int(np.prod(sh)) for sh in shapes)
     if total * 4 * (users + 8) * 2 > 120e9:      # both quantizers alive at once: parameters, gradients, residuals per user, two
         continue                                  # output buffers, clones -- a round of 4 GB tensors does not fit the 288 GB
