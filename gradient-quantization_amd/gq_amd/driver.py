@@ -166,7 +166,9 @@ def build_parser():
     p.add_argument('--train-size', type=int, default=4096, help='synthetic samples per epoch')
     p.add_argument('--log-interval', type=int, default=8, help='iterations between JSON log lines')
     p.add_argument('--logfile', type=str, default=None)
-    p.add_argument('--gq-rng', type=str, default=None, choices=[None, 'device', 'reference'])
+    p.add_argument('--gq-rng', type=str, default=None, choices=[None, 'device', 'reference', 'keyed'])
+    p.add_argument('--gq-graph', action='store_true', default=None,
+                   help='replay the quantizer step from HIP graphs per set of gradient addresses (needs --random 0 or --gq-rng keyed)')
     p.add_argument('--data', type=str, default='synthetic', choices=['synthetic', 'disk'],
                    help="disk: MNIST idx files / CIFAR-10 pickles under --data-root (no torchvision)")
     p.add_argument('--data-root', type=str, default='./data')

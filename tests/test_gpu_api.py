@@ -1378,3 +1378,18 @@ def test_keyed_draws_are_new_for_every_gradient_and_round_without_bias():
         assert (x != z).float().mean() > 0.2                       # another gradient (1e-4 relative away): other draws
         d = (x - w).float()
         assert bool(((d == 0) | (d == 1)).all()) and 0.47 < float(d.mean()) < 0.53
+
+
+def test_training_driver_with_graph_replay_learns_like_the_eager_run():
+    """A real training loop (fcn, synthetic MNIST-shaped data, two users): backward allocates new gradient tensors every
+    iteration, the allocator hands the same blocks out again, and from the second sighting on the quantizer's launches are
+    replayed from HIP graphs (--gq-graph with --gq-rng keyed).  Deterministic rounding: the same losses as the eager run."""
+    from gq_amd.driver import build_parser, train
+    base = ["--network", "fcn", "--dataset", "mnist", "--c-dim", "16", "--k-bit", "8", "--n-bit", "6", "--num-users", "2",
+            "--batch-size", "32", "--epochs", "2", "--train-size", "2048", "--lr", "0.05", "--log-interval", "4", "--quantizer", "hsq"]
+    _, qg, hist_g = train(build_parser().parse_args(base + ["--gq-graph", "--gq-rng", "keyed"]))
+    assert hist_g[-1]["loss"] < 0.7 * hist_g[0]["loss"]
+    assert any(e[1] is not None for e in qg._rec_graphs.values()), "no record was ever replayed from a graph"
+    _, qe, hist_e = train(build_parser().parse_args(base + ["--gq-rng", "keyed"]))
+    assert not qe._rec_graphs
+    assert [h["loss"] for h in hist_g] == [h["loss"] for h in hist_e]
