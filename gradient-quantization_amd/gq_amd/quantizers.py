@@ -853,7 +853,7 @@ class PSQuantizer(object):
         self._grad_objs = all_grads      # apply() rebinds .data of these very objects (161 fewer `param.grad` look-ups)
         # gq_graph: a record whose gradient addresses were seen before replays its device work as ONE graph launch
         graph_key = None
-        if (self.use_graphs and dev.type == "cuda" and not self._draw_total and world == 1
+        if (self.use_graphs and dev.type == "cuda" and not self._draw_total
                 and all(g[2] is not None and g[2].ready and g[2].graphable() for g in self._groups)):
             graph_key = (slot, user, self._wire.data_ptr(), tuple(map(_DATA_PTR, all_grads)))
             if self.error_feedback:     # the residual buffers' addresses are in the header too (a per-tensor step replaces them)
@@ -1098,11 +1098,16 @@ class PSQuantizer(object):
             gathered, pending = self._wire[:self.recorded], ()
         decoded = None
         graph_key = None
-        if (self.use_graphs and world == 1 and not self.two_phase and gathered.device.type == "cuda"
+        if (self.use_graphs and len(pending) <= 1 and not self.two_phase and gathered.device.type == "cuda"
                 and all(g[2] is not None and g[2].ready for g in self._groups)):
             # gq_graph: the decode-mean launches (+ the dense tensors' mean) of an apply that has been seen with these buffers
-            # before replay as ONE graph launch; the two output buffers are used in turn, so two graphs alternate
-            graph_key = (self.recorded, self._wire.data_ptr(), tuple(g[2]._out_turn for g in self._groups), self._dense_turn,
+            # before replay as ONE graph launch; the two output buffers are used in turn, so two graphs alternate.  With
+            # several ranks the exchange stays outside: its one transfer is waited for first (the split transport, whose
+            # decode is interleaved with its second transfer, keeps its eager launches)
+            for pnd in pending:
+                pnd.wait()
+            pending = ()
+            graph_key = (gathered.shape[0], gathered.data_ptr(), tuple(g[2]._out_turn for g in self._groups), self._dense_turn,
                          tuple(0 if o is None else o.data_ptr() for g in self._groups for o in g[2]._outs),
                          tuple(0 if m is None else m.data_ptr() for m in self._dense_mean))
             ent = self._apply_graphs.get(graph_key)

@@ -28,7 +28,8 @@ def grads_for(global_user, step):
     return [torch.randn(s, generator=g) * 1e-2 for s in SHAPES]
 
 
-def run(quantizer, params, local_users, first_global_user, steps=2):
+def run(quantizer, params, local_users, first_global_user, steps=None):
+    steps = int(os.environ.get("GQ_TEST_STEPS", "2")) if steps is None else steps
     out = {}
     for st in range(steps):
         for u in range(local_users):
@@ -66,5 +67,8 @@ if __name__ == "__main__":
     q, params = build(local, mode, quant, ef=ef)
     res = run(q, params, local, rank * local)
     np.savez(out + "_rank%d.npz" % rank, **res)
+    with open(out + "_rank%d_graphs.txt" % rank, "w") as f:      # (gq_graph: how many records / applies were captured)
+        f.write("%d %d" % (sum(1 for e in q._rec_graphs.values() if e[1] is not None),
+                           sum(1 for e in q._apply_graphs.values() if e[1] is not None)))
     dist.barrier()
     dist.destroy_process_group()

@@ -1393,3 +1393,31 @@ def test_training_driver_with_graph_replay_learns_like_the_eager_run():
     _, qe, hist_e = train(build_parser().parse_args(base + ["--gq-rng", "keyed"]))
     assert not qe._rec_graphs
     assert [h["loss"] for h in hist_g] == [h["loss"] for h in hist_e]
+
+
+@pytest.mark.parametrize("quant,ef", [("hsq", False), ("hsq", True)])
+def test_two_ranks_on_one_gpu_with_graph_replay(tmp_path, quant, ef):
+    """gq_graph with more than one rank: every rank's record() and the decode after the exchange replay from graphs
+    (the exchange itself stays outside); five steps, == the same users in one eager process, bit for bit."""
+    import subprocess
+    import sys
+    script = os.path.join(HERE, "_dist_worker_gpu.py")
+    out = str(tmp_path / "res")
+    port = 30100 + (os.getpid() % 1500) + (7 if ef else 0)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GQ_GRAPH="1", GQ_TEST_STEPS="5")
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", out, "ps", quant, "1" if ef else "0"], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r0, r1 = np.load(out + "_rank0.npz"), np.load(out + "_rank1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k].view(np.uint32), r1[k].view(np.uint32)), "ranks disagree on " + k
+    rec, app = map(int, open(out + "_rank0_graphs.txt").read().split())
+    assert rec >= 1 and app >= 1, "no graph was captured on rank 0 (%d records, %d applies)" % (rec, app)
+    sys.path.insert(0, HERE)
+    import _dist_worker_gpu as w
+    assert "GQ_GRAPH" not in os.environ
+    q, params = w.build(4, "ps", quant, ef=ef)
+    single = w.run(q, params, 4, 0, steps=5)
+    assert len(single) == len(r0.files)
+    for k in single:
+        assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
