@@ -956,7 +956,7 @@ class PSQuantizer(object):
         try:
             headers = [g[2]._host[g[2]._last_slot].clone().pin_memory() for g in self._groups]
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (other threads -- RCCL's watchdog -- may call into HIP meanwhile)
                 self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers)
         except Exception as e:      # a capture that fails leaves the eager path as it was (this record has already run eagerly)
             self.use_graphs = False
@@ -1134,7 +1134,7 @@ class PSQuantizer(object):
                             g[2]._out_turn = t
                         self._dense_turn = graph_key[3]
                         graph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(graph):
+                        with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (other threads -- RCCL's watchdog -- may call into HIP meanwhile)
                             again = self._decode_all(gathered, False, ())
                         if len(again) == len(decoded) and all(a is b for a, b in zip(again, decoded)):
                             ent[1], ent[2] = graph, decoded
