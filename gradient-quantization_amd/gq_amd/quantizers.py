@@ -870,13 +870,8 @@ class PSQuantizer(object):
         if len(skip) == self.num_layers:     # the usual case: everything went through the multi-tensor launches
             self.recorded += 1
             if graph_key is not None:
-                ent = self._rec_graphs.get(graph_key)
-                if ent is None:
-                    if len(self._rec_graphs) >= 16:     # a few address sets recur (the allocator hands the same blocks out again)
-                        self._rec_graphs.pop(next(iter(self._rec_graphs)))
-                    ent = self._rec_graphs[graph_key] = [0, None, None]
-                ent[0] += 1
-                if ent[0] >= 2 and ent[1] is None:      # the second sighting: worth a capture
+                ent = self._graph_entry(self._rec_graphs, graph_key)
+                if ent is not None and ent[0] >= 2 and ent[1] is None:      # the second sighting: worth a capture
                     self._capture_record(ent, all_grads, wire, slot, user, salt, scale, dev)
             return
         for i, param in enumerate(self.parameters):
@@ -949,6 +944,23 @@ class PSQuantizer(object):
                 torch._foreach_copy_(views, list(self._pick_dense(all_grads)))
             skip.update(self.dense_idx)
         return skip
+
+    @staticmethod
+    def _graph_entry(cache, key, max_captured=48, max_counting=64):
+        """[sightings, graph or None, keep-alive] of `key`, its sighting counted.  A few address sets recur (the allocator
+        hands the same blocks out again); captured graphs are never evicted -- once max_captured of them exist, new sets keep
+        their eager launches (None) instead of displacing one another capture by capture -- and among the entries that
+        only count sightings the oldest goes first."""
+        ent = cache.get(key)
+        if ent is None:
+            counting = [k for k, e in cache.items() if e[1] is None]
+            if len(cache) - len(counting) >= max_captured:
+                return None
+            if len(counting) >= max_counting:
+                cache.pop(counting[0])
+            ent = cache[key] = [0, None, None]
+        ent[0] += 1
+        return ent
 
     def _capture_record(self, ent, all_grads, wire, slot, user, salt, scale, dev):
         """Stream-capture the launches the record just made eagerly, with pinned copies of the headers it has just sent
@@ -1121,13 +1133,8 @@ class PSQuantizer(object):
         if decoded is None:
             decoded = self._decode_all(gathered, self.two_phase, pending)
             if graph_key is not None and self._plan is not None and not self._plan[2]:     # (no per-tensor decodes in the plan)
-                ent = self._apply_graphs.get(graph_key)
-                if ent is None:
-                    if len(self._apply_graphs) >= 8:
-                        self._apply_graphs.pop(next(iter(self._apply_graphs)))
-                    ent = self._apply_graphs[graph_key] = [0, None, None]
-                ent[0] += 1
-                if ent[0] >= 2 and ent[1] is None:
+                ent = self._graph_entry(self._apply_graphs, graph_key)
+                if ent is not None and ent[0] >= 2 and ent[1] is None:
                     after = ([g[2]._out_turn for g in self._groups], self._dense_turn)
                     try:
                         for g, t in zip(self._groups, graph_key[2]):      # the capture re-issues the launches of THIS apply
