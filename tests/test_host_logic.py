@@ -594,3 +594,23 @@ def test_batch_descriptor_is_validated_before_anything_is_launched():
     q.bits, q.wide = 4, 1
     assert L.gq_qsgd_compress_batched(ctypes.byref(q), ctypes.c_void_p(64), 0, ctypes.c_uint64(0), nan, None) == -1 and b"norm_bits" in L.gq_last_error()
     assert native.hsq_batched_path(16, 256, torch.uint8) == native.BATCH_PREFILTER and native.hsq_batched_path(200, 64, torch.uint8) == 0
+
+
+def test_graph_cache_never_evicts_a_captured_graph_and_does_not_thrash():
+    """gq_graph's cache (PSQuantizer._graph_entry): sightings are counted per key; entries that only count are dropped oldest
+    first; captured graphs stay, and once there are max_captured of them new keys get None (eager launches) instead of
+    displacing one another."""
+    from gq_amd.quantizers import PSQuantizer
+    cache = {}
+    e = PSQuantizer._graph_entry(cache, "a", max_captured=2, max_counting=3)
+    assert e == [1, None, None] and PSQuantizer._graph_entry(cache, "a", 2, 3)[0] == 2
+    cache["a"][1] = "graph-a"                                   # captured
+    for k in "bcd":
+        PSQuantizer._graph_entry(cache, k, 2, 3)
+    assert set(cache) == {"a", "b", "c", "d"}
+    PSQuantizer._graph_entry(cache, "e", 2, 3)                  # a fourth counting entry: the oldest counting one ("b") goes
+    assert set(cache) == {"a", "c", "d", "e"} and cache["a"][1] == "graph-a"
+    cache["c"][1] = "graph-c"                                   # second captured graph: the cache of captured graphs is full
+    assert PSQuantizer._graph_entry(cache, "f", 2, 3) is None and "f" not in cache
+    assert PSQuantizer._graph_entry(cache, "d", 2, 3)[0] == 2   # known keys still count
+    assert PSQuantizer._graph_entry(cache, "a", 2, 3)[1] == "graph-a"
