@@ -79,9 +79,12 @@ def parse_args():
                          "auto = live at N=1 when rocprofv3 is on PATH, else the committed profiles/hbm_traffic.json")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="--workload resnet50 / qsgd: record()'s device work replays from a HIP graph per set of gradient addresses "
-                         "(gq_graph; stochastic rounding with draws keyed by each tensor's (lb, ub), gq_rng='keyed')")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=True,
+                    help="--workload resnet50 / qsgd (default): record() and apply() replay their device work from HIP graphs per "
+                         "set of gradient addresses (gq_graph; stochastic rounding with draws keyed by each tensor's (lb, ub) / each "
+                         "bucket's norm, gq_rng='keyed')")
+    ap.add_argument("--no-graph", dest="graph", action="store_false",
+                    help="--workload resnet50 / qsgd: eager launches with per-call seeds for the on-device draws (rounds 1-3's line)")
     ap.add_argument("--cpu-scaling", action="store_true", help="print the CPU oracle's thread scaling on this host and exit (no GPU work)")
     ap.add_argument("--two-launches", action="store_true",
                     help="N = 1: levels and decode as two launches (as with N > 1) instead of gq_hsq_levels_decode")
@@ -586,6 +589,8 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
     from gq_amd.quantizers import BatchedHSQ, BatchedQSGD, Quantizer
 
     hsq = args.workload == "resnet50"
+    if args.traffic_child:      # (the PMC child runs count the bytes of individually dispatched kernels)
+        args.graph = False
     shapes = [tuple(p.shape) for p in ResNet50(num_classes=10).parameters()]
     n = sum(int(np.prod(s)) for s in shapes)
     if hsq:     # README: --quantizer hsq --network resnet50 --c-dim 16 --k-bit 8 --n-bit 6 (--random defaults to True)
@@ -648,11 +653,13 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
     gl = [params[i].grad.data for i in grp.idxs]
     wire0 = q._wire[0]
     cmp_ms = event_ms(torch, lambda: grp.encode(gl, wire0, 0, 0))       # HSQ: encode + levels; QSGD: the one compress launch
-    if hsq and args.graph:      # the encode's own time from armed dispatches of eager calls after the timed region
-        armed = list(range(8))
+    if hsq and args.graph:      # the encode's own time: armed dispatches of eager steps after the timed region (a replayed graph
+        armed = list(range(8))  # has no armed dispatch); whole steps, so that the encode meets the caches a step leaves behind
+        q.use_graphs = False
         for k in armed:
             grp.profile_slot = k
-            grp.encode(gl, wire0, 0, 0)
+            step(k)
+        q.use_graphs = True
         torch.cuda.synchronize()
     k_elems = sum(cd.numel for cd in grp.codecs)
     dec_ms = event_ms(torch, lambda: grp.decode_mean(q._wire[:1], 1))
@@ -674,8 +681,10 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
         match, metric = "hsq_encode_pf_kernel", "gradient elements quantized/sec (HSQ d=16 k=8, ResNet-50 list)"
         cfg = ("ResNet-50/CIFAR parameter list (161 tensors, %d elements) per rank through PSQuantizer.record + apply, HSQ c_dim=16 "
                "k_bit=8 n_bit=6 random=1 on-device draws (BASELINE configs[2]; the README's hsq command), byte wire, multi-tensor kernels" % n)
-        note = ("kernel_ms: HIP start/stop events attached to the encode's dispatch on %d of the timed steps; compress_ms = encode + "
-                "levels launches back to back after the timed region; the step itself is host-bound (per-parameter Python)" % len(armed))
+        note = ("kernel_ms: HIP start/stop events attached to the encode's dispatch on %d %s; compress_ms = encode + "
+                "levels launches back to back after the timed region; the step itself is host-bound (per-parameter torch work)"
+                % (len(armed), "eager steps run after the timed region (a replayed graph has no armed dispatch)" if args.graph
+                   else "of the timed steps"))
     else:
         k_ms = cmp_ms
         algo = QSGD_ALGO_BYTES_PER_ELEM * k_elems

@@ -9,13 +9,13 @@ O=gpurun_out/$TAG
 mkdir -p $O
 # 1. the driver's command under the kernel tracer (the profiler's own program is python3 itself)
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --traffic off > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> /dev/null)
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_resnet50 -- python3 $GRAFT_REPO_ROOT/bench.py --workload resnet50 --steps 100 --warmup 20 --traffic off > $GRAFT_REPO_ROOT/$O/bench_resnet50_under_rocprof.json 2> /dev/null)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_resnet50 -- python3 $GRAFT_REPO_ROOT/bench.py --workload resnet50 --no-graph --steps 100 --warmup 20 --traffic off > $GRAFT_REPO_ROOT/$O/bench_resnet50_under_rocprof.json 2> /dev/null)
 # 2. the default lines (live PMC traffic, CPU baseline) of the three workloads
 python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --workload resnet50 > $O/bench_resnet50.json 2> $O/bench_resnet50.err
-python bench.py --workload qsgd > $O/bench_qsgd.json 2> /dev/null
-python bench.py --workload resnet50 --graph --traffic off > $O/bench_resnet50_graph.json 2> /dev/null
-python bench.py --workload qsgd --graph --traffic off > $O/bench_qsgd_graph.json 2> /dev/null
+python bench.py --workload resnet50 --no-graph > $O/bench_resnet50.json 2> $O/bench_resnet50.err
+python bench.py --workload qsgd --no-graph > $O/bench_qsgd.json 2> /dev/null
+python bench.py --workload resnet50 --traffic off > $O/bench_resnet50_graph.json 2> /dev/null
+python bench.py --workload qsgd --traffic off > $O/bench_qsgd_graph.json 2> /dev/null
 python bench.py --wire-levels packed6 --no-cpu-baseline --traffic off > $O/bench_packed6.json 2> /dev/null
 GQ_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --exchange auto > $O/bench_2ranks_gloo.json 2> /dev/null
 # 3. SQ counters of the encode (three passes) and the in-kernel stamps
