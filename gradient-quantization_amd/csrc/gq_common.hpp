@@ -37,10 +37,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // sum / R of the parameter-server mean (ps_quantizer.py:48: torch.stack(...).mean(0) divides the sum by R).  For R a power
 // of two -- 1, 2, 4, 8 ranks -- the division is an exact scaling: x * (1/R) is the same correctly rounded x * 2^-k, subnormal
 // results included, for ONE VALU operation instead of the ~10 of the IEEE division sequence (16 divisions per lane and
-// iteration were a quarter of the R = 8 decode's instructions).  Other R divide.
+// iteration were a quarter of the R = 8 decode's instructions).  For an ODD R (3, 5, 7 ... users) the quotient by the
+// constant takes four: y = RN(1/R) once, q0 = RN(x y), r = x - q0 R (exact in one fma), RN(q0 + r y) is the correctly
+// rounded x / R (Markstein's correction step), with one v_max_f32 on the residual for the one case it breaks (x = +-inf:
+// inf - inf).  Subnormal quotients included: there q0 is on the 2^-149 grid, r is exact, and the only way the rounding of
+// q0 + r y could differ from that of x / R is a quotient exactly half way between two grid points, which needs an even
+// divisor -- with R = 6, 10, 12 exactly those ties come out wrong (2.8 M of the 2^32 inputs on the CPU), which is why an
+// even R that is not a power of two keeps the IEEE sequence.  tools/div_check.hip compares the four operations with the
+// device's own x / R for every one of the 2^32 inputs and every odd R up to GQ_ODD_DIV_MAX on the MI355X (0 differences,
+// profiles/r03_experiments.txt 18); the kernel-vs-oracle tests cover R = 3 ... 19 incl. subnormal and infinite sums.
+#define GQ_ODD_DIV_MAX 4097
 struct MeanDiv {
     float fR, inv;
-    bool pow2;
+    bool pow2, odd;
     bool apply;   // false: one payload, plain decompress -- the value is stored as decoded (a -0 stays -0)
 };
 // mean = the call IS the parameter-server aggregate (every multi-tensor decode): torch's sum starts from +0, so an element
@@ -51,11 +60,31 @@ __host__ __device__ inline MeanDiv mean_div_of(int R, bool mean = false) {
     m.fR = (float)R;
     m.inv = 1.0f / (float)R;
     m.pow2 = R > 0 && (R & (R - 1)) == 0;
+    m.odd = (R & 1) && R >= 3 && R <= GQ_ODD_DIV_MAX;
     m.apply = mean || R > 1;
     return m;
 }
+__device__ __forceinline__ float odd_quotient(float x, float fR, float y) {
+    const float q0 = __fmul_rn(x, y);
+    // x = +-inf: the residual is inf - inf = NaN, and the maximum with a number is that number (v_max_f32 returns the
+    // operand that is not a NaN), so that the last fma is (-FLT_MAX) y + (+-inf) = +-inf; a NaN x stays one through q0
+    const float r = fmaxf(__fmaf_rn(-q0, fR, x), -3.402823466e+38f);
+    return __fmaf_rn(r, y, q0);
+}
 template <class V>   // float or a vector of floats
 __device__ __forceinline__ V mean_div(V x, const MeanDiv &m) {
+    if (m.odd) {
+        // no (+0) + sum here: the four operations turn a -0 into the +0 of the mean by themselves (q0 = -0, r = (+0) R + (-0)
+        // = +0, (+0) y + (-0) = +0) and every other x is what x + 0 is
+        if constexpr (__is_same(V, float)) {
+            return odd_quotient(x, m.fR, m.inv);
+        } else {
+            V q;
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(V) / sizeof(float)); ++i) q[i] = odd_quotient(x[i], m.fR, m.inv);
+            return q;
+        }
+    }
     x = x + 0.0f;   // (+0) + sum, as torch.stack(...).mean(0) accumulates: -0 becomes +0, everything else is unchanged
     return m.pow2 ? x * m.inv : x / m.fR;
 }

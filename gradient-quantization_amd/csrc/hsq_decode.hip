@@ -389,14 +389,24 @@ void hsq_decode_sum_d16u8_r_kernel(
         const unsigned nxt = i + stride;
         const unsigned pre = nxt < full ? nxt : i;   // the last item re-requests itself: no branch around the loads
         f32x4 acc[4];
+        float hold[4];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int j = r >> 2;
-            const unsigned c4 = team_word(cw[j], r & 3), l4 = team_word(lw[j], r & 3);
+            unsigned c4 = team_word(cw[j], r & 3), l4 = team_word(lw[j], r & 3);
+            // R = 3: left alone, the compiler forms all 48 products before the first sum, which with the odd divisor's
+            // quotients no longer fits the 64 registers of 8 waves: the third payload's words wait for the first's products
+            if (R == 3 && r == 2) asm("" : "+v"(c4), "+v"(l4) : "v"(hold[0]), "v"(hold[1]), "v"(hold[2]), "v"(hold[3]));
             if (r == 0)
                 dec16_payload<true, PACKED6, true>(acc, c4, l4, lb[r], range[r], inv_s, q, cb_bytes, lane_const);
             else
                 dec16_payload<false, PACKED6, true>(acc, c4, l4, lb[r], range[r], inv_s, q, cb_bytes, lane_const);
+            if (R == 3 && r == 0) {
+                hold[0] = acc[0][0];
+                hold[1] = acc[1][1];
+                hold[2] = acc[2][2];
+                hold[3] = acc[3][3];
+            }
             if ((r & 3) == 3 || r == R - 1) request_group(pre, j);   // the group's four payloads are summed: its registers take the next item's
         }
         float *o = out + (int64_t)(i & ~3u) * 16 + 4 * q;
@@ -410,6 +420,8 @@ void hsq_decode_sum_d16u8_r_kernel(
                 a[3] = mean_div(a[3], md);
             }
             *reinterpret_cast<f32x4 *>(o + 16 * k) = a;
+            // an odd R's quotients (four dependent operations each) one subvector at a time: interleaved over all sixteen
+            // elements they need 3 x 16 registers at once, which R = 3 does not have at 8 waves
         }
         i = nxt;
     }

@@ -417,7 +417,7 @@ RESNET50_COMPRESSED = ([(64, 3, 3, 3)] + [(64, 64, 1, 1), (64, 64, 3, 3), (256, 
 RESNET50_SMALL = [(64,), (64,), (256,), (256,), (128,), (512,), (10, 64), (10,)]
 
 
-def _run_quantizer(shapes, users, seed, **argkw):
+def _run_quantizer(shapes, users, seed, grad_scale=1e-2, **argkw):
     from gq_amd.compressors import NearestNeighborCompressor
     from gq_amd.quantizers import Quantizer
     params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in shapes]
@@ -426,7 +426,7 @@ def _run_quantizer(shapes, users, seed, **argkw):
     for st in range(2):
         for u in range(users):
             for p in params:
-                p.grad = torch.randn(p.shape, device="cuda", generator=g) * 1e-2
+                p.grad = torch.randn(p.shape, device="cuda", generator=g) * grad_scale
             q.record(u, epoch=1)
         q.apply()
     return q, [p.grad.data.clone() for p in params]
@@ -458,6 +458,25 @@ def test_batched_quantizer_many_users_equal_per_tensor_path(users, kw):
     for a, b, s in zip(gb, gp, shapes):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), s
     assert torch.equal(qb._wire, qp._wire)
+
+
+@pytest.mark.parametrize("users", [3, 5, 7, 9, 17])
+@pytest.mark.parametrize("grad_scale", [1e-39, 8e37])
+def test_batched_quantizer_odd_user_counts_at_the_ends_of_the_float_range(users, grad_scale):
+    """The mean over an odd number of users is a four-operation quotient by the constant (csrc/gq_common.hpp): sums that are
+    subnormal (gradients of 1e-39) and sums that overflow (8e37 times a few users: +-inf) through the multi-tensor kernels,
+    against the per-tensor ones (which tests/test_gpu_kernels.py holds against the oracle's true division)."""
+    shapes = RESNET50_COMPRESSED[:6] + RESNET50_SMALL[:2]
+    qb, gb = _run_quantizer(shapes, users, 31, grad_scale=grad_scale)
+    qp, gp = _run_quantizer(shapes, users, 31, grad_scale=grad_scale, gq_no_batch=True)
+    assert qb._groups and qb._groups[0][2].ready and not qp._groups
+    for a, b, s in zip(gb, gp, shapes):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), s
+    big = torch.cat([a.reshape(-1) for a in gb])
+    if grad_scale < 1:
+        assert (big != 0).any() and big.abs().max() < 1.2e-38          # subnormal means, not flushed
+    elif users >= 9:
+        assert torch.isinf(big).any()
 
 
 @pytest.mark.parametrize("c_dim", [32, 8])
@@ -698,7 +717,7 @@ def _run_qsgd(shapes, users, seed, **argkw):
     for st in range(2):
         for u in range(users):
             for p in params:
-                p.grad = torch.randn(p.shape, device="cuda", generator=g) * 1e-2
+                p.grad = torch.randn(p.shape, device="cuda", generator=g) * grad_scale
             q.record(u, epoch=1)
         q.apply()
     return q, [p.grad.data.clone() for p in params]

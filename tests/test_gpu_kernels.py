@@ -251,6 +251,47 @@ def test_hsq_decode_sum_matches_oracle_mean(nat, oracle, R, M, K=256):
     assert np.array_equal(_bits(got), _bits(ref))
 
 
+@pytest.mark.parametrize("R", [3, 5, 6, 7, 9, 12, 13, 15, 17, 19, 33])
+@pytest.mark.parametrize("span", ["subnormal", "huge", "mixed", "inf"])
+def test_hsq_decode_mean_by_any_user_count_at_the_ends_of_the_float_range(nat, oracle, R, span):
+    """ps_quantizer.py:48 divides the sum by R.  For an odd R the kernels use a four-operation quotient by the constant
+    instead of the IEEE sequence (csrc/gq_common.hpp: exact for every input, tools/div_check.hip); an even R that is not a
+    power of two divides.  Payloads whose norms make the sums subnormal, overflow to +-inf, or NaN, against the oracle's
+    true division, bit for bit (any NaN equals any NaN)."""
+    M = 2051
+    rng = np.random.RandomState(700 + R)
+    cb = _cb(16, 256)
+    dev = torch.device("cuda:0")
+    codes = rng.randint(0, 256, (R, M)).astype(np.uint8)
+    levels = rng.randint(0, 65, (R, M)).astype(np.uint8)
+    if span == "subnormal":
+        lb = -rng.uniform(0, 4e-39, R)
+        ub = rng.uniform(0, 4e-39, R)
+    elif span == "huge":      # every payload finite (l * (ub - lb) < FLT_MAX for l <= 64); sums of many of them are not
+        lb = rng.choice([-1.0, 1.0], R) * rng.uniform(1.0e38, 1.65e38, R)
+        ub = lb + rng.uniform(0, 5e36, R)
+    elif span == "mixed":
+        lb = -10.0 ** rng.uniform(-44, 38, R)
+        ub = 10.0 ** rng.uniform(-44, 38, R)
+    else:                     # one payload's norms are +inf (level 0: 0 * inf = NaN): sums of +-inf and NaN
+        lb = -rng.uniform(0, 1, R)
+        ub = rng.uniform(0, 1, R)
+        ub[R - 1] = np.inf
+    lbub = np.stack([lb, ub], 1).astype(np.float32)
+    with np.errstate(all="ignore"):
+        decs = [oracle.hsq_decompress(codes[r], levels[r].astype(np.int32), lbub[r, 0], lbub[r, 1], cb, 6) for r in range(R)]
+        ref = oracle.mean_users(np.stack(decs, 0))
+    out = torch.empty(M * 16, dtype=torch.float32, device=dev)
+    nat.hsq_decode_sum(torch.from_numpy(codes).to(dev), torch.from_numpy(levels).to(dev),
+                       torch.from_numpy(lbub).to(dev), torch.from_numpy(cb).to(dev), 6, out, R=R)
+    got = out.cpu().numpy()
+    assert _same(got, ref)
+    if span == "subnormal":
+        assert (got != 0).any() and np.abs(got).max() < 1.2e-38
+    if span == "inf":
+        assert np.isinf(got).any() and np.isnan(got).any()
+
+
 @pytest.mark.parametrize("name", QSGD_CASES)
 def test_qsgd_matches_reference_golden(nat, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
