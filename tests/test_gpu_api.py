@@ -717,7 +717,7 @@ def _run_qsgd(shapes, users, seed, **argkw):
     for st in range(2):
         for u in range(users):
             for p in params:
-                p.grad = torch.randn(p.shape, device="cuda", generator=g) * grad_scale
+                p.grad = torch.randn(p.shape, device="cuda", generator=g) * 1e-2
             q.record(u, epoch=1)
         q.apply()
     return q, [p.grad.data.clone() for p in params]
