@@ -52,6 +52,14 @@ template <int OP> __global__ __launch_bounds__(256) void k(float *out, float see
             if (OP == 37) asm volatile("v_bfe_u32 %0, %0, 3, 5" : "+v"(f[u]));
             if (OP == 38) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(f[u]) : "v"(f[(u+1)&7]));
             if (OP == 39) asm volatile("v_max_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(f[u]) : "v"(f[(u+1)&7]));
+            if (OP == 40) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(f[u]) : "v"(f[(u+1)&7]));
+            if (OP == 41) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(f[u]) : "v"(f[(u+1)&7]));
+            if (OP == 42) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(f[u]) : "v"(f[(u+1)&7]), "v"(f[(u+2)&7]));
+            if (OP == 43) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(f[u]) : "v"(f[(u+1)&7]));
+            if (OP == 44) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(f[u]) : "v"(f[(u+1)&7]));
+            if (OP == 45) asm volatile("v_alignbit_b32 %0, %0, %0, 13" : "+v"(f[u]));
+            if (OP == 46) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(f[u]) : "v"(f[(u+1)&7]), "v"(f[(u+2)&7]));
+            if (OP == 47) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(f[u]) : "v"(f[(u+1)&7]));
         }
     }
     float s = c;
@@ -87,5 +95,7 @@ int main(int argc, char **argv) {
     run<29>("v_pk_fma_f32", 1); run<30>("v_cmp_gt_u32 vcc", 1); run<31>("v_cmp_gt_u32 sgpr", 1); run<32>("v_lshlrev_b32", 1);
     run<33>("v_perm_b32", 1); run<34>("v_maximum3_f32", 1); run<35>("v_fma_f32 sgpr src", 1); run<36>("v_min_f32", 1);
     run<37>("v_bfe_u32", 1); run<38>("v_mov_b32_dpp", 1); run<39>("v_max_f32_dpp", 1);
+    run<40>("v_mul_lo_u32", 1); run<41>("v_mul_u32_u24", 1); run<42>("v_mad_u32_u24", 1); run<43>("v_mul_hi_u32", 1);
+    run<44>("v_xor_b32", 1); run<45>("v_alignbit_b32", 1); run<46>("v_xad_u32", 1); run<47>("v_mul_hi_u32_u24", 1);
     return 0;
 }
