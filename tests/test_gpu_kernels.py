@@ -292,6 +292,32 @@ def test_hsq_decode_mean_by_any_user_count_at_the_ends_of_the_float_range(nat, o
         assert np.isinf(got).any() and np.isnan(got).any()
 
 
+@pytest.mark.parametrize("R", [1, 2, 3, 5, 6, 7, 12, 19, 64, 257])
+def test_mean_rows_divides_like_the_reference_mean(nat, R):
+    """gq_mean_rows (the dense side channel's aggregate, ps_quantizer.py:48 for the tensors IdenticalCompressor passes through):
+    (+0 + row 0 + row 1 + ...) / R with rows ascending; for an odd R the kernel's four-operation quotient must equal the true
+    division on subnormal, huge, infinite and NaN sums as well."""
+    n = 4099
+    rng = np.random.RandomState(900 + R)
+    rows = (rng.standard_normal((R, n)) * 10.0 ** rng.uniform(-44, 37, (1, n))).astype(np.float32)
+    rows[:, 0] = -0.0
+    rows[0, 1], rows[R - 1, 2] = np.inf, np.nan
+    rows[:, 3] = 3.0e38
+    with np.errstate(all="ignore"):
+        acc = np.zeros(n, np.float32)
+        for r in range(R):
+            acc = acc + rows[r]
+        ref = acc / np.float32(R)
+    dev = torch.device("cuda:0")
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    nat.mean_rows(torch.from_numpy(rows).to(dev), out)
+    got = out.cpu().numpy()
+    assert _same(got, ref)
+    assert _bits(got[:1])[0] == 0                      # the -0 column comes out as +0
+    if R >= 2:
+        assert np.isinf(got[3])
+
+
 @pytest.mark.parametrize("name", QSGD_CASES)
 def test_qsgd_matches_reference_golden(nat, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
