@@ -299,10 +299,14 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a collective that never completes (first RCCL contact on a new node) ends the job after five minutes with the
+        # watchdog's error instead of after the default ten
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("GQ_BENCH_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     from gq_amd import exchange, native
     native.lib()
