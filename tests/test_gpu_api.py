@@ -708,7 +708,7 @@ def test_fused_error_feedback_updates_grad_and_error_in_place(which):
         assert torch.equal(p.error[0], f - p.grad.data)
 
 
-def _run_qsgd(shapes, users, seed, **argkw):
+def _run_qsgd(shapes, users, seed, grad_fn=None, **argkw):
     from gq_amd.compressors import QSGDCompressor
     from gq_amd.quantizers import Quantizer
     params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in shapes]
@@ -718,9 +718,45 @@ def _run_qsgd(shapes, users, seed, **argkw):
         for u in range(users):
             for p in params:
                 p.grad = torch.randn(p.shape, device="cuda", generator=g) * 1e-2
+                if grad_fn is not None:
+                    p.grad = grad_fn(p.grad)
             q.record(u, epoch=1)
         q.apply()
     return q, [p.grad.data.clone() for p in params]
+
+
+QSGD_RANGES = {
+    "below": lambda t: t * 1e-23,            # bucket norms around 2^-81
+    "low": lambda t: t * 2e-22,              # ... 2^-77, elements down to 2^-90
+    "high": lambda t: t * 2e7,               # ... 2^19.6
+    "above": lambda t: t * 2e8,              # ... 2^23
+    "zeros": lambda t: torch.where(t.abs() < 3e-3, torch.zeros_like(t), t),   # exact zeros inside most buckets
+    "tiny": lambda t: torch.where(t.abs() < 1e-3, t * 1e-33, t),             # elements under 2^-102 beside ordinary ones
+}
+
+
+@pytest.mark.parametrize("span", sorted(QSGD_RANGES))
+def test_batched_qsgd_compress_divides_like_the_reference_at_every_scale(span, oracle):
+    """v / norm at the ends of the range (qsgd_compressor.py:52): the 4-bit multi-tensor compress against the per-tensor
+    kernels and against the oracle's decompress(compress(g)) for the deterministic rounding -- tiny and huge bucket norms,
+    exact zeros, elements forty orders of magnitude under their bucket's norm."""
+    shapes = RESNET50_COMPRESSED[:8] + RESNET50_SMALL[:2]
+    fn = QSGD_RANGES[span]
+    qb, gb = _run_qsgd(shapes, 1, 9, grad_fn=fn)
+    qp, gp = _run_qsgd(shapes, 1, 9, grad_fn=fn, gq_no_batch=True)
+    assert qb._groups and qb._groups[0][2].ready and not qp._groups
+    for a, b, s in zip(gb, gp, shapes):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), s
+    g = torch.Generator(device="cuda").manual_seed(9)
+    grads = [[fn(torch.randn(s, device="cuda", generator=g) * 1e-2) for s in shapes] for _ in range(2)][1]
+    for k, s in enumerate(shapes):
+        if int(np.prod(s)) <= 1000:
+            continue
+        d = qb.codecs[k].d
+        with np.errstate(all="ignore"):
+            norm, signs, levels = oracle.qsgd_compress(grads[k].cpu().numpy().reshape(-1), d, 2, 0)
+            want = oracle.qsgd_decompress(norm, signs, levels, d, 2).reshape(-1)
+        assert np.array_equal(gb[k].cpu().numpy().reshape(-1), want), s
 
 
 @pytest.mark.parametrize("kw", [dict(n_bit=8), dict(n_bit=8, c_dim=512, ef=True), dict(n_bit=5)])
