@@ -61,6 +61,43 @@ __device__ __forceinline__ void wave_first_max_nan(float &bv, int &bi) {
         br = take ? orr : br;
     }
 }
+// The same reduction without a trip through LDS per step (__shfl_xor is ds_bpermute_b32: ~100 cycles, and the six steps
+// depend on each other): quad permutes and row mirrors as DPP moves, v_permlane16_swap / v_permlane32_swap for the last
+// two steps.  Candidates are ordered by the 64-bit key (nan_rank << 32 | ~index): the largest rank, the lowest index
+// among equals.  Every lane holds a candidate and gets the result.
+__device__ __forceinline__ void wave_first_max_nan_dpp(float &bv, int &bi) {
+    unsigned br = nan_rank(bv);
+    auto better = [&](unsigned orr, int oi, float ov) {
+        const uint64_t mine = ((uint64_t)br << 32) | (unsigned)~bi, theirs = ((uint64_t)orr << 32) | (unsigned)~oi;
+        const bool take = theirs > mine;
+        br = take ? orr : br;
+        bi = take ? oi : bi;
+        bv = take ? ov : bv;
+    };
+#define GQ_DPP_STEP(CTRL)                                                                                          \
+    better(__builtin_amdgcn_update_dpp(0u, br, CTRL, 0xF, 0xF, false),                                             \
+           (int)__builtin_amdgcn_update_dpp(0u, (unsigned)bi, CTRL, 0xF, 0xF, false),                              \
+           __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(bv), CTRL, 0xF, 0xF, false)))
+    GQ_DPP_STEP(0xB1);    // quad_perm [1,0,3,2]
+    GQ_DPP_STEP(0x4E);    // quad_perm [2,3,0,1]
+    GQ_DPP_STEP(0x141);   // row_half_mirror: the other quad of each 8
+    GQ_DPP_STEP(0x140);   // row_mirror: the other 8 of each row of 16
+#undef GQ_DPP_STEP
+    {   // rows 0 <-> 1, 2 <-> 3: of two copies, the first keeps the even rows' values in both rows, the second the odd rows'
+        const auto r = __builtin_amdgcn_permlane16_swap(br, br, false, false);
+        const auto i = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+        const auto v = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+        br = r[0], bi = (int)i[0], bv = __uint_as_float(v[0]);
+        better(r[1], (int)i[1], __uint_as_float(v[1]));
+    }
+    {   // lanes 0-31 <-> 32-63
+        const auto r = __builtin_amdgcn_permlane32_swap(br, br, false, false);
+        const auto i = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+        const auto v = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+        br = r[0], bi = (int)i[0], bv = __uint_as_float(v[0]);
+        better(r[1], (int)i[1], __uint_as_float(v[1]));
+    }
+}
 // Wave-wide exact argmax for ONE subvector (rare path of the exact kernels): lane L scores codewords L, L + 64, ...
 // with the reference's fmaf chain, c(k, e) and v(e) supplied by the caller (v wave-uniform).
 template <class RowGet, class VGet>

@@ -1,36 +1,47 @@
-// HSQ encode, d = 16, K = 256: bf16x3 matrix-core prefilter + exact f32 rescoring.
+// HSQ encode, d = 16, K = 256: f16 matrix-core prefilter (two MFMAs per chain) + exact f32 rescoring + deferred
+// exact fix-ups.  Same bits as the exact f32 kernel (hsq_encode.hip) in about a quarter of its time.
 //
-// The exact f32 MFMA kernel (hsq_encode.hip) is bound by the f32 matrix rate, and on gfx950
-// the f32 MFMA shares its datapath with the VALU (measured, tools/enc_probe.hip: their times
-// ADD), so the 256-way argmax cannot hide behind it.  This kernel gets the same bits out
-// with ~4x less time:
+// The exact f32 MFMA is bound by the f32 matrix rate and shares its datapath with the VALU (tools/enc_probe.hip: their
+// times ADD), so the 256-way argmax cannot hide behind it.  This kernel scores approximately on the f16 matrix pipe
+// (which overlaps with the VALU), settles nearly every subvector from those scores plus FOUR exact scores, and hands
+// the rest to an exact scan:
 //
-//  1. APPROXIMATE scores on the bf16 matrix pipe (which does overlap with the VALU):
-//       c = ch + cl + O(2^-18 c),  v = vh + vl + O(2^-18 v)      (bf16 hi/lo splits)
-//       s~_k = ch.vh + ch.vl + cl.vh     (3 x v_mfma_f32_32x32x16_bf16, f32 accumulate)
-//     |s~_k - p_k| <= E := 2^-15 * max_k||c_k||_1 * max_j |v_j|   for the reference's p_k (fmaf chain):
-//     dropped terms 3*2^-18, chain/accumulate roundings ~2^-20, all relative to
-//     sum_j |c_kj||v_j| <= ||c_k||_1 max|v_j| <= 4 (1+eps) max|v_j|  (rows are unit L2 norm).
-//  2. The 16 scores a lane gets per row block are 8 GROUPS of 2 consecutive codewords
-//     (accumulator registers 2p, 2p+1).  Per group the VALU takes g = max |s~| (one v_max_f32
-//     with |.| modifiers) and forms ONE key
+//  1. APPROXIMATE scores, two v_mfma_f32_32x32x16_f16 per chain of 32 codewords x 32 subvectors:
+//       c = ch + cl + r_c  (f16 hi / lo split, |r_c| <= 2^-22 |c| + 2^-25),   v' = v * sigma,  vh = f16(v')
+//       s~_k = ch.vh + cl.vh          (products exact in f32, f32 accumulate)
+//     sigma is a power of two, ONE per wave and tile (an SGPR, so the conversion is one v_fma_mix per element): it
+//     keeps the tile's values in the middle of the f16 range and follows the data from tile to tile (below).
+//     Round 3 ran three bf16 MFMAs per chain (ch.vh + ch.vl + cl.vh, error 2^-15); measured in round 4
+//     (profiles/r04_encode_dvfs.txt): with the B operands zeroed the same instruction stream ran 18 % faster at
+//     2.06 GHz instead of 1.83 -- the chip lowers its clock under the matrix pipe's load -- and two MFMAs per chain
+//     without the lo split of the tile ran 15 % faster.  Two MFMAs cannot carry 2^-15: the tile is rounded ONCE, to
+//     11 bits, and the error bound below is 16 x larger; what makes that affordable is (3).
+//     Error against the reference's p_k (fmaf chain), in scaled units, for unit-free rows:
+//       |s~_k - sigma p_k| <= sum_j |c_kj| |v'_j - vh_j| + (r_c, accumulation: < 1 % of the first term)
+//                          <= 2^-11 ||c_k||_2 ||v'||_2 + 2^-25 ||c_k||_1          (Cauchy-Schwarz; subnormal grid)
+//     and sharper, with e_j the exponent of vh_j (|v'_j - vh_j| <= half an ulp = 2^-11 2^e_j; subnormal vh_j: 2^-25):
+//       E' := sqrt(n2) * (1.03 * 2^-11 * c2 + 2^-22) + 2^-21 * c2,   n2 = sum_j 4^e_j <= ||vh||_2^2 < 4 n2,
+//       c2 = max_k ||c_k||_2  (measured in the prologue),
+//     valid while 2^-12 <= n2 <= 2^24 (no f16 overflow; the subnormal term stays small): outside that window
+//     -- a subvector far off the wave's scale -- the subvector goes to the exact scan.  n2 costs four v_and_b32 and
+//     four v_dot2_f32_f16 per fragment.
+//  2. The 16 scores a lane gets per chain are 4 GROUPS of 4 consecutive codewords (accumulator registers 4q..4q+3).
+//     Per group the VALU takes g = max |s~| (v_max3_f32 + v_max_f32 with |.| modifiers) and forms ONE key
 //       key = (bits(g) & 0x7FFFFFE0) | group_id ,
-//     and keeps the TOP-2 group keys per lane (v_med3_u32 / v_max3_u32): ~1.6 VALU ops per
-//     score instead of ~3 for a compare/select argmax.  (On gfx950 min/max/med3 and v_and_or
-//     issue ~1.6x slower than add/fma -- tools/valu_probe.hip -- so op COUNT is what matters.)
-//  3. EXACT rescoring: both codewords of the best group of each half (4 per subvector) are
-//     recomputed with the reference's arithmetic, acc = fmaf(c[j], v[j], acc) for j ascending,
-//     codebook rows from LDS.  The largest |p| (lowest index on a tie) is the answer IF every
-//     other candidate is provably smaller:  upper(second-best group key of either half) + E < |u|.
-//     Every candidate that was not rescored lies in a group whose key is <= that bound, so it
-//     cannot reach |u| even after the approximation error: code and u are exactly the
-//     reference's first-max argmax and projection.
-//  4. Otherwise (top-2 gap below ~2e-4 relative, ~5e-4 of random subvectors; tiny / huge / non-finite
-//     inputs) the wave stops for a moment and recomputes that subvector exactly against all 256
-//     codewords (lane k takes codewords k, k+64, k+128, k+192; wave-wide first-max reduction).
-//     Correctness never depends on E being tight -- only on it being an upper bound.
-//  5. The last workgroup to finish folds the per-workgroup (min,max) of u into the final (lb, ub):
-//     the whole encode is ONE launch.
+//     and keeps the TOP-2 group keys per lane and half tile in five operations per chain (v_max3_u32 / v_med3_u32).
+//     (On gfx950 min / max / med3 / and_or issue ~1.6x slower than add / fma -- tools/oprate.hip -- so op COUNT matters.)
+//  3. EXACT rescoring: the four codewords of the best group are recomputed with the reference's arithmetic,
+//     acc = fmaf(c[j], v[j], acc) for j ascending, codebook rows from LDS.  The largest |p| (lowest index on a tie)
+//     is the answer IF every other candidate is provably smaller:  upper(second-best key) + E' < |p| sigma.
+//     Every codeword that was not rescored lies in a group whose key is <= that bound, so it cannot reach |p| even
+//     after the approximation error: code and u are exactly the reference's first-max argmax and projection.
+//  4. Otherwise (~0.6 % of N(0,1) subvectors; anything outside the window; non-finite inputs) the subvector is QUEUED:
+//     its 16 floats and its destination go to the wave's ring in LDS.  Whenever four are waiting (and once more when the
+//     wave has run out of tiles) the wave scans them exactly, a quarter wave per subvector, each lane 16 codewords
+//     (scan4 in the kernel).  Round 3 stopped the whole wave for ONE such subvector at a time (1,500 scans cost 1.5 us of
+//     a 42 us launch); batched, six times as many cost about as much.  Correctness never depends on E' being tight --
+//     only on it being an upper bound.
+//  5. Per-workgroup (min, max) of u go to the workspace; the level kernel folds them into (lb, ub).
 #include <hip/hip_ext.h>
 
 #include <type_traits>
@@ -46,6 +57,13 @@ constexpr int PF_THREADS = PF_WAVES * 64;
 constexpr int PF_TAIL = 4;   // swept 2..12 in round 1 (52.3 us at 4..8, 54 at 2 and 12); again at the end of round 3: 3-4 40.35, 6 40.48, 8 40.6, 10 40.8 us
 constexpr int PF_LDS_SEGS = 384;            // batched form: tensors whose segment records are kept in LDS (24 KiB)
 constexpr int QUAD_STRIDE = 68;             // LDS floats per GROUP of 4 codewords (64 used, 272 B = 17 x 16 B: random groups spread over the banks)
+constexpr int PF_QCAP = 64;                 // deferred exact scans a wave can hold (a ring in LDS; a tile adds at most 64)
+// Error bound of the f16 prefilter (header, 1): E' = ||vh||_2 * ERR_REL * c2 + ERR_ABS * c2 inside the window of ||vh||_2^2
+constexpr float ERR_REL = 1.03f * 4.8828125e-04f;     // 1.03 * 2^-11
+constexpr float ERR_ABS = 4.76837158203125e-07f;      // 2^-21
+constexpr unsigned N2_LO_BITS = 0x39800000u;          // 2^-12
+constexpr unsigned N2_HI_BITS = 0x4B800000u;          // 2^24  (||vh||_2^2 < 4 n2 <= 2^26: every |vh_j| < 2^13)
+constexpr int SIGMA_TARGET_EXP2 = 10;                 // the largest sampled n2 of a tile is steered to ~2^10 (norm 2^5 .. 2^6)
 
 // Arguments of the prefilter kernels.  Single-tensor form: grad/M/codes/u.  Batched form
 // (gq_hsq_encode_batched): a segment table describes many tensors that share the codebook; tiles
@@ -103,9 +121,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // which made this form 3x slower than the single-tensor one; from LDS the record is ~100 cycles away,
     // and the tile -> segment word is fetched one tile ahead.
     __shared__ int64_t s_seg[(BATCHED && SEGLDS) ? PF_LDS_SEGS * 8 : 1];
-    // bf16 hi / lo A fragments of the 8 row blocks as the waves of the workgroup produce them (one row block each)
+    // f16 hi / lo A fragments of the 8 row blocks as the waves of the workgroup produce them (one row block each)
     __shared__ __attribute__((aligned(16))) u32x4 s_frag[8 * 2 * 64];
     __shared__ float s_c1[PF_WAVES];
+    // deferred exact scans (header, 4): every wave's own ring of PF_QCAP entries = the subvector's 16 floats +
+    // {code address lo, hi, index into u, segment}.  Written and read by the same wave only: no flags, no atomics.
+    __shared__ __attribute__((aligned(16))) float s_qv[PF_WAVES * PF_QCAP * 16];
+    __shared__ __attribute__((aligned(16))) unsigned s_qm[PF_WAVES * PF_QCAP * 4];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -282,8 +304,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         lmax = -INFINITY;
     };
 
-    // B fragments: lane (col j, half h) holds v[8h .. 8h+7] of subvector j of each block
-    bf16x8 vh[2], vl[2];
+    // B fragments: lane (col j, half h) holds f16(sigma * v[8h .. 8h+7]) of subvector j of each block;
+    // n2p: sum of 4^exponent over those eight values (half of the subvector's n2: the header's error bound)
+    half8 vh[2];
+    float n2p[2] = {0.0f, 0.0f};
     Tile ti = {};
     auto seg_of = [&](int64_t tile) {   // batched: tile -> tensor, one global word (0 beyond the end)
         return (BATCHED && tile < tile_end) ? a.tile_seg[tile] : 0;
@@ -305,7 +329,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         load_tile(ti, cur);
         load_err(ti, nxte);
     }
-    if (threadIdx.x == 0) s_next = PF_WAVES;   // the first PF_WAVES tiles of the run go to the waves by index
+    if (threadIdx.x == 0) {
+        s_next = PF_WAVES;   // the first PF_WAVES tiles of the run go to the waves by index
+    }
 #pragma unroll
     for (int n = 0; n < 256 * 16 / PF_THREADS; ++n) {
         const int i = threadIdx.x + n * PF_THREADS, k = i >> 4, jj = i & 15;
@@ -316,44 +342,157 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         for (int i = threadIdx.x; i < n; i += PF_THREADS) s_seg[i] = a.seg_table[i];
     }
     {
-        bf16x8 fh, fl;
-        split8(q0, q1, fh, fl);
+        half8 fh, fl;
+        split8_f16(q0, q1, fh, fl);
         s_frag[(wave * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, fh);
         s_frag[(wave * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, fl);
-        // The error bound scales with max_k ||c_k||_1 (<= 4 for unit-L2 rows); measure it instead of
-        // trusting the caller's codebook to be normalised.  Row wave*32 + j: this lane's 8 elements + its partner's.
-        float l1 = 0.0f;
+        // The error bound scales with max_k ||c_k||_2 (1 for the reference's normalised codebooks); measure it instead
+        // of trusting the caller.  Row wave*32 + j: this lane's 8 elements + its partner's.  A row that is not finite
+        // (or beyond the f16 range) makes the maximum at least 2^30 or NaN -- tested on the bits below.
+        float l2 = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) l1 += fabsf(q0[e]) + fabsf(q1[e]);
-        l1 += __shfl_xor(l1, 32, 64);
-        l1 = wave_max(l1);
-        if (lane == 0) s_c1[wave] = l1;
+        for (int e = 0; e < 4; ++e) l2 = __fmaf_rn(q0[e], q0[e], __fmaf_rn(q1[e], q1[e], l2));
+        l2 += __shfl_xor(l2, 32, 64);
+        l2 = wave_max_nan(l2);
+        if (lane == 0) s_c1[wave] = l2;
     }
     __syncthreads();
-    // A fragments of v_mfma_f32_32x32x16_bf16: lane (row j, half h) holds c[rb*32+j][8h .. 8h+7];
-    // hi and lo bf16 parts, 64 VGPRs, resident for the kernel's lifetime.  (Keeping them in LDS
-    // instead and running 4 waves/SIMD measured slower: the kernel is bound by VALU issue, not
+    // A fragments of v_mfma_f32_32x32x16_f16: lane (row j, half h) holds c[rb*32+j][8h .. 8h+7];
+    // hi and lo f16 parts, 64 VGPRs, resident for the kernel's lifetime.  (Keeping them in LDS
+    // instead and running 3 waves/SIMD measured slower: the kernel is bound by VALU issue, not
     // by latency.)
-    bf16x8 ch[8], cl[8];
+    half8 ch[8], cl[8];
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb) {
-        ch[rb] = __builtin_bit_cast(bf16x8, s_frag[(rb * 2 + 0) * 64 + lane]);
-        cl[rb] = __builtin_bit_cast(bf16x8, s_frag[(rb * 2 + 1) * 64 + lane]);
+        ch[rb] = __builtin_bit_cast(half8, s_frag[(rb * 2 + 0) * 64 + lane]);
+        cl[rb] = __builtin_bit_cast(half8, s_frag[(rb * 2 + 1) * 64 + lane]);
     }
-    float c1 = s_c1[0];
+    unsigned c2b = __float_as_uint(s_c1[0]);   // squares: non-negative, so the bits order them, a NaN above everything
 #pragma unroll
-    for (int w = 1; w < PF_WAVES; ++w) c1 = fmaxf(c1, s_c1[w]);
-    const float err_scale = c1 * ERR_SCALE;  // E = max|v_j| * err_scale
+    for (int w = 1; w < PF_WAVES; ++w) c2b = max(c2b, __float_as_uint(s_c1[w]));
+    // E' = ||vh||_2 * err_rel + err_abs (header, 1); a codebook outside the f16 range: +infinity, nothing is ever "safe"
+    const float c2 = __builtin_sqrtf(__uint_as_float(c2b)) * 1.0000002f;
+    const float err_rel = c2b < 0x4E800000u ? c2 * ERR_REL + 2.4e-7f : INFINITY;   // (+ 2^-22: the lo parts of small codebook entries sit on f16's subnormal grid)
+    const float err_abs = c2b < 0x4E800000u ? c2 * ERR_ABS : INFINITY;
 
     int64_t tn = draw();                // the tile after this wave's first one
     int seg_n = seg_of(tn);             // in flight while the first tile is set up
     int seg_next = 0;                   // its value, read back BEFORE a tile's stores (see the consume point)
+    // sigma: the power of two the tile in flight was multiplied by before its conversion to f16 (wave-uniform, an SGPR).
+    // First tile: the largest |element| of the tile goes to [2^4, 2^5); afterwards every tile's scale follows the norms
+    // the previous tile showed (four sampled lanes, below).  A subvector that ends up outside the window of the error
+    // bound is queued for the exact scan, so a bad guess costs time, never bits.
+    // (the scale's exponent field lives in a scalar register: the compiler takes everything behind `t < tile_end` for
+    // lane-dependent -- t starts from the wave's index -- so the value is read back through readfirstlane where it changes)
+    float sigma_t = 1.0f;
     if (t < tile_end) {
         seg_next = BATCHED ? __builtin_amdgcn_readfirstlane(seg_n) : 0;
         fold_err(ti, cur, nxte);
+        float m = 0.0f;
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) split8(cur[2 * blk], cur[2 * blk + 1], vh[blk], vl[blk]);
+        for (int i = 0; i < 4; ++i) m = fmaxf(fmaxf(fabsf(cur[i][0]), fabsf(cur[i][1])), fmaxf(fmaxf(fabsf(cur[i][2]), fabsf(cur[i][3])), m));
+        const unsigned em = (unsigned)__builtin_amdgcn_readfirstlane((int)(__float_as_uint(wave_max(m)) >> 23));
+        if (em >= 1u && em <= 254u) {
+            int f = 258 - (int)em;
+            f = f < 27 ? 27 : (f > 227 ? 227 : f);
+            sigma_t = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(f << 23));
+        }
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) scale8_f16(cur[2 * blk], cur[2 * blk + 1], sigma_t, vh[blk], n2p[blk]);
     }
+    // (min, max) of one exactly scanned projection into its tensor's words (batched form)
+    auto fold_seg = [&](int seg, float v) {
+        unsigned *mm = a.seg_minmax + 2 * seg;
+        const unsigned mv = order_map(v);
+        if (mv < __hip_atomic_load(mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(mm, mv);
+        if (mv > __hip_atomic_load(mm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(mm + 1, mv);
+    };
+    auto poison_seg = [&](int seg) {   // (lb, ub) of this tensor become NaN (torch.min / torch.max propagate it)
+        atomicMin(a.seg_minmax + 2 * seg, MAPPED_NAN_LO);
+        atomicMax(a.seg_minmax + 2 * seg + 1, MAPPED_NAN_HI);
+    };
+    // Exact scan of `n` ring entries from `first` on, FOUR at a time: quarter wave e takes entry e of the batch, its lane r
+    // the 16 codewords of quads r, r + 16, r + 32, r + 48 (ascending index; the sixteen lanes of a ds_read_b128 group
+    // then read sixteen different quads: no bank conflicts) with the reference's fmaf chain, first maximum in
+    // torch.argmax's order (NaN largest, first one wins) inside the lane and then across the quarter's sixteen lanes by
+    // quad permutes and row mirrors (DPP moves: no trip through LDS).  ~360 cycles per subvector against ~1,700 for
+    // the whole wave on one subvector at a time (profiles/r04_experiments.txt).
+    int qhead = 0, qcnt = 0;   // this wave's ring: first entry, entries (wave-uniform)
+    auto scan4 = [&](int first, int n) {
+        const int e = lane >> 4, r = lane & 15;
+        for (int b0 = 0; b0 < n; b0 += 4) {
+            const bool live = b0 + e < n;   // (an idle quarter re-scans the batch's first entry and stores nothing)
+            const int slot = wave * PF_QCAP + ((first + b0 + (live ? e : 0)) & (PF_QCAP - 1));
+            float w[16];
+            {
+                const f32x4 *qv = reinterpret_cast<const f32x4 *>(s_qv + 16 * slot);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 x = qv[q];
+                    w[4 * q] = x[0];
+                    w[4 * q + 1] = x[1];
+                    w[4 * q + 2] = x[2];
+                    w[4 * q + 3] = x[3];
+                }
+            }
+            // The lane's sixteen scores in ascending index order: `>` on |.| keeps the first maximum (three operations a
+            // score); the sum of the |scores| is NaN exactly when one of them is, and only then the order of
+            // torch.argmax (NaN largest, the first one wins) needs the ranks -- a wave-uniform, rare branch.
+            f32x4 p[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p[q] = exact_score_quad<16>(s_cb + (r + 16 * q) * QUAD_STRIDE, w);
+            float bv = p[0][0], asum = fabsf(p[0][0]);
+            int bi = 4 * r;
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {
+                take_if_greater(bv, bi, p[i >> 2][i & 3], 64 * (i >> 2) + 4 * r + (i & 3));
+                asum += fabsf(p[i >> 2][i & 3]);
+            }
+            unsigned br = nan_rank(bv);
+            if (__ballot(nan_bits(asum))) {
+                bv = p[0][0], bi = 4 * r, br = nan_rank(bv);
+#pragma unroll
+                for (int i = 1; i < 16; ++i) {
+                    const unsigned pr = nan_rank(p[i >> 2][i & 3]);
+                    const bool gt = pr > br;
+                    br = gt ? pr : br;
+                    bv = gt ? p[i >> 2][i & 3] : bv;
+                    bi = gt ? 64 * (i >> 2) + 4 * r + (i & 3) : bi;
+                }
+            }
+            auto better = [&](unsigned orr, int oi, float ov) {   // the larger rank, the lower index among equals
+                const uint64_t mine = ((uint64_t)br << 32) | (unsigned)~bi, theirs = ((uint64_t)orr << 32) | (unsigned)~oi;
+                const bool take = theirs > mine;
+                br = take ? orr : br;
+                bi = take ? oi : bi;
+                bv = take ? ov : bv;
+            };
+#define GQ_DPP_STEP(CTRL)                                                                 \
+    better(__builtin_amdgcn_update_dpp(0u, br, CTRL, 0xF, 0xF, false),                    \
+           (int)__builtin_amdgcn_update_dpp(0u, (unsigned)bi, CTRL, 0xF, 0xF, false),     \
+           __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(bv), CTRL, 0xF, 0xF, false)))
+            GQ_DPP_STEP(0xB1);    // quad_perm [1,0,3,2]
+            GQ_DPP_STEP(0x4E);    // quad_perm [2,3,0,1]
+            GQ_DPP_STEP(0x141);   // row_half_mirror
+            GQ_DPP_STEP(0x140);   // row_mirror
+#undef GQ_DPP_STEP
+            const bool isnan = live && nan_bits(bv);
+            if (__ballot(isnan)) sawnan = true;   // (lb, ub) become NaN (torch.min / torch.max propagate it)
+            if (live && r == 0) {
+                const u32x4 m = *reinterpret_cast<const u32x4 *>(s_qm + 4 * slot);
+                *(gcode_ptr)(uintptr_t)((uint64_t)m[0] | ((uint64_t)m[1] << 32)) = (CodeT)bi;
+                ((gf_ptr)u)[m[2]] = bv;
+                if (BATCHED) {
+                    if (isnan) poison_seg((int)m[3]);
+                    else fold_seg((int)m[3], bv);
+                } else {
+                    worklist[m[2]] = (int)m[2];   // diagnostics only: which subvectors took an exact scan
+                    lmin = fminf(lmin, bv);
+                    lmax = fmaxf(lmax, bv);
+                }
+            }
+        }
+    };
     while (t < tile_end) {
         // single tensor: tn was drawn at the end of the previous tile; batched: a whole tile ago
         const int64_t tnn = BATCHED ? draw() : 0;
@@ -369,7 +508,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             cur_seg = ti.seg;
         }
         // ---- prefilter: 16 (block, row block) chains; top-2 GROUP keys per (block, row-block half) ----
-        // The three MFMAs of chain c+1 depend on each other and issue is in order, so they are
+        // The two MFMAs of chain c+1 depend on each other and issue is in order, so they are
         // placed one by one BETWEEN the key operations of chain c (sched_barrier pins the order):
         // the matrix pipe runs under the VALU stream.
         unsigned best[4] = {0, 0, 0, 0}, second[4] = {0, 0, 0, 0};
@@ -395,9 +534,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             second[trk] = max3u(second[trk], trk_a, b);
         };
         f32x16 acc = {0};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[0], vh[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[0], vl[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[0], vh[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[0], vh[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[0], vh[0], acc, 0, 0, 0);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int rb = c & 7, trk = c >> 2;
@@ -405,12 +543,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
                 const int nb = (c + 1) >> 3, nr = (c + 1) & 7;
                 f32x16 nacc = {0};
                 __builtin_amdgcn_sched_barrier(0);
-                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[nr], vh[nb], nacc, 0, 0, 0);
+                nacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[nr], vh[nb], nacc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 track_lo(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
                 __builtin_amdgcn_sched_barrier(0);
-                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vl[nb], nacc, 0, 0, 0);
-                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vh[nb], nacc, 0, 0, 0);
+                nacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[nr], vh[nb], nacc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 track_hi(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
                 __builtin_amdgcn_sched_barrier(0);
@@ -457,8 +594,16 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             bk[0] = (unsigned)b0;
             bk[1] = (unsigned)b1;
         }
+        // n2 of subvector `lane`: its two halves' sums (the same exchange)
+        float n2 = n2p[0];
+        {
+            float n2o = n2p[1];
+            swap32(n2, n2o);
+            n2 += n2o;
+        }
+        const unsigned n2b = __float_as_uint(n2);
 
-        // ---- exact rescoring of the better of the two halves' best groups (2 codewords; the
+        // ---- exact rescoring of the better of the two halves' best groups (4 codewords; the
         // reference's fmaf chain).  The other half's best group joins the bound on everything that
         // was not rescored.
         const bool pick1 = (bk[1] & KEY_MASK) > (bk[0] & KEY_MASK);
@@ -471,87 +616,97 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         take_if_greater(val, idx, p4[2], kc + 2);
         take_if_greater(val, idx, p4[3], kc + 3);
 
-        float vmax = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) vmax = fmaxf(fmaxf(fabsf(vf[e]), fabsf(vf[e + 1])), vmax);
-        const float E = vmax * err_scale;
+        // The bound (header, 1), in the tile's scaled units.  The window test is on the BITS of n2 (a sum of
+        // squares: never negative; NaN, infinity and zero fall outside): this file is compiled for NaN-free float compares.
+        const float E = __builtin_amdgcn_sqrtf(n2) * err_rel + err_abs;
         const float others = __uint_as_float(rest);  // >= every s~ outside the rescored group
-        bool safe = (others + E < fabsf(val)) && (vmax >= 8.27e-25f) && (vmax <= 1.0e30f);
-        // a NaN score: the float comparisons above are compiled for NaN-free operands (-fno-honor-nans: the
+        const bool in_window = (n2b - N2_LO_BITS) <= (N2_HI_BITS - N2_LO_BITS);
+        bool safe = in_window && (others + E < fabsf(val * sigma_t));
+        // a NaN score: the float comparison above is compiled for NaN-free operands (-fno-honor-nans: the
         // complement `others + E >= |val|` is what is evaluated, false for NaN), so the bits decide
         if (nan_bits(val)) safe = false;
-        if (vmax == 0.0f && !nan_bits(val)) {  // all-zero subvector: every score is +0 -> first index, u = +0
-            safe = true;
-            val = 0.0f;
-            idx = 0;
+        // All-zero subvector (every score is +0 -> first index, u = +0): common in real gradients (dead units), so it is
+        // settled here, not by the exact scan.  n2 == 0 (all sixteen f16 values zero or subnormal) is the cheap hint; the
+        // sixteen f32 values decide.
+        if (__ballot(n2b == 0u)) {
+            unsigned any = 0;
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) any |= (__float_as_uint(vf[e]) | __float_as_uint(vf[e + 1])) & 0x7FFFFFFFu;
+            if (any == 0u && !nan_bits(val)) {
+                safe = true;
+                val = 0.0f;
+                idx = 0;
+            }
         }
-        // NaN anywhere makes the comparisons false -> not safe -> exact fix-up path
 
         const bool valid = lane <= ti.rem;         // this lane's subvector exists (the tensor's last tile may be short)
+
+        // The next tile's scale: the larger n2 of two sampled subvectors of THIS tile goes to about
+        // 2^SIGMA_TARGET_EXP2 (two samples, one of each half tile; scalar arithmetic on exponents; a sample that overflowed
+        // pulls the scale down hard).
+        float sigma_n = sigma_t;
+        {
+            const unsigned s0 = (unsigned)__builtin_amdgcn_readlane((int)n2b, 5), s1 = (unsigned)__builtin_amdgcn_readlane((int)n2b, 58);
+            const unsigned smp = s0 > s1 ? s0 : s1;
+            if (smp != 0u) {
+                const int e2 = (int)(smp >> 23);
+                const int k = e2 >= 255 ? -16 : ((127 + SIGMA_TARGET_EXP2 - e2) >> 1);
+                int f = (int)((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sigma_t)) >> 23) + k;
+                f = f < 27 ? 27 : (f > 227 ? 227 : f);
+                sigma_n = __uint_as_float((unsigned)f << 23);
+            }
+        }
 
         // Consume the prefetched tile (convert it to the next B fragments) BEFORE this tile's
         // stores are issued: the wait for the prefetch then sees only long-finished memory ops.
         // Done the other way round, the compiler's vmcnt wait at the first use of `nxt` sits right
         // behind the just-issued stores and every tile eats a store round trip.
-        bf16x8 nvh[2], nvl[2];
+        half8 nvh[2];
+        float nn2p[2] = {0.0f, 0.0f};
         // the tile -> tensor word of the tile after next was requested at the top of this tile: read it
         // back here, with the prefetch, not behind the stores
         if (BATCHED) seg_next = __builtin_amdgcn_readfirstlane(seg_n);
         if (EF && tn < tile_end) fold_err(tin, nxt, nxte);
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) split8(nxt[2 * blk], nxt[2 * blk + 1], nvh[blk], nvl[blk]);
+        for (int blk = 0; blk < 2; ++blk) scale8_f16(nxt[2 * blk], nxt[2 * blk + 1], sigma_n, nvh[blk], nn2p[blk]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             vh[blk] = nvh[blk];
-            vl[blk] = nvl[blk];
+            n2p[blk] = nn2p[blk];
         }
         __builtin_amdgcn_sched_barrier(0);
 
-        // ---- exact fix-up, in place and wave-wide, for the few subvectors the bound could not settle
-        // (~5e-4 of random ones: a wave meets one every ~30 tiles).  The flagged lane's subvector is
-        // broadcast through SGPRs; lane k scores codewords k, k+64, k+128, k+192 with the reference's
-        // fmaf chain from the LDS codebook; a wave-wide first-max reduction picks the winner.
-        uint64_t todo = __ballot(valid && !safe);
-        while (todo) {
-            const int fl = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            float w[16];
+        // ---- the few subvectors the bound could not settle (header, 4): into this wave's ring; four at a time they are
+        // scanned exactly (scan4 below), the rest when the wave has run out of tiles.  A flagged lane writes its sixteen
+        // floats and where the answer goes.
+        const bool flagged = valid && !safe;
+        uint64_t todo = __ballot(flagged);
+        while (todo) {   // (one trip; a second one only when a tile flags more lanes than the ring has room for)
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)todo, 0u));
+            const bool mine = ((todo >> lane) & 1) && rank < PF_QCAP - qcnt;
+            if (mine) {
+                const int slot = wave * PF_QCAP + ((qhead + qcnt + rank) & (PF_QCAP - 1));
+                f32x4 *qv = reinterpret_cast<f32x4 *>(s_qv + 16 * slot);
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                w[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vf[e]), fl));
-            float bv = 0.0f;
-            int bi = lane;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = q * 64 + lane;
-                const float *row = s_cb + (k >> 2) * QUAD_STRIDE + (k & 3);
-                float acc = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc = __fmaf_rn(row[4 * e], w[e], acc);
-                if (q == 0) {
-                    bv = acc;
-                } else {
-                    take_if_greater_nan(bv, bi, acc, k);   // torch.argmax's order: NaN is the largest, the first one wins
-                }
+                for (int q = 0; q < 4; ++q) qv[q] = f32x4{vf[4 * q], vf[4 * q + 1], vf[4 * q + 2], vf[4 * q + 3]};
+                const uint64_t ca = (uint64_t)(uintptr_t)(ti.codes + ti.sv0) + (uint64_t)sizeof(CodeT) * (unsigned)lane;
+                *reinterpret_cast<u32x4 *>(s_qm + 4 * slot) =
+                    u32x4{(unsigned)ca, (unsigned)(ca >> 32), (unsigned)((BATCHED ? t * 64 : ti.sv0) + lane), (unsigned)ti.seg};
             }
-            wave_first_max_nan(bv, bi);
-            if (lane == fl) {
-                val = bv;
-                idx = bi;
+            const uint64_t took = __ballot(mine);
+            qcnt += (int)__builtin_popcountll(took);
+            todo &= ~took;
+            if (qcnt >= 4) {
+                const int nb = qcnt >> 2;
+                scan4(qhead, 4 * nb);
+                qhead = (qhead + 4 * nb) & (PF_QCAP - 1);
+                qcnt -= 4 * nb;
             }
-            if (nan_bits(bv)) {   // (lb, ub) of this tensor become NaN (torch.min / torch.max propagate it)
-                sawnan = true;
-                if (BATCHED && lane == 0) {
-                    atomicMin(a.seg_minmax + 2 * ti.seg, MAPPED_NAN_LO);
-                    atomicMax(a.seg_minmax + 2 * ti.seg + 1, MAPPED_NAN_HI);
-                }
-            }
-            if (!BATCHED && lane == 0) worklist[ti.sv0 + fl] = (int)(ti.sv0 + fl);   // diagnostics only: which subvectors took this path
         }
 
-        if (valid) {   // uniform bases (the tile's first code / projection) + the lane index
+        if (valid && safe) {   // uniform bases (the tile's first code / projection) + the lane index
             (ti.codes + ti.sv0)[(unsigned)lane] = (CodeT)idx;
             ((gf_ptr)u + (BATCHED ? t * 64 : ti.sv0))[(unsigned)lane] = val;
             lmin = fminf(lmin, val);
@@ -560,11 +715,12 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         ti = tin;
         t = tn;
         tn = BATCHED ? tnn : draw();
+        sigma_t = sigma_n;
     }
-    if (BATCHED) {
-        flush_minmax();
-        return;
-    }
+    if (BATCHED) flush_minmax();
+
+    if (qcnt) scan4(qhead, qcnt);   // out of tiles: what is left in the ring (one to three entries)
+    if (BATCHED) return;
     write_minmax_partials<PF_WAVES>(lmin, lmax, ws, sawnan);   // per-workgroup (min,max); the level kernel folds them
 }
 

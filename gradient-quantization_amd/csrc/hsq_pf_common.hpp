@@ -38,6 +38,46 @@ __device__ __forceinline__ void split8(const f32x4 &q0, const f32x4 &q1, bf16x8 
     lo = __builtin_bit_cast(bf16x8, L);
 }
 
+// ---- f16 operands of the d = 16 kernel (hsq_encode_pf.hip): two MFMAs per chain -------------------------------
+// Facts checked on the device by tools/f16_probe.hip (profiles/r04_f16_probe.txt): v_mfma_f32_32x32x16_f16 keeps
+// subnormal f16 inputs; v_fma_mixlo_f16 / v_fma_mixhi_f16 of (x, 2^s, 0) and v_cvt_pk_f16_f32 round to nearest even;
+// v_dot2_f32_f16(a, a, acc) is within 2^-23 of the sum of squares.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// 8 consecutive floats of a codebook row -> hi and lo f16 fragments: c = hi + lo + r, |r| <= 2^-22 |c| + 2^-25
+// (c - hi is exact in f32; the second term is the subnormal grid of f16 and is what is left for |c| < 2^-3)
+__device__ __forceinline__ void split8_f16(const f32x4 &q0, const f32x4 &q1, half8 &hi, half8 &lo) {
+    const float x[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hi[i] = (_Float16)x[i];
+        lo[i] = (_Float16)(x[i] - (float)hi[i]);
+    }
+}
+// 8 consecutive floats of a subvector, times the wave's power of two `scale` (an SGPR), -> ONE f16 fragment: one
+// v_fma_mix per element (the product is exact in f32, the conversion rounds once), no lo part.
+// n2 += sum of 4^e_j over the eight values, e_j = the exponent of the f16 value (its mantissa masked off: one v_and_b32
+// per pair, then v_dot2_f32_f16): the rounding error of element j is at most half an ulp = 2^-11 * 2^e_j (subnormal
+// results: 2^-25, counted separately), so 2^-11 sqrt(n2) bounds the L2 norm of the tile's rounding error -- ~1.5 x
+// tighter than 2^-11 ||vh||_2 for the price of the mask.
+__device__ __forceinline__ void scale8_f16(const f32x4 &q0, const f32x4 &q1, float scale, half8 &hi, float &n2) {
+    u32x4 H = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = i < 2 ? q0[2 * i] : q1[2 * i - 4], b = i < 2 ? q0[2 * i + 1] : q1[2 * i - 3];
+        unsigned r;   // the lo form writes bits 0-15 and leaves the rest, the hi form then fills bits 16-31
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(scale));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(r) : "v"(b), "s"(scale));
+        H[i] = r;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned e = H[i] & 0x7C007C00u;
+        asm("v_dot2_f32_f16 %0, %1, %1, %0" : "+v"(n2) : "v"(e));
+    }
+    hi = __builtin_bit_cast(half8, H);
+}
+
 __device__ __forceinline__ unsigned and_or(unsigned x, unsigned mask, unsigned c) { return (x & mask) | c; }
 // one VALU op each (hipcc does not reliably form these from min/max compositions)
 __device__ __forceinline__ unsigned max3u(unsigned a, unsigned b, unsigned c) {

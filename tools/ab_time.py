@@ -13,6 +13,8 @@ D = int(os.environ.get("GQ_AB_D", "16"))
 cb = torch.from_numpy(load_codebook(D, 256)).to(dev)
 torch.manual_seed(1234)
 g = torch.randn(25_000_000, device=dev)
+if os.environ.get("GQ_AB_INPUT") == "zeros":      # DVFS check: the same binary on all-zero data (MI355X_MICROARCH.md, DVFS give-back item 1)
+    g.zero_()
 M = g.numel() // D
 codes = torch.empty(M, dtype=torch.uint8, device=dev); u = torch.empty(M, dtype=torch.float32, device=dev)
 ws = native.new_workspace(dev, M)

@@ -1,0 +1,178 @@
+"""Diagnostic / experimental builds of the d16 prefilter encode (hsq_encode_pf.hip) for tools/ab_time.py -- never shipped:
+    python tools/pf_variants.py nofix zb4 zblo m32 m32ns        # -> tools/exp/libgq_<name>.so each
+  nofix   the product with the exact fix-up switched off (the baseline of the diagnostic builds below: wrong for ~5e-4 of the subvectors)
+  zb4     DVFS diagnostic: every prefilter MFMA's B operand is one of four zero vectors the compiler cannot see through (the tile's
+          bf16 split is kept alive): same instruction stream, the matrix pipe multiplies zeros
+  zblo    only the lo part of the tile (the ch x vl MFMA of each chain) is zero
+  m32     two MFMAs per chain (ch x vl dropped; vl still computed): the issue cost of 16 MFMAs per tile
+  m32ns   ... and the lo part of the tile not computed at all (what a two-term prefilter would issue)"""
+import os, re, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = open(os.path.join(ROOT, "gradient-quantization_amd", "csrc", "hsq_encode_pf.hip")).read()
+
+
+def rep(s, old, new, count=1):
+    assert s.count(old) >= 1, old
+    return s.replace(old, new, count)
+
+
+def nofix(s):
+    return rep(s, "uint64_t todo = __ballot(valid && !safe);", "uint64_t todo = 0; asm volatile(\"\" :: \"s\"(__ballot(valid && !safe)));")
+
+
+def keep_alive(s):
+    return rep(s, "        f32x16 acc = {0};\n",
+               "        asm volatile(\"\" :: \"v\"(vh[0]), \"v\"(vl[0]), \"v\"(vh[1]), \"v\"(vl[1]));\n        f32x16 acc = {0};\n")
+
+
+def zeros(s, which):
+    decl = "        bf16x8 zvh[2], zvl[2];\n"
+    for b in (0, 1):
+        for n in ("zvh", "zvl"):
+            decl += "        %s[%d] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; asm volatile(\"\" : \"+v\"(%s[%d]));\n" % (n, b, n, b)
+    s = rep(s, "        f32x16 acc = {0};\n", decl + "        f32x16 acc = {0};\n")
+    n = 0
+    for v in which:
+        s, k = re.subn(r"(__builtin_amdgcn_mfma_f32_32x32x16_bf16\(c[hl]\[\w+\], )%s\[(\w+)\]" % v, r"\1z%s[\2]" % v, s)
+        n += k
+    assert n == 3 * len(which) - (len(which) - 1) * 0 or n > 0
+    return s
+
+
+def m32(s):
+    s, k = re.subn(r"\n\s*n?acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16\(ch\[\w+\], vl\[\w+\], n?acc, 0, 0, 0\);", "", s)
+    assert k == 2, k
+    return s
+
+
+def nosplit_lo(s):
+    # the lo halves become copies of the hi halves' registers' worth of nothing: never computed
+    s = rep(s, "        for (int blk = 0; blk < 2; ++blk) split8(nxt[2 * blk], nxt[2 * blk + 1], nvh[blk], nvl[blk]);",
+            "        for (int blk = 0; blk < 2; ++blk) { split8hi(nxt[2 * blk], nxt[2 * blk + 1], nvh[blk]); nvl[blk] = nvh[blk]; }")
+    s = rep(s, "namespace gq {\n", "namespace gq {\n__device__ __forceinline__ void split8hi(const f32x4 &q0, const f32x4 &q1, bf16x8 &hi) {\n"
+            "    const u32x4 H = {cvt_pk_bf16(q0[0], q0[1]), cvt_pk_bf16(q0[2], q0[3]), cvt_pk_bf16(q1[0], q1[1]), cvt_pk_bf16(q1[2], q1[3])};\n"
+            "    hi = __builtin_bit_cast(bf16x8, H);\n}\n")
+    return s
+
+
+def hold(s):
+    """One operand held between consecutive MFMAs: even chains (cl,vh)(ch,vh)(ch,vl), odd chains (ch,vl)(ch,vh)(cl,vh)."""
+    s = rep(s, "        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[0], vl[0], acc, 0, 0, 0);\n        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[0], vh[0], acc, 0, 0, 0);\n",
+            "        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[0], vh[0], acc, 0, 0, 0);\n        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[0], vl[0], acc, 0, 0, 0);\n")
+    s = rep(s, "                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[nr], vh[nb], nacc, 0, 0, 0);\n",
+            "                if ((c + 1) & 1) nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vl[nb], nacc, 0, 0, 0);\n"
+            "                else nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[nr], vh[nb], nacc, 0, 0, 0);\n")
+    s = rep(s, "                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vl[nb], nacc, 0, 0, 0);\n                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vh[nb], nacc, 0, 0, 0);\n",
+            "                nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vh[nb], nacc, 0, 0, 0);\n"
+            "                if ((c + 1) & 1) nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[nr], vh[nb], nacc, 0, 0, 0);\n"
+            "                else nacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[nr], vl[nb], nacc, 0, 0, 0);\n")
+    return s
+
+
+def h32(s):
+    """m32ns with f16 operands (v_mfma_f32_32x32x16_f16, v_cvt_pk_f16_f32; no scaling: for N(0,1) test data only): the
+    clock and the time of a two-MFMA f16 prefilter, answers unchecked."""
+    s = nosplit_lo(m32(nofix(s)))
+    s = rep(s, "namespace gq {\n", "namespace gq {\ntypedef _Float16 half8_ __attribute__((ext_vector_type(8)));\n"
+            "__device__ __forceinline__ unsigned cvt_pk_f16_(float lo, float hi) { unsigned r; asm(\"v_cvt_pk_f16_f32 %0, %1, %2\" : \"=v\"(r) : \"v\"(lo), \"v\"(hi)); return r; }\n"
+            "__device__ __forceinline__ void split8h_(const f32x4 &q0, const f32x4 &q1, bf16x8 &hi, bf16x8 &lo) {\n"
+            "    half8_ h, l; float x[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};\n"
+            "    for (int i = 0; i < 8; ++i) { h[i] = (_Float16)x[i]; l[i] = (_Float16)(x[i] - (float)h[i]); }\n"
+            "    hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);\n}\n")
+    s = rep(s, "        split8(q0, q1, fh, fl);\n", "        split8h_(q0, q1, fh, fl);\n")
+    s = s.replace("const u32x4 H = {cvt_pk_bf16(q0[0], q0[1]), cvt_pk_bf16(q0[2], q0[3]), cvt_pk_bf16(q1[0], q1[1]), cvt_pk_bf16(q1[2], q1[3])};",
+                  "const u32x4 H = {cvt_pk_f16_(q0[0], q0[1]), cvt_pk_f16_(q0[2], q0[3]), cvt_pk_f16_(q1[0], q1[1]), cvt_pk_f16_(q1[2], q1[3])};")
+    # the first tile's split (prologue of the loop) also goes through the hi-only f16 form
+    s = rep(s, "        for (int blk = 0; blk < 2; ++blk) split8(cur[2 * blk], cur[2 * blk + 1], vh[blk], vl[blk]);",
+            "        for (int blk = 0; blk < 2; ++blk) { split8hi(cur[2 * blk], cur[2 * blk + 1], vh[blk]); vl[blk] = vh[blk]; }")
+    s, k = re.subn(r"__builtin_amdgcn_mfma_f32_32x32x16_bf16\((c[hl]\[\w+\]), (v[hl]\[\w+\]), ",
+                   r"__builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_, \1), __builtin_bit_cast(half8_, \2), ", s)
+    assert k == 4, k
+    return s
+
+
+def noqueue(s):
+    """Round 4's kernel with nothing ever flagged (no queueing, no exact scans): the floor of its tile loop."""
+    return rep(s, "        const bool flagged = valid && !safe;\n",
+               "        const bool flagged = false;\n        asm volatile(\"\" :: \"s\"(__ballot(valid && !safe)));\n")
+
+
+def zb2(s):
+    """DVFS diagnostic for round 4's kernel: nothing flagged, and the B operand of every prefilter MFMA one of two zero
+    vectors the compiler cannot see through (the tile's conversion kept alive)."""
+    s = noqueue(s)
+    s = rep(s, "        f32x16 acc = {0};\n",
+            "        half8 zvh[2];\n        zvh[0] = half8{0, 0, 0, 0, 0, 0, 0, 0}; asm volatile(\"\" : \"+v\"(zvh[0]));\n"
+            "        zvh[1] = half8{0, 0, 0, 0, 0, 0, 0, 0}; asm volatile(\"\" : \"+v\"(zvh[1]));\n"
+            "        asm volatile(\"\" :: \"v\"(vh[0]), \"v\"(vh[1]));\n        f32x16 acc = {0};\n")
+    s, k = re.subn(r"(__builtin_amdgcn_mfma_f32_32x32x16_f16\(c[hl]\[\w+\], )vh\[(\w+)\]", r"\1zvh[\2]", s)
+    assert k == 4, k
+    return s
+
+
+def fp8lo(s):
+    """Timing probe: the lo MFMA of every chain (cl x vh) as v_mfma_f32_32x32x16_fp8_fp8 on two registers of each operand
+    taken as they are (random bits), nothing flagged: what an 8-bit lo term would cost in time and clock.  Answers unchecked."""
+    s = noqueue(s)
+    s, k = re.subn(r"__builtin_amdgcn_mfma_f32_32x32x16_f16\(cl\[(\w+)\], vh\[(\w+)\], ",
+                   r"__builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(__builtin_bit_cast(long, __builtin_shufflevector(__builtin_bit_cast(u32x4, cl[\1]), __builtin_bit_cast(u32x4, cl[\1]), 0, 1)), "
+                   r"__builtin_bit_cast(long, __builtin_shufflevector(__builtin_bit_cast(u32x4, vh[\2]), __builtin_bit_cast(u32x4, vh[\2]), 0, 1)), ", s)
+    assert k == 2, k
+    return s
+
+
+def m1(s):
+    """Timing probe: ONE MFMA per chain (ch x vh), nothing flagged."""
+    s = noqueue(s)
+    s, k = re.subn(r"\n\s*n?acc = __builtin_amdgcn_mfma_f32_32x32x16_f16\(cl\[\w+\], vh\[\w+\], n?acc, 0, 0, 0\);", "", s)
+    assert k == 2, k
+    return s
+
+
+def fp8lo2(s):
+    """Timing probe closer to the real thing: the lo MFMA (cl x vh) as v_mfma_f32_32x32x16_fp8_fp8 on cl * 2^16 converted to
+    fp8 in the prologue and on the tile's f16 fragment converted by v_cvt_scalef32_pk_fp8_f16 (eight operations per tile and
+    lane); nothing flagged.  Scale semantics unpinned (scale 1.0), answers unchecked."""
+    s = noqueue(s)
+    s = rep(s, "    unsigned c2b = __float_as_uint(s_c1[0]);",
+            "    long cl8[8];\n    for (int rb = 0; rb < 8; ++rb) {\n        int w0 = 0, w1 = 0;\n"
+            "        w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)cl[rb][0] * 65536.0f, (float)cl[rb][1] * 65536.0f, w0, false);\n"
+            "        w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)cl[rb][2] * 65536.0f, (float)cl[rb][3] * 65536.0f, w0, true);\n"
+            "        w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)cl[rb][4] * 65536.0f, (float)cl[rb][5] * 65536.0f, w1, false);\n"
+            "        w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)cl[rb][6] * 65536.0f, (float)cl[rb][7] * 65536.0f, w1, true);\n"
+            "        cl8[rb] = (long)(((unsigned long long)(unsigned)w1 << 32) | (unsigned)w0);\n    }\n"
+            "    unsigned c2b = __float_as_uint(s_c1[0]);")
+    s = rep(s, "        f32x16 acc = {0};\n",
+            "        long vb8[2];\n        for (int blk = 0; blk < 2; ++blk) {\n            const u32x4 H = __builtin_bit_cast(u32x4, vh[blk]);\n            unsigned w0 = 0, w1 = 0;\n"
+            "            asm(\"v_cvt_scalef32_pk_fp8_f16 %0, %1, 1.0\" : \"+v\"(w0) : \"v\"(H[0]));\n"
+            "            asm(\"v_cvt_scalef32_pk_fp8_f16 %0, %1, 1.0 op_sel:[0,0,1]\" : \"+v\"(w0) : \"v\"(H[1]));\n"
+            "            asm(\"v_cvt_scalef32_pk_fp8_f16 %0, %1, 1.0\" : \"+v\"(w1) : \"v\"(H[2]));\n"
+            "            asm(\"v_cvt_scalef32_pk_fp8_f16 %0, %1, 1.0 op_sel:[0,0,1]\" : \"+v\"(w1) : \"v\"(H[3]));\n"
+            "            vb8[blk] = (long)(((unsigned long long)w1 << 32) | w0);\n        }\n        f32x16 acc = {0};\n")
+    s, k = re.subn(r"__builtin_amdgcn_mfma_f32_32x32x16_f16\(cl\[(\w+)\], vh\[(\w+)\], ", r"__builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(cl8[\1], vb8[\2], ", s)
+    assert k == 2, k
+    return s
+
+
+VARIANTS = {
+    "fp8lo2": fp8lo2,
+    "m1": m1,
+    "fp8lo": fp8lo,
+    "zb2": zb2,
+    "noqueue": noqueue,
+    "h32": h32,
+    "hold": hold,
+    "nofix": lambda s: nofix(s),
+    "zb4": lambda s: zeros(keep_alive(nofix(s)), ("vh", "vl")),
+    "zblo": lambda s: zeros(keep_alive(nofix(s)), ("vl",)),
+    "m32": lambda s: keep_alive(m32(nofix(s))),
+    "m32ns": lambda s: nosplit_lo(m32(nofix(s))),
+}
+
+if __name__ == "__main__":
+    os.makedirs("/tmp/gq_pfv", exist_ok=True)
+    for name in sys.argv[1:]:
+        src = "/tmp/gq_pfv/hsq_encode_pf_%s.hip" % name
+        open(src, "w").write(VARIANTS[name](SRC))
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), os.path.join(ROOT, "tools", "exp", "libgq_%s.so" % name), src],
+                              stderr=subprocess.DEVNULL)

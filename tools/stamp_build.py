@@ -27,21 +27,32 @@ for i, marker in enumerate(["        // ---- prefilter: 16 (block, row block) ch
                             "        // ---- per block: merge the two trackers",
                             "        // ---- exact rescoring of the better of the two",
                             "        // Consume the prefetched tile (convert it to the next B fragments)",
-                            "        // ---- exact fix-up, in place and wave-wide"]):
+                            "        // ---- the few subvectors the bound could not settle"]):
     rep(marker, stamp.replace("ID", str(i)) + marker)
-rep("        ti = tin;\n        t = tn;\n        tn = BATCHED ? tnn : draw();\n    }\n    if (BATCHED) {\n        flush_minmax();",
-    "        ti = tin;\n        t = tn;\n        tn = BATCHED ? tnn : draw();\n" + stamp.replace("ID", "5") + "        ++ntl;\n    }\n"
-    "    { const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();\n"
+rep("        tn = BATCHED ? tnn : draw();\n        sigma_t = sigma_n;\n    }\n    if (BATCHED) flush_minmax();",
+    "        tn = BATCHED ? tnn : draw();\n        sigma_t = sigma_n;\n" + stamp.replace("ID", "5") + "        ++ntl;\n    }\n"
+    "    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();\n    if (BATCHED) flush_minmax();")
+rep("    auto scan4 = [&](int first, int n) {\n", "    unsigned long long ndrained = 0;\n    auto scan4 = [&](int first, int n) {\n        ndrained += n;\n")
+rep("    if (BATCHED) return;\n",
+    "    { const unsigned long long rt2 = __builtin_amdgcn_s_memrealtime();\n"
     "      if (lane == 0 && blockIdx.x < 256) {\n"
-    "          unsigned long long *o = reinterpret_cast<unsigned long long *>(ws_worklist(ws) + (M - 65536)) + (blockIdx.x * 8 + wave) * 10;\n"
+    "          unsigned long long *o = reinterpret_cast<unsigned long long *>(ws_worklist(ws) + (M - 65536)) + (blockIdx.x * 8 + wave) * 12;\n"
     "          for (int i = 0; i < 6; ++i) o[i] = stamp_acc[i];\n"
-    "          o[6] = rt_entry; o[7] = rt0; o[8] = rt1; o[9] = ntl; } }\n    if (BATCHED) {\n        flush_minmax();")
+    "          o[6] = rt_entry; o[7] = rt0; o[8] = rt1; o[9] = ntl; o[10] = rt2; o[11] = ndrained; } }\n    if (BATCHED) return;\n")
 # diagnostics marks off: the fix-up log shares the workspace region the stamps are written to
-rep("if (!BATCHED && lane == 0) worklist[", "if (false) worklist[")
+s = s.replace("if (!BATCHED && lane == 0) worklist[", "if (false) worklist[").replace("                    worklist[m[2]] = (int)m[2];", "                    ;")
+OUT_NAME = "libgq_stamp.so"
+if os.environ.get("GQ_STAMP_VARIANT"):
+    # the stamps on one of tools/pf_variants.py's diagnostic builds (GQ_STAMP_VARIANT=zb4: the DVFS diagnostic of
+    # MI355X_MICROARCH.md 'DVFS give-back' item 6 -- cycles per tile stay, the clock the chip then holds is what the stamps read)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pf_variants
+    s = pf_variants.VARIANTS[os.environ["GQ_STAMP_VARIANT"]](s)
+    OUT_NAME = "libgq_stamp_%s.so" % os.environ["GQ_STAMP_VARIANT"]
 open(p, "w").write(s)
 out = os.path.join(ROOT, "tools", "exp")
 os.makedirs(out, exist_ok=True)
 cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-honor-nans", "-fPIC", "-shared", "-std=c++17",
-       "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"), "-I" + TMP, "-o", os.path.join(out, "libgq_stamp.so")] + sorted(glob.glob(TMP + "/*.hip"))
+       "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"), "-I" + TMP, "-o", os.path.join(out, OUT_NAME)] + sorted(glob.glob(TMP + "/*.hip"))
 subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
-print(os.path.join(out, "libgq_stamp.so"))
+print(os.path.join(out, OUT_NAME))

@@ -17,10 +17,10 @@ for _ in range(3):
     native.hsq_encode(g, cb, codes, u, ws, impl=4)
 torch.cuda.synchronize()
 wl = ws[2 * native.GQ_MAX_PARTIALS + 4:2 * native.GQ_MAX_PARTIALS + 4 + M]
-raw = wl[M - 65536:M - 65536 + 256 * 8 * 10 * 2].contiguous().view(torch.int64).view(-1, 10).cpu().numpy().astype(np.float64)
-seg, entry, rt0, rt1 = raw[:, :6], raw[:, 6], raw[:, 7], raw[:, 8]
+raw = wl[M - 65536:M - 65536 + 256 * 8 * 12 * 2].contiguous().view(torch.int64).view(-1, 12).cpu().numpy().astype(np.float64)
+seg, entry, rt0, rt1, rt2, drained = raw[:, :6], raw[:, 6], raw[:, 7], raw[:, 8], raw[:, 10], raw[:, 11]
 names = ["prefetch issue / loop top", "16 chains (MFMA + keys)", "tracker merge + swaps", "exact rescoring (LDS gather)",
-         "next-tile bf16 split", "exact fix-up (rare) + stores"]
+         "next-tile f16 conversion", "queueing of unsettled subvectors + stores"]
 tiles_w = raw[:, 9]                                   # tiles each wave actually processed (dynamic scheduling)
 first = (np.arange(len(raw)) % 8) < 4          # waves 0-3 of a workgroup (one per SIMD) vs waves 4-7
 tiles = tiles_w.mean()
@@ -31,6 +31,8 @@ for n, v in zip(names, seg.mean(0)):
     print("  %-30s %6.0f cycles/tile  %5.1f %%" % (n, v / tiles, 100 * v / cyc))
 print("prologue per wave %.1f us (min %.1f, max %.1f); first entry -> last loop end %.1f us; loop-end skew %.1f us"
       % ((rt0 - entry).mean() / 100, (rt0 - entry).min() / 100, (rt0 - entry).max() / 100, (rt1.max() - entry.min()) / 100, (rt1.max() - rt1.min()) / 100))
+print("exact scans: %.1f queued subvectors per wave on average (max %d; %d per launch of the first 256 workgroups); loop end -> end of the last scans %.2f us on average (max %.2f); the last wave ends %.1f us after the first entry"
+      % (drained.mean(), drained.max(), drained.sum(), ((rt2 - rt1) / 100).mean(), ((rt2 - rt1) / 100).max(), (rt2.max() - entry.min()) / 100))
 end = (rt1 - entry.min()) / 100
 blk = np.arange(len(end)) // 8
 for lo, hi in [(0, 64), (64, 128), (128, 192), (192, 256)]:
@@ -47,3 +49,11 @@ for x in range(8):
 cu = blk
 slow = np.argsort([end[cu == c].max() for c in range(256)])[-8:]
 print("slowest CUs-slots (workgroup index % 256):", slow, [round(float(end[cu == c].max()), 1) for c in slow])
+
+# where the launch's tail comes from: the end of every workgroup (its last wave, scans included) and of every wave inside it
+wend = ((rt2 - entry.min()) / 100).reshape(-1, 8)
+wg_end, wg_mean = wend.max(1), wend.mean(1)
+print("workgroup ends (last wave, scans included): mean %.1f us, percentiles 10/50/90/99/100: %s" % (wg_end.mean(), np.round(np.percentile(wg_end, [10, 50, 90, 99, 100]), 1)))
+print("inside a workgroup: last wave - mean wave = %.2f us on average (max %.2f); first wave to stop - last = %.2f us on average"
+      % ((wg_end - wg_mean).mean(), (wg_end - wg_mean).max(), (wg_end - wend.min(1)).mean()))
+print("across workgroups: latest workgroup end - mean workgroup end = %.2f us; mean workgroup end - mean wave end = %.2f us" % (wg_end.max() - wg_end.mean(), wg_end.mean() - wend.mean()))
