@@ -1,28 +1,30 @@
-// HSQ encode, d = 16, K = 256: f16 matrix-core prefilter (two MFMAs per chain) + exact f32 rescoring + deferred
-// exact fix-ups.  Same bits as the exact f32 kernel (hsq_encode.hip) in about a quarter of its time.
+// HSQ encode, d = 16, K = 256: f16 matrix-core prefilter (ONE MFMA per chain) + exact f32 rescoring + deferred
+// exact scans.  Same bits as the exact f32 kernel (hsq_encode.hip) in about a quarter of its time.
 //
 // The exact f32 MFMA is bound by the f32 matrix rate and shares its datapath with the VALU (tools/enc_probe.hip: their
 // times ADD), so the 256-way argmax cannot hide behind it.  This kernel scores approximately on the f16 matrix pipe
 // (which overlaps with the VALU), settles nearly every subvector from those scores plus FOUR exact scores, and hands
 // the rest to an exact scan:
 //
-//  1. APPROXIMATE scores, two v_mfma_f32_32x32x16_f16 per chain of 32 codewords x 32 subvectors:
-//       c = ch + cl + r_c  (f16 hi / lo split, |r_c| <= 2^-22 |c| + 2^-25),   v' = v * sigma,  vh = f16(v')
-//       s~_k = ch.vh + cl.vh          (products exact in f32, f32 accumulate)
-//     sigma is a power of two, ONE per wave and tile (an SGPR, so the conversion is one v_fma_mix per element): it
+//  1. APPROXIMATE scores, one v_mfma_f32_32x32x16_f16 per chain of 32 codewords x 32 subvectors:
+//       ch = f16(c),   v' = v * sigma,   vh = f16(v'),   s~_k = ch_k . vh      (products exact in f32, f32 accumulate)
+//     sigma is a power of two, ONE per wave and tile (a scalar, so the conversion is one v_fma_mix per element): it
 //     keeps the tile's values in the middle of the f16 range and follows the data from tile to tile (below).
-//     Round 3 ran three bf16 MFMAs per chain (ch.vh + ch.vl + cl.vh, error 2^-15); measured in round 4
-//     (profiles/r04_encode_dvfs.txt): with the B operands zeroed the same instruction stream ran 18 % faster at
-//     2.06 GHz instead of 1.83 -- the chip lowers its clock under the matrix pipe's load -- and two MFMAs per chain
-//     without the lo split of the tile ran 15 % faster.  Two MFMAs cannot carry 2^-15: the tile is rounded ONCE, to
-//     11 bits, and the error bound below is 16 x larger; what makes that affordable is (3).
-//     Error against the reference's p_k (fmaf chain), in scaled units, for unit-free rows:
-//       |s~_k - sigma p_k| <= sum_j |c_kj| |v'_j - vh_j| + (r_c, accumulation: < 1 % of the first term)
-//                          <= 2^-11 ||c_k||_2 ||v'||_2 + 2^-25 ||c_k||_1          (Cauchy-Schwarz; subnormal grid)
-//     and sharper, with e_j the exponent of vh_j (|v'_j - vh_j| <= half an ulp = 2^-11 2^e_j; subnormal vh_j: 2^-25):
-//       E' := sqrt(n2) * (1.03 * 2^-11 * c2 + 2^-22) + 2^-21 * c2,   n2 = sum_j 4^e_j <= ||vh||_2^2 < 4 n2,
-//       c2 = max_k ||c_k||_2  (measured in the prologue),
-//     valid while 2^-12 <= n2 <= 2^24 (no f16 overflow; the subnormal term stays small): outside that window
+//     Why one MFMA: round 3 ran three bf16 MFMAs per chain (ch.vh + ch.vl + cl.vh, error 2^-15).  Measured in round 4
+//     (profiles/r04_encode_dvfs.txt): what an MFMA costs this kernel is not its issue slot or its 32 cycles of matrix
+//     pipe but the CLOCK -- with the B operands zeroed the same instruction stream ran 18 % faster (2.06 GHz against
+//     1.83); dropping MFMAs gave 3 -> 2 per chain -13 %, 2 -> 1 another -16 % (an 8-bit lo term: -6 %).  One f16 MFMA
+//     rounds both operands ONCE to 11 bits; the error bound is ~30 x round 3's, ~1 % of N(0,1) subvectors are not
+//     settled by it, and what makes that affordable is the batched exact scan of (4).
+//     Error against the reference's p_k (fmaf chain), in scaled units:
+//       s'_k - s~_k = (c_k - ch_k) . v'  +  ch_k . (v' - vh)
+//       |ch_k . (v' - vh)| <= ||ch_k||_2 * 2^-11 sqrt(n2),  n2 = sum_j 4^e_j, e_j the exponent of vh_j: the rounding error
+//                             of element j is at most half an ulp = 2^-11 2^e_j (subnormal vh_j: 2^-25, in err_abs)
+//       |(c_k - ch_k) . v'| <= dc ||v'||_2,   dc = max_k ||c_k - ch_k||_2 -- the codebook's rounding residuals as they are,
+//                             measured in the prologue (~0.6 x 2^-11 for unit rows) --,  ||v'||_2 < 2.02 sqrt(n2)
+//       E' := sqrt(n2) * (1.03 * 2^-11 * c2 + 2.02 dc) + 2^-21 * c2,    c2 = max_k ||c_k||_2 (measured too);
+//     the 1.03 covers the accumulation roundings of the MFMA and of the reference's chain (< 1 % of the first term).
+//     Valid while 2^-12 <= n2 <= 2^24 (no f16 overflow; the subnormal terms stay small): outside that window
 //     -- a subvector far off the wave's scale -- the subvector goes to the exact scan.  n2 costs four v_and_b32 and
 //     four v_dot2_f32_f16 per fragment.
 //  2. The 16 scores a lane gets per chain are 4 GROUPS of 4 consecutive codewords (accumulator registers 4q..4q+3).
@@ -35,12 +37,16 @@
 //     is the answer IF every other candidate is provably smaller:  upper(second-best key) + E' < |p| sigma.
 //     Every codeword that was not rescored lies in a group whose key is <= that bound, so it cannot reach |p| even
 //     after the approximation error: code and u are exactly the reference's first-max argmax and projection.
-//  4. Otherwise (~0.6 % of N(0,1) subvectors; anything outside the window; non-finite inputs) the subvector is QUEUED:
-//     its 16 floats and its destination go to the wave's ring in LDS.  Whenever four are waiting (and once more when the
-//     wave has run out of tiles) the wave scans them exactly, a quarter wave per subvector, each lane 16 codewords
-//     (scan4 in the kernel).  Round 3 stopped the whole wave for ONE such subvector at a time (1,500 scans cost 1.5 us of
-//     a 42 us launch); batched, six times as many cost about as much.  Correctness never depends on E' being tight --
-//     only on it being an upper bound.
+//  4. Otherwise (~1.5 % of N(0,1) subvectors -- about one per tile --; anything outside the window) the subvector is
+//     QUEUED: its 16 floats and its destination go to the wave's ring in LDS (written and read by this wave only).  When
+//     the wave has run out of tiles (or 32 are waiting) the ring goes through a SECOND PASS of the same prefilter with
+//     everything the first one left out -- the codebook's lo part, the entry's lo part, a scale of the entry's own --, i.e.
+//     three MFMAs per chain on a half tile whose columns are the queued subvectors; its bound is ~150 x tighter.  What
+//     is still open after that (~1 % of the queued; non-finite values) is scanned exactly, a quarter wave per subvector,
+//     each lane 16 codewords (scan4).  Round 3 stopped the whole wave for ONE unsettled subvector at a time (1,500 scans
+//     cost 1.5 us of a 42 us launch); here 24,000 second-pass entries and 200 scans cost ~4 us of a launch that is
+//     16 % shorter (profiles/r04_encode_ab.txt).  Correctness never depends on a bound being tight -- only on it being
+//     an upper bound.
 //  5. Per-workgroup (min, max) of u go to the workspace; the level kernel folds them into (lb, ub).
 #include <hip/hip_ext.h>
 
@@ -61,6 +67,8 @@ constexpr int PF_QCAP = 64;                 // deferred exact scans a wave can h
 // Error bound of the f16 prefilter (header, 1): E' = ||vh||_2 * ERR_REL * c2 + ERR_ABS * c2 inside the window of ||vh||_2^2
 constexpr float ERR_REL = 1.03f * 4.8828125e-04f;     // 1.03 * 2^-11
 constexpr float ERR_ABS = 4.76837158203125e-07f;      // 2^-21
+// second pass (ch.vh + ch.vl + cl.vh): cl.vl, the splits' remainders (2^-22 each) and 48 accumulated products (< 2^-17.4 c2 sqrt(n2))
+constexpr float ERR2_REL = 1.2f * 7.62939453125e-06f;  // 1.2 * 2^-17
 constexpr unsigned N2_LO_BITS = 0x39800000u;          // 2^-12
 constexpr unsigned N2_HI_BITS = 0x4B800000u;          // 2^24  (||vh||_2^2 < 4 n2 <= 2^26: every |vh_j| < 2^13)
 constexpr int SIGMA_TARGET_EXP2 = 10;                 // the largest sampled n2 of a tile is steered to ~2^10 (norm 2^5 .. 2^6)
@@ -122,8 +130,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // and the tile -> segment word is fetched one tile ahead.
     __shared__ int64_t s_seg[(BATCHED && SEGLDS) ? PF_LDS_SEGS * 8 : 1];
     // f16 hi / lo A fragments of the 8 row blocks as the waves of the workgroup produce them (one row block each)
-    __shared__ __attribute__((aligned(16))) u32x4 s_frag[8 * 2 * 64];
-    __shared__ float s_c1[PF_WAVES];
+    __shared__ __attribute__((aligned(16))) u32x4 s_frag[8 * 64], s_fragl[8 * 64];   // hi parts (to registers) / lo parts (read by the second pass)
+    __shared__ float s_c1[PF_WAVES], s_dc[PF_WAVES];
     // deferred exact scans (header, 4): every wave's own ring of PF_QCAP entries = the subvector's 16 floats +
     // {code address lo, hi, index into u, segment}.  Written and read by the same wave only: no flags, no atomics.
     __shared__ __attribute__((aligned(16))) float s_qv[PF_WAVES * PF_QCAP * 16];
@@ -342,38 +350,52 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         for (int i = threadIdx.x; i < n; i += PF_THREADS) s_seg[i] = a.seg_table[i];
     }
     {
+        // This wave's row block of the codebook as an f16 A fragment (ONE rounding per entry, no lo part), and what the
+        // error bound needs of the codebook, measured instead of trusting the caller's normalisation: the largest
+        // ||c_k||_2 and the largest ||c_k - f16(c_k)||_2 (the rounding residuals as they are: x - f16(x) is exact in f32).
+        // Row wave*32 + j: this lane's 8 elements + its partner's.  A row that is not finite or beyond the f16 range makes
+        // a maximum NaN or >= 2^30 -- tested on the bits below.
         half8 fh, fl;
-        split8_f16(q0, q1, fh, fl);
-        s_frag[(wave * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, fh);
-        s_frag[(wave * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, fl);
-        // The error bound scales with max_k ||c_k||_2 (1 for the reference's normalised codebooks); measure it instead
-        // of trusting the caller.  Row wave*32 + j: this lane's 8 elements + its partner's.  A row that is not finite
-        // (or beyond the f16 range) makes the maximum at least 2^30 or NaN -- tested on the bits below.
-        float l2 = 0.0f;
+        float l2 = 0.0f, d2 = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) l2 = __fmaf_rn(q0[e], q0[e], __fmaf_rn(q1[e], q1[e], l2));
+        for (int e = 0; e < 8; ++e) {
+            const float x = e < 4 ? q0[e] : q1[e - 4];
+            fh[e] = (_Float16)x;
+            const float rr = x - (float)fh[e];
+            fl[e] = (_Float16)rr;   // c = hi + lo + r, |r| <= 2^-22 |c| + 2^-25 (the second term: f16's subnormal grid)
+            l2 = __fmaf_rn(x, x, l2);
+            d2 = __fmaf_rn(rr, rr, d2);
+        }
+        s_frag[wave * 64 + lane] = __builtin_bit_cast(u32x4, fh);
+        s_fragl[wave * 64 + lane] = __builtin_bit_cast(u32x4, fl);
         l2 += __shfl_xor(l2, 32, 64);
+        d2 += __shfl_xor(d2, 32, 64);
         l2 = wave_max_nan(l2);
-        if (lane == 0) s_c1[wave] = l2;
+        d2 = wave_max_nan(d2);
+        if (lane == 0) {
+            s_c1[wave] = l2;
+            s_dc[wave] = d2;
+        }
     }
     __syncthreads();
-    // A fragments of v_mfma_f32_32x32x16_f16: lane (row j, half h) holds c[rb*32+j][8h .. 8h+7];
-    // hi and lo f16 parts, 64 VGPRs, resident for the kernel's lifetime.  (Keeping them in LDS
-    // instead and running 3 waves/SIMD measured slower: the kernel is bound by VALU issue, not
-    // by latency.)
-    half8 ch[8], cl[8];
+    // A fragments of v_mfma_f32_32x32x16_f16: lane (row j, half h) holds f16(c[rb*32+j][8h .. 8h+7]); 32 VGPRs, resident
+    // for the kernel's lifetime.
+    half8 ch[8];
 #pragma unroll
-    for (int rb = 0; rb < 8; ++rb) {
-        ch[rb] = __builtin_bit_cast(half8, s_frag[(rb * 2 + 0) * 64 + lane]);
-        cl[rb] = __builtin_bit_cast(half8, s_frag[(rb * 2 + 1) * 64 + lane]);
+    for (int rb = 0; rb < 8; ++rb) ch[rb] = __builtin_bit_cast(half8, s_frag[rb * 64 + lane]);
+    unsigned c2b = __float_as_uint(s_c1[0]), dcb = __float_as_uint(s_dc[0]);   // squares: non-negative, so the bits order them, a NaN above everything
+#pragma unroll
+    for (int w = 1; w < PF_WAVES; ++w) {
+        c2b = max(c2b, __float_as_uint(s_c1[w]));
+        dcb = max(dcb, __float_as_uint(s_dc[w]));
     }
-    unsigned c2b = __float_as_uint(s_c1[0]);   // squares: non-negative, so the bits order them, a NaN above everything
-#pragma unroll
-    for (int w = 1; w < PF_WAVES; ++w) c2b = max(c2b, __float_as_uint(s_c1[w]));
-    // E' = ||vh||_2 * err_rel + err_abs (header, 1); a codebook outside the f16 range: +infinity, nothing is ever "safe"
-    const float c2 = __builtin_sqrtf(__uint_as_float(c2b)) * 1.0000002f;
-    const float err_rel = c2b < 0x4E800000u ? c2 * ERR_REL + 2.4e-7f : INFINITY;   // (+ 2^-22: the lo parts of small codebook entries sit on f16's subnormal grid)
-    const float err_abs = c2b < 0x4E800000u ? c2 * ERR_ABS : INFINITY;
+    // E' = sqrt(n2) * err_rel + err_abs (header, 1): the tile's rounding seen through the largest row, plus the codebook's
+    // rounding seen through ||vh||_2 < 2 sqrt(n2).  A codebook outside the f16 range: +infinity, nothing is ever "safe".
+    const float c2 = __builtin_sqrtf(__uint_as_float(c2b)) * 1.0000002f, dc = __builtin_sqrtf(__uint_as_float(dcb)) * 1.0000002f;
+    const bool cb_ok = c2b < 0x4E800000u && dcb < 0x4E800000u;
+    const float err_rel = cb_ok ? c2 * ERR_REL + 2.02f * dc : INFINITY;   // (2.02: ||vh||_2 < 2 sqrt(n2) + 2^-12, n2 >= 2^-12)
+    const float err_abs = cb_ok ? c2 * ERR_ABS : INFINITY;
+    const float err2_rel = cb_ok ? c2 * ERR2_REL + 2.4e-7f : INFINITY;   // the second pass (three MFMAs per chain)
 
     int64_t tn = draw();                // the tile after this wave's first one
     int seg_n = seg_of(tn);             // in flight while the first tile is set up
@@ -493,6 +515,137 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             }
         }
     };
+    // SECOND PASS over up to 32 ring entries from `first` on (header, 4): the same prefilter with everything it left out --
+    // the codebook's lo part (cl from LDS), the entry's lo part (vl = f16(v' - vh), one v_fma_mix with an f16 addend) and a
+    // scale of the ENTRY's own (its largest |element| goes to [2^4, 2^5): entries that fell out of the wave's window are at
+    // home here) -- three MFMAs per chain, error ~2^-17 instead of ~2^-10.  Entry i is column i of the one block; lanes
+    // (i, 0) and (i, 1) hold the two halves of its rows and, after the exchange, both score the same group (only (i, 0)
+    // stores).  What even this bound does not settle (~1 in 150 entries; non-finite values) is scanned exactly (scan4).
+    auto second_pass = [&](int first, int n) {
+        const int col = j < n ? j : 0;   // (idle columns repeat entry 0 and store nothing)
+        const int slot = wave * PF_QCAP + ((first + col) & (PF_QCAP - 1));
+        const f32x4 *qv = reinterpret_cast<const f32x4 *>(s_qv + 16 * slot);
+        const f32x4 x0 = qv[2 * h], x1 = qv[2 * h + 1];
+        auto both_halves = [&](float own, bool add) {   // own (+ or max) the partner lane's value: two copies through v_permlane32_swap
+            float a = own, b = own;
+            swap32(a, b);            // a = the lower lanes' values in both halves, b = the upper lanes'
+            return add ? a + b : fmaxf(a, b);
+        };
+        float m = fmaxf(fmaxf(fmaxf(fabsf(x0[0]), fabsf(x0[1])), fmaxf(fabsf(x0[2]), fabsf(x0[3]))),
+                        fmaxf(fmaxf(fabsf(x1[0]), fabsf(x1[1])), fmaxf(fabsf(x1[2]), fabsf(x1[3]))));
+        m = both_halves(m, false);
+        const unsigned em = __float_as_uint(m) >> 23;
+        int f = 258 - (int)em;
+        f = f < 27 ? 27 : (f > 227 ? 227 : f);
+        const float sig = (em >= 1u && em <= 254u) ? __uint_as_float((unsigned)f << 23) : 1.0f;   // per lane: the entry's scale
+        // vh = f16(x sig), vl = f16(x sig - vh): the second conversion's fma is exact in f32 (a rounding residual)
+        u32x4 H, L;
+        float n2q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = i < 2 ? x0[2 * i] : x1[2 * i - 4], b = i < 2 ? x0[2 * i + 1] : x1[2 * i - 3];
+            unsigned r, l;
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(sig));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(r) : "v"(b), "v"(sig));
+            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(sig), "v"(r));
+            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(sig), "v"(r));
+            const unsigned e = r & 0x7C007C00u;
+            asm("v_dot2_f32_f16 %0, %1, %1, %0" : "+v"(n2q) : "v"(e));
+            H[i] = r;
+            L[i] = l;
+        }
+        const half8 bh = __builtin_bit_cast(half8, H), bl = __builtin_bit_cast(half8, L);
+        const float n2 = both_halves(n2q, true);
+        // ---- 8 chains: the two trackers of the one block
+        unsigned best2[2] = {0, 0}, second2[2] = {0, 0};
+        unsigned vmask = KEY_MASK;
+        asm volatile("" : "+v"(vmask));
+        // (as in the tile loop: the MFMAs of chain rb + 1 are issued in front of the key operations of chain rb; the lo
+        // fragments come from LDS one chain ahead)
+        half8 al = __builtin_bit_cast(half8, s_fragl[lane]);
+        f32x16 acc = {0};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[0], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[0], bh, acc, 0, 0, 0);
+        al = __builtin_bit_cast(half8, s_fragl[64 + lane]);
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) {
+            f32x16 nacc = {0};
+            if (rb + 1 < 8) {
+                __builtin_amdgcn_sched_barrier(0);
+                nacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, nacc, 0, 0, 0);
+                nacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[rb + 1], bl, nacc, 0, 0, 0);
+                nacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[rb + 1], bh, nacc, 0, 0, 0);
+                if (rb + 2 < 8) al = __builtin_bit_cast(half8, s_fragl[(rb + 2) * 64 + lane]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            unsigned k[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                k[q] = and_or(__float_as_uint(absmax4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3])), vmask,
+                              (unsigned)((rb & 3) * 4 + q));
+            const int trk = rb >> 2;
+            const unsigned t0 = max3u(best2[trk], k[0], k[1]), a0 = med3u(best2[trk], k[0], k[1]);
+            const unsigned b0 = med3u(t0, k[2], k[3]);
+            best2[trk] = max3u(t0, k[2], k[3]);
+            second2[trk] = max3u(second2[trk], a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = nacc;
+        }
+        const bool useB = (best2[1] & KEY_MASK) > (best2[0] & KEY_MASK);
+        const unsigned bw = useB ? best2[1] : best2[0], blo = useB ? best2[0] : best2[1];
+        const int gid = (int)(bw & 31u);
+        const int kmine = ((gid >> 2) + (useB ? 4 : 0)) * 32 + 8 * (gid & 3) + 4 * h;
+        const unsigned smine = max3u(second2[0], second2[1], blo) | 31u;
+        // both lanes of a column get both halves' (best key, its group, bound on the rest)
+        int k0 = kmine, k1_ = kmine;
+        swap32(k0, k1_);
+        int s0 = (int)smine, s1 = (int)smine;
+        swap32(s0, s1);
+        int w0 = (int)bw, w1 = (int)bw;
+        swap32(w0, w1);
+        const bool pick1 = ((unsigned)w1 & KEY_MASK) > ((unsigned)w0 & KEY_MASK);
+        const int kc = pick1 ? k1_ : k0;
+        const unsigned rest = max3u((unsigned)s0, (unsigned)s1, (unsigned)(pick1 ? w0 : w1) | 31u);
+        float vf[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 x = qv[q];
+            vf[4 * q] = x[0];
+            vf[4 * q + 1] = x[1];
+            vf[4 * q + 2] = x[2];
+            vf[4 * q + 3] = x[3];
+        }
+        const f32x4 p4 = exact_score_quad<16>(s_cb + (kc >> 2) * QUAD_STRIDE, vf);
+        float val = p4[0];
+        int idx = kc;
+        take_if_greater(val, idx, p4[1], kc + 1);
+        take_if_greater(val, idx, p4[2], kc + 2);
+        take_if_greater(val, idx, p4[3], kc + 3);
+        const unsigned n2b = __float_as_uint(n2);
+        const float E = __builtin_amdgcn_sqrtf(n2) * err2_rel + err_abs;
+        bool safe = ((n2b - N2_LO_BITS) <= (N2_HI_BITS - N2_LO_BITS)) && (__uint_as_float(rest) + E < fabsf(val * sig));
+        if (nan_bits(val)) safe = false;
+        const bool owner = h == 0 && j < n;
+        if (owner && safe) {
+            const u32x4 mt = *reinterpret_cast<const u32x4 *>(s_qm + 4 * slot);
+            *(gcode_ptr)(uintptr_t)((uint64_t)mt[0] | ((uint64_t)mt[1] << 32)) = (CodeT)idx;
+            ((gf_ptr)u)[mt[2]] = val;
+            if (BATCHED) {
+                fold_seg((int)mt[3], val);
+            } else {
+                worklist[mt[2]] = (int)mt[2];   // diagnostics only: which subvectors took the second pass
+                lmin = fminf(lmin, val);
+                lmax = fmaxf(lmax, val);
+            }
+        }
+        uint64_t left = __ballot(owner && !safe);
+        while (left) {   // (rare) one exact scan per entry that is still open
+            const int i = __builtin_ctzll(left);
+            left &= left - 1;
+            scan4((first + i) & (PF_QCAP - 1), 1);
+        }
+    };
     while (t < tile_end) {
         // single tensor: tn was drawn at the end of the previous tile; batched: a whole tile ago
         const int64_t tnn = BATCHED ? draw() : 0;
@@ -508,8 +661,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             cur_seg = ti.seg;
         }
         // ---- prefilter: 16 (block, row block) chains; top-2 GROUP keys per (block, row-block half) ----
-        // The two MFMAs of chain c+1 depend on each other and issue is in order, so they are
-        // placed one by one BETWEEN the key operations of chain c (sched_barrier pins the order):
+        // The MFMA of chain c+1 is issued in front of the key operations of chain c (sched_barrier pins the order):
         // the matrix pipe runs under the VALU stream.
         unsigned best[4] = {0, 0, 0, 0}, second[4] = {0, 0, 0, 0};
         unsigned vmask = KEY_MASK;
@@ -534,7 +686,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             second[trk] = max3u(second[trk], trk_a, b);
         };
         f32x16 acc = {0};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[0], vh[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[0], vh[0], acc, 0, 0, 0);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -543,12 +694,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
                 const int nb = (c + 1) >> 3, nr = (c + 1) & 7;
                 f32x16 nacc = {0};
                 __builtin_amdgcn_sched_barrier(0);
-                nacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[nr], vh[nb], nacc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                track_lo(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
-                __builtin_amdgcn_sched_barrier(0);
                 nacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[nr], vh[nb], nacc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                track_lo(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
                 track_hi(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
                 __builtin_amdgcn_sched_barrier(0);
                 acc = nacc;
@@ -698,11 +846,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             const uint64_t took = __ballot(mine);
             qcnt += (int)__builtin_popcountll(took);
             todo &= ~took;
-            if (qcnt >= 4) {
-                const int nb = qcnt >> 2;
-                scan4(qhead, 4 * nb);
-                qhead = (qhead + 4 * nb) & (PF_QCAP - 1);
-                qcnt -= 4 * nb;
+            if (qcnt >= 32) {   // (a wave meets ~1 unsettled subvector per tile: this is the exception; the ring is emptied after the loop)
+                second_pass(qhead, 32);
+                qhead = (qhead + 32) & (PF_QCAP - 1);
+                qcnt -= 32;
             }
         }
 
@@ -719,7 +866,12 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     }
     if (BATCHED) flush_minmax();
 
-    if (qcnt) scan4(qhead, qcnt);   // out of tiles: what is left in the ring (one to three entries)
+    while (qcnt) {   // out of tiles: the ring's entries through the second pass (one trip: a wave collects ~12 per launch)
+        const int n = qcnt < 32 ? qcnt : 32;
+        second_pass(qhead, n);
+        qhead = (qhead + n) & (PF_QCAP - 1);
+        qcnt -= n;
+    }
     if (BATCHED) return;
     write_minmax_partials<PF_WAVES>(lmin, lmax, ws, sawnan);   // per-workgroup (min,max); the level kernel folds them
 }

@@ -512,7 +512,9 @@ def test_prefilter_equals_exact_mfma_at_full_size_and_fixup_rate(nat, d):
         assert torch.equal(res[exact][2].view(torch.int32), res[4][2].view(torch.int32))
         assert torch.equal(res[exact][3], res[4][3])
         n_fix = nat.fixup_count(res[4][4], M)
-        assert 0 < n_fix < M * 0.01, n_fix
+        # d = 16: one f16 MFMA per chain settles ~98.5 % of N(0,1) subvectors, the rest take the second pass (three MFMAs)
+        # or an exact scan; d = 8 / 32 (bf16x3): ~0.1 %
+        assert 0 < n_fix < M * (0.03 if d == 16 else 0.01), n_fix
         print("scale %g: fix-up worklist %d of %d subvectors (%.4f%%)" % (scale, n_fix, M, 100.0 * n_fix / M))
 
 

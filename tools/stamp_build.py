@@ -32,7 +32,8 @@ for i, marker in enumerate(["        // ---- prefilter: 16 (block, row block) ch
 rep("        tn = BATCHED ? tnn : draw();\n        sigma_t = sigma_n;\n    }\n    if (BATCHED) flush_minmax();",
     "        tn = BATCHED ? tnn : draw();\n        sigma_t = sigma_n;\n" + stamp.replace("ID", "5") + "        ++ntl;\n    }\n"
     "    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();\n    if (BATCHED) flush_minmax();")
-rep("    auto scan4 = [&](int first, int n) {\n", "    unsigned long long ndrained = 0;\n    auto scan4 = [&](int first, int n) {\n        ndrained += n;\n")
+rep("    auto scan4 = [&](int first, int n) {\n", "    unsigned long long ndrained = 0;\n    auto scan4 = [&](int first, int n) {\n        ndrained += 1000 * n;\n")
+rep("    auto second_pass = [&](int first, int n) {\n", "    auto second_pass = [&](int first, int n) {\n        ndrained += n;\n")
 rep("    if (BATCHED) return;\n",
     "    { const unsigned long long rt2 = __builtin_amdgcn_s_memrealtime();\n"
     "      if (lane == 0 && blockIdx.x < 256) {\n"
@@ -40,7 +41,7 @@ rep("    if (BATCHED) return;\n",
     "          for (int i = 0; i < 6; ++i) o[i] = stamp_acc[i];\n"
     "          o[6] = rt_entry; o[7] = rt0; o[8] = rt1; o[9] = ntl; o[10] = rt2; o[11] = ndrained; } }\n    if (BATCHED) return;\n")
 # diagnostics marks off: the fix-up log shares the workspace region the stamps are written to
-s = s.replace("if (!BATCHED && lane == 0) worklist[", "if (false) worklist[").replace("                    worklist[m[2]] = (int)m[2];", "                    ;")
+s = s.replace("if (!BATCHED && lane == 0) worklist[", "if (false) worklist[").replace("                    worklist[m[2]] = (int)m[2];", "                    ;").replace("                worklist[mt[2]] = (int)mt[2];", "                ;")
 OUT_NAME = "libgq_stamp.so"
 if os.environ.get("GQ_STAMP_VARIANT"):
     # the stamps on one of tools/pf_variants.py's diagnostic builds (GQ_STAMP_VARIANT=zb4: the DVFS diagnostic of

@@ -31,8 +31,9 @@ for n, v in zip(names, seg.mean(0)):
     print("  %-30s %6.0f cycles/tile  %5.1f %%" % (n, v / tiles, 100 * v / cyc))
 print("prologue per wave %.1f us (min %.1f, max %.1f); first entry -> last loop end %.1f us; loop-end skew %.1f us"
       % ((rt0 - entry).mean() / 100, (rt0 - entry).min() / 100, (rt0 - entry).max() / 100, (rt1.max() - entry.min()) / 100, (rt1.max() - rt1.min()) / 100))
-print("exact scans: %.1f queued subvectors per wave on average (max %d; %d per launch of the first 256 workgroups); loop end -> end of the last scans %.2f us on average (max %.2f); the last wave ends %.1f us after the first entry"
-      % (drained.mean(), drained.max(), drained.sum(), ((rt2 - rt1) / 100).mean(), ((rt2 - rt1) / 100).max(), (rt2.max() - entry.min()) / 100))
+scans, drained = drained // 1000, drained % 1000
+print("second pass: %.1f queued subvectors per wave on average (max %d; %d per launch of the first 256 workgroups), %d of them scanned exactly afterwards; loop end -> end of the wave %.2f us on average (max %.2f); the last wave ends %.1f us after the first entry"
+      % (drained.mean(), drained.max(), drained.sum(), scans.sum(), ((rt2 - rt1) / 100).mean(), ((rt2 - rt1) / 100).max(), (rt2.max() - entry.min()) / 100))
 end = (rt1 - entry.min()) / 100
 blk = np.arange(len(end)) // 8
 for lo, hi in [(0, 64), (64, 128), (128, 192), (192, 256)]:
