@@ -114,29 +114,32 @@ class OnDiskClassification(object):
             xb = pad[idx_n, idx_c, rows.view(n, 1, hgt, 1), cols.view(n, 1, 1, wid)]
         return (xb - self.mean) / self.std                 # transforms.Normalize
 
-    def batches(self, batch, epoch_seed, rank=0, world=1, shuffle=True):
+    def batches(self, batch, epoch_seed, rank=0, world=1, shuffle=True, min_share=1):
         """This rank's share of every global batch (world * batch consecutive entries of the epoch's permutation, as the
         reference's loader yields batch_size * num_users and main.py:189-193 splits it).  The loader's drop_last is False
-        (dataloaders.py: DataLoader defaults): the short last batch is kept and split the same way -- see rank_slice."""
+        (dataloaders.py: DataLoader defaults): the short last batch is kept and split the same way -- see rank_slices.
+        min_share: samples every rank needs of a batch (one per user); a short batch that cannot give that to EVERY rank is
+        dropped on ALL ranks, so that the ranks always agree on whether a step -- and its collectives -- happens."""
         gen = torch.Generator().manual_seed(epoch_seed)
         order = torch.randperm(self.n, generator=gen) if shuffle else torch.arange(self.n)
         order = order.to(self.x.device)
-        for lo, hi in rank_slices(self.n, batch, rank, world):
+        for lo, hi in rank_slices(self.n, batch, rank, world, min_share):
             idx = order[lo:hi]
             yield self._prepare(self.x[idx], gen), self.y[idx]
 
 
-def rank_slices(n, batch, rank, world):
+def rank_slices(n, batch, rank, world, min_share=1):
     """[lo, hi) of this rank's samples in every global batch of `world * batch` consecutive entries.  A full batch gives
     every rank `batch`.  The short last one (n % (world * batch) samples; DataLoader keeps it, drop_last=False) is split
     like main.py:189-193 splits a batch over its users: every rank but the last gets len // world, the last rank the
-    rest; when it holds fewer samples than ranks it is skipped on every rank (a rank without samples could not take
-    part in the step's collectives)."""
+    rest; when the smallest share (len // world) is below `min_share` it is skipped on EVERY rank -- decided from the
+    global size, never from a rank's own share: the last rank's share is larger, and a rank that ran the step alone would
+    enter the exchange's collectives alone."""
     per = batch * world
     for i in range(0, n, per):
         size = min(per, n - i)
         share = size // world
-        if share == 0:
+        if share < max(1, min_share):
             continue
         lo = i + rank * share
         hi = i + size if rank == world - 1 else lo + share

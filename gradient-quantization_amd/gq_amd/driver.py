@@ -244,9 +244,9 @@ def train(args, log=None):
         if epoch in steps:
             optimizer = optim.SGD(model.parameters(), lr=steps[epoch], momentum=momentum, weight_decay=5e-4)
         # the loader yields num_users*batch_size samples per rank; split across users as main.py:189-193
-        for x, y in data.batches(args.batch_size * args.num_users, 1000 * args.seed + epoch, rank, world):
-            if x.shape[0] < args.num_users:      # a last batch too short to give every user a sample (the reference would average an empty batch)
-                continue
+        # (a last batch too short to give every user of EVERY rank a sample is dropped by the loader on all ranks alike:
+        # the reference would average an empty batch, and ranks that disagreed would leave one another alone in a collective)
+        for x, y in data.batches(args.batch_size * args.num_users, 1000 * args.seed + epoch, rank, world, min_share=args.num_users):
             ub = x.shape[0] // args.num_users
             users = [(x[u * ub:(u + 1) * ub], y[u * ub:(u + 1) * ub]) for u in range(args.num_users - 1)]
             users.append((x[(args.num_users - 1) * ub:], y[(args.num_users - 1) * ub:]))

@@ -94,7 +94,13 @@ _LEVEL_BYTES = {torch.uint8: 1, torch.int16: 2, torch.int32: 4, torch.float32: 0
 
 
 def packed6_bytes(M):
+    """Bytes of a GQ_LEVELS_PACKED6 section (what the writers touch).  A section that a decode READS must be followed by one
+    more readable byte (include/gq_hsq.h): `packed6_alloc_bytes` for a section in a buffer of its own."""
     return 3 * ((int(M) + 3) // 4)
+
+
+def packed6_alloc_bytes(M):
+    return packed6_bytes(M) + 1
 
 
 def workspace_floats(M):
@@ -237,6 +243,8 @@ def hsq_decode_sum_packed(wire, M, codebook, n_bit, out, R, codes_off=0, levels_
     P = wire.shape[1]
     cb_, lb_ = _CODE_BYTES[code_dtype], _LEVEL_BYTES[level_dtype]
     assert out.numel() == M * d
+    if level_dtype == PACKED6:      # every group is fetched as one 32-bit word: a byte behind the section must exist (gq_hsq.h)
+        assert levels_off + packed6_bytes(M) + 1 <= P, "a packed level section must be followed by one more byte of its row"
     base = wire.data_ptr()
     _dev_ptr(wire, torch.uint8, "wire")
     rc = lib().gq_hsq_decode_sum_strided(

@@ -1092,7 +1092,7 @@ class PSQuantizer(object):
                 done[i] = g
         return [done[i] for i in range(self.num_layers)]
 
-    def apply(self):
+    def apply(self, refresh_grads=False):
         if self.recorded == 0:
             return
         world, rank = _dist_world(self.process_group)
@@ -1154,11 +1154,12 @@ class PSQuantizer(object):
                             g[2]._out_turn = t
                         self._dense_turn = after[1]
         # ps_quantizer.py:63 `param.grad.data = g`: the tensor OBJECT that is the parameter's gradient keeps its identity and
-        # gets the mean as its data.  The objects are the ones the last record() read (nobody touches `param.grad` between
-        # the last record and apply in the reference's loop, main.py:230-232); a parameter whose gradient was replaced in
-        # between is looked up again.
+        # gets the mean as its data.  The objects are the ones the last record() read: nobody touches `param.grad` between
+        # the last record and apply in the reference's loop (main.py:230-232), and a caller that REPLACES a parameter's
+        # .grad object in between must call apply(refresh_grads=True) ("What apply() writes to"): the 161
+        # attribute look-ups are the step's single largest host cost and are not spent on a case the protocol does not have.
         objs = self._grad_objs
-        if objs is None or len(objs) != len(decoded):
+        if refresh_grads or objs is None or len(objs) != len(decoded):
             objs = [p.grad for p in self.parameters]
         for obj, g in zip(objs, decoded):
             obj.data = g

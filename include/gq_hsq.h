@@ -66,7 +66,11 @@ size_t gq_hsq_workspace_bytes(int64_t M);
  * for configurations whose top level is <= 63 (n_bit <= 6 without stochastic rounding, <= 5 with).  A byte per level
  * spends 8 bits on 6: this form takes 12.5 % off the (codes, levels) payload of the BASELINE configuration.  Served
  * for d = 16 with byte codes: K <= 256 by the per-tensor entry points, K = 256 by the multi-tensor ones; the decode is
- * the same arithmetic on the same integers (bit-identical). */
+ * the same arithmetic on the same integers (bit-identical).
+ * The decode kernels fetch every group as ONE unaligned 32-bit word (three bytes of the group + the byte behind it), so a
+ * packed section that is READ (gq_hsq_decode_sum, gq_hsq_decode_sum_strided, gq_hsq_batch_decode) must be followed by at
+ * least one more readable byte: inside a wire the next section or the (lb, ub) words are; a section in a buffer of its own
+ * needs 3 * ceil(M / 4) + 1 bytes of allocation.  Writers (gq_hsq_levels, gq_hsq_levels_decode) touch exactly 3 * ceil(M / 4) bytes. */
 #define GQ_LEVELS_PACKED6 (-6)
 
 /* Library / device identification. */

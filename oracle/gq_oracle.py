@@ -29,9 +29,27 @@ def build(force=False):
     return _LIB_PATH
 
 
+def _require_avx2_fma():
+    """The oracle is built with -mavx2 -mfma (hardware fmaf, eight codeword chains per 256-bit register): on a host
+    without them the first call would die with SIGILL.  Say so instead."""
+    try:
+        flags = set()
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = set(line.split(":", 1)[1].split())
+                break
+    except OSError:
+        return      # not Linux: nothing to check against
+    missing = [f for f in ("avx2", "fma") if f not in flags]
+    if flags and missing:
+        raise RuntimeError("oracle/libgq_oracle.so is built with -mavx2 -mfma, but this host's CPU lacks %s (/proc/cpuinfo); "
+                           "the CPU checker cannot run here" % " and ".join(missing))
+
+
 def lib():
     global _lib
     if _lib is None:
+        _require_avx2_fma()
         if not os.path.exists(_LIB_PATH):
             build()
         _lib = ctypes.CDLL(_LIB_PATH)

@@ -164,3 +164,23 @@ def test_rank_slices_keep_the_short_last_batch_like_the_reference_loader():
         for step in range(len(per_rank[0])):
             sizes = [per_rank[r][step][1] - per_rank[r][step][0] for r in range(world)]
             assert len(set(sizes[:-1])) <= 1 and sizes[-1] >= sizes[0] and sizes[-1] - sizes[0] < world
+
+
+def test_rank_slices_drop_a_short_batch_on_every_rank_or_on_none():
+    """ADVICE r3 (driver.py): with several users per rank a short last batch must be skipped by ALL ranks or by none -- the
+    last rank's share is larger (len // world + len % world), so a per-rank test `my samples < num_users` let it run a
+    step, and enter the exchange's collectives, alone (n = 11, batch 2 x 2 users, 2 ranks: rank 0 held 1 sample, rank 1 two)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gradient-quantization_amd"))
+    from gq_amd.datasets import rank_slices
+    for n, batch, users, world in ((11, 2, 2, 2), (11, 1, 2, 2), (23, 4, 4, 3), (100, 8, 2, 4), (37, 3, 3, 2), (9, 2, 2, 4)):
+        per_rank = [list(rank_slices(n, batch * users, r, world, min_share=users)) for r in range(world)]
+        assert len(set(len(p) for p in per_rank)) == 1, ("ranks would take different numbers of steps", n, batch, users, world)
+        for step in range(len(per_rank[0])):
+            for r in range(world):
+                lo, hi = per_rank[r][step]
+                assert hi - lo >= users, "a rank holds fewer samples than users in a step that runs"
+        # nothing is dropped that could have run: the only batch that may go is the short last one
+        used = sum(hi - lo for p in per_rank for lo, hi in p)
+        rest = n % (batch * users * world)
+        assert used == (n if rest == 0 or rest // world >= users else n - rest)
