@@ -78,13 +78,17 @@ def parse_args():
                     help="roofline.traffic: live = two short child runs under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE); "
                          "auto = live at N=1 when rocprofv3 is on PATH, else the committed profiles/hbm_traffic.json")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--clock-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="workload hsq at N = 1: skip the compact `workloads` object (ResNet-50 list with HSQ, with QSGD, and with "
+                         "HSQ on back-propagated gradients: BASELINE configs[2] / [4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True,
-                    help="--workload resnet50 / qsgd (default): record() and apply() replay their device work from HIP graphs per "
-                         "set of gradient addresses (gq_graph; stochastic rounding with draws keyed by each tensor's (lb, ub) / each "
-                         "bucket's norm, gq_rng='keyed')")
+                    help="--workload resnet50 / qsgd (default, and the library's default): record() and apply() replay their device "
+                         "work from HIP graphs per set of gradient addresses (gq_graph); stochastic rounding draws from streams keyed "
+                         "by { seed, step } words in device memory (gq_rng = 'device', GQ_RANDOM_DEVICE_COUNTER)")
     ap.add_argument("--no-graph", dest="graph", action="store_false",
-                    help="--workload resnet50 / qsgd: eager launches with per-call seeds for the on-device draws (rounds 1-3's line)")
+                    help="--workload resnet50 / qsgd: eager launches (the same draws)")
     ap.add_argument("--cpu-scaling", action="store_true", help="print the CPU oracle's thread scaling on this host and exit (no GPU work)")
     ap.add_argument("--two-launches", action="store_true",
                     help="N = 1: levels and decode as two launches (as with N > 1) instead of gq_hsq_levels_decode")
@@ -133,7 +137,8 @@ def usable_cpus():
 
 def cpu_baseline(g_host, cb):
     """Time the CPU oracle's whole compress (encode + min/max + levels) on the rank-0 gradient, repeated until about
-    10 s of wall time have been spent (bounded sample), on all host cores and on ONE thread."""
+    5 s of wall time have been spent (bounded sample: ~80 core-seconds on the 16 CPUs of a GPU box), on all host cores and
+    on ONE thread (2 s)."""
     import oracle
     oracle.build()
     avail, why = usable_cpus()
@@ -142,7 +147,7 @@ def cpu_baseline(g_host, cb):
     oracle.hsq_compress(g_host[:16 * 20000], cb, N_BIT, 0)       # warm the thread pool
     n = SIZE
     reps, spent = 0, 0.0
-    while spent < 10.0 and reps < 4000:
+    while spent < 5.0 and reps < 4000:
         t0 = time.perf_counter()
         oracle.hsq_compress(g_host[:n], cb, N_BIT, 0)
         spent += time.perf_counter() - t0
@@ -151,7 +156,7 @@ def cpu_baseline(g_host, cb):
     n1 = 16 * 500_000
     oracle.hsq_compress(g_host[:n1], cb, N_BIT, 0)
     reps1, spent1 = 0, 0.0
-    while spent1 < 4.0 and reps1 < 200:
+    while spent1 < 2.0 and reps1 < 200:
         t0 = time.perf_counter()
         oracle.hsq_compress(g_host[:n1], cb, N_BIT, 0)
         spent1 += time.perf_counter() - t0
@@ -258,6 +263,68 @@ def traffic_for(args, world, workload, kernel_match, file_key):
     return None, why
 
 
+CLOCK_LIB = os.path.join(ROOT, "gradient-quantization_amd", "libgq_hsq_clock.so")
+ISA_FILE = os.path.join("profiles", "r04_encode_isa_floor.json")
+
+
+def clock_child():
+    """`bench.py --clock-child`, run by in_kernel_clock() with GQ_LIB_PATH = the DIAGNOSTIC twin of the library (hsq_encode_pf.hip
+    built with -DGQ_PF_STAMPS: s_memtime / s_memrealtime stamps; never the product): two seconds of back-to-back encodes of a
+    random 25 M-element gradient, then the stamps of the last launch -- shader cycles of the tile loop over its real time
+    (100 MHz counter), median over the workgroups' waves (MI355X_MICROARCH.md, 'DVFS give-back' item 6)."""
+    import numpy as np
+    import torch
+    from gq_amd import native
+    from gq_amd.codebook import load_codebook
+    dev = torch.device("cuda:0")
+    cb = torch.from_numpy(load_codebook(C_DIM, 2 ** K_BIT)).to(dev)
+    torch.manual_seed(1234)
+    g = torch.randn(SIZE, device=dev)
+    M = SIZE // C_DIM
+    codes, u = torch.empty(M, dtype=torch.uint8, device=dev), torch.empty(M, dtype=torch.float32, device=dev)
+    ws = native.new_workspace(dev, M)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 2.0:
+        for _ in range(200):
+            native.hsq_encode(g, cb, codes, u, ws)
+        torch.cuda.synchronize()
+    first = 2 * native.GQ_MAX_PARTIALS + 4
+    raw = ws[first + M - 65536:first + M - 65536 + 256 * 8 * 12 * 2].contiguous().view(torch.int64).view(-1, 12).cpu().numpy().astype(np.float64)
+    cyc, real, tiles = raw[:, :6].sum(1), (raw[:, 8] - raw[:, 7]) / 100.0, raw[:, 9]      # cycles, us, tiles per wave
+    ok = (real > 0) & (tiles > 0)
+    print(json.dumps({"in_kernel_clock_ghz": float(np.median(cyc[ok] / real[ok]) / 1e3),
+                      "cycles_per_tile_and_wave": float(cyc[ok].sum() / tiles[ok].sum()), "waves": int(ok.sum())}))
+
+
+def in_kernel_clock():
+    """(clock in GHz or None, how): a child run of this script on the stamped twin of the library (see clock_child)."""
+    if not os.path.exists(CLOCK_LIB):
+        return None, "gradient-quantization_amd/libgq_hsq_clock.so was not built"
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--clock-child"], env=dict(os.environ, GQ_LIB_PATH=CLOCK_LIB),
+                             capture_output=True, text=True, timeout=120).stdout.strip().splitlines()
+        rec = json.loads(out[-1])
+        return rec, ("child run of bench.py on libgq_hsq_clock.so (hsq_encode_pf.hip built with -DGQ_PF_STAMPS; never the product "
+                     "library): 2 s of back-to-back encodes on random data, then s_memtime cycles of the tile loop / its "
+                     "s_memrealtime span, median over %d waves" % rec["waves"])
+    except Exception as e:
+        return None, "clock child failed: %s" % (e,)
+
+
+def issue_floor(clock_ghz, cus):
+    """The launch's ISSUE floor: tiles x (4 cycles per VALU instruction + 8 per MFMA of the tile loop, from the compiler's ISA:
+    tools/isa_count.py -> profiles/r04_encode_isa_floor.json) / SIMDs / in-kernel clock.  What the instruction stream allows
+    with every issue slot used; tail, prologue, second pass and exact scans come on top."""
+    try:
+        isa = json.load(open(os.path.join(ROOT, ISA_FILE)))
+    except Exception:
+        return None, None
+    tiles = -(-(SIZE // C_DIM) // isa["subvectors_per_tile"])
+    if not clock_ghz:
+        return None, isa
+    return tiles * isa["issue_cycles_per_tile"] / (4.0 * cus) / (clock_ghz * 1e9) * 1e3, isa
+
+
 def event_ms(torch, fn, n=50, warm=10):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(warm):
@@ -284,6 +351,9 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "gradient-quantization_amd"))
         from gq_amd.codebook import load_codebook
         cpu_scaling(np.random.RandomState(1234).standard_normal(SIZE).astype(np.float32), load_codebook(C_DIM, 1 << K_BIT))
+        return
+    if args.clock_child:
+        clock_child()
         return
     import torch
     if not torch.cuda.is_available():
@@ -327,14 +397,62 @@ def main():
         dist.destroy_process_group()
 
 
-def exchange_report(ex, mode, requested, backend, world, dist, exchange_ms):
+def ranks_counted(torch, dist, dev):
+    """How many ranks the collective library actually joins: an all-reduce (sum) of a device one -- not get_world_size(),
+    which would read N whatever the backend formed."""
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(one)
+    return int(round(float(one.item())))
+
+
+def collective_library(torch, backend):
+    if backend != "nccl":
+        return backend, None
+    try:
+        v = torch.cuda.nccl.version()
+        return "rccl", ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        return "rccl", None
+
+
+def transports_ms(torch, dist, dev, run):
+    """Transfer time (no decode) of the in-place all-gather and of the direct all-pairs exchange, both, in every N > 1 run
+    (a few MB per rank: milliseconds of untimed work) -- max over ranks.  A transport that ANY rank's dry run refuses is
+    skipped on all of them (one all-reduced flag: the ranks never disagree on which collectives follow)."""
+    out = {}
+    for m in ("allgather", "direct"):
+        ok, why = 1.0, ""
+        try:
+            run(m, True)
+        except Exception as e:
+            ok, why = 0.0, str(e).splitlines()[0][:120]
+        flag = torch.tensor([ok], dtype=torch.float32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) < 1.0:
+            out[m] = "refused" + (": " + why if why else " by another rank")
+            continue
+        t = torch.tensor([event_ms(torch, lambda: run(m), n=20, warm=5)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out[m] = float(t.item())
+    return out
+
+
+def exchange_report(torch, counted, ex, mode, requested, backend, world, exchange_ms, per_transport_ms, wire_bytes):
+    """N > 1: what a first multi-GPU run needs to explain itself -- the ranks counted by a collective, the library and its
+    version, the transport used, and the time of EVERY transport measured in the untimed pass (transfer alone, no decode).
+    `counted`: ranks_counted(), called by EVERY rank before rank 0 builds the line."""
     if world == 1:
         return None
-    return {"backend": "rccl" if backend == "nccl" else backend, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
-            "ranks": world, "transport": mode, "requested": requested, "wire_bytes_per_rank": ex.user_bytes,
-            "ms": exchange_ms, "autotune_ms": ex.timings_ms,
-            "note": "ms = the chosen transport alone (no decode), HIP events, untimed pass; autotune_ms = exchange + "
-                    "decode-mean per transport (max over ranks), measured before the timed region when --exchange auto"}
+    name, version = collective_library(torch, backend)
+    return {"backend": name, "rccl_version": version, "rccl_ranks": counted, "ranks": world,
+            "transport": mode, "requested": requested, "wire_bytes_per_rank": wire_bytes,
+            "ms": exchange_ms, "ms_by_transport": per_transport_ms, "autotune_ms": ex.timings_ms,
+            "algorithm_env": {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "RCCL_MSCCL_ENABLE", "NCCL_DEBUG") if k in os.environ},
+            "note": "rccl_ranks = an all-reduce of ones over the process group (== n_gpus when every rank joined); ms = the chosen "
+                    "transport alone (no decode), HIP events, untimed pass; ms_by_transport = the same for the in-place all-gather and for "
+                    "the direct all-pairs isend / irecv (one xGMI link per peer), so that ONE run says which to default to: direct wins "
+                    "when its ms is below allgather's by more than the run-to-run spread (DESIGN.md section 5); autotune_ms = exchange + "
+                    "decode-mean per transport (max over ranks), only with --exchange auto"}
 
 
 def ranks_agree(torch, dist, world, tensors):
@@ -506,10 +624,12 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
             g8, M, cb, N_BIT, out, 8, wire.codes_off, wire.levels_off, wire.lbub_off,
             level_dtype=native.PACKED6 if packed6 else torch.uint8))
         del g8
-    exch_ms = None
+    exch_ms, exch_by = None, None
     if world > 1:
         exch_ms = event_ms(torch, (lambda: [p.wait() for p in sex.start("split", cut=swire.cut)[1]]) if mode == "split"
                            else (lambda: ex.run(mode)))
+        exch_by = transports_ms(torch, dist, dev, lambda m, dry=False: (ex.start(m, dry_run=True) if dry else ex.run(m)))
+    counted = ranks_counted(torch, dist, dev) if world > 1 else 1
 
     if rank != 0:
         return None
@@ -518,6 +638,9 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     achieved = ALGO_BYTES_PER_ELEM * SIZE / (enc_ms * 1e-3) / 1e9
     achieved_compress = ALGO_BYTES_PER_ELEM * SIZE / (cmp_ms * 1e-3) / 1e9
     traffic, traffic_source = traffic_for(args, world, "hsq", "hsq_encode_pf_kernel", "hsq_encode_hbm_bytes_per_launch")
+    clock, clock_source = (None, "not measured (N > 1 or a PMC child run)") if (world > 1 or args.traffic_child) else in_kernel_clock()
+    clock_ghz = clock["in_kernel_clock_ghz"] if clock else None
+    floor_ms, isa = issue_floor(clock_ghz, native.device_info(dev.index)[0])
     line = {
         "metric": "gradient elements quantized/sec (HSQ d=16 k=8)", "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -543,11 +666,19 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
                                 "definition, the whole compress: 4.125 B x 25e6 / (encode + levels, HIP events around "
                                 "back-to-back pairs on rotating inputs) / peak; frac_step = (4.125 + 2 R / 16 + 4) B x 25e6 / ms_per_step "
                                 "/ peak, the timed step's algorithmic bytes (compress + decode-mean of R = n_gpus payloads)",
-                     "kernel": "gq_hsq_encode = hsq_encode_pf_kernel (one launch: prefilter, exact rescoring, in-place exact fix-up; levels: a second launch)",
+                     "kernel": "gq_hsq_encode = hsq_encode_pf_kernel (one launch: f16 prefilter, exact rescoring, second pass and exact scan of the unsettled; levels: a second launch)",
                      "kernel_ms": enc_ms, "kernel_ms_back_to_back": enc_b2b_ms,
+                     # the kernel's own ceiling: its instruction stream at the clock the chip holds under it
+                     "in_kernel_clock_ghz": clock_ghz, "in_kernel_clock_source": clock_source,
+                     "issue_floor_ms": floor_ms, "frac_of_issue_floor": (floor_ms / enc_ms) if floor_ms else None,
+                     "issue_floor_is": ("tiles x (4 cycles x %d VALU + 8 x %d MFMA instructions of the tile loop, %s) / (4 SIMDs x CUs) / "
+                                        "in_kernel_clock_ghz: what the instruction stream allows with every issue slot used; "
+                                        "prologue, tail, second pass and exact scans come on top"
+                                        % (isa["valu"], isa["mfma"], ISA_FILE)) if isa else None,
                      "kernel_ms_recorded_bracket": enc_bracket_ms, "empty_recorded_bracket_ms": ev_overhead_ms,
-                     "note": "exact f32 scoring would need 512 flop/element (81 us at 157.3 TFLOP/s); the "
-                             "bf16x3 prefilter + exact rescoring path is bound by VALU issue, not by HBM.  kernel_ms: HIP "
+                     "note": "exact f32 scoring would need 512 flop/element (81 us at 157.3 TFLOP/s); the f16 prefilter "
+                             "(one MFMA per chain) + exact rescoring + second pass is bound by VALU issue and by the clock the "
+                             "chip holds under it, not by HBM.  kernel_ms: HIP "
                              "start/stop events attached to the kernel's dispatch inside the timed region "
                              "(agrees with rocprofv3, profiles/); a bracket RECORDED around the call reads "
                              "kernel_ms_recorded_bracket, an empty one empty_recorded_bracket_ms"},
@@ -562,7 +693,8 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
         "compress_only": {"value": world * SIZE / (cmp_ms * 1e-3), "unit": "elements/s"},
         "ranks_bit_identical": identical,
     }
-    rep = exchange_report(sex if mode == "split" else ex, mode, args.exchange, backend, world, dist, exch_ms)
+    rep = exchange_report(torch, counted, sex if mode == "split" else ex, mode, args.exchange, backend, world, exch_ms, exch_by,
+                          (swire if mode == "split" else wire).nbytes) if world > 1 else None
     if rep:
         rep["autotune_ms"] = ex.timings_ms
         line["exchange"] = rep
@@ -580,7 +712,130 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
         del small
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(grads[0].cpu().numpy(), cb_np)
+    if world == 1 and not args.no_workloads and not args.traffic_child:
+        del grads, out, u, partials      # 500 MB back before the parameter lists are built
+        torch.cuda.empty_cache()
+        line["workloads"] = list_workloads(args, torch, np, native, dev)
     return line
+
+
+# ------------------------------------------------------------------------------------------------------
+# the compact `workloads` object of the default line: BASELINE configs[2] / [4] under the driver's clock
+# ------------------------------------------------------------------------------------------------------
+def list_workloads(args, torch, np, native, dev, steps=150, warm=40):
+    """The ResNet-50/CIFAR parameter list (161 tensors, 23.5 M elements) through PSQuantizer.record + apply, three ways:
+    resnet50 (HSQ c_dim 16 k_bit 8 n_bit 6 random 1, N(0,1) x 1e-3 inputs), qsgd (QSGD c_dim 128 n_bit 2 random 1, same inputs) and
+    resnet50_real (HSQ on BACK-PROPAGATED gradients: one forward / backward of driver.ResNet50 per input list on a seeded
+    synthetic CIFAR batch of 128 -- real gradient statistics: dead units' all-zero subvectors, heavy tails).  Each with the
+    library's default launches (HIP graph replay) and with eager launches, `steps` timed steps after `warm`."""
+    import contextlib
+    from argparse import Namespace
+    from gq_amd.compressors import NearestNeighborCompressor, QSGDCompressor
+    from gq_amd.driver import ResNet50
+    from gq_amd.quantizers import BatchedHSQ, BatchedQSGD, Quantizer
+
+    torch.manual_seed(1234)
+    model = ResNet50(num_classes=10).to(dev)
+    shapes = [tuple(p.shape) for p in model.parameters()]
+    n = sum(int(np.prod(sh)) for sh in shapes)
+    lossf = torch.nn.CrossEntropyLoss()
+    real = []
+    for b in range(3):
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(4321 + b)
+        x = torch.randn(128, 3, 32, 32, device=dev, generator=gen)
+        y = torch.randint(0, 10, (128,), device=dev, generator=gen)
+        model.zero_grad(set_to_none=True)
+        lossf(model(x), y).backward()
+        real.append([p.grad.detach().clone() for p in model.parameters()])
+    del model
+    synth = [[torch.randn(sh, device=dev) * 1e-3 for sh in shapes] for _ in range(3)]
+    hsq_kw = dict(c_dim=C_DIM, k_bit=K_BIT, n_bit=N_BIT)
+    qsgd_kw = dict(c_dim=128, k_bit=8, n_bit=2)
+
+    def one(Comp, kw, lists, hsq):
+        res = {}
+        for graph in (False, True):
+            qargs = Namespace(no_cuda=False, random=1, ef=False, two_phase=False, scale="exp", num_users=1, mode="ps", cr=256,
+                              gq_graph=graph, **kw)
+            params = [torch.nn.Parameter(torch.zeros(*sh, device=dev)) for sh in shapes]
+            with contextlib.redirect_stdout(sys.stderr):     # the constructors report the reference's dimension repair on stdout
+                q = Quantizer(Comp, params, qargs)
+            total = warm + steps + 10
+            fresh = [[g.view(g.shape) for g in lists[i % 3]] for i in range(total)]     # apply() rebinds .grad.data: fresh objects per step
+
+            def step(i):
+                for p, g in zip(params, fresh[i]):
+                    p.grad = g
+                q.record(0, epoch=1)
+                q.apply()
+            for i in range(warm):
+                step(i)
+            Grp = BatchedHSQ if hsq else BatchedQSGD
+            grp = [g[2] for g in q._groups if isinstance(g[2], Grp) and not getattr(g[2], "wide", False)][0]
+            armed = {warm + k * (steps // 8): k for k in range(8)} if (hsq and not graph) else {}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(warm, warm + steps):
+                if i in armed:
+                    grp.profile_slot = armed[i]
+                step(i)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            res["ms_per_step_graph" if graph else "ms_per_step_eager"] = ms
+            if graph:
+                res["graphs_captured"] = [sum(1 for e in q._rec_graphs.values() if e[1] is not None),
+                                          sum(1 for e in q._apply_graphs.values() if e[1] is not None)]
+                continue
+            c0 = native.CALLS[0]
+            step(warm + steps)
+            res["launches"] = {"library_calls_per_step": native.CALLS[0] - c0,
+                               "torch_ops_per_step": "1 pinned header copy (HSQ) + the dense tensors' _foreach_copy_"}
+            for p, g in zip(params, lists[0]):
+                p.grad = g.view(g.shape)
+            gl = [params[i].grad.data for i in grp.idxs]
+            wire0 = q._wire[0]
+            cmp_ms = event_ms(torch, lambda: grp.encode(gl, wire0, 0, 0))       # HSQ: encode + levels; QSGD: the one compress launch
+            k_elems = sum(cd.numel for cd in grp.codecs)
+            if hsq:
+                k_ms = float(np.mean([native.profile_read(k) for k in range(8)]))
+                algo = ALGO_BYTES_PER_ELEM * k_elems
+            else:
+                k_ms, algo = cmp_ms, QSGD_ALGO_BYTES_PER_ELEM * k_elems
+            res.update({"kernel_ms": k_ms, "compress_ms": cmp_ms, "kernel_elements": k_elems,
+                        "frac": algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_compress": algo / (cmp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "decode_mean_ms_R1": event_ms(torch, lambda: grp.decode_mean(q._wire[:1], 1))})
+            if hsq:     # how many subvectors the prefilter's first pass does not settle (second pass / exact scan), per-tensor encodes
+                cbk, flagged, subv = grp.codebook, 0, 0
+                for i in grp.idxs:
+                    g = lists[0][i].contiguous().view(-1)
+                    if q.codecs[i].c.dim != 16 or g.numel() % 16:
+                        continue
+                    M = g.numel() // 16
+                    ws = native.new_workspace(dev, M)
+                    native.mark_worklist(ws, M)
+                    native.hsq_encode(g, cbk, torch.empty(M, dtype=torch.uint8, device=dev), torch.empty(M, dtype=torch.float32, device=dev), ws)
+                    flagged += native.fixup_count(ws, M)
+                    subv += M
+                res["fixup_fraction"] = flagged / max(1, subv)
+            del q
+        res["value_graph"] = n / (res["ms_per_step_graph"] * 1e-3)
+        res["unit"] = "elements/s"
+        return res
+
+    out = {"resnet50": one(NearestNeighborCompressor, hsq_kw, synth, True),
+           "qsgd": one(QSGDCompressor, qsgd_kw, synth, False),
+           "resnet50_real": one(NearestNeighborCompressor, hsq_kw, real, True),
+           "note": ("ResNet-50/CIFAR parameter list, %d elements in 161 tensors (76 through the codebook / the bucket quantiser, 85 of "
+                    "<= 1000 elements as f32), one rank, PSQuantizer.record + apply per step, %d timed steps after %d; ms_per_step_graph: the "
+                    "library's default (HIP graph replay, draws keyed by device step words), ms_per_step_eager: gq_graph off; kernel_ms: "
+                    "HSQ = HIP events attached to the multi-tensor encode's dispatch on 8 eager steps, QSGD = the one compress launch "
+                    "(events around 50 back-to-back launches); frac = algorithmic bytes of the compressed tensors / kernel_ms / 8 TB/s; "
+                    "resnet50_real: gradients of driver.ResNet50 back-propagated from seeded synthetic CIFAR batches of 128 (three lists "
+                    "in turn); fixup_fraction: subvectors the prefilter's first pass leaves to the second pass or the exact scan"
+                    % (n, steps, warm))}
+    return out
+
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -606,8 +861,7 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
         qargs = Namespace(c_dim=128, k_bit=8, n_bit=2, no_cuda=False, random=1, ef=False, two_phase=False, scale="exp",
                           num_users=1, mode="ps", cr=256)
         Comp = QSGDCompressor
-    if args.graph:      # stochastic rounding with draws keyed by each tensor's (lb, ub) / each bucket's norm: launches that never change
-        qargs.gq_graph, qargs.gq_rng = True, "keyed"
+    qargs.gq_graph = bool(args.graph)      # (the library's default is replay: gq_rng = "device" draws from device step words)
     params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
     os.environ["GQ_EXCHANGE"] = args.exchange
     os.environ["GQ_WIRE_LEVELS"] = args.wire_levels      # (auto: packed6 for N > 1.)  packed6 applies where the top level is <= 63 (not with the README's --random 1 at n_bit 6)
@@ -667,14 +921,18 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
         torch.cuda.synchronize()
     k_elems = sum(cd.numel for cd in grp.codecs)
     dec_ms = event_ms(torch, lambda: grp.decode_mean(q._wire[:1], 1))
-    exch_ms = None
+    exch_ms, exch_by = None, None
     if world > 1 and q._ex is not None:
         mode = q.exchange_mode
 
-        def only_exchange():
-            for pnd in q._ex.start(mode, 1, q.cut)[1]:
+        def only_exchange(m=None, dry=False):
+            if dry:
+                return q._ex.start(m, 1, q.cut, dry_run=True)
+            for pnd in q._ex.start(m or mode, 1, q.cut)[1]:
                 pnd.wait()
         exch_ms = event_ms(torch, only_exchange)
+        exch_by = transports_ms(torch, dist, dev, only_exchange)
+    counted = ranks_counted(torch, dist, dev) if world > 1 else 1
     if rank != 0:
         return None
     if hsq:
@@ -720,18 +978,15 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
                      "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": algo,
                      "frac_compress": achieved_compress / HBM_PEAK_GBS, "compress_ms": cmp_ms,
                      "kernel": kernel, "kernel_ms": k_ms, "kernel_elements": k_elems, "note": note},
-        "phases_ms": {"compress_kernels": cmp_ms, "decode_mean_kernel_R1": dec_ms, "exchange": exch_ms},
+        "phases_ms": {"compress_kernels": cmp_ms, "decode_mean_kernel_R1": dec_ms, "exchange": exch_ms,
+                      "note": "compress_kernels / decode_mean: the launches alone, back to back (HIP events); exchange: the chosen "
+                              "transport alone; with N > 1 the decode-mean of the step runs over R = n_gpus payloads"},
         "compress_only": {"value": world * k_elems / (cmp_ms * 1e-3), "unit": "elements/s"},
         "ranks_bit_identical": identical,
     }
-    if world > 1:
-        line["exchange"] = {"backend": "rccl" if backend == "nccl" else backend,
-                            "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "ranks": world,
-                            "transport": q.exchange_mode, "requested": args.exchange, "ms": exch_ms,
-                            "wire_bytes_per_rank": q.wire_bytes_per_user(),
-                            "autotune_ms": q._ex.timings_ms if q._ex is not None else None,
-                            "note": "ms = the chosen transport alone (no decode), HIP events, untimed pass; autotune_ms = exchange + "
-                                    "decode-mean per transport (max over ranks), only with --exchange auto"}
+    if world > 1 and q._ex is not None:
+        line["exchange"] = exchange_report(torch, counted, q._ex, q.exchange_mode, args.exchange, backend, world, exch_ms, exch_by,
+                                           q.wire_bytes_per_user())
     return line
 
 

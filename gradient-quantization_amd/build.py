@@ -36,7 +36,7 @@ def hipcc():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(os.path.join(HERE, "libgq_hsq_clock.so")):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "gq_hsq.h"), __file__]
@@ -77,7 +77,31 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
+    build_clock_lib(objs, verbose)
     return LIB
+
+
+CLOCK_LIB = os.path.join(HERE, "libgq_hsq_clock.so")
+
+
+def build_clock_lib(objs=None, verbose=False, source=None, out=None):
+    """DIAGNOSTIC twin of the library: the same objects, with hsq_encode_pf.hip compiled with -DGQ_PF_STAMPS (s_memtime /
+    s_memrealtime stamps around the phases of a tile; see the macro's comment in the file).  Never loaded by the product:
+    `bench.py` runs it in a child process to read the in-kernel clock (roofline.in_kernel_clock_ghz), tools/stamp_read.py
+    prints the whole breakdown.  `source` / `out`: a variant of the file (tools/stamp_build.py)."""
+    objdir = os.path.join(HERE, "build")
+    if objs is None:
+        objs = [os.path.join(objdir, f.replace(".hip", ".o")) for f in SOURCES]
+    src = source or os.path.join(CSRC, "hsq_encode_pf.hip")
+    obj = os.path.join(objdir, "hsq_encode_pf_stamps.o" if out is None else os.path.basename(out) + ".o")
+    flags = [f for f in FLAGS if f != "-shared"] + EXTRA.get("hsq_encode_pf.hip", [])
+    cmd = [hipcc()] + flags + ["-DGQ_PF_STAMPS", "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, stderr=None if verbose else subprocess.DEVNULL)
+    others = [o for o in objs if os.path.basename(o) != "hsq_encode_pf.o"]
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or CLOCK_LIB, obj] + others)
+    return out or CLOCK_LIB
 
 
 if __name__ == "__main__":

@@ -88,8 +88,10 @@ GQ_API int gq_hsq_levels_batched(const gq_hsq_batch *b, uint8_t *wire, int rando
     if (rc != GQ_OK) return rc;
     if (!wire || !b->u_flat || !b->seg_minmax) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: null pointer");
     if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_GIVEN && random_mode != GQ_RANDOM_DEVICE &&
-        random_mode != GQ_RANDOM_DEVICE_KEYED)
+        random_mode != GQ_RANDOM_DEVICE_KEYED && random_mode != GQ_RANDOM_DEVICE_COUNTER)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: random_mode %d", random_mode);
+    if (random_mode == GQ_RANDOM_DEVICE_COUNTER && (seed == 0 || (seed & 7) != 0))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: GQ_RANDOM_DEVICE_COUNTER takes the address of two device words as `seed`");
     if (random_mode != GQ_RANDOM_GIVEN) r_flat = nullptr;
     if (gq::byte_wire(b)) {
         if (write_error && b->d != 16)

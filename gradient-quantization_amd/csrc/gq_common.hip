@@ -75,7 +75,7 @@ static inline int grid_for(int64_t n, int block) {
 
 }  // namespace gq
 
-GQ_API int gq_abi_version(void) { return 2; }
+GQ_API int gq_abi_version(void) { return 3; }
 
 GQ_API const char *gq_last_error(void) { return gq::last_error_buf(); }
 
@@ -112,7 +112,8 @@ GQ_API int gq_sub(const float *grad, const float *decoded, float *err, int64_t n
 // ---- mean of R rows (the aggregate of identity-compressed tensors) -------------------------------------------
 namespace gq {
 __global__ __launch_bounds__(256) void mean_rows_kernel(const uint8_t *__restrict__ rows, int64_t row_stride_bytes, int R,
-                                                        int64_t n, float *__restrict__ out) {
+                                                        int64_t n, float *__restrict__ out, uint64_t *rng_state, int rng_pairs) {
+    bump_rng_counter(rng_state, rng_pairs);
     const MeanDiv md = mean_div_of(R, true);
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -121,14 +122,19 @@ __global__ __launch_bounds__(256) void mean_rows_kernel(const uint8_t *__restric
         out[i] = mean_div(acc, md);   // (+0 + row 0 + row 1 + ...) / R, rows ascending, a true division: torch's CPU mean
     }
 }
+__global__ void rng_step_kernel(uint64_t *rng_state, int rng_pairs) { bump_rng_counter(rng_state, rng_pairs); }
 }  // namespace gq
 
-GQ_API int gq_mean_rows(const void *rows, int64_t row_stride_bytes, int R, int64_t n, float *out, void *stream) {
-    if (R < 1 || n < 0 || (n > 0 && (!rows || !out)) || (row_stride_bytes & 3) != 0)
+GQ_API int gq_mean_rows(const void *rows, int64_t row_stride_bytes, int R, int64_t n, float *out, uint64_t *rng_state,
+                        int rng_pairs, void *stream) {
+    if (R < 1 || n < 0 || (n > 0 && (!rows || !out)) || (row_stride_bytes & 3) != 0 || (rng_state && (rng_pairs < 1 || rng_pairs > 256)))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_mean_rows: bad arguments");
-    if (n == 0) return GQ_OK;
-    hipLaunchKernelGGL(gq::mean_rows_kernel, dim3(gq::grid_for(n, 256)), dim3(256), 0, gq::as_stream(stream),
-                       static_cast<const uint8_t *>(rows), row_stride_bytes, R, n, out);
+    if (n == 0 && !rng_state) return GQ_OK;
+    if (n == 0)
+        hipLaunchKernelGGL(gq::rng_step_kernel, dim3(1), dim3(256), 0, gq::as_stream(stream), rng_state, rng_pairs);
+    else
+        hipLaunchKernelGGL(gq::mean_rows_kernel, dim3(gq::grid_for(n, 256)), dim3(256), 0, gq::as_stream(stream),
+                           static_cast<const uint8_t *>(rows), row_stride_bytes, R, n, out, rng_state, rng_pairs);
     GQ_CHECK_LAUNCH("gq_mean_rows");
     return GQ_OK;
 }

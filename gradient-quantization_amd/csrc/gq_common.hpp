@@ -168,6 +168,24 @@ __device__ __forceinline__ unsigned team_word(unsigned w, int t) {
 // multiply-xorshift rounds, then a third round that folds in the upper halves) of (seed, index); the top
 // 24 bits -> k * 2^-24, the same grid of values torch.rand produces for float32.  ~12 VALU operations --
 // the 64-bit splitmix64 it replaces cost ~40 and was most of the QSGD compress kernel's time.
+// GQ_RANDOM_DEVICE_COUNTER: `seed` is the address of two device words { seed, step counter }; the stream of this launch is
+// keyed by both.  Every multi-tensor decode launch adds one to the counter (bump_rng_counter), so launches whose arguments
+// never change -- nodes of a HIP graph -- draw fresh numbers every step.  Called first thing in a kernel (a uniform load).
+// A caller keeps one pair per (tensor group, user slot), all in one array that one gq_rng_step / gq_mean_rows_step steps.
+__device__ __forceinline__ void resolve_seed(int &random_mode, uint64_t &seed) {
+    if (random_mode == GQ_RANDOM_DEVICE_COUNTER) {
+        const uint64_t *st = reinterpret_cast<const uint64_t *>(static_cast<uintptr_t>(seed));
+        uint64_t z = st[1] + 0x9E3779B97F4A7C15ull;      // splitmix64 of the step counter
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        seed = st[0] ^ z ^ (z >> 31);
+        random_mode = GQ_RANDOM_DEVICE;
+    }
+}
+__device__ __forceinline__ void bump_rng_counter(uint64_t *state, int npairs) {   // nothing else reads the words meanwhile
+    if (state && blockIdx.x == 0 && (int)threadIdx.x < npairs) state[2 * threadIdx.x + 1] += 1;
+}
+
 __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
     uint32_t h = (uint32_t)idx + (uint32_t)seed * 0x9E3779B1u;
     h ^= h >> 16;

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
     uint64_t seed, const float *__restrict__ r_flat, uint8_t *__restrict__ wire) {
+    resolve_seed(random_mode, seed);
     const float s = (float)(1 << n_bit), smax = s - 1.0f;
     const int64_t total4 = ntiles * 16;
     const int64_t stride = (int64_t)gridDim.x * BT_THREADS;
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
     uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire) {
+    resolve_seed(random_mode, seed);
     // rows 20 floats apart: an odd number of 16-byte units spreads the random-row gathers over the banks
     __shared__ __attribute__((aligned(16))) float s_cb[256 * 20];
     for (int i = threadIdx.x; i < 256 * 16 / 4; i += BT_THREADS)
@@ -605,6 +607,7 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_d_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
     uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire) {
+    resolve_seed(random_mode, seed);
     constexpr int UPS = D / 4;
     constexpr int RS = ((D / 4) & 1) ? D : D + 4;
     __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];

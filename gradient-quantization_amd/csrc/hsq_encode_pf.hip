@@ -54,6 +54,29 @@
 
 #include "hsq_pf_common.hpp"
 
+// DIAGNOSTIC build only (-DGQ_PF_STAMPS: build.py's libgq_hsq_clock.so, loaded by `bench.py --clock-child` and tools/stamp_read.py;
+// never the product library): s_memtime stamps around the phases of a tile and s_memrealtime (100 MHz) at the ends of the
+// loop, written behind the diagnostics log of the workspace, which no other code of the kernel reads
+// (MI355X_MICROARCH.md, 'DVFS give-back' item 6: the in-kernel clock = shader cycles / real time).  Without the macro
+// every GQ_STAMP is empty and the kernel contains no stamp.
+#ifdef GQ_PF_STAMPS
+#define GQ_STAMP(ID)                                                                                  \
+    {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long ts_;                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");                   \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        stamp_acc[ID] += (ts_ - ts_prev);                                                             \
+        ts_prev = ts_;                                                                                \
+    }
+#define GQ_STAMPS_ONLY(...) __VA_ARGS__
+#define GQ_LOG_SCAN(...)
+#else
+#define GQ_STAMP(ID)
+#define GQ_STAMPS_ONLY(...)
+#define GQ_LOG_SCAN(...) __VA_ARGS__
+#endif
+
 namespace gq {
 
 // The d = 16 kernels run ONE workgroup of 8 waves per CU (two waves per SIMD, as before, but in one workgroup):
@@ -116,6 +139,7 @@ static void pf_split(PfArgs &a, int64_t ntiles, int64_t blocks) {
 // the two sources turns the record pointer into a flat pointer (see tile_info).
 template <typename CodeT, bool BATCHED, bool EF = false, bool SEGLDS = true>
 __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfArgs a) {
+    GQ_STAMPS_ONLY(const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime(); unsigned long long nscanned = 0, npassed = 0;)
     const float *__restrict__ cb = a.cb;
     float *__restrict__ ws = a.ws;
     float *__restrict__ u = a.u;
@@ -441,6 +465,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // the whole wave on one subvector at a time (profiles/r04_experiments.txt).
     int qhead = 0, qcnt = 0;   // this wave's ring: first entry, entries (wave-uniform)
     auto scan4 = [&](int first, int n) {
+        GQ_STAMPS_ONLY(nscanned += n;)
         const int e = lane >> 4, r = lane & 15;
         for (int b0 = 0; b0 < n; b0 += 4) {
             const bool live = b0 + e < n;   // (an idle quarter re-scans the batch's first entry and stores nothing)
@@ -508,7 +533,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
                     if (isnan) poison_seg((int)m[3]);
                     else fold_seg((int)m[3], bv);
                 } else {
-                    worklist[m[2]] = (int)m[2];   // diagnostics only: which subvectors took an exact scan
+                    GQ_LOG_SCAN(worklist[m[2]] = (int)m[2];)   // diagnostics only: which subvectors took an exact scan
                     lmin = fminf(lmin, bv);
                     lmax = fmaxf(lmax, bv);
                 }
@@ -522,6 +547,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // (i, 0) and (i, 1) hold the two halves of its rows and, after the exchange, both score the same group (only (i, 0)
     // stores).  What even this bound does not settle (~1 in 150 entries; non-finite values) is scanned exactly (scan4).
     auto second_pass = [&](int first, int n) {
+        GQ_STAMPS_ONLY(npassed += n;)
         const int col = j < n ? j : 0;   // (idle columns repeat entry 0 and store nothing)
         const int slot = wave * PF_QCAP + ((first + col) & (PF_QCAP - 1));
         const f32x4 *qv = reinterpret_cast<const f32x4 *>(s_qv + 16 * slot);
@@ -634,7 +660,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             if (BATCHED) {
                 fold_seg((int)mt[3], val);
             } else {
-                worklist[mt[2]] = (int)mt[2];   // diagnostics only: which subvectors took the second pass
+                GQ_LOG_SCAN(worklist[mt[2]] = (int)mt[2];)   // diagnostics only: which subvectors took the second pass
                 lmin = fminf(lmin, val);
                 lmax = fmaxf(lmax, val);
             }
@@ -646,6 +672,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             scan4((first + i) & (PF_QCAP - 1), 1);
         }
     };
+    GQ_STAMPS_ONLY(const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(); unsigned long long ntl = 0, stamp_acc[6] = {0, 0, 0, 0, 0, 0}, ts_prev;
+                   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_prev)::"memory");)
     while (t < tile_end) {
         // single tensor: tn was drawn at the end of the previous tile; batched: a whole tile ago
         const int64_t tnn = BATCHED ? draw() : 0;
@@ -660,6 +688,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             flush_minmax();
             cur_seg = ti.seg;
         }
+        GQ_STAMP(0)
         // ---- prefilter: 16 (block, row block) chains; top-2 GROUP keys per (block, row-block half) ----
         // The MFMA of chain c+1 is issued in front of the key operations of chain c (sched_barrier pins the order):
         // the matrix pipe runs under the VALU stream.
@@ -706,6 +735,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             }
         }
 
+        GQ_STAMP(1)
         // ---- per block: merge the two trackers; best group's first codeword and the bound on the rest ----
         int k1[2];
         unsigned s2[2], bk[2];
@@ -751,6 +781,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         }
         const unsigned n2b = __float_as_uint(n2);
 
+        GQ_STAMP(2)
         // ---- exact rescoring of the better of the two halves' best groups (4 codewords; the
         // reference's fmaf chain).  The other half's best group joins the bound on everything that
         // was not rescored.
@@ -805,6 +836,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             }
         }
 
+        GQ_STAMP(3)
         // Consume the prefetched tile (convert it to the next B fragments) BEFORE this tile's
         // stores are issued: the wait for the prefetch then sees only long-finished memory ops.
         // Done the other way round, the compiler's vmcnt wait at the first use of `nxt` sits right
@@ -826,6 +858,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         }
         __builtin_amdgcn_sched_barrier(0);
 
+        GQ_STAMP(4)
         // ---- the few subvectors the bound could not settle (header, 4): into this wave's ring; four at a time they are
         // scanned exactly (scan4 below), the rest when the wave has run out of tiles.  A flagged lane writes its sixteen
         // floats and where the answer goes.
@@ -863,7 +896,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         t = tn;
         tn = BATCHED ? tnn : draw();
         sigma_t = sigma_n;
+        GQ_STAMP(5)
+        GQ_STAMPS_ONLY(++ntl;)
     }
+    GQ_STAMPS_ONLY(const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();)
     if (BATCHED) flush_minmax();
 
     while (qcnt) {   // out of tiles: the ring's entries through the second pass (one trip: a wave collects ~12 per launch)
@@ -872,6 +908,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         qhead = (qhead + n) & (PF_QCAP - 1);
         qcnt -= n;
     }
+#ifdef GQ_PF_STAMPS
+    if (!BATCHED && lane == 0 && blockIdx.x < 256) {   // 12 words per wave behind the log (which this build does not write)
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(ws_worklist(ws) + (M - 65536)) + (blockIdx.x * 8 + wave) * 12;
+        for (int i = 0; i < 6; ++i) o[i] = stamp_acc[i];
+        o[6] = rt_entry, o[7] = rt0, o[8] = rt1, o[9] = ntl, o[10] = __builtin_amdgcn_s_memrealtime(), o[11] = 1000 * nscanned + npassed;
+    }
+#endif
     if (BATCHED) return;
     write_minmax_partials<PF_WAVES>(lmin, lmax, ws, sawnan);   // per-workgroup (min,max); the level kernel folds them
 }

@@ -42,6 +42,7 @@ template <bool EF>
 __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int n_bit,
     int bits, int random_mode, uint64_t seed, float ef_scale, uint8_t *__restrict__ wire) {
+    resolve_seed(random_mode, seed);
     const int lane = threadIdx.x & 63;
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float s = (float)(1 << n_bit), smax = s - 1.0f;
@@ -113,6 +114,7 @@ template <bool EF, bool SEGLDS>
 __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int nseg, int64_t nbuckets, int n_bit,
     int random_mode, uint64_t seed, float ef_scale, uint8_t *__restrict__ wire) {
+    resolve_seed(random_mode, seed);
     __shared__ int64_t s_seg[SEGLDS ? QB_LDS_SEGS * 8 : 1];
     if (SEGLDS) {
         for (int i = threadIdx.x; i < nseg * 8; i += QB_THREADS) s_seg[i] = seg_table[i];
@@ -599,7 +601,8 @@ static int qsgd_compress_batched(const char *what, const int64_t *seg_table, con
                                  uint8_t *wire, void *stream) {
     if (nseg < 1 || nbuckets < 1 || n_bit < 1) return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes", what);
     if (!seg_table || !bucket_seg || !wire) return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
-    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE && random_mode != GQ_RANDOM_DEVICE_KEYED)
+    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE && random_mode != GQ_RANDOM_DEVICE_KEYED &&
+        random_mode != GQ_RANDOM_DEVICE_COUNTER)
         return fail(GQ_ERR_UNSUPPORTED, "%s: random_mode must be OFF, DEVICE or DEVICE_KEYED", what);
     const int bits = gq_qsgd_code_bits(n_bit, random_mode);
     if (!bits) return fail(GQ_ERR_UNSUPPORTED, "%s: n_bit %d has no packed format", what, n_bit);

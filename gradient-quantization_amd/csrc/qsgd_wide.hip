@@ -133,6 +133,7 @@ template <bool EF, int BITS>
 __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_quantise_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ chunk_seg, int64_t nchunks, int n_bit,
     int random_mode, uint64_t seed, const unsigned *__restrict__ norm_bits, uint8_t *__restrict__ wire) {
+    resolve_seed(random_mode, seed);
     const int lane = threadIdx.x & 63;
     const float s = (float)(1 << n_bit), smax = s - 1.0f;
     constexpr unsigned lmask = (1u << (BITS - 1)) - 1u;
@@ -326,7 +327,8 @@ GQ_INTERNAL int gqi_qsgd_wide_compress(const int64_t *seg_table, const int32_t *
     if (nseg < 1 || nchunks < 1 || n_bit < 1) return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched (wide): bad sizes");
     if (!seg_table || !chunk_seg || !norm_bits || !wire)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched (wide): null pointer");
-    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE && random_mode != GQ_RANDOM_DEVICE_KEYED)
+    if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE && random_mode != GQ_RANDOM_DEVICE_KEYED &&
+        random_mode != GQ_RANDOM_DEVICE_COUNTER)
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched (wide): random_mode must be OFF, DEVICE or DEVICE_KEYED");
     const int bits = gq_qsgd_code_bits(n_bit, random_mode);
     if (!bits) return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched (wide): n_bit %d has no packed format", n_bit);

@@ -131,12 +131,13 @@ class SyntheticClassification(object):
         return (SyntheticClassification(None, 0, 0, self.x.device, 0, self.x[:k], self.y[:k]),
                 SyntheticClassification(None, 0, 0, self.x.device, 0, self.x[k:], self.y[k:]))
 
-    def batches(self, batch, epoch_seed, rank=0, world=1, shuffle=True):
-        """As OnDiskClassification.batches: the short last batch is kept (the reference's loader has drop_last=False)."""
+    def batches(self, batch, epoch_seed, rank=0, world=1, shuffle=True, min_share=1):
+        """As OnDiskClassification.batches: the short last batch is kept (the reference's loader has drop_last=False) unless it
+        cannot give every rank `min_share` samples -- then it is dropped on all ranks alike."""
         from .datasets import rank_slices
         g = torch.Generator().manual_seed(epoch_seed)
         perm = (torch.randperm(self.n, generator=g) if shuffle else torch.arange(self.n)).to(self.x.device)
-        for lo, hi in rank_slices(self.n, batch, rank, world):
+        for lo, hi in rank_slices(self.n, batch, rank, world, min_share):
             idx = perm[lo:hi]
             yield self.x[idx], self.y[idx]
 

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GQ_LIB_PATH") or os.path.join(_PKG_DIR, "libgq_hsq.so
 
 GQ_MAX_PARTIALS = 1024
 GQ_FIXUP_PARTIALS = 256
-RANDOM_OFF, RANDOM_GIVEN, RANDOM_DEVICE, RANDOM_DEVICE_KEYED = 0, 1, 2, 3
+RANDOM_OFF, RANDOM_GIVEN, RANDOM_DEVICE, RANDOM_DEVICE_KEYED, RANDOM_DEVICE_COUNTER = 0, 1, 2, 3, 4
 ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFILTER_D16K256 = 0, 1, 2, 3, 4
 
 EXPORTS = [     # every entry point include/gq_hsq.h declares (tests/test_host_logic.py compares the two lists)
@@ -26,7 +26,7 @@ EXPORTS = [     # every entry point include/gq_hsq.h declares (tests/test_host_l
     "gq_axpy_inplace", "gq_sub", "gq_mean_rows", "gq_qsgd_compress", "gq_qsgd_decode_sum", "gq_qsgd_code_bits",
     "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched", "gq_pvq_encode",
 ]
-ABI_VERSION = 2
+ABI_VERSION = 3
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3      # GQ_ERR_* of include/gq_hsq.h
 
 _lib = None
@@ -57,7 +57,11 @@ def lib():
     return _lib
 
 
+CALLS = [0]      # entry-point calls that went through _check (each is one launch, or two for the wide QSGD compress): bench.py's `launches`
+
+
 def _check(rc, what):
+    CALLS[0] += 1
     if rc != 0:
         raise GQNativeError("%s failed (%d): %s" % (what, rc, lib().gq_last_error().decode()))
 
@@ -337,16 +341,25 @@ def hsq_batched_path(d, K, code_dtype, nseg=1):
     return int(lib().gq_hsq_batched_path(ctypes.byref(s)))
 
 
-def mean_rows(rows, out):
+def mean_rows(rows, out, rng_state=None):
     """out[i] = (+0 + rows[0, i] + ... + rows[R-1, i]) / R for a [R, n] float32 view whose rows may be strided (the dense
-    region of the gathered wire): torch.stack(...).mean(0) with the CPU's arithmetic."""
+    region of the gathered wire): torch.stack(...).mean(0) with the CPU's arithmetic.  rng_state (int64 [pairs, 2], the
+    { seed, step } words of RANDOM_DEVICE_COUNTER): the same launch adds one to every step word."""
     assert rows.dtype == torch.float32 and rows.dim() == 2 and rows.stride(1) == 1
     R, n = int(rows.shape[0]), int(rows.shape[1])
     stride = int(rows.stride(0)) * 4 if R > 1 else n * 4
     if rows.device.index != torch._C._cuda_getDevice():
         raise GQNativeError("rows are on %s but the current device is cuda:%d" % (rows.device, torch._C._cuda_getDevice()))
+    sp, pairs = (ctypes.c_void_p(rng_state.data_ptr()), int(rng_state.shape[0])) if rng_state is not None else (ctypes.c_void_p(0), 0)
     _check(lib().gq_mean_rows(ctypes.c_void_p(rows.data_ptr()), ctypes.c_int64(stride), ctypes.c_int(R), ctypes.c_int64(n),
-                              _dev_ptr(out, torch.float32, "out"), _stream()), "gq_mean_rows")
+                                   _dev_ptr(out, torch.float32, "out"), sp, ctypes.c_int(pairs), _stream()), "gq_mean_rows")
+
+
+def rng_step(rng_state):
+    """step += 1 in every { seed, step } pair of rng_state (int64 [pairs, 2]; RANDOM_DEVICE_COUNTER)."""
+    assert rng_state.dtype == torch.int64 and rng_state.dim() == 2 and rng_state.shape[1] == 2 and rng_state.is_contiguous()
+    _check(lib().gq_mean_rows(ctypes.c_void_p(0), ctypes.c_int64(0), ctypes.c_int(1), ctypes.c_int64(0), ctypes.c_void_p(0),
+                              ctypes.c_void_p(rng_state.data_ptr()), ctypes.c_int(int(rng_state.shape[0])), _stream()), "gq_mean_rows (step)")
 
 
 

@@ -376,6 +376,7 @@ class _BatchedBase(object):
         self._outs, self._out_views, self._out_turn = [None, None], [None, None], 0
         self._layout = table.clone()    # host copy of the segment table without pointers (decode needs no pointers)
         self._head = self._tail = None  # (first segment, launch descriptor) of the two parts of a split decode
+        self.rng_pairs = None           # this group's { seed, step } pairs, one per user slot (PSQuantizer._rng_pairs_for)
 
     def _out_buffer(self, device, advance=True):
         """Decode target + its per-tensor views.  Two buffers used in turn (the mean and its two-phase
@@ -436,6 +437,13 @@ class _BatchedBase(object):
             self._events[slot] = torch.cuda.Event()
         self._events[slot].record()
         return True
+
+    def _counter_seed(self, slot):
+        """GQ_RANDOM_DEVICE_COUNTER: the address of this group's { seed, step } pair of user slot `slot`, or None when the
+        quantizer gave the group no pairs (a codec used on its own) or not enough of them."""
+        if self.rng_pairs is None or not 0 <= slot < self.rng_pairs.shape[0]:
+            return None
+        return self.rng_pairs.data_ptr() + 16 * slot
 
     def _part(self, part, first_seg):
         """Launch descriptor of one part of a split decode (PSQuantizer.apply under GQ_EXCHANGE=split): "head" = the
@@ -517,6 +525,7 @@ class BatchedHSQ(_BatchedBase):
         self.n_bit = c0.n_bit                                  # 32: the projections travel as f32 (no level quantiser)
         self.random = bool(c0.compressed_norm and c0.norm_compressor.random)
         self.keyed = bool(self.random and c0.norm_compressor._rng == "keyed")   # draws keyed by (lb, ub): a launch that never changes
+        self.counter = bool(self.random and c0.norm_compressor._rng == "device")  # draws keyed by a device step word: likewise, and fresh every step
         self.reference_draws = self.codecs[0].uses_reference_draws()     # the reference's CPU draws, handed in per record
         self._r_index = self._r_flat = None
         self.codebook = c0._codebook_on(device)
@@ -572,7 +581,8 @@ class BatchedHSQ(_BatchedBase):
     def graphable(self):
         """True when nothing in this group's launches changes from record to record for fixed gradient addresses (no
         per-call seed, no host-side draws): the launches can be nodes of a HIP graph (PSQuantizer, gq_graph)."""
-        return (not self.random or self.keyed) and not self.reference_draws and self._batch.path != 0
+        return (not self.random or self.keyed or (self.counter and self.rng_pairs is not None)) and not self.reference_draws \
+            and self._batch.path != 0
 
     def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None):
         """Compress `tensors` (one per batched parameter, in order) into one user's wire.
@@ -599,6 +609,8 @@ class BatchedHSQ(_BatchedBase):
             mode, seed, r_flat = native.RANDOM_GIVEN, 0, self._given_draws(draws)
         elif self.keyed:
             mode, seed, r_flat = native.RANDOM_DEVICE_KEYED, (salt * 0x2545F4914F6CDD1D + 0x5851F42D4C957F2D) & (2 ** 63 - 1), None
+        elif self.counter and self._counter_seed(slot) is not None:
+            mode, seed, r_flat = native.RANDOM_DEVICE_COUNTER, self._counter_seed(slot), None
         elif self.random:
             mode, seed, r_flat = native.RANDOM_DEVICE, _next_seed() ^ salt, None
         else:
@@ -628,6 +640,7 @@ class BatchedQSGD(_BatchedBase):
         c0 = self.codecs[0]
         self.n_bit, self.bits, self.random = c0.c.bit, c0.bits, bool(c0.c.random)
         self.keyed = bool(self.random and c0.c._rng == "keyed")
+        self.counter = bool(self.random and c0.c._rng == "device")
         self.wide = c0.d > self.WIDE_MIN
         assert all(cd.bits == self.bits and cd.c.bit == self.n_bit and (cd.d > self.WIDE_MIN) == self.wide
                    for cd in self.codecs)
@@ -662,7 +675,7 @@ class BatchedQSGD(_BatchedBase):
     def graphable(self):
         """The compress launch takes a fresh seed per record when it rounds stochastically: only the deterministic form
         can be a HIP graph node (see BatchedHSQ.graphable)."""
-        return not self.random or self.keyed
+        return not self.random or self.keyed or (self.counter and self.rng_pairs is not None)
 
     def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None):
         """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place).
@@ -673,6 +686,8 @@ class BatchedQSGD(_BatchedBase):
             return False
         if self.keyed:      # gq_rng = "keyed": every bucket's draws keyed by its norm, the seed never changes
             mode, seed = native.RANDOM_DEVICE_KEYED, (salt * 0x2545F4914F6CDD1D + 0x5851F42D4C957F2D) & (2 ** 63 - 1)
+        elif self.counter and self._counter_seed(slot) is not None:      # gq_rng = "device": keyed by the slot's device step word
+            mode, seed = native.RANDOM_DEVICE_COUNTER, self._counter_seed(slot)
         else:
             mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
             seed = (_next_seed() ^ salt) if self.random else 0
@@ -766,7 +781,12 @@ class PSQuantizer(object):
         # is replayed as ONE HIP graph launch (the step is a launch-bound loop: ten launches and copies against ~85 us of
         # kernels).  Needs launches whose arguments do not change between records: deterministic rounding or gq_rng="keyed".
         g = getattr(args, "gq_graph", None)
-        self.use_graphs = bool(int(os.environ.get("GQ_GRAPH", "0"))) if g is None else bool(g)
+        self.use_graphs = bool(int(os.environ.get("GQ_GRAPH", "1"))) if g is None else bool(g)
+        # gq_rng = "device" (the default): the multi-tensor launches draw from streams keyed by { seed, step } pairs in device
+        # memory, one pair per (tensor group, user slot) (GQ_RANDOM_DEVICE_COUNTER); every aggregate adds one to the step
+        # words.  The launches' arguments never change -- they replay from a HIP graph -- and the draws are fresh every
+        # step whatever the gradients are (the reference draws per call: probabilistic_scalar_compressor.py:22-26).
+        self._rng_state = None
         self._rec_graphs = {}        # (slot, user, scale, gradient addresses) -> [sightings, graph or None, keep-alive]
         self._apply_graphs = {}      # (users recorded, wire, output-buffer turns) -> [sightings, graph or None, decoded list]
         # gq_rng = "reference": the reference draws r = torch.rand(M) per compressed tensor, in parameter order, from
@@ -818,6 +838,21 @@ class PSQuantizer(object):
     def wire_bytes_per_user(self):
         return self.user_bytes
 
+    RNG_SLOTS = 17      # user slots with a { seed, step } pair of their own per group (16 users + the two-phase re-compress)
+
+    def _rng_pairs_for(self, device, group_index):
+        """This group's rows of the quantizer's { seed, step } array (made on first use; seeds from torch's seed, the
+        rank, the group and the slot; steps start at 0)."""
+        if self._rng_state is None or self._rng_state.device != device:
+            world, rank = _dist_world(self.process_group)
+            n = max(1, len(self._groups)) * self.RNG_SLOTS
+            host = torch.zeros((n, 2), dtype=torch.int64)
+            base = _next_seed()
+            for i in range(n):
+                host[i, 0] = ((base ^ ((rank * 1000003 + i + 1) * 0x9E3779B97F4A7C15)) & (2 ** 63 - 1))
+            self._rng_state = host.to(device)
+        return self._rng_state[group_index * self.RNG_SLOTS:(group_index + 1) * self.RNG_SLOTS]
+
     def _draws(self, device):
         """One torch.rand for all reference-parity tensors of this record / two-phase apply -> (device tensor, offsets)."""
         if not self._draw_total:
@@ -853,8 +888,9 @@ class PSQuantizer(object):
         self._grad_objs = all_grads      # apply() rebinds .data of these very objects (161 fewer `param.grad` look-ups)
         # gq_graph: a record whose gradient addresses were seen before replays its device work as ONE graph launch
         graph_key = None
-        if (self.use_graphs and dev.type == "cuda" and not self._draw_total
-                and all(g[2] is not None and g[2].ready and g[2].graphable() for g in self._groups)):
+        if (self.use_graphs and dev.type == "cuda" and not self._draw_total and slot < self.RNG_SLOTS
+                and all(g[2] is not None and g[2].ready and g[2].graphable() for g in self._groups)
+                and not torch.cuda.is_current_stream_capturing()):      # (inside a caller's own capture the launches are simply recorded)
             graph_key = (slot, user, self._wire.data_ptr(), tuple(map(_DATA_PTR, all_grads)))
             if self.error_feedback:     # the residual buffers' addresses are in the header too (a per-tensor step replaces them)
                 graph_key += (scale, tuple(p.error[user].data_ptr() for p in self.parameters))
@@ -915,6 +951,8 @@ class PSQuantizer(object):
             cls, idxs, obj = grp
             if obj is None:
                 obj = grp[2] = cls(self.codecs, self.offsets, idxs, dev, self.capacity, self.user_bytes)
+                if getattr(obj, "counter", False) and len(self._groups) * self.RNG_SLOTS <= 256:
+                    obj.rng_pairs = self._rng_pairs_for(dev, self._groups.index(grp))
             pick = self._pick_group.get(id(grp))      # operator.itemgetter over the group's indices, built once
             if pick is None:
                 pick = self._pick_group[id(grp)] = operator.itemgetter(*idxs)     # (a group has at least two tensors)
@@ -1022,6 +1060,7 @@ class PSQuantizer(object):
         if split:
             pending.pop(0).wait()
             decode_part("tail")
+        step_rng = self._rng_state is not None and on_gpu     # one step of the device draws per aggregate (GQ_RANDOM_DEVICE_COUNTER)
         draws2 = self._draws(gathered.device) if two_phase else None     # the second phase compresses again: new draws
         sources = []        # the lists of output views this call's result is assembled from (persistent objects, see below)
         for gi, (cls, idxs, obj) in enumerate(groups):
@@ -1054,10 +1093,14 @@ class PSQuantizer(object):
             if plain and R == 1:
                 self._dense_mean[k].copy_(rows[0])      # the ring's hop: the payload as it is (a -0 stays -0)
             elif rows.device.type == "cuda":
-                native.mean_rows(rows, self._dense_mean[k])     # stack().mean(0) with the CPU's arithmetic (true division)
+                # stack().mean(0) with the CPU's arithmetic (true division); the same launch steps the draws' step words
+                native.mean_rows(rows, self._dense_mean[k], rng_state=self._rng_state if step_rng else None)
+                step_rng = False
             else:
                 torch.mean(rows, dim=0, out=self._dense_mean[k])   # stack().mean(0) of the reference, all at once
             sources.append((self.dense_idx, self._dense_views[k]))
+        if step_rng:        # no identity-compressed tensors to average (or the ring's plain hop): a launch of its own
+            native.rng_step(self._rng_state)
         if not single and not done:
             # everything came out of multi-tensor launches: the result is a fixed interleaving of a few PERSISTENT view lists
             # (two output buffers per group used in turn, their per-tensor views built once), so the parameter-ordered
@@ -1111,7 +1154,7 @@ class PSQuantizer(object):
         decoded = None
         graph_key = None
         if (self.use_graphs and len(pending) <= 1 and not self.two_phase and gathered.device.type == "cuda"
-                and all(g[2] is not None and g[2].ready for g in self._groups)):
+                and all(g[2] is not None and g[2].ready for g in self._groups) and not torch.cuda.is_current_stream_capturing()):
             # gq_graph: the decode-mean launches (+ the dense tensors' mean) of an apply that has been seen with these buffers
             # before replay as ONE graph launch; the two output buffers are used in turn, so two graphs alternate.  With
             # several ranks the exchange stays outside: its one transfer is waited for first (the split transport, whose

@@ -58,6 +58,12 @@ size_t gq_hsq_workspace_bytes(int64_t M);
                               tensor's (QSGD: bucket's) stream keyed by the bits of its (lb, ub) (QSGD: norm) besides
                               `seed`: new draws for every new gradient although `seed` stays what it was -- a
                               launch whose arguments never change (a HIP graph node)                              */
+#define GQ_RANDOM_DEVICE_COUNTER 4 /* gq_hsq_levels_batched / gq_qsgd_compress_batched only: as GQ_RANDOM_DEVICE, but `seed`
+                              is the ADDRESS of two device words { uint64 seed, uint64 step }: the launch's stream is keyed
+                              by both, and gq_mean_rows adds one to `step` once per aggregate (apply).  The
+                              launch's arguments never change (a HIP graph node), the draws do, whatever the gradients
+                              are, and a run is reproducible from the two words' initial values
+                              (probabilistic_scalar_compressor.py:22-26, qsgd_compressor.py:56-61 draw per call)          */
 
 /* level_bytes of the level / decode entry points: 1 | 2 | 4 = one uint8 / uint16 / int32 per level, 0 = the f32
  * projections travel instead of levels (--n-bit 32), and
@@ -74,7 +80,7 @@ size_t gq_hsq_workspace_bytes(int64_t M);
 #define GQ_LEVELS_PACKED6 (-6)
 
 /* Library / device identification. */
-int gq_abi_version(void);            /* 2 since the round-3 descriptor form of the multi-tensor entry points */
+int gq_abi_version(void);            /* 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words); 2: the round-3 descriptor form of the multi-tensor entry points */
 const char *gq_last_error(void);     /* text of the calling thread's last failure (the library's only per-thread state) */
 /* Fills CU count and the gcnArchName (e.g. "gfx950:sramecc+:xnack-") of `device`. */
 int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
@@ -259,7 +265,11 @@ int gq_sub(const float *grad, const float *decoded, float *err, int64_t n, void 
  * on the CPU.  (torch's GPU mean multiplies by 1/R and sums in another order: last-bit differences for R = 3, 5, 6, 7.)
  * rows_r = (const float *)((const char *)rows + r * row_stride_bytes).
  */
-int gq_mean_rows(const void *rows, int64_t row_stride_bytes, int R, int64_t n, float *out, void *stream);
+/* rng_state != NULL (GQ_RANDOM_DEVICE_COUNTER): the same launch adds one to the step words of rng_pairs (1 .. 256)
+ * consecutive { uint64 seed, uint64 step } pairs -- a caller keeps one pair per (tensor group, user slot) and steps them
+ * once per aggregate; with n == 0 that is all the call does. */
+int gq_mean_rows(const void *rows, int64_t row_stride_bytes, int R, int64_t n, float *out, uint64_t *rng_state, int rng_pairs,
+                 void *stream);
 
 /*
  * QSGD compress -- replaces qsgd_compressor.py:47-64.  `grad` is Mb buckets of d floats.

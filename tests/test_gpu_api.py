@@ -1304,6 +1304,10 @@ def test_bench_launches_its_own_ranks(extra):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["ranks_bit_identical"] is True
     assert d["exchange"]["ranks"] == 2 and d["exchange"]["backend"] == "gloo"
+    # the self-explaining part of a first multi-GPU run: ranks COUNTED by a collective, and both transports timed in every run
+    assert d["exchange"]["rccl_ranks"] == 2 and "rccl_version" in d["exchange"]
+    assert set(d["exchange"]["ms_by_transport"]) == {"allgather", "direct"}
+    assert all(isinstance(v, float) and v > 0 for v in d["exchange"]["ms_by_transport"].values()), d["exchange"]["ms_by_transport"]
     if extra[:1] == ["--exchange"]:
         assert d["exchange"]["transport"] == ("split" if extra[1] == "split" else d["exchange"]["transport"])
         if extra[1] == "auto":     # opt-in: every transport timed before the timed region, all ranks decide alike
@@ -1352,7 +1356,8 @@ def test_a_gradient_replaced_at_the_same_address_is_revalidated():
     assert not torch.equal(first[0], second[0])
 
 
-@pytest.mark.parametrize("kw", [dict(random=0), dict(random=1, gq_rng="keyed"), dict(random=0, ef=True, scale="0.5"),
+@pytest.mark.parametrize("kw", [dict(random=0), dict(random=1), dict(random=1, gq_rng="keyed"), dict(random=0, ef=True, scale="0.5"),
+                                dict(qsgd=True, c_dim=128, n_bit=2, random=1), dict(random=1, ef=True, scale="0.5"),
                                 dict(random=1, gq_rng="keyed", gq_wire_levels="packed6", n_bit=5),
                                 dict(qsgd=True, c_dim=128, n_bit=2, random=1, gq_rng="keyed"),
                                 dict(qsgd=True, c_dim=0, n_bit=1, random=1, gq_rng="keyed", ef=True, scale="0.5")])
@@ -1373,6 +1378,8 @@ def test_record_replayed_from_a_hip_graph_equals_the_eager_launches(kw):
     order = [0, 1, 0, 1, 0, 1, 2, 2, 2]
 
     def run(graph):
+        from gq_amd import compressors
+        compressors._seed_counter[0] = 0      # gq_rng = "device": both runs start from the same { seed, step } words
         params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
         q = Quantizer(Comp, params, make_args(num_users=1, gq_graph=graph, **kw))
         outs = []
@@ -1397,6 +1404,48 @@ def test_record_replayed_from_a_hip_graph_equals_the_eager_launches(kw):
     if kw.get("ef"):
         for pg, pe in zip(qg.parameters, qe.parameters):
             assert torch.equal(pg.error[0], pe.error[0])
+
+
+def test_device_counter_draws_are_fresh_every_step_reproducible_and_unbiased():
+    """gq_rng = "device" on the multi-tensor launches (GQ_RANDOM_DEVICE_COUNTER): the launch arguments never change, the
+    stream is keyed by a { seed, step } pair in device memory that every aggregate steps.  The SAME gradient recorded in
+    two consecutive steps is rounded with different draws (the keyed variant of round 3 repeated them: ADVICE r3), a second
+    quantizer built from the same torch seed reproduces the sequence, and the rounding is unbiased."""
+    from gq_amd import compressors
+    from gq_amd.compressors import NearestNeighborCompressor
+    from gq_amd.quantizers import Quantizer
+    dev = torch.device("cuda:0")
+    shapes = [(40000, 16), (30000, 16), (10,)]
+    torch.manual_seed(22)
+    g = [torch.randn(s, device=dev) * 1e-2 for s in shapes]
+
+    def run(random, steps=3):
+        compressors._seed_counter[0] = 0
+        params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
+        q = Quantizer(NearestNeighborCompressor, params, make_args(num_users=1, random=random))
+        out = []
+        for _ in range(steps):
+            for p, t in zip(params, g):
+                p.grad = t.clone()
+            q.record(0, epoch=1)
+            torch.cuda.synchronize()
+            grp = q._groups[0][2]
+            out.append([q._wire[0, q.offsets[i] + cd.levels_off:q.offsets[i] + cd.levels_off + cd.M].clone().to(torch.int32)
+                        for i, cd in zip(grp.idxs, grp.codecs)])
+            q.apply()
+        return q, out
+    q1, a = run(1)
+    q2, b = run(1)
+    _, t = run(0, steps=1)
+    assert q1._groups[0][2].counter and q1._rng_state is not None and int(q1._rng_state[0, 1]) == 3     # three aggregates, three steps
+    for s1, s2 in zip(a, b):
+        for x, y in zip(s1, s2):
+            assert torch.equal(x, y)                                  # same torch seed: the same sequence of draws
+    for x0, x1, x2, w in zip(a[0], a[1], a[2], t[0]):
+        assert (x0 != x1).float().mean() > 0.2 and (x1 != x2).float().mean() > 0.2     # the same gradient, new draws every step
+        for x in (x0, x1, x2):
+            d = (x - w).float()
+            assert bool(((d == 0) | (d == 1)).all()) and 0.47 < float(d.mean()) < 0.53
 
 
 def test_keyed_draws_are_new_for_every_gradient_and_round_without_bias():

@@ -58,7 +58,7 @@ def test_library_exports_every_declared_symbol():
     assert set(native.EXPORTS) == set(names), "the binding's list and the header differ"
     assert len(names) <= 25, "the ABI was collapsed to <= 25 entry points in round 3 (descriptor structs instead of variants)"
     lib.gq_abi_version.restype = ctypes.c_int
-    assert lib.gq_abi_version() == native.ABI_VERSION == 2
+    assert lib.gq_abi_version() == native.ABI_VERSION == 3
     # nothing but the declared entry points leaves the library (the per-variant launchers are hidden)
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True).stdout

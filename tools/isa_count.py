@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--list", action="store_true", help="print the per-mnemonic table too")
     ap.add_argument("--extra", default="", help="extra compiler flags, e.g. -DPF_GROUP8=1")
     ap.add_argument("--asm", default=None, help="an existing .s instead of compiling")
+    ap.add_argument("--json", default=None, help="also write the counts as JSON (profiles/r04_encode_isa_floor.json: bench.py's issue_floor_ms)")
     a = ap.parse_args()
     txt = open(a.asm).read() if a.asm else build_asm(a.file, a.extra.split())
     name, lines, meta = kernel_body(txt, a.kernel)
@@ -133,6 +134,18 @@ def main():
           % (valu, cls["half"], cls["full"], cls["swap"], cls["mfma"], cls["lds"], cls["vmem"], cls["salu"]))
     print("issue time per tile and wave at two waves per SIMD: %.0f ns VALU + %.0f ns MFMA issue = %.0f ns"
           % (ns - cls["mfma"] * NS["mfma"], cls["mfma"] * NS["mfma"], ns))
+    if a.json:
+        import json
+        json.dump({"kernel": name, "vgprs": meta["vgprs"], "scratch": meta["scratch"], "valu": valu, "valu_half_slot": cls["half"],
+                   "valu_full_slot": cls["full"], "permlane_swaps": cls["swap"], "mfma": cls["mfma"], "lds": cls["lds"],
+                   "vmem": cls["vmem"], "salu": cls["salu"], "subvectors_per_tile": 64,
+                   "issue_cycles_per_tile": 4 * valu + 8 * cls["mfma"],
+                   "note": "instructions of the steady-state tile loop per wave and 64-subvector tile, from the compiler's ISA "
+                           "(tools/isa_count.py; the second pass and the exact scans, nested loops, are not in it; ~40 of the VALU "
+                           "instructions sit in branches most tiles skip); issue_cycles_per_tile = 4 cycles per VALU "
+                           "instruction + 8 per MFMA (MI355X_MICROARCH.md, vector-instruction issue cost): a SIMD issues for its "
+                           "two waves in turn, so the launch cannot take less than tiles x issue_cycles / SIMDs / clock"},
+                  open(a.json, "w"), indent=1)
     if a.list:
         for (c, op), k in sorted(per.items(), key=lambda x: (-x[1], x[0])):
             if c in ("half", "full", "swap", "mfma", "lds", "vmem"):
