@@ -93,7 +93,8 @@ def build_clock_lib(objs=None, verbose=False, source=None, out=None):
     if objs is None:
         objs = [os.path.join(objdir, f.replace(".hip", ".o")) for f in SOURCES]
     src = source or os.path.join(CSRC, "hsq_encode_pf.hip")
-    obj = os.path.join(objdir, "hsq_encode_pf_stamps.o" if out is None else os.path.basename(out) + ".o")
+    obj = os.path.join(objdir, "stamps", "hsq_encode_pf_stamps.o" if out is None else os.path.basename(out) + ".o")   # (a directory of its own: build/*.o are the product's objects)
+    os.makedirs(os.path.dirname(obj), exist_ok=True)
     flags = [f for f in FLAGS if f != "-shared"] + EXTRA.get("hsq_encode_pf.hip", [])
     cmd = [hipcc()] + flags + ["-DGQ_PF_STAMPS", "-c", src, "-o", obj]
     if verbose:

@@ -24,6 +24,7 @@ static int check_batch(const gq_hsq_batch *b, const char *what) {
         return fail(GQ_ERR_UNSUPPORTED, "%s: the multi-tensor kernels take GQ_LEVELS_PACKED6 for d = 16, K = 256, byte codes, n_bit <= 6", what);
     if (!b->seg_table || !b->tile_seg || !b->codebook) return fail(GQ_ERR_INVALID_ARG, "%s: null pointer in the descriptor", what);
     if (b->profile_slot >= GQ_PROFILE_SLOTS) return fail(GQ_ERR_INVALID_ARG, "%s: profile_slot %d", what, b->profile_slot);
+    if (b->ndense < 0 || (b->ndense > 0 && !b->dense_table)) return fail(GQ_ERR_INVALID_ARG, "%s: ndense = %d without a dense_table", what, b->ndense);
     return GQ_OK;
 }
 
@@ -96,15 +97,15 @@ GQ_API int gq_hsq_levels_batched(const gq_hsq_batch *b, uint8_t *wire, int rando
     if (gq::byte_wire(b)) {
         if (write_error && b->d != 16)
             return gqi_hsq_levels_batched_ef_d(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->u_flat, b->seg_minmax, b->n_bit,
-                                               random_mode, seed, r_flat, b->codebook, b->d, wire, stream);
+                                               random_mode, seed, r_flat, b->codebook, b->d, wire, b->dense_table, b->ndense, stream);
         return gqi_hsq_levels_batched_d16(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->u_flat, b->seg_minmax, b->n_bit,
                                           random_mode, seed, r_flat, (write_error && b->d == 16) ? b->codebook : nullptr,
-                                          b->level_bytes == GQ_LEVELS_PACKED6, wire, stream);
+                                          b->level_bytes == GQ_LEVELS_PACKED6, wire, b->dense_table, b->ndense, stream);
     }
     if (b->level_bytes == GQ_LEVELS_PACKED6)
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched: GQ_LEVELS_PACKED6 needs d = 16, K = 256, n_bit <= 6");
     rc = gqi_hsq_levels_batched_any(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->u_flat, b->seg_minmax, b->n_bit,
-                                    random_mode, seed, r_flat, b->level_bytes, wire, stream);
+                                    random_mode, seed, r_flat, b->level_bytes, wire, b->dense_table, b->ndense, stream);
     if (rc != GQ_OK || !write_error) return rc;
     return gqi_hsq_error_batched_any(b->seg_table, b->tile_seg, b->nseg, b->ntiles, wire, b->codebook, b->d, b->K,
                                      b->code_bytes, b->level_bytes, b->n_bit, stream);
@@ -139,6 +140,7 @@ static int check_qsgd(const gq_qsgd_batch *b, const char *what) {
     if (b->nseg < 1 || b->nitems < 1 || b->n_bit < 1) return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes", what);
     if (!b->seg_table || !b->item_seg) return fail(GQ_ERR_INVALID_ARG, "%s: null pointer in the descriptor", what);
     if (b->wide && !b->norm_bits) return fail(GQ_ERR_INVALID_ARG, "%s: wide buckets need norm_bits", what);
+    if (b->ndense < 0 || (b->ndense > 0 && !b->dense_table)) return fail(GQ_ERR_INVALID_ARG, "%s: ndense = %d without a dense_table", what, b->ndense);
     return GQ_OK;
 }
 }  // namespace gq
@@ -155,9 +157,9 @@ GQ_API int gq_qsgd_compress_batched(const gq_qsgd_batch *b, uint8_t *wire, int r
     const float scale = ef ? ef_scale : 0.0f;
     if (b->wide)
         return gqi_qsgd_wide_compress(b->seg_table, b->item_seg, b->nseg, b->nitems, b->n_bit, random_mode, seed, ef, scale,
-                                      b->norm_bits, wire, stream);
+                                      b->norm_bits, wire, b->dense_table, b->ndense, stream);
     return gqi_qsgd_compress_batched(b->seg_table, b->item_seg, b->nseg, b->nitems, b->n_bit, random_mode, seed, ef, scale, wire,
-                                     stream);
+                                     b->dense_table, b->ndense, stream);
 }
 
 GQ_API int gq_qsgd_decode_sum_batched(const gq_qsgd_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,

@@ -186,7 +186,20 @@ __device__ __forceinline__ void bump_rng_counter(uint64_t *state, int npairs) { 
     if (state && blockIdx.x == 0 && (int)threadIdx.x < npairs) state[2 * threadIdx.x + 1] += 1;
 }
 
-__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
+// The tensors that travel uncompressed (IdenticalCompressor, ps_quantizer.py:18-19: <= 1000 elements each) ride in the same
+// launch as the level quantiser / the QSGD compress: workgroup b copies tensors b, b + grid, ... into their place in the
+// wire.  dense_table int64[ndense][3] = { source (float *), byte offset in ONE user's wire, elements }.
+__device__ __forceinline__ void copy_dense_segments(const int64_t *__restrict__ dense_table, int ndense, uint8_t *__restrict__ wire) {
+    typedef const float __attribute__((address_space(1))) *gcf_ptr;
+    for (int t = blockIdx.x; t < ndense; t += gridDim.x) {
+        const gcf_ptr src = (gcf_ptr)(uintptr_t)dense_table[3 * t];
+        float *dst = reinterpret_cast<float *>(wire + dense_table[3 * t + 1]);
+        const int64_t n = dense_table[3 * t + 2];
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+__device__ __forceinline__ uint32_t uniform_bits(uint64_t seed, uint64_t idx) {
     uint32_t h = (uint32_t)idx + (uint32_t)seed * 0x9E3779B1u;
     h ^= h >> 16;
     h *= 0x7FEB352Du;
@@ -196,7 +209,21 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
     h += (uint32_t)(seed >> 32) ^ ((uint32_t)(idx >> 32) * 0x85EBCA77u);
     h *= 0xC2B2AE3Du;
     h ^= h >> 15;
-    return (float)(h >> 8) * 5.9604644775390625e-08f;  // 2^-24
+    return h;
+}
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
+    return (float)(uniform_bits(seed, idx) >> 8) * 5.9604644775390625e-08f;  // 2^-24
+}
+// TWO 16-bit draws per hash: elements 2i and 2i + 1 share the word of index i (the QSGD bucket kernels visit them
+// together, so the hash -- a quarter of the 4-bit compress's instructions -- is computed once per pair).  A level is rounded
+// up with probability ceil(p 2^16) / 2^16 instead of p: a bias below 2^-16 of one level (the 24-bit draws': 2^-24), far
+// under the quantisation step; GQ_RANDOM_GIVEN (the reference's own draws) is not touched.
+__device__ __forceinline__ float uniform16(uint64_t seed, uint64_t idx) {
+#ifdef GQ_QSGD_DRAWS24   // A/B builds only (tools/list_step_ab.py): one 24-bit draw per element, as rounds 1-3
+    return uniform01(seed, idx);
+#endif
+    const uint32_t h = uniform_bits(seed, idx >> 1);
+    return (float)((idx & 1) ? (h >> 16) : (h & 0xFFFFu)) * 1.52587890625e-05f;   // 2^-16
 }
 
 }  // namespace gq

@@ -25,14 +25,14 @@ GQ_INTERNAL int gqi_hsq_encode_batched_any(const int64_t *seg_table, const int32
 GQ_INTERNAL int gqi_hsq_levels_batched_d16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                            const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
                                            uint64_t seed, const float *r_flat, const float *ef_codebook, int packed6,
-                                           uint8_t *wire, void *stream);
+                                           uint8_t *wire, const int64_t *dense_table, int ndense, void *stream);
 GQ_INTERNAL int gqi_hsq_levels_batched_ef_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                             const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                                            uint64_t seed, const float *r_flat, const float *codebook, int d, uint8_t *wire,
+                                            uint64_t seed, const float *r_flat, const float *codebook, int d, uint8_t *wire, const int64_t *dense_table, int ndense,
                                             void *stream);
 GQ_INTERNAL int gqi_hsq_levels_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                            const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                                           uint64_t seed, const float *r_flat, int level_bytes, uint8_t *wire, void *stream);
+                                           uint64_t seed, const float *r_flat, int level_bytes, uint8_t *wire, const int64_t *dense_table, int ndense, void *stream);
 GQ_INTERNAL int gqi_hsq_error_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                           const uint8_t *wire, const float *codebook, int d, int K, int code_bytes,
                                           int level_bytes, int n_bit, void *stream);
@@ -52,14 +52,14 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_any(const int64_t *seg_table, const i
 
 // QSGD on the packed wire (qsgd_batched.hip, qsgd_wide.hip)
 GQ_INTERNAL int gqi_qsgd_compress_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
-                                          int n_bit, int random_mode, uint64_t seed, int ef, float ef_scale, uint8_t *wire,
+                                          int n_bit, int random_mode, uint64_t seed, int ef, float ef_scale, uint8_t *wire, const int64_t *dense_table, int ndense,
                                           void *stream);
 GQ_INTERNAL int gqi_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
                                             int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                             float *out, int plain, void *stream);
 GQ_INTERNAL int gqi_qsgd_wide_compress(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks,
                                        int n_bit, int random_mode, uint64_t seed, int ef, float ef_scale,
-                                       uint32_t *norm_bits, uint8_t *wire, void *stream);
+                                       uint32_t *norm_bits, uint8_t *wire, const int64_t *dense_table, int ndense, void *stream);
 GQ_INTERNAL int gqi_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks,
                                          int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                          float *out, int plain, void *stream);

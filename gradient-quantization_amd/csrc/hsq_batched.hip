@@ -26,8 +26,9 @@ template <typename LevelT>
 __global__ __launch_bounds__(BT_THREADS) void hsq_levels_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
-    uint64_t seed, const float *__restrict__ r_flat, uint8_t *__restrict__ wire) {
+    uint64_t seed, const float *__restrict__ r_flat, uint8_t *__restrict__ wire, const int64_t *__restrict__ dense_table, int ndense) {
     resolve_seed(random_mode, seed);
+    copy_dense_segments(dense_table, ndense, wire);
     const float s = (float)(1 << n_bit), smax = s - 1.0f;
     const int64_t total4 = ntiles * 16;
     const int64_t stride = (int64_t)gridDim.x * BT_THREADS;
@@ -98,8 +99,9 @@ template <bool PACKED6>
 __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
-    uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire) {
+    uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire, const int64_t *__restrict__ dense_table, int ndense) {
     resolve_seed(random_mode, seed);
+    copy_dense_segments(dense_table, ndense, wire);
     // rows 20 floats apart: an odd number of 16-byte units spreads the random-row gathers over the banks
     __shared__ __attribute__((aligned(16))) float s_cb[256 * 20];
     for (int i = threadIdx.x; i < 256 * 16 / 4; i += BT_THREADS)
@@ -606,8 +608,9 @@ template <int D>
 __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_d_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
-    uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire) {
+    uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire, const int64_t *__restrict__ dense_table, int ndense) {
     resolve_seed(random_mode, seed);
+    copy_dense_segments(dense_table, ndense, wire);
     constexpr int UPS = D / 4;
     constexpr int RS = ((D / 4) & 1) ? D : D + 4;
     __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];
@@ -842,7 +845,7 @@ static inline int64_t bt_grid(int64_t items) {
 GQ_INTERNAL int gqi_hsq_levels_batched_d16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                            const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
                                            uint64_t seed, const float *r_flat, const float *ef_codebook, int packed6,
-                                           uint8_t *wire, void *stream) {
+                                           uint8_t *wire, const int64_t *dense_table, int ndense, void *stream) {
     // ef_codebook != NULL: additionally error = v - decode(wire) for the rows that have an error buffer (d = 16)
     if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > 8)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: bad sizes");
@@ -856,16 +859,16 @@ GQ_INTERNAL int gqi_hsq_levels_batched_d16(const int64_t *seg_table, const int32
     hipStream_t st = gq::as_stream(stream);
     if (ef_codebook && packed6)
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_kernel<true>, dim3((unsigned)gq::bt_grid(ntiles * 256)), block, 0, st,
-                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, wire);
+                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, wire, dense_table, ndense);
     else if (ef_codebook)
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_kernel<false>, dim3((unsigned)gq::bt_grid(ntiles * 256)), block, 0, st,
-                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, wire);
+                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, wire, dense_table, ndense);
     else if (packed6)
         hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<gq::Packed6>, dim3((unsigned)gq::bt_grid(ntiles * 16)), block, 0, st,
-                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, wire);
+                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, wire, dense_table, ndense);
     else
         hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<uint8_t>, dim3((unsigned)gq::bt_grid(ntiles * 16)), block, 0, st,
-                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, wire);
+                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, wire, dense_table, ndense);
     GQ_CHECK_LAUNCH("gq_hsq_levels_batched");
     return GQ_OK;
 }
@@ -925,7 +928,7 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_d(const int64_t *seg_table, const int
 // error-feedback level kernel of d = 8 / 32 (K = 256): levels + error = v - decode(wire) in one launch
 GQ_INTERNAL int gqi_hsq_levels_batched_ef_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                             const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                                            uint64_t seed, const float *r_flat, const float *codebook, int d, uint8_t *wire,
+                                            uint64_t seed, const float *r_flat, const float *codebook, int d, uint8_t *wire, const int64_t *dense_table, int ndense,
                                             void *stream) {
     if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > 8)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: bad sizes");
@@ -938,11 +941,11 @@ GQ_INTERNAL int gqi_hsq_levels_batched_ef_d(const int64_t *seg_table, const int3
     if (d == 8) {
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_d_kernel<8>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 2)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
-                           n_bit, random_mode, seed, r_flat, codebook, wire);
+                           n_bit, random_mode, seed, r_flat, codebook, wire, dense_table, ndense);
     } else if (d == 32) {
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_d_kernel<32>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 8)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
-                           n_bit, random_mode, seed, r_flat, codebook, wire);
+                           n_bit, random_mode, seed, r_flat, codebook, wire, dense_table, ndense);
     } else {
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched: the fused error-feedback form serves d = 8, 16 or 32 (K = 256)");
     }
@@ -953,7 +956,7 @@ GQ_INTERNAL int gqi_hsq_levels_batched_ef_d(const int64_t *seg_table, const int3
 // any level width (1 / 2 / 4 bytes, or 0: the f32 projections travel); independent of (d, K)
 GQ_INTERNAL int gqi_hsq_levels_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                            const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                                           uint64_t seed, const float *r_flat, int level_bytes, uint8_t *wire, void *stream) {
+                                           uint64_t seed, const float *r_flat, int level_bytes, uint8_t *wire, const int64_t *dense_table, int ndense, void *stream) {
     if (nseg < 1 || ntiles < 1 || n_bit < 1 || (n_bit > 30 && level_bytes != 0))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: bad sizes");
     if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !wire)
@@ -963,7 +966,7 @@ GQ_INTERNAL int gqi_hsq_levels_batched_any(const int64_t *seg_table, const int32
     if (level_bytes == 0) {   // n_bit == 32 (nearest_neighbor_compressor.py:14,75-76): u itself is the payload
         hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<float>, dim3((unsigned)gq::bt_grid(ntiles * 16)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
-                           1, GQ_RANDOM_OFF, (uint64_t)0, (const float *)nullptr, wire);
+                           1, GQ_RANDOM_OFF, (uint64_t)0, (const float *)nullptr, wire, dense_table, ndense);
         GQ_CHECK_LAUNCH("gq_hsq_levels_batched");
         return GQ_OK;
     }
@@ -975,13 +978,13 @@ GQ_INTERNAL int gqi_hsq_levels_batched_any(const int64_t *seg_table, const int32
     hipStream_t st = gq::as_stream(stream);
     if (level_bytes == 1)
         hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<uint8_t>, grid, block, 0, st, seg_table, tile_seg, ntiles, u_flat,
-                           seg_minmax, n_bit, random_mode, seed, r_flat, wire);
+                           seg_minmax, n_bit, random_mode, seed, r_flat, wire, dense_table, ndense);
     else if (level_bytes == 2)
         hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<int16_t>, grid, block, 0, st, seg_table, tile_seg, ntiles, u_flat,
-                           seg_minmax, n_bit, random_mode, seed, r_flat, wire);
+                           seg_minmax, n_bit, random_mode, seed, r_flat, wire, dense_table, ndense);
     else if (level_bytes == 4)
         hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<int32_t>, grid, block, 0, st, seg_table, tile_seg, ntiles, u_flat,
-                           seg_minmax, n_bit, random_mode, seed, r_flat, wire);
+                           seg_minmax, n_bit, random_mode, seed, r_flat, wire, dense_table, ndense);
     else
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: level_bytes must be 0, 1, 2 or 4");
     GQ_CHECK_LAUNCH("gq_hsq_levels_batched");

@@ -27,7 +27,7 @@ __device__ __forceinline__ unsigned qsgd_code(float v, float norm, float s, floa
         l = (unsigned)(int)c;
         if (random_mode >= GQ_RANDOM_DEVICE) {   // DEVICE, or DEVICE_KEYED with the bucket's keyed seed handed in
             const float prob = x - (float)l;
-            l += (prob > uniform01(seed, gidx)) ? 1u : 0u;
+            l += (prob > uniform16(seed, gidx)) ? 1u : 0u;   // two 16-bit draws per hash (gq_common.hpp)
         }
     }
     return l | ((v > 0.0f ? 1u : 0u) << (bits - 1));
@@ -41,8 +41,9 @@ __device__ __forceinline__ unsigned qsgd_code(float v, float norm, float s, floa
 template <bool EF>
 __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int n_bit,
-    int bits, int random_mode, uint64_t seed, float ef_scale, uint8_t *__restrict__ wire) {
+    int bits, int random_mode, uint64_t seed, float ef_scale, uint8_t *__restrict__ wire, const int64_t *__restrict__ dense_table, int ndense) {
     resolve_seed(random_mode, seed);
+    copy_dense_segments(dense_table, ndense, wire);
     const int lane = threadIdx.x & 63;
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float s = (float)(1 << n_bit), smax = s - 1.0f;
@@ -113,8 +114,9 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
 template <bool EF, bool SEGLDS>
 __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int nseg, int64_t nbuckets, int n_bit,
-    int random_mode, uint64_t seed, float ef_scale, uint8_t *__restrict__ wire) {
+    int random_mode, uint64_t seed, float ef_scale, uint8_t *__restrict__ wire, const int64_t *__restrict__ dense_table, int ndense) {
     resolve_seed(random_mode, seed);
+    copy_dense_segments(dense_table, ndense, wire);
     __shared__ int64_t s_seg[SEGLDS ? QB_LDS_SEGS * 8 : 1];
     if (SEGLDS) {
         for (int i = threadIdx.x; i < nseg * 8; i += QB_THREADS) s_seg[i] = seg_table[i];
@@ -598,7 +600,7 @@ namespace gq {
 template <bool EF>
 static int qsgd_compress_batched(const char *what, const int64_t *seg_table, const int32_t *bucket_seg, int nseg,
                                  int64_t nbuckets, int n_bit, int random_mode, uint64_t seed, float ef_scale,
-                                 uint8_t *wire, void *stream) {
+                                 uint8_t *wire, const int64_t *dense_table, int ndense, void *stream) {
     if (nseg < 1 || nbuckets < 1 || n_bit < 1) return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes", what);
     if (!seg_table || !bucket_seg || !wire) return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
     if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE && random_mode != GQ_RANDOM_DEVICE_KEYED &&
@@ -609,15 +611,15 @@ static int qsgd_compress_batched(const char *what, const int64_t *seg_table, con
     if (bits == 4 && nseg <= QB_LDS_SEGS) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched4_kernel<EF, true>), dim3((unsigned)qb_grid((nbuckets + 3) / 4)),
                            dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nseg, nbuckets, n_bit,
-                           random_mode, seed, ef_scale, wire);
+                           random_mode, seed, ef_scale, wire, dense_table, ndense);
     } else if (bits == 4) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched4_kernel<EF, false>), dim3((unsigned)qb_grid((nbuckets + 3) / 4)),
                            dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nseg, nbuckets, n_bit,
-                           random_mode, seed, ef_scale, wire);
+                           random_mode, seed, ef_scale, wire, dense_table, ndense);
     } else {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched_kernel<EF>), dim3((unsigned)qb_grid(nbuckets)),
                            dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, bits,
-                           random_mode, seed, ef_scale, wire);
+                           random_mode, seed, ef_scale, wire, dense_table, ndense);
     }
     GQ_CHECK_LAUNCH(what);
     return GQ_OK;
@@ -625,13 +627,13 @@ static int qsgd_compress_batched(const char *what, const int64_t *seg_table, con
 }  // namespace gq
 
 GQ_INTERNAL int gqi_qsgd_compress_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
-                                          int n_bit, int random_mode, uint64_t seed, int ef, float ef_scale, uint8_t *wire,
+                                          int n_bit, int random_mode, uint64_t seed, int ef, float ef_scale, uint8_t *wire, const int64_t *dense_table, int ndense,
                                           void *stream) {
     if (ef)
         return gq::qsgd_compress_batched<true>("gq_qsgd_compress_batched", seg_table, bucket_seg, nseg, nbuckets, n_bit,
-                                               random_mode, seed, ef_scale, wire, stream);
+                                               random_mode, seed, ef_scale, wire, dense_table, ndense, stream);
     return gq::qsgd_compress_batched<false>("gq_qsgd_compress_batched", seg_table, bucket_seg, nseg, nbuckets, n_bit,
-                                            random_mode, seed, 0.0f, wire, stream);
+                                            random_mode, seed, 0.0f, wire, dense_table, ndense, stream);
 }
 
 GQ_INTERNAL int gqi_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,

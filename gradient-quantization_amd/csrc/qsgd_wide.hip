@@ -123,7 +123,7 @@ __device__ __forceinline__ unsigned wide_code(float v, float norm, float s, floa
         l = (unsigned)(int)c;
         if (random_mode >= GQ_RANDOM_DEVICE) {   // DEVICE, or DEVICE_KEYED with the keyed seed handed in
             const float prob = x - (float)l;
-            l += (prob > uniform01(seed, gidx)) ? 1u : 0u;
+            l += (prob > uniform16(seed, gidx)) ? 1u : 0u;   // two 16-bit draws per hash (gq_common.hpp)
         }
     }
     return l | ((v > 0.0f ? 1u : 0u) << (bits - 1));
@@ -132,8 +132,9 @@ __device__ __forceinline__ unsigned wide_code(float v, float norm, float s, floa
 template <bool EF, int BITS>
 __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_quantise_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ chunk_seg, int64_t nchunks, int n_bit,
-    int random_mode, uint64_t seed, const unsigned *__restrict__ norm_bits, uint8_t *__restrict__ wire) {
+    int random_mode, uint64_t seed, const unsigned *__restrict__ norm_bits, uint8_t *__restrict__ wire, const int64_t *__restrict__ dense_table, int ndense) {
     resolve_seed(random_mode, seed);
+    copy_dense_segments(dense_table, ndense, wire);
     const int lane = threadIdx.x & 63;
     const float s = (float)(1 << n_bit), smax = s - 1.0f;
     constexpr unsigned lmask = (1u << (BITS - 1)) - 1u;
@@ -323,7 +324,7 @@ static inline int64_t qw_grid(int64_t nchunks) {
 
 GQ_INTERNAL int gqi_qsgd_wide_compress(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks,
                                  int n_bit, int random_mode, uint64_t seed, int ef, float ef_scale,
-                                 uint32_t *norm_bits, uint8_t *wire, void *stream) {
+                                 uint32_t *norm_bits, uint8_t *wire, const int64_t *dense_table, int ndense, void *stream) {
     if (nseg < 1 || nchunks < 1 || n_bit < 1) return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched (wide): bad sizes");
     if (!seg_table || !chunk_seg || !norm_bits || !wire)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched (wide): null pointer");
@@ -342,7 +343,7 @@ GQ_INTERNAL int gqi_qsgd_wide_compress(const int64_t *seg_table, const int32_t *
                            norm_bits);
 #define GQ_QW_LAUNCH(EFV, BITSV)                                                                                        \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gq::qsgd_wide_quantise_kernel<EFV, BITSV>), grid, block, 0, st, seg_table, chunk_seg, \
-                       nchunks, n_bit, random_mode, seed, norm_bits, wire)
+                       nchunks, n_bit, random_mode, seed, norm_bits, wire, dense_table, ndense)
     if (ef && bits == 4) GQ_QW_LAUNCH(true, 4);
     else if (ef && bits == 8) GQ_QW_LAUNCH(true, 8);
     else if (ef) GQ_QW_LAUNCH(true, 16);

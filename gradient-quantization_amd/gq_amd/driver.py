@@ -168,8 +168,10 @@ def build_parser():
     p.add_argument('--log-interval', type=int, default=8, help='iterations between JSON log lines')
     p.add_argument('--logfile', type=str, default=None)
     p.add_argument('--gq-rng', type=str, default=None, choices=[None, 'device', 'reference', 'keyed'])
-    p.add_argument('--gq-graph', action='store_true', default=None,
-                   help='replay the quantizer step from HIP graphs per set of gradient addresses (needs --random 0 or --gq-rng keyed)')
+    p.add_argument('--gq-graph', dest='gq_graph', action='store_true', default=None,
+                   help='replay the quantizer step from HIP graphs per set of gradient addresses (the default, also $GQ_GRAPH=1; '
+                        'with --gq-rng reference the draws come from the host and the launches stay eager)')
+    p.add_argument('--no-gq-graph', dest='gq_graph', action='store_false', help='eager launches')
     p.add_argument('--data', type=str, default='synthetic', choices=['synthetic', 'disk'],
                    help="disk: MNIST idx files / CIFAR-10 pickles under --data-root (no torchvision)")
     p.add_argument('--data-root', type=str, default='./data')

@@ -265,7 +265,8 @@ class _HSQBatchStruct(ctypes.Structure):      # gq_hsq_batch (include/gq_hsq.h)
                 ("code_bytes", ctypes.c_int32), ("level_bytes", ctypes.c_int32), ("n_bit", ctypes.c_int32),
                 ("nseg", ctypes.c_int32), ("profile_slot", ctypes.c_int32), ("ntiles", ctypes.c_int64),
                 ("seg_table", ctypes.c_void_p), ("tile_seg", ctypes.c_void_p), ("codebook", ctypes.c_void_p),
-                ("u_flat", ctypes.c_void_p), ("seg_minmax", ctypes.c_void_p), ("workspace", ctypes.c_void_p)]
+                ("u_flat", ctypes.c_void_p), ("seg_minmax", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+                ("dense_table", ctypes.c_void_p), ("ndense", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 _NAN = float("nan")
@@ -291,9 +292,16 @@ class HSQBatch(object):
                                  int(n_bit), int(nseg), -1, int(ntiles), _dev_ptr(seg_table, torch.int64, "seg_table").value,
                                  _dev_ptr(tile_seg, torch.int32, "tile_seg").value,
                                  _dev_ptr(codebook, torch.float32, "codebook").value, opt(u_flat, torch.float32, "u_flat"),
-                                 opt(seg_minmax, torch.int32, "seg_minmax"), opt(workspace, torch.float32, "workspace"))
+                                 opt(seg_minmax, torch.int32, "seg_minmax"), opt(workspace, torch.float32, "workspace"), None, 0, 0)
         self.ref = ctypes.byref(self.s)
         self.path = int(self.L.gq_hsq_batched_path(self.ref))
+
+    def set_dense(self, dense_table, ndense):
+        """dense_table (int64 [ndense, 3] on the device: source pointer, byte offset in one user's wire, elements): the level
+        launch also copies the uncompressed tensors into the wire.  None: no copies."""
+        self.keep_dense = dense_table
+        self.s.dense_table = _dev_ptr(dense_table, torch.int64, "dense_table").value if dense_table is not None else None
+        self.s.ndense = int(ndense) if dense_table is not None else 0
 
     def part(self, seg_table, tile_seg, nseg, ntiles):
         """The same configuration over another table (the head / tail of a split decode)."""
@@ -337,7 +345,7 @@ class HSQBatch(object):
 def hsq_batched_path(d, K, code_dtype, nseg=1):
     """Which multi-tensor encode serves (d, K, code width, number of tensors): BATCH_PREFILTER / PAGED / EXACT or 0."""
     s = _HSQBatchStruct(ctypes.sizeof(_HSQBatchStruct), int(d), int(K), _CODE_BYTES[code_dtype], 1, 6, int(nseg), -1, 1, 1, 1, 1,
-                        None, None, None)      # the path depends on the shape only; the (non-null) pointers are not read
+                        None, None, None, None, 0, 0)      # the path depends on the shape only; the (non-null) pointers are not read
     return int(lib().gq_hsq_batched_path(ctypes.byref(s)))
 
 
@@ -366,7 +374,8 @@ def rng_step(rng_state):
 class _QSGDBatchStruct(ctypes.Structure):     # gq_qsgd_batch (include/gq_hsq.h)
     _fields_ = [("struct_bytes", ctypes.c_uint32), ("n_bit", ctypes.c_int32), ("bits", ctypes.c_int32),
                 ("wide", ctypes.c_int32), ("nseg", ctypes.c_int32), ("reserved", ctypes.c_int32), ("nitems", ctypes.c_int64),
-                ("seg_table", ctypes.c_void_p), ("item_seg", ctypes.c_void_p), ("norm_bits", ctypes.c_void_p)]
+                ("seg_table", ctypes.c_void_p), ("item_seg", ctypes.c_void_p), ("norm_bits", ctypes.c_void_p),
+                ("dense_table", ctypes.c_void_p), ("ndense", ctypes.c_int32), ("reserved2", ctypes.c_int32)]
 
 
 class QSGDBatch(object):
@@ -378,8 +387,14 @@ class QSGDBatch(object):
         self.s = _QSGDBatchStruct(ctypes.sizeof(_QSGDBatchStruct), int(n_bit), int(bits), 1 if wide else 0, int(nseg), 0,
                                   int(nitems), _dev_ptr(seg_table, torch.int64, "seg_table").value,
                                   _dev_ptr(item_seg, torch.int32, "item_seg").value,
-                                  _dev_ptr(norm_bits, torch.int32, "norm_bits").value if norm_bits is not None else None)
+                                  _dev_ptr(norm_bits, torch.int32, "norm_bits").value if norm_bits is not None else None, None, 0, 0)
         self.ref = ctypes.byref(self.s)
+
+    def set_dense(self, dense_table, ndense):
+        """As HSQBatch.set_dense: the compress launch also copies the uncompressed tensors into the wire."""
+        self.keep_dense = dense_table
+        self.s.dense_table = _dev_ptr(dense_table, torch.int64, "dense_table").value if dense_table is not None else None
+        self.s.ndense = int(ndense) if dense_table is not None else 0
 
     def part(self, seg_table, item_seg, nseg, nitems):
         return QSGDBatch(seg_table, item_seg, nseg, nitems, self.s.n_bit, self.s.bits, bool(self.s.wide), self.keep[2])

@@ -358,14 +358,25 @@ class _BatchedBase(object):
     pinned H2D copy; a ring of pinned buffers (one per user slot + one) keeps a copy in flight from
     being overwritten."""
 
-    def _setup(self, table, extra, device, slots, user_bytes):
+    def _setup(self, table, extra, device, slots, user_bytes, dense=None):
+        """dense: [(byte offset in one user's wire, elements), ...] of the identity-compressed tensors this group's compress
+        launch also copies into the wire (the quantizer gives them to its first group), or None."""
         self.nseg = table.shape[0]
         self.device = device
         self.user_bytes = user_bytes
         self._table_words = self.nseg * 8
         host = torch.cat([table.view(-1), extra.view(-1)]) if extra is not None else table.view(-1).clone()
+        self.ndense = len(dense) if dense else 0
+        self._dense_at = int(host.numel())      # the dense table's first word in the header
+        if self.ndense:
+            dt = torch.zeros((self.ndense, 3), dtype=torch.int64)
+            for k, (off, numel) in enumerate(dense):
+                dt[k, 1], dt[k, 2] = off, numel
+            host = torch.cat([host, dt.view(-1)])
         self._host = [host.clone().pin_memory() for _ in range(slots + 1)]
         self._host_np = [h[:self._table_words].view(self.nseg, 8).numpy() for h in self._host]   # views of the pinned tables
+        self._host_dense_np = [h[self._dense_at:].view(self.ndense, 3).numpy() for h in self._host] if self.ndense else None
+        self._last_dptrs = None
         self._zeros = [0] * self.nseg
         self._resets = extra is not None    # the header also carries per-step reset values (min / max accumulators)
         self._last_ptrs = self._last_eptrs = None
@@ -394,7 +405,10 @@ class _BatchedBase(object):
             self._out_views[k] = [out[o:o + cd.numel].view(cd.shape) for o, cd in zip(self.out_off, self.codecs)]
         return self._outs[k], self._out_views[k]
 
-    def _upload(self, tensors, slot, align, errs=None):
+    def dense_table_dev(self):
+        return self._dev[self._dense_at:].view(self.ndense, 3) if self.ndense else None
+
+    def _upload(self, tensors, slot, align, errs=None, dense=None):
         """Column 0 of the segment table <- the tensors' device pointers; column 7 <- the error
         buffers' (error-feedback kernels) or 0.  False if any tensor cannot be addressed that way.
         A header that also carries the reset values of the kernels' min / max accumulators (HSQ, wide-bucket QSGD)
@@ -402,12 +416,14 @@ class _BatchedBase(object):
         step to step) the pinned copy is sent as it is, without checking and rewriting the table."""
         ptrs = list(map(_DATA_PTR, tensors))
         eptrs = list(map(_DATA_PTR, errs)) if errs is not None else self._zeros
+        dptrs = list(map(_DATA_PTR, dense)) if dense is not None else None
         # the fast path still checks what the kernels assume about every tensor: a gradient replaced by a strided view or
         # another dtype AT THE SAME ADDRESS (channels_last, the caching allocator handing the block out again) must not
         # ride on the last upload's validation.  (map() over the C-level accessors: ~6 us for 76 tensors; a Python-level
         # list of (dtype, is_contiguous) tuples cost 20.)
-        if (self.ready and ptrs == self._last_ptrs and eptrs == self._last_eptrs
-                and all(map(_IS_CONTIGUOUS, tensors)) and set(map(_DTYPE_OF, tensors)) == _F32_ONLY):
+        if (self.ready and ptrs == self._last_ptrs and eptrs == self._last_eptrs and dptrs == self._last_dptrs
+                and all(map(_IS_CONTIGUOUS, tensors)) and set(map(_DTYPE_OF, tensors)) == _F32_ONLY
+                and (dense is None or (all(map(_IS_CONTIGUOUS, dense)) and set(map(_DTYPE_OF, dense)) == _F32_ONLY))):
             if not self._resets:
                 return True     # nothing but the table in this header, and the device copy still holds it
             self._dev.copy_(self._host[self._last_slot], non_blocking=True)     # unchanged since its last copy
@@ -416,12 +432,14 @@ class _BatchedBase(object):
         # (the same facts for a new set of pointers, from the C-level accessors: a Python loop over
         # `g.device != ... or g.dtype != ...` cost 40 us for 76 tensors, most of it building torch.device objects)
         dev_index = self.device.index if self.device.index is not None else torch._C._cuda_getDevice()
-        for ts, ps in ((tensors, ptrs), (errs or (), eptrs if errs is not None else ())):
+        for ts, ps, al in ((tensors, ptrs, align), (errs or (), eptrs if errs is not None else (), align), (dense or (), dptrs or (), 4)):
             if not ts:
                 continue
             if (not all(map(_IS_CONTIGUOUS, ts)) or set(map(_DTYPE_OF, ts)) != _F32_ONLY
-                    or set(map(_GET_DEVICE, ts)) != {dev_index} or any(p % align for p in ps)):
+                    or set(map(_GET_DEVICE, ts)) != {dev_index} or any(p % al for p in ps)):
                 return False
+        if dense is not None and len(dense) != self.ndense:
+            return False
         if len(eptrs) != len(ptrs):
             return False
         slot %= len(self._host)
@@ -430,9 +448,11 @@ class _BatchedBase(object):
         tab = self._host_np[slot]
         tab[:, 0] = ptrs
         tab[:, 7] = eptrs
+        if dptrs is not None:
+            self._host_dense_np[slot][:, 0] = dptrs
         self._dev.copy_(self._host[slot], non_blocking=True)
         self.ready = True
-        self._last_ptrs, self._last_eptrs, self._last_slot = ptrs, eptrs, slot
+        self._last_ptrs, self._last_eptrs, self._last_slot, self._last_dptrs = ptrs, eptrs, slot, dptrs
         if self._events[slot] is None:
             self._events[slot] = torch.cuda.Event()
         self._events[slot].record()
@@ -482,7 +502,7 @@ class _BatchedBase(object):
     def upload_layout(self):
         """Device header with the layout columns only (no tensor pointers): enough for decode_mean,
         which a ring rank may need before it has encoded anything."""
-        self._last_ptrs = self._last_eptrs = None
+        self._last_ptrs = self._last_eptrs = self._last_dptrs = None
         self._dev.copy_(self._host[0], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -518,7 +538,7 @@ class BatchedHSQ(_BatchedBase):
     def group_key(codec):
         return (codec.c.dim, codec.c.K, _esize(codec.code_dtype), _esize(codec.level_dtype), int(codec.c.n_bit), int(codec.packed6))
 
-    def __init__(self, codecs, offsets, idxs, device, slots, user_bytes):
+    def __init__(self, codecs, offsets, idxs, device, slots, user_bytes, dense=None):
         self.idxs = list(idxs)
         self.codecs = [codecs[i] for i in self.idxs]
         c0 = self.codecs[0].c
@@ -550,7 +570,7 @@ class BatchedHSQ(_BatchedBase):
         self._item_seg, self._nitems = self.tile_seg, tile
         init = torch.empty((nseg, 2), dtype=torch.int32)
         init[:, 0], init[:, 1] = -1, 0            # 0xFFFFFFFF / 0: identities of the mapped min / max
-        self._setup(table, init.view(torch.int64), device, slots, user_bytes)
+        self._setup(table, init.view(torch.int64), device, slots, user_bytes, dense)
         self.u_flat = torch.empty(self.ntiles * 64, dtype=torch.float32, device=device)
         cd0 = self.codecs[0]
         self.code_dtype, self.level_dtype = cd0.code_dtype, cd0.level_dtype
@@ -560,7 +580,7 @@ class BatchedHSQ(_BatchedBase):
         # d = 8 / 16 / 32), the same with the pages of a larger codebook resident, or exact scoring for every other shape
         self._batch = native.HSQBatch(self._dev[:self._table_words], self.tile_seg, self.nseg, self.ntiles, self.codebook,
                                       self.code_dtype, cd0.wire_level_kind(), self.n_bit, self.u_flat,
-                                      self._dev[self._table_words:].view(torch.int32), self.ws)
+                                      self._dev[self._table_words:self._dense_at].view(torch.int32), self.ws)
         self.profile_slot = -1      # measurement hook (bench.py): the NEXT encode's dispatch is timed into this slot
 
     def _given_draws(self, draws):
@@ -584,8 +604,9 @@ class BatchedHSQ(_BatchedBase):
         return (not self.random or self.keyed or (self.counter and self.rng_pairs is not None)) and not self.reference_draws \
             and self._batch.path != 0
 
-    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None):
+    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None, dense=None):
         """Compress `tensors` (one per batched parameter, in order) into one user's wire.
+        dense: the identity-compressed tensors (the quantizer's, in its order) that the level launch also copies into the wire.
         Returns False (nothing launched) when a tensor is not a contiguous, 16-byte aligned f32
         tensor on this device: the caller then takes the per-tensor path for this step.
         With `errs` (error feedback, ps_quantizer.py:34-39) the same launches also do
@@ -598,8 +619,9 @@ class BatchedHSQ(_BatchedBase):
             return False
         if graph_header is not None:
             self._dev.copy_(graph_header, non_blocking=True)
-        elif not self._upload(tensors, slot, self.align, errs):
+        elif not self._upload(tensors, slot, self.align, errs, dense):
             return False
+        self._batch.set_dense(self.dense_table_dev() if dense is not None else None, self.ndense)
         ef = ef_scale if errs is not None else None
         self._batch.encode(wire_user, ef, self.profile_slot)
         self.profile_slot = -1
@@ -634,7 +656,7 @@ class BatchedQSGD(_BatchedBase):
     def group_key(codec):
         return (codec.bits, codec.c.bit, int(codec.d > BatchedQSGD.WIDE_MIN))
 
-    def __init__(self, codecs, offsets, idxs, device, slots, user_bytes):
+    def __init__(self, codecs, offsets, idxs, device, slots, user_bytes, dense=None):
         self.idxs = list(idxs)
         self.codecs = [codecs[i] for i in self.idxs]
         c0 = self.codecs[0]
@@ -667,23 +689,24 @@ class BatchedQSGD(_BatchedBase):
         self._item_seg, self._nitems = self.bucket_seg, item
         # wide: max |v| per bucket is folded into words that the per-step header resets to zero
         extra = torch.zeros((word + 1) // 2, dtype=torch.int64) if self.wide else None
-        self._setup(table, extra, device, slots, user_bytes)
+        self._setup(table, extra, device, slots, user_bytes, dense)
         self._batch = native.QSGDBatch(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets, self.n_bit,
                                        self.bits, self.wide,
-                                       self._dev[self._table_words:].view(torch.int32) if self.wide else None)
+                                       self._dev[self._table_words:self._dense_at].view(torch.int32) if self.wide else None)
 
     def graphable(self):
         """The compress launch takes a fresh seed per record when it rounds stochastically: only the deterministic form
         can be a HIP graph node (see BatchedHSQ.graphable)."""
         return not self.random or self.keyed or (self.counter and self.rng_pairs is not None)
 
-    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None):
+    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None, dense=None):
         """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place).
-        graph_header: see BatchedHSQ.encode."""
+        graph_header, dense: see BatchedHSQ.encode."""
         if graph_header is not None:
             self._dev.copy_(graph_header, non_blocking=True)
-        elif not self._upload(tensors, slot, 8, errs):
+        elif not self._upload(tensors, slot, 8, errs, dense):
             return False
+        self._batch.set_dense(self.dense_table_dev() if dense is not None else None, self.ndense)
         if self.keyed:      # gq_rng = "keyed": every bucket's draws keyed by its norm, the seed never changes
             mode, seed = native.RANDOM_DEVICE_KEYED, (salt * 0x2545F4914F6CDD1D + 0x5851F42D4C957F2D) & (2 ** 63 - 1)
         elif self.counter and self._counter_seed(slot) is not None:      # gq_rng = "device": keyed by the slot's device step word
@@ -950,7 +973,10 @@ class PSQuantizer(object):
         for grp in (self._groups if dev.type == "cuda" else []):
             cls, idxs, obj = grp
             if obj is None:
-                obj = grp[2] = cls(self.codecs, self.offsets, idxs, dev, self.capacity, self.user_bytes)
+                # the first group's compress launch also copies the identity-compressed tensors into the wire
+                dense = ([(self.offsets[i], self.codecs[i].numel) for i in self.dense_idx]
+                         if (grp is self._groups[0] and len(self.dense_idx) >= 2) else None)
+                obj = grp[2] = cls(self.codecs, self.offsets, idxs, dev, self.capacity, self.user_bytes, dense=dense)
                 if getattr(obj, "counter", False) and len(self._groups) * self.RNG_SLOTS <= 256:
                     obj.rng_pairs = self._rng_pairs_for(dev, self._groups.index(grp))
             pick = self._pick_group.get(id(grp))      # operator.itemgetter over the group's indices, built once
@@ -962,9 +988,12 @@ class PSQuantizer(object):
             errs = [self.parameters[i].error[user] for i in idxs] if self.error_feedback else None
             hdr = headers[len(skip_groups)] if headers is not None else None
             skip_groups.append(obj)
-            if obj.encode(grads, wire, slot, salt, errs, scale, draws=draws, graph_header=hdr):
+            dense = list(self._pick_dense(all_grads)) if obj.ndense else None
+            if obj.encode(grads, wire, slot, salt, errs, scale, draws=draws, graph_header=hdr, dense=dense):
                 skip.update(idxs)
-        if len(self.dense_idx) >= 2:
+                if dense is not None:
+                    skip.update(self.dense_idx)      # (copied by that launch)
+        if len(self.dense_idx) >= 2 and self.dense_idx[0] not in skip:
             # all small tensors with one concatenation straight into the packed wire region.  Under
             # error feedback their residual is identically zero (decoded == grad), so nothing else to do.
             key = (self._wire.data_ptr(), slot)

@@ -222,6 +222,12 @@ typedef struct gq_hsq_batch {
     float *u_flat;
     uint32_t *seg_minmax;
     float *workspace;
+    /* The tensors that travel uncompressed (IdenticalCompressor: ps_quantizer.py:18-19, <= 1000 elements each) ride in the
+     * level launch: dense_table int64[ndense][3] = { source (float *, device), byte offset in ONE user's wire (a multiple
+     * of 4), elements }; gq_hsq_levels_batched copies every source to wire + offset.  ndense == 0: nothing to copy. */
+    const int64_t *dense_table;
+    int32_t ndense;
+    int32_t reserved;
 } gq_hsq_batch;
 int gq_hsq_batched_path(const gq_hsq_batch *b);
 
@@ -324,6 +330,9 @@ typedef struct gq_qsgd_batch {
     const int64_t *seg_table;
     const int32_t *item_seg;
     uint32_t *norm_bits;       /* wide only */
+    const int64_t *dense_table; /* as gq_hsq_batch.dense_table: copied by gq_qsgd_compress_batched's launch */
+    int32_t ndense;
+    int32_t reserved2;
 } gq_qsgd_batch;
 int gq_qsgd_code_bits(int n_bit, int random_mode);
 int gq_qsgd_compress_batched(const gq_qsgd_batch *b, uint8_t *wire, int random_mode, uint64_t seed, float ef_scale,

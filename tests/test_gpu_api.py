@@ -1494,7 +1494,7 @@ def test_training_driver_with_graph_replay_learns_like_the_eager_run():
     _, qg, hist_g = train(build_parser().parse_args(base + ["--gq-graph", "--gq-rng", "keyed"]))
     assert hist_g[-1]["loss"] < 0.7 * hist_g[0]["loss"]
     assert any(e[1] is not None for e in qg._rec_graphs.values()), "no record was ever replayed from a graph"
-    _, qe, hist_e = train(build_parser().parse_args(base + ["--gq-rng", "keyed"]))
+    _, qe, hist_e = train(build_parser().parse_args(base + ["--no-gq-graph", "--gq-rng", "keyed"]))
     assert not qe._rec_graphs
     assert [h["loss"] for h in hist_g] == [h["loss"] for h in hist_e]
 
