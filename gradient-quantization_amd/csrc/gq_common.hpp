@@ -214,16 +214,5 @@ __device__ __forceinline__ uint32_t uniform_bits(uint64_t seed, uint64_t idx) {
 __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
     return (float)(uniform_bits(seed, idx) >> 8) * 5.9604644775390625e-08f;  // 2^-24
 }
-// TWO 16-bit draws per hash: elements 2i and 2i + 1 share the word of index i (the QSGD bucket kernels visit them
-// together, so the hash -- a quarter of the 4-bit compress's instructions -- is computed once per pair).  A level is rounded
-// up with probability ceil(p 2^16) / 2^16 instead of p: a bias below 2^-16 of one level (the 24-bit draws': 2^-24), far
-// under the quantisation step; GQ_RANDOM_GIVEN (the reference's own draws) is not touched.
-__device__ __forceinline__ float uniform16(uint64_t seed, uint64_t idx) {
-#ifdef GQ_QSGD_DRAWS24   // A/B builds only (tools/list_step_ab.py): one 24-bit draw per element, as rounds 1-3
-    return uniform01(seed, idx);
-#endif
-    const uint32_t h = uniform_bits(seed, idx >> 1);
-    return (float)((idx & 1) ? (h >> 16) : (h & 0xFFFFu)) * 1.52587890625e-05f;   // 2^-16
-}
 
 }  // namespace gq

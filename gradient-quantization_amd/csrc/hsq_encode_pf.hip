@@ -83,7 +83,10 @@ namespace gq {
 // the waves of a workgroup share their tiles through an LDS counter (see the kernel).
 constexpr int PF_WAVES = 8;
 constexpr int PF_THREADS = PF_WAVES * 64;
-constexpr int PF_TAIL = 4;   // swept 2..12 in round 1 (52.3 us at 4..8, 54 at 2 and 12); again at the end of round 3: 3-4 40.35, 6 40.48, 8 40.6, 10 40.8 us
+#ifndef GQ_PF_TAIL
+#define GQ_PF_TAIL 4
+#endif
+constexpr int PF_TAIL = GQ_PF_TAIL;   // swept 2..12 in round 1 (52.3 us at 4..8, 54 at 2 and 12); again at the end of round 3: 3-4 40.35, 6 40.48, 8 40.6, 10 40.8 us
 constexpr int PF_LDS_SEGS = 384;            // batched form: tensors whose segment records are kept in LDS (24 KiB)
 constexpr int QUAD_STRIDE = 68;             // LDS floats per GROUP of 4 codewords (64 used, 272 B = 17 x 16 B: random groups spread over the banks)
 constexpr int PF_QCAP = 64;                 // deferred exact scans a wave can hold (a ring in LDS; a tile adds at most 64)

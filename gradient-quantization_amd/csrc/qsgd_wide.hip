@@ -123,7 +123,7 @@ __device__ __forceinline__ unsigned wide_code(float v, float norm, float s, floa
         l = (unsigned)(int)c;
         if (random_mode >= GQ_RANDOM_DEVICE) {   // DEVICE, or DEVICE_KEYED with the keyed seed handed in
             const float prob = x - (float)l;
-            l += (prob > uniform16(seed, gidx)) ? 1u : 0u;   // two 16-bit draws per hash (gq_common.hpp)
+            l += (prob > uniform01(seed, gidx)) ? 1u : 0u;
         }
     }
     return l | ((v > 0.0f ? 1u : 0u) << (bits - 1));
