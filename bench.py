@@ -300,6 +300,8 @@ def in_kernel_clock():
     """(clock in GHz or None, how): a child run of this script on the stamped twin of the library (see clock_child)."""
     if not os.path.exists(CLOCK_LIB):
         return None, "gradient-quantization_amd/libgq_hsq_clock.so was not built"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is being profiled: the stamped twin's launches would be counted as the product kernel's"
     try:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--clock-child"], env=dict(os.environ, GQ_LIB_PATH=CLOCK_LIB),
                              capture_output=True, text=True, timeout=120).stdout.strip().splitlines()

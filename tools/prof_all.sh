@@ -1,29 +1,29 @@
 #!/bin/bash
-# Everything profiles/ holds for one round, in one gpurun call:  gpurun --timeout 2400 -- 'bash tools/prof_all.sh r03'
+# Everything profiles/ holds for one round, in one gpurun call:  gpurun --timeout 2400 -- 'bash tools/prof_all.sh r04'
 # -> gpurun_out/<tag>/{stats (rocprofv3 --kernel-trace --stats of bench.py), bench*.json, pmc_show.txt, stamps.txt, ...};
-# copy what is to be judged into profiles/.  Needs tools/exp/libgq_stamp.so / libgq_pstamp.so / libgq_pfdstamp.so
-# (python tools/stamp_build.py; python tools/stamp_prologue.py; python tools/stamp_pfd.py) for the stamp sections.
-TAG=${1:-r03}
+# copy what is to be judged into profiles/.  Needs tools/exp/libgq_stamp.so / libgq_pfdstamp.so
+# (python tools/stamp_build.py; python tools/stamp_pfd.py) for the stamp sections.
+TAG=${1:-r04}
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 mkdir -p $O
 # 1. the driver's command under the kernel tracer (the profiler's own program is python3 itself)
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --traffic off > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> /dev/null)
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_resnet50 -- python3 $GRAFT_REPO_ROOT/bench.py --workload resnet50 --no-graph --steps 100 --warmup 20 --traffic off > $GRAFT_REPO_ROOT/$O/bench_resnet50_under_rocprof.json 2> /dev/null)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-workloads --traffic off > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> /dev/null)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_resnet50 -- python3 $GRAFT_REPO_ROOT/bench.py --workload resnet50 --steps 200 --warmup 20 --traffic off > $GRAFT_REPO_ROOT/$O/bench_resnet50_under_rocprof.json 2> /dev/null)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_qsgd -- python3 $GRAFT_REPO_ROOT/bench.py --workload qsgd --steps 200 --warmup 20 --traffic off > $GRAFT_REPO_ROOT/$O/bench_qsgd_under_rocprof.json 2> /dev/null)
 # 2. the default lines (live PMC traffic, CPU baseline) of the three workloads
 python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --workload resnet50 --no-graph > $O/bench_resnet50.json 2> $O/bench_resnet50.err
-python bench.py --workload qsgd --no-graph > $O/bench_qsgd.json 2> /dev/null
-python bench.py --workload resnet50 --traffic off > $O/bench_resnet50_graph.json 2> /dev/null
-python bench.py --workload qsgd --traffic off > $O/bench_qsgd_graph.json 2> /dev/null
+python bench.py --workload resnet50 > $O/bench_resnet50.json 2> $O/bench_resnet50.err
+python bench.py --workload qsgd > $O/bench_qsgd.json 2> /dev/null
+python bench.py --workload resnet50 --no-graph --traffic off > $O/bench_resnet50_eager.json 2> /dev/null
+python bench.py --workload qsgd --no-graph --traffic off > $O/bench_qsgd_eager.json 2> /dev/null
 python bench.py --wire-levels packed6 --no-cpu-baseline --traffic off > $O/bench_packed6.json 2> /dev/null
-GQ_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --exchange auto > $O/bench_2ranks_gloo.json 2> /dev/null
+GQ_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_2ranks_gloo.json 2> /dev/null
 # 3. SQ counters of the encode (three passes) and the in-kernel stamps
 bash tools/pmc_any.sh $TAG tools/exp_time.py
 bash tools/pmc_overlap.sh $TAG tools/exp_time.py
 python tools/pmc_show.py $TAG > $O/pmc_show.txt 2>&1
 GQ_LIB_PATH=tools/exp/libgq_stamp.so python tools/stamp_read.py > $O/stamps.txt 2>&1
-GQ_LIB_PATH=tools/exp/libgq_pstamp.so python tools/stamp_prologue.py read > $O/prologue_stamps.txt 2>&1
 # 4. side measurements
 python tools/decode_r.py 1 2 4 8 16 > $O/decode_r.txt 2>&1
 python tools/hsq_batched_r.py > $O/hsq_batched_r.txt 2>&1

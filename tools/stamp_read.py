@@ -58,3 +58,13 @@ print("workgroup ends (last wave, scans included): mean %.1f us, percentiles 10/
 print("inside a workgroup: last wave - mean wave = %.2f us on average (max %.2f); first wave to stop - last = %.2f us on average"
       % ((wg_end - wg_mean).mean(), (wg_end - wg_mean).max(), (wg_end - wend.min(1)).mean()))
 print("across workgroups: latest workgroup end - mean workgroup end = %.2f us; mean workgroup end - mean wave end = %.2f us" % (wg_end.max() - wg_end.mean(), wg_end.mean() - wend.mean()))
+# is the spread across workgroups systematic?  ends by XCD (index % 8) and by dispatch order (index // 32)
+bx = np.arange(256) % 8
+print("workgroup end by XCD (index %% 8):      " + "  ".join("%d: %.1f" % (x, wg_end[bx == x].mean()) for x in range(8)))
+print("workgroup end by dispatch octile:       " + "  ".join("%d: %.1f" % (o, wg_end[(np.arange(256) // 32) == o].mean()) for o in range(8)))
+pro = ((rt0 - entry) / 100).reshape(-1, 8).mean(1)
+tl = tiles_w.reshape(-1, 8).sum(1)
+print("prologue by dispatch octile (us):       " + "  ".join("%d: %.2f" % (o, pro[(np.arange(256) // 32) == o].mean()) for o in range(8)))
+print("correlation of a workgroup's end with: its prologue %.2f, its entry time %.2f, its tiles %.2f, its second-pass entries %.2f"
+      % (np.corrcoef(wg_end, pro)[0, 1], np.corrcoef(wg_end, ((entry - entry.min()) / 100).reshape(-1, 8).mean(1))[0, 1],
+         np.corrcoef(wg_end, tl)[0, 1], np.corrcoef(wg_end, drained.reshape(-1, 8).sum(1))[0, 1]))
