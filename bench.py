@@ -67,10 +67,11 @@ def parse_args():
     ap.add_argument("--random", type=int, default=0, choices=[0, 2],
                     help="hsq: 0 = deterministic levels (the bit-exact configuration); 2 = on-device stochastic rounding")
     ap.add_argument("--exchange", default=os.environ.get("GQ_EXCHANGE", "allgather"),
-                    choices=["auto", "allgather", "direct", "split"],
+                    choices=["auto", "allgather", "direct", "split", "pipelined"],
                     help="N > 1: how the wire travels.  Default: the in-place all-gather (the one collective every backend has); "
                          "auto = time all three before the timed region and keep the fastest (opt-in: direct / split have not "
-                         "met RCCL with more than one rank yet)")
+                         "met RCCL with more than one rank yet); pipelined (opt-in, never picked by auto): the codes travel "
+                         "under the level kernel (hsq) / the wire travels and is decoded in $GQ_PIPELINE_CHUNKS ranges (lists)")
     ap.add_argument("--wire-levels", default=os.environ.get("GQ_WIRE_LEVELS", "auto"), choices=["auto", "bytes", "packed6"],
                     help="how the 6-bit levels travel: a byte each, or four per three bytes (12.5 %% less wire; same decode bits); "
                          "auto = packed6 when there is an exchange (N > 1, all-gather / direct), bytes at N = 1")
@@ -288,7 +289,7 @@ def clock_child():
         for _ in range(200):
             native.hsq_encode(g, cb, codes, u, ws)
         torch.cuda.synchronize()
-    first = 2 * native.GQ_MAX_PARTIALS + 4
+    first = native.WS_LOG_FIRST
     raw = ws[first + M - 65536:first + M - 65536 + 256 * 8 * 12 * 2].contiguous().view(torch.int64).view(-1, 12).cpu().numpy().astype(np.float64)
     cyc, real, tiles = raw[:, :6].sum(1), (raw[:, 8] - raw[:, 7]) / 100.0, raw[:, 9]      # cycles, us, tiles per wave
     ok = (real > 0) & (tiles > 0)
@@ -482,7 +483,7 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     grads = [torch.randn(SIZE, device=dev, generator=gen) for _ in range(3)]
     M = SIZE // C_DIM
     if args.wire_levels == "auto":
-        args.wire_levels = "packed6" if (world > 1 and args.exchange in ("allgather", "direct")) else "bytes"
+        args.wire_levels = "packed6" if (world > 1 and args.exchange in ("allgather", "direct", "pipelined")) else "bytes"
     packed6 = args.wire_levels == "packed6" and args.random == 0      # top level 63 (n_bit 6 without stochastic rounding)
     if packed6 and args.exchange in ("split", "auto"):
         sys.exit("bench.py: --wire-levels packed6 goes with --exchange allgather or direct (the split arrangement keeps byte levels)")
@@ -520,6 +521,17 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
             native.hsq_decode_sum_packed(buf, swire.MB, cb, N_BIT, out[swire.MA * C_DIM:], world,
                                          swire.codes_off + swire.MA, swire.levels_b_off, swire.lbub_off)
 
+    def step_pipelined(g, profile_slot=-1):
+        """The codes are final when the encode has run, one launch before the levels: their transfer is queued behind the
+        encode and travels under the level kernel; the levels (+ lb, ub) follow; the decode waits for both."""
+        native.hsq_encode(g, cb, codes, u, partials, profile_slot=profile_slot)
+        first = ex.send_range(0, wire.levels_off)
+        native.hsq_levels(u, N_BIT, args.random, None, seed, partials, lb_ub, levels, packed6)
+        second = ex.send_range(wire.levels_off, wire.nbytes)
+        first.wait()
+        second.wait()
+        decode(ex.gathered)
+
     def roundtrip(g, profile_slot=-1):
         """One rank: decompress(compress(g)) = the encode, then level quantiser + decode as ONE launch (gq_hsq_levels_decode:
         the same (codes, lb, ub, levels) in the wire and the same decoded tensor as the two calls, bit for bit)."""
@@ -535,6 +547,8 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
         if mode == "split":
             compress_split(g, profile_slot)
             exchange_decode_split()
+        elif mode == "pipelined":
+            step_pipelined(g, profile_slot)
         elif fused:
             roundtrip(g, profile_slot)
         else:
@@ -629,6 +643,7 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     exch_ms, exch_by = None, None
     if world > 1:
         exch_ms = event_ms(torch, (lambda: [p.wait() for p in sex.start("split", cut=swire.cut)[1]]) if mode == "split"
+                           else (lambda: [p.wait() for p in ex.start("pipelined", cuts=[wire.levels_off])[1]]) if mode == "pipelined"
                            else (lambda: ex.run(mode)))
         exch_by = transports_ms(torch, dist, dev, lambda m, dry=False: (ex.start(m, dry_run=True) if dry else ex.run(m)))
     counted = ranks_counted(torch, dist, dev) if world > 1 else 1
@@ -930,7 +945,7 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
         def only_exchange(m=None, dry=False):
             if dry:
                 return q._ex.start(m, 1, q.cut, dry_run=True)
-            for pnd in q._ex.start(m or mode, 1, q.cut)[1]:
+            for pnd in q._ex.start(m or mode, 1, q.cut, cuts=q.cuts)[1]:
                 pnd.wait()
         exch_ms = event_ms(torch, only_exchange)
         exch_by = transports_ms(torch, dist, dev, only_exchange)

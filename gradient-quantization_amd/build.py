@@ -35,10 +35,13 @@ def hipcc():
     raise RuntimeError("hipcc not found (ROCm toolchain required)")
 
 
+HOST_EXT = os.path.join(HERE, "gq_amd", "_gq_host.so")
+
+
 def needs_build():
-    if not os.path.exists(LIB) or not os.path.exists(os.path.join(HERE, "libgq_hsq_clock.so")):
+    if not os.path.exists(LIB) or not os.path.exists(os.path.join(HERE, "libgq_hsq_clock.so")) or not os.path.exists(HOST_EXT):
         return True
-    t = os.path.getmtime(LIB)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(HOST_EXT))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "gq_hsq.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -76,9 +79,31 @@ def build(force=False, verbose=False):
     link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(link))
+    host = build_host_ext(verbose, wait=False)      # g++ against libtorch: ~25 s, next to the link and the clock twin
     subprocess.check_call(link)
     build_clock_lib(objs, verbose)
+    if host[1].wait() != 0:
+        raise subprocess.CalledProcessError(host[1].returncode, host[0])
     return LIB
+
+
+def build_host_ext(verbose=False, wait=True):
+    """gq_amd/_gq_host.so: the CPython helper of the quantizer's host loop (csrc/host_ext.cpp; no device code)."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    cmd = (["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+            "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+           + ["-I" + d for d in ce.include_paths() + [sysconfig.get_paths()["include"]]]
+           + [os.path.join(CSRC, "host_ext.cpp"), "-o", HOST_EXT]
+           + ["-L" + d for d in ce.library_paths()] + ["-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10"]
+           + ["-Wl,-rpath," + d for d in ce.library_paths()])
+    if verbose:
+        print(" ".join(cmd))
+    p = subprocess.Popen(cmd)
+    if wait and p.wait() != 0:
+        raise subprocess.CalledProcessError(p.returncode, cmd)
+    return cmd, p
 
 
 CLOCK_LIB = os.path.join(HERE, "libgq_hsq_clock.so")

@@ -215,4 +215,29 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
     return (float)(uniform_bits(seed, idx) >> 8) * 5.9604644775390625e-08f;  // 2^-24
 }
 
+// acc += (the norm of lane K of this lane's quad) * c as ONE v_fmac_f32_dpp (GQ_AGGREGATE_FMA): the broadcast rides in the
+// multiply-add the way it rides in v_mul_f32_dpp for the unfused form.  (The compiler does not fold a DPP move into a
+// v_fmac -- the tied accumulator -- and with four explicit moves per payload the fused form was SLOWER than the unfused
+// one: 31.3 against 25.9 us at R = 8, profiles/r04_decode_r.txt.)  n_own must have left the VALU two wait states ago
+// (DPP read-after-VALU-write hazard, which the compiler does not see inside an asm): quad_norm_ready() right behind its
+// definition holds that.
+__device__ __forceinline__ float quad_norm_ready(float n_own) {
+    asm volatile("s_nop 1" : "+v"(n_own));
+    return n_own;
+}
+template <int K>
+__device__ __forceinline__ float fmac_quad(float acc, float n_own, float c) {
+    static_assert(K >= 0 && K < 4, "lane of the quad");
+    if constexpr (K == 0) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(n_own), "v"(c));
+    if constexpr (K == 1) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(n_own), "v"(c));
+    if constexpr (K == 2) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(n_own), "v"(c));
+    if constexpr (K == 3) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(n_own), "v"(c));
+    return acc;
+}
+template <int K>
+__device__ __forceinline__ f32x4 fmac_quad4(const f32x4 &acc, float n_own, const f32x4 &c) {
+    return f32x4{fmac_quad<K>(acc[0], n_own, c[0]), fmac_quad<K>(acc[1], n_own, c[1]), fmac_quad<K>(acc[2], n_own, c[2]),
+                 fmac_quad<K>(acc[3], n_own, c[3])};
+}
+
 }  // namespace gq

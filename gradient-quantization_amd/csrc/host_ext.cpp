@@ -1,0 +1,62 @@
+// Host-side helper of gq_amd.quantizers.PSQuantizer (a CPython module, built by build.py with g++ against libtorch).
+//
+// With its launches replayed from HIP graphs, a quantizer step over a model's parameter list is bound by the HOST: per
+// step the reference's protocol (quantizers/ps_quantizer.py:27-41 record, :43-63 apply) walks the parameters three
+// times -- read every `param.grad`, look at its address / layout / dtype to decide whether a captured graph still
+// describes it, and rebind `param.grad.data` to the mean.  161 tensors x ~0.5 us of interpreter work per visit is more
+// than the kernels take.  The two walks below do the same visits in C++; nothing here computes on gradient data.
+#include <torch/extension.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace py = pybind11;
+
+// scan_grads(parameters) -> (grads, key, ok)
+//   grads : the parameters' .grad tensors (the same Python objects `p.grad` returns; None where there is none)
+//   key   : bytes, the grads' device addresses as int64 (dictionary key of the graph cache; 0 for a missing grad)
+//   ok    : every grad is defined, float32, contiguous and on ONE device (what the captured launches assume)
+static py::tuple scan_grads(const py::list &parameters) {
+    const size_t n = parameters.size();
+    py::list grads(n);
+    std::string key(n * sizeof(int64_t), '\0');
+    bool ok = true;
+    c10::Device dev(c10::DeviceType::CPU);
+    for (size_t i = 0; i < n; ++i) {
+        const at::Tensor &p = THPVariable_Unpack(parameters[i].ptr());
+        const at::Tensor &g = p.grad();
+        int64_t ptr = 0;
+        if (g.defined()) {
+            ptr = reinterpret_cast<int64_t>(g.data_ptr());
+            ok = ok && g.scalar_type() == at::kFloat && g.is_contiguous();
+            if (i == 0)
+                dev = g.device();
+            else
+                ok = ok && g.device() == dev;
+            grads[i] = py::reinterpret_steal<py::object>(THPVariable_Wrap(g));
+        } else {
+            ok = false;
+            grads[i] = py::none();
+        }
+        std::memcpy(&key[i * sizeof(int64_t)], &ptr, sizeof(int64_t));
+    }
+    return py::make_tuple(grads, py::bytes(key), ok);
+}
+
+// set_data(objects, values): objects[i].data = values[i]  (ps_quantizer.py:63 for every parameter)
+static void set_data(const py::list &objects, const py::list &values) {
+    const size_t n = objects.size();
+    if (values.size() != n) throw std::invalid_argument("set_data: the two lists differ in length");
+    for (size_t i = 0; i < n; ++i) {
+        const at::Tensor &o = THPVariable_Unpack(objects[i].ptr());
+        const at::Tensor &v = THPVariable_Unpack(values[i].ptr());
+        o.set_data(v);
+    }
+}
+
+PYBIND11_MODULE(_gq_host, m) {
+    m.def("scan_grads", &scan_grads, "The .grad tensors of a parameter list, their addresses as a bytes key, and whether all are plain f32");
+    m.def("set_data", &set_data, "objects[i].data = values[i]");
+}

@@ -235,7 +235,7 @@ __device__ __forceinline__ unsigned bt4_row_addr(unsigned c4, unsigned lane_cons
 }
 
 typedef const f32x4 __attribute__((address_space(3))) bt4_lds_f32x4;
-template <bool FIRST, bool PACKED6, bool ABS0 = false>   // ABS0: the image starts at LDS address 0 (see dec16_payload)
+template <bool FIRST, bool PACKED6, bool ABS0 = false, bool FMA = false>   // ABS0: the image starts at LDS address 0; FMA: opt-in fused accumulation (see dec16_payload)
 __device__ __forceinline__ void bt4_payload(f32x4 (&acc)[4], unsigned c4, unsigned l4, float lb, float ub, float inv_s, int q,
                                             const char *cb_bytes, unsigned lane_const) {
     const float range = ub - lb;
@@ -252,6 +252,18 @@ __device__ __forceinline__ void bt4_payload(f32x4 (&acc)[4], unsigned c4, unsign
         __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xFF, 0xF, 0xF, true))};
     const unsigned a[4] = {bt4_row_addr<0>(c4, lane_const), bt4_row_addr<1>(c4, lane_const), bt4_row_addr<2>(c4, lane_const),
                            bt4_row_addr<3>(c4, lane_const)};
+    if constexpr (FMA && !FIRST) {      // one v_fmac_f32_dpp per element: the team's norms are read across the quad by the multiply-add itself
+        const float n_rdy = quad_norm_ready(n_own);
+        const f32x4 c0 = ABS0 ? *reinterpret_cast<bt4_lds_f32x4 *>((uintptr_t)a[0]) : *reinterpret_cast<const f32x4 *>(cb_bytes + a[0]);
+        const f32x4 c1 = ABS0 ? *reinterpret_cast<bt4_lds_f32x4 *>((uintptr_t)a[1]) : *reinterpret_cast<const f32x4 *>(cb_bytes + a[1]);
+        const f32x4 c2 = ABS0 ? *reinterpret_cast<bt4_lds_f32x4 *>((uintptr_t)a[2]) : *reinterpret_cast<const f32x4 *>(cb_bytes + a[2]);
+        const f32x4 c3 = ABS0 ? *reinterpret_cast<bt4_lds_f32x4 *>((uintptr_t)a[3]) : *reinterpret_cast<const f32x4 *>(cb_bytes + a[3]);
+        acc[0] = fmac_quad4<0>(acc[0], n_rdy, c0);
+        acc[1] = fmac_quad4<1>(acc[1], n_rdy, c1);
+        acc[2] = fmac_quad4<2>(acc[2], n_rdy, c2);
+        acc[3] = fmac_quad4<3>(acc[3], n_rdy, c3);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float n = n_team[k];
@@ -308,7 +320,7 @@ __device__ __forceinline__ Bt4Tile bt4_tile(const int64_t *__restrict__ seg_tabl
 constexpr int bt4r_threads(int R) { return R > 8 ? 1024 : (R >= GQ_BT4_R_NARROW ? 768 : 1024); }
 constexpr int bt4r_waves(int R) { return R > 8 ? 4 : (R >= GQ_BT4_R_NARROW ? 6 : 8); }
 
-template <int R, bool PACKED6>
+template <int R, bool PACKED6, bool FMA = false>
 __global__ __launch_bounds__(bt4r_threads(R)) __attribute__((amdgpu_waves_per_eu(bt4r_waves(R), bt4r_waves(R))))
 void hsq_decode_sum_batched4_r_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
@@ -396,7 +408,7 @@ void hsq_decode_sum_batched4_r_kernel(
             if (r == 0)
                 bt4_payload<true, PACKED6, true>(acc, c4, l4, lb[r], ub[r], inv_s, q, cb_bytes, lane_const);
             else
-                bt4_payload<false, PACKED6, true>(acc, c4, l4, lb[r], ub[r], inv_s, q, cb_bytes, lane_const);
+                bt4_payload<false, PACKED6, true, FMA>(acc, c4, l4, lb[r], ub[r], inv_s, q, cb_bytes, lane_const);
             // keep each re-request behind the payload it replaces (hoisted to the top of the trip, the new words were
             // spilled until their registers came free): the lane offset is made to "depend" on the payload's last sum.
             // No instruction; a sched_barrier or a volatile asm counts as a store and turns the scalar (lb, ub) loads into vector loads
@@ -433,22 +445,22 @@ void hsq_decode_sum_batched4_r_kernel(
     }
 }
 
-template <int R, bool P6>
+template <int R, bool P6, bool FMA = false>
 static void launch_bt4_r(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
                          int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st) {
     static const int bpc = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_batched4_r_kernel<R, P6>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_batched4_r_kernel<R, P6, FMA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipGetLastError();
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hsq_decode_sum_batched4_r_kernel<R, P6>, bt4r_threads(R),
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hsq_decode_sum_batched4_r_kernel<R, P6, FMA>, bt4r_threads(R),
                                                          (size_t)64 * 1024) != hipSuccess || n < 1)
             n = 1;
         return n;
     }();
     int64_t blocks = (ntiles * 64 + bt4r_threads(R) - 1) / bt4r_threads(R);
     if (blocks > (int64_t)cu_count() * bpc) blocks = (int64_t)cu_count() * bpc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched4_r_kernel<R, P6>), dim3((unsigned)blocks), dim3(bt4r_threads(R)),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched4_r_kernel<R, P6, FMA>), dim3((unsigned)blocks), dim3(bt4r_threads(R)),
                        (size_t)64 * 1024, st, seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain);
 }
 
@@ -585,10 +597,18 @@ static void launch_bt4_rc(int R, const int64_t *seg_table, const int32_t *tile_s
 
 template <bool P6>
 static void launch_bt4_fixed_r(int R, const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
-                               int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st) {
+                               int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st, bool fma = false) {
     // (the lane's payload inside a group of four travels in the 32-bit offset of its loads: 3 strides + a payload must fit;
     // wires of a gigabyte and more per user take the chunked kernel, whose bases are 64-bit)
     const bool fits32 = user_stride >= 0 && 4 * user_stride < ((int64_t)1 << 32);
+    if (fma && fits32 && !plain) {   // GQ_AGGREGATE_FMA: the power-of-two payload counts; every other R keeps the exact kernels
+        switch (R) {
+#define GQ_BT4_FMA(N) case N: launch_bt4_r<N, P6, true>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st); return;
+            GQ_BT4_FMA(2) GQ_BT4_FMA(4) GQ_BT4_FMA(8) GQ_BT4_FMA(16)
+#undef GQ_BT4_FMA
+            default: break;
+        }
+    }
     switch (fits32 ? R : 0) {
 #define GQ_BT4_CASE(N) case N: launch_bt4_r<N, P6>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st); return;
         GQ_BT4_CASE(1) GQ_BT4_CASE(2) GQ_BT4_CASE(3) GQ_BT4_CASE(4)
@@ -787,7 +807,7 @@ template <typename CodeT, typename LevelT, bool ERR>
 static int launch_decode_any(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
                              int64_t user_stride, int R, const float *cb, int d, int K, int n_bit, float *out,
                              hipStream_t st, const char *what, int plain_arg) {
-    const int plain = (!ERR && plain_arg) ? 1 : 0;   // the ring's hop / a round trip, not the aggregate
+    const int plain = (!ERR && (plain_arg & 1)) ? 1 : 0;   // the ring's hop / a round trip, not the aggregate (bit 1: GQ_AGGREGATE_FMA, not served here)
     const size_t cb_bytes = (size_t)K * d * sizeof(float);
     const int in_lds = cb_bytes <= 64 * 1024;
     const size_t lds = in_lds ? cb_bytes : 0;
@@ -881,15 +901,16 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_d16(const int64_t *seg_table, const i
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: bad sizes");
     if (!seg_table || !tile_seg || !gathered || !codebook || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: null pointer");
-    plain = plain ? 1 : 0;
+    const bool fma = (plain & 2) != 0 && R >= 2;   // GQ_AGGREGATE_FMA >> 7 in the flags word
+    plain = (plain & 1) ? 1 : 0;
     if ((user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0) {
         // compile-time-R kernels up to BT4_RMAX payloads, the chunked one above: every R is served
         if (packed6)
             gq::launch_bt4_fixed_r<true>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, n_bit, out, plain,
-                                         gq::as_stream(stream));
+                                         gq::as_stream(stream), fma);
         else
             gq::launch_bt4_fixed_r<false>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, n_bit, out, plain,
-                                          gq::as_stream(stream));
+                                          gq::as_stream(stream), fma);
     } else if (packed6) {
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched: packed levels need 4-byte aligned wires");
     } else {
@@ -909,7 +930,7 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_d(const int64_t *seg_table, const int
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: bad sizes");
     if (!seg_table || !tile_seg || !gathered || !codebook || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: null pointer");
-    plain = plain ? 1 : 0;
+    plain = (plain & 1) ? 1 : 0;
     if (d == 8) {
         hipLaunchKernelGGL(gq::hsq_decode_sum_batched_d_kernel<8>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 2)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,

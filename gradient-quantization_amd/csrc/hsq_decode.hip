@@ -120,7 +120,10 @@ __device__ __forceinline__ unsigned row_addr(unsigned c4, unsigned lane_const) {
 // ABS0: the codebook image starts at LDS address 0 (a kernel whose only LDS is its dynamic array) and the v_perm_b32
 // result IS the address; through a pointer the compiler adds the array's link-time base (0) to every row address.
 typedef const f32x4 __attribute__((address_space(3))) lds_f32x4;
-template <bool FIRST, bool PACKED6, bool ABS0 = false>
+// FMA (opt-in, GQ_AGGREGATE_FMA in n_bit; payloads after the first): acc = fma(c, n, acc) instead of the reference's
+// separately rounded product and sum -- half the operations per payload, within 1e-6 relative L2 of the exact mean
+// (north_star grants 1e-5 on the decoded aggregate); never used for a plain decompress, R = 1 or error-feedback round trips.
+template <bool FIRST, bool PACKED6, bool ABS0 = false, bool FMA = false>
 __device__ __forceinline__ void dec16_payload(f32x4 (&acc)[4], unsigned c4, unsigned l4, float lb, float range, float inv_s,
                                               int q, const char *cb_bytes, unsigned lane_const) {
     const float n_own = level_to_norm<unsigned>(PACKED6 ? ((l4 >> (6 * q)) & 63u) : ((l4 >> (8 * q)) & 255u), lb, range, inv_s);
@@ -132,6 +135,18 @@ __device__ __forceinline__ void dec16_payload(f32x4 (&acc)[4], unsigned c4, unsi
         __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(n_bits, 0xFF, 0xF, 0xF, true))};
     const unsigned a[4] = {row_addr<0>(c4, lane_const), row_addr<1>(c4, lane_const), row_addr<2>(c4, lane_const),
                            row_addr<3>(c4, lane_const)};
+    if constexpr (FMA && !FIRST) {      // one v_fmac_f32_dpp per element: the team's norms are read across the quad by the multiply-add itself
+        const float n_rdy = quad_norm_ready(n_own);
+        const f32x4 c0 = ABS0 ? *reinterpret_cast<lds_f32x4 *>((uintptr_t)a[0]) : *reinterpret_cast<const f32x4 *>(cb_bytes + a[0]);
+        const f32x4 c1 = ABS0 ? *reinterpret_cast<lds_f32x4 *>((uintptr_t)a[1]) : *reinterpret_cast<const f32x4 *>(cb_bytes + a[1]);
+        const f32x4 c2 = ABS0 ? *reinterpret_cast<lds_f32x4 *>((uintptr_t)a[2]) : *reinterpret_cast<const f32x4 *>(cb_bytes + a[2]);
+        const f32x4 c3 = ABS0 ? *reinterpret_cast<lds_f32x4 *>((uintptr_t)a[3]) : *reinterpret_cast<const f32x4 *>(cb_bytes + a[3]);
+        acc[0] = fmac_quad4<0>(acc[0], n_rdy, c0);
+        acc[1] = fmac_quad4<1>(acc[1], n_rdy, c1);
+        acc[2] = fmac_quad4<2>(acc[2], n_rdy, c2);
+        acc[3] = fmac_quad4<3>(acc[3], n_rdy, c3);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float n = n_team[k];
@@ -268,7 +283,7 @@ constexpr int DEC16_RMAX = 16;
 #define GQ_DEC16R_WAVES 8
 #endif
 
-template <int R, bool PACKED6>
+template <int R, bool PACKED6, bool FMA = false>
 __global__ __launch_bounds__(DEC16_THREADS) __attribute__((amdgpu_waves_per_eu(GQ_DEC16R_WAVES, GQ_DEC16R_WAVES)))
 void hsq_decode_sum_d16u8_r_kernel(
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ levels, const float *__restrict__ lb_ub,
@@ -368,7 +383,7 @@ void hsq_decode_sum_d16u8_r_kernel(
             if (r == 0)
                 dec16_payload<true, PACKED6, true>(acc, c, l, tl, tr, inv_s, q, cb_bytes, lane_const);
             else
-                dec16_payload<false, PACKED6, true>(acc, c, l, tl, tr, inv_s, q, cb_bytes, lane_const);
+                dec16_payload<false, PACKED6, true, FMA>(acc, c, l, tl, tr, inv_s, q, cb_bytes, lane_const);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -400,7 +415,7 @@ void hsq_decode_sum_d16u8_r_kernel(
             if (r == 0)
                 dec16_payload<true, PACKED6, true>(acc, c4, l4, lb[r], range[r], inv_s, q, cb_bytes, lane_const);
             else
-                dec16_payload<false, PACKED6, true>(acc, c4, l4, lb[r], range[r], inv_s, q, cb_bytes, lane_const);
+                dec16_payload<false, PACKED6, true, FMA>(acc, c4, l4, lb[r], range[r], inv_s, q, cb_bytes, lane_const);
             if (R == 3 && r == 0) {
                 hold[0] = acc[0][0];
                 hold[1] = acc[1][1];
@@ -563,15 +578,15 @@ static void launch_dec16_rc(int R, const uint8_t *codes, const uint8_t *levels, 
                        (size_t)K * 64 * sizeof(float) + 8 * (size_t)R, st, codes, levels, lb_ub, cs, ls, bs, cb, R, M, K, n_bit, out);
 }
 
-template <int R, bool P6>
+template <int R, bool P6, bool FMA = false>
 static void launch_dec16_r(const uint8_t *codes, const uint8_t *levels, const float *lb_ub, int64_t cs, int64_t ls, int64_t bs,
                            const float *cb, int64_t M, int K, int n_bit, float *out, hipStream_t st) {
     static const int bpc = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_d16u8_r_kernel<R, P6>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_d16u8_r_kernel<R, P6, FMA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipGetLastError();
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hsq_decode_sum_d16u8_r_kernel<R, P6>, DEC16_THREADS,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hsq_decode_sum_d16u8_r_kernel<R, P6, FMA>, DEC16_THREADS,
                                                          (size_t)256 * 64 * sizeof(float)) != hipSuccess || n < 1)
             n = 1;
         return n;
@@ -579,16 +594,24 @@ static void launch_dec16_r(const uint8_t *codes, const uint8_t *levels, const fl
     const int64_t total = ((M + 3) >> 2) * 4;
     int64_t blocks = (total + DEC16_THREADS - 1) / DEC16_THREADS;
     if (blocks > (int64_t)cu_count() * bpc) blocks = (int64_t)cu_count() * bpc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_d16u8_r_kernel<R, P6>), dim3((unsigned)blocks), dim3(DEC16_THREADS),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_d16u8_r_kernel<R, P6, FMA>), dim3((unsigned)blocks), dim3(DEC16_THREADS),
                        (size_t)K * 64 * sizeof(float), st, codes, levels, lb_ub, cs, ls, bs, cb, M, K, n_bit, out);
 }
 
 template <bool P6>
 static bool launch_dec16_fixed_r(int R, const uint8_t *codes, const uint8_t *levels, const float *lb_ub, int64_t cs, int64_t ls,
-                                 int64_t bs, const float *cb, int64_t M, int K, int n_bit, float *out, hipStream_t st) {
+                                 int64_t bs, const float *cb, int64_t M, int K, int n_bit, float *out, hipStream_t st, bool fma = false) {
     if (M >= ((int64_t)1 << 31) - ((int64_t)1 << 21)) return false;
     // the lane's payload inside a group of four travels in the 32-bit offset of its loads: up to 3 strides + the section
     if (cs < 0 || ls < 0 || 3 * (cs > ls ? cs : ls) + M + 64 >= ((int64_t)1 << 32)) return false;
+    if (fma) {   // GQ_AGGREGATE_FMA: built for the power-of-two payload counts (ranks); every other R keeps the exact kernels
+        switch (R) {
+#define GQ_DEC16_FMA(N) case N: launch_dec16_r<N, P6, true>(codes, levels, lb_ub, cs, ls, bs, cb, M, K, n_bit, out, st); return true;
+            GQ_DEC16_FMA(2) GQ_DEC16_FMA(4) GQ_DEC16_FMA(8) GQ_DEC16_FMA(16)
+#undef GQ_DEC16_FMA
+            default: break;
+        }
+    }
     switch (R) {
 #define GQ_DEC16_CASE(N) case N: launch_dec16_r<N, P6>(codes, levels, lb_ub, cs, ls, bs, cb, M, K, n_bit, out, st); return true;
         GQ_DEC16_CASE(1) GQ_DEC16_CASE(2) GQ_DEC16_CASE(3) GQ_DEC16_CASE(4)
@@ -762,6 +785,8 @@ template <typename CodeT, typename LevelT>
 static int launch_decode(const CodeT *codes, const LevelT *levels, const float *lb_ub, int64_t cs, int64_t ls,
                          int64_t bs, const float *cb, int R, int64_t M, int d, int K, int n_bit, float *out,
                          hipStream_t st) {
+    const bool fma = (n_bit & GQ_AGGREGATE_FMA) != 0 && R >= 2;   // opt-in fused accumulation (the d16 / byte kernels, R = 2, 4, 8, 16)
+    n_bit &= 0xFF;
     const int64_t cap = (int64_t)cu_count() * 8;
     if constexpr (sizeof(CodeT) == 1 && (std::is_same<LevelT, uint8_t>::value || std::is_same<LevelT, Packed6>::value)) {
         constexpr bool P6 = std::is_same<LevelT, Packed6>::value;
@@ -771,7 +796,7 @@ static int launch_decode(const CodeT *codes, const LevelT *levels, const float *
         if (d == 16 && K <= 256 && lb_ub && (align & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(cb) & 15) == 0 && (M >= (int64_t)K || P6)) {
             if (launch_dec16_fixed_r<P6>(R, reinterpret_cast<const uint8_t *>(codes), reinterpret_cast<const uint8_t *>(levels),
-                                         lb_ub, cs, ls, bs, cb, M, K, n_bit, out, st)) {
+                                         lb_ub, cs, ls, bs, cb, M, K, n_bit, out, st, fma)) {
                 GQ_CHECK_LAUNCH("gq_hsq_decode_sum");
                 return GQ_OK;
             }
@@ -863,10 +888,12 @@ GQ_API int gq_hsq_decode_sum_strided(const void *codes, int code_bytes, int64_t 
     if (M < 1 || d < 1 || K < 1 || R < 1)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: bad sizes R=%d M=%lld d=%d K=%d", R, (long long)M, d, K);
     if (!codes || !levels || !codebook || !out) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: null pointer");
-    if (level_bytes != 0 && (!lb_ub || n_bit < 1 || n_bit > 30))
+    if ((n_bit & ~(0xFF | GQ_AGGREGATE_FMA)) != 0) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: n_bit %d", n_bit);
+    const int nb = n_bit & 0xFF;
+    if (level_bytes != 0 && (!lb_ub || nb < 1 || nb > 30))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: lb_ub / n_bit required with integer levels");
     const int lsz = level_bytes == 0 ? 4 : (level_bytes == GQ_LEVELS_PACKED6 ? 1 : level_bytes);
-    if (level_bytes == GQ_LEVELS_PACKED6 && (n_bit > 6 || code_bytes != 1))
+    if (level_bytes == GQ_LEVELS_PACKED6 && (nb > 6 || code_bytes != 1))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum: GQ_LEVELS_PACKED6 holds levels up to 63 and goes with byte codes");
     if ((code_bytes != 1 && code_bytes != 4) || code_stride_bytes % code_bytes || level_stride_bytes % lsz ||
         lbub_stride_bytes % 4)

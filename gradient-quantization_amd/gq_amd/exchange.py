@@ -16,6 +16,11 @@ of the exchange.  Three ways to fill the other ranks' rows, all bit-identical in
     "split"      "direct" in two byte ranges [0, cut) and [cut, user_bytes): both are queued at once, the
                  caller decodes the first range while the second is still in flight (needs one user per
                  rank so that a row's byte range is contiguous; otherwise it degrades to "direct").
+    "pipelined"  "split" with any number of byte ranges (`cuts`, ascending): chunk k is decoded while the chunks
+                 behind it are in flight.  WireExchange.send_range queues one range on its own, so that a caller
+                 whose compress launches fill the wire range by range (bench.py's flat tensor: the codes are
+                 final one launch before the levels) can start a range's transfer under its next launch.
+                 Opt-in only: never part of "auto".
 
 `GQ_EXCHANGE` selects the mode; the default is "allgather", the one collective every backend has ("auto" is
 opt-in: time all of them on the first exchange and keep the fastest, every rank taking the same decision from the
@@ -27,22 +32,24 @@ import time
 
 import torch
 
-MODES = ("allgather", "direct", "split")
+MODES = ("allgather", "direct", "split")       # what "auto" times
+OPT_IN_MODES = ("pipelined",)
 
 
 def configured_mode(default="allgather"):
     mode = os.environ.get("GQ_EXCHANGE", default)
-    if mode not in MODES + ("auto",):
-        raise ValueError("GQ_EXCHANGE must be one of %s or 'auto', got %r" % (", ".join(MODES), mode))
+    if mode not in MODES + OPT_IN_MODES + ("auto",):
+        raise ValueError("GQ_EXCHANGE must be one of %s or 'auto', got %r" % (", ".join(MODES + OPT_IN_MODES), mode))
     return mode
 
 
 class _Pending(object):
     """Outstanding transfers of one byte range; wait() orders the current stream behind them."""
 
-    def __init__(self, works, after=()):
+    def __init__(self, works, after=(), lo=0, hi=None):
         self.works = works
         self.after = list(after)      # (device view, host buffer) pairs to copy once the transfers are done
+        self.lo, self.hi = lo, hi     # the byte range of a row these transfers fill (hi None: to the end)
 
     def wait(self):
         for w in self.works:
@@ -137,7 +144,13 @@ class WireExchange(object):
             ops.append(dist.P2POp(dist.irecv, recv_t, self._peer(src), group=self.group))
         if dry:
             return None
-        return _Pending(dist.batch_isend_irecv(ops) if ops else [], after)
+        return _Pending(dist.batch_isend_irecv(ops) if ops else [], after, lo, hi)
+
+    def send_range(self, lo, hi):
+        """Queue bytes [lo, hi) of this rank's (single) row to every peer and the peers' into `gathered`, behind the
+        work queued on the current stream so far -> the pending transfer."""
+        assert self.users == 1 and 0 <= lo < hi <= self.user_bytes
+        return self._direct(1, lo, hi)
 
     def _host_buffer(self, key, n):
         buf = self._host.get(key)
@@ -146,9 +159,10 @@ class WireExchange(object):
         return buf
 
     # ---- public -----------------------------------------------------------------------------
-    def start(self, mode, rows=None, cut=None, dry_run=False):
+    def start(self, mode, rows=None, cut=None, dry_run=False, cuts=None):
         """Queue the exchange of the first `rows` rows per rank.  Returns (buffer, [pending...]): one pending
-        transfer for "allgather" / "direct", two for "split" (bytes [0, cut) then [cut, user_bytes)).
+        transfer for "allgather" / "direct", two for "split" (bytes [0, cut) then [cut, user_bytes)), len(cuts) + 1
+        for "pipelined" (the ranges between consecutive `cuts`; each pending carries its .lo / .hi).
         dry_run: everything but the transfers themselves -- the buffers, views and operation lists are built and
         checked, nothing is queued and no peer is engaged (autotune's preflight); returns (buffer, [])."""
         rows = self.users if rows is None else rows
@@ -157,12 +171,19 @@ class WireExchange(object):
             return (self.gathered[:rows], [])
         if mode == "split" and (rows != 1 or not cut or cut <= 0 or cut >= self.user_bytes):
             mode = "direct"
+        if mode == "pipelined":
+            cuts = sorted(set(c for c in (cuts or ()) if 0 < c < self.user_bytes))
+            if rows != 1 or not cuts:
+                mode = "direct"
         if mode == "allgather":
             pend = [self._allgather(rows, dry_run)]
         elif mode == "direct":
             pend = [self._direct(rows, 0, self.user_bytes, dry_run)]
         elif mode == "split":
             pend = [self._direct(rows, 0, cut, dry_run), self._direct(rows, cut, self.user_bytes, dry_run)]
+        elif mode == "pipelined":
+            edges = [0] + cuts + [self.user_bytes]
+            pend = [self._direct(rows, a, b, dry_run) for a, b in zip(edges[:-1], edges[1:])]
         else:
             raise ValueError(mode)
         return buf, ([] if dry_run else pend)

@@ -14,6 +14,7 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("GQ_LIB_PATH") or os.path.join(_PKG_DIR, "libgq_hsq.so")
 
 GQ_MAX_PARTIALS = 1024
+WS_LOG_FIRST = 2 * GQ_MAX_PARTIALS + 4      # f32-sized words in front of the workspace's log: (min, max) pairs, 4 flags (include/gq_hsq.h)
 GQ_FIXUP_PARTIALS = 256
 RANDOM_OFF, RANDOM_GIVEN, RANDOM_DEVICE, RANDOM_DEVICE_KEYED, RANDOM_DEVICE_COUNTER = 0, 1, 2, 3, 4
 ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFILTER_D16K256 = 0, 1, 2, 3, 4
@@ -92,6 +93,7 @@ def _stream():
 
 
 _CODE_BYTES = {torch.uint8: 1, torch.int32: 4}
+AGGREGATE_FMA = 0x100   # GQ_AGGREGATE_FMA: OR-ed into n_bit (per-tensor decodes) / bit 1 of `plain` (multi-tensor decode)
 LEVELS_PACKED6 = -6     # GQ_LEVELS_PACKED6: four 6-bit levels per three bytes (include/gq_hsq.h)
 PACKED6 = "packed6"     # stands in for a level dtype wherever one is passed: the section is uint8[3 * ceil(M / 4)]
 _LEVEL_BYTES = {torch.uint8: 1, torch.int16: 2, torch.int32: 4, torch.float32: 0, PACKED6: LEVELS_PACKED6}
@@ -122,12 +124,12 @@ def fixup_count(workspace, M):
     """Number of subvectors the last prefilter encode recomputed exactly (syncs).  The kernel
     zeroes its counter when it ends, so this counts the entries it left in the log: call it on a
     workspace whose log was filled with -1 beforehand (tests do)."""
-    wl = workspace[2 * GQ_MAX_PARTIALS + 4:2 * GQ_MAX_PARTIALS + 4 + M].view(torch.int32)
+    wl = workspace[WS_LOG_FIRST:WS_LOG_FIRST + M].view(torch.int32)
     return int((wl >= 0).sum().item())
 
 
 def mark_worklist(workspace, M):
-    workspace[2 * GQ_MAX_PARTIALS + 4:2 * GQ_MAX_PARTIALS + 4 + M].view(torch.int32).fill_(-1)
+    workspace[WS_LOG_FIRST:WS_LOG_FIRST + M].view(torch.int32).fill_(-1)
 
 
 def profile_read(slot):
@@ -333,12 +335,14 @@ class HSQBatch(object):
                                           _stream())
         _check(rc, "gq_hsq_levels_batched")
 
-    def decode(self, gathered, R, out, plain=False):
-        """Mean of the R payloads (plain: the decompress of ONE payload as the reference returns it, a -0 stays -0)."""
+    def decode(self, gathered, R, out, plain=False, fma=False):
+        """Mean of the R payloads (plain: the decompress of ONE payload as the reference returns it, a -0 stays -0).
+        fma: GQ_AGGREGATE_FMA for this launch (opt-in; not with plain)."""
         assert gathered.dtype == torch.uint8 and gathered.dim() == 2 and gathered.shape[0] == R and gathered.stride(1) == 1
         stride = int(gathered.stride(0)) if R > 1 else int(gathered.shape[1])
         rc = self.L.gq_hsq_decode_sum_batched(self.ref, self._wire(gathered), ctypes.c_int64(stride), ctypes.c_int(R),
-                                              _dev_ptr(out, torch.float32, "out"), ctypes.c_int(1 if plain else 0), _stream())
+                                              _dev_ptr(out, torch.float32, "out"),
+                                              ctypes.c_int(1 if plain else (2 if fma else 0)), _stream())
         _check(rc, "gq_hsq_decode_sum_batched")
 
 

@@ -32,6 +32,18 @@ from . import exchange, native
 from .compressors import (IdenticalCompressor, NearestNeighborCompressor, QSGDCompressor, _next_seed,
                           _require_device)
 
+# The C++ walks of the parameter list (csrc/host_ext.cpp -> gq_amd/_gq_host.so, built by build.py): the grads, their
+# addresses as one bytes key and the "all plain f32" flag in one pass; `.data =` for all parameters in another.  A step
+# whose launches replay from graphs is host-bound, and these walks are most of the host's work.  GQ_HOST_EXT=0: the
+# Python walks (same results; tests/test_host_logic.py compares the two).
+_HOST = None
+if os.environ.get("GQ_HOST_EXT", "1") != "0":
+    try:
+        from . import _gq_host as _HOST
+    except ImportError as _e:      # not built: the Python walks below do the same, slower; say so once
+        import warnings
+        warnings.warn("gq_amd: the host helper _gq_host.so is not built (%s); run gradient-quantization_amd/build.py" % (_e,))
+
 
 def _up(x, a=16):
     return (x + a - 1) // a * a
@@ -94,6 +106,16 @@ class GenericCodec(object):
             native.mean_rows(rows, out)
             return out.view(self.shape)
         return rows.mean(dim=0).view(self.shape)
+
+
+def aggregate_fma(args=None):
+    """Opt-in (args.gq_aggregate = "fma" / $GQ_AGGREGATE=fma): the decode-mean over R >= 2 payloads accumulates with fused
+    multiply-adds (GQ_AGGREGATE_FMA: half the arithmetic per payload, aggregate within 1e-6 relative L2 of the bit-exact one;
+    the north star grants 1e-5).  Default "exact": the reference's separately rounded product and sum."""
+    mode = getattr(args, "gq_aggregate", None) or os.environ.get("GQ_AGGREGATE", "exact")
+    if mode not in ("exact", "fma"):
+        raise ValueError("gq_aggregate / GQ_AGGREGATE must be 'exact' or 'fma', got %r" % (mode,))
+    return mode == "fma"
 
 
 def wire_levels_mode(args=None, world=1):
@@ -231,7 +253,10 @@ class HSQCodec(object):
     def _decode(self, gathered, off, R, out):
         P = gathered.shape[1]
         cbk = self.c._codebook_on(gathered.device)
-        native.hsq_decode_sum_packed(gathered, self.M, cbk, self.c.n_bit if self.c.compressed_norm else 32, out, R,
+        n_bit = self.c.n_bit if self.c.compressed_norm else 32
+        if getattr(self, "fma", False) and R >= 2 and self.c.compressed_norm:
+            n_bit |= native.AGGREGATE_FMA
+        native.hsq_decode_sum_packed(gathered, self.M, cbk, n_bit, out, R,
                                      codes_off=off + self.codes_off, levels_off=off + self.levels_off,
                                      lbub_off=off + self.lbub_off, code_dtype=self.code_dtype,
                                      level_dtype=self.wire_level_kind())
@@ -386,7 +411,7 @@ class _BatchedBase(object):
         self.ready = False      # the device header has been written at least once
         self._outs, self._out_views, self._out_turn = [None, None], [None, None], 0
         self._layout = table.clone()    # host copy of the segment table without pointers (decode needs no pointers)
-        self._head = self._tail = None  # (first segment, launch descriptor) of the two parts of a split decode
+        self._parts = {}                # (first tensor, end) -> launch descriptor of one chunk of a split / pipelined decode
         self.rng_pairs = None           # this group's { seed, step } pairs, one per user slot (PSQuantizer._rng_pairs_for)
 
     def _out_buffer(self, device, advance=True):
@@ -465,38 +490,40 @@ class _BatchedBase(object):
             return None
         return self.rng_pairs.data_ptr() + 16 * slot
 
-    def _part(self, part, first_seg):
-        """Launch descriptor of one part of a split decode (PSQuantizer.apply under GQ_EXCHANGE=split): "head" = the
-        tensors before segment `first_seg` (the same device table, fewer items), "tail" = the others (a table
-        of their own, built once: segment and item indices restart at zero).  None when the part is empty."""
-        first_item = int(self._layout[first_seg, 2]) if first_seg < self.nseg else self._nitems
-        if part == "head":
-            if first_seg == 0:
-                return None
-            if self._head is None or self._head[0] != first_seg:
-                self._head = (first_seg, self._batch.part(self._dev[:self._table_words], self._item_seg, first_seg, first_item))
-            return self._head[1]
-        if first_seg >= self.nseg:
+    def _range(self, lo, hi):
+        """Launch descriptor of the tensors [lo, hi) of the group (one chunk of a split / pipelined decode, PSQuantizer.apply
+        under GQ_EXCHANGE=split|pipelined).  lo == 0: the same device table, fewer items; otherwise a table of its own, built
+        once (segment and item indices restart at zero).  None when the range is empty."""
+        if lo >= hi:
             return None
-        if self._tail is None or self._tail[0] != first_seg:
-            tab = self._layout[first_seg:].clone()
-            tab[:, 2] -= first_item
-            items = (self._item_seg[first_item:] - first_seg).contiguous()
-            self._tail = (first_seg, self._batch.part(tab.view(-1).to(self.device), items, self.nseg - first_seg,
-                                                      self._nitems - first_item))
-        return self._tail[1]
+        ent = self._parts.get((lo, hi))
+        if ent is None:
+            i_lo = int(self._layout[lo, 2])
+            i_hi = int(self._layout[hi, 2]) if hi < self.nseg else self._nitems
+            if lo == 0:
+                ent = self._batch.part(self._dev[:self._table_words], self._item_seg, hi, i_hi)
+            else:
+                tab = self._layout[lo:hi].clone()
+                tab[:, 2] -= i_lo
+                items = (self._item_seg[i_lo:i_hi] - lo).contiguous()
+                ent = self._batch.part(tab.view(-1).to(self.device), items, hi - lo, i_hi - i_lo)
+            self._parts[(lo, hi)] = ent
+        return ent
 
-    def decode_mean(self, gathered, R, part=None, first_seg=0, plain=False):
+    def decode_mean(self, gathered, R, part=None, plain=False):
         """Mean of the R payloads of `gathered` for every tensor of the group (views of one output buffer).
-        part = "head" / "tail": only the tensors before / from segment `first_seg` (the two halves of a split
-        exchange land in the same buffer: "head" first, then "tail").  plain: the decompress of ONE payload as the
-        reference returns it (a -0 stays -0) instead of the aggregate."""
+        part = (lo, hi, first): only the tensors [lo, hi) of the group -- the chunks of a split / pipelined exchange land in
+        the same buffer, `first` on the first of them (it takes the next output buffer, the others write into it too).
+        plain: the decompress of ONE payload as the reference returns it (a -0 stays -0) instead of the aggregate."""
         if not self.ready:      # a rank that decodes before it has encoded anything (ring hop, late joiner)
             self.upload_layout()
-        out, views = self._out_buffer(gathered.device, advance=part != "tail")
-        batch = self._batch if part is None else self._part(part, first_seg)
+        out, views = self._out_buffer(gathered.device, advance=part is None or part[2])
+        batch = self._batch if part is None else self._range(part[0], part[1])
         if batch is not None:
-            batch.decode(gathered, R, out, plain=plain)
+            if getattr(self, "fma", False) and R >= 2 and not plain:
+                batch.decode(gathered, R, out, fma=True)      # (BatchedHSQ only: the quantizer sets `fma` on its HSQ groups)
+            else:
+                batch.decode(gathered, R, out, plain=plain)
         return views
 
     def upload_layout(self):
@@ -754,6 +781,7 @@ class PSQuantizer(object):
         self.two_phase = args.two_phase
         self.process_group = process_group
         factory = codec_factory or default_codec_factory
+        self.aggregate_fma = aggregate_fma(args)     # opt-in fused accumulation of the decode-mean (R >= 2 only)
         self.wire_levels = wire_levels_mode(args, _dist_world(process_group)[0])      # "bytes" | "packed6" (6-bit levels where the configuration allows)
         if self.wire_levels == "packed6":
             base_factory = factory
@@ -765,6 +793,8 @@ class PSQuantizer(object):
             comp = Compressor(param_size, param.shape, args) if param_size > 1000 else IdenticalCompressor()
             self.compressors.append(comp)
             self.codecs.append(factory(comp, param_size, param.shape))
+            if self.aggregate_fma and isinstance(self.codecs[-1], HSQCodec):
+                self.codecs[-1].fma = True
             if self.error_feedback:
                 param.error = [torch.zeros_like(param) for _ in range(args.num_users)]
             if self.error_feedback and self.two_phase:
@@ -836,6 +866,17 @@ class PSQuantizer(object):
         bounds = [self.offsets[i] for i in range(self.num_layers) if i not in self.dense_idx]
         later = [o for o in bounds if o >= self.dense_off // 2]
         self.cut = min(later) if later else 0
+        # pipelined exchange ($GQ_EXCHANGE=pipelined, opt-in): $GQ_PIPELINE_CHUNKS byte ranges (default 4) of about equal size
+        # with their boundaries on tensor boundaries; the identity-compressed tensors ride in the last one
+        nchunks = max(2, int(os.environ.get("GQ_PIPELINE_CHUNKS", "4")))
+        self.cuts = []
+        for k in range(1, nchunks):
+            inner = [o for o in bounds if o > 0]
+            if inner:
+                c = min(inner, key=lambda o: (abs(o - self.dense_off * k // nchunks), o))      # the tensor boundary nearest to k / nchunks
+                if c not in self.cuts:
+                    self.cuts.append(c)
+        self.cuts.sort()
 
     # ---- buffers -------------------------------------------------------------------------
     def _ensure_wire(self, device, slots):
@@ -900,26 +941,28 @@ class PSQuantizer(object):
     # ---- reference protocol -------------------------------------------------------------
     def record(self, user, epoch):
         scale = _ef_scale(self.args, epoch)
-        dev = self.parameters[0].grad.device
+        scan = _HOST.scan_grads(self.parameters) if _HOST is not None else None     # (grads, addresses as bytes, all plain f32)
+        all_grads = scan[0] if scan is not None else [p.grad for p in self.parameters]     # (p.grad.data builds an alias tensor per access: ~1 us each)
+        dev = all_grads[0].device
         slot = self.recorded
         wire = self._ensure_wire(dev, slot + 1)[slot]
         world, rank = _dist_world(self.process_group)
         salt = ((rank * 1000003 + user) * 0x9E3779B1) & (2 ** 62 - 1)
         skip = set()
         draws = self._draws(dev)
-        all_grads = [p.grad for p in self.parameters]     # (p.grad.data builds an alias tensor per access: ~1 us each)
         self._grad_objs = all_grads      # apply() rebinds .data of these very objects (161 fewer `param.grad` look-ups)
         # gq_graph: a record whose gradient addresses were seen before replays its device work as ONE graph launch
         graph_key = None
         if (self.use_graphs and dev.type == "cuda" and not self._draw_total and slot < self.RNG_SLOTS
                 and all(g[2] is not None and g[2].ready and g[2].graphable() for g in self._groups)
                 and not torch.cuda.is_current_stream_capturing()):      # (inside a caller's own capture the launches are simply recorded)
-            graph_key = (slot, user, self._wire.data_ptr(), tuple(map(_DATA_PTR, all_grads)))
+            graph_key = (slot, user, self._wire.data_ptr(), scan[1] if scan is not None else tuple(map(_DATA_PTR, all_grads)))
             if self.error_feedback:     # the residual buffers' addresses are in the header too (a per-tensor step replaces them)
                 graph_key += (scale, tuple(p.error[user].data_ptr() for p in self.parameters))
             ent = self._rec_graphs.get(graph_key)
-            if (ent is not None and ent[1] is not None and all(map(_IS_CONTIGUOUS, all_grads))
-                    and set(map(_DTYPE_OF, all_grads)) == _F32_ONLY):
+            if (ent is not None and ent[1] is not None
+                    and (scan[2] if scan is not None else (all(map(_IS_CONTIGUOUS, all_grads))
+                                                           and set(map(_DTYPE_OF, all_grads)) == _F32_ONLY))):
                 ent[1].replay()
                 for g in self._groups:
                     g[2]._last_ptrs = None      # the device header now holds this graph's table: the next eager call re-sends its own
@@ -977,6 +1020,7 @@ class PSQuantizer(object):
                 dense = ([(self.offsets[i], self.codecs[i].numel) for i in self.dense_idx]
                          if (grp is self._groups[0] and len(self.dense_idx) >= 2) else None)
                 obj = grp[2] = cls(self.codecs, self.offsets, idxs, dev, self.capacity, self.user_bytes, dense=dense)
+                obj.fma = bool(self.aggregate_fma and cls is BatchedHSQ)
                 if getattr(obj, "counter", False) and len(self._groups) * self.RNG_SLOTS <= 256:
                     obj.rng_pairs = self._rng_pairs_for(dev, self._groups.index(grp))
             pick = self._pick_group.get(id(grp))      # operator.itemgetter over the group's indices, built once
@@ -1054,12 +1098,12 @@ class PSQuantizer(object):
     def _decode_all(self, gathered, two_phase, pending=(), plain=False):
         """Mean of the R = gathered.shape[0] user payloads for every parameter (ps_quantizer.py:47-61),
         as a list of tensors in parameter order.  `pending`: the transfers that fill `gathered`
-        (exchange.WireExchange.start) -- one, or two for a split exchange, in which case the tensors below
-        self.cut are decoded while the rest of the wire is still in flight."""
+        (exchange.WireExchange.start) -- one, or one per byte range for a split / pipelined exchange, in which case the
+        tensors of a range are decoded while the ranges behind it are still in flight."""
         R = gathered.shape[0]
         done = {}
         pending = list(pending)
-        split = len(pending) == 2
+        chunked = len(pending) >= 2      # split / pipelined: byte ranges of the wire, each decoded as soon as it has arrived
         on_gpu = gathered.device.type == "cuda"
         # a group that did not encode in multi-tensor form this run (unaligned tensors, too many of them) is not
         # `ready`: its tensors take the per-tensor decode below
@@ -1069,26 +1113,34 @@ class PSQuantizer(object):
             batched = set(i for g in groups for i in g[1])
             dense = set(self.dense_idx) if len(self.dense_idx) >= 2 else set()
             single = [i for i in range(self.num_layers) if i not in batched and i not in dense]
-            firsts = [sum(1 for i in g[1] if self.offsets[i] < self.cut) for g in groups]
-            self._plan = (key, groups, single, firsts)
-        _, groups, single, firsts = self._plan
+            self._plan = (key, groups, single, {})
+        _, groups, single, seg_ranges = self._plan
         single = list(single)
         group_views = {}
 
-        def decode_part(part):
+        def decode_range(lo, hi, first):
+            """The tensors whose wire section starts in [lo, hi) (None: all of them)."""
             for gi, (cls, idxs, obj) in enumerate(groups):
-                group_views[gi] = obj.decode_mean(gathered, R, part if split else None, firsts[gi] if split else 0, plain=plain)
+                part = None
+                if lo is not None:
+                    part = seg_ranges.get((gi, lo, hi))
+                    if part is None:      # a group's tensors are in wire order: the range is a run of them
+                        part = seg_ranges[(gi, lo, hi)] = (sum(1 for i in idxs if self.offsets[i] < lo),
+                                                          sum(1 for i in idxs if self.offsets[i] < hi))
+                    part = part + (first,)
+                group_views[gi] = obj.decode_mean(gathered, R, part, plain=plain)
             for i in single:
-                if split and (self.offsets[i] < self.cut) != (part == "head"):
-                    continue
-                done[i] = self.codecs[i].decode_mean(gathered, self.offsets[i], R, plain=plain)
+                if lo is None or lo <= self.offsets[i] < hi:
+                    done[i] = self.codecs[i].decode_mean(gathered, self.offsets[i], R, plain=plain)
 
-        if pending:
-            pending.pop(0).wait()
-        decode_part("head")
-        if split:
-            pending.pop(0).wait()
-            decode_part("tail")
+        if not chunked:
+            if pending:
+                pending.pop(0).wait()
+            decode_range(None, None, True)
+        else:
+            for k, pnd in enumerate(pending):
+                pnd.wait()
+                decode_range(pnd.lo, self.user_bytes if pnd.hi is None else pnd.hi, k == 0)
         step_rng = self._rng_state is not None and on_gpu     # one step of the device draws per aggregate (GQ_RANDOM_DEVICE_COUNTER)
         draws2 = self._draws(gathered.device) if two_phase else None     # the second phase compresses again: new draws
         sources = []        # the lists of output views this call's result is assembled from (persistent objects, see below)
@@ -1177,7 +1229,7 @@ class PSQuantizer(object):
                     self._decode_all(buf, False, pend)
                 self.exchange_mode = ex.autotune(
                     step, preflight=lambda mode: ex.start(mode, self.recorded, self.cut, dry_run=True))
-            gathered, pending = ex.start(self.exchange_mode, self.recorded, self.cut)
+            gathered, pending = ex.start(self.exchange_mode, self.recorded, self.cut, cuts=self.cuts)
         else:
             gathered, pending = self._wire[:self.recorded], ()
         decoded = None
@@ -1233,8 +1285,11 @@ class PSQuantizer(object):
         objs = self._grad_objs
         if refresh_grads or objs is None or len(objs) != len(decoded):
             objs = [p.grad for p in self.parameters]
-        for obj, g in zip(objs, decoded):
-            obj.data = g
+        if _HOST is not None and type(objs) is list and type(decoded) is list and len(objs) == len(decoded):
+            _HOST.set_data(objs, decoded)
+        else:
+            for obj, g in zip(objs, decoded):
+                obj.data = g
         self._grad_objs = None
         self.recorded = 0
 

@@ -79,6 +79,14 @@ size_t gq_hsq_workspace_bytes(int64_t M);
  * needs 3 * ceil(M / 4) + 1 bytes of allocation.  Writers (gq_hsq_levels, gq_hsq_levels_decode) touch exactly 3 * ceil(M / 4) bytes. */
 #define GQ_LEVELS_PACKED6 (-6)
 
+/* OR-ed into the n_bit argument of gq_hsq_decode_sum / gq_hsq_decode_sum_strided and into gq_hsq_batch.n_bit for
+ * gq_hsq_decode_sum_batched (opt-in; the quantizer: $GQ_AGGREGATE=fma): the mean over R >= 2 payloads accumulates
+ * acc = fma(codeword element, norm, acc) instead of the reference's separately rounded product and sum (ps_quantizer.py:48
+ * over nearest_neighbor_compressor.py:88): half the arithmetic per payload, and the aggregate is within 1e-6 relative L2 of the
+ * bit-exact one (the north star grants 1e-5 on the decoded aggregate; codes, levels and every plain decompress are untouched).
+ * Served by the d = 16 / byte-code kernels for R = 2, 4, 8, 16; every other case ignores the flag and stays bit-exact. */
+#define GQ_AGGREGATE_FMA 0x100
+
 /* Library / device identification. */
 int gq_abi_version(void);            /* 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words); 2: the round-3 descriptor form of the multi-tensor entry points */
 const char *gq_last_error(void);     /* text of the calling thread's last failure (the library's only per-thread state) */
@@ -252,6 +260,7 @@ int gq_hsq_levels_batched(const gq_hsq_batch *b, uint8_t *wire, int random_mode,
  * plain != 0: the plain decompress of ONE payload as the reference returns it (a -0 stays -0) -- the ring's hop and
  * final gradient (ring_quantizer.py:32,41-47), the two-phase / error-feedback round trips (ps_quantizer.py:37,52-61);
  * plain == 0: the aggregate (+0 + sum) / R, also for R == 1.  Only the sign of zeros differs.
+ * `plain` is a flags word: bit 0 as above; bit 1 (value 2, with bit 0 clear): GQ_AGGREGATE_FMA for this launch.
  * Only d, K, the widths, n_bit, nseg, ntiles, seg_table, tile_seg and codebook of `b` are read: a decode of a PART of
  * the tensors (split exchange) passes a copy of the struct with another table. */
 int gq_hsq_decode_sum_batched(const gq_hsq_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,

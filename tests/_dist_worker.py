@@ -65,6 +65,7 @@ if __name__ == "__main__":
     res = run(q, params, local, rank * local)
     if mode == "ps":
         res["exchange_mode"] = np.array(q.exchange_mode)
+        res["cuts"] = np.array(len(q.cuts))
     res["wire_bytes"] = np.array(q.wire_bytes_per_user())
     os.environ["GQ_WIRE_LEVELS"] = "bytes"
     res["byte_wire_bytes"] = np.array(build(local, mode, slots)[0].wire_bytes_per_user())

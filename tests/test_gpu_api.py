@@ -1240,10 +1240,11 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, mode, quant, ef):
         assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
 
 
-@pytest.mark.parametrize("exchange,users", [("direct", 2), ("split", 1), ("auto", 1)])
+@pytest.mark.parametrize("exchange,users", [("direct", 2), ("split", 1), ("auto", 1), ("pipelined", 1)])
 def test_two_ranks_on_one_gpu_every_exchange_transport(tmp_path, exchange, users):
     """gq_amd/exchange.py with the real kernels: direct all-pairs, split (the tensors below the cut are decoded by the
-    multi-tensor kernels' "head" launch while the rest of the wire is in flight, then the "tail" launch) and auto ==
+    multi-tensor kernels' "head" launch while the rest of the wire is in flight, then the "tail" launch), pipelined (the same
+    with $GQ_PIPELINE_CHUNKS ranges: a launch over the group's tensors of each range as it arrives) and auto ==
     the same users in one process, bit for bit (HSQ and the small dense tensors; error feedback on)."""
     import subprocess
     import sys
@@ -1286,7 +1287,8 @@ def test_bench_two_rank_code_path_on_one_gpu():
 
 
 
-@pytest.mark.parametrize("extra", [[], ["--exchange", "split"], ["--exchange", "auto"], ["--workload", "qsgd"], ["--workload", "resnet50"]])
+@pytest.mark.parametrize("extra", [[], ["--exchange", "split"], ["--exchange", "auto"], ["--workload", "qsgd"], ["--workload", "resnet50"],
+                                   ["--exchange", "pipelined"], ["--exchange", "pipelined", "--workload", "resnet50"]])
 def test_bench_launches_its_own_ranks(extra):
     """`python bench.py --gpus 2` from a bare shell (no RANK / WORLD_SIZE): bench.py starts its own two ranks before
     anything touches the GPU and rank 0 prints the one JSON line (GQ_BENCH_BACKEND=gloo: both ranks share this GPU)."""
@@ -1309,7 +1311,7 @@ def test_bench_launches_its_own_ranks(extra):
     assert set(d["exchange"]["ms_by_transport"]) == {"allgather", "direct"}
     assert all(isinstance(v, float) and v > 0 for v in d["exchange"]["ms_by_transport"].values()), d["exchange"]["ms_by_transport"]
     if extra[:1] == ["--exchange"]:
-        assert d["exchange"]["transport"] == ("split" if extra[1] == "split" else d["exchange"]["transport"])
+        assert d["exchange"]["transport"] == (extra[1] if extra[1] in ("split", "pipelined") else d["exchange"]["transport"])
         if extra[1] == "auto":     # opt-in: every transport timed before the timed region, all ranks decide alike
             assert d["exchange"]["transport"] in ("allgather", "direct", "split")
             assert set(d["exchange"]["autotune_ms"]) == {"allgather", "direct", "split"}
@@ -1404,6 +1406,39 @@ def test_record_replayed_from_a_hip_graph_equals_the_eager_launches(kw):
     if kw.get("ef"):
         for pg, pe in zip(qg.parameters, qe.parameters):
             assert torch.equal(pg.error[0], pe.error[0])
+
+
+@pytest.mark.parametrize("users", [2, 4, 3])
+def test_quantizer_fma_aggregate_is_opt_in_and_within_tolerance(users, monkeypatch):
+    """$GQ_AGGREGATE=fma / args.gq_aggregate: the multi-tensor decode-mean accumulates with fused multiply-adds for R >= 2
+    payloads (R = 2, 4, 8, 16; other R stay exact).  The wire -- codes, levels, (lb, ub) -- is the exact run's bit for bit, the
+    aggregate within 1e-6 relative L2; without the option nothing changes."""
+    from gq_amd.compressors import NearestNeighborCompressor
+    from gq_amd.quantizers import Quantizer
+    dev = torch.device("cuda:0")
+    shapes = RESNET50_COMPRESSED[:6] + RESNET50_SMALL[:3]
+    torch.manual_seed(31)
+    grads = [[torch.randn(s, device=dev) * 1e-2 for s in shapes] for _ in range(users)]
+
+    def run(**kw):
+        params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
+        q = Quantizer(NearestNeighborCompressor, params, make_args(num_users=users, random=0, **kw))
+        for u in range(users):
+            for p, g in zip(params, grads[u]):
+                p.grad = g.clone()
+            q.record(u, epoch=1)
+        wire = q._wire[:users].clone()
+        q.apply()
+        return wire, [p.grad.data.clone() for p in params]
+    w_exact, a_exact = run()
+    w_fma, a_fma = run(gq_aggregate="fma")
+    assert torch.equal(w_exact, w_fma)
+    for x, y in zip(a_exact, a_fma):
+        if users == 3:
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+        else:
+            rel = float((x.double() - y.double()).norm() / x.double().norm())
+            assert rel <= 1e-6, rel
 
 
 def test_device_counter_draws_are_fresh_every_step_reproducible_and_unbiased():

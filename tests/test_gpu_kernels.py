@@ -251,6 +251,37 @@ def test_hsq_decode_sum_matches_oracle_mean(nat, oracle, R, M, K=256):
     assert np.array_equal(_bits(got), _bits(ref))
 
 
+@pytest.mark.parametrize("R", list(range(2, 20)))
+def test_fma_aggregate_is_within_1e6_of_the_oracle_mean_and_opt_in(nat, oracle, R, M=40_001):
+    """GQ_AGGREGATE_FMA (OR-ed into n_bit; the quantizer: $GQ_AGGREGATE=fma): the decode-mean over R payloads accumulates with
+    fused multiply-adds.  Tolerance, written here: relative L2 <= 1e-6 against the oracle's bit-exact mean (the north star
+    grants 1e-5 on the decoded aggregate).  Built for R = 2, 4, 8, 16; every other R ignores the flag and stays bit-exact; the
+    default (no flag) is bit-exact for every R."""
+    rng = np.random.RandomState(140 + R)
+    cb = _cb(16, 256)
+    dev = torch.device("cuda:0")
+    codes, levels, lbub, decs = [], [], [], []
+    for r in range(R):
+        x = (rng.standard_normal(16 * M) * (0.5 + r)).astype(np.float32)
+        c = oracle.hsq_compress(x, cb, 6, 0)
+        codes.append(c["codes"].astype(np.uint8))
+        levels.append(c["levels"].astype(np.uint8))
+        lbub.append([c["lb"], c["ub"]])
+        decs.append(oracle.hsq_decompress(c["codes"], c["levels"], c["lb"], c["ub"], cb, 6))
+    ref = oracle.mean_users(np.stack(decs, 0))
+    args = (torch.from_numpy(np.stack(codes)).to(dev), torch.from_numpy(np.stack(levels)).to(dev),
+            torch.tensor(lbub, dtype=torch.float32, device=dev), torch.from_numpy(cb).to(dev))
+    exact, fused = torch.empty(M * 16, dtype=torch.float32, device=dev), torch.empty(M * 16, dtype=torch.float32, device=dev)
+    nat.hsq_decode_sum(*args, 6, exact, R=R)
+    nat.hsq_decode_sum(*args, 6 | nat.AGGREGATE_FMA, fused, R=R)
+    assert np.array_equal(_bits(exact.cpu().numpy()), _bits(ref))
+    got = fused.cpu().numpy().astype(np.float64)
+    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    assert rel <= 1e-6, rel
+    if R not in (2, 4, 8, 16):
+        assert np.array_equal(_bits(fused.cpu().numpy()), _bits(ref))
+
+
 @pytest.mark.parametrize("R", [3, 5, 6, 7, 9, 12, 13, 15, 17, 19, 33])
 @pytest.mark.parametrize("span", ["subnormal", "huge", "mixed", "inf"])
 def test_hsq_decode_mean_by_any_user_count_at_the_ends_of_the_float_range(nat, oracle, R, span):

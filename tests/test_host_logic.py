@@ -409,16 +409,20 @@ def _run_ranks(tmp_path, world, mode, users, exchange, slots=None, tag=0, wire_l
 @pytest.mark.parametrize("world,users,mode,exchange", [
     (2, 2, "ps", "allgather"), (2, 2, "ring", "allgather"), (2, 2, "ps", "direct"), (2, 1, "ps", "split"),
     (1, 4, "ps", "allgather"), (4, 1, "ps", "split"), (4, 2, "ps", "auto"), (8, 1, "ps", "direct"),
-    (8, 1, "ps", "allgather"), (8, 1, "ring", "allgather")])
+    (8, 1, "ps", "allgather"), (8, 1, "ring", "allgather"),
+    (2, 1, "ps", "pipelined"), (4, 1, "ps", "pipelined"), (8, 1, "ps", "pipelined"), (2, 2, "ps", "pipelined")])
 def test_quantizer_ranks_gloo(tmp_path, oracle, world, users, mode, exchange):
     """R ranks x U local users over gloo == R*U simulated users in one process, bitwise, for R = 1, 2, 4, 8 and every
     exchange transport (gq_amd/exchange.py: all-gather, direct all-pairs, split with the decode of the first half
-    under the second half's transfer, auto = pick by timing).  ps: the payloads are summed in (rank, user) order
+    under the second half's transfer, auto = pick by timing, pipelined = $GQ_PIPELINE_CHUNKS byte ranges each decoded as it
+    arrives -- with two users per rank a row's range is not contiguous and it runs as "direct").  ps: the payloads are summed in (rank, user) order
     either way (ps_quantizer.py:48).  ring: the compressed running sum hops rank r -> r+1 and the last rank's wire
     is broadcast (ring_quantizer.py semantics with the users numbered rank-major)."""
     r0 = _run_ranks(tmp_path, world, mode, users, exchange, tag=world * 10 + users + len(exchange) + len(mode))
     if mode == "ps" and exchange != "auto":
         assert str(r0["exchange_mode"]) == exchange
+    if exchange == "pipelined":
+        assert int(r0["cuts"]) >= 2, "the test's wire has fewer than three ranges"
     sys.path.insert(0, HERE)
     import _dist_worker as w
     single = w.run_single_process(world * users, mode)
@@ -426,7 +430,7 @@ def test_quantizer_ranks_gloo(tmp_path, oracle, world, users, mode, exchange):
         assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
 
 
-@pytest.mark.parametrize("world,users,mode,exchange,levels", [(2, 2, "ps", "allgather", "packed6"), (4, 1, "ps", "split", "packed6"),
+@pytest.mark.parametrize("world,users,mode,exchange,levels", [(2, 2, "ps", "allgather", "packed6"), (4, 1, "ps", "split", "packed6"), (4, 1, "ps", "pipelined", "packed6"),
                                                               (8, 1, "ps", "direct", "packed6"), (2, 2, "ring", "allgather", "packed6"),
                                                               (2, 1, "ps", "allgather", "auto")])
 def test_quantizer_ranks_gloo_packed6_levels(tmp_path, oracle, world, users, mode, exchange, levels):
@@ -614,3 +618,50 @@ def test_graph_cache_never_evicts_a_captured_graph_and_does_not_thrash():
     assert PSQuantizer._graph_entry(cache, "f", 2, 3) is None and "f" not in cache
     assert PSQuantizer._graph_entry(cache, "d", 2, 3)[0] == 2   # known keys still count
     assert PSQuantizer._graph_entry(cache, "a", 2, 3)[1] == "graph-a"
+
+
+def test_host_helper_walks_match_the_python_walks():
+    """csrc/host_ext.cpp (gq_amd/_gq_host.so): scan_grads returns the SAME .grad objects `p.grad` returns, their addresses
+    as the bytes of an int64 array, and ok only when every grad is a defined contiguous float32 tensor on one device;
+    set_data is `objects[i].data = values[i]` (ps_quantizer.py:63)."""
+    import struct
+    sys.path.insert(0, os.path.join(ROOT, "gradient-quantization_amd"))
+    from gq_amd import _gq_host as H
+    from gq_amd import quantizers
+    assert quantizers._HOST is H, "the quantizer does not use the built helper"
+    params = [torch.nn.Parameter(torch.zeros(*s)) for s in ((3, 4), (5,), (2, 3, 4), (7, 2))]
+    for p in params:
+        p.grad = torch.randn_like(p)
+    grads, key, ok = H.scan_grads(params)
+    assert ok and all(g is p.grad for g, p in zip(grads, params))
+    assert struct.unpack("%dq" % len(params), key) == tuple(p.grad.data_ptr() for p in params)
+    new = [torch.randn_like(p) for p in params]
+    objs = [p.grad for p in params]
+    H.set_data(grads, new)
+    for p, o, v in zip(params, objs, new):
+        assert p.grad is o and p.grad.data_ptr() == v.data_ptr() and torch.equal(p.grad, v)
+    with pytest.raises(Exception):
+        H.set_data(grads, new[:-1])
+    params[3].grad = torch.zeros(2, 7).t()            # same shape, not contiguous
+    assert not H.scan_grads(params)[2]
+    params[3].grad = None
+    g3 = H.scan_grads(params)
+    assert not g3[2] and g3[0][3] is None and struct.unpack("4q", g3[1])[3] == 0
+    params[3].grad = torch.zeros(7, 2)
+    assert H.scan_grads(params)[2]
+    params[1].grad_dtype = None
+    params[1].grad = torch.zeros(5, dtype=torch.float64)
+    assert not H.scan_grads(params)[2]
+
+
+def test_quantizer_results_do_not_depend_on_the_host_helper(oracle, monkeypatch):
+    """GQ_HOST_EXT=0 (the Python walks of the parameter list) and the C++ helper: the same gradients after apply()."""
+    sys.path.insert(0, HERE)
+    import _dist_worker as w
+    from gq_amd import quantizers
+    with_helper = w.run_single_process(3, "ps")
+    assert quantizers._HOST is not None
+    monkeypatch.setattr(quantizers, "_HOST", None)
+    without = w.run_single_process(3, "ps")
+    for k in with_helper:
+        assert np.array_equal(with_helper[k].view(np.uint32), without[k].view(np.uint32)), k

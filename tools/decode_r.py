@@ -22,13 +22,19 @@ for R in ([int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]):
         codes, levels, lb_ub = wire.views(gathered[r])
         native.hsq_encode(g, cb, codes, u, ws)
         native.hsq_levels(u, 6, 0, None, 0, ws, lb_ub, levels)
-    def dec():
-        native.hsq_decode_sum_packed(gathered, M, cb, 6, out, R, wire.codes_off, wire.levels_off, wire.lbub_off)
-    for _ in range(3): dec()
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(20): dec()
-    e.record(); torch.cuda.synchronize()
-    us = s.elapsed_time(e) / 20 * 1e3
-    print("R=%d: %.1f us  (%.2f TB/s of output, %.1f B algorithmic per output element)" % (R, us, 0.1 / us * 1e3, 2 * R / 16 + 4))
+    def timed(n_bit):
+        def dec():
+            native.hsq_decode_sum_packed(gathered, M, cb, n_bit, out, R, wire.codes_off, wire.levels_off, wire.lbub_off)
+        for _ in range(3): dec()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(20): dec()
+        e.record(); torch.cuda.synchronize()
+        return s.elapsed_time(e) / 20 * 1e3
+    us = timed(6)
+    exact = out.clone()
+    fma = timed(6 | native.AGGREGATE_FMA) if R >= 2 else us      # the opt-in fused accumulation (GQ_AGGREGATE_FMA; R in {2, 4, 8, 16} have a kernel of their own)
+    rel = float((out.double() - exact.double()).norm() / exact.double().norm()) if R >= 2 else 0.0
+    print("R=%d: %.1f us  (%.2f TB/s of output, %.1f B algorithmic per output element); GQ_AGGREGATE_FMA: %.1f us, relative L2 distance to the exact aggregate %.1e"
+          % (R, us, 0.1 / us * 1e3, 2 * R / 16 + 4, fma, rel))

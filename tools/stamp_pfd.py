@@ -70,7 +70,7 @@ def read():
     for _ in range(3):
         native.hsq_encode(g, cb, codes, u, ws, impl=4)
     torch.cuda.synchronize()
-    wl = ws[2 * native.GQ_MAX_PARTIALS + 4:2 * native.GQ_MAX_PARTIALS + 4 + M]
+    wl = ws[native.WS_LOG_FIRST:native.WS_LOG_FIRST + M]
     n = NP + 4
     nblk = min(256, 32768 // (n * W))
     raw = wl[M - 65536:M - 65536 + nblk * W * n * 2].contiguous().view(torch.int64).view(-1, n).cpu().numpy().astype(np.float64)

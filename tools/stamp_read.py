@@ -16,7 +16,7 @@ ws = native.new_workspace(dev, M)
 for _ in range(3):
     native.hsq_encode(g, cb, codes, u, ws, impl=4)
 torch.cuda.synchronize()
-wl = ws[2 * native.GQ_MAX_PARTIALS + 4:2 * native.GQ_MAX_PARTIALS + 4 + M]
+wl = ws[native.WS_LOG_FIRST:native.WS_LOG_FIRST + M]
 raw = wl[M - 65536:M - 65536 + 256 * 8 * 12 * 2].contiguous().view(torch.int64).view(-1, 12).cpu().numpy().astype(np.float64)
 seg, entry, rt0, rt1, rt2, drained = raw[:, :6], raw[:, 6], raw[:, 7], raw[:, 8], raw[:, 10], raw[:, 11]
 names = ["prefetch issue / loop top", "16 chains (MFMA + keys)", "tracker merge + swaps", "exact rescoring (LDS gather)",
