@@ -737,6 +737,28 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
 
 
 # ------------------------------------------------------------------------------------------------------
+def gradient_feeder(torch, params, lists):
+    """feed(i): the parameters' gradients become list i % len(lists) -- what autograd's backward does between two quantizer
+    steps.  apply() rebinds `param.grad.data` like the reference (ps_quantizer.py:63), so after a step a gradient object
+    points at the decoded mean; the next step's inputs are put back under the SAME gradient objects (autograd accumulates
+    into an existing .grad in place) by the library's C++ helper -- 161 Python-level `p.grad = g` assignments cost more host
+    time than the whole quantizer step and are not part of what is measured.  Without the helper: the Python assignments."""
+    from gq_amd import quantizers
+    host = quantizers._HOST
+    for p, g in zip(params, lists[0]):
+        p.grad = g.view(g.shape)
+    objs = [p.grad for p in params]
+    data = [[g.view(g.shape) for g in lst] for lst in lists]
+
+    def feed(i):
+        if host is not None:
+            host.set_data(objs, data[i % len(data)])
+        else:
+            for o, g in zip(objs, data[i % len(data)]):
+                o.data = g
+    return feed
+
+
 # the compact `workloads` object of the default line: BASELINE configs[2] / [4] under the driver's clock
 # ------------------------------------------------------------------------------------------------------
 def list_workloads(args, torch, np, native, dev, steps=150, warm=40):
@@ -778,12 +800,10 @@ def list_workloads(args, torch, np, native, dev, steps=150, warm=40):
             params = [torch.nn.Parameter(torch.zeros(*sh, device=dev)) for sh in shapes]
             with contextlib.redirect_stdout(sys.stderr):     # the constructors report the reference's dimension repair on stdout
                 q = Quantizer(Comp, params, qargs)
-            total = warm + steps + 10
-            fresh = [[g.view(g.shape) for g in lists[i % 3]] for i in range(total)]     # apply() rebinds .grad.data: fresh objects per step
+            feed = gradient_feeder(torch, params, lists)
 
             def step(i):
-                for p, g in zip(params, fresh[i]):
-                    p.grad = g
+                feed(i)
                 q.record(0, epoch=1)
                 q.apply()
             for i in range(warm):
@@ -888,14 +908,13 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
         q = Quantizer(Comp, params, qargs)
     grads = [[torch.randn(s, device=dev) * 1e-3 for s in shapes] for _ in range(3)]
     prewarm = 10 if args.traffic_child else 200
-    # apply() rebinds `param.grad.data` like the reference (ps_quantizer.py:63): a tensor object that was handed in as a
-    # gradient points at the decoded mean afterwards.  Every step therefore gets its own alias objects of the three input
-    # lists (made here, outside the timed region), and the inputs stay N(0,1) * 1e-3 for the whole run.
-    fresh = [[g.view(g.shape) for g in grads[i % 3]] for i in range(prewarm + args.warmup + args.steps)]
+    # apply() rebinds `param.grad.data` like the reference (ps_quantizer.py:63): a gradient object points at the decoded
+    # mean afterwards.  Before every step the three input lists are put back under the gradient objects in turn
+    # (gradient_feeder), so the inputs stay N(0,1) * 1e-3 for the whole run.
+    feed = gradient_feeder(torch, params, grads)
 
     def step(i):
-        for p, g in zip(params, fresh[i]):
-            p.grad = g
+        feed(i)
         q.record(0, epoch=1)
         q.apply()
 

@@ -164,7 +164,14 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     __shared__ __attribute__((aligned(16))) float s_qv[PF_WAVES * PF_QCAP * 16];
     __shared__ __attribute__((aligned(16))) unsigned s_qm[PF_WAVES * PF_QCAP * 4];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Batched form: the workgroup's (min, max) per tensor, for the PF_MM_SEGS tensors from its first tile's on (a run is
+    // contiguous: typically 1-3 tensors, a few dozen where the list has many small ones).  Waves fold into it with LDS
+    // atomics; ONE pair of global atomics per (workgroup, tensor) when the workgroup ends.  Before, every wave looked at the
+    // tensor's global words (an agent-scope load: a trip to the memory side, ~2 us) and then hit them, at every change of
+    // tensor and at its end -- 10 us of a 48 us launch on the ResNet-50 list (tools/graph_pieces.py, profiles/r04_minmax_lds.txt).
+    constexpr int PF_MM_SEGS = 64;
+    __shared__ unsigned s_mm[BATCHED ? 2 * PF_MM_SEGS : 2];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform to the compiler too: tile indices and everything derived from them stay in scalar registers)
     const int j = lane & 31, h = lane >> 5;
 
     const int64_t ntiles = BATCHED ? a.ntiles : ((M + 63) >> 6);
@@ -197,6 +204,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     float lmin = INFINITY, lmax = -INFINITY;
     bool sawnan = false;   // a projection of this wave is NaN (wave-uniform)
     int cur_seg = -1;  // batched: segment the running (lmin, lmax) belongs to
+    int seg_first = 0; // batched: the tensor of this workgroup's first tile (s_mm's entry 0)
     f32x4 cur[4], nxt[4];
     f32x4 nxte[4];   // EF: the error tile that goes with nxt (dead otherwise)
 
@@ -213,6 +221,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     struct Tile {
         gcf_ptr base;
         int64_t m, sv0;
+        int64_t tile0;   // batched: the tensor's first tile
         int rem;       // index of the tile's last valid subvector (0..63): m - 1 - sv0, capped at 63
         int seg;
         gcode_ptr codes;
@@ -252,13 +261,15 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             }
             ti.base = (gcf_ptr)(uintptr_t)uniform64(r0);
             ti.m = uniform64(r1);
-            ti.sv0 = (tile - uniform64(r2)) * 64;
+            ti.tile0 = uniform64(r2);
+            ti.sv0 = (tile - ti.tile0) * 64;
             ti.codes = (gcode_ptr)((uintptr_t)a.wire + (uintptr_t)uniform64(r3));
             ti.err = EF ? (gcf_ptr)(uintptr_t)uniform64(r7) : (gcf_ptr)0;
             const int64_t rem = ti.m - 1 - ti.sv0;
             ti.rem = rem > 63 ? 63 : (int)rem;
         } else {
             ti.seg = 0;
+            ti.tile0 = 0;
             ti.base = (gcf_ptr)a.grad;
             ti.m = M;
             ti.sv0 = tile * 64;
@@ -321,20 +332,24 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             }
         }
     };
+    // (min, max) candidates of tensor `seg` (order-mapped): into the workgroup's LDS table, or -- a tensor beyond its window --
+    // straight into the tensor's global words.  There: look before the atomic.  A tensor's words are hit by every wave that
+    // touched it (~90 atomics/us per address), but only the first few still improve them; the words only ever move towards
+    // the extremes, so a value that is already as good as ours -- however stale -- makes ours redundant.
+    auto mm_fold = [&](int seg, unsigned mlo, unsigned mhi) {
+        const unsigned idx = (unsigned)(seg - seg_first);
+        if (idx < (unsigned)PF_MM_SEGS) {
+            atomicMin(&s_mm[2 * idx], mlo);
+            atomicMax(&s_mm[2 * idx + 1], mhi);
+        } else {
+            unsigned *mm = a.seg_minmax + 2 * seg;
+            if (mlo < __hip_atomic_load(mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(mm, mlo);
+            if (mhi > __hip_atomic_load(mm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(mm + 1, mhi);
+        }
+    };
     auto flush_minmax = [&]() {  // batched: fold this wave's running (min,max) into its segment
         const float lo = wave_min(lmin), hi = wave_max(lmax);
-        if (lane == 0 && cur_seg >= 0 && lo <= hi) {
-            // Look before the atomic: a tensor's (min,max) words are hit by every wave that touched the
-            // tensor (all ~2000 of them for one big tensor, ~90 atomics/us per address: a 23 us tail),
-            // but only the first few still improve them.  The words only ever move towards the extremes,
-            // so a value that is already as good as ours -- however stale -- makes ours redundant.
-            unsigned *mm = a.seg_minmax + 2 * cur_seg;
-            const unsigned mlo = order_map(lo), mhi = order_map(hi);
-            const unsigned seen_lo = __hip_atomic_load(mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned seen_hi = __hip_atomic_load(mm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (mlo < seen_lo) atomicMin(mm, mlo);
-            if (mhi > seen_hi) atomicMax(mm + 1, mhi);
-        }
+        if (lane == 0 && cur_seg >= 0 && lo <= hi) mm_fold(cur_seg, order_map(lo), order_map(hi));
         lmin = INFINITY;
         lmax = -INFINITY;
     };
@@ -359,6 +374,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     for (int n = 0; n < 256 * 16 / PF_THREADS; ++n) cbv[n] = cb[threadIdx.x + n * PF_THREADS];
     const f32x4 q0 = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * 16 + 8 * h);
     const f32x4 q1 = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * 16 + 8 * h + 4);
+    const int seg_first_v = (BATCHED && lo_tile < ntiles) ? a.tile_seg[lo_tile] : 0;   // (requested with the first tile's word)
     if (t < tile_end) {
         ti = tile_info(t, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[t]) : 0, std::true_type{});
         load_tile(ti, cur);
@@ -366,6 +382,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     }
     if (threadIdx.x == 0) {
         s_next = PF_WAVES;   // the first PF_WAVES tiles of the run go to the waves by index
+    }
+    seg_first = BATCHED ? __builtin_amdgcn_readfirstlane(seg_first_v) : 0;
+    if (BATCHED && threadIdx.x < PF_MM_SEGS) {
+        s_mm[2 * threadIdx.x] = 0xFFFFFFFFu;
+        s_mm[2 * threadIdx.x + 1] = 0u;
     }
 #pragma unroll
     for (int n = 0; n < 256 * 16 / PF_THREADS; ++n) {
@@ -451,10 +472,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     }
     // (min, max) of one exactly scanned projection into its tensor's words (batched form)
     auto fold_seg = [&](int seg, float v) {
-        unsigned *mm = a.seg_minmax + 2 * seg;
         const unsigned mv = order_map(v);
-        if (mv < __hip_atomic_load(mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(mm, mv);
-        if (mv > __hip_atomic_load(mm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(mm + 1, mv);
+        mm_fold(seg, mv, mv);
     };
     auto poison_seg = [&](int seg) {   // (lb, ub) of this tensor become NaN (torch.min / torch.max propagate it)
         atomicMin(a.seg_minmax + 2 * seg, MAPPED_NAN_LO);
@@ -682,7 +701,15 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         const int64_t tnn = BATCHED ? draw() : 0;
         Tile tin = ti;
         if (tn < tile_end) {
-            tin = tile_info(tn, seg_next, std::false_type{});
+            // a wave's consecutive tiles mostly stay with one tensor (contiguous runs): its record is already in scalar
+            // registers -- the LDS reads and the eight v_readfirstlane of a look-up only when the tensor changes
+            if (BATCHED && seg_next == ti.seg) {
+                tin.sv0 = (tn - ti.tile0) * 64;
+                const int64_t rem = ti.m - 1 - tin.sv0;
+                tin.rem = rem > 63 ? 63 : (int)rem;
+            } else {
+                tin = tile_info(tn, seg_next, std::false_type{});
+            }
             load_tile(tin, nxt);  // prefetch the next tile
             load_err(tin, nxte);
         }
@@ -918,7 +945,18 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         o[6] = rt_entry, o[7] = rt0, o[8] = rt1, o[9] = ntl, o[10] = __builtin_amdgcn_s_memrealtime(), o[11] = 1000 * nscanned + npassed;
     }
 #endif
-    if (BATCHED) return;
+    if (BATCHED) {   // the workgroup's table into the tensors' global words: one pair of atomics per tensor it met
+        __syncthreads();
+        if (threadIdx.x < PF_MM_SEGS) {
+            const unsigned lo = s_mm[2 * threadIdx.x], hi = s_mm[2 * threadIdx.x + 1];
+            if (lo != 0xFFFFFFFFu || hi != 0u) {
+                unsigned *mm = a.seg_minmax + 2 * (seg_first + (int)threadIdx.x);
+                atomicMin(mm, lo);
+                atomicMax(mm + 1, hi);
+            }
+        }
+        return;
+    }
     write_minmax_partials<PF_WAVES>(lmin, lmax, ws, sawnan);   // per-workgroup (min,max); the level kernel folds them
 }
 

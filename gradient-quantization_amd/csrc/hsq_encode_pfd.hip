@@ -94,7 +94,7 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : (D == 16 ? 8 : GQ_W8)) * 64, 1)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *const s_cb = lds;                                                         // [npages * 64 groups][QS]
     bf16x8 *const s_a = reinterpret_cast<bf16x8 *>(lds + npages * 64 * QS);          // [npages * 8 * KS * 2][64 lanes]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
 
     __shared__ int s_next;

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float
                                                                     float *__restrict__ partials, int dpad,
                                                                     int chunk_rows, PvqResidual rs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
     const int stride = dpad + LDS_ROW_PAD, half = dpad >> 1;
     float *const s_cb = lds;

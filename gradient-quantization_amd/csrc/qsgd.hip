@@ -57,7 +57,7 @@ __global__ __launch_bounds__(QS_THREADS) void qsgd_compress_wave_kernel(const fl
     const int lane = threadIdx.x & 63;
     const int64_t nw = (int64_t)gridDim.x * (QS_THREADS / 64);
     const float s = (float)(1 << n_bit), smax = s - 1.0f;
-    for (int64_t b = (int64_t)blockIdx.x * (QS_THREADS / 64) + (threadIdx.x >> 6); b < Mb; b += nw) {
+    for (int64_t b = (int64_t)blockIdx.x * (QS_THREADS / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); b < Mb; b += nw) {   // (the wave's index: uniform to the compiler too, the bucket's address arithmetic stays scalar)
         const float *v = grad + b * (int64_t)d;
         float mx = 0.0f;
         for (int jj = lane; jj < d; jj += 64) mx = absmax3_nan(mx, v[jj], v[jj]);   // NaN-propagating, like torch.max

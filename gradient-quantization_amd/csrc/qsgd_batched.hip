@@ -48,7 +48,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float s = (float)(1 << n_bit), smax = s - 1.0f;
     const unsigned lmask = (1u << (bits - 1)) - 1u;
-    for (int64_t b = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); b < nbuckets; b += nw) {
+    for (int64_t b = (int64_t)blockIdx.x * (QB_THREADS / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); b < nbuckets; b += nw) {
         const int seg = __builtin_amdgcn_readfirstlane(bucket_seg[b]);
         const int64_t *rec = seg_table + 8 * (int64_t)seg;
         const int d = (int)rec[1];
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float s = (float)(1 << n_bit), smax = s - 1.0f, inv_s = 1.0f / s;
     const int64_t nquads = (nbuckets + 3) >> 2;
-    int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6);
+    int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int seg_next = (qd < nquads && 4 * qd + sub < nbuckets) ? bucket_seg[4 * qd + sub] : 0;
     for (; qd < nquads; qd += nw) {
         const int64_t b = 4 * qd + sub;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched_kernel(
     const float s = (float)(1 << n_bit);
     const MeanDiv md = mean_div_of(R, !plain);   // the aggregate of R users (ps_quantizer.py:48)
     const unsigned lmask = (1u << (bits - 1)) - 1u;
-    for (int64_t b = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); b < nbuckets; b += nw) {
+    for (int64_t b = (int64_t)blockIdx.x * (QB_THREADS / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); b < nbuckets; b += nw) {
         const int seg = __builtin_amdgcn_readfirstlane(bucket_seg[b]);
         const int64_t *rec = seg_table + 8 * (int64_t)seg;
         const int d = (int)rec[1];
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_kernel(
     const float inv_s = 1.0f / (float)(1 << n_bit);
     const MeanDiv md = mean_div_of(R, !plain);   // the aggregate of R users (ps_quantizer.py:48)
     const int64_t nquads = (nbuckets + 3) >> 2;
-    for (int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6); qd < nquads; qd += nw) {
+    for (int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); qd < nquads; qd += nw) {
         const int64_t b = 4 * qd + sub;
         if (b >= nbuckets) continue;
         const int seg = bucket_seg[b];
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_r_kernel(
         w[r] = *reinterpret_cast<gword *>(reinterpret_cast<gbyte *>(base) + co);
         nm[r] = *reinterpret_cast<gfloat *>(reinterpret_cast<gbyte *>(base) + (it.norm_off + guard));
     };
-    int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + (threadIdx.x >> 6);
+    int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (qd >= nquads) return;
     int64_t qn = qd + nw < nquads ? qd + nw : qd;
     Item cur = item_of(bucket_of(qd), bucket_seg[bucket_of(qd)]);

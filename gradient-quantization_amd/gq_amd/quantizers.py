@@ -79,6 +79,13 @@ class DenseCodec(object):
         return rows.mean(dim=0).view(self.shape)
 
 
+def _kernel_copy(dst, src):
+    """dst <- src (int64 device tensors of one size) by an elementwise KERNEL, for use under stream capture: a memcpy node in a
+    replayed HIP graph costs ~15 us of every step whether its source is pinned host memory or device memory (84.9 / 83.4 us
+    against 69.7 without the node, tools/graph_pieces.py -- the copy engine's hand-over), a kernel node ~2."""
+    torch.bitwise_or(src, 0, out=dst)
+
+
 def _esize(dtype):
     return torch.empty(0, dtype=dtype).element_size()
 
@@ -638,14 +645,14 @@ class BatchedHSQ(_BatchedBase):
         tensor on this device: the caller then takes the per-tensor path for this step.
         With `errs` (error feedback, ps_quantizer.py:34-39) the same launches also do
         t += ef_scale*err (in place, before encoding) and err = t - decoded (in place, after).
-        graph_header (stream capture): a pinned copy of the header of exactly these tensors that nobody rewrites; it is
+        graph_header (stream capture): a device copy of the header of exactly these tensors that nobody rewrites; it is
         copied instead of the shared pinned buffers (no events, no validation: the caller has just run the same call eagerly)."""
         if self.reference_draws and draws is None:
             return False
         if self._batch.path == 0:       # e.g. more than 384 tensors of d = 8 / 32 and no exact kernel for the shape
             return False
         if graph_header is not None:
-            self._dev.copy_(graph_header, non_blocking=True)
+            _kernel_copy(self._dev, graph_header)
         elif not self._upload(tensors, slot, self.align, errs, dense):
             return False
         self._batch.set_dense(self.dense_table_dev() if dense is not None else None, self.ndense)
@@ -730,7 +737,7 @@ class BatchedQSGD(_BatchedBase):
         """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place).
         graph_header, dense: see BatchedHSQ.encode."""
         if graph_header is not None:
-            self._dev.copy_(graph_header, non_blocking=True)
+            _kernel_copy(self._dev, graph_header)
         elif not self._upload(tensors, slot, 8, errs, dense):
             return False
         self._batch.set_dense(self.dense_table_dev() if dense is not None else None, self.ndense)
@@ -842,6 +849,13 @@ class PSQuantizer(object):
         self._rng_state = None
         self._rec_graphs = {}        # (slot, user, scale, gradient addresses) -> [sightings, graph or None, keep-alive]
         self._apply_graphs = {}      # (users recorded, wire, output-buffer turns) -> [sightings, graph or None, decoded list]
+        # One rank, one user per step (args.num_users == 1, no process group): record() is always followed by the apply() of
+        # exactly that payload, so the two replay as ONE graph from record() -- compress and decode-mean launches back to
+        # back, one graph launch less per step (5 us of ~70, tools/graph_pieces.py) -- and apply() only rebinds the gradients.
+        # $GQ_FUSE_STEP=0 keeps the two graphs.
+        self._step_graphs = {}       # (record key, apply key) -> [sightings, graph or None, decoded list]
+        self._fused = None           # the decoded list of a step whose record() has already replayed its apply()
+        self._fuse_steps = type(self) is PSQuantizer and os.environ.get("GQ_FUSE_STEP", "1") != "0"
         # gq_rng = "reference": the reference draws r = torch.rand(M) per compressed tensor, in parameter order, from
         # the CPU generator (probabilistic_scalar_compressor.py:23).  torch.rand is one sequential stream, so ONE
         # torch.rand(sum of M) per record (and one per two-phase apply) gives every tensor the same numbers; the
@@ -960,13 +974,32 @@ class PSQuantizer(object):
             if self.error_feedback:     # the residual buffers' addresses are in the header too (a per-tensor step replaces them)
                 graph_key += (scale, tuple(p.error[user].data_ptr() for p in self.parameters))
             ent = self._rec_graphs.get(graph_key)
-            if (ent is not None and ent[1] is not None
-                    and (scan[2] if scan is not None else (all(map(_IS_CONTIGUOUS, all_grads))
-                                                           and set(map(_DTYPE_OF, all_grads)) == _F32_ONLY))):
+            plain_f32 = ent is not None and ent[1] is not None and (
+                scan[2] if scan is not None else (all(map(_IS_CONTIGUOUS, all_grads)) and set(map(_DTYPE_OF, all_grads)) == _F32_ONLY))
+            step_key = None
+            if (plain_f32 and self._fuse_steps and world == 1 and slot == 0 and self.capacity == 1 and not self.two_phase
+                    and self._plan is not None and not self._plan[2]):      # (the plan: everything decodes through multi-tensor launches)
+                step_key = (graph_key, self._apply_key(self._wire[:1]))
+                fent = self._step_graphs.get(step_key)
+                if fent is not None and fent[1] is not None:      # compress + decode-mean of this step in one launch
+                    fent[1].replay()
+                    for g in self._groups:
+                        g[2]._last_ptrs = None
+                        g[2]._out_turn ^= 1
+                    if len(self.dense_idx) >= 2:
+                        self._dense_turn ^= 1
+                    self._fused = fent[2]
+                    self.recorded += 1
+                    return
+            if plain_f32:
                 ent[1].replay()
                 for g in self._groups:
                     g[2]._last_ptrs = None      # the device header now holds this graph's table: the next eager call re-sends its own
                 self.recorded += 1
+                if step_key is not None:
+                    fent = self._graph_entry(self._step_graphs, step_key)
+                    if fent is not None and fent[0] >= 2 and fent[1] is None:
+                        self._capture_step(fent, ent[2], all_grads, wire, slot, user, salt, scale, dev)
                 return
         skip = self._record_launches(all_grads, wire, slot, user, salt, scale, draws, dev)
         if len(skip) == self.num_layers:     # the usual case: everything went through the multi-tensor launches
@@ -1010,7 +1043,7 @@ class PSQuantizer(object):
 
     def _record_launches(self, all_grads, wire, slot, user, salt, scale, draws, dev, headers=None):
         """The multi-tensor launches of a record (+ the dense tensors' copy into the wire) -> the set of parameters served.
-        headers (stream capture): one pinned header per group, see BatchedHSQ.encode."""
+        headers (stream capture): one device-resident header per group, see BatchedHSQ.encode."""
         skip = set()
         skip_groups = []
         for grp in (self._groups if dev.type == "cuda" else []):
@@ -1074,10 +1107,12 @@ class PSQuantizer(object):
         return ent
 
     def _capture_record(self, ent, all_grads, wire, slot, user, salt, scale, dev):
-        """Stream-capture the launches the record just made eagerly, with pinned copies of the headers it has just sent
+        """Stream-capture the launches the record just made eagerly, with copies of the headers it has just sent
         (the shared pinned buffers are rewritten by later records, a graph's memcpy node reads its source at every replay)."""
         try:
-            headers = [g[2]._host[g[2]._last_slot].clone().pin_memory() for g in self._groups]
+            # (device-resident: the graph's copy node is device-to-device.  A host-to-device node -- pinned memory over PCIe --
+            # cost 15 us of every replayed step, tools/graph_pieces.py; the 5 KB header per captured graph is nothing)
+            headers = [g[2]._host[g[2]._last_slot].to(dev) for g in self._groups]
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (other threads -- RCCL's watchdog -- may call into HIP meanwhile)
                 self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers)
@@ -1087,6 +1122,32 @@ class PSQuantizer(object):
             warnings.warn("gq_graph: capturing a record failed (%s); continuing with eager launches" % (e,))
             return
         ent[1], ent[2] = graph, headers
+
+    def _capture_step(self, fent, headers, all_grads, wire, slot, user, salt, scale, dev):
+        """One graph for a whole step: the record's launches (headers: the device copies its own graph keeps) and the
+        decode-mean launches the following apply() would make, captured from record() after this record has run.  Nothing
+        executes here; the output-buffer turns the capture advances are put back for the apply() that is still to come."""
+        after = ([g[2]._out_turn for g in self._groups], self._dense_turn)
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers)
+                decoded = self._decode_all(self._wire[:1], False, ())
+            fent[1], fent[2] = graph, decoded
+        except Exception as e:      # the two-graph replay keeps working
+            self._fuse_steps = False
+            import warnings
+            warnings.warn("gq_graph: capturing a whole step failed (%s); record and apply keep their own graphs" % (e,))
+        finally:
+            for g, t in zip(self._groups, after[0]):
+                g[2]._out_turn = t
+            self._dense_turn = after[1]
+
+    def _apply_key(self, gathered):
+        """What an apply()'s captured launches depend on: payload count, the wire, and which output buffers are next."""
+        return (gathered.shape[0], gathered.data_ptr(), tuple(g[2]._out_turn for g in self._groups), self._dense_turn,
+                tuple(0 if o is None else o.data_ptr() for g in self._groups for o in g[2]._outs),
+                tuple(0 if m is None else m.data_ptr() for m in self._dense_mean))
 
     def _slice(self, draws, i):
         """This parameter's share of the record's draws as a keyword for the codec (nothing for the other codecs)."""
@@ -1234,7 +1295,10 @@ class PSQuantizer(object):
             gathered, pending = self._wire[:self.recorded], ()
         decoded = None
         graph_key = None
-        if (self.use_graphs and len(pending) <= 1 and not self.two_phase and gathered.device.type == "cuda"
+        fused, self._fused = self._fused, None
+        if fused is not None and self.recorded == 1 and world == 1:
+            decoded = fused      # record() has replayed this step's decode-mean already (self._step_graphs)
+        elif (self.use_graphs and len(pending) <= 1 and not self.two_phase and gathered.device.type == "cuda"
                 and all(g[2] is not None and g[2].ready for g in self._groups) and not torch.cuda.is_current_stream_capturing()):
             # gq_graph: the decode-mean launches (+ the dense tensors' mean) of an apply that has been seen with these buffers
             # before replay as ONE graph launch; the two output buffers are used in turn, so two graphs alternate.  With
@@ -1243,9 +1307,7 @@ class PSQuantizer(object):
             for pnd in pending:
                 pnd.wait()
             pending = ()
-            graph_key = (gathered.shape[0], gathered.data_ptr(), tuple(g[2]._out_turn for g in self._groups), self._dense_turn,
-                         tuple(0 if o is None else o.data_ptr() for g in self._groups for o in g[2]._outs),
-                         tuple(0 if m is None else m.data_ptr() for m in self._dense_mean))
+            graph_key = self._apply_key(gathered)
             ent = self._apply_graphs.get(graph_key)
             if ent is not None and ent[1] is not None:
                 ent[1].replay()

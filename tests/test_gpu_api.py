@@ -1408,6 +1408,56 @@ def test_record_replayed_from_a_hip_graph_equals_the_eager_launches(kw):
             assert torch.equal(pg.error[0], pe.error[0])
 
 
+@pytest.mark.parametrize("kw", [dict(random=1), dict(random=0, ef=True, scale="0.5"), dict(qsgd=True, c_dim=128, n_bit=2, random=1)])
+def test_whole_step_replayed_as_one_graph_equals_the_eager_launches(kw, monkeypatch):
+    """One rank, args.num_users == 1: once a set of gradient addresses has its record graph, record() replays the compress AND
+    the decode-mean launches of the step as ONE graph (PSQuantizer._step_graphs) and apply() only rebinds the gradients.
+    Same aggregates, wire and residuals as eager launches over 14 steps on two alternating address sets; $GQ_FUSE_STEP=0 keeps
+    the two graphs per step and gives the same bits too."""
+    from gq_amd.compressors import NearestNeighborCompressor, QSGDCompressor
+    from gq_amd.quantizers import Quantizer
+    kw = dict(kw)
+    Comp = QSGDCompressor if kw.pop("qsgd", False) else NearestNeighborCompressor
+    shapes = RESNET50_COMPRESSED[:10] + RESNET50_SMALL[:4]
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    store = [[torch.randn(s, device=dev) * 1e-2 for s in shapes] for _ in range(2)]
+    order = [0, 1] * 7
+    fills = [[torch.randn(s, device=dev) * 1e-2 for s in shapes] for _ in order]
+
+    def run(graph, fuse="1"):
+        from gq_amd import compressors
+        compressors._seed_counter[0] = 0
+        monkeypatch.setenv("GQ_FUSE_STEP", fuse)
+        params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
+        q = Quantizer(Comp, params, make_args(num_users=1, gq_graph=graph, **kw))
+        outs, fused_steps = [], 0
+        for step, k in enumerate(order):
+            for t, f in zip(store[k], fills[step]):
+                t.copy_(f)
+            for p, t in zip(params, store[k]):
+                p.grad = t.view(t.shape)
+            q.record(0, epoch=1)
+            fused_steps += q._fused is not None
+            q.apply()
+            outs.append([p.grad.data.clone() for p in params])
+        return q, outs, fused_steps
+
+    qf, of, nf = run(True)
+    q2, o2, n2 = run(True, fuse="0")
+    qe, oe, ne = run(False)
+    assert sum(1 for e in qf._step_graphs.values() if e[1] is not None) == 2 and nf >= 4, (len(qf._step_graphs), nf)
+    assert not q2._step_graphs and n2 == 0 and ne == 0
+    for other in (of, o2):
+        for a, b in zip(other, oe):
+            for x, y in zip(a, b):
+                assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    assert torch.equal(qf._wire, qe._wire) and torch.equal(q2._wire, qe._wire)
+    if kw.get("ef"):
+        for pf, pe in zip(qf.parameters, qe.parameters):
+            assert torch.equal(pf.error[0], pe.error[0])
+
+
 @pytest.mark.parametrize("users", [2, 4, 3])
 def test_quantizer_fma_aggregate_is_opt_in_and_within_tolerance(users, monkeypatch):
     """$GQ_AGGREGATE=fma / args.gq_aggregate: the multi-tensor decode-mean accumulates with fused multiply-adds for R >= 2
