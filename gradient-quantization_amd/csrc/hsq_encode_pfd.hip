@@ -100,6 +100,10 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : (D == 16 ? 8 : GQ_W8)) * 64, 1)
     __shared__ int s_next;
     __shared__ int64_t s_seg[BATCHED ? PFD_LDS_SEGS * 8 : 1];
     __shared__ float s_c1[WAVES];
+    // batched: the workgroup's (min, max) per tensor for the PFD_MM_SEGS tensors from its first tile's on, folded by LDS
+    // atomics; one pair of global atomics per (workgroup, tensor) at the end (hsq_encode_pf.hip, s_mm)
+    constexpr int PFD_MM_SEGS = 64;
+    __shared__ unsigned s_mm[BATCHED ? 2 * PFD_MM_SEGS : 2];
 
     const int b = (int)blockIdx.x;
     const int64_t lo_tile = (int64_t)b * a.tiles_q + (b < a.tiles_r ? b : a.tiles_r);
@@ -116,6 +120,13 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : (D == 16 ? 8 : GQ_W8)) * 64, 1)
     };
     int64_t t = lo_tile + wave;
     int *const worklist = ws_worklist(ws);
+    // (the tensor of the workgroup's first tile = entry 0 of s_mm; the table is cleared here, every fold lies behind the
+    // kernel's first barrier)
+    const int seg_first = (BATCHED && lo_tile < tile_end) ? __builtin_amdgcn_readfirstlane(a.tile_seg[lo_tile]) : 0;
+    if (BATCHED && threadIdx.x < PFD_MM_SEGS) {
+        s_mm[2 * threadIdx.x] = 0xFFFFFFFFu;
+        s_mm[2 * threadIdx.x + 1] = 0u;
+    }
 
     typedef const float __attribute__((address_space(1))) *gcf_ptr;
     typedef const f32x4 __attribute__((address_space(1))) *gcv_ptr;
@@ -229,12 +240,16 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : (D == 16 ? 8 : GQ_W8)) * 64, 1)
     auto flush_minmax = [&]() {  // batched: fold this wave's running (min,max) into its segment
         const float lo = wave_min(lmin), hi = wave_max(lmax);
         if (lane == 0 && cur_seg >= 0 && lo <= hi) {
-            unsigned *mm = a.seg_minmax + 2 * cur_seg;   // look before the atomic (hsq_encode_pf.hip)
             const unsigned mlo = order_map(lo), mhi = order_map(hi);
-            const unsigned seen_lo = __hip_atomic_load(mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned seen_hi = __hip_atomic_load(mm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (mlo < seen_lo) atomicMin(mm, mlo);
-            if (mhi > seen_hi) atomicMax(mm + 1, mhi);
+            const unsigned idx = (unsigned)(cur_seg - seg_first);
+            if (idx < (unsigned)PFD_MM_SEGS) {
+                atomicMin(&s_mm[2 * idx], mlo);
+                atomicMax(&s_mm[2 * idx + 1], mhi);
+            } else {   // beyond the table: the tensor's global words, looking before the atomic (hsq_encode_pf.hip)
+                unsigned *mm = a.seg_minmax + 2 * cur_seg;
+                if (mlo < __hip_atomic_load(mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(mm, mlo);
+                if (mhi > __hip_atomic_load(mm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(mm + 1, mhi);
+            }
         }
         lmin = INFINITY;
         lmax = -INFINITY;
@@ -609,6 +624,15 @@ __global__ __launch_bounds__((D == 32 ? GQ_W32 : (D == 16 ? 8 : GQ_W8)) * 64, 1)
     }
     if (BATCHED) {
         flush_minmax();
+        __syncthreads();
+        if (threadIdx.x < PFD_MM_SEGS) {   // the workgroup's table into the tensors' global words
+            const unsigned lo = s_mm[2 * threadIdx.x], hi = s_mm[2 * threadIdx.x + 1];
+            if (lo != 0xFFFFFFFFu || hi != 0u) {
+                unsigned *mm = a.seg_minmax + 2 * (seg_first + (int)threadIdx.x);
+                atomicMin(mm, lo);
+                atomicMax(mm + 1, hi);
+            }
+        }
         return;
     }
     write_minmax_partials<WAVES>(lmin, lmax, ws, sawnan);   // per-workgroup (min,max); the level kernel folds them
