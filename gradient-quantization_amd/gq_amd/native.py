@@ -298,6 +298,11 @@ class HSQBatch(object):
         self.ref = ctypes.byref(self.s)
         self.path = int(self.L.gq_hsq_batched_path(self.ref))
 
+    def set_table(self, seg_table):
+        """Another copy of the segment table for the launches that follow (a captured graph's own, which nobody rewrites)."""
+        self.keep_table = seg_table
+        self.s.seg_table = _dev_ptr(seg_table, torch.int64, "seg_table").value
+
     def set_dense(self, dense_table, ndense):
         """dense_table (int64 [ndense, 3] on the device: source pointer, byte offset in one user's wire, elements): the level
         launch also copies the uncompressed tensors into the wire.  None: no copies."""
@@ -393,6 +398,11 @@ class QSGDBatch(object):
                                   _dev_ptr(item_seg, torch.int32, "item_seg").value,
                                   _dev_ptr(norm_bits, torch.int32, "norm_bits").value if norm_bits is not None else None, None, 0, 0)
         self.ref = ctypes.byref(self.s)
+
+    def set_table(self, seg_table):
+        """As HSQBatch.set_table."""
+        self.keep_table = seg_table
+        self.s.seg_table = _dev_ptr(seg_table, torch.int64, "seg_table").value
 
     def set_dense(self, dense_table, ndense):
         """As HSQBatch.set_dense: the compress launch also copies the uncompressed tensors into the wire."""

@@ -411,6 +411,8 @@ class _BatchedBase(object):
         self._last_dptrs = None
         self._zeros = [0] * self.nseg
         self._resets = extra is not None    # the header also carries per-step reset values (min / max accumulators)
+        self._acc_init = extra.view(-1).to(device) if extra is not None else None     # the accumulators' empty state, on the device
+        self._acc_clean = False             # the device accumulators are in that state right now (see _graph_tables)
         self._last_ptrs = self._last_eptrs = None
         self._events = [None] * (slots + 1)
         self._dev = torch.empty_like(host, device=device)
@@ -439,6 +441,28 @@ class _BatchedBase(object):
 
     def dense_table_dev(self):
         return self._dev[self._dense_at:].view(self.ndense, 3) if self.ndense else None
+
+    # ---- launches under stream capture: a graph's own tables, accumulators reset behind their last reader -----------------
+    # A captured record reads the segment / dense tables from a device copy that belongs to the graph (nobody rewrites
+    # it), so a replay needs no header copy in front of the encode -- any node there, memcpy or kernel, cost ~7 us of every
+    # step (profiles/r04_graph_pieces.txt).  What the header copy also did, resetting the accumulators the kernels fold into
+    # ((min, max) per tensor; wide QSGD buckets' norms), is a small kernel BEHIND the group's last launch instead: a graph
+    # leaves them clean for the next replay, an eager step leaves them used (`_acc_clean`), and whoever replays a graph
+    # after an eager step cleans them first (ensure_clean).
+    def _graph_tables(self, graph_header, dense):
+        self._batch.set_table(graph_header[:self._table_words])
+        self._batch.set_dense(graph_header[self._dense_at:].view(self.ndense, 3) if (dense is not None and self.ndense) else None,
+                              self.ndense)
+
+    def _graph_tables_done(self):
+        if self._resets:
+            _kernel_copy(self._dev[self._table_words:self._dense_at], self._acc_init)
+        self._batch.set_table(self._dev[:self._table_words])
+
+    def ensure_clean(self):
+        if self._resets and not self._acc_clean:
+            _kernel_copy(self._dev[self._table_words:self._dense_at], self._acc_init)
+            self._acc_clean = True
 
     def _upload(self, tensors, slot, align, errs=None, dense=None):
         """Column 0 of the segment table <- the tensors' device pointers; column 7 <- the error
@@ -652,10 +676,12 @@ class BatchedHSQ(_BatchedBase):
         if self._batch.path == 0:       # e.g. more than 384 tensors of d = 8 / 32 and no exact kernel for the shape
             return False
         if graph_header is not None:
-            _kernel_copy(self._dev, graph_header)
+            self._graph_tables(graph_header, dense)
         elif not self._upload(tensors, slot, self.align, errs, dense):
             return False
-        self._batch.set_dense(self.dense_table_dev() if dense is not None else None, self.ndense)
+        else:
+            self._batch.set_dense(self.dense_table_dev() if dense is not None else None, self.ndense)
+            self._acc_clean = False
         ef = ef_scale if errs is not None else None
         self._batch.encode(wire_user, ef, self.profile_slot)
         self.profile_slot = -1
@@ -672,6 +698,8 @@ class BatchedHSQ(_BatchedBase):
         else:
             mode, seed, r_flat = native.RANDOM_OFF, 0, None
         self._batch.levels(wire_user, mode, seed, r_flat, write_error=errs is not None)
+        if graph_header is not None:
+            self._graph_tables_done()
         return True
 
 
@@ -737,10 +765,12 @@ class BatchedQSGD(_BatchedBase):
         """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place).
         graph_header, dense: see BatchedHSQ.encode."""
         if graph_header is not None:
-            _kernel_copy(self._dev, graph_header)
+            self._graph_tables(graph_header, dense)
         elif not self._upload(tensors, slot, 8, errs, dense):
             return False
-        self._batch.set_dense(self.dense_table_dev() if dense is not None else None, self.ndense)
+        else:
+            self._batch.set_dense(self.dense_table_dev() if dense is not None else None, self.ndense)
+            self._acc_clean = False
         if self.keyed:      # gq_rng = "keyed": every bucket's draws keyed by its norm, the seed never changes
             mode, seed = native.RANDOM_DEVICE_KEYED, (salt * 0x2545F4914F6CDD1D + 0x5851F42D4C957F2D) & (2 ** 63 - 1)
         elif self.counter and self._counter_seed(slot) is not None:      # gq_rng = "device": keyed by the slot's device step word
@@ -749,6 +779,8 @@ class BatchedQSGD(_BatchedBase):
             mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
             seed = (_next_seed() ^ salt) if self.random else 0
         self._batch.compress(wire_user, mode, seed, ef_scale if errs is not None else None)
+        if graph_header is not None:
+            self._graph_tables_done()
         return True
 
 
@@ -982,6 +1014,8 @@ class PSQuantizer(object):
                 step_key = (graph_key, self._apply_key(self._wire[:1]))
                 fent = self._step_graphs.get(step_key)
                 if fent is not None and fent[1] is not None:      # compress + decode-mean of this step in one launch
+                    for g in self._groups:
+                        g[2].ensure_clean()
                     fent[1].replay()
                     for g in self._groups:
                         g[2]._last_ptrs = None
@@ -992,6 +1026,8 @@ class PSQuantizer(object):
                     self.recorded += 1
                     return
             if plain_f32:
+                for g in self._groups:
+                    g[2].ensure_clean()
                 ent[1].replay()
                 for g in self._groups:
                     g[2]._last_ptrs = None      # the device header now holds this graph's table: the next eager call re-sends its own
