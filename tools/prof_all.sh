@@ -1,8 +1,7 @@
 #!/bin/bash
 # Everything profiles/ holds for one round, in one gpurun call:  gpurun --timeout 2400 -- 'bash tools/prof_all.sh r04'
 # -> gpurun_out/<tag>/{stats (rocprofv3 --kernel-trace --stats of bench.py), bench*.json, pmc_show.txt, stamps.txt, ...};
-# copy what is to be judged into profiles/.  Needs tools/exp/libgq_stamp.so / libgq_pfdstamp.so
-# (python tools/stamp_build.py; python tools/stamp_pfd.py) for the stamp sections.
+# copy what is to be judged into profiles/.  The stamp section reads the stamped twin build.py makes (libgq_hsq_clock.so).
 TAG=${1:-r04}
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
@@ -23,7 +22,7 @@ GQ_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_
 bash tools/pmc_any.sh $TAG tools/exp_time.py
 bash tools/pmc_overlap.sh $TAG tools/exp_time.py
 python tools/pmc_show.py $TAG > $O/pmc_show.txt 2>&1
-GQ_LIB_PATH=tools/exp/libgq_stamp.so python tools/stamp_read.py > $O/stamps.txt 2>&1
+GQ_LIB_PATH=gradient-quantization_amd/libgq_hsq_clock.so python tools/stamp_read.py > $O/stamps.txt 2>&1
 # 4. side measurements
 python tools/decode_r.py 1 2 4 8 16 > $O/decode_r.txt 2>&1
 python tools/hsq_batched_r.py > $O/hsq_batched_r.txt 2>&1
@@ -33,4 +32,8 @@ python tools/qsgd_r.py > $O/qsgd_r.txt 2>&1
 python tools/bench_resnet50.py > $O/resnet50_steps.txt 2>&1
 python tools/host_breakdown.py > $O/host_breakdown.txt 2>&1
 python tools/cpu_scaling.py > $O/cpu_scaling.txt 2>&1
+python tools/graph_pieces.py > $O/graph_pieces.txt 2>&1
+python tools/batched_vs_flat.py > $O/batched_vs_flat.txt 2>&1
+GQ_FUSE_STEP=0 python bench.py --workload resnet50 --no-workloads --traffic off > $O/bench_resnet50_two_graphs.json 2> /dev/null
+GQ_AGGREGATE=fma GQ_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_2ranks_gloo_fma.json 2> /dev/null
 ls $O
