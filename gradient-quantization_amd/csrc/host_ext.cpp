@@ -25,6 +25,7 @@ static py::tuple scan_grads(const py::list &parameters) {
     bool ok = true;
     c10::Device dev(c10::DeviceType::CPU);
     for (size_t i = 0; i < n; ++i) {
+        if (!THPVariable_Check(parameters[i].ptr())) throw py::type_error("scan_grads: the list holds something that is not a tensor");
         const at::Tensor &p = THPVariable_Unpack(parameters[i].ptr());
         const at::Tensor &g = p.grad();
         int64_t ptr = 0;
@@ -50,6 +51,8 @@ static void set_data(const py::list &objects, const py::list &values) {
     const size_t n = objects.size();
     if (values.size() != n) throw std::invalid_argument("set_data: the two lists differ in length");
     for (size_t i = 0; i < n; ++i) {
+        if (!THPVariable_Check(objects[i].ptr()) || !THPVariable_Check(values[i].ptr()))
+            throw py::type_error("set_data: the lists hold something that is not a tensor");
         const at::Tensor &o = THPVariable_Unpack(objects[i].ptr());
         const at::Tensor &v = THPVariable_Unpack(values[i].ptr());
         o.set_data(v);

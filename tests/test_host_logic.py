@@ -642,6 +642,10 @@ def test_host_helper_walks_match_the_python_walks():
         assert p.grad is o and p.grad.data_ptr() == v.data_ptr() and torch.equal(p.grad, v)
     with pytest.raises(Exception):
         H.set_data(grads, new[:-1])
+    with pytest.raises(TypeError):
+        H.scan_grads(params[:2] + [None])
+    with pytest.raises(TypeError):
+        H.set_data(grads, new[:-1] + [3])
     params[3].grad = torch.zeros(2, 7).t()            # same shape, not contiguous
     assert not H.scan_grads(params)[2]
     params[3].grad = None

@@ -38,6 +38,7 @@ hdr_dev = hdr.to(dev)
 def copy(): grp._dev.copy_(hdr, non_blocking=True)
 def copy_dd(): grp._dev.copy_(hdr_dev, non_blocking=True)
 def copy_k(): torch.bitwise_or(hdr_dev, 0, out=grp._dev)
+def reset(): grp._acc_clean = False; grp.ensure_clean()
 def enc(): grp._batch.encode(wire, None, -1)
 def lev(): grp._batch.levels(wire, mode, seed or 0, None)
 def dec(): grp._batch.decode(q._wire[:1], 1, out)
@@ -68,7 +69,9 @@ def timed(graphs, reps=300):
 cases = [("record [copy, encode, levels] + apply [decode, mean]  (header from pinned host memory)", [[copy, enc, lev], [dec, mean]]),
          ("record [device-to-device copy, encode, levels] + apply [decode, mean]", [[copy_dd, enc, lev], [dec, mean]]),
          ("[device-to-device copy]", [[copy_dd]]),
-         ("record [copy by an elementwise kernel, encode, levels] + apply [decode, mean]  (the library since round 4)", [[copy_k, enc, lev], [dec, mean]]),
+         ("record [copy by an elementwise kernel, encode, levels] + apply [decode, mean]", [[copy_k, enc, lev], [dec, mean]]),
+         ("record [encode, levels, accumulator reset kernel] + apply [decode, mean]  (the library: a graph reads its own tables)", [[enc, lev, reset], [dec, mean]]),
+         ("one graph [encode, levels, reset, decode, mean]  (the library, one rank and one user)", [[enc, lev, reset, dec, mean]]),
          ("one graph [copy, encode, levels, decode, mean]", [[copy, enc, lev, dec, mean]]),
          ("no header copy: [encode, levels] + [decode, mean]", [[enc, lev], [dec, mean]]),
          ("no mean launch: [copy, encode, levels] + [decode]", [[copy, enc, lev], [dec]]),
