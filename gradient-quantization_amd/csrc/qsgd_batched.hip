@@ -558,6 +558,25 @@ template <int R>
 static void launch_qb4_r(const int64_t *seg_table, const int32_t *bucket_seg, int64_t nbuckets, int nseg, int n_bit,
                          const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st);
 
+// One resident wave of workgroups for `kernel` (the occupancy API) instead of a fixed 8 per CU: the 4-bit compress kernel
+// holds 5-6 waves per SIMD (74-84 registers), so a quarter of an 8-per-CU grid queued behind the resident workgroups.
+// (Measured: no difference for the ResNet-50 list, 36.7 us either way -- the kernel is bound by VALU issue, the quarter-rate
+// v_mul_lo_u32 of the draws and v_rcp_f32 / v_div_* of the IEEE division; a software-pipelined loop, the next item's
+// elements requested before the current item's arithmetic, cost 104 registers / 4 waves per SIMD and ran 41.5 us:
+// profiles/r04_qsgd_pipeline.txt.)
+template <typename KernelT>
+static int64_t qb_grid_resident(KernelT kernel, int64_t nitems) {
+    static const int bpc = [&] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, QB_THREADS, 0) != hipSuccess || n < 1) n = 8;
+        return n;
+    }();
+    int64_t blocks = (nitems + (QB_THREADS / 64) - 1) / (QB_THREADS / 64);
+    const int64_t cap = (int64_t)cu_count() * bpc;
+    if (blocks > cap) blocks = cap;
+    return blocks < 1 ? 1 : blocks;
+}
+
 static inline int64_t qb_grid(int64_t nbuckets) {
     int64_t blocks = (nbuckets + (QB_THREADS / 64) - 1) / (QB_THREADS / 64);
     const int64_t cap = (int64_t)cu_count() * 8;
@@ -568,7 +587,8 @@ static inline int64_t qb_grid(int64_t nbuckets) {
 template <int R>
 static void launch_qb4_r(const int64_t *seg_table, const int32_t *bucket_seg, int64_t nbuckets, int nseg, int n_bit,
                          const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_decode_sum_batched4_r_kernel<R>), dim3((unsigned)qb_grid((nbuckets + 3) / 4)),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_decode_sum_batched4_r_kernel<R>),
+                       dim3((unsigned)qb_grid_resident(qsgd_decode_sum_batched4_r_kernel<R>, (nbuckets + 3) / 4)),
                        dim3(QB_THREADS), 0, st, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride, out, plain);
 }
 
@@ -609,11 +629,13 @@ static int qsgd_compress_batched(const char *what, const int64_t *seg_table, con
     const int bits = gq_qsgd_code_bits(n_bit, random_mode);
     if (!bits) return fail(GQ_ERR_UNSUPPORTED, "%s: n_bit %d has no packed format", what, n_bit);
     if (bits == 4 && nseg <= QB_LDS_SEGS) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched4_kernel<EF, true>), dim3((unsigned)qb_grid((nbuckets + 3) / 4)),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched4_kernel<EF, true>),
+                           dim3((unsigned)qb_grid_resident(qsgd_compress_batched4_kernel<EF, true>, (nbuckets + 3) / 4)),
                            dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nseg, nbuckets, n_bit,
                            random_mode, seed, ef_scale, wire, dense_table, ndense);
     } else if (bits == 4) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched4_kernel<EF, false>), dim3((unsigned)qb_grid((nbuckets + 3) / 4)),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched4_kernel<EF, false>),
+                           dim3((unsigned)qb_grid_resident(qsgd_compress_batched4_kernel<EF, false>, (nbuckets + 3) / 4)),
                            dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nseg, nbuckets, n_bit,
                            random_mode, seed, ef_scale, wire, dense_table, ndense);
     } else {
