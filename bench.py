@@ -821,8 +821,9 @@ def list_workloads(args, torch, np, native, dev, steps=150, warm=40):
             ms = (time.perf_counter() - t0) / steps * 1e3
             res["ms_per_step_graph" if graph else "ms_per_step_eager"] = ms
             if graph:
-                res["graphs_captured"] = [sum(1 for e in q._rec_graphs.values() if e[1] is not None),
-                                          sum(1 for e in q._apply_graphs.values() if e[1] is not None)]
+                res["graphs_captured"] = {"record": sum(1 for e in q._rec_graphs.values() if e[1] is not None),
+                                          "apply": sum(1 for e in q._apply_graphs.values() if e[1] is not None),
+                                          "whole_step": sum(1 for e in q._step_graphs.values() if e[1] is not None)}
                 continue
             c0 = native.CALLS[0]
             step(warm + steps)
@@ -865,7 +866,7 @@ def list_workloads(args, torch, np, native, dev, steps=150, warm=40):
            "resnet50_real": one(NearestNeighborCompressor, hsq_kw, real, True),
            "note": ("ResNet-50/CIFAR parameter list, %d elements in 161 tensors (76 through the codebook / the bucket quantiser, 85 of "
                     "<= 1000 elements as f32), one rank, PSQuantizer.record + apply per step, %d timed steps after %d; ms_per_step_graph: the "
-                    "library's default (HIP graph replay, draws keyed by device step words), ms_per_step_eager: gq_graph off; kernel_ms: "
+                    "library's default (HIP graph replay -- record + apply as ONE graph per step at one rank and one user --, draws keyed by device step words), ms_per_step_eager: gq_graph off; kernel_ms: "
                     "HSQ = HIP events attached to the multi-tensor encode's dispatch on 8 eager steps, QSGD = the one compress launch "
                     "(events around 50 back-to-back launches); frac = algorithmic bytes of the compressed tensors / kernel_ms / 8 TB/s; "
                     "resnet50_real: gradients of driver.ResNet50 back-propagated from seeded synthetic CIFAR batches of 128 (three lists "

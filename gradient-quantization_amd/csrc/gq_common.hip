@@ -111,9 +111,17 @@ GQ_API int gq_sub(const float *grad, const float *decoded, float *err, int64_t n
 
 // ---- mean of R rows (the aggregate of identity-compressed tensors) -------------------------------------------
 namespace gq {
+// (reset_dst <- reset_src, reset_words 64-bit words: the accumulators the NEXT step's kernels fold into go back to their empty
+// state in the step's last launch -- see gq_mean_rows in gq_hsq.h)
+__device__ __forceinline__ void copy_reset_words(uint64_t *__restrict__ dst, const uint64_t *__restrict__ src, int words) {
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+}
 __global__ __launch_bounds__(256) void mean_rows_kernel(const uint8_t *__restrict__ rows, int64_t row_stride_bytes, int R,
-                                                        int64_t n, float *__restrict__ out, uint64_t *rng_state, int rng_pairs) {
+                                                        int64_t n, float *__restrict__ out, uint64_t *rng_state, int rng_pairs,
+                                                        uint64_t *reset_dst, const uint64_t *reset_src, int reset_words) {
     bump_rng_counter(rng_state, rng_pairs);
+    copy_reset_words(reset_dst, reset_src, reset_words);
     const MeanDiv md = mean_div_of(R, true);
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -122,19 +130,25 @@ __global__ __launch_bounds__(256) void mean_rows_kernel(const uint8_t *__restric
         out[i] = mean_div(acc, md);   // (+0 + row 0 + row 1 + ...) / R, rows ascending, a true division: torch's CPU mean
     }
 }
-__global__ void rng_step_kernel(uint64_t *rng_state, int rng_pairs) { bump_rng_counter(rng_state, rng_pairs); }
+__global__ void rng_step_kernel(uint64_t *rng_state, int rng_pairs, uint64_t *reset_dst, const uint64_t *reset_src, int reset_words) {
+    bump_rng_counter(rng_state, rng_pairs);
+    copy_reset_words(reset_dst, reset_src, reset_words);
+}
 }  // namespace gq
 
 GQ_API int gq_mean_rows(const void *rows, int64_t row_stride_bytes, int R, int64_t n, float *out, uint64_t *rng_state,
-                        int rng_pairs, void *stream) {
-    if (R < 1 || n < 0 || (n > 0 && (!rows || !out)) || (row_stride_bytes & 3) != 0 || (rng_state && (rng_pairs < 1 || rng_pairs > 256)))
+                        int rng_pairs, uint64_t *reset_dst, const uint64_t *reset_src, int reset_words, void *stream) {
+    if (R < 1 || n < 0 || (n > 0 && (!rows || !out)) || (row_stride_bytes & 3) != 0 || (rng_state && (rng_pairs < 1 || rng_pairs > 256)) ||
+        reset_words < 0 || (reset_words > 0 && (!reset_dst || !reset_src)))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_mean_rows: bad arguments");
-    if (n == 0 && !rng_state) return GQ_OK;
+    if (n == 0 && !rng_state && reset_words == 0) return GQ_OK;
     if (n == 0)
-        hipLaunchKernelGGL(gq::rng_step_kernel, dim3(1), dim3(256), 0, gq::as_stream(stream), rng_state, rng_pairs);
+        hipLaunchKernelGGL(gq::rng_step_kernel, dim3(1), dim3(256), 0, gq::as_stream(stream), rng_state, rng_state ? rng_pairs : 0,
+                           reset_dst, reset_src, reset_words);
     else
         hipLaunchKernelGGL(gq::mean_rows_kernel, dim3(gq::grid_for(n, 256)), dim3(256), 0, gq::as_stream(stream),
-                           static_cast<const uint8_t *>(rows), row_stride_bytes, R, n, out, rng_state, rng_pairs);
+                           static_cast<const uint8_t *>(rows), row_stride_bytes, R, n, out, rng_state, rng_pairs, reset_dst,
+                           reset_src, reset_words);
     GQ_CHECK_LAUNCH("gq_mean_rows");
     return GQ_OK;
 }

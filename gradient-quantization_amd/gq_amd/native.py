@@ -358,10 +358,20 @@ def hsq_batched_path(d, K, code_dtype, nseg=1):
     return int(lib().gq_hsq_batched_path(ctypes.byref(s)))
 
 
-def mean_rows(rows, out, rng_state=None):
+def _reset_args(reset):
+    """reset = (dst, src): int64 device tensors of one size (accumulators, their empty state), or None."""
+    if reset is None:
+        return ctypes.c_void_p(0), ctypes.c_void_p(0), ctypes.c_int(0)
+    dst, src = reset
+    assert dst.dtype == torch.int64 and src.dtype == torch.int64 and dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
+    return _dev_ptr(dst, torch.int64, "reset_dst"), _dev_ptr(src, torch.int64, "reset_src"), ctypes.c_int(int(dst.numel()))
+
+
+def mean_rows(rows, out, rng_state=None, reset=None):
     """out[i] = (+0 + rows[0, i] + ... + rows[R-1, i]) / R for a [R, n] float32 view whose rows may be strided (the dense
     region of the gathered wire): torch.stack(...).mean(0) with the CPU's arithmetic.  rng_state (int64 [pairs, 2], the
-    { seed, step } words of RANDOM_DEVICE_COUNTER): the same launch adds one to every step word."""
+    { seed, step } words of RANDOM_DEVICE_COUNTER): the same launch adds one to every step word.  reset = (dst, src): it
+    also copies src over dst (the next step's accumulators back to their empty state)."""
     assert rows.dtype == torch.float32 and rows.dim() == 2 and rows.stride(1) == 1
     R, n = int(rows.shape[0]), int(rows.shape[1])
     stride = int(rows.stride(0)) * 4 if R > 1 else n * 4
@@ -369,14 +379,15 @@ def mean_rows(rows, out, rng_state=None):
         raise GQNativeError("rows are on %s but the current device is cuda:%d" % (rows.device, torch._C._cuda_getDevice()))
     sp, pairs = (ctypes.c_void_p(rng_state.data_ptr()), int(rng_state.shape[0])) if rng_state is not None else (ctypes.c_void_p(0), 0)
     _check(lib().gq_mean_rows(ctypes.c_void_p(rows.data_ptr()), ctypes.c_int64(stride), ctypes.c_int(R), ctypes.c_int64(n),
-                                   _dev_ptr(out, torch.float32, "out"), sp, ctypes.c_int(pairs), _stream()), "gq_mean_rows")
+                                   _dev_ptr(out, torch.float32, "out"), sp, ctypes.c_int(pairs), *_reset_args(reset), _stream()), "gq_mean_rows")
 
 
-def rng_step(rng_state):
-    """step += 1 in every { seed, step } pair of rng_state (int64 [pairs, 2]; RANDOM_DEVICE_COUNTER)."""
+def rng_step(rng_state, reset=None):
+    """step += 1 in every { seed, step } pair of rng_state (int64 [pairs, 2]; RANDOM_DEVICE_COUNTER); reset: see mean_rows."""
     assert rng_state.dtype == torch.int64 and rng_state.dim() == 2 and rng_state.shape[1] == 2 and rng_state.is_contiguous()
     _check(lib().gq_mean_rows(ctypes.c_void_p(0), ctypes.c_int64(0), ctypes.c_int(1), ctypes.c_int64(0), ctypes.c_void_p(0),
-                              ctypes.c_void_p(rng_state.data_ptr()), ctypes.c_int(int(rng_state.shape[0])), _stream()), "gq_mean_rows (step)")
+                              ctypes.c_void_p(rng_state.data_ptr()), ctypes.c_int(int(rng_state.shape[0])), *_reset_args(reset), _stream()),
+           "gq_mean_rows (step)")
 
 
 

@@ -454,9 +454,14 @@ class _BatchedBase(object):
         self._batch.set_dense(graph_header[self._dense_at:].view(self.ndense, 3) if (dense is not None and self.ndense) else None,
                               self.ndense)
 
-    def _graph_tables_done(self):
+    def _graph_tables_done(self, defer=None):
+        """defer (a list): the reset is left to the caller -- (accumulators, their empty state) is appended -- who folds it
+        into a launch that runs anyway behind this group's last one (the aggregate's gq_mean_rows in a whole-step graph)."""
         if self._resets:
-            _kernel_copy(self._dev[self._table_words:self._dense_at], self._acc_init)
+            if defer is not None:
+                defer.append((self._dev[self._table_words:self._dense_at], self._acc_init))
+            else:
+                _kernel_copy(self._dev[self._table_words:self._dense_at], self._acc_init)
         self._batch.set_table(self._dev[:self._table_words])
 
     def ensure_clean(self):
@@ -662,7 +667,7 @@ class BatchedHSQ(_BatchedBase):
         return (not self.random or self.keyed or (self.counter and self.rng_pairs is not None)) and not self.reference_draws \
             and self._batch.path != 0
 
-    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None, dense=None):
+    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None, dense=None, defer_reset=None):
         """Compress `tensors` (one per batched parameter, in order) into one user's wire.
         dense: the identity-compressed tensors (the quantizer's, in its order) that the level launch also copies into the wire.
         Returns False (nothing launched) when a tensor is not a contiguous, 16-byte aligned f32
@@ -699,7 +704,7 @@ class BatchedHSQ(_BatchedBase):
             mode, seed, r_flat = native.RANDOM_OFF, 0, None
         self._batch.levels(wire_user, mode, seed, r_flat, write_error=errs is not None)
         if graph_header is not None:
-            self._graph_tables_done()
+            self._graph_tables_done(defer_reset)
         return True
 
 
@@ -761,7 +766,7 @@ class BatchedQSGD(_BatchedBase):
         can be a HIP graph node (see BatchedHSQ.graphable)."""
         return not self.random or self.keyed or (self.counter and self.rng_pairs is not None)
 
-    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None, dense=None):
+    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None, dense=None, defer_reset=None):
         """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place).
         graph_header, dense: see BatchedHSQ.encode."""
         if graph_header is not None:
@@ -780,7 +785,7 @@ class BatchedQSGD(_BatchedBase):
             seed = (_next_seed() ^ salt) if self.random else 0
         self._batch.compress(wire_user, mode, seed, ef_scale if errs is not None else None)
         if graph_header is not None:
-            self._graph_tables_done()
+            self._graph_tables_done(defer_reset)
         return True
 
 
@@ -1077,7 +1082,7 @@ class PSQuantizer(object):
                 codec.encode_into(grad, wire, off, salt, **self._slice(draws, i))
         self.recorded += 1
 
-    def _record_launches(self, all_grads, wire, slot, user, salt, scale, draws, dev, headers=None):
+    def _record_launches(self, all_grads, wire, slot, user, salt, scale, draws, dev, headers=None, defer_resets=None):
         """The multi-tensor launches of a record (+ the dense tensors' copy into the wire) -> the set of parameters served.
         headers (stream capture): one device-resident header per group, see BatchedHSQ.encode."""
         skip = set()
@@ -1102,7 +1107,7 @@ class PSQuantizer(object):
             hdr = headers[len(skip_groups)] if headers is not None else None
             skip_groups.append(obj)
             dense = list(self._pick_dense(all_grads)) if obj.ndense else None
-            if obj.encode(grads, wire, slot, salt, errs, scale, draws=draws, graph_header=hdr, dense=dense):
+            if obj.encode(grads, wire, slot, salt, errs, scale, draws=draws, graph_header=hdr, dense=dense, defer_reset=defer_resets):
                 skip.update(idxs)
                 if dense is not None:
                     skip.update(self.dense_idx)      # (copied by that launch)
@@ -1167,8 +1172,9 @@ class PSQuantizer(object):
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers)
-                decoded = self._decode_all(self._wire[:1], False, ())
+                resets = []      # the groups' accumulator resets ride in the step's last launch (gq_mean_rows)
+                self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers, defer_resets=resets)
+                decoded = self._decode_all(self._wire[:1], False, (), resets=resets)
             fent[1], fent[2] = graph, decoded
         except Exception as e:      # the two-graph replay keeps working
             self._fuse_steps = False
@@ -1192,7 +1198,7 @@ class PSQuantizer(object):
         o = self._draw_off[i]
         return {"r": draws[0][o:o + self.codecs[i].M]}
 
-    def _decode_all(self, gathered, two_phase, pending=(), plain=False):
+    def _decode_all(self, gathered, two_phase, pending=(), plain=False, resets=None):
         """Mean of the R = gathered.shape[0] user payloads for every parameter (ps_quantizer.py:47-61),
         as a list of tensors in parameter order.  `pending`: the transfers that fill `gathered`
         (exchange.WireExchange.start) -- one, or one per byte range for a split / pipelined exchange, in which case the
@@ -1272,13 +1278,16 @@ class PSQuantizer(object):
                 self._dense_mean[k].copy_(rows[0])      # the ring's hop: the payload as it is (a -0 stays -0)
             elif rows.device.type == "cuda":
                 # stack().mean(0) with the CPU's arithmetic (true division); the same launch steps the draws' step words
-                native.mean_rows(rows, self._dense_mean[k], rng_state=self._rng_state if step_rng else None)
+                native.mean_rows(rows, self._dense_mean[k], rng_state=self._rng_state if step_rng else None,
+                                 reset=resets.pop(0) if resets else None)
                 step_rng = False
             else:
                 torch.mean(rows, dim=0, out=self._dense_mean[k])   # stack().mean(0) of the reference, all at once
             sources.append((self.dense_idx, self._dense_views[k]))
         if step_rng:        # no identity-compressed tensors to average (or the ring's plain hop): a launch of its own
-            native.rng_step(self._rng_state)
+            native.rng_step(self._rng_state, reset=resets.pop(0) if resets else None)
+        for dst, src in (resets or ()):      # (whole-step capture) what no launch of the aggregate took along
+            _kernel_copy(dst, src)
         if not single and not done:
             # everything came out of multi-tensor launches: the result is a fixed interleaving of a few PERSISTENT view lists
             # (two output buffers per group used in turn, their per-tensor views built once), so the parameter-ordered

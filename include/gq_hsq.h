@@ -88,7 +88,7 @@ size_t gq_hsq_workspace_bytes(int64_t M);
 #define GQ_AGGREGATE_FMA 0x100
 
 /* Library / device identification. */
-int gq_abi_version(void);            /* 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words); 2: the round-3 descriptor form of the multi-tensor entry points */
+int gq_abi_version(void);            /* 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words and takes reset words; gq_hsq_batch / gq_qsgd_batch carry the dense table); 2: the round-3 descriptor form of the multi-tensor entry points */
 const char *gq_last_error(void);     /* text of the calling thread's last failure (the library's only per-thread state) */
 /* Fills CU count and the gcnArchName (e.g. "gfx950:sramecc+:xnack-") of `device`. */
 int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
@@ -283,8 +283,12 @@ int gq_sub(const float *grad, const float *decoded, float *err, int64_t n, void 
 /* rng_state != NULL (GQ_RANDOM_DEVICE_COUNTER): the same launch adds one to the step words of rng_pairs (1 .. 256)
  * consecutive { uint64 seed, uint64 step } pairs -- a caller keeps one pair per (tensor group, user slot) and steps them
  * once per aggregate; with n == 0 that is all the call does. */
+/* reset_words > 0: the same launch also copies reset_words 64-bit words reset_src -> reset_dst (device memory): the
+ * accumulators the next step's multi-tensor kernels fold into (gq_hsq_batch.seg_minmax, wide QSGD norm words) go back to
+ * their empty state in the step's LAST launch instead of a copy in front of its first -- what a replayed HIP graph of a
+ * whole step wants (every extra node costs ~4 us). */
 int gq_mean_rows(const void *rows, int64_t row_stride_bytes, int R, int64_t n, float *out, uint64_t *rng_state, int rng_pairs,
-                 void *stream);
+                 uint64_t *reset_dst, const uint64_t *reset_src, int reset_words, void *stream);
 
 /*
  * QSGD compress -- replaces qsgd_compressor.py:47-64.  `grad` is Mb buckets of d floats.
