@@ -432,6 +432,21 @@ def _run_quantizer(shapes, users, seed, grad_scale=1e-2, **argkw):
     return q, [p.grad.data.clone() for p in params]
 
 
+@pytest.mark.parametrize("c_dim", [16, 32])
+def test_many_small_tensors_in_one_workgroups_run_equal_per_tensor_path(c_dim):
+    """The multi-tensor encodes fold (min, max) per workgroup in a 64-tensor table in LDS, tensors beyond it straight into
+    the global words (hsq_encode_pf.hip / hsq_encode_pfd.hip, s_mm).  150 one-tile tensors in front of a 20 M-element one:
+    the first workgroup's run of ~76 tiles covers 76 tensors -- 64 through the table, the rest through the fallback -- and the
+    big tensor is met by every other workgroup.  Wire (codes, levels, lb / ub) and aggregate equal the per-tensor kernels."""
+    shapes = [(64 * c_dim,)] * 150 + [(19531 * 64 * c_dim,)] + [(64 * c_dim,)] * 3
+    qb, gb = _run_quantizer(shapes, 1, 5, c_dim=c_dim)
+    qp, gp = _run_quantizer(shapes, 1, 5, c_dim=c_dim, gq_no_batch=True)
+    assert qb._groups and qb._groups[0][2].ready and not qp._groups
+    assert torch.equal(qb._wire, qp._wire)
+    for a, b in zip(gb, gp):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 def test_batched_quantizer_equals_per_tensor_path():
     """One launch for all tensors (segment table) == the per-tensor kernels, bit for bit."""
     shapes = RESNET50_COMPRESSED + RESNET50_SMALL
