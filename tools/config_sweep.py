@@ -12,7 +12,7 @@ from gq_amd.quantizers import Quantizer
 shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "resnet50_cifar_shapes.json")))["parameter_shapes"]
 
 
-def run(comp, users=1, steps=5, **kw):
+def run(comp, users=1, steps=20, **kw):
     base = dict(c_dim=16, k_bit=8, n_bit=6, no_cuda=False, random=1, ef=False, two_phase=False, scale="exp",
                 num_users=users, mode="ps", cr=256)
     base.update(kw)
@@ -28,7 +28,7 @@ def run(comp, users=1, steps=5, **kw):
                 p.grad = g
             q.record(u, epoch=1)
         q.apply()
-    for _ in range(2):
+    for _ in range(14):      # (graph replay is the default: its captures happen in the first dozen steps)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
