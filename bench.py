@@ -865,7 +865,7 @@ def list_workloads(args, torch, np, native, dev, steps=150, warm=40):
            "qsgd": one(QSGDCompressor, qsgd_kw, synth, False),
            "resnet50_real": one(NearestNeighborCompressor, hsq_kw, real, True),
            "note": ("ResNet-50/CIFAR parameter list, %d elements in 161 tensors (76 through the codebook / the bucket quantiser, 85 of "
-                    "<= 1000 elements as f32), one rank, PSQuantizer.record + apply per step, %d timed steps after %d; ms_per_step_graph: the "
+                    "<= 1000 elements as f32), one rank, PSQuantizer.record + apply per step (three input lists in turn, put under the parameters' existing .grad objects by the library's C++ helper inside the timed region), %d timed steps after %d; ms_per_step_graph: the "
                     "library's default (HIP graph replay -- record + apply as ONE graph per step at one rank and one user --, draws keyed by device step words), ms_per_step_eager: gq_graph off; kernel_ms: "
                     "HSQ = HIP events attached to the multi-tensor encode's dispatch on 8 eager steps, QSGD = the one compress launch "
                     "(events around 50 back-to-back launches); frac = algorithmic bytes of the compressed tensors / kernel_ms / 8 TB/s; "
@@ -1004,7 +1004,8 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
                     + "decode-mean, small tensors dense), host launch time included",
         "prewarm_steps": prewarm,
         "config": {"workload": cfg, "elements_per_rank": n, "ranks": world, "wire_bytes_per_rank": q.wire_bytes_per_user(),
-                   "inputs": "3 gradient lists used in turn through fresh tensor objects, N(0,1)*1e-3",
+                   "inputs": "3 gradient lists used in turn, N(0,1)*1e-3: before every step the next list is put under the parameters' "
+                             "existing .grad objects (in place, as autograd writes gradients) by the library's C++ helper, inside the timed region",
                    "launches": ("gq_graph: record() and apply() replay their device work from HIP graphs (one per set of gradient "
                                 "addresses / output buffer; %d + %d captured), stochastic rounding with draws keyed by each tensor's "
                                 "(lb, ub) / each bucket's norm (gq_rng = 'keyed')" % (
