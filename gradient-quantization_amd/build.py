@@ -79,11 +79,18 @@ def build(force=False, verbose=False):
     link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(link))
-    host = build_host_ext(verbose, wait=False)      # g++ against libtorch: ~25 s, next to the link and the clock twin
-    subprocess.check_call(link)
-    build_clock_lib(objs, verbose)
-    if host[1].wait() != 0:
-        raise subprocess.CalledProcessError(host[1].returncode, host[0])
+    host = None
+    try:
+        host = build_host_ext(verbose, wait=False)      # g++ against libtorch: ~25 s, next to the link and the clock twin
+    except Exception as e:      # (no libtorch headers, no g++): the helper is optional, quantizers.py walks in Python without it
+        print("build.py: host helper not built (%s); gq_amd falls back to its Python walks" % (e,), file=sys.stderr)
+    try:
+        subprocess.check_call(link)
+        build_clock_lib(objs, verbose)
+    finally:
+        if host is not None and host[1].wait() != 0:     # (always reaped, also when the link above raised)
+            print("build.py: host helper failed to compile (exit %d); gq_amd falls back to its Python walks" % host[1].returncode,
+                  file=sys.stderr)
     return LIB
 
 

@@ -153,6 +153,8 @@ GQ_API int gq_qsgd_compress_batched(const gq_qsgd_batch *b, uint8_t *wire, int r
     if (b->bits != gq_qsgd_code_bits(b->n_bit, random_mode))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched: bits = %d, but n_bit %d with random_mode %d packs to %d",
                         b->bits, b->n_bit, random_mode, gq_qsgd_code_bits(b->n_bit, random_mode));
+    if (random_mode == GQ_RANDOM_DEVICE_COUNTER && (seed == 0 || (seed & 7) != 0))   // (the kernel dereferences it)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched: GQ_RANDOM_DEVICE_COUNTER takes the address of two device words as `seed`");
     const int ef = isnan(ef_scale) ? 0 : 1;
     const float scale = ef ? ef_scale : 0.0f;
     if (b->wide)

@@ -234,10 +234,27 @@ __device__ __forceinline__ float fmac_quad(float acc, float n_own, float c) {
     if constexpr (K == 3) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(n_own), "v"(c));
     return acc;
 }
+// Four of them on one norm as ONE asm block behind its own `s_nop 1`: whatever the compiler puts in front of the block (a
+// copy or a spill reload of n_own) has left the VALU two wait states before the first DPP read, and nothing can be
+// scheduled between the four.  (The single-instruction form above relies on quad_norm_ready() alone; the kernels use this.)
 template <int K>
 __device__ __forceinline__ f32x4 fmac_quad4(const f32x4 &acc, float n_own, const f32x4 &c) {
-    return f32x4{fmac_quad<K>(acc[0], n_own, c[0]), fmac_quad<K>(acc[1], n_own, c[1]), fmac_quad<K>(acc[2], n_own, c[2]),
-                 fmac_quad<K>(acc[3], n_own, c[3])};
+    static_assert(K >= 0 && K < 4, "lane of the quad");
+    float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+#define GQ_FMAC_QUAD4(QP)                                                                     \
+    asm("s_nop 1\n\t"                                                                         \
+        "v_fmac_f32_dpp %0, %4, %5 quad_perm:" QP " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_fmac_f32_dpp %1, %4, %6 quad_perm:" QP " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_fmac_f32_dpp %2, %4, %7 quad_perm:" QP " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_fmac_f32_dpp %3, %4, %8 quad_perm:" QP " row_mask:0xf bank_mask:0xf bound_ctrl:1"     \
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)                                              \
+        : "v"(n_own), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]))
+    if constexpr (K == 0) GQ_FMAC_QUAD4("[0,0,0,0]");
+    if constexpr (K == 1) GQ_FMAC_QUAD4("[1,1,1,1]");
+    if constexpr (K == 2) GQ_FMAC_QUAD4("[2,2,2,2]");
+    if constexpr (K == 3) GQ_FMAC_QUAD4("[3,3,3,3]");
+#undef GQ_FMAC_QUAD4
+    return f32x4{a0, a1, a2, a3};
 }
 
 }  // namespace gq

@@ -59,7 +59,25 @@ static void set_data(const py::list &objects, const py::list &values) {
     }
 }
 
+// set_grad_data(parameters, values): parameters[i].grad.data = values[i], with `param.grad` evaluated NOW, as
+// ps_quantizer.py:63 does -- a caller that replaced a parameter's .grad object between the last record() and apply()
+// gets the mean in the object it holds now.  (p.grad() in C++ builds no Python object: this costs what set_data on the
+// remembered objects did.)  A parameter without a gradient raises AttributeError, as `None.data = g` does.
+static void set_grad_data(const py::list &parameters, const py::list &values) {
+    const size_t n = parameters.size();
+    if (values.size() != n) throw std::invalid_argument("set_grad_data: the two lists differ in length");
+    for (size_t i = 0; i < n; ++i) {
+        if (!THPVariable_Check(parameters[i].ptr()) || !THPVariable_Check(values[i].ptr()))
+            throw py::type_error("set_grad_data: the lists hold something that is not a tensor");
+        const at::Tensor &p = THPVariable_Unpack(parameters[i].ptr());
+        const at::Tensor &g = p.grad();
+        if (!g.defined()) throw py::attribute_error("'NoneType' object has no attribute 'data' (parameter " + std::to_string(i) + " has no .grad)");
+        g.set_data(THPVariable_Unpack(values[i].ptr()));
+    }
+}
+
 PYBIND11_MODULE(_gq_host, m) {
+    m.def("set_grad_data", &set_grad_data, "parameters[i].grad.data = values[i], .grad evaluated at the call");
     m.def("scan_grads", &scan_grads, "The .grad tensors of a parameter list, their addresses as a bytes key, and whether all are plain f32");
     m.def("set_data", &set_data, "objects[i].data = values[i]");
 }

@@ -625,7 +625,7 @@ static int qsgd_compress_batched(const char *what, const int64_t *seg_table, con
     if (!seg_table || !bucket_seg || !wire) return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
     if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE && random_mode != GQ_RANDOM_DEVICE_KEYED &&
         random_mode != GQ_RANDOM_DEVICE_COUNTER)
-        return fail(GQ_ERR_UNSUPPORTED, "%s: random_mode must be OFF, DEVICE or DEVICE_KEYED", what);
+        return fail(GQ_ERR_UNSUPPORTED, "%s: random_mode must be OFF, DEVICE, DEVICE_KEYED or DEVICE_COUNTER", what);
     const int bits = gq_qsgd_code_bits(n_bit, random_mode);
     if (!bits) return fail(GQ_ERR_UNSUPPORTED, "%s: n_bit %d has no packed format", what, n_bit);
     if (bits == 4 && nseg <= QB_LDS_SEGS) {

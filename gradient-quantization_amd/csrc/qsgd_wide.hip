@@ -330,7 +330,7 @@ GQ_INTERNAL int gqi_qsgd_wide_compress(const int64_t *seg_table, const int32_t *
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_compress_batched (wide): null pointer");
     if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE && random_mode != GQ_RANDOM_DEVICE_KEYED &&
         random_mode != GQ_RANDOM_DEVICE_COUNTER)
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched (wide): random_mode must be OFF, DEVICE or DEVICE_KEYED");
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched (wide): random_mode must be OFF, DEVICE, DEVICE_KEYED or DEVICE_COUNTER");
     const int bits = gq_qsgd_code_bits(n_bit, random_mode);
     if (!bits) return gq::fail(GQ_ERR_UNSUPPORTED, "gq_qsgd_compress_batched (wide): n_bit %d has no packed format", n_bit);
     hipStream_t st = gq::as_stream(stream);

@@ -464,6 +464,16 @@ class _BatchedBase(object):
                 _kernel_copy(self._dev[self._table_words:self._dense_at], self._acc_init)
         self._batch.set_table(self._dev[:self._table_words])
 
+    def _graph_tables_abort(self):
+        """A launch failed between _graph_tables and _graph_tables_done (an invalidated capture, a launch error): the callers
+        fall back to eager launches, which must not read their pointers from the graph's header.  The descriptor goes back to
+        the shared device header and the next eager encode re-validates and re-sends it (no reset kernel: the stream may be
+        in a broken capture; `_acc_clean = False` makes the next replay clean the accumulators first)."""
+        self._batch.set_table(self._dev[:self._table_words])
+        self._batch.set_dense(self.dense_table_dev(), self.ndense)
+        self._last_ptrs = self._last_eptrs = self._last_dptrs = None
+        self._acc_clean = False
+
     def ensure_clean(self):
         if self._resets and not self._acc_clean:
             _kernel_copy(self._dev[self._table_words:self._dense_at], self._acc_init)
@@ -572,12 +582,13 @@ class _BatchedBase(object):
         self._events[0] = ev
         self.ready = True
 
-    def roundtrip(self, tensors, slot, salt, errs=None, ef_scale=None, draws=None):
+    def roundtrip(self, tensors, slot, salt, errs=None, ef_scale=None, draws=None, rng_slot=None):
         """decompress(compress(t)) for every batched tensor in a few launches; None if not batchable.
-        With `errs`: t <- t + ef_scale*err in place first and err <- t - decoded afterwards."""
+        With `errs`: t <- t + ef_scale*err in place first and err <- t - decoded afterwards.
+        rng_slot: the { seed, step } pair the stochastic rounding draws from (default: the one of `slot`)."""
         if self._tmp_wire is None:
             self._tmp_wire = torch.zeros((1, self.user_bytes), dtype=torch.uint8, device=self.device)
-        if not self.encode(tensors, self._tmp_wire[0], slot, salt, errs, ef_scale, draws=draws):
+        if not self.encode(tensors, self._tmp_wire[0], slot, salt, errs, ef_scale, draws=draws, rng_slot=rng_slot):
             return None
         return self.decode_mean(self._tmp_wire, 1, plain=True)     # decompress(compress(t)) (ps_quantizer.py:52-61): a -0 stays -0
 
@@ -667,7 +678,8 @@ class BatchedHSQ(_BatchedBase):
         return (not self.random or self.keyed or (self.counter and self.rng_pairs is not None)) and not self.reference_draws \
             and self._batch.path != 0
 
-    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None, dense=None, defer_reset=None):
+    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None, dense=None, defer_reset=None,
+               rng_slot=None):
         """Compress `tensors` (one per batched parameter, in order) into one user's wire.
         dense: the identity-compressed tensors (the quantizer's, in its order) that the level launch also copies into the wire.
         Returns False (nothing launched) when a tensor is not a contiguous, 16-byte aligned f32
@@ -688,21 +700,27 @@ class BatchedHSQ(_BatchedBase):
             self._batch.set_dense(self.dense_table_dev() if dense is not None else None, self.ndense)
             self._acc_clean = False
         ef = ef_scale if errs is not None else None
-        self._batch.encode(wire_user, ef, self.profile_slot)
-        self.profile_slot = -1
-        if self.n_bit == 32:
-            mode, seed, r_flat = native.RANDOM_OFF, 0, None
-        elif self.reference_draws:
-            mode, seed, r_flat = native.RANDOM_GIVEN, 0, self._given_draws(draws)
-        elif self.keyed:
-            mode, seed, r_flat = native.RANDOM_DEVICE_KEYED, (salt * 0x2545F4914F6CDD1D + 0x5851F42D4C957F2D) & (2 ** 63 - 1), None
-        elif self.counter and self._counter_seed(slot) is not None:
-            mode, seed, r_flat = native.RANDOM_DEVICE_COUNTER, self._counter_seed(slot), None
-        elif self.random:
-            mode, seed, r_flat = native.RANDOM_DEVICE, _next_seed() ^ salt, None
-        else:
-            mode, seed, r_flat = native.RANDOM_OFF, 0, None
-        self._batch.levels(wire_user, mode, seed, r_flat, write_error=errs is not None)
+        rng_slot = slot if rng_slot is None else rng_slot
+        try:
+            self._batch.encode(wire_user, ef, self.profile_slot)
+            self.profile_slot = -1
+            if self.n_bit == 32:
+                mode, seed, r_flat = native.RANDOM_OFF, 0, None
+            elif self.reference_draws:
+                mode, seed, r_flat = native.RANDOM_GIVEN, 0, self._given_draws(draws)
+            elif self.keyed:
+                mode, seed, r_flat = native.RANDOM_DEVICE_KEYED, (salt * 0x2545F4914F6CDD1D + 0x5851F42D4C957F2D) & (2 ** 63 - 1), None
+            elif self.counter and self._counter_seed(rng_slot) is not None:
+                mode, seed, r_flat = native.RANDOM_DEVICE_COUNTER, self._counter_seed(rng_slot), None
+            elif self.random:
+                mode, seed, r_flat = native.RANDOM_DEVICE, _next_seed() ^ salt, None
+            else:
+                mode, seed, r_flat = native.RANDOM_OFF, 0, None
+            self._batch.levels(wire_user, mode, seed, r_flat, write_error=errs is not None)
+        except BaseException:
+            if graph_header is not None:
+                self._graph_tables_abort()
+            raise
         if graph_header is not None:
             self._graph_tables_done(defer_reset)
         return True
@@ -766,9 +784,11 @@ class BatchedQSGD(_BatchedBase):
         can be a HIP graph node (see BatchedHSQ.graphable)."""
         return not self.random or self.keyed or (self.counter and self.rng_pairs is not None)
 
-    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None, dense=None, defer_reset=None):
+    def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None, dense=None, defer_reset=None,
+               rng_slot=None):
         """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place).
-        graph_header, dense: see BatchedHSQ.encode."""
+        graph_header, dense, rng_slot: see BatchedHSQ.encode."""
+        rng_slot = slot if rng_slot is None else rng_slot
         if graph_header is not None:
             self._graph_tables(graph_header, dense)
         elif not self._upload(tensors, slot, 8, errs, dense):
@@ -778,12 +798,17 @@ class BatchedQSGD(_BatchedBase):
             self._acc_clean = False
         if self.keyed:      # gq_rng = "keyed": every bucket's draws keyed by its norm, the seed never changes
             mode, seed = native.RANDOM_DEVICE_KEYED, (salt * 0x2545F4914F6CDD1D + 0x5851F42D4C957F2D) & (2 ** 63 - 1)
-        elif self.counter and self._counter_seed(slot) is not None:      # gq_rng = "device": keyed by the slot's device step word
-            mode, seed = native.RANDOM_DEVICE_COUNTER, self._counter_seed(slot)
+        elif self.counter and self._counter_seed(rng_slot) is not None:      # gq_rng = "device": keyed by the slot's device step word
+            mode, seed = native.RANDOM_DEVICE_COUNTER, self._counter_seed(rng_slot)
         else:
             mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
             seed = (_next_seed() ^ salt) if self.random else 0
-        self._batch.compress(wire_user, mode, seed, ef_scale if errs is not None else None)
+        try:
+            self._batch.compress(wire_user, mode, seed, ef_scale if errs is not None else None)
+        except BaseException:
+            if graph_header is not None:
+                self._graph_tables_abort()
+            raise
         if graph_header is not None:
             self._graph_tables_done(defer_reset)
         return True
@@ -904,7 +929,6 @@ class PSQuantizer(object):
                 n += c.M
         self._draw_total = n
         self._draw_host = None
-        self._grad_objs = None
         self._assembled = {}
         self._plan = None
         self.capacity = max(1, int(args.num_users))
@@ -953,18 +977,22 @@ class PSQuantizer(object):
     def wire_bytes_per_user(self):
         return self.user_bytes
 
-    RNG_SLOTS = 17      # user slots with a { seed, step } pair of their own per group (16 users + the two-phase re-compress)
+    RNG_SLOTS = 17      # { seed, step } pairs per group: 16 user slots + the two-phase re-compress (the last one)
+    TWO_PHASE_RNG_SLOT = RNG_SLOTS - 1
 
     def _rng_pairs_for(self, device, group_index):
         """This group's rows of the quantizer's { seed, step } array (made on first use; seeds from torch's seed, the
-        rank, the group and the slot; steps start at 0)."""
+        rank, the group and the slot; steps start at 0).  The two-phase slot's seed leaves the rank out: the second
+        phase runs replicated on every rank and must round identically everywhere (ps_quantizer.py:52-61 runs it once,
+        on the server); the step words advance in lockstep on all ranks."""
         if self._rng_state is None or self._rng_state.device != device:
             world, rank = _dist_world(self.process_group)
             n = max(1, len(self._groups)) * self.RNG_SLOTS
             host = torch.zeros((n, 2), dtype=torch.int64)
             base = _next_seed()
             for i in range(n):
-                host[i, 0] = ((base ^ ((rank * 1000003 + i + 1) * 0x9E3779B97F4A7C15)) & (2 ** 63 - 1))
+                r = 0 if i % self.RNG_SLOTS == self.TWO_PHASE_RNG_SLOT else rank
+                host[i, 0] = ((base ^ ((r * 1000003 + i + 1) * 0x9E3779B97F4A7C15)) & (2 ** 63 - 1))
             self._rng_state = host.to(device)
         return self._rng_state[group_index * self.RNG_SLOTS:(group_index + 1) * self.RNG_SLOTS]
 
@@ -1001,10 +1029,9 @@ class PSQuantizer(object):
         salt = ((rank * 1000003 + user) * 0x9E3779B1) & (2 ** 62 - 1)
         skip = set()
         draws = self._draws(dev)
-        self._grad_objs = all_grads      # apply() rebinds .data of these very objects (161 fewer `param.grad` look-ups)
         # gq_graph: a record whose gradient addresses were seen before replays its device work as ONE graph launch
         graph_key = None
-        if (self.use_graphs and dev.type == "cuda" and not self._draw_total and slot < self.RNG_SLOTS
+        if (self.use_graphs and dev.type == "cuda" and not self._draw_total and slot < self.TWO_PHASE_RNG_SLOT
                 and all(g[2] is not None and g[2].ready and g[2].graphable() for g in self._groups)
                 and not torch.cuda.is_current_stream_capturing()):      # (inside a caller's own capture the launches are simply recorded)
             graph_key = (slot, user, self._wire.data_ptr(), scan[1] if scan is not None else tuple(map(_DATA_PTR, all_grads)))
@@ -1082,6 +1109,19 @@ class PSQuantizer(object):
                 codec.encode_into(grad, wire, off, salt, **self._slice(draws, i))
         self.recorded += 1
 
+    def _make_group(self, grp, dev):
+        """The multi-tensor launch object of one group, built the same way whoever needs it first (a record, or a ring rank
+        that decodes before it has encoded anything): dense copy table, draws' { seed, step } pairs, aggregate form."""
+        cls, idxs = grp[0], grp[1]
+        # the first group's compress launch also copies the identity-compressed tensors into the wire
+        dense = ([(self.offsets[i], self.codecs[i].numel) for i in self.dense_idx]
+                 if (grp is self._groups[0] and len(self.dense_idx) >= 2) else None)
+        obj = grp[2] = cls(self.codecs, self.offsets, idxs, dev, self.capacity, self.user_bytes, dense=dense)
+        obj.fma = bool(self.aggregate_fma and cls is BatchedHSQ)
+        if getattr(obj, "counter", False) and len(self._groups) * self.RNG_SLOTS <= 256:
+            obj.rng_pairs = self._rng_pairs_for(dev, self._groups.index(grp))
+        return obj
+
     def _record_launches(self, all_grads, wire, slot, user, salt, scale, draws, dev, headers=None, defer_resets=None):
         """The multi-tensor launches of a record (+ the dense tensors' copy into the wire) -> the set of parameters served.
         headers (stream capture): one device-resident header per group, see BatchedHSQ.encode."""
@@ -1090,13 +1130,7 @@ class PSQuantizer(object):
         for grp in (self._groups if dev.type == "cuda" else []):
             cls, idxs, obj = grp
             if obj is None:
-                # the first group's compress launch also copies the identity-compressed tensors into the wire
-                dense = ([(self.offsets[i], self.codecs[i].numel) for i in self.dense_idx]
-                         if (grp is self._groups[0] and len(self.dense_idx) >= 2) else None)
-                obj = grp[2] = cls(self.codecs, self.offsets, idxs, dev, self.capacity, self.user_bytes, dense=dense)
-                obj.fma = bool(self.aggregate_fma and cls is BatchedHSQ)
-                if getattr(obj, "counter", False) and len(self._groups) * self.RNG_SLOTS <= 256:
-                    obj.rng_pairs = self._rng_pairs_for(dev, self._groups.index(grp))
+                obj = self._make_group(grp, dev)
             pick = self._pick_group.get(id(grp))      # operator.itemgetter over the group's indices, built once
             if pick is None:
                 pick = self._pick_group[id(grp)] = operator.itemgetter(*idxs)     # (a group has at least two tensors)
@@ -1253,7 +1287,7 @@ class PSQuantizer(object):
                 # ps_quantizer.py:52-61, replicated on every rank (salt 0, same call count); with error
                 # feedback g += server_error and server_error = g - decoded happen inside the launches
                 serr = [self.parameters[i].server_error for i in idxs] if self.error_feedback else None
-                dec = obj.roundtrip(list(gs), self.capacity, 0, serr, 1.0, draws=draws2)
+                dec = obj.roundtrip(list(gs), self.capacity, 0, serr, 1.0, draws=draws2, rng_slot=self.TWO_PHASE_RNG_SLOT)
                 if dec is None:     # not batchable this step: per-tensor second phase below
                     for i, g in zip(idxs, gs):
                         done[i] = g
@@ -1323,6 +1357,7 @@ class PSQuantizer(object):
         return [done[i] for i in range(self.num_layers)]
 
     def apply(self, refresh_grads=False):
+        """ps_quantizer.py:46-65.  refresh_grads: accepted for callers of earlier versions; `param.grad` is always evaluated here."""
         if self.recorded == 0:
             return
         world, rank = _dist_world(self.process_group)
@@ -1384,20 +1419,15 @@ class PSQuantizer(object):
                         for g, t in zip(self._groups, after[0]):
                             g[2]._out_turn = t
                         self._dense_turn = after[1]
-        # ps_quantizer.py:63 `param.grad.data = g`: the tensor OBJECT that is the parameter's gradient keeps its identity and
-        # gets the mean as its data.  The objects are the ones the last record() read: nobody touches `param.grad` between
-        # the last record and apply in the reference's loop (main.py:230-232), and a caller that REPLACES a parameter's
-        # .grad object in between must call apply(refresh_grads=True) ("What apply() writes to"): the 161
-        # attribute look-ups are the step's single largest host cost and are not spent on a case the protocol does not have.
-        objs = self._grad_objs
-        if refresh_grads or objs is None or len(objs) != len(decoded):
-            objs = [p.grad for p in self.parameters]
-        if _HOST is not None and type(objs) is list and type(decoded) is list and len(objs) == len(decoded):
-            _HOST.set_data(objs, decoded)
+        # ps_quantizer.py:63 `param.grad.data = g`: `param.grad` is evaluated HERE, at apply time -- a caller that replaced a
+        # parameter's .grad object after the last record() gets the mean in the object it holds now.  The C++ helper reads
+        # p.grad() without building Python objects (the 161 attribute look-ups were the step's largest host cost, which is
+        # why earlier rounds rebound the objects record() had seen); without the helper the look-ups are paid.
+        if _HOST is not None and hasattr(_HOST, "set_grad_data") and type(decoded) is list and len(decoded) == len(self.parameters):
+            _HOST.set_grad_data(self.parameters, decoded)
         else:
-            for obj, g in zip(objs, decoded):
-                obj.data = g
-        self._grad_objs = None
+            for p, g in zip(self.parameters, decoded):
+                p.grad.data = g
         self.recorded = 0
 
     aggregate = apply
@@ -1455,7 +1485,7 @@ class RingQuantizer(PSQuantizer):
         segment tables (the layout part; pointers are not needed for a decode) must exist."""
         for grp in (self._groups if dev.type == "cuda" else []):
             if grp[2] is None:
-                grp[2] = grp[0](self.codecs, self.offsets, grp[1], dev, self.capacity, self.user_bytes)
+                self._make_group(grp, dev)
             if not grp[2].ready:
                 grp[2].upload_layout()
 

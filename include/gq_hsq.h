@@ -62,7 +62,8 @@ size_t gq_hsq_workspace_bytes(int64_t M);
                               is the ADDRESS of two device words { uint64 seed, uint64 step }: the launch's stream is keyed
                               by both, and gq_mean_rows adds one to `step` once per aggregate (apply).  The
                               launch's arguments never change (a HIP graph node), the draws do, whatever the gradients
-                              are, and a run is reproducible from the two words' initial values
+                              are, and a run is reproducible from the two words' initial values; a `seed` that is 0 or not 8-byte
+                              aligned is GQ_ERR_INVALID_ARG at both entry points
                               (probabilistic_scalar_compressor.py:22-26, qsgd_compressor.py:56-61 draw per call)          */
 
 /* level_bytes of the level / decode entry points: 1 | 2 | 4 = one uint8 / uint16 / int32 per level, 0 = the f32

@@ -64,7 +64,12 @@ if __name__ == "__main__":
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     local = int(sys.argv[7]) if len(sys.argv) > 7 else 2
-    q, params = build(local, mode, quant, ef=ef)
+    extra = {}      # argv[8]: more Namespace fields, "two_phase=1,random=1"
+    for kv in (sys.argv[8].split(",") if len(sys.argv) > 8 and sys.argv[8] else []):
+        k, v = kv.split("=")
+        extra[k] = int(v)
+    torch.manual_seed(1234)     # what "identical on every rank" (ps_quantizer.py:52-61 replicated) presupposes
+    q, params = build(local, mode, quant, ef=ef, **extra)
     res = run(q, params, local, rank * local)
     np.savez(out + "_rank%d.npz" % rank, **res)
     with open(out + "_rank%d_graphs.txt" % rank, "w") as f:      # (gq_graph: how many records / applies were captured)

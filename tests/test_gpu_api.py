@@ -2,6 +2,7 @@
 the HIP kernels: signatures and results against the golden vectors captured from the reference."""
 import glob
 import os
+import sys
 from argparse import Namespace
 
 import numpy as np
@@ -1253,6 +1254,64 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, mode, quant, ef):
     single = w.run_single_process(4, mode, quant, ef=ef)
     for k in single:
         assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
+
+
+def test_failed_capture_leaves_no_graph_table_behind():
+    """A launch that raises between _graph_tables() and _graph_tables_done() (an invalidated capture, a launch error) must not
+    leave the group's descriptor pointing at the graph's own header: the eager launches the quantizer falls back to would read
+    their gradient pointers from it.  After the failure the descriptor reads the shared device header again, the next eager
+    encode re-sends it, and the step's result equals a fresh quantizer's."""
+    sys.path.insert(0, HERE)
+    import _dist_worker_gpu as w
+    q, params = w.build(1, "ps", "hsq")
+    ref_q, ref_params = w.build(1, "ps", "hsq")
+    def step(qq, pp, st):
+        for p, gr in zip(pp, w.grads_for(0, st)):
+            p.grad = gr.cuda()
+        qq.record(0, epoch=1)
+        qq.apply()
+        return [p.grad.data.clone() for p in pp]
+    step(q, params, 0)
+    obj = q._groups[0][2]
+    shared = obj._dev.data_ptr()
+    assert obj._batch.keep_table.data_ptr() == shared
+    header = obj._host[obj._last_slot].to("cuda")
+    real_levels = obj._batch.levels
+    def boom(*a, **k):
+        raise RuntimeError("injected launch failure")
+    obj._batch.levels = boom
+    grads = [params[i].grad for i in obj.idxs]
+    dense = list(q._pick_dense([p.grad for p in params])) if obj.ndense else None
+    with pytest.raises(RuntimeError, match="injected"):
+        obj.encode(grads, q._wire[0], 0, 0, graph_header=header, dense=dense)
+    obj._batch.levels = real_levels
+    assert obj._batch.keep_table.data_ptr() == shared and obj._last_ptrs is None and not obj._acc_clean
+    for st in (1, 2, 3):
+        a, b = step(q, params, st), step(ref_q, ref_params, st)
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+
+
+@pytest.mark.parametrize("quant,ef,steps", [("hsq", False, 2), ("hsq", True, 5), ("qsgd", True, 5)])
+def test_two_ranks_two_phase_stochastic_rounding_agrees_across_ranks(tmp_path, quant, ef, steps):
+    """--two-phase --random 1 on two ranks: the second phase (ps_quantizer.py:52-61) is replicated on every rank, so its
+    stochastic rounding must draw the SAME numbers everywhere -- the { seed, step } pair of the two-phase slot leaves the
+    rank out (PSQuantizer._rng_pairs_for) -- or the replicas apply different gradients and, under error feedback, carry
+    different server residuals.  The applied gradients of every step are bit-equal on both ranks; steps >= 3 replay graphs."""
+    import subprocess
+    import sys
+    script = os.path.join(HERE, "_dist_worker_gpu.py")
+    out = str(tmp_path / "res")
+    port = 29700 + (os.getpid() % 1500) + {"hsq": 0, "qsgd": 7}[quant] + (13 if ef else 0)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GQ_TEST_STEPS=str(steps))
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", out, "ps", quant, "1" if ef else "0", "2", "two_phase=1,random=1"],
+                              env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r0, r1 = np.load(out + "_rank0.npz"), np.load(out + "_rank1.npz")
+    assert len(r0.files) == steps * 6
+    for k in r0.files:
+        assert np.array_equal(r0[k].view(np.uint32), r1[k].view(np.uint32)), "ranks disagree on " + k
 
 
 @pytest.mark.parametrize("exchange,users", [("direct", 2), ("split", 1), ("auto", 1), ("pipelined", 1)])

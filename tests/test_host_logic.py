@@ -669,3 +669,42 @@ def test_quantizer_results_do_not_depend_on_the_host_helper(oracle, monkeypatch)
     without = w.run_single_process(3, "ps")
     for k in with_helper:
         assert np.array_equal(with_helper[k].view(np.uint32), without[k].view(np.uint32)), k
+
+
+@pytest.mark.parametrize("helper", [True, False])
+def test_apply_writes_to_the_grad_object_the_parameter_holds_at_apply_time(oracle, monkeypatch, helper):
+    """ps_quantizer.py:63 `param.grad.data = g` evaluates `param.grad` when apply() runs: a caller that replaces a
+    parameter's .grad OBJECT between its last record() and apply() finds the mean in the object it holds then (with and
+    without the C++ helper's set_grad_data); a parameter whose .grad is gone raises AttributeError, as the reference does."""
+    from oracle_codec import oracle_codec_factory
+    from gq_amd import quantizers
+    from gq_amd.compressors import NearestNeighborCompressor
+    if not helper:
+        monkeypatch.setattr(quantizers, "_HOST", None)
+    else:
+        assert quantizers._HOST is not None and hasattr(quantizers._HOST, "set_grad_data")
+    torch.manual_seed(5)
+    params = [torch.nn.Parameter(torch.zeros(64, 32)), torch.nn.Parameter(torch.zeros(10))]
+    q = quantizers.Quantizer(NearestNeighborCompressor, params, make_args(num_users=1, no_cuda=True), codec_factory=oracle_codec_factory)
+    for p in params:
+        p.grad = torch.randn_like(p)
+    seen_by_record = [p.grad for p in params]
+    before = [g.clone() for g in seen_by_record]
+    q.record(0, epoch=1)
+    replaced = torch.full_like(params[0], 7.0)
+    params[0].grad = replaced                         # a new object after the last record()
+    q.apply()
+    assert params[0].grad is replaced and not torch.equal(replaced, torch.full_like(replaced, 7.0))     # the mean went into it
+    assert torch.equal(seen_by_record[0], before[0])                                                  # the old object is left alone
+    assert torch.equal(params[1].grad, before[1])                                                     # identity-compressed: the mean of one user
+    # the same step without the replacement gives the same numbers
+    q2 = quantizers.Quantizer(NearestNeighborCompressor, params, make_args(num_users=1, no_cuda=True), codec_factory=oracle_codec_factory)
+    params[0].grad, params[1].grad = before[0].clone(), before[1].clone()
+    q2.record(0, epoch=1)
+    q2.apply()
+    assert torch.equal(params[0].grad, replaced)
+    params[0].grad = before[0].clone()
+    q2.record(0, epoch=1)
+    params[1].grad = None
+    with pytest.raises(AttributeError):
+        q2.apply()
