@@ -32,9 +32,8 @@ static bool pf_dim(int d) { return d == 8 || d == 16 || d == 32; }
 
 // Which encode serves the descriptor (see gq_hsq_batched_path in the header); 0 + an error text if none.
 static int batch_path(const gq_hsq_batch *b) {
-    const int seg_cap = b->d == 16 ? 1 << 30 : 384;   // d = 8 / 32 keep their segment records in LDS
     if (pf_dim(b->d) && b->K == 256 && b->code_bytes == 1) {
-        if (b->nseg <= seg_cap) return GQ_BATCH_PREFILTER;
+        return GQ_BATCH_PREFILTER;   // (any number of tensors: beyond 384 the segment records are read from global memory)
     } else if (pf_dim(b->d) && b->K > 256 && (b->K & 255) == 0 && b->code_bytes == 4 && b->nseg <= 384) {
         return GQ_BATCH_PAGED;
     }
@@ -66,11 +65,8 @@ GQ_API int gq_hsq_encode_batched(const gq_hsq_batch *b, uint8_t *wire, float ef_
     switch (gq::batch_path(b)) {
         case GQ_BATCH_PREFILTER:
             if (!b->workspace) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched: the prefilter path needs a workspace");
-            if (b->d == 16)
-                return gqi_hsq_encode_batched_d16(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->codebook, ef, scale, wire,
-                                                  b->u_flat, b->seg_minmax, b->workspace, b->profile_slot, stream);
-            return gqi_hsq_encode_batched_d(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->codebook, b->d, ef, scale, wire,
-                                            b->u_flat, b->seg_minmax, b->workspace, stream);
+            return gqi_hsq_encode_batched_pf(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->codebook, b->d, ef, scale, wire,
+                                             b->u_flat, b->seg_minmax, b->workspace, b->profile_slot, stream);
         case GQ_BATCH_PAGED:
             if (!b->workspace) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched: the paged prefilter path needs a workspace");
             return gqi_hsq_encode_batched_paged(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->codebook, b->d, b->K, ef,

@@ -3,14 +3,10 @@
 #pragma once
 #include "gq_common.hpp"
 
-// d = 16, K = 256, byte codes: bf16x3 prefilter + exact rescoring (hsq_encode_pf.hip)
-GQ_INTERNAL int gqi_hsq_encode_batched_d16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                           const float *codebook, int ef, float ef_scale, uint8_t *wire, float *u_flat,
-                                           uint32_t *seg_minmax, float *workspace, int profile_slot, void *stream);
-// d = 8 / 32, K = 256 (hsq_encode_pfd.hip)
-GQ_INTERNAL int gqi_hsq_encode_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                         const float *codebook, int d, int ef, float ef_scale, uint8_t *wire, float *u_flat,
-                                         uint32_t *seg_minmax, float *workspace, void *stream);
+// d = 8 / 16 / 32, K = 256, byte codes: f16 prefilter + exact rescoring + second pass (hsq_encode_pf.hip)
+GQ_INTERNAL int gqi_hsq_encode_batched_pf(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                          const float *codebook, int d, int ef, float ef_scale, uint8_t *wire, float *u_flat,
+                                          uint32_t *seg_minmax, float *workspace, int profile_slot, void *stream);
 // d in {8, 16, 32}, K = 512 ... 65536 in pages of 256, int32 codes
 GQ_INTERNAL int gqi_hsq_encode_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                              const float *codebook, int d, int K, int ef, float ef_scale, uint8_t *wire,

@@ -668,7 +668,8 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
             return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: K > 256 needs int32 codes");
         }
     }
-    if (impl == 4 && K == 256 && (d == 8 || d == 32)) {
+    if (impl == 6) {   // round 3's bf16 x 3 prefilter for d = 8 / 32 (hsq_encode_pfd.hip's single-page form): kept as a cross-check
+        if (K != 256 || (d != 8 && d != 32)) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 6 needs K=256 and d in {8, 32}");
         if (!pf_ok) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: grad must be 16-byte aligned");
         return launch_encode_pfd<CodeT>(grad, codebook, M, d, codes, u, partials, st);
     }
@@ -693,10 +694,10 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
         return GQ_OK;
     }
     if (impl == 4) {
-        if (d != 16 || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 4 needs K=256 and d in {8, 16, 32}");
+        if (!(d == 8 || d == 16 || d == 32) || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 4 needs K=256 and d in {8, 16, 32}");
         if ((reinterpret_cast<uintptr_t>(grad) & 15) != 0)
             return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: grad must be 16-byte aligned");
-        return launch_encode_pf<CodeT>(grad, codebook, M, codes, u, partials, st, profile_slot);
+        return launch_encode_pf<CodeT>(grad, codebook, M, d, codes, u, partials, st, profile_slot);
     }
     if (impl == 1) {
         if (d != 16 || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 1 needs d=16, K=256");

@@ -190,11 +190,11 @@ static int resident_blocks_per_cu(KernelT kernel, int threads, size_t lds) {
     return n;
 }
 
-// hsq_encode_pf.hip: bf16x3 MFMA prefilter + exact f32 rescoring + fix-up kernel (d=16, K=256).
+// hsq_encode_pf.hip: f16 MFMA prefilter + exact f32 rescoring + second pass + exact scans (d = 8 / 16 / 32, K = 256).
 template <typename CodeT>
-int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *workspace,
+int launch_encode_pf(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u, float *workspace,
                      hipStream_t st, int profile_slot = -1);
-// hsq_encode_pfd.hip: the same for d = 8 and d = 32 (K = 256).
+// hsq_encode_pfd.hip: round 3's bf16 x 3 prefilter for d = 8 and d = 32 (K = 256): gq_hsq_encode_ex's impl 6, a cross-check.
 template <typename CodeT>
 int launch_encode_pfd(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u,
                       float *workspace, hipStream_t st);

@@ -1,5 +1,8 @@
-// HSQ encode, d = 16, K = 256: f16 matrix-core prefilter (ONE MFMA per chain) + exact f32 rescoring + deferred
-// exact scans.  Same bits as the exact f32 kernel (hsq_encode.hip) in about a quarter of its time.
+// HSQ encode, K = 256, sub-dimension D = 8, 16 or 32: f16 matrix-core prefilter (ONE MFMA per chain and 16 dimensions) +
+// exact f32 rescoring + deferred exact scans.  Same bits as the exact f32 kernel (hsq_encode.hip) in about a quarter of
+// its time.  Written for D = 16 (BASELINE's shape; the text below describes that instantiation); round 5 made D a template
+// parameter (main.py:90's default is --c-dim 32): a chain is KS = ceil(D / 16) MFMAs, D = 8 feeds zeros for the upper half
+// of its one k-step, D = 32 keeps the codebook's f16 fragments in LDS (64 VGPRs otherwise) and a 32-entry ring per wave.
 //
 // The exact f32 MFMA is bound by the f32 matrix rate and shares its datapath with the VALU (tools/enc_probe.hip: their
 // times ADD), so the 256-way argmax cannot hide behind it.  This kernel scores approximately on the f16 matrix pipe
@@ -88,13 +91,26 @@ constexpr int PF_THREADS = PF_WAVES * 64;
 #endif
 constexpr int PF_TAIL = GQ_PF_TAIL;   // swept 2..12 in round 1 (52.3 us at 4..8, 54 at 2 and 12); again at the end of round 3: 3-4 40.35, 6 40.48, 8 40.6, 10 40.8 us
 constexpr int PF_LDS_SEGS = 384;            // batched form: tensors whose segment records are kept in LDS (24 KiB)
-constexpr int QUAD_STRIDE = 68;             // LDS floats per GROUP of 4 codewords (64 used, 272 B = 17 x 16 B: random groups spread over the banks)
-constexpr int PF_QCAP = 64;                 // deferred exact scans a wave can hold (a ring in LDS; a tile adds at most 64)
-// Error bound of the f16 prefilter (header, 1): E' = ||vh||_2 * ERR_REL * c2 + ERR_ABS * c2 inside the window of ||vh||_2^2
-constexpr float ERR_REL = 1.03f * 4.8828125e-04f;     // 1.03 * 2^-11
-constexpr float ERR_ABS = 4.76837158203125e-07f;      // 2^-21
-// second pass (ch.vh + ch.vl + cl.vh): cl.vl, the splits' remainders (2^-22 each) and 48 accumulated products (< 2^-17.4 c2 sqrt(n2))
-constexpr float ERR2_REL = 1.2f * 7.62939453125e-06f;  // 1.2 * 2^-17
+// What depends on the sub-dimension.
+template <int D>
+struct PfShape {
+    static_assert(D == 8 || D == 16 || D == 32, "the prefilter kernel is built for D = 8, 16 and 32");
+    static constexpr int KS = D > 16 ? D / 16 : 1;    // MFMA k-steps (of 16 dimensions) per chain
+    static constexpr bool HALF = D < 16;              // D = 8: the upper half of the one k-step is zero (lanes 32-63 hold no data)
+    static constexpr int QS = 4 * D + 4;              // LDS floats per GROUP of 4 codewords (4 D used; an odd number of 16-byte units: random groups spread over the banks)
+    static constexpr int QCAP = D > 16 ? 32 : 64;     // deferred subvectors a wave can hold (a ring in LDS: D floats each)
+    static constexpr bool A_REGS = D <= 16;           // the codebook's f16 A fragments stay in registers (32 VGPRs); D = 32: read from LDS a row block ahead
+    static constexpr int NF = 4 * KS;                 // f32x4 registers of a tile per lane: [(block * KS + k-step) * 2 + q]
+    // Error bound of the f16 prefilter (header, 1): E' = sqrt(n2) * (ERR_REL * c2 + 2.02 dc) + ERR_ABS * c2 inside the window of n2.
+    // The factor over 2^-11 covers the accumulation roundings of the MFMA and of the reference's chain, 2 D 2^-24 of
+    // sum |c_j v_j| <= c2 ||v'||_2 < 2.02 c2 sqrt(n2) together: 0.8 % of the first term for D = 16, 1.6 % for D = 32.
+    static constexpr float ERR_REL = (D > 16 ? 1.05f : 1.03f) * 4.8828125e-04f;     // x 2^-11
+    // second pass (ch.vh + ch.vl + cl.vh): cl.vl and the splits' remainders (3 x 2^-22 x 2.02) + 4 D accumulated products
+    // (x 2^-24 x 2.02): 1.19 x 2^-17 for D = 16, 2.21 x 2^-17 for D = 32; the codebook split's subnormal grid on top (ERR2_SUB)
+    static constexpr float ERR2_REL = (D > 16 ? 2.3f : 1.2f) * 7.62939453125e-06f;  // x 2^-17
+    static constexpr float ERR2_SUB = D > 16 ? 3.5e-7f : 2.4e-7f;                   // 2.02 sqrt(D) 2^-25
+};
+constexpr float ERR_ABS = 4.76837158203125e-07f;      // 2^-21 (subnormal f16 results: sqrt(D) 2^-25 per subvector)
 constexpr unsigned N2_LO_BITS = 0x39800000u;          // 2^-12
 constexpr unsigned N2_HI_BITS = 0x4B800000u;          // 2^24  (||vh||_2^2 < 4 n2 <= 2^26: every |vh_j| < 2^13)
 constexpr int SIGMA_TARGET_EXP2 = 10;                 // the largest sampled n2 of a tile is steered to ~2^10 (norm 2^5 .. 2^6)
@@ -140,16 +156,19 @@ static void pf_split(PfArgs &a, int64_t ntiles, int64_t blocks) {
 // SEGLDS (batched only): the segment records are read from their LDS copy (nseg <= PF_LDS_SEGS) or, for
 // longer tensor lists, from global memory -- as two instantiations, because a run-time choice between
 // the two sources turns the record pointer into a flat pointer (see tile_info).
-template <typename CodeT, bool BATCHED, bool EF = false, bool SEGLDS = true>
+template <typename CodeT, int D, bool BATCHED, bool EF = false, bool SEGLDS = true>
 __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfArgs a) {
+    typedef PfShape<D> SH;
+    constexpr int KS = SH::KS, QS = SH::QS, QCAP = SH::QCAP, NF = SH::NF;
+    constexpr bool HALF = SH::HALF;
     GQ_STAMPS_ONLY(const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime(); unsigned long long nscanned = 0, npassed = 0;)
     const float *__restrict__ cb = a.cb;
     float *__restrict__ ws = a.ws;
     float *__restrict__ u = a.u;
     const int64_t M = a.M;
     // f32 codebook for the exact rescoring, codeword pairs interleaved element by element:
-    // s_cb[(k>>2)*QUAD_STRIDE + 4*j + (k&3)] = c[k][j]
-    __shared__ __attribute__((aligned(16))) float s_cb[64 * QUAD_STRIDE];
+    // s_cb[(k>>2)*QS + 4*j + (k&3)] = c[k][j]
+    __shared__ __attribute__((aligned(16))) float s_cb[64 * QS];
     __shared__ int s_next;                     // tile counter of this workgroup's run (see below)
     // Batched form: the segment table (64 B per tensor) goes to LDS once.  Looking a tile's tensor up in
     // global memory costs two dependent round trips at the top of every tile (tile -> segment -> record),
@@ -157,12 +176,12 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // and the tile -> segment word is fetched one tile ahead.
     __shared__ int64_t s_seg[(BATCHED && SEGLDS) ? PF_LDS_SEGS * 8 : 1];
     // f16 hi / lo A fragments of the 8 row blocks as the waves of the workgroup produce them (one row block each)
-    __shared__ __attribute__((aligned(16))) u32x4 s_frag[8 * 64], s_fragl[8 * 64];   // hi parts (to registers) / lo parts (read by the second pass)
+    __shared__ __attribute__((aligned(16))) u32x4 s_frag[8 * KS * 64], s_fragl[8 * KS * 64];   // [(row block * KS + k-step) * 64 + lane]: hi parts (to registers; D = 32: read per chain) / lo parts (read by the second pass)
     __shared__ float s_c1[PF_WAVES], s_dc[PF_WAVES];
     // deferred exact scans (header, 4): every wave's own ring of PF_QCAP entries = the subvector's 16 floats +
     // {code address lo, hi, index into u, segment}.  Written and read by the same wave only: no flags, no atomics.
-    __shared__ __attribute__((aligned(16))) float s_qv[PF_WAVES * PF_QCAP * 16];
-    __shared__ __attribute__((aligned(16))) unsigned s_qm[PF_WAVES * PF_QCAP * 4];
+    __shared__ __attribute__((aligned(16))) float s_qv[PF_WAVES * QCAP * D];
+    __shared__ __attribute__((aligned(16))) unsigned s_qm[PF_WAVES * QCAP * 4];
 
     // Batched form: the workgroup's (min, max) per tensor, for the PF_MM_SEGS tensors from its first tile's on (a run is
     // contiguous: typically 1-3 tensors, a few dozen where the list has many small ones).  Waves fold into it with LDS
@@ -205,8 +224,12 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     bool sawnan = false;   // a projection of this wave is NaN (wave-uniform)
     int cur_seg = -1;  // batched: segment the running (lmin, lmax) belongs to
     int seg_first = 0; // batched: the tensor of this workgroup's first tile (s_mm's entry 0)
-    f32x4 cur[4], nxt[4];
-    f32x4 nxte[4];   // EF: the error tile that goes with nxt (dead otherwise)
+    f32x4 cur[NF], nxt[NF];   // [(block * KS + k-step) * 2 + q]: floats [16 s + 8 h + 4 q, + 4) of subvector 32 block + j
+    f32x4 nxte[NF];  // EF: the error tile that goes with nxt (dead otherwise)
+    if (HALF) {      // D = 8: lanes 32-63 never load (their half of the k-step is zero)
+#pragma unroll
+        for (int i = 0; i < NF; ++i) cur[i] = nxt[i] = nxte[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
 
     // where tile `tile` lives: base pointer, subvector count of its tensor, local index of its first subvector
     // Pointers that come out of the segment table are integers to the compiler: cast to plain pointers
@@ -286,48 +309,49 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // each block, clamped to the tile's last valid one (tail: re-read it, the result is masked).
     auto lane_off = [&](const Tile &ti, int blk) {   // float offset of v[8h..] of subvector blk*32+j from the tile's first float
         const unsigned li = min((unsigned)(blk * 32 + j), (unsigned)ti.rem);
-        return li * 16u + 8u * (unsigned)h;
+        return li * (unsigned)D + (HALF ? 0u : 8u * (unsigned)h);
     };
-    auto load_tile = [&](const Tile &ti, f32x4(&dst)[4]) {
-        const gcf_ptr tb = ti.base + ti.sv0 * 16;
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const gcv_ptr p = (gcv_ptr)(tb + lane_off(ti, blk));
-            dst[2 * blk] = p[0];
-            dst[2 * blk + 1] = p[1];
-        }
-    };
-    auto load_err = [&](const Tile &ti, f32x4(&dst)[4]) {
-        if (EF && ti.err) {
-            const gcf_ptr tb = ti.err + ti.sv0 * 16;
+    const bool loads_here = !HALF || h == 0;   // D = 8: the lower lanes hold the subvectors, the upper ones zeros
+    auto load_rows = [&](gcf_ptr tb, const Tile &ti, f32x4(&dst)[NF]) {
+        if (loads_here) {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 const gcv_ptr p = (gcv_ptr)(tb + lane_off(ti, blk));
-                dst[2 * blk] = p[0];
-                dst[2 * blk + 1] = p[1];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    dst[(blk * KS + s) * 2] = p[4 * s];
+                    dst[(blk * KS + s) * 2 + 1] = p[4 * s + 1];
+                }
             }
         }
     };
+    auto load_tile = [&](const Tile &ti, f32x4(&dst)[NF]) { load_rows(ti.base + ti.sv0 * D, ti, dst); };
+    auto load_err = [&](const Tile &ti, f32x4(&dst)[NF]) {
+        if (EF && ti.err) load_rows(ti.err + ti.sv0 * D, ti, dst);
+    };
     // v = grad + scale*error, written back over grad (valid subvectors only)
-    auto fold_err = [&](const Tile &ti, f32x4(&g)[4], const f32x4(&e)[4]) {
+    auto fold_err = [&](const Tile &ti, f32x4(&g)[NF], const f32x4(&e)[NF]) {
         if (EF && ti.err) {
-            const gf_ptr tb = (gf_ptr)(ti.base + ti.sv0 * 16);
+            const gf_ptr tb = (gf_ptr)(ti.base + ti.sv0 * D);
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    f32x4 &x = g[2 * blk + q];
-                    const f32x4 &y = e[2 * blk + q];
+                for (int q = 0; q < 2 * KS; ++q) {
+                    f32x4 &x = g[2 * KS * blk + q];
+                    const f32x4 &y = e[2 * KS * blk + q];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const float prod = a.ef_scale * y[c];
                         x[c] = x[c] + prod;
                     }
                 }
-                if (blk * 32 + j <= ti.rem) {
-                    const gv_ptr p = (gv_ptr)(tb + (unsigned)((blk * 32 + j) * 16 + 8 * h));
-                    p[0] = g[2 * blk];
-                    p[1] = g[2 * blk + 1];
+                if (blk * 32 + j <= ti.rem && loads_here) {
+                    const gv_ptr p = (gv_ptr)(tb + (unsigned)((blk * 32 + j) * D + (HALF ? 0 : 8 * h)));
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        p[4 * s] = g[(blk * KS + s) * 2];
+                        p[4 * s + 1] = g[(blk * KS + s) * 2 + 1];
+                    }
                 }
             }
         }
@@ -356,7 +380,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
 
     // B fragments: lane (col j, half h) holds f16(sigma * v[8h .. 8h+7]) of subvector j of each block;
     // n2p: sum of 4^exponent over those eight values (half of the subvector's n2: the header's error bound)
-    half8 vh[2];
+    half8 vh[2 * KS];   // [block * KS + k-step]
     float n2p[2] = {0.0f, 0.0f};
     Tile ti = {};
     auto seg_of = [&](int64_t tile) {   // batched: tile -> tensor, one global word (0 beyond the end)
@@ -369,11 +393,19 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // through LDS -- each wave splitting all 8 cost 0.8 us of VALU time per SIMD), and the wave's first tile,
     // whose HBM latency then hides behind the staging.  One barrier.  (Before: staging, fragments, barrier,
     // ||c||_1, barrier and only then the first tile's loads: 5.2 us; profiles/r02_b_pf_prologue_stamps.txt.)
-    float cbv[256 * 16 / PF_THREADS];
+    float cbv[256 * D / PF_THREADS];
 #pragma unroll
-    for (int n = 0; n < 256 * 16 / PF_THREADS; ++n) cbv[n] = cb[threadIdx.x + n * PF_THREADS];
-    const f32x4 q0 = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * 16 + 8 * h);
-    const f32x4 q1 = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * 16 + 8 * h + 4);
+    for (int n = 0; n < 256 * D / PF_THREADS; ++n) cbv[n] = cb[threadIdx.x + n * PF_THREADS];
+    f32x4 aq[2 * KS];   // row wave*32 + j, k-step s: floats [16 s + 8 h, + 8)
+#pragma unroll
+    for (int i = 0; i < 2 * KS; ++i) aq[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (loads_here) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            aq[2 * s] = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * D + 16 * s + (HALF ? 0 : 8 * h));
+            aq[2 * s + 1] = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * D + 16 * s + (HALF ? 0 : 8 * h) + 4);
+        }
+    }
     const int seg_first_v = (BATCHED && lo_tile < ntiles) ? a.tile_seg[lo_tile] : 0;   // (requested with the first tile's word)
     if (t < tile_end) {
         ti = tile_info(t, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[t]) : 0, std::true_type{});
@@ -389,9 +421,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         s_mm[2 * threadIdx.x + 1] = 0u;
     }
 #pragma unroll
-    for (int n = 0; n < 256 * 16 / PF_THREADS; ++n) {
-        const int i = threadIdx.x + n * PF_THREADS, k = i >> 4, jj = i & 15;
-        s_cb[(k >> 2) * QUAD_STRIDE + 4 * jj + (k & 3)] = cbv[n];
+    for (int n = 0; n < 256 * D / PF_THREADS; ++n) {
+        const int i = threadIdx.x + n * PF_THREADS, k = i / D, jj = i % D;
+        s_cb[(k >> 2) * QS + 4 * jj + (k & 3)] = cbv[n];
     }
     if (BATCHED && SEGLDS) {
         const int n = (a.nseg < PF_LDS_SEGS ? a.nseg : PF_LDS_SEGS) * 8;
@@ -403,19 +435,22 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         // ||c_k||_2 and the largest ||c_k - f16(c_k)||_2 (the rounding residuals as they are: x - f16(x) is exact in f32).
         // Row wave*32 + j: this lane's 8 elements + its partner's.  A row that is not finite or beyond the f16 range makes
         // a maximum NaN or >= 2^30 -- tested on the bits below.
-        half8 fh, fl;
         float l2 = 0.0f, d2 = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = e < 4 ? q0[e] : q1[e - 4];
-            fh[e] = (_Float16)x;
-            const float rr = x - (float)fh[e];
-            fl[e] = (_Float16)rr;   // c = hi + lo + r, |r| <= 2^-22 |c| + 2^-25 (the second term: f16's subnormal grid)
-            l2 = __fmaf_rn(x, x, l2);
-            d2 = __fmaf_rn(rr, rr, d2);
+        for (int s = 0; s < KS; ++s) {
+            half8 fh, fl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = e < 4 ? aq[2 * s][e] : aq[2 * s + 1][e - 4];
+                fh[e] = (_Float16)x;
+                const float rr = x - (float)fh[e];
+                fl[e] = (_Float16)rr;   // c = hi + lo + r, |r| <= 2^-22 |c| + 2^-25 (the second term: f16's subnormal grid)
+                l2 = __fmaf_rn(x, x, l2);
+                d2 = __fmaf_rn(rr, rr, d2);
+            }
+            s_frag[(wave * KS + s) * 64 + lane] = __builtin_bit_cast(u32x4, fh);
+            s_fragl[(wave * KS + s) * 64 + lane] = __builtin_bit_cast(u32x4, fl);
         }
-        s_frag[wave * 64 + lane] = __builtin_bit_cast(u32x4, fh);
-        s_fragl[wave * 64 + lane] = __builtin_bit_cast(u32x4, fl);
         l2 += __shfl_xor(l2, 32, 64);
         d2 += __shfl_xor(d2, 32, 64);
         l2 = wave_max_nan(l2);
@@ -426,11 +461,18 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         }
     }
     __syncthreads();
-    // A fragments of v_mfma_f32_32x32x16_f16: lane (row j, half h) holds f16(c[rb*32+j][8h .. 8h+7]); 32 VGPRs, resident
-    // for the kernel's lifetime.
-    half8 ch[8];
+    // A fragments of v_mfma_f32_32x32x16_f16: lane (row j, half h) holds f16(c[rb*32+j][16s+8h .. +7]); D <= 16: 32 VGPRs,
+    // resident for the kernel's lifetime; D = 32 (64 VGPRs: they do not fit beside two tiles of 32 floats per lane) reads them
+    // from s_frag a row block ahead (frag_hi).
+    half8 ch[SH::A_REGS ? 8 : 1];
+    if constexpr (SH::A_REGS) {
 #pragma unroll
-    for (int rb = 0; rb < 8; ++rb) ch[rb] = __builtin_bit_cast(half8, s_frag[rb * 64 + lane]);
+        for (int rb = 0; rb < 8; ++rb) ch[rb] = __builtin_bit_cast(half8, s_frag[rb * 64 + lane]);
+    }
+    auto frag_hi = [&](int rb, int s) -> half8 {   // (D <= 16: s == 0, a register)
+        if constexpr (SH::A_REGS) return ch[rb];
+        else return __builtin_bit_cast(half8, s_frag[(rb * KS + s) * 64 + lane]);
+    };
     unsigned c2b = __float_as_uint(s_c1[0]), dcb = __float_as_uint(s_dc[0]);   // squares: non-negative, so the bits order them, a NaN above everything
 #pragma unroll
     for (int w = 1; w < PF_WAVES; ++w) {
@@ -441,9 +483,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // rounding seen through ||vh||_2 < 2 sqrt(n2).  A codebook outside the f16 range: +infinity, nothing is ever "safe".
     const float c2 = __builtin_sqrtf(__uint_as_float(c2b)) * 1.0000002f, dc = __builtin_sqrtf(__uint_as_float(dcb)) * 1.0000002f;
     const bool cb_ok = c2b < 0x4E800000u && dcb < 0x4E800000u;
-    const float err_rel = cb_ok ? c2 * ERR_REL + 2.02f * dc : INFINITY;   // (2.02: ||vh||_2 < 2 sqrt(n2) + 2^-12, n2 >= 2^-12)
+    const float err_rel = cb_ok ? c2 * SH::ERR_REL + 2.02f * dc : INFINITY;   // (2.02: ||vh||_2 < 2 sqrt(n2) + 2^-12, n2 >= 2^-12)
     const float err_abs = cb_ok ? c2 * ERR_ABS : INFINITY;
-    const float err2_rel = cb_ok ? c2 * ERR2_REL + 2.4e-7f : INFINITY;   // the second pass (three MFMAs per chain)
+    const float err2_rel = cb_ok ? c2 * SH::ERR2_REL + SH::ERR2_SUB : INFINITY;   // the second pass (three MFMAs per chain and k-step)
 
     int64_t tn = draw();                // the tile after this wave's first one
     int seg_n = seg_of(tn);             // in flight while the first tile is set up
@@ -460,7 +502,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         fold_err(ti, cur, nxte);
         float m = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) m = fmaxf(fmaxf(fabsf(cur[i][0]), fabsf(cur[i][1])), fmaxf(fmaxf(fabsf(cur[i][2]), fabsf(cur[i][3])), m));
+        for (int i = 0; i < NF; ++i) m = fmaxf(fmaxf(fabsf(cur[i][0]), fabsf(cur[i][1])), fmaxf(fmaxf(fabsf(cur[i][2]), fabsf(cur[i][3])), m));
         const unsigned em = (unsigned)__builtin_amdgcn_readfirstlane((int)(__float_as_uint(wave_max(m)) >> 23));
         if (em >= 1u && em <= 254u) {
             int f = 258 - (int)em;
@@ -468,7 +510,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             sigma_t = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(f << 23));
         }
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) scale8_f16(cur[2 * blk], cur[2 * blk + 1], sigma_t, vh[blk], n2p[blk]);
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) scale8_f16(cur[(blk * KS + s) * 2], cur[(blk * KS + s) * 2 + 1], sigma_t, vh[blk * KS + s], n2p[blk]);
     }
     // (min, max) of one exactly scanned projection into its tensor's words (batched form)
     auto fold_seg = [&](int seg, float v) {
@@ -491,12 +535,12 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         const int e = lane >> 4, r = lane & 15;
         for (int b0 = 0; b0 < n; b0 += 4) {
             const bool live = b0 + e < n;   // (an idle quarter re-scans the batch's first entry and stores nothing)
-            const int slot = wave * PF_QCAP + ((first + b0 + (live ? e : 0)) & (PF_QCAP - 1));
-            float w[16];
+            const int slot = wave * QCAP + ((first + b0 + (live ? e : 0)) & (QCAP - 1));
+            float w[D];
             {
-                const f32x4 *qv = reinterpret_cast<const f32x4 *>(s_qv + 16 * slot);
+                const f32x4 *qv = reinterpret_cast<const f32x4 *>(s_qv + D * slot);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < D / 4; ++q) {
                     const f32x4 x = qv[q];
                     w[4 * q] = x[0];
                     w[4 * q + 1] = x[1];
@@ -509,7 +553,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             // torch.argmax (NaN largest, the first one wins) needs the ranks -- a wave-uniform, rare branch.
             f32x4 p[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) p[q] = exact_score_quad<16>(s_cb + (r + 16 * q) * QUAD_STRIDE, w);
+            for (int q = 0; q < 4; ++q) p[q] = exact_score_quad<D>(s_cb + (r + 16 * q) * QS, w);
             float bv = p[0][0], asum = fabsf(p[0][0]);
             int bi = 4 * r;
 #pragma unroll
@@ -571,60 +615,92 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     auto second_pass = [&](int first, int n) {
         GQ_STAMPS_ONLY(npassed += n;)
         const int col = j < n ? j : 0;   // (idle columns repeat entry 0 and store nothing)
-        const int slot = wave * PF_QCAP + ((first + col) & (PF_QCAP - 1));
-        const f32x4 *qv = reinterpret_cast<const f32x4 *>(s_qv + 16 * slot);
-        const f32x4 x0 = qv[2 * h], x1 = qv[2 * h + 1];
+        const int slot = wave * QCAP + ((first + col) & (QCAP - 1));
+        const f32x4 *qv = reinterpret_cast<const f32x4 *>(s_qv + D * slot);
+        f32x4 xs[2 * KS];   // the entry's floats [16 s + 8 h, + 8) for every k-step (D = 8: zeros in the upper lanes)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (HALF) {
+                const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                xs[0] = h ? z : qv[0];
+                xs[1] = h ? z : qv[1];
+            } else {
+                xs[2 * s] = qv[4 * s + 2 * h];
+                xs[2 * s + 1] = qv[4 * s + 2 * h + 1];
+            }
+        }
         auto both_halves = [&](float own, bool add) {   // own (+ or max) the partner lane's value: two copies through v_permlane32_swap
             float a = own, b = own;
             swap32(a, b);            // a = the lower lanes' values in both halves, b = the upper lanes'
             return add ? a + b : fmaxf(a, b);
         };
-        float m = fmaxf(fmaxf(fmaxf(fabsf(x0[0]), fabsf(x0[1])), fmaxf(fabsf(x0[2]), fabsf(x0[3]))),
-                        fmaxf(fmaxf(fabsf(x1[0]), fabsf(x1[1])), fmaxf(fabsf(x1[2]), fabsf(x1[3]))));
+        float m = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i)
+            m = fmaxf(fmaxf(fmaxf(fabsf(xs[i][0]), fabsf(xs[i][1])), fmaxf(fabsf(xs[i][2]), fabsf(xs[i][3]))), m);
         m = both_halves(m, false);
         const unsigned em = __float_as_uint(m) >> 23;
         int f = 258 - (int)em;
         f = f < 27 ? 27 : (f > 227 ? 227 : f);
         const float sig = (em >= 1u && em <= 254u) ? __uint_as_float((unsigned)f << 23) : 1.0f;   // per lane: the entry's scale
         // vh = f16(x sig), vl = f16(x sig - vh): the second conversion's fma is exact in f32 (a rounding residual)
-        u32x4 H, L;
+        half8 bh[KS], bl[KS];
         float n2q = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float a = i < 2 ? x0[2 * i] : x1[2 * i - 4], b = i < 2 ? x0[2 * i + 1] : x1[2 * i - 3];
-            unsigned r, l;
-            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(sig));
-            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(r) : "v"(b), "v"(sig));
-            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(sig), "v"(r));
-            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(sig), "v"(r));
-            const unsigned e = r & 0x7C007C00u;
-            asm("v_dot2_f32_f16 %0, %1, %1, %0" : "+v"(n2q) : "v"(e));
-            H[i] = r;
-            L[i] = l;
+        for (int s = 0; s < KS; ++s) {
+            u32x4 H, L;
+            const f32x4 x0 = xs[2 * s], x1 = xs[2 * s + 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = i < 2 ? x0[2 * i] : x1[2 * i - 4], b = i < 2 ? x0[2 * i + 1] : x1[2 * i - 3];
+                unsigned r, l;
+                asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(sig));
+                asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(r) : "v"(b), "v"(sig));
+                asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(sig), "v"(r));
+                asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(sig), "v"(r));
+                const unsigned e = r & 0x7C007C00u;
+                asm("v_dot2_f32_f16 %0, %1, %1, %0" : "+v"(n2q) : "v"(e));
+                H[i] = r;
+                L[i] = l;
+            }
+            bh[s] = __builtin_bit_cast(half8, H);
+            bl[s] = __builtin_bit_cast(half8, L);
         }
-        const half8 bh = __builtin_bit_cast(half8, H), bl = __builtin_bit_cast(half8, L);
         const float n2 = both_halves(n2q, true);
         // ---- 8 chains: the two trackers of the one block
         unsigned best2[2] = {0, 0}, second2[2] = {0, 0};
         unsigned vmask = KEY_MASK;
         asm volatile("" : "+v"(vmask));
         // (as in the tile loop: the MFMAs of chain rb + 1 are issued in front of the key operations of chain rb; the lo
-        // fragments come from LDS one chain ahead)
-        half8 al = __builtin_bit_cast(half8, s_fragl[lane]);
+        // fragments -- D = 32: the hi ones too -- come from LDS one chain ahead)
+        half8 al[KS], ah[KS];
+        auto frags_of = [&](int rb) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                al[s] = __builtin_bit_cast(half8, s_fragl[(rb * KS + s) * 64 + lane]);
+                ah[s] = frag_hi(rb, s);
+            }
+        };
+        auto chain3 = [&](f32x16 c) {   // the three products of a chain, every k-step: cl.vh + ch.vl + ch.vh
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], c, 0, 0, 0);
+            }
+            return c;
+        };
+        frags_of(0);
         f32x16 acc = {0};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[0], bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[0], bh, acc, 0, 0, 0);
-        al = __builtin_bit_cast(half8, s_fragl[64 + lane]);
+        acc = chain3(acc);
+        frags_of(1);
 #pragma unroll
         for (int rb = 0; rb < 8; ++rb) {
             f32x16 nacc = {0};
             if (rb + 1 < 8) {
                 __builtin_amdgcn_sched_barrier(0);
-                nacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, nacc, 0, 0, 0);
-                nacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[rb + 1], bl, nacc, 0, 0, 0);
-                nacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[rb + 1], bh, nacc, 0, 0, 0);
-                if (rb + 2 < 8) al = __builtin_bit_cast(half8, s_fragl[(rb + 2) * 64 + lane]);
+                nacc = chain3(nacc);
+                if (rb + 2 < 8) frags_of(rb + 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
             unsigned k[4];
@@ -655,16 +731,16 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         const bool pick1 = ((unsigned)w1 & KEY_MASK) > ((unsigned)w0 & KEY_MASK);
         const int kc = pick1 ? k1_ : k0;
         const unsigned rest = max3u((unsigned)s0, (unsigned)s1, (unsigned)(pick1 ? w0 : w1) | 31u);
-        float vf[16];
+        float vf[D];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < D / 4; ++q) {
             const f32x4 x = qv[q];
             vf[4 * q] = x[0];
             vf[4 * q + 1] = x[1];
             vf[4 * q + 2] = x[2];
             vf[4 * q + 3] = x[3];
         }
-        const f32x4 p4 = exact_score_quad<16>(s_cb + (kc >> 2) * QUAD_STRIDE, vf);
+        const f32x4 p4 = exact_score_quad<D>(s_cb + (kc >> 2) * QS, vf);
         float val = p4[0];
         int idx = kc;
         take_if_greater(val, idx, p4[1], kc + 1);
@@ -691,7 +767,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         while (left) {   // (rare) one exact scan per entry that is still open
             const int i = __builtin_ctzll(left);
             left &= left - 1;
-            scan4((first + i) & (PF_QCAP - 1), 1);
+            scan4((first + i) & (QCAP - 1), 1);
         }
     };
     GQ_STAMPS_ONLY(const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(); unsigned long long ntl = 0, stamp_acc[6] = {0, 0, 0, 0, 0, 0}, ts_prev;
@@ -744,16 +820,37 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             best[trk] = max3u(trk_t, k2, k3);
             second[trk] = max3u(second[trk], trk_a, b);
         };
+        // Chain order.  D <= 16 (A fragments in registers): block 0's eight row blocks, then block 1's.  D = 32 (A fragments
+        // from LDS): (rb, block 0), (rb, block 1), so that both blocks share a row block's fragments, fetched a row block ahead.
+        auto chain_rb = [](int c) { return SH::A_REGS ? (c & 7) : (c >> 1); };
+        auto chain_blk = [](int c) { return SH::A_REGS ? (c >> 3) : (c & 1); };
+        half8 af[2][KS];   // D = 32: the row block in use / the next one
+        if constexpr (!SH::A_REGS) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) af[0][s] = frag_hi(0, s);
+        }
+        auto chain = [&](int c, f32x16 x) {
+            const int rb = chain_rb(c), blk = chain_blk(c);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                x = __builtin_amdgcn_mfma_f32_32x32x16_f16(SH::A_REGS ? ch[SH::A_REGS ? rb : 0] : af[rb & 1][s], vh[blk * KS + s], x, 0, 0, 0);
+            return x;
+        };
         f32x16 acc = {0};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[0], vh[0], acc, 0, 0, 0);
+        acc = chain(0, acc);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            const int rb = c & 7, trk = c >> 2;
+            const int rb = chain_rb(c), trk = chain_blk(c) * 2 + (rb >> 2);
+            if constexpr (!SH::A_REGS) {
+                if (chain_blk(c) == 0 && rb + 1 < 8) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) af[(rb + 1) & 1][s] = frag_hi(rb + 1, s);
+                }
+            }
             if (c + 1 < 16) {
-                const int nb = (c + 1) >> 3, nr = (c + 1) & 7;
                 f32x16 nacc = {0};
                 __builtin_amdgcn_sched_barrier(0);
-                nacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[nr], vh[nb], nacc, 0, 0, 0);
+                nacc = chain(c + 1, nacc);
                 __builtin_amdgcn_sched_barrier(0);
                 track_lo(trk, group_key(acc, rb, 0), group_key(acc, rb, 1));
                 track_hi(trk, group_key(acc, rb, 2), group_key(acc, rb, 3));
@@ -781,14 +878,17 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         }
 
         // ---- this lane's own full subvector (tile subvector `lane`): 8 swaps of the B loads ----
-        float vf[16];
+        float vf[D];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float x = cur[e >> 2][e & 3];        // block 0: floats 8h+e of subvector j
-            float y = cur[2 + (e >> 2)][e & 3];  // block 1
-            swap32(x, y);                        // x = floats e (0..7), y = floats 8+e of subvector `lane`
-            vf[e] = x;
-            vf[8 + e] = y;
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = cur[2 * s + (e >> 2)][e & 3];            // block 0: floats 16s+8h+e of subvector j
+                float y = cur[2 * KS + 2 * s + (e >> 2)][e & 3];   // block 1
+                swap32(x, y);                                      // x = floats 16s+e (0..7), y = floats 16s+8+e of subvector `lane`
+                vf[16 * s + e] = x;
+                if (!HALF) vf[(16 * s + 8 + e) % D] = y;           // (D = 8: the upper lanes' registers hold zeros, not data)
+            }
         }
         // cross-half exchange of the candidates: [0] = lower-half rows, [1] = upper-half rows
         swap32(k1[0], k1[1]);
@@ -818,7 +918,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         const bool pick1 = (bk[1] & KEY_MASK) > (bk[0] & KEY_MASK);
         const int kc = pick1 ? k1[1] : k1[0];
         const unsigned rest = max3u(s2[0], s2[1], (pick1 ? bk[0] : bk[1]) | 31u);
-        const f32x4 p4 = exact_score_quad<16>(s_cb + (kc >> 2) * QUAD_STRIDE, vf);   // kc is a multiple of 4: one quad
+        const f32x4 p4 = exact_score_quad<D>(s_cb + (kc >> 2) * QS, vf);   // kc is a multiple of 4: one quad
         float val = p4[0];
         int idx = kc;
         take_if_greater(val, idx, p4[1], kc + 1);
@@ -840,7 +940,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         if (__ballot(n2b == 0u)) {
             unsigned any = 0;
 #pragma unroll
-            for (int e = 0; e < 16; e += 2) any |= (__float_as_uint(vf[e]) | __float_as_uint(vf[e + 1])) & 0x7FFFFFFFu;
+            for (int e = 0; e < D; e += 2) any |= (__float_as_uint(vf[e]) | __float_as_uint(vf[e + 1])) & 0x7FFFFFFFu;
             if (any == 0u && !nan_bits(val)) {
                 safe = true;
                 val = 0.0f;
@@ -871,21 +971,22 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         // stores are issued: the wait for the prefetch then sees only long-finished memory ops.
         // Done the other way round, the compiler's vmcnt wait at the first use of `nxt` sits right
         // behind the just-issued stores and every tile eats a store round trip.
-        half8 nvh[2];
+        half8 nvh[2 * KS];
         float nn2p[2] = {0.0f, 0.0f};
         // the tile -> tensor word of the tile after next was requested at the top of this tile: read it
         // back here, with the prefetch, not behind the stores
         if (BATCHED) seg_next = __builtin_amdgcn_readfirstlane(seg_n);
         if (EF && tn < tile_end) fold_err(tin, nxt, nxte);
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) scale8_f16(nxt[2 * blk], nxt[2 * blk + 1], sigma_n, nvh[blk], nn2p[blk]);
+        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+            for (int s = 0; s < KS; ++s) scale8_f16(nxt[(blk * KS + s) * 2], nxt[(blk * KS + s) * 2 + 1], sigma_n, nvh[blk * KS + s], nn2p[blk]);
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            vh[blk] = nvh[blk];
-            n2p[blk] = nn2p[blk];
-        }
+        for (int i = 0; i < NF; ++i) cur[i] = nxt[i];
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i) vh[i] = nvh[i];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) n2p[blk] = nn2p[blk];
         __builtin_amdgcn_sched_barrier(0);
 
         GQ_STAMP(4)
@@ -896,12 +997,12 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         uint64_t todo = __ballot(flagged);
         while (todo) {   // (one trip; a second one only when a tile flags more lanes than the ring has room for)
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)todo, 0u));
-            const bool mine = ((todo >> lane) & 1) && rank < PF_QCAP - qcnt;
+            const bool mine = ((todo >> lane) & 1) && rank < QCAP - qcnt;
             if (mine) {
-                const int slot = wave * PF_QCAP + ((qhead + qcnt + rank) & (PF_QCAP - 1));
-                f32x4 *qv = reinterpret_cast<f32x4 *>(s_qv + 16 * slot);
+                const int slot = wave * QCAP + ((qhead + qcnt + rank) & (QCAP - 1));
+                f32x4 *qv = reinterpret_cast<f32x4 *>(s_qv + D * slot);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) qv[q] = f32x4{vf[4 * q], vf[4 * q + 1], vf[4 * q + 2], vf[4 * q + 3]};
+                for (int q = 0; q < D / 4; ++q) qv[q] = f32x4{vf[4 * q], vf[4 * q + 1], vf[4 * q + 2], vf[4 * q + 3]};
                 const uint64_t ca = (uint64_t)(uintptr_t)(ti.codes + ti.sv0) + (uint64_t)sizeof(CodeT) * (unsigned)lane;
                 *reinterpret_cast<u32x4 *>(s_qm + 4 * slot) =
                     u32x4{(unsigned)ca, (unsigned)(ca >> 32), (unsigned)((BATCHED ? t * 64 : ti.sv0) + lane), (unsigned)ti.seg};
@@ -911,7 +1012,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             todo &= ~took;
             if (qcnt >= 32) {   // (a wave meets ~1 unsettled subvector per tile: this is the exception; the ring is emptied after the loop)
                 second_pass(qhead, 32);
-                qhead = (qhead + 32) & (PF_QCAP - 1);
+                qhead = (qhead + 32) & (QCAP - 1);
                 qcnt -= 32;
             }
         }
@@ -935,7 +1036,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     while (qcnt) {   // out of tiles: the ring's entries through the second pass (one trip: a wave collects ~12 per launch)
         const int n = qcnt < 32 ? qcnt : 32;
         second_pass(qhead, n);
-        qhead = (qhead + n) & (PF_QCAP - 1);
+        qhead = (qhead + n) & (QCAP - 1);
         qcnt -= n;
     }
 #ifdef GQ_PF_STAMPS
@@ -969,11 +1070,11 @@ static int64_t pf16_grid(int64_t ntiles, int bpc) {
     return blocks < 1 ? 1 : blocks;
 }
 
-template <typename CodeT>
-int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *ws,
+template <typename CodeT, int D>
+static int launch_pf(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *ws,
                      hipStream_t st, int profile_slot) {
     if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
-    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<CodeT, false>, PF_THREADS, 0);
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<CodeT, D, false>, PF_THREADS, 0);
     PfArgs a = {};
     a.grad = grad;
     a.M = M;
@@ -985,23 +1086,33 @@ int launch_encode_pf(const float *grad, const float *codebook, int64_t M, CodeT 
     pf_split(a, (M + 63) / 64, blocks);
     hipEvent_t ev_start, ev_stop;
     if (profile_events(profile_slot, &ev_start, &ev_stop)) {   // events attached to this dispatch (gq_profile_read)
-        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, false>), dim3((unsigned)blocks),
+        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, D, false>), dim3((unsigned)blocks),
                               dim3(PF_THREADS), 0, st, ev_start, ev_stop, 0, a);
     } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, false>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, D, false>), dim3((unsigned)blocks),
                            dim3(PF_THREADS), 0, st, a);
     }
     GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter)");
     return GQ_OK;
 }
 
-template int launch_encode_pf<uint8_t>(const float *, const float *, int64_t, uint8_t *, float *, float *, hipStream_t, int);
-template int launch_encode_pf<int32_t>(const float *, const float *, int64_t, int32_t *, float *, float *, hipStream_t, int);
+// d = 8, 16 or 32 (K = 256)
+template <typename CodeT>
+int launch_encode_pf(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u, float *ws,
+                     hipStream_t st, int profile_slot) {
+    if (d == 16) return launch_pf<CodeT, 16>(grad, codebook, M, codes, u, ws, st, profile_slot);
+    if (d == 32) return launch_pf<CodeT, 32>(grad, codebook, M, codes, u, ws, st, profile_slot);
+    if (d == 8) return launch_pf<CodeT, 8>(grad, codebook, M, codes, u, ws, st, profile_slot);
+    return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: the prefilter kernel was asked for d = %d", d);
+}
+
+template int launch_encode_pf<uint8_t>(const float *, const float *, int64_t, int, uint8_t *, float *, float *, hipStream_t, int);
+template int launch_encode_pf<int32_t>(const float *, const float *, int64_t, int, int32_t *, float *, float *, hipStream_t, int);
 
 }  // namespace gq
 
 namespace gq {
-template <bool EF>
+template <int D, bool EF>
 static int encode_batched(const char *what, const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                           const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax, float *workspace,
                           float ef_scale, int profile_slot, void *stream) {
@@ -1009,7 +1120,7 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
         return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes nseg=%d ntiles=%lld", what, nseg, (long long)ntiles);
     if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
         return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
-    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<uint8_t, true, EF, true>, PF_THREADS, 0);
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<uint8_t, D, true, EF, true>, PF_THREADS, 0);
     PfArgs a = {};
     a.M = ntiles * 64;
     a.u = u_flat;
@@ -1027,13 +1138,13 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
     pf_split(a, ntiles, blocks);
     hipEvent_t ev_start, ev_stop;
     if (nseg <= PF_LDS_SEGS && profile_events(profile_slot, &ev_start, &ev_stop)) {   // events attached to this dispatch
-        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, true, EF, true>), dim3((unsigned)blocks),
+        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, true>), dim3((unsigned)blocks),
                               dim3(PF_THREADS), 0, st, ev_start, ev_stop, 0, a);
     } else if (nseg <= PF_LDS_SEGS) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, true, EF, true>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, true>), dim3((unsigned)blocks),
                            dim3(PF_THREADS), 0, st, a);
     } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, true, EF, false>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, false>), dim3((unsigned)blocks),
                            dim3(PF_THREADS), 0, st, a);
     }
     GQ_CHECK_LAUNCH(what);
@@ -1065,12 +1176,20 @@ GQ_INTERNAL int gqi_hsq_encode_batched_paged(const int64_t *seg_table, const int
                                         seg_minmax, workspace, st);
 }
 
-GQ_INTERNAL int gqi_hsq_encode_batched_d16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                           const float *codebook, int ef, float ef_scale, uint8_t *wire, float *u_flat,
-                                           uint32_t *seg_minmax, float *workspace, int profile_slot, void *stream) {
-    if (ef)
-        return gq::encode_batched<true>("gq_hsq_encode_batched", seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat,
-                                        seg_minmax, workspace, ef_scale, profile_slot, stream);
-    return gq::encode_batched<false>("gq_hsq_encode_batched", seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat,
-                                     seg_minmax, workspace, 0.0f, profile_slot, stream);
+// K = 256, d = 8 / 16 / 32, byte codes: the multi-tensor prefilter launch (gq_hsq_encode_batched)
+GQ_INTERNAL int gqi_hsq_encode_batched_pf(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                          const float *codebook, int d, int ef, float ef_scale, uint8_t *wire, float *u_flat,
+                                          uint32_t *seg_minmax, float *workspace, int profile_slot, void *stream) {
+    const char *what = "gq_hsq_encode_batched";
+#define GQ_PF_BATCHED(DD)                                                                                                 \
+    if (d == DD)                                                                                                          \
+        return ef ? gq::encode_batched<DD, true>(what, seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, \
+                                                 workspace, ef_scale, profile_slot, stream)                               \
+                  : gq::encode_batched<DD, false>(what, seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, \
+                                                  workspace, 0.0f, profile_slot, stream);
+    GQ_PF_BATCHED(16)
+    GQ_PF_BATCHED(32)
+    GQ_PF_BATCHED(8)
+#undef GQ_PF_BATCHED
+    return gq::fail(GQ_ERR_UNSUPPORTED, "%s: d must be 8, 16 or 32 (K = 256)", what);
 }

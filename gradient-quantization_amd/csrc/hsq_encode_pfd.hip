@@ -801,64 +801,4 @@ int launch_pfd_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, 
     return pfd_batched_paged<32>(seg_table, tile_seg, nseg, ntiles, codebook, K, ef, ef_scale, wire, u_flat, seg_minmax, ws, st);
 }
 
-template <int D, bool EF>
-static int launch_pfd_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                              const float *codebook, float ef_scale, uint8_t *wire, float *u_flat,
-                              uint32_t *seg_minmax, float *ws, hipStream_t st) {
-    constexpr int KS = D > 16 ? D / 16 : 1;
-    constexpr int WAVES = D == 32 ? GQ_W32 : GQ_W8, THREADS = WAVES * 64;
-    constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
-    static const int bpc = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<uint8_t, D, true, EF>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipGetLastError();
-        return resident_blocks_per_cu(hsq_encode_pfd_kernel<uint8_t, D, true, EF>, THREADS, lds);
-    }();
-    PfdArgs a = {};
-    a.M = ntiles * 64;
-    a.u = u_flat;
-    a.cb = codebook;
-    a.ws = ws;
-    a.seg_table = seg_table;
-    a.tile_seg = tile_seg;
-    a.wire = wire;
-    a.seg_minmax = seg_minmax;
-    a.ntiles = ntiles;
-    a.nseg = nseg;
-    a.ef_scale = ef_scale;
-    const int64_t blocks = pfd_grid(ntiles, bpc, WAVES);
-    pfd_split(a, ntiles, blocks);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<uint8_t, D, true, EF>), dim3((unsigned)blocks),
-                       dim3(THREADS), lds, st, a);
-    GQ_CHECK_LAUNCH("gq_hsq_encode_batched_d");
-    return GQ_OK;
-}
-
 }  // namespace gq
-
-namespace gq {
-template <bool EF>
-static int encode_batched_d(const char *what, const int64_t *seg_table, const int32_t *tile_seg, int nseg,
-                            int64_t ntiles, const float *codebook, int d, float ef_scale, uint8_t *wire, float *u_flat,
-                            uint32_t *seg_minmax, float *workspace, void *stream) {
-    if (nseg < 1 || ntiles < 1 || ntiles * 64 > 0x7FFFFFFFLL)
-        return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes nseg=%d ntiles=%lld", what, nseg, (long long)ntiles);
-    if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
-        return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
-    if (nseg > PFD_LDS_SEGS) return fail(GQ_ERR_UNSUPPORTED, "%s: at most %d tensors per launch for d = %d", what, PFD_LDS_SEGS, d);
-    hipStream_t st = as_stream(stream);
-    if (d == 8) return launch_pfd_batched<8, EF>(seg_table, tile_seg, nseg, ntiles, codebook, ef_scale, wire, u_flat, seg_minmax, workspace, st);
-    if (d == 32) return launch_pfd_batched<32, EF>(seg_table, tile_seg, nseg, ntiles, codebook, ef_scale, wire, u_flat, seg_minmax, workspace, st);
-    return fail(GQ_ERR_UNSUPPORTED, "%s: d must be 8, 16 or 32 (K = 256)", what);
-}
-}  // namespace gq
-
-GQ_INTERNAL int gqi_hsq_encode_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                         const float *codebook, int d, int ef, float ef_scale, uint8_t *wire, float *u_flat,
-                                         uint32_t *seg_minmax, float *workspace, void *stream) {
-    if (ef)
-        return gq::encode_batched_d<true>("gq_hsq_encode_batched", seg_table, tile_seg, nseg, ntiles, codebook, d, ef_scale,
-                                          wire, u_flat, seg_minmax, workspace, stream);
-    return gq::encode_batched_d<false>("gq_hsq_encode_batched", seg_table, tile_seg, nseg, ntiles, codebook, d, 0.0f, wire,
-                                       u_flat, seg_minmax, workspace, stream);
-}

@@ -110,19 +110,23 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // register-tight error-feedback instantiation, and there ONE result in ~1e5 -- always the low half, always
 // lanes 48-63 -- came out with a wrong term (found by tools/fuzz_batched.py; codes right, u off by 1e-3
 // relative).  The plain form is also faster beside the MFMAs (encode 52-54 -> 49 us).
+#ifndef GQ_RESCORE_BATCH
+#define GQ_RESCORE_BATCH 8
+#endif
 template <int D>
 __device__ __forceinline__ f32x4 exact_score_quad(const float *__restrict__ quad, const float (&v)[D]) {
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
     // the rows are fetched in batches of 8 (the accumulators of the prefilter are dead by now, there is room): with
     // the reads issued one by one beside their FMAs the group cost 16 LDS round trips in a row
+    constexpr int B = D < GQ_RESCORE_BATCH ? D : GQ_RESCORE_BATCH;
 #pragma unroll
-    for (int j0 = 0; j0 < D; j0 += 8) {
-        f32x4 c[8];
+    for (int j0 = 0; j0 < D; j0 += B) {
+        f32x4 c[B];
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) c[jj] = *reinterpret_cast<const f32x4 *>(quad + 4 * (j0 + jj));
+        for (int jj = 0; jj < B; ++jj) c[jj] = *reinterpret_cast<const f32x4 *>(quad + 4 * (j0 + jj));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
+        for (int jj = 0; jj < B; ++jj) {
             asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(c[jj][0]), "v"(v[j0 + jj]));
             asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(c[jj][1]), "v"(v[j0 + jj]));
             asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a2) : "v"(c[jj][2]), "v"(v[j0 + jj]));

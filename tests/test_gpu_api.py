@@ -1274,7 +1274,7 @@ def test_failed_capture_leaves_no_graph_table_behind():
     step(q, params, 0)
     obj = q._groups[0][2]
     shared = obj._dev.data_ptr()
-    assert obj._batch.keep_table.data_ptr() == shared
+    assert obj._batch.s.seg_table == shared
     header = obj._host[obj._last_slot].to("cuda")
     real_levels = obj._batch.levels
     def boom(*a, **k):
@@ -1285,7 +1285,7 @@ def test_failed_capture_leaves_no_graph_table_behind():
     with pytest.raises(RuntimeError, match="injected"):
         obj.encode(grads, q._wire[0], 0, 0, graph_header=header, dense=dense)
     obj._batch.levels = real_levels
-    assert obj._batch.keep_table.data_ptr() == shared and obj._last_ptrs is None and not obj._acc_clean
+    assert obj._batch.s.seg_table == shared and obj._last_ptrs is None and not obj._acc_clean
     for st in (1, 2, 3):
         a, b = step(q, params, st), step(ref_q, ref_params, st)
         for x, y in zip(a, b):

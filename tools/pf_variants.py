@@ -154,7 +154,29 @@ def fp8lo2(s):
     return s
 
 
+# ---- round 5: where the ~5 us between `noqueue` and the product go (the safety arithmetic stays alive in all of these) ----
+def nowr(s):
+    """Diagnostic (wrong for ~1.5 % of the subvectors): `safe` is computed and kept alive, but nothing is queued and every
+    valid lane stores its rescored candidate: the product minus queue writes, second pass and exact scans."""
+    s = rep(s, "        uint64_t todo = __ballot(flagged);\n", "        uint64_t todo = 0; asm volatile(\"\" :: \"s\"(__ballot(flagged)));\n")
+    return rep(s, "        if (valid && safe) {   // uniform bases", "        if (valid) {   // uniform bases")
+
+
+def nopass(s):
+    """Diagnostic (wrong for the queued subvectors): entries are queued as in the product, but the ring is dropped instead of
+    going through the second pass: the product minus second pass and exact scans (queue writes stay)."""
+    s = rep(s, "                second_pass(qhead, 32);\n", "                asm volatile(\"\" :: \"s\"(qhead));\n")
+    return rep(s, "        second_pass(qhead, n);\n", "        asm volatile(\"\" :: \"s\"(qhead), \"s\"(n));\n")
+
+
+def r16(s, hdr=None):
+    """Rescoring rows fetched as ONE batch of 16 ds_read_b128 instead of two of 8 (one LDS round trip per tile less; +32 VGPRs)."""
+    return s      # (the edit is in hsq_pf_common.hpp: built with -DGQ_RESCORE_BATCH=16)
+
+
 VARIANTS = {
+    "nowr": nowr,
+    "nopass": nopass,
     "fp8lo2": fp8lo2,
     "m1": m1,
     "fp8lo": fp8lo,
@@ -169,10 +191,15 @@ VARIANTS = {
     "m32ns": lambda s: nosplit_lo(m32(nofix(s))),
 }
 
+# variants that are a compile-time switch of the shipped source: name -> extra hipcc flags (the source is taken as it is)
+EXTRA_FLAGS = {"r16": ["-DGQ_RESCORE_BATCH=16"]}
+for _n in EXTRA_FLAGS:
+    VARIANTS.setdefault(_n, lambda s: s)
+
 if __name__ == "__main__":
     os.makedirs("/tmp/gq_pfv", exist_ok=True)
     for name in sys.argv[1:]:
         src = "/tmp/gq_pfv/hsq_encode_pf_%s.hip" % name
         open(src, "w").write(VARIANTS[name](SRC))
-        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), os.path.join(ROOT, "tools", "exp", "libgq_%s.so" % name), src],
-                              stderr=subprocess.DEVNULL)
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), os.path.join(ROOT, "tools", "exp", "libgq_%s.so" % name), src]
+                              + EXTRA_FLAGS.get(name, []), stderr=subprocess.DEVNULL)
