@@ -55,6 +55,15 @@ QSGD_ALGO_BYTES_PER_ELEM = 4.0 + 0.5 + 4.0 / 128     # 4 B read + 4-bit code + o
 FLOP_PER_ELEM = 512                  # 2 * d * K / d
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PREWARM_STEPS = 3000
+EF_ENCODE_BYTES_PER_ELEM = 12.0 + 5.0 / 16    # error-feedback encode: grad + error read, grad written, u + code per 16 elements
+EF_ALGO_BYTES_PER_ELEM = 20.0 + 10.0 / 16     # + the level launch: u + grad read, error + level written
+# Error-feedback workloads run with --scale 0: the reference adds scale * error INTO the gradient in place (ps_quantizer.py:35), and
+# this bench puts the same three input lists under the parameters again and again -- with the reference's scale ('exp': 0.46 at
+# epoch 1) every visit would add 0.46 x (65 % quantisation error) to the inputs themselves, which overflow after ~400 visits
+# (seen: 6 ms steps once the values were infinite).  scale 0 runs the same launches, bytes and arithmetic (error read, product,
+# sum, gradient written back, residual written) on inputs that stay what they are; training rewrites its gradients every step.
+EF_BENCH_SCALE = "0.0"
+TIMED_WINDOWS = 5                     # windows of --steps steps each; the line reports the median window (+ min / max)
 TRAFFIC_FILE = os.path.join("profiles", "hbm_traffic.json")
 
 
@@ -93,6 +102,10 @@ def parse_args():
     ap.add_argument("--cpu-scaling", action="store_true", help="print the CPU oracle's thread scaling on this host and exit (no GPU work)")
     ap.add_argument("--two-launches", action="store_true",
                     help="N = 1: levels and decode as two launches (as with N > 1) instead of gq_hsq_levels_decode")
+    ap.add_argument("--ef", action="store_true", help="--workload resnet50: error feedback (ps_quantizer.py:34-39)")
+    ap.add_argument("--two-phase", action="store_true", help="--workload resnet50: the second phase (ps_quantizer.py:52-61)")
+    ap.add_argument("--c-dim", type=int, default=0, help="--workload resnet50: sub-dimension (default 16; main.py's own default is 32)")
+    ap.add_argument("--n-bit", type=int, default=0, help="--workload resnet50: level bits (default 6; main.py's own default is 8)")
     ap.add_argument("--no-variants", action="store_true", help="skip the untimed random=2 / 1e-3-scale side measurements")
     return ap.parse_args()
 
@@ -279,16 +292,27 @@ def clock_child():
     from gq_amd.codebook import load_codebook
     dev = torch.device("cuda:0")
     cb = torch.from_numpy(load_codebook(C_DIM, 2 ** K_BIT)).to(dev)
-    torch.manual_seed(1234)
-    g = torch.randn(SIZE, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    # the conditions of the timed step (run_hsq at N = 1): three gradients in turn, every encode followed by the fused
+    # level quantiser + decode of the rank's own payload -- the clock the chip holds under the STEP, not under
+    # back-to-back encodes of one Infinity-Cache-warm input (2.34 GHz there against ~2.0 under the step's mix)
+    grads = [torch.randn(SIZE, device=dev, generator=gen) for _ in range(3)]
     M = SIZE // C_DIM
     codes, u = torch.empty(M, dtype=torch.uint8, device=dev), torch.empty(M, dtype=torch.float32, device=dev)
+    levels, lb_ub = torch.empty(M, dtype=torch.uint8, device=dev), torch.empty(2, dtype=torch.float32, device=dev)
+    out = torch.empty(SIZE, dtype=torch.float32, device=dev)
     ws = native.new_workspace(dev, M)
     t0 = time.perf_counter()
+    i = 0
     while time.perf_counter() - t0 < 2.0:
         for _ in range(200):
-            native.hsq_encode(g, cb, codes, u, ws)
+            native.hsq_encode(grads[i % 3], cb, codes, u, ws)
+            native.hsq_levels_decode(u, N_BIT, 0, None, 0, ws, lb_ub, levels, codes, cb, out, False)
+            i += 1
         torch.cuda.synchronize()
+    native.hsq_encode(grads[i % 3], cb, codes, u, ws)      # (the level kernel reads the head of the workspace only; the stamps sit behind the log)
+    torch.cuda.synchronize()
     first = native.WS_LOG_FIRST
     raw = ws[first + M - 65536:first + M - 65536 + 256 * 8 * 12 * 2].contiguous().view(torch.int64).view(-1, 12).cpu().numpy().astype(np.float64)
     cyc, real, tiles = raw[:, :6].sum(1), (raw[:, 8] - raw[:, 7]) / 100.0, raw[:, 9]      # cycles, us, tiles per wave
@@ -308,8 +332,8 @@ def in_kernel_clock():
                              capture_output=True, text=True, timeout=120).stdout.strip().splitlines()
         rec = json.loads(out[-1])
         return rec, ("child run of bench.py on libgq_hsq_clock.so (hsq_encode_pf.hip built with -DGQ_PF_STAMPS; never the product "
-                     "library): 2 s of back-to-back encodes on random data, then s_memtime cycles of the tile loop / its "
-                     "s_memrealtime span, median over %d waves" % rec["waves"])
+                     "library): 2 s of the timed step's launches (encode + fused levels-decode, three random gradients in turn), then "
+                     "s_memtime cycles of the last encode's tile loop / its s_memrealtime span, median over %d waves" % rec["waves"])
     except Exception as e:
         return None, "clock child failed: %s" % (e,)
 
@@ -590,16 +614,23 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     stride = max(1, -(-args.steps // 16))          # at most 16 armed steps: an armed dispatch costs a few us of its own
     armed = list(range(0, args.steps, stride))[:16]
     slot_of = {i: k for k, i in enumerate(armed)}
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, mode, slot_of.get(i, -1))
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # TIMED_WINDOWS windows of exactly --steps steps each, every one bracketed by barrier + synchronize on both sides and
+    # reduced to the slowest rank; the line reports the MEDIAN window (ms_per_step, value) with the fastest and slowest next
+    # to it: one window of 20 steps is 1.2 ms of wall clock, and single windows differ by a few percent on one box.
+    window_dt = []
+    for w in range(TIMED_WINDOWS):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, mode, slot_of.get(i, -1) if w == 0 else -1)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        window_dt.append(dt)
+    dt = float(np.median(window_dt))
     enc_ms = float(np.mean([native.profile_read(k) for k in range(len(armed))]))
     identical = ranks_agree(torch, dist, world, [out])
 
@@ -631,14 +662,33 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     # rank's payload; untimed, N = 1 only (with N > 1 the step's own decode already runs over R = N payloads)
     lvdec_ms = event_ms(torch, lambda: native.hsq_levels_decode(u, N_BIT, args.random, None, seed, partials, lb_ub, levels, codes, cb,
                                                                  out, packed6)) if world == 1 else None
-    dec8_ms = None
+    dec8_ms, dec8 = None, None
     if world == 1:
+        # EIGHT DIFFERENT payloads (the three gradients at eight scales, compressed by this rank's kernels), decoded in a timed
+        # region of its own with the step's scheme: windows of --steps launches between synchronize() pairs on the host
+        # clock, median window reported, next to the event-timed back-to-back figure
         g8 = wire.alloc(dev, ranks=8)
         for r in range(8):
+            compress(grads[r % 3] * (1.0 + 0.25 * r))
             g8[r].copy_(ex.gathered[0])
-        dec8_ms = event_ms(torch, lambda: native.hsq_decode_sum_packed(
-            g8, M, cb, N_BIT, out, 8, wire.codes_off, wire.levels_off, wire.lbub_off,
-            level_dtype=native.PACKED6 if packed6 else torch.uint8))
+        compress(grads[0])
+
+        def dec8_call():
+            native.hsq_decode_sum_packed(g8, M, cb, N_BIT, out, 8, wire.codes_off, wire.levels_off, wire.lbub_off,
+                                         level_dtype=native.PACKED6 if packed6 else torch.uint8)
+        dec8_ms = event_ms(torch, dec8_call)
+        wins = []
+        for w in range(TIMED_WINDOWS):
+            torch.cuda.synchronize()
+            t8 = time.perf_counter()
+            for _ in range(max(args.steps, 20)):
+                dec8_call()
+            torch.cuda.synchronize()
+            wins.append((time.perf_counter() - t8) / max(args.steps, 20) * 1e3)
+        dec8 = {"ms_median_window": float(np.median(wins)), "ms_min": min(wins), "ms_max": max(wins), "launches_per_window": max(args.steps, 20),
+                "ms_events_back_to_back": dec8_ms, "payloads": "8 different (three gradients at eight scales)",
+                "algorithmic_bytes": (2.0 * 8 / 16 + 4.0) * SIZE,
+                "frac": (2.0 * 8 / 16 + 4.0) * SIZE / (float(np.median(wins)) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del g8
     exch_ms, exch_by = None, None
     if world > 1:
@@ -661,6 +711,9 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     line = {
         "metric": "gradient elements quantized/sec (HSQ d=16 k=8)", "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "ms_per_step_min": min(window_dt) / args.steps * 1e3, "ms_per_step_max": max(window_dt) / args.steps * 1e3,
+        "timed_windows": {"count": len(window_dt), "steps_each": args.steps, "ms_per_step": [d / args.steps * 1e3 for d in window_dt],
+                          "reported": "median window (value and ms_per_step); kernel_ms: events on the first window's dispatches"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "value_is": "end_to_end (encode + levels" + (" + exchange" if world > 1 else "") + " + decode-mean per step); "
                     "compress_only holds the encode + levels rate (SURVEY 8d's definition)",
@@ -700,7 +753,7 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
                              "(agrees with rocprofv3, profiles/); a bracket RECORDED around the call reads "
                              "kernel_ms_recorded_bracket, an empty one empty_recorded_bracket_ms"},
         "phases_ms": {"encode": enc_ms, "levels": lv_ms, "compress": cmp_ms, "decode_mean": dec_ms, "levels_decode_fused": lvdec_ms,
-                      "decode_mean_R8": dec8_ms, "exchange": exch_ms,
+                      "decode_mean_R8": dec8_ms, "decode_mean_R8_timed": dec8, "exchange": exch_ms,
                       "step": ("encode + gq_hsq_levels_decode (level quantiser and decode of the rank's own payload in one launch)" if fused
                                else "encode + levels + " + ("exchange + " if world > 1 else "") + "decode-mean"),
                       "note": "encode: HIP events attached to the dispatch in the timed region; levels / compress / decode_mean / "
@@ -792,11 +845,13 @@ def list_workloads(args, torch, np, native, dev, steps=150, warm=40):
     hsq_kw = dict(c_dim=C_DIM, k_bit=K_BIT, n_bit=N_BIT)
     qsgd_kw = dict(c_dim=128, k_bit=8, n_bit=2)
 
-    def one(Comp, kw, lists, hsq):
+    def one(Comp, kw, lists, hsq, ef=False, two_phase=False):
         res = {}
+        if ef:      # error feedback adds into the gradients in place (ps_quantizer.py:35): private copies of the input lists
+            lists = [[g.clone() for g in l] for l in lists]
         for graph in (False, True):
-            qargs = Namespace(no_cuda=False, random=1, ef=False, two_phase=False, scale="exp", num_users=1, mode="ps", cr=256,
-                              gq_graph=graph, **kw)
+            qargs = Namespace(no_cuda=False, random=1, ef=ef, two_phase=two_phase, scale=EF_BENCH_SCALE if ef else "exp", num_users=1,
+                              mode="ps", cr=256, gq_graph=graph, **kw)
             params = [torch.nn.Parameter(torch.zeros(*sh, device=dev)) for sh in shapes]
             with contextlib.redirect_stdout(sys.stderr):     # the constructors report the reference's dimension repair on stdout
                 q = Quantizer(Comp, params, qargs)
@@ -833,17 +888,29 @@ def list_workloads(args, torch, np, native, dev, steps=150, warm=40):
                 p.grad = g.view(g.shape)
             gl = [params[i].grad.data for i in grp.idxs]
             wire0 = q._wire[0]
-            cmp_ms = event_ms(torch, lambda: grp.encode(gl, wire0, 0, 0))       # HSQ: encode + levels; QSGD: the one compress launch
+            errs = [params[i].error[0] for i in grp.idxs] if ef else None
+            cmp_ms = event_ms(torch, lambda: grp.encode(gl, wire0, 0, 0, errs, float(EF_BENCH_SCALE) if ef else None))   # HSQ: encode + levels; QSGD: the one compress launch
             k_elems = sum(cd.numel for cd in grp.codecs)
             if hsq:
                 k_ms = float(np.mean([native.profile_read(k) for k in range(8)]))
                 algo = ALGO_BYTES_PER_ELEM * k_elems
             else:
                 k_ms, algo = cmp_ms, QSGD_ALGO_BYTES_PER_ELEM * k_elems
-            res.update({"kernel_ms": k_ms, "compress_ms": cmp_ms, "kernel_elements": k_elems,
-                        "frac": algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_compress": algo / (cmp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "decode_mean_ms_R1": event_ms(torch, lambda: grp.decode_mean(q._wire[:1], 1))})
-            if hsq:     # how many subvectors the prefilter's first pass does not settle (second pass / exact scan), per-tensor encodes
+            if ef and hsq:
+                # error feedback, per element of a compressed tensor: the encode reads grad and error and writes grad + scale*error
+                # back (12 B) + u, code (5 / 16 B); the level launch reads u and the updated grad and writes the residual and the
+                # level (8 B + 5 / 16 B): 20.625 B against 4.125 B without error feedback
+                algo_c = EF_ALGO_BYTES_PER_ELEM * k_elems
+                res.update({"kernel_ms": k_ms, "compress_ms": cmp_ms, "levels_ms": max(0.0, cmp_ms - k_ms), "kernel_elements": k_elems,
+                            "algorithmic_bytes": algo_c, "algorithmic_bytes_encode": EF_ENCODE_BYTES_PER_ELEM * k_elems,
+                            "frac": EF_ENCODE_BYTES_PER_ELEM * k_elems / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "frac_compress": algo_c / (cmp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "decode_mean_ms_R1": event_ms(torch, lambda: grp.decode_mean(q._wire[:1], 1))})
+            else:
+                res.update({"kernel_ms": k_ms, "compress_ms": cmp_ms, "kernel_elements": k_elems, "algorithmic_bytes": algo,
+                            "frac": algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_compress": algo / (cmp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "decode_mean_ms_R1": event_ms(torch, lambda: grp.decode_mean(q._wire[:1], 1))})
+            if hsq and not ef:     # how many subvectors the prefilter's first pass does not settle (second pass / exact scan), per-tensor encodes
                 cbk, flagged, subv = grp.codebook, 0, 0
                 for i in grp.idxs:
                     g = lists[0][i].contiguous().view(-1)
@@ -864,13 +931,20 @@ def list_workloads(args, torch, np, native, dev, steps=150, warm=40):
     out = {"resnet50": one(NearestNeighborCompressor, hsq_kw, synth, True),
            "qsgd": one(QSGDCompressor, qsgd_kw, synth, False),
            "resnet50_real": one(NearestNeighborCompressor, hsq_kw, real, True),
+           # error feedback (ps_quantizer.py:34-39) and error feedback + two-phase (:52-61) on the back-propagated gradients
+           "resnet50_ef": one(NearestNeighborCompressor, hsq_kw, real, True, ef=True),
+           "resnet50_ef_twophase": one(NearestNeighborCompressor, hsq_kw, real, True, ef=True, two_phase=True),
            "note": ("ResNet-50/CIFAR parameter list, %d elements in 161 tensors (76 through the codebook / the bucket quantiser, 85 of "
                     "<= 1000 elements as f32), one rank, PSQuantizer.record + apply per step (three input lists in turn, put under the parameters' existing .grad objects by the library's C++ helper inside the timed region), %d timed steps after %d; ms_per_step_graph: the "
                     "library's default (HIP graph replay -- record + apply as ONE graph per step at one rank and one user --, draws keyed by device step words), ms_per_step_eager: gq_graph off; kernel_ms: "
                     "HSQ = HIP events attached to the multi-tensor encode's dispatch on 8 eager steps, QSGD = the one compress launch "
                     "(events around 50 back-to-back launches); frac = algorithmic bytes of the compressed tensors / kernel_ms / 8 TB/s; "
                     "resnet50_real: gradients of driver.ResNet50 back-propagated from seeded synthetic CIFAR batches of 128 (three lists "
-                    "in turn); fixup_fraction: subvectors the prefilter's first pass leaves to the second pass or the exact scan"
+                    "in turn); fixup_fraction: subvectors the prefilter's first pass leaves to the second pass or the exact scan; "
+                    "resnet50_ef / resnet50_ef_twophase: --ef (and --two-phase) on the same gradients with --scale 0 (the in-place add of "
+                    "ps_quantizer.py:35 would otherwise accumulate in the bench's recycled inputs; same launches, bytes and arithmetic), kernel_ms = the error-feedback encode (reads grad + error, writes grad back: 12.3125 B per "
+                    "element), levels_ms = compress_ms - kernel_ms (reads u and grad, writes error and level: 8.3125 B), frac_compress "
+                    "against 20.625 B per element"
                     % (n, steps, warm))}
     return out
 
@@ -891,8 +965,8 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
     shapes = [tuple(p.shape) for p in ResNet50(num_classes=10).parameters()]
     n = sum(int(np.prod(s)) for s in shapes)
     if hsq:     # README: --quantizer hsq --network resnet50 --c-dim 16 --k-bit 8 --n-bit 6 (--random defaults to True)
-        qargs = Namespace(c_dim=C_DIM, k_bit=K_BIT, n_bit=N_BIT, no_cuda=False, random=1, ef=False, two_phase=False,
-                          scale="exp", num_users=1, mode="ps", cr=256)
+        qargs = Namespace(c_dim=args.c_dim or C_DIM, k_bit=K_BIT, n_bit=args.n_bit or N_BIT, no_cuda=False, random=1, ef=bool(args.ef),
+                          two_phase=bool(args.two_phase), scale=EF_BENCH_SCALE if args.ef else "exp", num_users=1, mode="ps", cr=256)
 
         Comp = NearestNeighborCompressor
     else:       # README: --quantizer qsgd --c-dim 128 --n-bit 2
@@ -947,7 +1021,8 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
         p.grad = g.view(g.shape)
     gl = [params[i].grad.data for i in grp.idxs]
     wire0 = q._wire[0]
-    cmp_ms = event_ms(torch, lambda: grp.encode(gl, wire0, 0, 0))       # HSQ: encode + levels; QSGD: the one compress launch
+    errs = [params[i].error[0] for i in grp.idxs] if (hsq and args.ef) else None
+    cmp_ms = event_ms(torch, lambda: grp.encode(gl, wire0, 0, 0, errs, float(EF_BENCH_SCALE) if errs else None))       # HSQ: encode + levels; QSGD: the one compress launch
     if hsq and args.graph:      # the encode's own time: armed dispatches of eager steps after the timed region (a replayed graph
         armed = list(range(8))  # has no armed dispatch); whole steps, so that the encode meets the caches a step leaves behind
         q.use_graphs = False
@@ -974,12 +1049,15 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
         return None
     if hsq:
         k_ms = float(np.mean([native.profile_read(k) for k in range(len(armed))]))
-        algo = ALGO_BYTES_PER_ELEM * k_elems
+        dd = qargs.c_dim
+        algo = (4.0 + 2.0 / dd) * k_elems      # 4 B read + (code + level) per dd elements
         kernel = ("gq_hsq_encode_batched = hsq_encode_pf_kernel<uint8_t, BATCHED> (ONE launch for the 76 codebook-compressed "
                   "tensors: prefilter, exact rescoring, in-place fix-up, per-tensor lb/ub by atomics)")
-        match, metric = "hsq_encode_pf_kernel", "gradient elements quantized/sec (HSQ d=16 k=8, ResNet-50 list)"
-        cfg = ("ResNet-50/CIFAR parameter list (161 tensors, %d elements) per rank through PSQuantizer.record + apply, HSQ c_dim=16 "
-               "k_bit=8 n_bit=6 random=1 on-device draws (BASELINE configs[2]; the README's hsq command), byte wire, multi-tensor kernels" % n)
+        match, metric = "hsq_encode_pf_kernel", "gradient elements quantized/sec (HSQ d=%d k=8, ResNet-50 list)" % dd
+        cfg = ("ResNet-50/CIFAR parameter list (161 tensors, %d elements) per rank through PSQuantizer.record + apply, HSQ c_dim=%d "
+               "k_bit=8 n_bit=%d random=1 on-device draws%s%s (%s), byte wire, multi-tensor kernels"
+               % (n, dd, qargs.n_bit, ", error feedback" if args.ef else "", ", two-phase" if args.two_phase else "",
+                  "BASELINE configs[2]; the README's hsq command" if (dd == 16 and qargs.n_bit == 6) else "main.py:90-92's own defaults" if (dd == 32 and qargs.n_bit == 8) else "a variant"))
         note = ("kernel_ms: HIP start/stop events attached to the encode's dispatch on %d %s; compress_ms = encode + "
                 "levels launches back to back after the timed region; the step itself is host-bound (per-parameter torch work)"
                 % (len(armed), "eager steps run after the timed region (a replayed graph has no armed dispatch)" if args.graph

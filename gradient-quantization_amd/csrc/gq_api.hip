@@ -118,8 +118,12 @@ GQ_API int gq_hsq_decode_sum_batched(const gq_hsq_batch *b, const uint8_t *gathe
                                                   b->codebook, b->n_bit, b->level_bytes == GQ_LEVELS_PACKED6, out, plain,
                                                   stream);
         return gqi_hsq_decode_sum_batched_d(b->seg_table, b->tile_seg, b->nseg, b->ntiles, gathered, user_stride_bytes, R,
-                                            b->codebook, b->d, b->n_bit, out, plain, stream);
+                                            b->codebook, b->d, 1, b->n_bit, out, plain, stream);
     }
+    // 16-bit levels on a prefilter shape (main.py's own defaults: n_bit 8 with stochastic rounding reaches level 256)
+    if (gq::pf_dim(b->d) && b->K == 256 && b->code_bytes == 1 && b->level_bytes == 2 && b->n_bit >= 1 && b->n_bit <= 15 && !(plain & 2))
+        return gqi_hsq_decode_sum_batched_d(b->seg_table, b->tile_seg, b->nseg, b->ntiles, gathered, user_stride_bytes, R,
+                                            b->codebook, b->d, 2, b->n_bit, out, plain, stream);
     if (b->level_bytes == GQ_LEVELS_PACKED6)
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched: GQ_LEVELS_PACKED6 needs d = 16, K = 256, n_bit <= 6");
     return gqi_hsq_decode_sum_batched_any(b->seg_table, b->tile_seg, b->nseg, b->ntiles, gathered, user_stride_bytes, R,

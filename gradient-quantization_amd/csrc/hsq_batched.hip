@@ -686,58 +686,95 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_d_kernel(
     }
 }
 
-// decode-mean over a segment table for the other prefilter sub-dimensions (D = 8, 32; K = 256): one thread
-// per (padded subvector, 4-float unit); codebook rows an odd number of 16-byte units apart in LDS.
-template <int D>
-__global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_d_kernel(
+// decode-mean over a segment table for K = 256 and D = 8 / 16 / 32 with byte or 16-bit levels (main.py:90-92's own defaults
+// -- c_dim 32, n_bit 8, stochastic rounding -- reach level 256: the levels travel as int16): a WAVE per tile of 64 padded
+// subvectors.  Round 4 ran one thread per (subvector, 16-byte unit) -- every thread fetched its tensor's record, the
+// payload's (lb, ub), the code and the level for 16 bytes of output: 38.8 us for the ResNet-50 list at D = 32, int16 levels,
+// one payload (2.4 TB/s written).  Here lane l is subvector l when the payloads are read -- ONE code and ONE level load per
+// subvector and payload, the norm computed once (level * range, * 2^-n, + lb: unfused, probabilistic_scalar_compressor.py:31-32)
+// and parked with the code in the wave's LDS slots -- and unit l of each of the D / 4 passes when the tile is written:
+// unit u = 64 p + l belongs to subvector u / (D / 4), its lanes read that subvector's (code, norm) pair (a broadcast read),
+// the codebook row's four floats, multiply, add in PAYLOAD ORDER (chunks of DT_RCH payloads, ascending), and every store
+// instruction of the wave writes one contiguous kilobyte.  The tile's record and the payloads' (lb, ub) are wave-uniform.
+constexpr int DT_THREADS = 512;
+constexpr int DT_WAVES = DT_THREADS / 64;
+constexpr int DT_RCH = 8;   // payloads staged per chunk
+template <int D, typename LevelT>
+__global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
     float *__restrict__ out, int plain) {
-    constexpr int UPS = D / 4;                               // 16-byte units per subvector
-    constexpr int RS = ((D / 4) & 1) ? D : D + 4;            // LDS row stride in floats
+    constexpr int UPS = D / 4;                               // 16-byte units per subvector = passes per tile
+    constexpr int RS = ((D / 4) & 1) ? D : D + 4;            // LDS row stride in floats: an odd number of 16-byte units
     __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];
-    for (int i = threadIdx.x; i < 256 * UPS; i += BT_THREADS)
+    __shared__ __attribute__((aligned(8))) unsigned s_pair[DT_WAVES * DT_RCH * 64 * 2];   // { code, bits of the norm } per (wave, payload of the chunk, subvector)
+    for (int i = threadIdx.x; i < 256 * UPS; i += DT_THREADS)
         *reinterpret_cast<f32x4 *>(s_cb + (i / UPS) * RS + 4 * (i % UPS)) = reinterpret_cast<const f32x4 *>(cb)[i];
     __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const float inv_s = 1.0f / (float)(1 << n_bit);
     const MeanDiv md = mean_div_of(R, !plain);
-    const int64_t total = ntiles * 64 * UPS;
-    const int64_t stride = (int64_t)gridDim.x * BT_THREADS;
-    for (int64_t i = (int64_t)blockIdx.x * BT_THREADS + threadIdx.x; i < total; i += stride) {
-        const int64_t g = i / UPS;
-        const int q = (int)(i % UPS);
-        const int64_t tile = g >> 6;
-        const int seg = tile_seg[tile];
+    auto uniform64 = [](int64_t v) {   // a wave-uniform value read through a vector path -> SGPRs
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    unsigned *const pairs = s_pair + wave * (DT_RCH * 64 * 2);
+    const int q = lane % UPS, ls = lane / UPS;               // this lane's unit inside a subvector / subvector inside a pass
+    for (int64_t tile = (int64_t)blockIdx.x * DT_WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * DT_WAVES) {
+        const int seg = __builtin_amdgcn_readfirstlane(tile_seg[tile]);
         const int64_t *rec = seg_table + 8 * (int64_t)seg;
-        const int64_t local = (tile - rec[2]) * 64 + (g & 63);
-        if (local >= rec[1]) continue;
-        const int64_t code_off = rec[3] + local, level_off = rec[4] + local, lbub_off = rec[5];
-        f32x4 acc;
-        auto payload = [&](int r, auto first) {
-            const uint8_t *p = gathered + (int64_t)r * user_stride;
-            const float *lbub = reinterpret_cast<const float *>(p + lbub_off);
-            const float lb = lbub[0], range = lbub[1] - lb;
-            float n = (float)p[level_off] * range;   // prob_scalar:31-32, unfused
-            n = n * inv_s;                           // == / 2^n_bit exactly
-            n = n + lb;
-            const f32x4 c = *reinterpret_cast<const f32x4 *>(s_cb + (int)p[code_off] * RS + 4 * q);
-            const f32x4 n4 = {n, n, n, n};
-            const f32x4 dec = c * n4;
-            if constexpr (decltype(first)::value) {
-                acc = dec;
-            } else {
-                acc = acc + dec;
+        const int64_t m = uniform64(rec[1]), sv0 = (tile - uniform64(rec[2])) * 64;
+        const int64_t code_off = uniform64(rec[3]) + sv0, level_off = uniform64(rec[4]), lbub_off = uniform64(rec[5]);
+        float *const dst = out + uniform64(rec[6]) + sv0 * D;
+        const int valid = (int)(m - sv0 < 64 ? m - sv0 : 64);      // subvectors of this tile that exist (>= 1)
+        const int lsv = lane < valid ? lane : valid - 1;           // (a padding lane re-reads the last one; its units are not stored)
+        f32x4 acc[UPS];
+        for (int r0 = 0; r0 < R; r0 += DT_RCH) {
+            const int nr = R - r0 < DT_RCH ? R - r0 : DT_RCH;
+            // lane = subvector: this chunk's (code, norm) pairs into the wave's slots
+            for (int rr = 0; rr < nr; ++rr) {
+                const uint8_t *p = gathered + (int64_t)(r0 + rr) * user_stride;
+                const float *lbub = reinterpret_cast<const float *>(p + lbub_off);
+                const float lb = lbub[0], range = lbub[1] - lb;
+                float n = (float)reinterpret_cast<const LevelT *>(p + level_off)[sv0 + lsv] * range;   // prob_scalar:31-32, unfused
+                n = n * inv_s;                                                                        // == / 2^n_bit exactly
+                n = n + lb;
+                const unsigned code = p[code_off + lsv];
+                *reinterpret_cast<uint2 *>(pairs + (rr * 64 + lane) * 2) = make_uint2(code, __float_as_uint(n));
             }
-        };
-        payload(0, std::true_type{});
-        for (int r = 1; r < R; ++r) payload(r, std::false_type{});
-        if (md.apply) {
-            acc[0] = mean_div(acc[0], md);
-            acc[1] = mean_div(acc[1], md);
-            acc[2] = mean_div(acc[2], md);
-            acc[3] = mean_div(acc[3], md);
+            __builtin_amdgcn_wave_barrier();   // (written and read by this wave only: LDS operations of a wave stay in order)
+            // lane = unit of a pass: products in payload order
+#pragma unroll
+            for (int pss = 0; pss < UPS; ++pss) {
+                const int s = pss * (64 / UPS) + ls;
+                for (int rr = 0; rr < nr; ++rr) {
+                    const uint2 cn = *reinterpret_cast<const uint2 *>(pairs + (rr * 64 + s) * 2);
+                    const f32x4 c = *reinterpret_cast<const f32x4 *>(s_cb + cn.x * RS + 4 * q);
+                    const float n = __uint_as_float(cn.y);
+                    const f32x4 n4 = {n, n, n, n};
+                    const f32x4 dec = c * n4;
+                    if (r0 == 0 && rr == 0) {
+                        acc[pss] = dec;
+                    } else {
+                        acc[pss] = acc[pss] + dec;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        *reinterpret_cast<f32x4 *>(out + rec[6] + local * D + 4 * q) = acc;
+#pragma unroll
+        for (int pss = 0; pss < UPS; ++pss) {
+            const int s = pss * (64 / UPS) + ls;
+            f32x4 v = acc[pss];
+            if (md.apply) {
+                v[0] = mean_div(v[0], md);
+                v[1] = mean_div(v[1], md);
+                v[2] = mean_div(v[2], md);
+                v[3] = mean_div(v[3], md);
+            }
+            if (s < valid) *reinterpret_cast<f32x4 *>(dst + (pss * 64 + lane) * 4) = v;
+        }
     }
 }
 
@@ -922,28 +959,45 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_d16(const int64_t *seg_table, const i
     return GQ_OK;
 }
 
-// K = 256, d = 8 or 32, byte codes and levels
+// K = 256, d = 8 / 16 / 32, byte codes, byte or 16-bit levels: a wave per tile (hsq_decode_sum_batched_tile_kernel)
+namespace gq {
+template <int D, typename LevelT>
+static void launch_decode_tile(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
+                               int64_t user_stride_bytes, int R, const float *codebook, int n_bit, float *out, int plain,
+                               hipStream_t st) {
+    static const int bpc = resident_blocks_per_cu(hsq_decode_sum_batched_tile_kernel<D, LevelT>, DT_THREADS, 0);
+    int64_t blocks = (ntiles + DT_WAVES - 1) / DT_WAVES;
+    const int64_t cap = (int64_t)cu_count() * bpc;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched_tile_kernel<D, LevelT>), dim3((unsigned)(blocks < 1 ? 1 : blocks)),
+                       dim3(DT_THREADS), 0, st, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, R, codebook, n_bit, out, plain);
+}
+}  // namespace gq
+
 GQ_INTERNAL int gqi_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                              const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                             const float *codebook, int d, int n_bit, float *out, int plain, void *stream) {
-    if (nseg < 1 || ntiles < 1 || R < 1 || n_bit < 1 || n_bit > 8)
+                                             const float *codebook, int d, int level_bytes, int n_bit, float *out, int plain,
+                                             void *stream) {
+    if (nseg < 1 || ntiles < 1 || R < 1 || n_bit < 1 || n_bit > (level_bytes == 1 ? 8 : 15))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: bad sizes");
     if (!seg_table || !tile_seg || !gathered || !codebook || !out)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: null pointer");
     plain = (plain & 1) ? 1 : 0;
-    if (d == 8) {
-        hipLaunchKernelGGL(gq::hsq_decode_sum_batched_d_kernel<8>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 2)),
-                           dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
-                           user_stride_bytes, R, codebook, n_bit, out, plain);
-    } else if (d == 32) {
-        hipLaunchKernelGGL(gq::hsq_decode_sum_batched_d_kernel<32>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 8)),
-                           dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
-                           user_stride_bytes, R, codebook, n_bit, out, plain);
-    } else {
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched: this path serves d = 8 or 32 (K = 256)");
+    hipStream_t st = gq::as_stream(stream);
+#define GQ_DT_CASE(DD, LB, LT)                                                                                          \
+    if (d == DD && level_bytes == LB) {                                                                                 \
+        gq::launch_decode_tile<DD, LT>(seg_table, tile_seg, ntiles, gathered, user_stride_bytes, R, codebook, n_bit, out, \
+                                       plain, st);                                                                      \
+        GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched");                                                                   \
+        return GQ_OK;                                                                                                   \
     }
-    GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched");
-    return GQ_OK;
+    GQ_DT_CASE(32, 1, uint8_t)
+    GQ_DT_CASE(32, 2, uint16_t)
+    GQ_DT_CASE(8, 1, uint8_t)
+    GQ_DT_CASE(8, 2, uint16_t)
+    GQ_DT_CASE(16, 2, uint16_t)
+#undef GQ_DT_CASE
+    return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched: this path serves d = 8 / 32 (byte or 16-bit levels) and d = 16 (16-bit levels), K = 256");
 }
 
 // error-feedback level kernel of d = 8 / 32 (K = 256): levels + error = v - decode(wire) in one launch

@@ -209,7 +209,7 @@ int gq_hsq_levels_decode(const float *u, int64_t M, int n_bit, int random_mode, 
  *              gq_hsq_batched_path() says GQ_BATCH_EXACT
  *
  * gq_hsq_batched_path(b): which kernels serve (d, K, code_bytes, level_bytes, nseg) --
- *   GQ_BATCH_PREFILTER  K = 256, d in {8, 16, 32}, byte codes: bf16x3 prefilter + exact rescoring (d = 8 / 32: <= 384 tensors)
+ *   GQ_BATCH_PREFILTER  K = 256, d in {8, 16, 32}, byte codes: f16 prefilter + exact rescoring + second pass (any number of tensors)
  *   GQ_BATCH_PAGED      d in {8, 16, 32}, K = 512, 768, ... 65536, int32 codes, <= 384 tensors: the prefilter with the
  *                       pages of 256 codewords resident in LDS (an earlier page keeps a tie: the first maximum)
  *   GQ_BATCH_EXACT      any other d <= 104 and K: exact f32 MFMA scoring, codebook chunked in LDS when large

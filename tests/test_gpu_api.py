@@ -605,16 +605,16 @@ def test_batched_quantizer_reference_default_flags():
 
 @pytest.mark.parametrize("c_dim", [16, 32])
 def test_batched_quantizer_long_tensor_lists(c_dim):
-    """More tensors than the kernels keep segment records for in LDS (384): d = 16 switches to the instantiation
-    that reads the records from global memory, d = 32 is served by the exact multi-tensor kernels instead of the
-    prefilter (the library's choice, gq_hsq_batched_path); same results as per-tensor launches either way."""
+    """More tensors than the kernels keep segment records for in LDS (384): the prefilter kernel (d = 16 and, since
+    round 5, d = 32 / 8 as well) switches to the instantiation that reads the records from global memory; same results as
+    per-tensor launches."""
     shapes = [(1024,)] * 300 + [(32, 64)] * 100 + [(10,)] * 3
     qb, gb = _run_quantizer(shapes, 1, 4, c_dim=c_dim)
     qp, gp = _run_quantizer(shapes, 1, 4, c_dim=c_dim, gq_no_batch=True)
     assert qb._groups and len(qb._groups[0][1]) == 400
     from gq_amd import native
     assert qb._groups[0][2].ready
-    assert qb._groups[0][2]._batch.path == (native.BATCH_PREFILTER if c_dim == 16 else native.BATCH_EXACT)
+    assert qb._groups[0][2]._batch.path == native.BATCH_PREFILTER
     for a, b in zip(gb, gp):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     assert torch.equal(qb._wire, qp._wire)

@@ -516,6 +516,37 @@ def test_full_size_compress_and_decode_mean_equal_the_oracle(nat, oracle):
     assert np.array_equal(_bits(out.cpu().numpy()), _bits(want))
 
 
+@pytest.mark.parametrize("R", [8, 16])
+def test_full_size_decode_mean_of_eight_and_sixteen_payloads_equals_the_oracle(nat, oracle, R):
+    """The kernel ps_quantizer.py:48 becomes on 8 (16) GPUs -- decode-mean over R different payloads -- at BASELINE size,
+    bit for bit against the oracle: R gradients of 25 M elements at different scales compressed on the device (the
+    compress itself is pinned by the test above), every payload decoded by the ORACLE, summed in payload order from +0
+    and divided by R (torch.stack(...).mean(0))."""
+    dev = torch.device("cuda:0")
+    cb_np = _cb(16, 256)
+    cb = torch.from_numpy(cb_np).to(dev)
+    M = 25_000_000 // 16
+    codes = torch.empty((R, M), dtype=torch.uint8, device=dev)
+    levels = torch.empty((R, M), dtype=torch.uint8, device=dev)
+    lb_ub = torch.empty((R, 2), dtype=torch.float32, device=dev)
+    u = torch.empty(M, dtype=torch.float32, device=dev)
+    ws = nat.new_workspace(dev, M)
+    want = np.zeros(25_000_000, dtype=np.float32)
+    for r in range(R):
+        torch.manual_seed(500 + r)
+        g = torch.randn(25_000_000, device=dev) * float(10.0 ** ((r % 5) - 3))
+        nat.hsq_encode(g, cb, codes[r], u, ws)
+        nat.hsq_levels(u, 6, 0, None, 0, ws, lb_ub[r], levels[r])
+        torch.cuda.synchronize()
+        lu = lb_ub[r].cpu().numpy()
+        want = want + oracle.hsq_decompress(codes[r].cpu().numpy(), levels[r].cpu().numpy().astype(np.int32), lu[0], lu[1], cb_np, 6).reshape(-1)
+        del g
+    want = want / np.float32(R)
+    out = torch.empty(25_000_000, dtype=torch.float32, device=dev)
+    nat.hsq_decode_sum(codes.reshape(-1), levels.reshape(-1), lb_ub.reshape(-1), cb, 6, out, R=R)
+    assert np.array_equal(_bits(out.cpu().numpy()), _bits(want))
+
+
 @pytest.mark.parametrize("d", [16, 8, 32])
 def test_prefilter_equals_exact_mfma_at_full_size_and_fixup_rate(nat, d):
     """The f16 prefilter path (d = 16, 8 and 32) must reproduce the exact f32 MFMA kernel bit for bit on 25M
