@@ -90,6 +90,29 @@ constexpr int PF_THREADS = PF_WAVES * 64;
 #define GQ_PF_TAIL 4
 #endif
 constexpr int PF_TAIL = GQ_PF_TAIL;   // swept 2..12 in round 1 (52.3 us at 4..8, 54 at 2 and 12); again at the end of round 3: 3-4 40.35, 6 40.48, 8 40.6, 10 40.8 us
+// End of a workgroup's run.  Every wave takes its ring through the second pass when its tiles are gone: a fixed ~1.2 us
+// for ~11 entries, two waves per SIMD at once, on the launch's critical path (profiles/r05_encode_ab.txt: second pass +
+// leftover scans = 3.9 of 36.5 us).  Round 5 tried the obvious cure -- a wave flushes its ring through the second pass
+// once, when the tile it is about to start lies within PF_FLUSH_AHEAD tiles of the end of its workgroup's run, so that the
+// other waves draw the remaining tiles meanwhile, and scans the 0-3 entries of its last tiles exactly (scan1) -- and
+// measured it SLOWER at every distance (8 ... 32 tiles: 36.7-38.5 us against 35.7; same file, block B): a pass in the loop
+// takes its issue slots from the SIMD's other wave, whose tiles are the critical path by then.  The switch stays (0 = off)
+// for the record; scan1 serves the leftovers of a pass.
+#ifndef GQ_PF_FLUSH_AHEAD
+#define GQ_PF_FLUSH_AHEAD 0
+#endif
+#ifndef GQ_PF_PAIR
+#define GQ_PF_PAIR -1   // -1: per sub-dimension (PfShape::PAIR); 0 / 1: off / on for every D (A/B builds)
+#endif
+#ifndef GQ_PF_FLUSH_MIN
+#define GQ_PF_FLUSH_MIN 3
+#endif
+#ifndef GQ_PF_SCAN1_MAX
+#define GQ_PF_SCAN1_MAX 4
+#endif
+constexpr int PF_FLUSH_AHEAD = GQ_PF_FLUSH_AHEAD;   // 0: no early flush (round 4's behaviour)
+constexpr int PF_FLUSH_MIN = GQ_PF_FLUSH_MIN;       // entries that make an early flush worth a pass
+constexpr int PF_SCAN1_MAX = GQ_PF_SCAN1_MAX;       // leftovers up to this many are scanned one by one by the whole wave
 constexpr int PF_LDS_SEGS = 384;            // batched form: tensors whose segment records are kept in LDS (24 KiB)
 // What depends on the sub-dimension.
 template <int D>
@@ -101,6 +124,9 @@ struct PfShape {
     static constexpr int QCAP = D > 16 ? 32 : 64;     // deferred subvectors a wave can hold (a ring in LDS: D floats each)
     static constexpr bool A_REGS = D <= 16;           // the codebook's f16 A fragments stay in registers (32 VGPRs); D = 32: read from LDS a row block ahead
     static constexpr int NF = 4 * KS;                 // f32x4 registers of a tile per lane: [(block * KS + k-step) * 2 + q]
+    // the two waves of a SIMD end their runs as a pair (the end of the kernel).  Measured (profiles/r05_encode_ab.txt, block C):
+    // D = 32 30.52 against 31.24 us, D = 16 33.83 against 32.96, D = 8 55.4 against 54.6 -- on for D = 32 only
+    static constexpr bool PAIR = GQ_PF_PAIR < 0 ? D > 16 : GQ_PF_PAIR != 0;
     // Error bound of the f16 prefilter (header, 1): E' = sqrt(n2) * (ERR_REL * c2 + 2.02 dc) + ERR_ABS * c2 inside the window of n2.
     // The factor over 2^-11 covers the accumulation roundings of the MFMA and of the reference's chain, 2 D 2^-24 of
     // sum |c_j v_j| <= c2 ||v'||_2 < 2.02 c2 sqrt(n2) together: 0.8 % of the first term for D = 16, 1.6 % for D = 32.
@@ -160,7 +186,7 @@ template <typename CodeT, int D, bool BATCHED, bool EF = false, bool SEGLDS = tr
 __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfArgs a) {
     typedef PfShape<D> SH;
     constexpr int KS = SH::KS, QS = SH::QS, QCAP = SH::QCAP, NF = SH::NF;
-    constexpr bool HALF = SH::HALF;
+    constexpr bool HALF = SH::HALF, PF_PAIR = SH::PAIR;
     GQ_STAMPS_ONLY(const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime(); unsigned long long nscanned = 0, npassed = 0;)
     const float *__restrict__ cb = a.cb;
     float *__restrict__ ws = a.ws;
@@ -170,6 +196,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // s_cb[(k>>2)*QS + 4*j + (k&3)] = c[k][j]
     __shared__ __attribute__((aligned(16))) float s_cb[64 * QS];
     __shared__ int s_next;                     // tile counter of this workgroup's run (see below)
+    __shared__ int s_pairdone[PF_WAVES / 2], s_ringpub[PF_WAVES];   // PF_PAIR: waves of the pair that have ended their runs / a wave's ring (head << 8 | count) at that point
     // Batched form: the segment table (64 B per tensor) goes to LDS once.  Looking a tile's tensor up in
     // global memory costs two dependent round trips at the top of every tile (tile -> segment -> record),
     // which made this form 3x slower than the single-tensor one; from LDS the record is ~100 cycles away,
@@ -415,6 +442,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     if (threadIdx.x == 0) {
         s_next = PF_WAVES;   // the first PF_WAVES tiles of the run go to the waves by index
     }
+    if (threadIdx.x < PF_WAVES / 2) s_pairdone[threadIdx.x] = 0;
     seg_first = BATCHED ? __builtin_amdgcn_readfirstlane(seg_first_v) : 0;
     if (BATCHED && threadIdx.x < PF_MM_SEGS) {
         s_mm[2 * threadIdx.x] = 0xFFFFFFFFu;
@@ -530,6 +558,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // quad permutes and row mirrors (DPP moves: no trip through LDS).  ~360 cycles per subvector against ~1,700 for
     // the whole wave on one subvector at a time (profiles/r04_experiments.txt).
     int qhead = 0, qcnt = 0;   // this wave's ring: first entry, entries (wave-uniform)
+    bool flushed = false;      // the early flush has run (wave-uniform)
+    const int64_t run_len = tile_end - lo_tile;
     auto scan4 = [&](int first, int n) {
         GQ_STAMPS_ONLY(nscanned += n;)
         const int e = lane >> 4, r = lane & 15;
@@ -606,16 +636,63 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             }
         }
     };
+    // Exact scan of ONE ring entry by the whole wave: lane l scores codewords 4l .. 4l+3 (its own quad of the LDS image: 64
+    // different quads, conflict-free; the entry's floats are a broadcast read), first maximum inside the lane in index order,
+    // then across the wave by DPP moves (wave_first_max_nan_dpp: lower lanes hold lower indices).  ~450 cycles; for the one
+    // or two entries a wave's last tiles leave behind (scan4 spends a batch of ~1,200 cycles on up to four).
+    auto scan1 = [&](int slot) {   // slot: entry of s_qv / s_qm (any wave's ring)
+        GQ_STAMPS_ONLY(nscanned += 1;)
+        float w[D];
+        {
+            const f32x4 *qv = reinterpret_cast<const f32x4 *>(s_qv + D * slot);
+#pragma unroll
+            for (int q = 0; q < D / 4; ++q) {
+                const f32x4 x = qv[q];
+                w[4 * q] = x[0];
+                w[4 * q + 1] = x[1];
+                w[4 * q + 2] = x[2];
+                w[4 * q + 3] = x[3];
+            }
+        }
+        const f32x4 p = exact_score_quad<D>(s_cb + lane * QS, w);
+        float bv = p[0];
+        int bi = 4 * lane;
+        take_if_greater_nan(bv, bi, p[1], 4 * lane + 1);
+        take_if_greater_nan(bv, bi, p[2], 4 * lane + 2);
+        take_if_greater_nan(bv, bi, p[3], 4 * lane + 3);
+        wave_first_max_nan_dpp(bv, bi);
+        const bool isnan = nan_bits(bv);     // (every lane holds the result)
+        if (isnan) sawnan = true;
+        if (lane == 0) {
+            const u32x4 m = *reinterpret_cast<const u32x4 *>(s_qm + 4 * slot);
+            *(gcode_ptr)(uintptr_t)((uint64_t)m[0] | ((uint64_t)m[1] << 32)) = (CodeT)bi;
+            ((gf_ptr)u)[m[2]] = bv;
+            if (BATCHED) {
+                if (isnan) poison_seg((int)m[3]);
+                else fold_seg((int)m[3], bv);
+            } else {
+                GQ_LOG_SCAN(worklist[m[2]] = (int)m[2];)   // diagnostics only: which subvectors took an exact scan
+                lmin = fminf(lmin, bv);
+                lmax = fmaxf(lmax, bv);
+            }
+        }
+    };
     // SECOND PASS over up to 32 ring entries from `first` on (header, 4): the same prefilter with everything it left out --
     // the codebook's lo part (cl from LDS), the entry's lo part (vl = f16(v' - vh), one v_fma_mix with an f16 addend) and a
     // scale of the ENTRY's own (its largest |element| goes to [2^4, 2^5): entries that fell out of the wave's window are at
     // home here) -- three MFMAs per chain, error ~2^-17 instead of ~2^-10.  Entry i is column i of the one block; lanes
     // (i, 0) and (i, 1) hold the two halves of its rows and, after the exchange, both score the same group (only (i, 0)
     // stores).  What even this bound does not settle (~1 in 150 entries; non-finite values) is scanned exactly (scan4).
-    auto second_pass = [&](int first, int n) {
+    // Columns 0 .. na-1 are entries first .. of THIS wave's ring, columns na .. na+nb-1 entries first_b .. of wave_b's ring
+    // (the SIMD partner's, handed over at the end of the run: see PF_PAIR below); n = na + nb <= 32.
+    auto second_pass = [&](int first, int na, int wave_b, int first_b, int nb) {
+        const int n = na + nb;
         GQ_STAMPS_ONLY(npassed += n;)
+        auto slot_of = [&](int c) {   // column -> entry of s_qv / s_qm
+            return c < na ? wave * QCAP + ((first + c) & (QCAP - 1)) : wave_b * QCAP + ((first_b + c - na) & (QCAP - 1));
+        };
         const int col = j < n ? j : 0;   // (idle columns repeat entry 0 and store nothing)
-        const int slot = wave * QCAP + ((first + col) & (QCAP - 1));
+        const int slot = slot_of(col);
         const f32x4 *qv = reinterpret_cast<const f32x4 *>(s_qv + D * slot);
         f32x4 xs[2 * KS];   // the entry's floats [16 s + 8 h, + 8) for every k-step (D = 8: zeros in the upper lanes)
 #pragma unroll
@@ -767,7 +844,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         while (left) {   // (rare) one exact scan per entry that is still open
             const int i = __builtin_ctzll(left);
             left &= left - 1;
-            scan4((first + i) & (QCAP - 1), 1);
+            scan1(slot_of(i));   // the whole wave on the one entry: ~450 cycles against scan4's ~1,200 for a batch of one
         }
     };
     GQ_STAMPS_ONLY(const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(); unsigned long long ntl = 0, stamp_acc[6] = {0, 0, 0, 0, 0, 0}, ts_prev;
@@ -995,7 +1072,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         // floats and where the answer goes.
         const bool flagged = valid && !safe;
         uint64_t todo = __ballot(flagged);
-        while (todo) {   // (one trip; a second one only when a tile flags more lanes than the ring has room for)
+        // the one early flush of this wave's ring (see PF_FLUSH_AHEAD): the next tile lies near the end of the workgroup's run
+        bool want_flush = PF_FLUSH_AHEAD > 0 && !flushed && (tn - lo_tile) >= run_len - PF_FLUSH_AHEAD;
+        while (todo || want_flush) {   // (one trip; a second one only when a tile flags more lanes than the ring has room for)
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)todo, 0u));
             const bool mine = ((todo >> lane) & 1) && rank < QCAP - qcnt;
             if (mine) {
@@ -1010,10 +1089,15 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             const uint64_t took = __ballot(mine);
             qcnt += (int)__builtin_popcountll(took);
             todo &= ~took;
-            if (qcnt >= 32) {   // (a wave meets ~1 unsettled subvector per tile: this is the exception; the ring is emptied after the loop)
-                second_pass(qhead, 32);
-                qhead = (qhead + 32) & (QCAP - 1);
-                qcnt -= 32;
+            if (qcnt >= 32 || (want_flush && !todo)) {   // (a full ring is the exception: a wave meets ~1 unsettled subvector per tile)
+                if (qcnt >= 32 || qcnt >= PF_FLUSH_MIN) {
+                    const int n = qcnt < 32 ? qcnt : 32;
+                    second_pass(qhead, n, wave, 0, 0);
+                    qhead = (qhead + n) & (QCAP - 1);
+                    qcnt -= n;
+                    if (want_flush && !todo) flushed = true;
+                }
+                if (!todo) want_flush = false;   // (too few entries for a pass: asked again at the next tile)
             }
         }
 
@@ -1033,11 +1117,52 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     GQ_STAMPS_ONLY(const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();)
     if (BATCHED) flush_minmax();
 
-    while (qcnt) {   // out of tiles: the ring's entries through the second pass (one trip: a wave collects ~12 per launch)
-        const int n = qcnt < 32 ? qcnt : 32;
-        second_pass(qhead, n);
-        qhead = (qhead + n) & (QCAP - 1);
-        qcnt -= n;
+    // out of tiles: what the early flush did not see -- a few entries: exact scans by the whole wave; more (no flush happened:
+    // short runs, PF_FLUSH_AHEAD = 0): the second pass
+    // PF_PAIR (D = 32 only: PfShape::PAIR): the two waves of a SIMD (w and w ^ 4) end their runs as a pair.  The first one to
+    // get here publishes its ring and LEAVES -- its partner's last tiles then have the SIMD to themselves --, the second one
+    // takes both rings through ONE second pass instead of two, the second of them contended.  For D = 16 / 8 this measured
+    // SLOWER (a pair's ~23 entries exceed the 32 columns of a pass often enough that the launch, which ends with its last
+    // wave, waits for a second pass somewhere).  The hand-over is an LDS counter: a wave's ring writes, its published (head, count) word and its add are DS operations of one wave
+    // (in order); the wave whose add returns 1 reads the other's word and entries behind that return.
+    int other_first = 0, other_n = 0;
+    const int partner = wave ^ (PF_WAVES / 2);
+    if (PF_PAIR) {
+        int old = 0;
+        if (lane == 0) {
+            __hip_atomic_store(&s_ringpub[wave], (qhead << 8) | qcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = __hip_atomic_fetch_add(&s_pairdone[wave & (PF_WAVES / 2 - 1)], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == 0) {
+            qcnt = 0;     // the partner takes this ring
+        } else {
+            int pub = 0;
+            if (lane == 0) pub = __hip_atomic_load(&s_ringpub[partner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pub = __builtin_amdgcn_readfirstlane(pub);
+            other_first = pub >> 8;
+            other_n = pub & 255;
+        }
+    }
+    while (qcnt + other_n) {
+        if (qcnt + other_n <= PF_SCAN1_MAX) {   // (a few entries: exact scans by the whole wave are cheaper than a pass)
+            if (qcnt) {
+                scan1(wave * QCAP + qhead);
+                qhead = (qhead + 1) & (QCAP - 1);
+                qcnt -= 1;
+            } else {
+                scan1(partner * QCAP + other_first);
+                other_first = (other_first + 1) & (QCAP - 1);
+                other_n -= 1;
+            }
+        } else {
+            const int na = qcnt < 32 ? qcnt : 32, nb = other_n < 32 - na ? other_n : 32 - na;
+            second_pass(qhead, na, partner, other_first, nb);
+            qhead = (qhead + na) & (QCAP - 1);
+            qcnt -= na;
+            other_first = (other_first + nb) & (QCAP - 1);
+            other_n -= nb;
+        }
     }
 #ifdef GQ_PF_STAMPS
     if (!BATCHED && lane == 0 && blockIdx.x < 256) {   // 12 words per wave behind the log (which this build does not write)
