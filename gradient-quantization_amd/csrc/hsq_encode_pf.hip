@@ -45,9 +45,9 @@
 //     the wave has run out of tiles (or 32 are waiting) the ring goes through a SECOND PASS of the same prefilter with
 //     everything the first one left out -- the codebook's lo part, the entry's lo part, a scale of the entry's own --, i.e.
 //     three MFMAs per chain on a half tile whose columns are the queued subvectors; its bound is ~150 x tighter.  What
-//     is still open after that (~1 % of the queued; non-finite values) is scanned exactly, a quarter wave per subvector,
-//     each lane 16 codewords (scan4).  Round 3 stopped the whole wave for ONE unsettled subvector at a time (1,500 scans
-//     cost 1.5 us of a 42 us launch); here 24,000 second-pass entries and 200 scans cost ~4 us of a launch that is
+//     is still open after that (~1 % of the queued; non-finite values) is scanned exactly by the whole wave, one entry
+//     at a time, each lane 4 codewords (scan1; round 4: a quarter wave per entry, four at a time).  Round 3 stopped the
+//     whole wave for ONE unsettled subvector at a time (1,500 scans cost 1.5 us of a 42 us launch); here 24,000 second-pass entries and 200 scans cost ~4 us of a launch that is
 //     16 % shorter (profiles/r04_encode_ab.txt).  Correctness never depends on a bound being tight -- only on it being
 //     an upper bound.
 //  5. Per-workgroup (min, max) of u go to the workspace; the level kernel folds them into (lb, ub).
@@ -551,95 +551,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         atomicMin(a.seg_minmax + 2 * seg, MAPPED_NAN_LO);
         atomicMax(a.seg_minmax + 2 * seg + 1, MAPPED_NAN_HI);
     };
-    // Exact scan of `n` ring entries from `first` on, FOUR at a time: quarter wave e takes entry e of the batch, its lane r
-    // the 16 codewords of quads r, r + 16, r + 32, r + 48 (ascending index; the sixteen lanes of a ds_read_b128 group
-    // then read sixteen different quads: no bank conflicts) with the reference's fmaf chain, first maximum in
-    // torch.argmax's order (NaN largest, first one wins) inside the lane and then across the quarter's sixteen lanes by
-    // quad permutes and row mirrors (DPP moves: no trip through LDS).  ~360 cycles per subvector against ~1,700 for
-    // the whole wave on one subvector at a time (profiles/r04_experiments.txt).
     int qhead = 0, qcnt = 0;   // this wave's ring: first entry, entries (wave-uniform)
     bool flushed = false;      // the early flush has run (wave-uniform)
     const int64_t run_len = tile_end - lo_tile;
-    auto scan4 = [&](int first, int n) {
-        GQ_STAMPS_ONLY(nscanned += n;)
-        const int e = lane >> 4, r = lane & 15;
-        for (int b0 = 0; b0 < n; b0 += 4) {
-            const bool live = b0 + e < n;   // (an idle quarter re-scans the batch's first entry and stores nothing)
-            const int slot = wave * QCAP + ((first + b0 + (live ? e : 0)) & (QCAP - 1));
-            float w[D];
-            {
-                const f32x4 *qv = reinterpret_cast<const f32x4 *>(s_qv + D * slot);
-#pragma unroll
-                for (int q = 0; q < D / 4; ++q) {
-                    const f32x4 x = qv[q];
-                    w[4 * q] = x[0];
-                    w[4 * q + 1] = x[1];
-                    w[4 * q + 2] = x[2];
-                    w[4 * q + 3] = x[3];
-                }
-            }
-            // The lane's sixteen scores in ascending index order: `>` on |.| keeps the first maximum (three operations a
-            // score); the sum of the |scores| is NaN exactly when one of them is, and only then the order of
-            // torch.argmax (NaN largest, the first one wins) needs the ranks -- a wave-uniform, rare branch.
-            f32x4 p[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) p[q] = exact_score_quad<D>(s_cb + (r + 16 * q) * QS, w);
-            float bv = p[0][0], asum = fabsf(p[0][0]);
-            int bi = 4 * r;
-#pragma unroll
-            for (int i = 1; i < 16; ++i) {
-                take_if_greater(bv, bi, p[i >> 2][i & 3], 64 * (i >> 2) + 4 * r + (i & 3));
-                asum += fabsf(p[i >> 2][i & 3]);
-            }
-            unsigned br = nan_rank(bv);
-            if (__ballot(nan_bits(asum))) {
-                bv = p[0][0], bi = 4 * r, br = nan_rank(bv);
-#pragma unroll
-                for (int i = 1; i < 16; ++i) {
-                    const unsigned pr = nan_rank(p[i >> 2][i & 3]);
-                    const bool gt = pr > br;
-                    br = gt ? pr : br;
-                    bv = gt ? p[i >> 2][i & 3] : bv;
-                    bi = gt ? 64 * (i >> 2) + 4 * r + (i & 3) : bi;
-                }
-            }
-            auto better = [&](unsigned orr, int oi, float ov) {   // the larger rank, the lower index among equals
-                const uint64_t mine = ((uint64_t)br << 32) | (unsigned)~bi, theirs = ((uint64_t)orr << 32) | (unsigned)~oi;
-                const bool take = theirs > mine;
-                br = take ? orr : br;
-                bi = take ? oi : bi;
-                bv = take ? ov : bv;
-            };
-#define GQ_DPP_STEP(CTRL)                                                                 \
-    better(__builtin_amdgcn_update_dpp(0u, br, CTRL, 0xF, 0xF, false),                    \
-           (int)__builtin_amdgcn_update_dpp(0u, (unsigned)bi, CTRL, 0xF, 0xF, false),     \
-           __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(bv), CTRL, 0xF, 0xF, false)))
-            GQ_DPP_STEP(0xB1);    // quad_perm [1,0,3,2]
-            GQ_DPP_STEP(0x4E);    // quad_perm [2,3,0,1]
-            GQ_DPP_STEP(0x141);   // row_half_mirror
-            GQ_DPP_STEP(0x140);   // row_mirror
-#undef GQ_DPP_STEP
-            const bool isnan = live && nan_bits(bv);
-            if (__ballot(isnan)) sawnan = true;   // (lb, ub) become NaN (torch.min / torch.max propagate it)
-            if (live && r == 0) {
-                const u32x4 m = *reinterpret_cast<const u32x4 *>(s_qm + 4 * slot);
-                *(gcode_ptr)(uintptr_t)((uint64_t)m[0] | ((uint64_t)m[1] << 32)) = (CodeT)bi;
-                ((gf_ptr)u)[m[2]] = bv;
-                if (BATCHED) {
-                    if (isnan) poison_seg((int)m[3]);
-                    else fold_seg((int)m[3], bv);
-                } else {
-                    GQ_LOG_SCAN(worklist[m[2]] = (int)m[2];)   // diagnostics only: which subvectors took an exact scan
-                    lmin = fminf(lmin, bv);
-                    lmax = fmaxf(lmax, bv);
-                }
-            }
-        }
-    };
     // Exact scan of ONE ring entry by the whole wave: lane l scores codewords 4l .. 4l+3 (its own quad of the LDS image: 64
     // different quads, conflict-free; the entry's floats are a broadcast read), first maximum inside the lane in index order,
     // then across the wave by DPP moves (wave_first_max_nan_dpp: lower lanes hold lower indices).  ~450 cycles; for the one
-    // or two entries a wave's last tiles leave behind (scan4 spends a batch of ~1,200 cycles on up to four).
+    // or two entries a second pass leaves open (round 4's quarter-wave scan spent a batch of ~1,200 cycles on up to four).
     auto scan1 = [&](int slot) {   // slot: entry of s_qv / s_qm (any wave's ring)
         GQ_STAMPS_ONLY(nscanned += 1;)
         float w[D];
@@ -682,7 +600,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // scale of the ENTRY's own (its largest |element| goes to [2^4, 2^5): entries that fell out of the wave's window are at
     // home here) -- three MFMAs per chain, error ~2^-17 instead of ~2^-10.  Entry i is column i of the one block; lanes
     // (i, 0) and (i, 1) hold the two halves of its rows and, after the exchange, both score the same group (only (i, 0)
-    // stores).  What even this bound does not settle (~1 in 150 entries; non-finite values) is scanned exactly (scan4).
+    // stores).  What even this bound does not settle (~1 in 150 entries; non-finite values) is scanned exactly (scan1).
     // Columns 0 .. na-1 are entries first .. of THIS wave's ring, columns na .. na+nb-1 entries first_b .. of wave_b's ring
     // (the SIMD partner's, handed over at the end of the run: see PF_PAIR below); n = na + nb <= 32.
     auto second_pass = [&](int first, int na, int wave_b, int first_b, int nb) {
@@ -844,7 +762,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         while (left) {   // (rare) one exact scan per entry that is still open
             const int i = __builtin_ctzll(left);
             left &= left - 1;
-            scan1(slot_of(i));   // the whole wave on the one entry: ~450 cycles against scan4's ~1,200 for a batch of one
+            scan1(slot_of(i));   // the whole wave on the one entry: ~450 cycles
         }
     };
     GQ_STAMPS_ONLY(const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(); unsigned long long ntl = 0, stamp_acc[6] = {0, 0, 0, 0, 0, 0}, ts_prev;
@@ -1067,9 +985,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         __builtin_amdgcn_sched_barrier(0);
 
         GQ_STAMP(4)
-        // ---- the few subvectors the bound could not settle (header, 4): into this wave's ring; four at a time they are
-        // scanned exactly (scan4 below), the rest when the wave has run out of tiles.  A flagged lane writes its sixteen
-        // floats and where the answer goes.
+        // ---- the few subvectors the bound could not settle (header, 4): into this wave's ring, which goes through the
+        // second pass when 32 are waiting and when the wave has run out of tiles.  A flagged lane writes its D floats and
+        // where the answer goes.
         const bool flagged = valid && !safe;
         uint64_t todo = __ballot(flagged);
         // the one early flush of this wave's ring (see PF_FLUSH_AHEAD): the next tile lies near the end of the workgroup's run
