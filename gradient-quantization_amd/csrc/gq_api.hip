@@ -107,27 +107,65 @@ GQ_API int gq_hsq_levels_batched(const gq_hsq_batch *b, uint8_t *wire, int rando
                                      b->code_bytes, b->level_bytes, b->n_bit, stream);
 }
 
-GQ_API int gq_hsq_decode_sum_batched(const gq_hsq_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                     float *out, int plain, void *stream) {
-    const int rc = gq::check_batch(b, "gq_hsq_decode_sum_batched");
+namespace gq {
+// the decode-mean of `b`; *tail_taken = 1 when the launch also did the step's tail work
+static int decode_sum_batched(const gq_hsq_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R, float *out,
+                              int plain, const StepTail *tail, int *tail_taken, void *stream) {
+    if (tail_taken) *tail_taken = 0;
+    const int rc = check_batch(b, "gq_hsq_decode_sum_batched");
     if (rc != GQ_OK) return rc;
-    if (!gathered || !out) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: null pointer");
-    if (gq::byte_wire(b)) {
+    if (!gathered || !out) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: null pointer");
+    if (byte_wire(b)) {
         if (b->d == 16)
             return gqi_hsq_decode_sum_batched_d16(b->seg_table, b->tile_seg, b->nseg, b->ntiles, gathered, user_stride_bytes, R,
-                                                  b->codebook, b->n_bit, b->level_bytes == GQ_LEVELS_PACKED6, out, plain,
-                                                  stream);
+                                                  b->codebook, b->n_bit, b->level_bytes == GQ_LEVELS_PACKED6, out, plain, tail,
+                                                  tail_taken, stream);
         return gqi_hsq_decode_sum_batched_d(b->seg_table, b->tile_seg, b->nseg, b->ntiles, gathered, user_stride_bytes, R,
-                                            b->codebook, b->d, 1, b->n_bit, out, plain, stream);
+                                            b->codebook, b->d, 1, b->n_bit, out, plain, tail, tail_taken, stream);
     }
     // 16-bit levels on a prefilter shape (main.py's own defaults: n_bit 8 with stochastic rounding reaches level 256)
-    if (gq::pf_dim(b->d) && b->K == 256 && b->code_bytes == 1 && b->level_bytes == 2 && b->n_bit >= 1 && b->n_bit <= 15 && !(plain & 2))
+    if (pf_dim(b->d) && b->K == 256 && b->code_bytes == 1 && b->level_bytes == 2 && b->n_bit >= 1 && b->n_bit <= 15 && !(plain & 2))
         return gqi_hsq_decode_sum_batched_d(b->seg_table, b->tile_seg, b->nseg, b->ntiles, gathered, user_stride_bytes, R,
-                                            b->codebook, b->d, 2, b->n_bit, out, plain, stream);
+                                            b->codebook, b->d, 2, b->n_bit, out, plain, tail, tail_taken, stream);
     if (b->level_bytes == GQ_LEVELS_PACKED6)
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched: GQ_LEVELS_PACKED6 needs d = 16, K = 256, n_bit <= 6");
+        return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched: GQ_LEVELS_PACKED6 needs d = 16, K = 256, n_bit <= 6");
     return gqi_hsq_decode_sum_batched_any(b->seg_table, b->tile_seg, b->nseg, b->ntiles, gathered, user_stride_bytes, R,
                                           b->codebook, b->d, b->K, b->code_bytes, b->level_bytes, b->n_bit, out, plain, stream);
+}
+}  // namespace gq
+
+GQ_API int gq_hsq_decode_sum_batched(const gq_hsq_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                     float *out, int plain, void *stream) {
+    return gq::decode_sum_batched(b, gathered, user_stride_bytes, R, out, plain, nullptr, nullptr, stream);
+}
+
+GQ_API int gq_hsq_decode_sum_batched_tail(const gq_hsq_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                          float *out, int plain, const gq_step_tail *t, void *stream) {
+    if (!t) return gq::decode_sum_batched(b, gathered, user_stride_bytes, R, out, plain, nullptr, nullptr, stream);
+    if (t->struct_bytes != sizeof(gq_step_tail))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched_tail: gq_step_tail.struct_bytes is %u, this library's layout has %zu",
+                        t->struct_bytes, sizeof(gq_step_tail));
+    if (t->rows_R < 1 || t->n < 0 || (t->n > 0 && (!t->rows || !t->out)) || (t->row_stride_bytes & 3) != 0 ||
+        (t->rng_state && (t->rng_pairs < 1 || t->rng_pairs > 256)) || t->reset_words < 0 ||
+        (t->reset_words > 0 && (!t->reset_dst || !t->reset_src)))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched_tail: bad gq_step_tail");
+    gq::StepTail tail = {};
+    tail.rows = static_cast<const uint8_t *>(t->rows);
+    tail.row_stride_bytes = t->row_stride_bytes;
+    tail.n = t->n;
+    tail.out = t->out;
+    tail.rng_state = t->rng_state;
+    tail.reset_dst = t->reset_dst;
+    tail.reset_src = t->reset_src;
+    tail.R = t->rows_R;
+    tail.rng_pairs = t->rng_state ? t->rng_pairs : 0;
+    tail.reset_words = t->reset_words;
+    int taken = 0;
+    const int rc = gq::decode_sum_batched(b, gathered, user_stride_bytes, R, out, plain, &tail, &taken, stream);
+    if (rc != GQ_OK || taken) return rc;
+    // a decode path without the in-kernel tail (exact kernels, unaligned wires): the same work as a launch of its own
+    return gq_mean_rows(t->rows, t->row_stride_bytes, t->rows_R, t->n, t->out, t->rng_state, t->rng_pairs, t->reset_dst, t->reset_src,
+                        t->reset_words, stream);
 }
 
 // ---- QSGD ------------------------------------------------------------------------------------------------------

@@ -75,7 +75,7 @@ static inline int grid_for(int64_t n, int block) {
 
 }  // namespace gq
 
-GQ_API int gq_abi_version(void) { return 3; }
+GQ_API int gq_abi_version(void) { return 4; }
 
 GQ_API const char *gq_last_error(void) { return gq::last_error_buf(); }
 

@@ -186,6 +186,35 @@ __device__ __forceinline__ void bump_rng_counter(uint64_t *state, int npairs) { 
     if (state && blockIdx.x == 0 && (int)threadIdx.x < npairs) state[2 * threadIdx.x + 1] += 1;
 }
 
+// The small per-step work of an aggregate (gq_step_tail of include/gq_hsq.h): mean of the uncompressed tensors' rows, one step
+// of the draws' { seed, step } words, the accumulators' reset.  It depends on EARLIER launches only, so a decode-mean launch
+// can take it along (a launch of its own -- gq_mean_rows -- costs ~4 us of kernel and a boundary in a ~70 us step): the first
+// lines of the kernel, spread over the grid; by the time a workgroup reaches its tiles its lanes are back together.
+struct StepTail {
+    const uint8_t *rows;        // [R][row_stride_bytes]: the dense region of the gathered wire (n == 0: no mean)
+    int64_t row_stride_bytes, n;
+    float *out;
+    uint64_t *rng_state;        // nullable
+    uint64_t *reset_dst;        // reset_words == 0: none
+    const uint64_t *reset_src;
+    int R, rng_pairs, reset_words;
+};
+__device__ __forceinline__ void step_tail_run(const StepTail &t) {
+    if (t.n == 0 && !t.rng_state && t.reset_words == 0) return;
+    bump_rng_counter(t.rng_state, t.rng_pairs);
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < t.reset_words; i += blockDim.x) t.reset_dst[i] = t.reset_src[i];
+    if (t.n) {
+        const MeanDiv md = mean_div_of(t.R, true);
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += stride) {
+            float acc = reinterpret_cast<const float *>(t.rows)[i];
+            for (int r = 1; r < t.R; ++r) acc = acc + reinterpret_cast<const float *>(t.rows + (int64_t)r * t.row_stride_bytes)[i];
+            t.out[i] = mean_div(acc, md);   // (+0 + row 0 + row 1 + ...) / R, rows ascending, a true division: torch's CPU mean
+        }
+    }
+}
+
 // The tensors that travel uncompressed (IdenticalCompressor, ps_quantizer.py:18-19: <= 1000 elements each) ride in the same
 // launch as the level quantiser / the QSGD compress: workgroup b copies tensors b, b + grid, ... into their place in the
 // wire.  dense_table int64[ndense][3] = { source (float *), byte offset in ONE user's wire, elements }.

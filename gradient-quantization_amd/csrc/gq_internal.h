@@ -37,11 +37,11 @@ GQ_INTERNAL int gqi_hsq_error_batched_any(const int64_t *seg_table, const int32_
 GQ_INTERNAL int gqi_hsq_decode_sum_batched_d16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                                const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                                const float *codebook, int n_bit, int packed6, float *out, int plain,
-                                               void *stream);
+                                               const gq::StepTail *tail_or_null, int *tail_taken, void *stream);
 GQ_INTERNAL int gqi_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                              const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                              const float *codebook, int d, int level_bytes, int n_bit, float *out, int plain,
-                                             void *stream);
+                                             const gq::StepTail *tail_or_null, int *tail_taken, void *stream);
 GQ_INTERNAL int gqi_hsq_decode_sum_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                                const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                                const float *codebook, int d, int K, int code_bytes, int level_bytes,

@@ -325,8 +325,9 @@ __global__ __launch_bounds__(bt4r_threads(R)) __attribute__((amdgpu_waves_per_eu
 void hsq_decode_sum_batched4_r_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, const float *__restrict__ cb, int n_bit,
-    float *__restrict__ out, int plain) {
+    float *__restrict__ out, int plain, const StepTail tail) {
     extern __shared__ __attribute__((aligned(16))) float s_cb4[];   // [256][4 copies][16] at LDS address 0 (bt4_payload<.., ABS0>)
+    step_tail_run(tail);
     constexpr int THREADS = bt4r_threads(R);
     const float inv_s = 1.0f / (float)(1 << n_bit);
     const MeanDiv md = mean_div_of(R, !plain);
@@ -447,7 +448,7 @@ void hsq_decode_sum_batched4_r_kernel(
 
 template <int R, bool P6, bool FMA = false>
 static void launch_bt4_r(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
-                         int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st) {
+                         int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st, const StepTail &tail) {
     static const int bpc = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_batched4_r_kernel<R, P6, FMA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -461,7 +462,7 @@ static void launch_bt4_r(const int64_t *seg_table, const int32_t *tile_seg, int6
     int64_t blocks = (ntiles * 64 + bt4r_threads(R) - 1) / bt4r_threads(R);
     if (blocks > (int64_t)cu_count() * bpc) blocks = (int64_t)cu_count() * bpc;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched4_r_kernel<R, P6, FMA>), dim3((unsigned)blocks), dim3(bt4r_threads(R)),
-                       (size_t)64 * 1024, st, seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain);
+                       (size_t)64 * 1024, st, seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, tail);
 }
 
 // Any R above BT4_RMAX: the same pipeline in chunks of BT4_RMAX payloads (see hsq_decode_sum_d16u8_rc_kernel): the words of
@@ -475,8 +476,9 @@ __global__ __launch_bounds__(BT4_RC_THREADS) __attribute__((amdgpu_waves_per_eu(
 void hsq_decode_sum_batched4_rc_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
-    float *__restrict__ out, int plain) {
+    float *__restrict__ out, int plain, const StepTail tail) {
     extern __shared__ __attribute__((aligned(16))) float s_cb4[];   // [256][4 copies][16] at LDS address 0
+    step_tail_run(tail);
     constexpr int THREADS = BT4_RC_THREADS, C = 8;
     const float inv_s = 1.0f / (float)(1 << n_bit);
     const MeanDiv md = mean_div_of(R, !plain);
@@ -578,7 +580,7 @@ void hsq_decode_sum_batched4_rc_kernel(
 
 template <bool P6>
 static void launch_bt4_rc(int R, const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
-                          int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st) {
+                          int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st, const StepTail &tail) {
     static const int bpc = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_batched4_rc_kernel<P6>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -592,32 +594,33 @@ static void launch_bt4_rc(int R, const int64_t *seg_table, const int32_t *tile_s
     int64_t blocks = (ntiles * 64 + BT4_RC_THREADS - 1) / BT4_RC_THREADS;
     if (blocks > (int64_t)cu_count() * bpc) blocks = (int64_t)cu_count() * bpc;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched4_rc_kernel<P6>), dim3((unsigned)blocks), dim3(BT4_RC_THREADS), (size_t)64 * 1024, st,
-                       seg_table, tile_seg, ntiles, gathered, user_stride, R, cb, n_bit, out, plain);
+                       seg_table, tile_seg, ntiles, gathered, user_stride, R, cb, n_bit, out, plain, tail);
 }
 
 template <bool P6>
 static void launch_bt4_fixed_r(int R, const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
-                               int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st, bool fma = false) {
+                               int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st, bool fma,
+                               const StepTail &tail) {
     // (the lane's payload inside a group of four travels in the 32-bit offset of its loads: 3 strides + a payload must fit;
     // wires of a gigabyte and more per user take the chunked kernel, whose bases are 64-bit)
     const bool fits32 = user_stride >= 0 && 4 * user_stride < ((int64_t)1 << 32);
     if (fma && fits32 && !plain) {   // GQ_AGGREGATE_FMA: the power-of-two payload counts; every other R keeps the exact kernels
         switch (R) {
-#define GQ_BT4_FMA(N) case N: launch_bt4_r<N, P6, true>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st); return;
+#define GQ_BT4_FMA(N) case N: launch_bt4_r<N, P6, true>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st, tail); return;
             GQ_BT4_FMA(2) GQ_BT4_FMA(4) GQ_BT4_FMA(8) GQ_BT4_FMA(16)
 #undef GQ_BT4_FMA
             default: break;
         }
     }
     switch (fits32 ? R : 0) {
-#define GQ_BT4_CASE(N) case N: launch_bt4_r<N, P6>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st); return;
+#define GQ_BT4_CASE(N) case N: launch_bt4_r<N, P6>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st, tail); return;
         GQ_BT4_CASE(1) GQ_BT4_CASE(2) GQ_BT4_CASE(3) GQ_BT4_CASE(4)
         GQ_BT4_CASE(5) GQ_BT4_CASE(6) GQ_BT4_CASE(7) GQ_BT4_CASE(8)
         GQ_BT4_CASE(9) GQ_BT4_CASE(10) GQ_BT4_CASE(11) GQ_BT4_CASE(12)
         GQ_BT4_CASE(13) GQ_BT4_CASE(14) GQ_BT4_CASE(15) GQ_BT4_CASE(16)
 #undef GQ_BT4_CASE
         default:
-            launch_bt4_rc<P6>(R, seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st);
+            launch_bt4_rc<P6>(R, seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st, tail);
             return;
     }
 }
@@ -703,7 +706,8 @@ template <int D, typename LevelT>
 __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
-    float *__restrict__ out, int plain) {
+    float *__restrict__ out, int plain, const StepTail tail) {
+    step_tail_run(tail);
     constexpr int UPS = D / 4;                               // 16-byte units per subvector = passes per tile
     constexpr int RS = ((D / 4) & 1) ? D : D + 4;            // LDS row stride in floats: an odd number of 16-byte units
     __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];
@@ -933,7 +937,8 @@ GQ_INTERNAL int gqi_hsq_levels_batched_d16(const int64_t *seg_table, const int32
 GQ_INTERNAL int gqi_hsq_decode_sum_batched_d16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                                const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                                const float *codebook, int n_bit, int packed6, float *out, int plain,
-                                               void *stream) {
+                                               const gq::StepTail *tail_or_null, int *tail_taken, void *stream) {
+    if (tail_taken) *tail_taken = 0;
     if (nseg < 1 || ntiles < 1 || R < 1 || n_bit < 1 || n_bit > 8)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: bad sizes");
     if (!seg_table || !tile_seg || !gathered || !codebook || !out)
@@ -942,12 +947,14 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_d16(const int64_t *seg_table, const i
     plain = (plain & 1) ? 1 : 0;
     if ((user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0) {
         // compile-time-R kernels up to BT4_RMAX payloads, the chunked one above: every R is served
+        const gq::StepTail tail = tail_or_null ? *tail_or_null : gq::StepTail{};
         if (packed6)
             gq::launch_bt4_fixed_r<true>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, n_bit, out, plain,
-                                         gq::as_stream(stream), fma);
+                                         gq::as_stream(stream), fma, tail);
         else
             gq::launch_bt4_fixed_r<false>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, n_bit, out, plain,
-                                          gq::as_stream(stream), fma);
+                                          gq::as_stream(stream), fma, tail);
+        if (tail_taken) *tail_taken = 1;
     } else if (packed6) {
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched: packed levels need 4-byte aligned wires");
     } else {
@@ -964,20 +971,22 @@ namespace gq {
 template <int D, typename LevelT>
 static void launch_decode_tile(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
                                int64_t user_stride_bytes, int R, const float *codebook, int n_bit, float *out, int plain,
-                               hipStream_t st) {
+                               hipStream_t st, const StepTail &tail) {
     static const int bpc = resident_blocks_per_cu(hsq_decode_sum_batched_tile_kernel<D, LevelT>, DT_THREADS, 0);
     int64_t blocks = (ntiles + DT_WAVES - 1) / DT_WAVES;
     const int64_t cap = (int64_t)cu_count() * bpc;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched_tile_kernel<D, LevelT>), dim3((unsigned)(blocks < 1 ? 1 : blocks)),
-                       dim3(DT_THREADS), 0, st, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, R, codebook, n_bit, out, plain);
+                       dim3(DT_THREADS), 0, st, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, R, codebook, n_bit, out, plain, tail);
 }
 }  // namespace gq
 
 GQ_INTERNAL int gqi_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                              const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                              const float *codebook, int d, int level_bytes, int n_bit, float *out, int plain,
-                                             void *stream) {
+                                             const gq::StepTail *tail_or_null, int *tail_taken, void *stream) {
+    const gq::StepTail tail = tail_or_null ? *tail_or_null : gq::StepTail{};
+    if (tail_taken) *tail_taken = 0;
     if (nseg < 1 || ntiles < 1 || R < 1 || n_bit < 1 || n_bit > (level_bytes == 1 ? 8 : 15))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched: bad sizes");
     if (!seg_table || !tile_seg || !gathered || !codebook || !out)
@@ -987,8 +996,9 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_d(const int64_t *seg_table, const int
 #define GQ_DT_CASE(DD, LB, LT)                                                                                          \
     if (d == DD && level_bytes == LB) {                                                                                 \
         gq::launch_decode_tile<DD, LT>(seg_table, tile_seg, ntiles, gathered, user_stride_bytes, R, codebook, n_bit, out, \
-                                       plain, st);                                                                      \
+                                       plain, st, tail);                                                                \
         GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched");                                                                   \
+        if (tail_taken) *tail_taken = 1;                                                                                \
         return GQ_OK;                                                                                                   \
     }
     GQ_DT_CASE(32, 1, uint8_t)

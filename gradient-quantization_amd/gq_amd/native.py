@@ -18,16 +18,17 @@ WS_LOG_FIRST = 2 * GQ_MAX_PARTIALS + 4      # f32-sized words in front of the wo
 GQ_FIXUP_PARTIALS = 256
 RANDOM_OFF, RANDOM_GIVEN, RANDOM_DEVICE, RANDOM_DEVICE_KEYED, RANDOM_DEVICE_COUNTER = 0, 1, 2, 3, 4
 ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFILTER_D16K256 = 0, 1, 2, 3, 4
+ENCODE_MFMA_LDS, ENCODE_PREFILTER_BF16X3 = 5, 6
 
 EXPORTS = [     # every entry point include/gq_hsq.h declares (tests/test_host_logic.py compares the two lists)
     "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_workspace_bytes", "gq_profile_read",
     "gq_hsq_encode", "gq_hsq_encode_ex", "gq_hsq_levels", "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided",
     "gq_hsq_levels_decode",
-    "gq_hsq_batched_path", "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched",
+    "gq_hsq_batched_path", "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched", "gq_hsq_decode_sum_batched_tail",
     "gq_axpy_inplace", "gq_sub", "gq_mean_rows", "gq_qsgd_compress", "gq_qsgd_decode_sum", "gq_qsgd_code_bits",
     "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched", "gq_pvq_encode",
 ]
-ABI_VERSION = 3
+ABI_VERSION = 4
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3      # GQ_ERR_* of include/gq_hsq.h
 
 _lib = None
@@ -340,11 +341,18 @@ class HSQBatch(object):
                                           _stream())
         _check(rc, "gq_hsq_levels_batched")
 
-    def decode(self, gathered, R, out, plain=False, fma=False):
+    def decode(self, gathered, R, out, plain=False, fma=False, tail=None):
         """Mean of the R payloads (plain: the decompress of ONE payload as the reference returns it, a -0 stays -0).
-        fma: GQ_AGGREGATE_FMA for this launch (opt-in; not with plain)."""
+        fma: GQ_AGGREGATE_FMA for this launch (opt-in; not with plain).  tail (StepTail): the aggregate's small per-step
+        work rides in the same launch (gq_hsq_decode_sum_batched_tail)."""
         assert gathered.dtype == torch.uint8 and gathered.dim() == 2 and gathered.shape[0] == R and gathered.stride(1) == 1
         stride = int(gathered.stride(0)) if R > 1 else int(gathered.shape[1])
+        if tail is not None:
+            rc = self.L.gq_hsq_decode_sum_batched_tail(self.ref, self._wire(gathered), ctypes.c_int64(stride), ctypes.c_int(R),
+                                                       _dev_ptr(out, torch.float32, "out"),
+                                                       ctypes.c_int(1 if plain else (2 if fma else 0)), tail.ref, _stream())
+            _check(rc, "gq_hsq_decode_sum_batched_tail")
+            return
         rc = self.L.gq_hsq_decode_sum_batched(self.ref, self._wire(gathered), ctypes.c_int64(stride), ctypes.c_int(R),
                                               _dev_ptr(out, torch.float32, "out"),
                                               ctypes.c_int(1 if plain else (2 if fma else 0)), _stream())
@@ -356,6 +364,31 @@ def hsq_batched_path(d, K, code_dtype, nseg=1):
     s = _HSQBatchStruct(ctypes.sizeof(_HSQBatchStruct), int(d), int(K), _CODE_BYTES[code_dtype], 1, 6, int(nseg), -1, 1, 1, 1, 1,
                         None, None, None, None, 0, 0)      # the path depends on the shape only; the (non-null) pointers are not read
     return int(lib().gq_hsq_batched_path(ctypes.byref(s)))
+
+
+class _StepTailStruct(ctypes.Structure):      # gq_step_tail (include/gq_hsq.h)
+    _fields_ = [("struct_bytes", ctypes.c_uint32), ("rows_R", ctypes.c_int32), ("rows", ctypes.c_void_p),
+                ("row_stride_bytes", ctypes.c_int64), ("n", ctypes.c_int64), ("out", ctypes.c_void_p),
+                ("rng_state", ctypes.c_void_p), ("reset_dst", ctypes.c_void_p), ("reset_src", ctypes.c_void_p),
+                ("rng_pairs", ctypes.c_int32), ("reset_words", ctypes.c_int32)]
+
+
+class StepTail(object):
+    """What gq_mean_rows does, as a rider of a decode-mean launch: rows ([R, n] float32 view, rows may be strided) -> out[n];
+    rng_state (int64 [pairs, 2]) stepped; reset = (dst, src) int64 tensors copied src -> dst.  Any part may be None."""
+
+    def __init__(self, rows=None, out=None, rng_state=None, reset=None):
+        self.keep = (rows, out, rng_state, reset)
+        R, n, stride, rp, op = 1, 0, 0, None, None
+        if rows is not None:
+            assert rows.dtype == torch.float32 and rows.dim() == 2 and rows.stride(1) == 1
+            R, n = int(rows.shape[0]), int(rows.shape[1])
+            stride = int(rows.stride(0)) * 4 if R > 1 else n * 4
+            rp, op = rows.data_ptr(), _dev_ptr(out, torch.float32, "out").value
+        sp, pairs = (rng_state.data_ptr(), int(rng_state.shape[0])) if rng_state is not None else (None, 0)
+        rd, rs, rw = _reset_args(reset)
+        self.s = _StepTailStruct(ctypes.sizeof(_StepTailStruct), R, rp, stride, n, op, sp, rd.value, rs.value, pairs, rw.value)
+        self.ref = ctypes.byref(self.s)
 
 
 def _reset_args(reset):

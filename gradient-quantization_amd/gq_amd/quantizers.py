@@ -556,7 +556,7 @@ class _BatchedBase(object):
             self._parts[(lo, hi)] = ent
         return ent
 
-    def decode_mean(self, gathered, R, part=None, plain=False):
+    def decode_mean(self, gathered, R, part=None, plain=False, tail=None):
         """Mean of the R payloads of `gathered` for every tensor of the group (views of one output buffer).
         part = (lo, hi, first): only the tensors [lo, hi) of the group -- the chunks of a split / pipelined exchange land in
         the same buffer, `first` on the first of them (it takes the next output buffer, the others write into it too).
@@ -566,11 +566,14 @@ class _BatchedBase(object):
         out, views = self._out_buffer(gathered.device, advance=part is None or part[2])
         batch = self._batch if part is None else self._range(part[0], part[1])
         if batch is not None:
+            kw = {"tail": tail} if tail is not None else {}      # (BatchedHSQ only: see takes_tail)
             if getattr(self, "fma", False) and R >= 2 and not plain:
-                batch.decode(gathered, R, out, fma=True)      # (BatchedHSQ only: the quantizer sets `fma` on its HSQ groups)
+                batch.decode(gathered, R, out, fma=True, **kw)      # (BatchedHSQ only: the quantizer sets `fma` on its HSQ groups)
             else:
-                batch.decode(gathered, R, out, plain=plain)
+                batch.decode(gathered, R, out, plain=plain, **kw)
         return views
+
+    takes_tail = False      # the group's decode-mean launch can take the aggregate's small per-step work along (native.StepTail)
 
     def upload_layout(self):
         """Device header with the layout columns only (no tensor pointers): enough for decode_mean,
@@ -600,6 +603,8 @@ class BatchedHSQ(_BatchedBase):
     The library decides which kernels serve the group's shape (include/gq_hsq.h, gq_hsq_batched_path): K = 256 with
     d = 8 / 16 / 32 and byte-sized codes the prefilter encode and the specialised levels / decode kernels, larger
     codebooks of those dimensions the paged prefilter, every other shape exact scoring."""
+
+    takes_tail = True      # gq_hsq_decode_sum_batched_tail
 
     @staticmethod
     def eligible(codec):
@@ -1255,6 +1260,40 @@ class PSQuantizer(object):
         single = list(single)
         group_views = {}
 
+        # The aggregate's small per-step work -- the mean of the identity-compressed tensors' rows, one step of the draws'
+        # { seed, step } words, the accumulators' reset (whole-step capture) -- rides in the LAST multi-tensor decode launch
+        # that can take it (native.StepTail: gq_hsq_decode_sum_batched_tail): one kernel and one boundary less per step.
+        # Not with a chunked exchange (several decode launches per group), not with two-phase (its re-compress draws from
+        # the step words and folds into the accumulators AFTER this decode).
+        step_rng = self._rng_state is not None and on_gpu     # one step of the device draws per aggregate (GQ_RANDOM_DEVICE_COUNTER)
+        dense_job = None
+        if len(self.dense_idx) >= 2:
+            # identity tensors: two-phase / error feedback leave them unchanged (roundtrip == clone)
+            rows = gathered[:, self.dense_off:self.dense_off + self.dense_bytes].view(torch.float32)
+            k = self._dense_turn
+            self._dense_turn ^= 1
+            if self._dense_mean[k] is None or self._dense_mean[k].device != rows.device:
+                mean = torch.empty(rows.shape[1], dtype=torch.float32, device=rows.device)
+                views, o = [], 0
+                for i in self.dense_idx:
+                    n = self.codecs[i].numel
+                    views.append(mean[o:o + n].view(self.codecs[i].shape))
+                    o += n
+                self._dense_mean[k], self._dense_views[k] = mean, views
+            dense_job = (rows, k)
+        tail, tail_group = None, -1
+        if on_gpu and not chunked and not two_phase and os.environ.get("GQ_STEP_TAIL", "1") != "0":
+            takers = [gi for gi, g in enumerate(groups) if g[2].takes_tail]
+            mean_in_tail = dense_job is not None and not (plain and R == 1)
+            if takers and (mean_in_tail or step_rng or resets):
+                tail_group = takers[-1]
+                tail = native.StepTail(rows=dense_job[0] if mean_in_tail else None,
+                                       out=self._dense_mean[dense_job[1]] if mean_in_tail else None,
+                                       rng_state=self._rng_state if step_rng else None, reset=resets.pop(0) if resets else None)
+                step_rng = False
+                if mean_in_tail:
+                    dense_job = (None, dense_job[1])      # (done by the decode launch)
+
         def decode_range(lo, hi, first):
             """The tensors whose wire section starts in [lo, hi) (None: all of them)."""
             for gi, (cls, idxs, obj) in enumerate(groups):
@@ -1265,7 +1304,7 @@ class PSQuantizer(object):
                         part = seg_ranges[(gi, lo, hi)] = (sum(1 for i in idxs if self.offsets[i] < lo),
                                                           sum(1 for i in idxs if self.offsets[i] < hi))
                     part = part + (first,)
-                group_views[gi] = obj.decode_mean(gathered, R, part, plain=plain)
+                group_views[gi] = obj.decode_mean(gathered, R, part, plain=plain, tail=tail if gi == tail_group else None)
             for i in single:
                 if lo is None or lo <= self.offsets[i] < hi:
                     done[i] = self.codecs[i].decode_mean(gathered, self.offsets[i], R, plain=plain)
@@ -1278,7 +1317,6 @@ class PSQuantizer(object):
             for k, pnd in enumerate(pending):
                 pnd.wait()
                 decode_range(pnd.lo, self.user_bytes if pnd.hi is None else pnd.hi, k == 0)
-        step_rng = self._rng_state is not None and on_gpu     # one step of the device draws per aggregate (GQ_RANDOM_DEVICE_COUNTER)
         draws2 = self._draws(gathered.device) if two_phase else None     # the second phase compresses again: new draws
         sources = []        # the lists of output views this call's result is assembled from (persistent objects, see below)
         for gi, (cls, idxs, obj) in enumerate(groups):
@@ -1295,20 +1333,11 @@ class PSQuantizer(object):
                     continue
                 gs = dec
             sources.append((idxs, gs))
-        if len(self.dense_idx) >= 2:
-            # identity tensors: two-phase / error feedback leave them unchanged (roundtrip == clone)
-            rows = gathered[:, self.dense_off:self.dense_off + self.dense_bytes].view(torch.float32)
-            k = self._dense_turn
-            self._dense_turn ^= 1
-            if self._dense_mean[k] is None or self._dense_mean[k].device != rows.device:
-                mean = torch.empty(rows.shape[1], dtype=torch.float32, device=rows.device)
-                views, o = [], 0
-                for i in self.dense_idx:
-                    n = self.codecs[i].numel
-                    views.append(mean[o:o + n].view(self.codecs[i].shape))
-                    o += n
-                self._dense_mean[k], self._dense_views[k] = mean, views
-            if plain and R == 1:
+        if dense_job is not None:
+            rows, k = dense_job
+            if rows is None:
+                pass                                     # the mean rode in a decode launch (tail)
+            elif plain and R == 1:
                 self._dense_mean[k].copy_(rows[0])      # the ring's hop: the payload as it is (a -0 stays -0)
             elif rows.device.type == "cuda":
                 # stack().mean(0) with the CPU's arithmetic (true division); the same launch steps the draws' step words

@@ -89,7 +89,7 @@ size_t gq_hsq_workspace_bytes(int64_t M);
 #define GQ_AGGREGATE_FMA 0x100
 
 /* Library / device identification. */
-int gq_abi_version(void);            /* 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words and takes reset words; gq_hsq_batch / gq_qsgd_batch carry the dense table); 2: the round-3 descriptor form of the multi-tensor entry points */
+int gq_abi_version(void);            /* 4: round 5 (gq_hsq_decode_sum_batched_tail, gq_step_tail; impl 6 of gq_hsq_encode_ex); 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words and takes reset words; gq_hsq_batch / gq_qsgd_batch carry the dense table); 2: the round-3 descriptor form of the multi-tensor entry points */
 const char *gq_last_error(void);     /* text of the calling thread's last failure (the library's only per-thread state) */
 /* Fills CU count and the gcnArchName (e.g. "gfx950:sramecc+:xnack-") of `device`. */
 int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
@@ -269,6 +269,28 @@ int gq_hsq_levels_batched(const gq_hsq_batch *b, uint8_t *wire, int random_mode,
  * the tensors (split exchange) passes a copy of the struct with another table. */
 int gq_hsq_decode_sum_batched(const gq_hsq_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
                               float *out, int plain, void *stream);
+
+/* The same launch may take the aggregate's small per-step work along -- everything gq_mean_rows (below) does: the mean of the
+ * uncompressed tensors' rows over rows_R payloads (ps_quantizer.py:18,48), one step of the GQ_RANDOM_DEVICE_COUNTER words, the
+ * reset of the accumulators the next step's kernels fold into.  All of it depends on EARLIER launches only.  A step of the
+ * ResNet-50 list is then three kernels (encode, levels, decode-mean) instead of four; a launch of its own cost ~4 us of
+ * kernel and a boundary in a ~70 us step.  Decode paths without the in-kernel form (exact kernels, unaligned wires) run
+ * gq_mean_rows behind the decode: the results are the same either way.  t == NULL: gq_hsq_decode_sum_batched. */
+typedef struct gq_step_tail {
+    uint32_t struct_bytes;       /* sizeof(gq_step_tail) */
+    int32_t rows_R;              /* rows of the mean (>= 1) */
+    const void *rows;            /* row r = (const float *)((const char *)rows + r * row_stride_bytes); n == 0: no mean */
+    int64_t row_stride_bytes;
+    int64_t n;
+    float *out;                  /* float[n] */
+    uint64_t *rng_state;         /* NULL or rng_pairs (1 .. 256) consecutive { uint64 seed, uint64 step } pairs: step += 1 */
+    uint64_t *reset_dst;         /* reset_words 64-bit words reset_src -> reset_dst (0: none) */
+    const uint64_t *reset_src;
+    int32_t rng_pairs;
+    int32_t reset_words;
+} gq_step_tail;
+int gq_hsq_decode_sum_batched_tail(const gq_hsq_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                   float *out, int plain, const gq_step_tail *t, void *stream);
 
 /*
  * Error-feedback helpers around the per-tensor codec (ps_quantizer.py:35,39):

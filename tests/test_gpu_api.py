@@ -448,6 +448,47 @@ def test_many_small_tensors_in_one_workgroups_run_equal_per_tensor_path(c_dim):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(c_dim=32, n_bit=8), dict(c_dim=8), dict(users=3), dict(ef=True)])
+def test_step_tail_in_the_decode_launch_equals_a_launch_of_its_own(monkeypatch, kw):
+    """gq_hsq_decode_sum_batched_tail: the dense tensors' mean, the step of the draws' { seed, step } words and (whole-step
+    graphs) the accumulators' reset ride in the decode-mean launch by default; $GQ_STEP_TAIL=0 keeps gq_mean_rows as a launch
+    of its own.  Eight steps with stochastic rounding on the device draws (graphs are captured on the way): the same
+    gradients bit for bit, i.e. the same means AND the same sequence of draws."""
+    from gq_amd import native
+    from gq_amd.compressors import NearestNeighborCompressor
+    from gq_amd.quantizers import Quantizer
+    kw = dict(kw)
+    users = kw.pop("users", 1)
+    shapes = RESNET50_COMPRESSED[:7] + RESNET50_SMALL[:4]
+
+    def run(tail):
+        monkeypatch.setenv("GQ_STEP_TAIL", "1" if tail else "0")
+        torch.manual_seed(77)
+        from gq_amd import compressors
+        compressors._seed_counter[0] = 0      # (the pairs' seeds come from torch's seed and a per-process call counter)
+        params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in shapes]
+        q = Quantizer(NearestNeighborCompressor, params, make_args(num_users=users, random=1, **kw))
+        g = torch.Generator(device="cuda").manual_seed(5)
+        inputs = [[[torch.randn(p.shape, device="cuda", generator=g) * 1e-2 for p in params] for _ in range(users)] for _ in range(2)]
+        outs, calls = [], 0
+        for st in range(8):
+            c0 = native.CALLS[0]
+            for u in range(users):
+                for p, x in zip(params, inputs[st % 2][u]):
+                    p.grad = x.clone()
+                q.record(u, epoch=1)
+            q.apply()
+            calls = native.CALLS[0] - c0
+            outs.append([p.grad.data.clone() for p in params])
+        return outs, calls, q
+    with_tail, calls_tail, q1 = run(True)
+    own_launch, calls_own, q0 = run(False)
+    for a, b in zip(with_tail, own_launch):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    assert torch.equal(q1._rng_state, q0._rng_state) and int(q1._rng_state[0, 1]) == 8      # one step per aggregate either way
+
+
 def test_batched_quantizer_equals_per_tensor_path():
     """One launch for all tensors (segment table) == the per-tensor kernels, bit for bit."""
     shapes = RESNET50_COMPRESSED + RESNET50_SMALL

@@ -56,9 +56,9 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libgq_hsq.so does not export %s declared in include/gq_hsq.h" % n
     assert set(native.EXPORTS) == set(names), "the binding's list and the header differ"
-    assert len(names) <= 25, "the ABI was collapsed to <= 25 entry points in round 3 (descriptor structs instead of variants)"
+    assert len(names) <= 26, "the ABI was collapsed to <= 25 entry points in round 3 (descriptor structs instead of variants); round 5 added gq_hsq_decode_sum_batched_tail"
     lib.gq_abi_version.restype = ctypes.c_int
-    assert lib.gq_abi_version() == native.ABI_VERSION == 3
+    assert lib.gq_abi_version() == native.ABI_VERSION == 4
     # nothing but the declared entry points leaves the library (the per-variant launchers are hidden)
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True).stdout
@@ -571,7 +571,7 @@ def test_batch_descriptor_is_validated_before_anything_is_launched():
     assert path() == native.BATCH_PREFILTER and path(d=8) == native.BATCH_PREFILTER and path(d=32, nseg=384) == native.BATCH_PREFILTER
     assert path(K=1024, code_bytes=4) == native.BATCH_PAGED and path(d=32, K=4096, code_bytes=4) == native.BATCH_PAGED
     assert path(d=12, K=512, code_bytes=4) == native.BATCH_EXACT and path(d=24, K=64) == native.BATCH_EXACT
-    assert path(d=32, nseg=385) == native.BATCH_EXACT            # more tensors than the d = 32 prefilter keeps records for
+    assert path(d=32, nseg=385) == native.BATCH_PREFILTER        # (round 5: beyond 384 tensors the records are read from global memory, d = 8 / 32 too)
     assert path(K=1024, code_bytes=4, nseg=500) == native.BATCH_EXACT
     assert path(d=600, K=256) == 0 and b"no multi-tensor kernel" in L.gq_last_error()
     # refused descriptors
@@ -583,13 +583,21 @@ def test_batch_descriptor_is_validated_before_anything_is_launched():
     nan = ctypes.c_float(float("nan"))
     for fn, args in ((L.gq_hsq_encode_batched, (ctypes.c_void_p(64), nan, None)),
                      (L.gq_hsq_levels_batched, (ctypes.c_void_p(64), 0, ctypes.c_uint64(0), None, 0, None)),
-                     (L.gq_hsq_decode_sum_batched, (ctypes.c_void_p(64), ctypes.c_int64(128), 1, ctypes.c_void_p(64), 0, None))):
+                     (L.gq_hsq_decode_sum_batched, (ctypes.c_void_p(64), ctypes.c_int64(128), 1, ctypes.c_void_p(64), 0, None)),
+                     (L.gq_hsq_decode_sum_batched_tail, (ctypes.c_void_p(64), ctypes.c_int64(128), 1, ctypes.c_void_p(64), 0, None, None))):
         assert fn(None, *args) == -1 and b"null descriptor" in L.gq_last_error()
         assert fn(ctypes.byref(desc(struct_bytes=4)), *args) == -1
         assert fn(ctypes.byref(desc(code_bytes=1, K=300)), *args) == -1
     assert L.gq_hsq_encode_batched(ctypes.byref(desc(d=600)), ctypes.c_void_p(64), nan, None) == -2      # no kernel serves the shape
     assert L.gq_hsq_encode_batched(ctypes.byref(desc()), None, nan, None) == -1          # null wire
     assert L.gq_hsq_levels_batched(ctypes.byref(desc()), ctypes.c_void_p(64), 7, ctypes.c_uint64(0), None, 0, None) == -1   # random_mode
+    T = native._StepTailStruct      # a refused tail: before the decode is looked at
+    bad_tail = T(struct_bytes=8, rows_R=1)
+    assert L.gq_hsq_decode_sum_batched_tail(ctypes.byref(desc()), ctypes.c_void_p(64), ctypes.c_int64(128), 1, ctypes.c_void_p(64), 0,
+                                            ctypes.byref(bad_tail), None) == -1 and b"gq_step_tail" in L.gq_last_error()
+    bad_tail = T(struct_bytes=ctypes.sizeof(T), rows_R=0)
+    assert L.gq_hsq_decode_sum_batched_tail(ctypes.byref(desc()), ctypes.c_void_p(64), ctypes.c_int64(128), 1, ctypes.c_void_p(64), 0,
+                                            ctypes.byref(bad_tail), None) == -1
     Q = native._QSGDBatchStruct
     q = Q(ctypes.sizeof(Q), 2, 4, 0, 3, 0, 10, 64, 64, None)
     assert L.gq_qsgd_compress_batched(None, ctypes.c_void_p(64), 0, ctypes.c_uint64(0), nan, None) == -1
