@@ -1402,6 +1402,38 @@ def test_bench_two_rank_code_path_on_one_gpu():
 
 
 
+def test_bench_watchdog_ends_a_hung_transport_and_fresh_ranks_finish_on_the_all_gather():
+    """A rank that never joins the first collective of `--exchange direct` ($GQ_BENCH_TEST_HANG): the other rank's watchdog
+    ends the job after $GQ_BENCH_TIMEOUT_S with exit code 3 and what was in flight on stderr; the self-launched parent
+    then starts FRESH ranks (new processes, no exec) on the all-gather, which print the one JSON line."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GQ_BENCH_BACKEND="gloo", GQ_BENCH_TIMEOUT_S="20", GQ_BENCH_TEST_HANG="direct")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--exchange", "direct"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "bench_watchdog" in r.stderr and "first exchange" in r.stderr and "starting fresh ranks with --exchange allgather" in r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["exchange"]["transport"] == "allgather" and d["exchange"]["rccl_ranks"] == 2
+
+
+def test_bench_fails_when_the_collectives_joined_fewer_ranks_than_were_launched():
+    """`bench.py --gpus 2` whose collective library reports one joined rank ($GQ_BENCH_TEST_RANKS): the line is printed, the
+    exchange object is repeated on stderr, and the exit code is 4 -- such a line is not a 2-GPU measurement."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GQ_BENCH_BACKEND="gloo", GQ_BENCH_TEST_RANKS="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0
+    assert "the collectives joined 1 ranks, not 2" in r.stderr and '"rccl_ranks": 1' in r.stderr
+
+
 @pytest.mark.parametrize("extra", [[], ["--exchange", "split"], ["--exchange", "auto"], ["--workload", "qsgd"], ["--workload", "resnet50"],
                                    ["--exchange", "pipelined"], ["--exchange", "pipelined", "--workload", "resnet50"]])
 def test_bench_launches_its_own_ranks(extra):

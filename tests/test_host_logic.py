@@ -716,3 +716,26 @@ def test_apply_writes_to_the_grad_object_the_parameter_holds_at_apply_time(oracl
     params[1].grad = None
     with pytest.raises(AttributeError):
         q2.apply()
+
+
+def test_bench_watchdog_exits_with_its_code_and_says_what_was_in_flight():
+    """bench.Watchdog (N > 1): a phase that outlives the limit ends the process with exit code 3 (os._exit from a daemon
+    thread -- never an exec) and one JSON object on stderr naming the phase and what was in flight; a finished run
+    (`done`) is left alone.  No GPU involved."""
+    import json
+    import subprocess
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "w = bench.Watchdog(1, 4, 1.0); w.enter('timed window 2 of 5', transport='direct', steps=20)\n"
+            "time.sleep(30)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3, r.stderr[-800:]
+    rec = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith("{")][-1])
+    assert rec["phase"] == "timed window 2 of 5" and rec["info"] == {"transport": "direct", "steps": 20} and rec["exit_code"] == 3
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "w = bench.Watchdog(0, 2, 1.0); w.enter('report'); w.done(); time.sleep(2.5); print('alive')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "alive" in r.stdout
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "w = bench.Watchdog(0, 1, 0.5); w.enter('x'); time.sleep(2.0); print('one rank: no watchdog')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "no watchdog" in r.stdout
