@@ -100,6 +100,10 @@ GQ_API int gq_hsq_levels_batched(const gq_hsq_batch *b, uint8_t *wire, int rando
     }
     if (b->level_bytes == GQ_LEVELS_PACKED6)
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched: GQ_LEVELS_PACKED6 needs d = 16, K = 256, n_bit <= 6");
+    // error feedback with 16-bit levels on a prefilter shape (main.py's own defaults with --ef): levels and residual in one pass
+    if (write_error && gq::pf_dim(b->d) && b->K == 256 && b->code_bytes == 1 && b->level_bytes == 2 && b->n_bit >= 1 && b->n_bit <= 15)
+        return gqi_hsq_levels_batched_ef16(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->u_flat, b->seg_minmax, b->n_bit,
+                                           random_mode, seed, r_flat, b->codebook, b->d, wire, b->dense_table, b->ndense, stream);
     rc = gqi_hsq_levels_batched_any(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->u_flat, b->seg_minmax, b->n_bit,
                                     random_mode, seed, r_flat, b->level_bytes, wire, b->dense_table, b->ndense, stream);
     if (rc != GQ_OK || !write_error) return rc;

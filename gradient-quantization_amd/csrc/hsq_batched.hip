@@ -10,6 +10,7 @@
 // out off (floats), - } (include/gq_hsq.h).  The matching encode is gq_hsq_encode_batched
 // (hsq_encode_pf.hip).
 #include "hsq_encode_common.hpp"
+#include "hsq_levels_common.hpp"
 #include <type_traits>
 
 namespace gq {
@@ -702,6 +703,9 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_d_kernel(
 constexpr int DT_THREADS = 512;
 constexpr int DT_WAVES = DT_THREADS / 64;
 constexpr int DT_RCH = 8;   // payloads staged per chunk
+#ifndef GQ_EF_LEVELS_TILE
+#define GQ_EF_LEVELS_TILE 1   // 0: round 4's one-thread-per-unit error-feedback level kernels (A/B builds)
+#endif
 template <int D, typename LevelT>
 __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
@@ -779,6 +783,87 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel
             }
             if (s < valid) *reinterpret_cast<f32x4 *>(dst + (pss * 64 + lane) * 4) = v;
         }
+    }
+}
+
+// Error-feedback level launch, a WAVE per tile (K = 256, D = 8 / 16 / 32, byte or 16-bit levels): the level quantiser
+// (probabilistic_scalar_compressor.py:12-27) and  error = v - codebook[code] * (l (ub - lb) / 2^n + lb)  (ps_quantizer.py:37-39) for
+// every tensor in one pass.  Round 4's kernels ran one thread per (subvector, 16-byte unit): every thread looked up its
+// tensor's record and (lb, ub) and worked the level out again (an IEEE division and, with stochastic rounding, a hash per
+// thread: four times per subvector for D = 16) -- 42.5 us for the ResNet-50 list (195 MB: 4.6 TB/s).  Here lane l is
+// subvector l for the level -- once per subvector, stored as one coalesced 64 / 128 bytes per wave, (code, norm) parked in the
+// wave's LDS slots -- and unit l of each of the D / 4 passes for the residual: v and error move as contiguous kilobytes.
+template <int D, typename LevelT>
+__global__ __launch_bounds__(DT_THREADS) void hsq_levels_ef_tile_kernel(
+    const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
+    const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
+    uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire,
+    const int64_t *__restrict__ dense_table, int ndense) {
+    resolve_seed(random_mode, seed);
+    copy_dense_segments(dense_table, ndense, wire);
+    constexpr int UPS = D / 4;
+    constexpr int RS = ((D / 4) & 1) ? D : D + 4;
+    __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];
+    __shared__ __attribute__((aligned(8))) unsigned s_pair[DT_WAVES * 64 * 2];   // { code, bits of the norm } per (wave, subvector)
+    for (int i = threadIdx.x; i < 256 * UPS; i += DT_THREADS)
+        *reinterpret_cast<f32x4 *>(s_cb + (i / UPS) * RS + 4 * (i % UPS)) = reinterpret_cast<const f32x4 *>(cb)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const float s = (float)(1 << n_bit);
+    auto uniform64 = [](int64_t v) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    unsigned *const pairs = s_pair + wave * (64 * 2);
+    const int q = lane % UPS, ls = lane / UPS;
+    for (int64_t tile = (int64_t)blockIdx.x * DT_WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * DT_WAVES) {
+        const int seg = __builtin_amdgcn_readfirstlane(tile_seg[tile]);
+        const int64_t *rec = seg_table + 8 * (int64_t)seg;
+        const int64_t m = uniform64(rec[1]), sv0 = (tile - uniform64(rec[2])) * 64;
+        const int valid = (int)(m - sv0 < 64 ? m - sv0 : 64);
+        const float lb = order_unmap_f(seg_minmax[2 * seg]), ub = order_unmap_f(seg_minmax[2 * seg + 1]);
+        const LevelQuant lq(lb, ub, n_bit, random_mode == GQ_RANDOM_DEVICE_KEYED ? GQ_RANDOM_DEVICE : random_mode, r_flat,
+                            random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, lb, ub) : seed);
+        const int64_t flat = tile * 64 + lane;            // index into u_flat / r_flat and of this subvector's draw
+        int l = 0;
+        if (lane < valid) {
+            l = lq.level(u_flat[flat], flat);
+            reinterpret_cast<LevelT *>(wire + uniform64(rec[4]))[sv0 + lane] = (LevelT)l;
+            if (sv0 == 0 && lane == 0) {
+                float *lbub = reinterpret_cast<float *>(wire + uniform64(rec[5]));
+                lbub[0] = lb;
+                lbub[1] = ub;
+            }
+        }
+        float *const err = reinterpret_cast<float *>(uniform64(rec[7]));
+        if (!err) continue;                                // (wave-uniform: a tensor without an error buffer gets its levels only)
+        const float range = ub - lb;
+        float n = (float)l * range;   // prob_scalar:31-32, unfused
+        n = n / s;
+        n = n + lb;
+        const unsigned code = wire[uniform64(rec[3]) + sv0 + (lane < valid ? lane : valid - 1)];
+        *reinterpret_cast<uint2 *>(pairs + lane * 2) = make_uint2(code, __float_as_uint(n));
+        __builtin_amdgcn_wave_barrier();   // (written and read by this wave only: LDS operations of a wave stay in order)
+        const float *const grad = reinterpret_cast<const float *>(uniform64(rec[0])) + sv0 * D;
+        float *const edst = err + sv0 * D;
+#pragma unroll
+        for (int pss = 0; pss < UPS; ++pss) {
+            const int sv = pss * (64 / UPS) + ls;
+            if (sv < valid) {
+                const uint2 cn = *reinterpret_cast<const uint2 *>(pairs + sv * 2);
+                const f32x4 c = *reinterpret_cast<const f32x4 *>(s_cb + cn.x * RS + 4 * q);
+                const float nn = __uint_as_float(cn.y);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(grad + (pss * 64 + lane) * 4);
+                f32x4 e;
+                e[0] = v[0] - c[0] * nn;
+                e[1] = v[1] - c[1] * nn;
+                e[2] = v[2] - c[2] * nn;
+                e[3] = v[3] - c[3] * nn;
+                *reinterpret_cast<f32x4 *>(edst + (pss * 64 + lane) * 4) = e;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -903,6 +988,20 @@ static inline int64_t bt_grid(int64_t items) {
 
 }  // namespace gq
 
+namespace gq {
+template <int D, typename LevelT>
+static void launch_levels_ef_tile(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const float *u_flat,
+                                  const uint32_t *seg_minmax, int n_bit, int random_mode, uint64_t seed, const float *r_flat,
+                                  const float *cb, uint8_t *wire, const int64_t *dense_table, int ndense, hipStream_t st) {
+    static const int bpc = resident_blocks_per_cu(hsq_levels_ef_tile_kernel<D, LevelT>, DT_THREADS, 0);
+    int64_t blocks = (ntiles + DT_WAVES - 1) / DT_WAVES;
+    const int64_t cap = (int64_t)cu_count() * bpc;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_levels_ef_tile_kernel<D, LevelT>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(DT_THREADS), 0,
+                       st, seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, cb, wire, dense_table, ndense);
+}
+}  // namespace gq
+
 GQ_INTERNAL int gqi_hsq_levels_batched_d16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                            const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
                                            uint64_t seed, const float *r_flat, const float *ef_codebook, int packed6,
@@ -921,6 +1020,9 @@ GQ_INTERNAL int gqi_hsq_levels_batched_d16(const int64_t *seg_table, const int32
     if (ef_codebook && packed6)
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_kernel<true>, dim3((unsigned)gq::bt_grid(ntiles * 256)), block, 0, st,
                            seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, wire, dense_table, ndense);
+    else if (ef_codebook && GQ_EF_LEVELS_TILE)
+        gq::launch_levels_ef_tile<16, uint8_t>(seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, wire,
+                                               dense_table, ndense, st);
     else if (ef_codebook)
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_kernel<false>, dim3((unsigned)gq::bt_grid(ntiles * 256)), block, 0, st,
                            seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, wire, dense_table, ndense);
@@ -1023,7 +1125,14 @@ GQ_INTERNAL int gqi_hsq_levels_batched_ef_d(const int64_t *seg_table, const int3
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: GQ_RANDOM_GIVEN needs r_flat");
     if (((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > 255)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: levels do not fit uint8");
-    if (d == 8) {
+    if (GQ_EF_LEVELS_TILE && (d == 8 || d == 32)) {
+        if (d == 8)
+            gq::launch_levels_ef_tile<8, uint8_t>(seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, codebook, wire,
+                                                  dense_table, ndense, gq::as_stream(stream));
+        else
+            gq::launch_levels_ef_tile<32, uint8_t>(seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, codebook, wire,
+                                                   dense_table, ndense, gq::as_stream(stream));
+    } else if (d == 8) {
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_d_kernel<8>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 2)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
                            n_bit, random_mode, seed, r_flat, codebook, wire, dense_table, ndense);
@@ -1036,6 +1145,31 @@ GQ_INTERNAL int gqi_hsq_levels_batched_ef_d(const int64_t *seg_table, const int3
     }
     GQ_CHECK_LAUNCH("gq_hsq_levels_batched");
     return GQ_OK;
+}
+
+GQ_INTERNAL int gqi_hsq_levels_batched_ef16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                            const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
+                                            uint64_t seed, const float *r_flat, const float *codebook, int d, uint8_t *wire,
+                                            const int64_t *dense_table, int ndense, void *stream) {
+    if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > 15)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: bad sizes");
+    if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !codebook || !wire)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: null pointer");
+    if (random_mode == GQ_RANDOM_GIVEN && !r_flat)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: GQ_RANDOM_GIVEN needs r_flat");
+    hipStream_t st = gq::as_stream(stream);
+#define GQ_EF16_CASE(DD)                                                                                                       \
+    if (d == DD) {                                                                                                             \
+        gq::launch_levels_ef_tile<DD, uint16_t>(seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, \
+                                                codebook, wire, dense_table, ndense, st);                                      \
+        GQ_CHECK_LAUNCH("gq_hsq_levels_batched");                                                                              \
+        return GQ_OK;                                                                                                          \
+    }
+    GQ_EF16_CASE(32)
+    GQ_EF16_CASE(16)
+    GQ_EF16_CASE(8)
+#undef GQ_EF16_CASE
+    return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched: d must be 8, 16 or 32 (K = 256)");
 }
 
 // any level width (1 / 2 / 4 bytes, or 0: the f32 projections travel); independent of (d, K)

@@ -1402,6 +1402,15 @@ def test_bench_two_rank_code_path_on_one_gpu():
 
 
 
+def test_integration_example_runs():
+    """tools/integration_example.py -- INTEGRATION.md section 3's ctypes stubs (per-tensor calls, the gq_hsq_batch descriptor
+    and gq_step_tail with every table built by hand) -- against the package's own classes and torch.stack().mean(0)."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "integration_example.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIFFERS" not in r.stdout and r.stdout.count("equal") >= 8, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_bench_watchdog_ends_a_hung_transport_and_fresh_ranks_finish_on_the_all_gather():
     """A rank that never joins the first collective of `--exchange direct` ($GQ_BENCH_TEST_HANG): the other rank's watchdog
     ends the job after $GQ_BENCH_TIMEOUT_S with exit code 3 and what was in flight on stderr; the self-launched parent
