@@ -124,12 +124,18 @@ def self_launch(args):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import tempfile
+    mark = os.path.join(tempfile.gettempdir(), "gq_bench_watchdog_%d.json" % os.getpid())      # a rank's watchdog leaves its record here
+    env["GQ_BENCH_WATCHDOG_FILE"] = mark                                                          # (torch.distributed.run reports any child failure as 1)
+
     def launch(extra, port):
+        if os.path.exists(mark):
+            os.remove(mark)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
         return subprocess.call(cmd, env=env)
     rc = launch([], port)
-    if rc == WATCHDOG_EXIT and args.exchange != "allgather":
+    if rc != 0 and os.path.exists(mark) and args.exchange != "allgather":
         # a rank's watchdog ended the job (a collective of the requested transport did not complete): ONE fresh set of
         # ranks -- new processes, never a re-exec of one that has touched the GPU -- on the transport every backend has
         print("bench.py: the ranks' watchdog ended the run with --exchange %s; starting fresh ranks with --exchange allgather"
@@ -138,6 +144,8 @@ def self_launch(args):
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
         rc = launch(["--exchange", "allgather"], port)
+    if os.path.exists(mark):
+        os.remove(mark)
     sys.exit(rc)
 
 
@@ -166,10 +174,16 @@ class Watchdog(object):
     def _run(self):
         while not self._stop.wait(1.0):
             if time.monotonic() - self.since > self.limit:
-                print(json.dumps({"bench_watchdog": "rank %d of %d: phase %r has not completed in %.0f s; ending the job"
+                rec = json.dumps({"bench_watchdog": "rank %d of %d: phase %r has not completed in %.0f s; ending the job"
                                                     % (self.rank, self.world, self.phase, self.limit),
-                                  "phase": self.phase, "info": self.info, "exit_code": WATCHDOG_EXIT}), file=sys.stderr, flush=True)
-                os._exit(WATCHDOG_EXIT)
+                                  "phase": self.phase, "info": self.info, "exit_code": WATCHDOG_EXIT})
+                print(rec, file=sys.stderr, flush=True)
+                try:
+                    if os.environ.get("GQ_BENCH_WATCHDOG_FILE"):      # a self-launched run: the parent looks for this
+                        with open(os.environ["GQ_BENCH_WATCHDOG_FILE"], "a") as f:
+                            f.write(rec + "\n")
+                finally:
+                    os._exit(WATCHDOG_EXIT)
 
 
 WATCHDOG = None
@@ -451,7 +465,8 @@ def main():
         # a collective that never completes (first RCCL contact on a new node) ends the job after five minutes with the
         # watchdog's error instead of after the default ten
         import datetime
-        limit = datetime.timedelta(seconds=int(os.environ.get("GQ_BENCH_TIMEOUT_S", "300")))
+        # (+ 30 s: bench.Watchdog, with the plain figure, speaks first and says which phase and transport were in flight)
+        limit = datetime.timedelta(seconds=int(os.environ.get("GQ_BENCH_TIMEOUT_S", "300")) + 30)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
