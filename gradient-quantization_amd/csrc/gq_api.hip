@@ -112,6 +112,58 @@ GQ_API int gq_hsq_levels_batched(const gq_hsq_batch *b, uint8_t *wire, int rando
 }
 
 namespace gq {
+static int check_tail(const gq_step_tail *t, const char *what) {
+    if (t->struct_bytes != sizeof(gq_step_tail))
+        return fail(GQ_ERR_INVALID_ARG, "%s: gq_step_tail.struct_bytes is %u, this library's layout has %zu", what, t->struct_bytes,
+                    sizeof(gq_step_tail));
+    if (t->rows_R < 1 || t->n < 0 || (t->n > 0 && (!t->rows || !t->out)) || (t->row_stride_bytes & 3) != 0 ||
+        (t->rng_state && (t->rng_pairs < 1 || t->rng_pairs > 256)) || t->reset_words < 0 ||
+        (t->reset_words > 0 && (!t->reset_dst || !t->reset_src)))
+        return fail(GQ_ERR_INVALID_ARG, "%s: bad gq_step_tail", what);
+    return GQ_OK;
+}
+}  // namespace gq
+
+GQ_API int gq_hsq_levels_decode_batched(const gq_hsq_batch *b, uint8_t *wire, int random_mode, uint64_t seed, const float *r_flat,
+                                        int write_error, float *out, int plain, const gq_step_tail *t, void *stream) {
+    int rc = gq::check_batch(b, "gq_hsq_levels_decode_batched");
+    if (rc != GQ_OK) return rc;
+    if (!wire || !out || !b->u_flat || !b->seg_minmax) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode_batched: null pointer");
+    if (t && (rc = gq::check_tail(t, "gq_hsq_levels_decode_batched")) != GQ_OK) return rc;
+    if (t && (t->rows_R != 1 || ((t->rng_state || t->reset_words) && !t->ticket)))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode_batched: the tail of a one-payload step has rows_R = 1 and, with rng_state or reset words, a ticket word");
+    if (t && t->n > 0 && (static_cast<const uint8_t *>(t->rows) < wire || (static_cast<const uint8_t *>(t->rows) - wire) % 4 != 0))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode_batched: tail.rows must point into `wire` (its dense region)");
+    const bool served = gq::pf_dim(b->d) && b->K == 256 && b->code_bytes == 1 && (b->level_bytes == 1 || b->level_bytes == 2) &&
+                        b->n_bit >= 1 && b->n_bit <= (b->level_bytes == 1 ? 8 : 15) &&
+                        (random_mode == GQ_RANDOM_OFF || random_mode == GQ_RANDOM_GIVEN || random_mode == GQ_RANDOM_DEVICE ||
+                         random_mode == GQ_RANDOM_DEVICE_KEYED || random_mode == GQ_RANDOM_DEVICE_COUNTER) &&
+                        !(b->level_bytes == 1 && ((int64_t)1 << b->n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > 255);
+    if (!served) {   // the two launches: the same results
+        rc = gq_hsq_levels_batched(b, wire, random_mode, seed, r_flat, write_error, stream);
+        if (rc != GQ_OK) return rc;
+        return gq_hsq_decode_sum_batched_tail(b, wire, 0, 1, out, plain, t, stream);
+    }
+    if (random_mode == GQ_RANDOM_DEVICE_COUNTER && (seed == 0 || (seed & 7) != 0))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode_batched: GQ_RANDOM_DEVICE_COUNTER takes the address of two device words as `seed`");
+    if (random_mode != GQ_RANDOM_GIVEN) r_flat = nullptr;
+    gq::FusedTail ft = {};
+    if (t) {
+        ft.dense_mean = t->n > 0 ? t->out : nullptr;
+        ft.dense_off = t->n > 0 ? static_cast<const uint8_t *>(t->rows) - wire : 0;
+        ft.rng_state = t->rng_state;
+        ft.rng_pairs = t->rng_state ? t->rng_pairs : 0;
+        ft.reset_dst = t->reset_dst;
+        ft.reset_src = t->reset_src;
+        ft.reset_words = t->reset_words;
+        ft.ticket = t->ticket;
+    }
+    return gqi_hsq_levels_decode_batched(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->u_flat, b->seg_minmax, b->n_bit, random_mode,
+                                         seed, r_flat, b->codebook, b->d, b->level_bytes, wire, b->dense_table, b->ndense, write_error,
+                                         out, plain, &ft, stream);
+}
+
+namespace gq {
 // the decode-mean of `b`; *tail_taken = 1 when the launch also did the step's tail work
 static int decode_sum_batched(const gq_hsq_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R, float *out,
                               int plain, const StepTail *tail, int *tail_taken, void *stream) {
@@ -146,13 +198,8 @@ GQ_API int gq_hsq_decode_sum_batched(const gq_hsq_batch *b, const uint8_t *gathe
 GQ_API int gq_hsq_decode_sum_batched_tail(const gq_hsq_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                           float *out, int plain, const gq_step_tail *t, void *stream) {
     if (!t) return gq::decode_sum_batched(b, gathered, user_stride_bytes, R, out, plain, nullptr, nullptr, stream);
-    if (t->struct_bytes != sizeof(gq_step_tail))
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched_tail: gq_step_tail.struct_bytes is %u, this library's layout has %zu",
-                        t->struct_bytes, sizeof(gq_step_tail));
-    if (t->rows_R < 1 || t->n < 0 || (t->n > 0 && (!t->rows || !t->out)) || (t->row_stride_bytes & 3) != 0 ||
-        (t->rng_state && (t->rng_pairs < 1 || t->rng_pairs > 256)) || t->reset_words < 0 ||
-        (t->reset_words > 0 && (!t->reset_dst || !t->reset_src)))
-        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_decode_sum_batched_tail: bad gq_step_tail");
+    const int trc = gq::check_tail(t, "gq_hsq_decode_sum_batched_tail");
+    if (trc != GQ_OK) return trc;
     gq::StepTail tail = {};
     tail.rows = static_cast<const uint8_t *>(t->rows);
     tail.row_stride_bytes = t->row_stride_bytes;

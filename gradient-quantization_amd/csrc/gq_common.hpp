@@ -215,6 +215,17 @@ __device__ __forceinline__ void step_tail_run(const StepTail &t) {
     }
 }
 
+// The rider of the one-rank step's fused level + decode launch (hsq_batched.hip: hsq_levels_ef_tile_kernel<.., OUT>)
+struct FusedTail {
+    float *dense_mean;          // nullable; mean[(byte offset in the wire - dense_off) / 4 + i]
+    int64_t dense_off;
+    uint64_t *rng_state;        // nullable
+    uint64_t *reset_dst;        // reset_words == 0: none
+    const uint64_t *reset_src;
+    unsigned *ticket;           // zero between launches (needed when rng_state or reset_words)
+    int rng_pairs, reset_words;
+};
+
 // The tensors that travel uncompressed (IdenticalCompressor, ps_quantizer.py:18-19: <= 1000 elements each) ride in the same
 // launch as the level quantiser / the QSGD compress: workgroup b copies tensors b, b + grid, ... into their place in the
 // wire.  dense_table int64[ndense][3] = { source (float *), byte offset in ONE user's wire, elements }.

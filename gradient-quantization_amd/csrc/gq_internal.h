@@ -31,6 +31,12 @@ GQ_INTERNAL int gqi_hsq_levels_batched_ef16(const int64_t *seg_table, const int3
                                             const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
                                             uint64_t seed, const float *r_flat, const float *codebook, int d, uint8_t *wire,
                                             const int64_t *dense_table, int ndense, void *stream);
+// levels (+ residual) + decode of the finished payload + the step's tail in one launch (K = 256, d = 8 / 16 / 32, byte or 16-bit levels)
+GQ_INTERNAL int gqi_hsq_levels_decode_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                              const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
+                                              uint64_t seed, const float *r_flat, const float *codebook, int d, int level_bytes,
+                                              uint8_t *wire, const int64_t *dense_table, int ndense, int write_error, float *out,
+                                              int plain, const gq::FusedTail *ft, void *stream);
 GQ_INTERNAL int gqi_hsq_levels_batched_any(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                            const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
                                            uint64_t seed, const float *r_flat, int level_bytes, uint8_t *wire, const int64_t *dense_table, int ndense, void *stream);

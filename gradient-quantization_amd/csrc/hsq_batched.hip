@@ -703,6 +703,9 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_d_kernel(
 constexpr int DT_THREADS = 512;
 constexpr int DT_WAVES = DT_THREADS / 64;
 constexpr int DT_RCH = 8;   // payloads staged per chunk
+// gq_step_tail.ticket of gq_hsq_levels_decode_batched: (1 + GQ_TICKET_SHARDS) counters GQ_TICKET_STRIDE words apart (include/gq_hsq.h: GQ_TICKET_WORDS)
+#define GQ_TICKET_SHARDS 16
+#define GQ_TICKET_STRIDE 32
 #ifndef GQ_EF_LEVELS_TILE
 #define GQ_EF_LEVELS_TILE 1   // 0: round 4's one-thread-per-unit error-feedback level kernels (A/B builds)
 #endif
@@ -793,14 +796,31 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel
 // thread: four times per subvector for D = 16) -- 42.5 us for the ResNet-50 list (195 MB: 4.6 TB/s).  Here lane l is
 // subvector l for the level -- once per subvector, stored as one coalesced 64 / 128 bytes per wave, (code, norm) parked in the
 // wave's LDS slots -- and unit l of each of the D / 4 passes for the residual: v and error move as contiguous kilobytes.
-template <int D, typename LevelT>
+//
+// OUT (round 5: the one-rank step's twin of gq_hsq_levels_decode): the same pass also DECODES the payload it has just finished
+// -- out = (+0 + codebook[code] * norm) / 1, the aggregate of one user (plain: the decompress as it is) -- so that a step of one
+// rank and one user is two kernels, encode and this one.  What the aggregate's launch would have taken along rides here too:
+// the uncompressed tensors' mean (of one row: straight from the gradients, next to their copy into the wire), and -- by the
+// LAST workgroup to finish, told by a ticket counter, because every workgroup reads the draws' words and the accumulators
+// first -- the step of the { seed, step } words and the accumulators' reset.
+template <int D, typename LevelT, bool OUT>
 __global__ __launch_bounds__(DT_THREADS) void hsq_levels_ef_tile_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
     uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire,
-    const int64_t *__restrict__ dense_table, int ndense) {
+    const int64_t *__restrict__ dense_table, int ndense, int write_error, float *__restrict__ out, int plain, const FusedTail ft) {
     resolve_seed(random_mode, seed);
     copy_dense_segments(dense_table, ndense, wire);
+    if (OUT && ft.dense_mean) {   // the mean of ONE row: (+0 + x) / 1 (plain: x), from the gradients themselves
+        typedef const float __attribute__((address_space(1))) *gcf_ptr;
+        for (int t = blockIdx.x; t < ndense; t += gridDim.x) {
+            const gcf_ptr src = (gcf_ptr)(uintptr_t)dense_table[3 * t];
+            float *dst = ft.dense_mean + (dense_table[3 * t + 1] - ft.dense_off) / 4;
+            const int64_t n = dense_table[3 * t + 2];
+            for (int64_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = plain ? src[i] : src[i] + 0.0f;
+        }
+    }
+    const MeanDiv md = mean_div_of(1, !plain);
     constexpr int UPS = D / 4;
     constexpr int RS = ((D / 4) & 1) ? D : D + 4;
     __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];
@@ -836,8 +856,8 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_levels_ef_tile_kernel(
                 lbub[1] = ub;
             }
         }
-        float *const err = reinterpret_cast<float *>(uniform64(rec[7]));
-        if (!err) continue;                                // (wave-uniform: a tensor without an error buffer gets its levels only)
+        float *const err = write_error ? reinterpret_cast<float *>(uniform64(rec[7])) : nullptr;
+        if (!OUT && !err) continue;                        // (wave-uniform: a tensor without an error buffer gets its levels only)
         const float range = ub - lb;
         float n = (float)l * range;   // prob_scalar:31-32, unfused
         n = n / s;
@@ -847,6 +867,7 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_levels_ef_tile_kernel(
         __builtin_amdgcn_wave_barrier();   // (written and read by this wave only: LDS operations of a wave stay in order)
         const float *const grad = reinterpret_cast<const float *>(uniform64(rec[0])) + sv0 * D;
         float *const edst = err + sv0 * D;
+        float *const odst = OUT ? out + uniform64(rec[6]) + sv0 * D : nullptr;
 #pragma unroll
         for (int pss = 0; pss < UPS; ++pss) {
             const int sv = pss * (64 / UPS) + ls;
@@ -854,16 +875,62 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_levels_ef_tile_kernel(
                 const uint2 cn = *reinterpret_cast<const uint2 *>(pairs + sv * 2);
                 const f32x4 c = *reinterpret_cast<const f32x4 *>(s_cb + cn.x * RS + 4 * q);
                 const float nn = __uint_as_float(cn.y);
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(grad + (pss * 64 + lane) * 4);
-                f32x4 e;
-                e[0] = v[0] - c[0] * nn;
-                e[1] = v[1] - c[1] * nn;
-                e[2] = v[2] - c[2] * nn;
-                e[3] = v[3] - c[3] * nn;
-                *reinterpret_cast<f32x4 *>(edst + (pss * 64 + lane) * 4) = e;
+                f32x4 dec;
+                dec[0] = c[0] * nn;
+                dec[1] = c[1] * nn;
+                dec[2] = c[2] * nn;
+                dec[3] = c[3] * nn;
+                if (err) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(grad + (pss * 64 + lane) * 4);
+                    f32x4 e;
+                    e[0] = v[0] - dec[0];
+                    e[1] = v[1] - dec[1];
+                    e[2] = v[2] - dec[2];
+                    e[3] = v[3] - dec[3];
+                    *reinterpret_cast<f32x4 *>(edst + (pss * 64 + lane) * 4) = e;
+                }
+                if (OUT) {
+                    if (md.apply) {
+                        dec[0] = mean_div(dec[0], md);
+                        dec[1] = mean_div(dec[1], md);
+                        dec[2] = mean_div(dec[2], md);
+                        dec[3] = mean_div(dec[3], md);
+                    }
+                    *reinterpret_cast<f32x4 *>(odst + (pss * 64 + lane) * 4) = dec;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (OUT && ft.ticket && (ft.rng_state || ft.reset_words)) {
+        // every workgroup has read the draws' words (resolve_seed) and the accumulators (lb, ub) by now: the last one to get
+        // here steps the words and puts the accumulators back to their empty state for the next step's encode
+        // (a returning atomic on ONE word serialises at ~90 per microsecond -- MI355X_MICROARCH.md, 'dequeue' -- and a persistent
+        // grid ends all at once: 1,000+ workgroups on one counter were 33 us of a 56 us launch.  Sixteen shard counters, each
+        // on a line of its own, and a top counter for the shards' last arrivers.)
+        __shared__ int s_last;
+        __syncthreads();
+        // No fence: what must come first are this workgroup's READS of the words (their data has been used by now -- the
+        // barrier above is behind every wave's last tile), what comes after the last add are the last workgroup's WRITES.
+        // (A __threadfence() here -- buffer_wbl2: the XCD L2's dirty lines, i.e. the launch's own output, written back by
+        // every workgroup -- made this a 57 us launch instead of 19.)
+        if (threadIdx.x == 0) {
+            const unsigned shard = blockIdx.x & (GQ_TICKET_SHARDS - 1);
+            const unsigned members = (gridDim.x - shard + GQ_TICKET_SHARDS - 1) / GQ_TICKET_SHARDS;      // workgroups b with b % 16 == shard
+            int last = 0;
+            if (atomicAdd(ft.ticket + GQ_TICKET_STRIDE * (1 + shard), 1u) == members - 1) {
+                ft.ticket[GQ_TICKET_STRIDE * (1 + shard)] = 0u;
+                const unsigned shards = gridDim.x < GQ_TICKET_SHARDS ? gridDim.x : GQ_TICKET_SHARDS;
+                last = atomicAdd(ft.ticket, 1u) == shards - 1 ? 1 : 0;
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        if (s_last) {
+            if (ft.rng_state && (int)threadIdx.x < ft.rng_pairs) ft.rng_state[2 * threadIdx.x + 1] += 1;
+            for (int i = threadIdx.x; i < ft.reset_words; i += blockDim.x) ft.reset_dst[i] = ft.reset_src[i];
+            if (threadIdx.x == 0) *ft.ticket = 0u;
+        }
     }
 }
 
@@ -989,16 +1056,18 @@ static inline int64_t bt_grid(int64_t items) {
 }  // namespace gq
 
 namespace gq {
-template <int D, typename LevelT>
+template <int D, typename LevelT, bool OUT = false>
 static void launch_levels_ef_tile(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const float *u_flat,
                                   const uint32_t *seg_minmax, int n_bit, int random_mode, uint64_t seed, const float *r_flat,
-                                  const float *cb, uint8_t *wire, const int64_t *dense_table, int ndense, hipStream_t st) {
-    static const int bpc = resident_blocks_per_cu(hsq_levels_ef_tile_kernel<D, LevelT>, DT_THREADS, 0);
+                                  const float *cb, uint8_t *wire, const int64_t *dense_table, int ndense, hipStream_t st,
+                                  int write_error = 1, float *out = nullptr, int plain = 0, const FusedTail &ft = FusedTail{}) {
+    static const int bpc = resident_blocks_per_cu(hsq_levels_ef_tile_kernel<D, LevelT, OUT>, DT_THREADS, 0);
     int64_t blocks = (ntiles + DT_WAVES - 1) / DT_WAVES;
     const int64_t cap = (int64_t)cu_count() * bpc;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_levels_ef_tile_kernel<D, LevelT>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(DT_THREADS), 0,
-                       st, seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, cb, wire, dense_table, ndense);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_levels_ef_tile_kernel<D, LevelT, OUT>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(DT_THREADS), 0,
+                       st, seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, cb, wire, dense_table, ndense,
+                       write_error, out, plain, ft);
 }
 }  // namespace gq
 
@@ -1170,6 +1239,39 @@ GQ_INTERNAL int gqi_hsq_levels_batched_ef16(const int64_t *seg_table, const int3
     GQ_EF16_CASE(8)
 #undef GQ_EF16_CASE
     return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched: d must be 8, 16 or 32 (K = 256)");
+}
+
+// levels (+ residual) + decode of the finished payload + the step's tail in ONE launch (K = 256, d = 8 / 16 / 32, byte or 16-bit levels)
+GQ_INTERNAL int gqi_hsq_levels_decode_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                                              const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
+                                              uint64_t seed, const float *r_flat, const float *codebook, int d, int level_bytes,
+                                              uint8_t *wire, const int64_t *dense_table, int ndense, int write_error, float *out,
+                                              int plain, const gq::FusedTail *ft, void *stream) {
+    if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > (level_bytes == 1 ? 8 : 15))
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode_batched: bad sizes");
+    if (!seg_table || !tile_seg || !u_flat || !seg_minmax || !codebook || !wire || !out)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode_batched: null pointer");
+    if (random_mode == GQ_RANDOM_GIVEN && !r_flat)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode_batched: GQ_RANDOM_GIVEN needs r_flat");
+    if (level_bytes == 1 && ((int64_t)1 << n_bit) - (random_mode == GQ_RANDOM_OFF ? 1 : 0) > 255)
+        return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode_batched: levels do not fit uint8");
+    hipStream_t st = gq::as_stream(stream);
+    const gq::FusedTail tail = ft ? *ft : gq::FusedTail{};
+#define GQ_LD_CASE(DD, LB, LT)                                                                                                       \
+    if (d == DD && level_bytes == LB) {                                                                                              \
+        gq::launch_levels_ef_tile<DD, LT, true>(seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat,    \
+                                                codebook, wire, dense_table, ndense, st, write_error, out, plain & 1, tail);         \
+        GQ_CHECK_LAUNCH("gq_hsq_levels_decode_batched");                                                                             \
+        return GQ_OK;                                                                                                                \
+    }
+    GQ_LD_CASE(16, 1, uint8_t)
+    GQ_LD_CASE(32, 1, uint8_t)
+    GQ_LD_CASE(32, 2, uint16_t)
+    GQ_LD_CASE(8, 1, uint8_t)
+    GQ_LD_CASE(8, 2, uint16_t)
+    GQ_LD_CASE(16, 2, uint16_t)
+#undef GQ_LD_CASE
+    return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_decode_batched: d must be 8, 16 or 32 (K = 256), byte or 16-bit levels");
 }
 
 // any level width (1 / 2 / 4 bytes, or 0: the f32 projections travel); independent of (d, K)

@@ -19,12 +19,14 @@ GQ_FIXUP_PARTIALS = 256
 RANDOM_OFF, RANDOM_GIVEN, RANDOM_DEVICE, RANDOM_DEVICE_KEYED, RANDOM_DEVICE_COUNTER = 0, 1, 2, 3, 4
 ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFILTER_D16K256 = 0, 1, 2, 3, 4
 ENCODE_MFMA_LDS, ENCODE_PREFILTER_BF16X3 = 5, 6
+TICKET_WORDS = 544      # GQ_TICKET_WORDS: int32 words of gq_step_tail.ticket (StepTail(ticket=...))
 
 EXPORTS = [     # every entry point include/gq_hsq.h declares (tests/test_host_logic.py compares the two lists)
     "gq_abi_version", "gq_last_error", "gq_device_info", "gq_hsq_workspace_bytes", "gq_profile_read",
     "gq_hsq_encode", "gq_hsq_encode_ex", "gq_hsq_levels", "gq_minmax_partials", "gq_hsq_decode_sum", "gq_hsq_decode_sum_strided",
     "gq_hsq_levels_decode",
     "gq_hsq_batched_path", "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched", "gq_hsq_decode_sum_batched_tail",
+    "gq_hsq_levels_decode_batched",
     "gq_axpy_inplace", "gq_sub", "gq_mean_rows", "gq_qsgd_compress", "gq_qsgd_decode_sum", "gq_qsgd_code_bits",
     "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched", "gq_pvq_encode",
 ]
@@ -341,6 +343,15 @@ class HSQBatch(object):
                                           _stream())
         _check(rc, "gq_hsq_levels_batched")
 
+    def levels_decode(self, wire, random_mode, seed, r_flat, write_error, out, plain=False, tail=None):
+        """gq_hsq_levels_decode_batched: levels (+ residual) of the one payload `wire`, its decode into `out` and the step's tail
+        (StepTail with rows inside `wire` and a ticket) in ONE launch."""
+        rp = _dev_ptr(r_flat, torch.float32, "r_flat") if r_flat is not None else ctypes.c_void_p(0)
+        rc = self.L.gq_hsq_levels_decode_batched(self.ref, self._wire(wire), ctypes.c_int(random_mode), ctypes.c_uint64(seed & (2 ** 64 - 1)), rp,
+                                                 ctypes.c_int(1 if write_error else 0), _dev_ptr(out, torch.float32, "out"),
+                                                 ctypes.c_int(1 if plain else 0), tail.ref if tail is not None else None, _stream())
+        _check(rc, "gq_hsq_levels_decode_batched")
+
     def decode(self, gathered, R, out, plain=False, fma=False, tail=None):
         """Mean of the R payloads (plain: the decompress of ONE payload as the reference returns it, a -0 stays -0).
         fma: GQ_AGGREGATE_FMA for this launch (opt-in; not with plain).  tail (StepTail): the aggregate's small per-step
@@ -370,15 +381,16 @@ class _StepTailStruct(ctypes.Structure):      # gq_step_tail (include/gq_hsq.h)
     _fields_ = [("struct_bytes", ctypes.c_uint32), ("rows_R", ctypes.c_int32), ("rows", ctypes.c_void_p),
                 ("row_stride_bytes", ctypes.c_int64), ("n", ctypes.c_int64), ("out", ctypes.c_void_p),
                 ("rng_state", ctypes.c_void_p), ("reset_dst", ctypes.c_void_p), ("reset_src", ctypes.c_void_p),
-                ("rng_pairs", ctypes.c_int32), ("reset_words", ctypes.c_int32)]
+                ("rng_pairs", ctypes.c_int32), ("reset_words", ctypes.c_int32), ("ticket", ctypes.c_void_p)]
 
 
 class StepTail(object):
     """What gq_mean_rows does, as a rider of a decode-mean launch: rows ([R, n] float32 view, rows may be strided) -> out[n];
     rng_state (int64 [pairs, 2]) stepped; reset = (dst, src) int64 tensors copied src -> dst.  Any part may be None."""
 
-    def __init__(self, rows=None, out=None, rng_state=None, reset=None):
-        self.keep = (rows, out, rng_state, reset)
+    def __init__(self, rows=None, out=None, rng_state=None, reset=None, ticket=None):
+        """ticket (int32 [1], zero): gq_hsq_levels_decode_batched's last-workgroup counter (HSQBatch.levels_decode)."""
+        self.keep = (rows, out, rng_state, reset, ticket)
         R, n, stride, rp, op = 1, 0, 0, None, None
         if rows is not None:
             assert rows.dtype == torch.float32 and rows.dim() == 2 and rows.stride(1) == 1
@@ -387,7 +399,8 @@ class StepTail(object):
             rp, op = rows.data_ptr(), _dev_ptr(out, torch.float32, "out").value
         sp, pairs = (rng_state.data_ptr(), int(rng_state.shape[0])) if rng_state is not None else (None, 0)
         rd, rs, rw = _reset_args(reset)
-        self.s = _StepTailStruct(ctypes.sizeof(_StepTailStruct), R, rp, stride, n, op, sp, rd.value, rs.value, pairs, rw.value)
+        self.s = _StepTailStruct(ctypes.sizeof(_StepTailStruct), R, rp, stride, n, op, sp, rd.value, rs.value, pairs, rw.value,
+                                 _dev_ptr(ticket, torch.int32, "ticket").value if ticket is not None else None)
         self.ref = ctypes.byref(self.s)
 
 

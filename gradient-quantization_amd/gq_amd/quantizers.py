@@ -684,8 +684,10 @@ class BatchedHSQ(_BatchedBase):
             and self._batch.path != 0
 
     def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None, dense=None, defer_reset=None,
-               rng_slot=None):
+               rng_slot=None, skip_levels=False):
         """Compress `tensors` (one per batched parameter, in order) into one user's wire.
+        skip_levels (whole-step capture at one rank and one user): only the encode is launched; the level launch is left to
+        decode_mean(..., fused_levels=True), which runs it together with the decode (gq_hsq_levels_decode_batched).
         dense: the identity-compressed tensors (the quantizer's, in its order) that the level launch also copies into the wire.
         Returns False (nothing launched) when a tensor is not a contiguous, 16-byte aligned f32
         tensor on this device: the caller then takes the per-tensor path for this step.
@@ -721,14 +723,42 @@ class BatchedHSQ(_BatchedBase):
                 mode, seed, r_flat = native.RANDOM_DEVICE, _next_seed() ^ salt, None
             else:
                 mode, seed, r_flat = native.RANDOM_OFF, 0, None
-            self._batch.levels(wire_user, mode, seed, r_flat, write_error=errs is not None)
+            if skip_levels:
+                self._pending_levels = (wire_user, mode, seed, r_flat, errs is not None)
+            else:
+                self._batch.levels(wire_user, mode, seed, r_flat, write_error=errs is not None)
         except BaseException:
             if graph_header is not None:
                 self._graph_tables_abort()
             raise
-        if graph_header is not None:
+        if graph_header is not None and not skip_levels:
             self._graph_tables_done(defer_reset)
+        elif graph_header is not None:
+            # the level launch is still to come and reads the graph's own tables: the descriptor goes back to the shared header
+            # behind it (levels_decode); the accumulators' reset is handed to the caller now -- it rides in that same launch
+            if self._resets:
+                assert defer_reset is not None, "skip_levels is for the whole-step capture, which folds the resets into its last launch"
+                defer_reset.append((self._dev[self._table_words:self._dense_at], self._acc_init))
         return True
+
+    def fusable_levels(self):
+        """The level launch and the decode of the one payload can be ONE launch (native.HSQBatch.levels_decode)."""
+        c0 = self.codecs[0]
+        return (self._batch.path == native.BATCH_PREFILTER and self.n_bit != 32 and not c0.packed6
+                and self.level_dtype in (torch.uint8, torch.int16) and not getattr(self, "fma", False))
+
+    def levels_decode(self, plain, tail):
+        """The launch encode(..., skip_levels=True) left out + the decode of that payload (+ tail) -> the output views."""
+        wire_user, mode, seed, r_flat, write_error = self._pending_levels
+        self._pending_levels = None
+        out, views = self._out_buffer(wire_user.device)
+        try:
+            self._batch.levels_decode(wire_user, mode, seed, r_flat, write_error, out, plain=plain, tail=tail)
+        except BaseException:
+            self._graph_tables_abort()
+            raise
+        self._batch.set_table(self._dev[:self._table_words])      # (the reset itself rode in the launch: tail.reset)
+        return views
 
 
 class BatchedQSGD(_BatchedBase):
@@ -914,6 +944,7 @@ class PSQuantizer(object):
         # words.  The launches' arguments never change -- they replay from a HIP graph -- and the draws are fresh every
         # step whatever the gradients are (the reference draws per call: probabilistic_scalar_compressor.py:22-26).
         self._rng_state = None
+        self._ticket = None          # gq_hsq_levels_decode_batched's last-workgroup counter (one device word, zero between launches)
         self._rec_graphs = {}        # (slot, user, scale, gradient addresses) -> [sightings, graph or None, keep-alive]
         self._apply_graphs = {}      # (users recorded, wire, output-buffer turns) -> [sightings, graph or None, decoded list]
         # One rank, one user per step (args.num_users == 1, no process group): record() is always followed by the apply() of
@@ -1127,9 +1158,10 @@ class PSQuantizer(object):
             obj.rng_pairs = self._rng_pairs_for(dev, self._groups.index(grp))
         return obj
 
-    def _record_launches(self, all_grads, wire, slot, user, salt, scale, draws, dev, headers=None, defer_resets=None):
+    def _record_launches(self, all_grads, wire, slot, user, salt, scale, draws, dev, headers=None, defer_resets=None, fuse_levels=False):
         """The multi-tensor launches of a record (+ the dense tensors' copy into the wire) -> the set of parameters served.
-        headers (stream capture): one device-resident header per group, see BatchedHSQ.encode."""
+        headers (stream capture): one device-resident header per group, see BatchedHSQ.encode.
+        fuse_levels (whole-step capture, _can_fuse_levels): the group's level launch is left to the aggregate's decode."""
         skip = set()
         skip_groups = []
         for grp in (self._groups if dev.type == "cuda" else []):
@@ -1146,7 +1178,8 @@ class PSQuantizer(object):
             hdr = headers[len(skip_groups)] if headers is not None else None
             skip_groups.append(obj)
             dense = list(self._pick_dense(all_grads)) if obj.ndense else None
-            if obj.encode(grads, wire, slot, salt, errs, scale, draws=draws, graph_header=hdr, dense=dense, defer_reset=defer_resets):
+            kw = {"skip_levels": True} if fuse_levels else {}
+            if obj.encode(grads, wire, slot, salt, errs, scale, draws=draws, graph_header=hdr, dense=dense, defer_reset=defer_resets, **kw):
                 skip.update(idxs)
                 if dense is not None:
                     skip.update(self.dense_idx)      # (copied by that launch)
@@ -1211,9 +1244,11 @@ class PSQuantizer(object):
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                resets = []      # the groups' accumulator resets ride in the step's last launch (gq_mean_rows)
-                self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers, defer_resets=resets)
-                decoded = self._decode_all(self._wire[:1], False, (), resets=resets)
+                resets = []      # the groups' accumulator resets ride in the step's last launch
+                fuse = self._can_fuse_levels()      # one rank, one user: level launch + decode of that payload as ONE launch
+                self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers, defer_resets=resets,
+                                      fuse_levels=fuse)
+                decoded = self._decode_all(self._wire[:1], False, (), resets=resets, fused_levels=fuse)
             fent[1], fent[2] = graph, decoded
         except Exception as e:      # the two-graph replay keeps working
             self._fuse_steps = False
@@ -1223,6 +1258,19 @@ class PSQuantizer(object):
             for g, t in zip(self._groups, after[0]):
                 g[2]._out_turn = t
             self._dense_turn = after[1]
+
+    def _can_fuse_levels(self):
+        """A whole step of one rank and one user whose tensors all go through ONE HSQ group (+ the dense tensors riding in
+        its launches): encode, then gq_hsq_levels_decode_batched.  $GQ_FUSE_LEVELS=0 keeps the three launches."""
+        if os.environ.get("GQ_FUSE_LEVELS", "1") == "0" or len(self._groups) != 1:
+            return False
+        if self.error_feedback and os.environ.get("GQ_FUSE_LEVELS") != "ef":
+            # measured (profiles/r05_experiments.txt, 2): with error feedback the one launch moves three streams (updated gradient in,
+            # residual and decoded tensor out) and is SLOWER than the level launch + the decode (0.1233 against 0.1158 ms per step)
+            return False
+        obj = self._groups[0][2]
+        return (isinstance(obj, BatchedHSQ) and obj.fusable_levels() and (not self.dense_idx or (len(self.dense_idx) >= 2 and obj.ndense))
+                and os.environ.get("GQ_STEP_TAIL", "1") != "0")
 
     def _apply_key(self, gathered):
         """What an apply()'s captured launches depend on: payload count, the wire, and which output buffers are next."""
@@ -1237,7 +1285,7 @@ class PSQuantizer(object):
         o = self._draw_off[i]
         return {"r": draws[0][o:o + self.codecs[i].M]}
 
-    def _decode_all(self, gathered, two_phase, pending=(), plain=False, resets=None):
+    def _decode_all(self, gathered, two_phase, pending=(), plain=False, resets=None, fused_levels=False):
         """Mean of the R = gathered.shape[0] user payloads for every parameter (ps_quantizer.py:47-61),
         as a list of tensors in parameter order.  `pending`: the transfers that fill `gathered`
         (exchange.WireExchange.start) -- one, or one per byte range for a split / pipelined exchange, in which case the
@@ -1287,9 +1335,12 @@ class PSQuantizer(object):
             mean_in_tail = dense_job is not None and not (plain and R == 1)
             if takers and (mean_in_tail or step_rng or resets):
                 tail_group = takers[-1]
+                if self._ticket is None or self._ticket.device != gathered.device:
+                    self._ticket = torch.zeros(native.TICKET_WORDS, dtype=torch.int32, device=gathered.device)
                 tail = native.StepTail(rows=dense_job[0] if mean_in_tail else None,
                                        out=self._dense_mean[dense_job[1]] if mean_in_tail else None,
-                                       rng_state=self._rng_state if step_rng else None, reset=resets.pop(0) if resets else None)
+                                       rng_state=self._rng_state if step_rng else None, reset=resets.pop(0) if resets else None,
+                                       ticket=self._ticket)
                 step_rng = False
                 if mean_in_tail:
                     dense_job = (None, dense_job[1])      # (done by the decode launch)
@@ -1304,7 +1355,10 @@ class PSQuantizer(object):
                         part = seg_ranges[(gi, lo, hi)] = (sum(1 for i in idxs if self.offsets[i] < lo),
                                                           sum(1 for i in idxs if self.offsets[i] < hi))
                     part = part + (first,)
-                group_views[gi] = obj.decode_mean(gathered, R, part, plain=plain, tail=tail if gi == tail_group else None)
+                if fused_levels and lo is None and getattr(obj, "_pending_levels", None) is not None:
+                    group_views[gi] = obj.levels_decode(plain, tail if gi == tail_group else None)      # levels + decode (+ tail): one launch
+                else:
+                    group_views[gi] = obj.decode_mean(gathered, R, part, plain=plain, tail=tail if gi == tail_group else None)
             for i in single:
                 if lo is None or lo <= self.offsets[i] < hi:
                     done[i] = self.codecs[i].decode_mean(gathered, self.offsets[i], R, plain=plain)

@@ -89,7 +89,7 @@ size_t gq_hsq_workspace_bytes(int64_t M);
 #define GQ_AGGREGATE_FMA 0x100
 
 /* Library / device identification. */
-int gq_abi_version(void);            /* 4: round 5 (gq_hsq_decode_sum_batched_tail, gq_step_tail; impl 6 of gq_hsq_encode_ex); 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words and takes reset words; gq_hsq_batch / gq_qsgd_batch carry the dense table); 2: the round-3 descriptor form of the multi-tensor entry points */
+int gq_abi_version(void);            /* 4: round 5 (gq_hsq_decode_sum_batched_tail, gq_hsq_levels_decode_batched, gq_step_tail; impl 6 of gq_hsq_encode_ex); 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words and takes reset words; gq_hsq_batch / gq_qsgd_batch carry the dense table); 2: the round-3 descriptor form of the multi-tensor entry points */
 const char *gq_last_error(void);     /* text of the calling thread's last failure (the library's only per-thread state) */
 /* Fills CU count and the gcnArchName (e.g. "gfx950:sramecc+:xnack-") of `device`. */
 int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
@@ -276,6 +276,7 @@ int gq_hsq_decode_sum_batched(const gq_hsq_batch *b, const uint8_t *gathered, in
  * ResNet-50 list is then three kernels (encode, levels, decode-mean) instead of four; a launch of its own cost ~4 us of
  * kernel and a boundary in a ~70 us step.  Decode paths without the in-kernel form (exact kernels, unaligned wires) run
  * gq_mean_rows behind the decode: the results are the same either way.  t == NULL: gq_hsq_decode_sum_batched. */
+#define GQ_TICKET_WORDS 544   /* (1 + 16) counters of the last-workgroup hand-over, each on a 128-byte line of its own */
 typedef struct gq_step_tail {
     uint32_t struct_bytes;       /* sizeof(gq_step_tail) */
     int32_t rows_R;              /* rows of the mean (>= 1) */
@@ -288,9 +289,22 @@ typedef struct gq_step_tail {
     const uint64_t *reset_src;
     int32_t rng_pairs;
     int32_t reset_words;
+    uint32_t *ticket;            /* gq_hsq_levels_decode_batched only: GQ_TICKET_WORDS device words, zero before the first launch (the
+                                    launch leaves them zero); else NULL */
 } gq_step_tail;
 int gq_hsq_decode_sum_batched_tail(const gq_hsq_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                    float *out, int plain, const gq_step_tail *t, void *stream);
+
+/* One rank, one user per step: decompress(compress(g)) for every tensor is the aggregate (ps_quantizer.py:37,48 with one
+ * decoded tensor per parameter).  This is gq_hsq_levels_batched followed by gq_hsq_decode_sum_batched_tail over the ONE
+ * payload `wire` as ONE launch -- the multi-tensor twin of gq_hsq_levels_decode: levels and (lb, ub) into the wire (+ the
+ * residual when write_error), out = (+0 + codebook[code] * norm) / 1 (plain: the decompress as it is), the uncompressed
+ * tensors copied into the wire AND averaged (t->rows points at the wire's dense region, rows_R = 1), and -- by the last
+ * workgroup to finish, told by t->ticket -- the step of the draws' words and the accumulators' reset.  A step of the
+ * ResNet-50 list is then two kernels.  Served in one launch for K = 256, d in {8, 16, 32}, byte codes, byte or 16-bit levels;
+ * every other descriptor runs the two calls (same results). */
+int gq_hsq_levels_decode_batched(const gq_hsq_batch *b, uint8_t *wire, int random_mode, uint64_t seed, const float *r_flat,
+                                 int write_error, float *out, int plain, const gq_step_tail *t, void *stream);
 
 /*
  * Error-feedback helpers around the per-tensor codec (ps_quantizer.py:35,39):

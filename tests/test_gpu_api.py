@@ -461,8 +461,9 @@ def test_step_tail_in_the_decode_launch_equals_a_launch_of_its_own(monkeypatch, 
     users = kw.pop("users", 1)
     shapes = RESNET50_COMPRESSED[:7] + RESNET50_SMALL[:4]
 
-    def run(tail):
+    def run(tail, fuse_levels=False):
         monkeypatch.setenv("GQ_STEP_TAIL", "1" if tail else "0")
+        monkeypatch.setenv("GQ_FUSE_LEVELS", ("ef" if kw.get("ef") else "1") if fuse_levels else "0")      # ("ef": the fused form is off by default under error feedback)
         torch.manual_seed(77)
         from gq_amd import compressors
         compressors._seed_counter[0] = 0      # (the pairs' seeds come from torch's seed and a per-process call counter)
@@ -470,12 +471,18 @@ def test_step_tail_in_the_decode_launch_equals_a_launch_of_its_own(monkeypatch, 
         q = Quantizer(NearestNeighborCompressor, params, make_args(num_users=users, random=1, **kw))
         g = torch.Generator(device="cuda").manual_seed(5)
         inputs = [[[torch.randn(p.shape, device="cuda", generator=g) * 1e-2 for p in params] for _ in range(users)] for _ in range(2)]
-        outs, calls = [], 0
+        outs, calls, bufs = [], 0, {}
         for st in range(8):
             c0 = native.CALLS[0]
             for u in range(users):
                 for p, x in zip(params, inputs[st % 2][u]):
-                    p.grad = x.clone()
+                    if st == 0:
+                        p.grad = x.clone()
+                    else:
+                        p.grad.data = bufs[id(p)]      # apply() rebinds .grad.data to the mean: back to the parameter's own buffer,
+                        p.grad.data.copy_(x)           # as autograd writes into the same storage every step (graphs need recurring addresses)
+                    if st == 0:
+                        bufs[id(p)] = p.grad.data
                 q.record(u, epoch=1)
             q.apply()
             calls = native.CALLS[0] - c0
@@ -487,6 +494,19 @@ def test_step_tail_in_the_decode_launch_equals_a_launch_of_its_own(monkeypatch, 
         for x, y in zip(a, b):
             assert torch.equal(x.view(torch.int32), y.view(torch.int32))
     assert torch.equal(q1._rng_state, q0._rng_state) and int(q1._rng_state[0, 1]) == 8      # one step per aggregate either way
+    # ... and the one-rank step's two-kernel form (gq_hsq_levels_decode_batched: level launch + decode of the payload + tail as
+    # ONE launch in the whole-step graph; one user only): the same gradients, the same sequence of draws, the wire complete
+    fused, calls_fused, q2 = run(True, fuse_levels=True)
+    for a, b in zip(fused, own_launch):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    assert torch.equal(q2._rng_state, q0._rng_state) and torch.equal(q2._wire, q0._wire)
+    if users == 1:
+        assert any(e[1] is not None for e in q2._step_graphs.values()), "no whole-step graph was captured"
+        assert int(q2._ticket.abs().sum()) == 0                                                  # the ticket counters are back at zero
+        if kw.get("ef"):
+            for p2, p0 in zip(q2.parameters, q0.parameters):
+                assert torch.equal(p2.error[0], p0.error[0])
 
 
 def test_batched_quantizer_equals_per_tensor_path():

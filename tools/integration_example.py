@@ -63,7 +63,7 @@ class GQStepTail(ctypes.Structure):                       # gq_step_tail
     _fields_ = [("struct_bytes", ctypes.c_uint32), ("rows_R", ctypes.c_int32), ("rows", ctypes.c_void_p),
                 ("row_stride_bytes", ctypes.c_int64), ("n", ctypes.c_int64), ("out", ctypes.c_void_p),
                 ("rng_state", ctypes.c_void_p), ("reset_dst", ctypes.c_void_p), ("reset_src", ctypes.c_void_p),
-                ("rng_pairs", ctypes.c_int32), ("reset_words", ctypes.c_int32)]
+                ("rng_pairs", ctypes.c_int32), ("reset_words", ctypes.c_int32), ("ticket", ctypes.c_void_p)]
 
 dev = torch.device("cuda")
 up = lambda n: (n + 15) // 16 * 16
@@ -117,7 +117,7 @@ for u in range(U):                                          # record(user): one 
     torch.cuda.synchronize()                               # (the tables above are rebuilt per user in this example)
 # apply(): ONE decode-mean over the U wires; the small tensors' mean rides in the same launch (gq_step_tail)
 rows = gathered[:, dense_off:dense_off + 4 * dense_mean.numel()]
-tail = GQStepTail(ctypes.sizeof(GQStepTail), U, rows.data_ptr(), gathered.stride(0), dense_mean.numel(), dense_mean.data_ptr(), None, None, None, 0, 0)
+tail = GQStepTail(ctypes.sizeof(GQStepTail), U, rows.data_ptr(), gathered.stride(0), dense_mean.numel(), dense_mean.data_ptr(), None, None, None, 0, 0, None)
 rc = _gq.gq_hsq_decode_sum_batched_tail(ctypes.byref(b), P(gathered), ctypes.c_int64(user_bytes), U, P(out), 0, ctypes.byref(tail), st)
 assert rc == 0, _gq.gq_last_error()
 torch.cuda.synchronize()
