@@ -124,6 +124,23 @@ static int check_tail(const gq_step_tail *t, const char *what) {
 }
 }  // namespace gq
 
+namespace gq {
+static StepTail tail_of(const gq_step_tail *t) {
+    StepTail tail = {};
+    tail.rows = static_cast<const uint8_t *>(t->rows);
+    tail.row_stride_bytes = t->row_stride_bytes;
+    tail.n = t->n;
+    tail.out = t->out;
+    tail.rng_state = t->rng_state;
+    tail.reset_dst = t->reset_dst;
+    tail.reset_src = t->reset_src;
+    tail.R = t->rows_R;
+    tail.rng_pairs = t->rng_state ? t->rng_pairs : 0;
+    tail.reset_words = t->reset_words;
+    return tail;
+}
+}  // namespace gq
+
 GQ_API int gq_hsq_levels_decode_batched(const gq_hsq_batch *b, uint8_t *wire, int random_mode, uint64_t seed, const float *r_flat,
                                         int write_error, float *out, int plain, const gq_step_tail *t, void *stream) {
     int rc = gq::check_batch(b, "gq_hsq_levels_decode_batched");
@@ -200,17 +217,7 @@ GQ_API int gq_hsq_decode_sum_batched_tail(const gq_hsq_batch *b, const uint8_t *
     if (!t) return gq::decode_sum_batched(b, gathered, user_stride_bytes, R, out, plain, nullptr, nullptr, stream);
     const int trc = gq::check_tail(t, "gq_hsq_decode_sum_batched_tail");
     if (trc != GQ_OK) return trc;
-    gq::StepTail tail = {};
-    tail.rows = static_cast<const uint8_t *>(t->rows);
-    tail.row_stride_bytes = t->row_stride_bytes;
-    tail.n = t->n;
-    tail.out = t->out;
-    tail.rng_state = t->rng_state;
-    tail.reset_dst = t->reset_dst;
-    tail.reset_src = t->reset_src;
-    tail.R = t->rows_R;
-    tail.rng_pairs = t->rng_state ? t->rng_pairs : 0;
-    tail.reset_words = t->reset_words;
+    const gq::StepTail tail = gq::tail_of(t);
     int taken = 0;
     const int rc = gq::decode_sum_batched(b, gathered, user_stride_bytes, R, out, plain, &tail, &taken, stream);
     if (rc != GQ_OK || taken) return rc;
@@ -253,13 +260,34 @@ GQ_API int gq_qsgd_compress_batched(const gq_qsgd_batch *b, uint8_t *wire, int r
                                      b->dense_table, b->ndense, stream);
 }
 
-GQ_API int gq_qsgd_decode_sum_batched(const gq_qsgd_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                      float *out, int plain, void *stream) {
-    const int rc = gq::check_qsgd(b, "gq_qsgd_decode_sum_batched");
+namespace gq {
+static int qsgd_decode_sum_batched(const gq_qsgd_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R, float *out,
+                                   int plain, const StepTail *tail, int *tail_taken, void *stream) {
+    if (tail_taken) *tail_taken = 0;
+    const int rc = check_qsgd(b, "gq_qsgd_decode_sum_batched");
     if (rc != GQ_OK) return rc;
     if (b->wide)
         return gqi_qsgd_wide_decode_sum(b->seg_table, b->item_seg, b->nseg, b->nitems, b->n_bit, b->bits, gathered,
                                         user_stride_bytes, R, out, plain, stream);
     return gqi_qsgd_decode_sum_batched(b->seg_table, b->item_seg, b->nseg, b->nitems, b->n_bit, b->bits, gathered,
-                                       user_stride_bytes, R, out, plain, stream);
+                                       user_stride_bytes, R, out, plain, tail, tail_taken, stream);
+}
+}  // namespace gq
+
+GQ_API int gq_qsgd_decode_sum_batched(const gq_qsgd_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                      float *out, int plain, void *stream) {
+    return gq::qsgd_decode_sum_batched(b, gathered, user_stride_bytes, R, out, plain, nullptr, nullptr, stream);
+}
+
+GQ_API int gq_qsgd_decode_sum_batched_tail(const gq_qsgd_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                           float *out, int plain, const gq_step_tail *t, void *stream) {
+    if (!t) return gq::qsgd_decode_sum_batched(b, gathered, user_stride_bytes, R, out, plain, nullptr, nullptr, stream);
+    const int trc = gq::check_tail(t, "gq_qsgd_decode_sum_batched_tail");
+    if (trc != GQ_OK) return trc;
+    const gq::StepTail tail = gq::tail_of(t);
+    int taken = 0;
+    const int rc = gq::qsgd_decode_sum_batched(b, gathered, user_stride_bytes, R, out, plain, &tail, &taken, stream);
+    if (rc != GQ_OK || taken) return rc;
+    return gq_mean_rows(t->rows, t->row_stride_bytes, t->rows_R, t->n, t->out, t->rng_state, t->rng_pairs, t->reset_dst, t->reset_src,
+                        t->reset_words, stream);
 }

@@ -399,8 +399,9 @@ constexpr int QB4_RMAX = 8;
 template <int R>
 __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_r_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int nseg, int n_bit,
-    const uint8_t *__restrict__ gathered, int64_t user_stride, float *__restrict__ out, int plain) {
+    const uint8_t *__restrict__ gathered, int64_t user_stride, float *__restrict__ out, int plain, const StepTail tail) {
     __shared__ int64_t s_seg[QB_LDS_SEGS * 8];
+    step_tail_run(tail);      // the aggregate's small per-step work (gq_qsgd_decode_sum_batched_tail)
     for (int i = threadIdx.x; i < nseg * 8; i += QB_THREADS) s_seg[i] = seg_table[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, sub = lane >> 4, c0 = lane & 15;
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_r_kernel(
 
 template <int R>
 static void launch_qb4_r(const int64_t *seg_table, const int32_t *bucket_seg, int64_t nbuckets, int nseg, int n_bit,
-                         const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st);
+                         const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st, const StepTail &tail);
 
 // One resident wave of workgroups for `kernel` (the occupancy API) instead of a fixed 8 per CU: the 4-bit compress kernel
 // holds 5-6 waves per SIMD (74-84 registers), so a quarter of an 8-per-CU grid queued behind the resident workgroups.
@@ -586,18 +587,18 @@ static inline int64_t qb_grid(int64_t nbuckets) {
 
 template <int R>
 static void launch_qb4_r(const int64_t *seg_table, const int32_t *bucket_seg, int64_t nbuckets, int nseg, int n_bit,
-                         const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st) {
+                         const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st, const StepTail &tail) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_decode_sum_batched4_r_kernel<R>),
                        dim3((unsigned)qb_grid_resident(qsgd_decode_sum_batched4_r_kernel<R>, (nbuckets + 3) / 4)),
-                       dim3(QB_THREADS), 0, st, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride, out, plain);
+                       dim3(QB_THREADS), 0, st, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride, out, plain, tail);
 }
 
 static bool launch_qb4_fixed_r(int R, const int64_t *seg_table, const int32_t *bucket_seg, int64_t nbuckets, int nseg, int n_bit,
-                               const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st) {
+                               const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st, const StepTail &tail) {
     // byte offsets inside a payload are 32-bit in this kernel, the table sits in LDS
     if (nseg > QB_LDS_SEGS || user_stride >= ((int64_t)1 << 31)) return false;
     switch (R) {
-#define GQ_QB4_CASE(N) case N: launch_qb4_r<N>(seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride, out, plain, st); return true;
+#define GQ_QB4_CASE(N) case N: launch_qb4_r<N>(seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride, out, plain, st, tail); return true;
         GQ_QB4_CASE(1) GQ_QB4_CASE(2) GQ_QB4_CASE(3) GQ_QB4_CASE(4)
         GQ_QB4_CASE(5) GQ_QB4_CASE(6) GQ_QB4_CASE(7) GQ_QB4_CASE(8)
 #undef GQ_QB4_CASE
@@ -660,8 +661,9 @@ GQ_INTERNAL int gqi_qsgd_compress_batched(const int64_t *seg_table, const int32_
 
 GQ_INTERNAL int gqi_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
                                             int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                            float *out, int plain, void *stream) {
+                                            float *out, int plain, const gq::StepTail *tail_or_null, int *tail_taken, void *stream) {
     plain = plain ? 1 : 0;
+    if (tail_taken) *tail_taken = 0;
     if (nseg < 1 || nbuckets < 1 || n_bit < 1 || R < 1 || (bits != 4 && bits != 8 && bits != 16))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: bad sizes");
     if (!seg_table || !bucket_seg || !gathered || !out)
@@ -669,8 +671,9 @@ GQ_INTERNAL int gqi_qsgd_decode_sum_batched(const int64_t *seg_table, const int3
     if (bits == 4 && (user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
         if (gq::launch_qb4_fixed_r(R, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride_bytes, out, plain,
-                                   gq::as_stream(stream))) {
+                                   gq::as_stream(stream), tail_or_null ? *tail_or_null : gq::StepTail{})) {
             GQ_CHECK_LAUNCH("gq_qsgd_decode_sum_batched");
+            if (tail_taken) *tail_taken = 1;
             return GQ_OK;
         }
         hipLaunchKernelGGL(gq::qsgd_decode_sum_batched4_kernel, dim3((unsigned)gq::qb_grid((nbuckets + 3) / 4)),

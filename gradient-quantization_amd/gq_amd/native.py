@@ -28,7 +28,7 @@ EXPORTS = [     # every entry point include/gq_hsq.h declares (tests/test_host_l
     "gq_hsq_batched_path", "gq_hsq_encode_batched", "gq_hsq_levels_batched", "gq_hsq_decode_sum_batched", "gq_hsq_decode_sum_batched_tail",
     "gq_hsq_levels_decode_batched",
     "gq_axpy_inplace", "gq_sub", "gq_mean_rows", "gq_qsgd_compress", "gq_qsgd_decode_sum", "gq_qsgd_code_bits",
-    "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched", "gq_pvq_encode",
+    "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched", "gq_qsgd_decode_sum_batched_tail", "gq_pvq_encode",
 ]
 ABI_VERSION = 4
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3      # GQ_ERR_* of include/gq_hsq.h
@@ -477,8 +477,15 @@ class QSGDBatch(object):
                                              ctypes.c_float(_NAN if ef_scale is None else ef_scale), _stream())
         _check(rc, "gq_qsgd_compress_batched")
 
-    def decode(self, gathered, R, out, plain=False):
+    def decode(self, gathered, R, out, plain=False, tail=None):
+        """tail (StepTail): gq_qsgd_decode_sum_batched_tail."""
         assert gathered.dtype == torch.uint8 and gathered.dim() == 2 and gathered.shape[0] == R and gathered.is_contiguous()
+        if tail is not None:
+            rc = self.L.gq_qsgd_decode_sum_batched_tail(self.ref, _dev_ptr(gathered, torch.uint8, "gathered"),
+                                                        ctypes.c_int64(gathered.shape[1]), ctypes.c_int(R),
+                                                        _dev_ptr(out, torch.float32, "out"), ctypes.c_int(1 if plain else 0), tail.ref, _stream())
+            _check(rc, "gq_qsgd_decode_sum_batched_tail")
+            return
         rc = self.L.gq_qsgd_decode_sum_batched(self.ref, _dev_ptr(gathered, torch.uint8, "gathered"),
                                                ctypes.c_int64(gathered.shape[1]), ctypes.c_int(R),
                                                _dev_ptr(out, torch.float32, "out"), ctypes.c_int(1 if plain else 0), _stream())

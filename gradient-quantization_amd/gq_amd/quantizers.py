@@ -766,6 +766,7 @@ class BatchedQSGD(_BatchedBase):
     Tensors with WIDE buckets (TernGrad's `--c-dim 0`: the tensor is one bucket; any bucket above WIDE_MIN
     elements) form their own group on the chunked kernels (gq_qsgd_wide_*: bucket norms, codes, decode)."""
 
+    takes_tail = True      # gq_qsgd_decode_sum_batched_tail (the library runs gq_mean_rows behind a decode path without the in-kernel form)
     WIDE_MIN = 4096
 
     @staticmethod

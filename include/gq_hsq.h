@@ -89,7 +89,7 @@ size_t gq_hsq_workspace_bytes(int64_t M);
 #define GQ_AGGREGATE_FMA 0x100
 
 /* Library / device identification. */
-int gq_abi_version(void);            /* 4: round 5 (gq_hsq_decode_sum_batched_tail, gq_hsq_levels_decode_batched, gq_step_tail; impl 6 of gq_hsq_encode_ex); 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words and takes reset words; gq_hsq_batch / gq_qsgd_batch carry the dense table); 2: the round-3 descriptor form of the multi-tensor entry points */
+int gq_abi_version(void);            /* 4: round 5 (gq_hsq_decode_sum_batched_tail, gq_qsgd_decode_sum_batched_tail, gq_hsq_levels_decode_batched, gq_step_tail; impl 6 of gq_hsq_encode_ex); 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words and takes reset words; gq_hsq_batch / gq_qsgd_batch carry the dense table); 2: the round-3 descriptor form of the multi-tensor entry points */
 const char *gq_last_error(void);     /* text of the calling thread's last failure (the library's only per-thread state) */
 /* Fills CU count and the gcnArchName (e.g. "gfx950:sramecc+:xnack-") of `device`. */
 int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
@@ -392,6 +392,9 @@ int gq_qsgd_compress_batched(const gq_qsgd_batch *b, uint8_t *wire, int random_m
                              void *stream);
 int gq_qsgd_decode_sum_batched(const gq_qsgd_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
                                float *out, int plain, void *stream);
+/* ... with the aggregate's small per-step work riding in the same launch (gq_step_tail: see gq_hsq_decode_sum_batched_tail). */
+int gq_qsgd_decode_sum_batched_tail(const gq_qsgd_batch *b, const uint8_t *gathered, int64_t user_stride_bytes, int R,
+                                    float *out, int plain, const gq_step_tail *t, void *stream);
 
 /*
  * ProbabilisticVectorCompressor encode -- probabilistic_vector_compressor.py:42-63 (pinned by the reference's own

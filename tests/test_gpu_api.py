@@ -448,17 +448,19 @@ def test_many_small_tensors_in_one_workgroups_run_equal_per_tensor_path(c_dim):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(c_dim=32, n_bit=8), dict(c_dim=8), dict(users=3), dict(ef=True)])
+@pytest.mark.parametrize("kw", [dict(), dict(c_dim=32, n_bit=8), dict(c_dim=8), dict(users=3), dict(ef=True),
+                                dict(quant="qsgd", c_dim=128, n_bit=2), dict(quant="qsgd", c_dim=128, n_bit=2, users=2), dict(quant="qsgd", c_dim=0, n_bit=1)])
 def test_step_tail_in_the_decode_launch_equals_a_launch_of_its_own(monkeypatch, kw):
     """gq_hsq_decode_sum_batched_tail: the dense tensors' mean, the step of the draws' { seed, step } words and (whole-step
     graphs) the accumulators' reset ride in the decode-mean launch by default; $GQ_STEP_TAIL=0 keeps gq_mean_rows as a launch
     of its own.  Eight steps with stochastic rounding on the device draws (graphs are captured on the way): the same
     gradients bit for bit, i.e. the same means AND the same sequence of draws."""
     from gq_amd import native
-    from gq_amd.compressors import NearestNeighborCompressor
+    from gq_amd.compressors import NearestNeighborCompressor, QSGDCompressor
     from gq_amd.quantizers import Quantizer
     kw = dict(kw)
     users = kw.pop("users", 1)
+    Comp = QSGDCompressor if kw.pop("quant", "hsq") == "qsgd" else NearestNeighborCompressor
     shapes = RESNET50_COMPRESSED[:7] + RESNET50_SMALL[:4]
 
     def run(tail, fuse_levels=False):
@@ -468,7 +470,7 @@ def test_step_tail_in_the_decode_launch_equals_a_launch_of_its_own(monkeypatch, 
         from gq_amd import compressors
         compressors._seed_counter[0] = 0      # (the pairs' seeds come from torch's seed and a per-process call counter)
         params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in shapes]
-        q = Quantizer(NearestNeighborCompressor, params, make_args(num_users=users, random=1, **kw))
+        q = Quantizer(Comp, params, make_args(num_users=users, random=1, **kw))
         g = torch.Generator(device="cuda").manual_seed(5)
         inputs = [[[torch.randn(p.shape, device="cuda", generator=g) * 1e-2 for p in params] for _ in range(users)] for _ in range(2)]
         outs, calls, bufs = [], 0, {}

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Everything profiles/ holds for one round, in one gpurun call:  gpurun --timeout 2400 -- 'bash tools/prof_all.sh r04'
+# Everything profiles/ holds for one round, in one gpurun call:  gpurun --timeout 2400 -- 'bash tools/prof_all.sh r05'
 # -> gpurun_out/<tag>/{stats (rocprofv3 --kernel-trace --stats of bench.py), bench*.json, pmc_show.txt, stamps.txt, ...};
 # copy what is to be judged into profiles/.  The stamp section reads the stamped twin build.py makes (libgq_hsq_clock.so).
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 mkdir -p $O
@@ -10,10 +10,18 @@ mkdir -p $O
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-workloads --traffic off > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> /dev/null)
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_resnet50 -- python3 $GRAFT_REPO_ROOT/bench.py --workload resnet50 --steps 200 --warmup 20 --traffic off > $GRAFT_REPO_ROOT/$O/bench_resnet50_under_rocprof.json 2> /dev/null)
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_qsgd -- python3 $GRAFT_REPO_ROOT/bench.py --workload qsgd --steps 200 --warmup 20 --traffic off > $GRAFT_REPO_ROOT/$O/bench_qsgd_under_rocprof.json 2> /dev/null)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_resnet50_ef -- python3 $GRAFT_REPO_ROOT/bench.py --workload resnet50 --ef --steps 200 --warmup 20 --traffic off > $GRAFT_REPO_ROOT/$O/bench_resnet50_ef_under_rocprof.json 2> /dev/null)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_resnet50_ef_twophase -- python3 $GRAFT_REPO_ROOT/bench.py --workload resnet50 --ef --two-phase --steps 200 --warmup 20 --traffic off > $GRAFT_REPO_ROOT/$O/bench_resnet50_ef_twophase_under_rocprof.json 2> /dev/null)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_resnet50_main_defaults -- python3 $GRAFT_REPO_ROOT/bench.py --workload resnet50 --c-dim 32 --n-bit 8 --steps 200 --warmup 20 --traffic off > $GRAFT_REPO_ROOT/$O/bench_resnet50_main_defaults_under_rocprof.json 2> /dev/null)
+python tools/kstats.py $O 100 > $O/kernel_stats_short.txt 2>&1
 # 2. the default lines (live PMC traffic, CPU baseline) of the three workloads
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --workload resnet50 > $O/bench_resnet50.json 2> $O/bench_resnet50.err
 python bench.py --workload qsgd > $O/bench_qsgd.json 2> /dev/null
+python bench.py --workload resnet50 --ef --traffic off > $O/bench_resnet50_ef.json 2> /dev/null
+python bench.py --workload resnet50 --ef --two-phase --traffic off > $O/bench_resnet50_ef_twophase.json 2> /dev/null
+python bench.py --workload resnet50 --c-dim 32 --n-bit 8 --traffic off > $O/bench_resnet50_main_defaults.json 2> /dev/null
+python bench.py --workload resnet50 --c-dim 8 --traffic off > $O/bench_resnet50_d8.json 2> /dev/null
 python bench.py --workload resnet50 --no-graph --traffic off > $O/bench_resnet50_eager.json 2> /dev/null
 python bench.py --workload qsgd --no-graph --traffic off > $O/bench_qsgd_eager.json 2> /dev/null
 python bench.py --wire-levels packed6 --no-cpu-baseline --traffic off > $O/bench_packed6.json 2> /dev/null
@@ -27,6 +35,7 @@ GQ_LIB_PATH=gradient-quantization_amd/libgq_hsq_clock.so python tools/stamp_read
 python tools/decode_r.py 1 2 4 8 16 > $O/decode_r.txt 2>&1
 python tools/hsq_batched_r.py > $O/hsq_batched_r.txt 2>&1
 python tools/time_generic.py > $O/time_generic.txt 2>&1
+python tools/time_pf_d.py 32 8 16 >> $O/time_generic.txt 2>&1
 python tools/pvq_time.py > $O/pvq_time.txt 2>&1
 python tools/qsgd_r.py > $O/qsgd_r.txt 2>&1
 python tools/bench_resnet50.py > $O/resnet50_steps.txt 2>&1
