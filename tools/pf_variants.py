@@ -194,7 +194,7 @@ VARIANTS = {
 # variants that are a compile-time switch of the shipped source: name -> extra hipcc flags (the source is taken as it is)
 EXTRA_FLAGS = {"r16": ["-DGQ_RESCORE_BATCH=16"],
                # round 5's early ring flush (hsq_encode_pf.hip, PF_FLUSH_AHEAD): off / other distances from the end of the run
-               "nopair": ["-DGQ_PF_PAIR=0"], "pair": ["-DGQ_PF_PAIR=1"], "fa16": ["-DGQ_PF_FLUSH_AHEAD=16"],
+               "nopair": ["-DGQ_PF_PAIR=0"], "pair": ["-DGQ_PF_PAIR=1"], "tail0": ["-DGQ_PF_TAIL=0"], "tail1": ["-DGQ_PF_TAIL=1"], "tail2": ["-DGQ_PF_TAIL=2"], "tail3": ["-DGQ_PF_TAIL=3"], "tail6": ["-DGQ_PF_TAIL=6"], "fa16": ["-DGQ_PF_FLUSH_AHEAD=16"],
                "fa0": ["-DGQ_PF_FLUSH_AHEAD=0"], "fa8": ["-DGQ_PF_FLUSH_AHEAD=8"], "fa12": ["-DGQ_PF_FLUSH_AHEAD=12"],
                "fa24": ["-DGQ_PF_FLUSH_AHEAD=24"], "fa32": ["-DGQ_PF_FLUSH_AHEAD=32"],
                "fa16s2": ["-DGQ_PF_SCAN1_MAX=2"], "fa16s8": ["-DGQ_PF_SCAN1_MAX=8"], "fa16m1": ["-DGQ_PF_FLUSH_MIN=1"]}
