@@ -447,6 +447,51 @@ def test_pvq_encode_on_the_matrix_cores_matches_the_oracle(nat, oracle, d, K, M)
     assert lb_ub[0].item() == float(ou.min()) and lb_ub[1].item() == float(ou.max())
 
 
+@pytest.mark.parametrize("d,K,M", [(16, 256, 64 * 900 + 17), (32, 256, 20011), (8, 256, 30001), (16, 96, 9000), (32, 32, 4097),
+                                   (8, 224, 5003)])
+def test_pvq_one_sweep_kernel_matches_the_oracle(nat, oracle, d, K, M):
+    """The one-sweep kernel (pvq.hip: pvq_encode_walk_kernel; d in {8, 16, 32}, K = 32 ... 256 in whole blocks): codes and u bit
+    for bit against the CPU restatement, on data with whole zero subvectors, subvectors with one element, scales on both
+    sides of the range its three-operation quotient accepts (those lanes go through the wave's exact prefix sum or the
+    term-by-term walk), and draws on the edges."""
+    rng = np.random.RandomState(7 * d + K)
+    cdag = rng.standard_normal((K, d)).astype(np.float32) * 0.3
+    x = (rng.standard_normal((M, d)) * 0.05).astype(np.float32)
+    x[5::97] = 0.0
+    x[7::89, 1:] = 0.0
+    x[11::83] *= np.float32(1e-28)
+    x[13::79] *= np.float32(1e9)
+    x[17::101, 2:] *= np.float32(1e-12)        # quotients far below 2^-29 next to ordinary ones
+    r = rng.random_sample(M).astype(np.float32)
+    r[:4] = [0.0, np.float32(1e-5), np.float32(1.0) - np.float32(2.0 ** -24), np.float32(0.5)]
+    x = x.reshape(-1)
+    dev = torch.device("cuda:0")
+    g, c, rt = torch.from_numpy(x).to(dev), torch.from_numpy(cdag).to(dev), torch.from_numpy(r).to(dev)
+    codes = torch.empty(M, dtype=torch.uint8, device=dev)
+    u = torch.empty(M, dtype=torch.float32, device=dev)
+    ws = nat.new_workspace(dev, M)
+    nat.pvq_encode(g, c, codes, u, ws, nat.RANDOM_GIVEN, rt, 0)
+    torch.cuda.synchronize()
+    oc, ou = oracle.pvq_encode(x, cdag, r)
+    assert np.array_equal(codes.cpu().numpy().astype(np.int64), oc.astype(np.int64))
+    assert np.array_equal(_bits(u.cpu().numpy()), _bits(ou))
+
+
+@pytest.mark.parametrize("env", [{"GQ_PVQ_EPS": "1e-3"}, {"GQ_PVQ_EPS": "-1e-3"}, {"GQ_PVQ_TWO_SWEEPS": "1"}])
+def test_pvq_one_sweep_kernel_rare_paths(env):
+    """The same PVQ / residual tests with the one-sweep kernel's window widened to 1e-3 (read once per process, hence the child):
+    about half of the lanes are then unsettled and go through the wave's prefix-sum walk (GQ_PVQ_EPS > 0) or the
+    term-by-term walk (< 0); and with the two-sweep kernel in its place (GQ_PVQ_TWO_SWEEPS, the cross-check)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", __file__,
+                        os.path.join(here, "test_gpu_api.py"), "-k", "(pvq or residual or vector) and not rare_paths"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 @pytest.mark.parametrize("K", [256, 250])
 def test_pvq_shared_quotient_walk_equals_the_division(nat, oracle, K):
     """The inverse-CDF walk divides every |p_k| by the same l1: the kernel's three-operation quotient (pvq.hip,
