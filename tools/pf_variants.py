@@ -174,7 +174,69 @@ def r16(s, hdr=None):
     return s      # (the edit is in hsq_pf_common.hpp: built with -DGQ_RESCORE_BATCH=16)
 
 
+# ---- round 5, second half: the verdict's (c) and (d), and the gather split over two memory pipes ----
+def prep2x(s):
+    """Timing probe for a per-codebook prepared image (verdict item 1c): the prologue's f16 split and norm measurement done
+    TWICE (the second time on copies the compiler cannot see through; same answers) -- the time this adds is what a prologue
+    that only loads prepared fragments (same bytes, same barrier) would save."""
+    s = rep(s, "                fl[e] = (_Float16)rr;   // c = hi + lo + r",
+            "                fl[e] = (_Float16)rr;\n"
+            "                { float x2 = x; asm volatile(\"\" : \"+v\"(x2)); const _Float16 h2 = (_Float16)x2; const float r2 = x2 - (float)h2; const _Float16 l2h = (_Float16)r2;\n"
+            "                  float t2 = __fmaf_rn(x2, x2, l2); float u2 = __fmaf_rn(r2, r2, d2); asm volatile(\"\" :: \"v\"(t2), \"v\"(u2));\n"
+            "                  fh[e] = h2; fl[e] = l2h; }   // c = hi + lo + r")
+    s = rep(s, "        l2 = wave_max_nan(l2);\n        d2 = wave_max_nan(d2);\n",
+            "        { float a2 = l2, b2 = d2; asm volatile(\"\" : \"+v\"(a2), \"+v\"(b2)); a2 = wave_max_nan(a2); b2 = wave_max_nan(b2); asm volatile(\"\" :: \"v\"(a2), \"v\"(b2)); }\n"
+            "        l2 = wave_max_nan(l2);\n        d2 = wave_max_nan(d2);\n")
+    return s
+
+
+def twophase(s):
+    """Verdict item 1d: the f32 codebook image twice in LDS, the second copy 8 banks (two 16-byte bank groups) further on;
+    lanes 8-15 of every 16 gather from the second.  Bit-identical answers."""
+    s = rep(s, "    __shared__ __attribute__((aligned(16))) float s_cb[64 * QS];",
+            "    __shared__ __attribute__((aligned(16))) float s_cb[64 * QS];\n    __shared__ __attribute__((aligned(16))) float s_cb2[64 * QS + 8];")
+    s = rep(s, "        s_cb[(k >> 2) * QS + 4 * jj + (k & 3)] = cbv[n];",
+            "        s_cb[(k >> 2) * QS + 4 * jj + (k & 3)] = cbv[n];\n        s_cb2[8 + (k >> 2) * QS + 4 * jj + (k & 3)] = cbv[n];")
+    s = rep(s, "        const f32x4 p4 = exact_score_quad<D>(s_cb + (kc >> 2) * QS, vf);   // kc is a multiple of 4: one quad",
+            "        const f32x4 p4 = exact_score_quad<D>(((lane & 8) ? s_cb2 + 8 : s_cb) + (kc >> 2) * QS, vf);")
+    return s
+
+
+def l1half(s):
+    """Timing probe: the second half of the rescoring gather (8 of the 16 rows of a group) comes through the vector L1 from
+    global memory instead of LDS (same 16-byte-per-lane pattern on the caller's codebook: values wrong) -- would two memory
+    pipes instead of one shorten the gather?"""
+    s = rep(s, "namespace gq {\n", """namespace gq {
+template <int D>
+__device__ __forceinline__ f32x4 exact_score_quad_l1(const float *__restrict__ quad, const float *__restrict__ gq_, const float (&v)[D]) {
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    f32x4 c[D];
+#pragma unroll
+    for (int jj = D / 2; jj < D; ++jj) c[jj] = *reinterpret_cast<const f32x4 *>(gq_ + 4 * jj);
+#pragma unroll
+    for (int jj = 0; jj < D / 2; ++jj) c[jj] = *reinterpret_cast<const f32x4 *>(quad + 4 * jj);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < D; ++jj) {
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(c[jj][0]), "v"(v[jj]));
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(c[jj][1]), "v"(v[jj]));
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a2) : "v"(c[jj][2]), "v"(v[jj]));
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a3) : "v"(c[jj][3]), "v"(v[jj]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 r = {a0, a1, a2, a3};
+    return r;
+}
+""")
+    s = rep(s, "        const f32x4 p4 = exact_score_quad<D>(s_cb + (kc >> 2) * QS, vf);   // kc is a multiple of 4: one quad",
+            "        const f32x4 p4 = exact_score_quad_l1<D>(s_cb + (kc >> 2) * QS, cb + (kc >> 2) * 4 * D, vf);")
+    return s
+
+
 VARIANTS = {
+    "prep2x": prep2x,
+    "twophase": twophase,
+    "l1half": l1half,
     "nowr": nowr,
     "nopass": nopass,
     "fp8lo2": fp8lo2,
