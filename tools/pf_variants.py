@@ -233,7 +233,28 @@ __device__ __forceinline__ f32x4 exact_score_quad_l1(const float *__restrict__ q
     return s
 
 
+def w12(s, waves=12, aregs=False):
+    """Three waves per SIMD for d = 16: workgroups of 12 waves (768 threads, <= 168 VGPRs), the codebook's f16 A fragments read
+    from LDS per chain as d = 32 does (-32 VGPRs) -- does a third wave fill the loop's stalls (5,084 cycles per tile against
+    4,256 of issue)?  Bit-identical answers."""
+    s = rep(s, "constexpr int PF_WAVES = 8;", "constexpr int PF_WAVES = %d;" % waves)
+    if not aregs:
+        s = rep(s, "static constexpr bool A_REGS = D <= 16;", "static constexpr bool A_REGS = D < 16;")
+    s = rep(s, "    float cbv[256 * D / PF_THREADS];\n#pragma unroll\n    for (int n = 0; n < 256 * D / PF_THREADS; ++n) cbv[n] = cb[threadIdx.x + n * PF_THREADS];",
+            "    constexpr int NCB = (256 * D + PF_THREADS - 1) / PF_THREADS;\n    float cbv[NCB];\n#pragma unroll\n    for (int n = 0; n < NCB; ++n) cbv[n] = (threadIdx.x + n * PF_THREADS < 256 * D) ? cb[threadIdx.x + n * PF_THREADS] : 0.0f;")
+    s = rep(s, "    for (int n = 0; n < 256 * D / PF_THREADS; ++n) {\n        const int i = threadIdx.x + n * PF_THREADS, k = i / D, jj = i % D;\n        s_cb[(k >> 2) * QS + 4 * jj + (k & 3)] = cbv[n];",
+            "    for (int n = 0; n < NCB; ++n) {\n        const int i = threadIdx.x + n * PF_THREADS, k = i / D, jj = i % D;\n        if (i < 256 * D) s_cb[(k >> 2) * QS + 4 * jj + (k & 3)] = cbv[n];")
+    s = rep(s, "    if (loads_here) {\n#pragma unroll\n        for (int s = 0; s < KS; ++s) {\n            aq[2 * s] =", "    if (loads_here && wave < 8) {\n#pragma unroll\n        for (int s = 0; s < KS; ++s) {\n            aq[2 * s] =")
+    s = rep(s, "        float l2 = 0.0f, d2 = 0.0f;\n#pragma unroll\n        for (int s = 0; s < KS; ++s) {\n            half8 fh, fl;", "        float l2 = 0.0f, d2 = 0.0f;\n        if (wave < 8) {\n#pragma unroll\n        for (int s = 0; s < KS; ++s) {\n            half8 fh, fl;")
+    s = rep(s, "        if (lane == 0) {\n            s_c1[wave] = l2;\n            s_dc[wave] = d2;\n        }\n", "        if (lane == 0) {\n            s_c1[wave] = l2;\n            s_dc[wave] = d2;\n        }\n        }\n")
+    s = rep(s, "    for (int w = 1; w < PF_WAVES; ++w) {\n        c2b = max(c2b", "    for (int w = 1; w < 8; ++w) {\n        c2b = max(c2b")
+    return s
+
+
 VARIANTS = {
+    "w12": w12,
+    "w12a": lambda s: w12(s, 12, True),
+    "w16": lambda s: w12(s, 16, False),
     "prep2x": prep2x,
     "twophase": twophase,
     "l1half": l1half,
