@@ -381,11 +381,11 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_lds_kernel(const float
 // that boundary up to
 //     eps >= |sum_k RN32(a_k / l1) - (sum_k a_k) / l1|  (<= 2^-24 of the sum)  +  the f32 group sums' rounding
 //            (<= 3 * 2^-24 of the sum)  +  the double roundings (< 2^-44),            sum <= 1 + 2^-15:
-// eps = 1.0625 * 2^-22.  The lane finds the run b* of 16 codewords whose boundaries bracket its threshold, recomputes THAT
-// run's 16 projections itself (the same fmaf chain the matrix instruction evaluates, codeword rows read from the staged
+// eps = 1.0625 * 2^-22.  The lane finds the run b* of 16 codewords whose boundaries bracket its threshold -- and, from the f32 sum
+// of the run's first eight terms kept beside P[], the half of it --, recomputes THAT half's 8 projections itself (the same fmaf chain the matrix instruction evaluates, codeword rows read from the staged
 // codebook at lane-dependent addresses: the rows of one in-run index lie d + 4 floats apart, sixteen runs on sixteen
 // different bank quartets) and walks them from P[b*-1] / l1 with the reference's own terms.  Every comparison of the walk
-// is made against T - eps and T + eps: when both agree for the start value and all 16 terms -- and the crossing is where the boundaries said -- the count
+// is made against T - eps and T + eps: when both agree for the start value and all 8 terms -- and the crossing is where the boundaries said -- the count
 // equals the exact walk's (the running sums never decrease).  Otherwise (one lane in ~2^-13, and every lane whose l1
 // or terms leave the range the three-operation quotient is proven for) the WAVE walks that lane's K codewords, four per
 // lane, with a prefix sum in double that is exact in any order (see there); a term-by-term walk by the lane alone, as
@@ -409,8 +409,10 @@ struct PwShape {
     static constexpr size_t LDS_BYTES = (size_t)(CB_FLOATS + ENC_WAVES * TILE_FLOATS) * sizeof(float);
 };
 
+// Registers: d <= 16 is held to three waves per SIMD (168 VGPRs; the allocator took 169 on its own: 144.8 against 148.1 us);
+// d = 32 needs its 200+ (held to three waves it spills: 175 against 129 us).
 template <typename CodeT, int D>
-__global__ __launch_bounds__(ENC_THREADS) void pvq_encode_walk_kernel(const float *__restrict__ grad,
+__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(D <= 16 ? 3 : 1))) void pvq_encode_walk_kernel(const float *__restrict__ grad,
                                                                      const float *__restrict__ cdag, int64_t M, int K,
                                                                      int random_mode, const float *__restrict__ r,
                                                                      uint64_t seed, CodeT *__restrict__ codes,
@@ -516,6 +518,7 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_walk_kernel(const floa
         // ---- sweep 1: l1 (sequential f32, the reference's sum) and the block boundaries' running sums in double
         float l1 = 0.0f;
         double P[16];
+        float S8[16];   // the first eight terms of every run of 16, as they entered the running sum
         {
             f32x4 xb0[KQ], xb1[KQ];
             const float *b0 = s_v + j * RS + h * HALF;
@@ -529,6 +532,7 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_walk_kernel(const floa
 #pragma unroll
             for (int rb = 0; rb < 8; ++rb) {
                 P[2 * rb] = P[2 * rb + 1] = INFINITY;
+                S8[2 * rb] = S8[2 * rb + 1] = 0.0f;
                 if (rb < nb) {
                     const float *arow = s_cb + (j & 15) * SI + (2 * rb + (j >> 4)) * RS + h * HALF;
                     f32x16 acc0 = {0}, acc1 = {0};
@@ -572,6 +576,7 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_walk_kernel(const floa
                                          ((fabsf(yv[4 * g]) + fabsf(yv[4 * g + 1])) + (fabsf(yv[4 * g + 2]) + fabsf(yv[4 * g + 3])));
                         run = run + (double)s8;
                         if (g & 1) P[2 * rb + (g >> 1)] = run;
+                        else S8[2 * rb + (g >> 1)] = s8;
                     }
                 }
             }
@@ -583,12 +588,21 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_walk_kernel(const floa
         // ---- the block whose boundaries bracket the threshold, and the walk's value at its start
         const double U = T * (double)l1;
         double startP = 0.0;
+        float mid = S8[0];
         int bstar = 0;
 #pragma unroll
         for (int b = 0; b < ((PVQ_DIAG & 64) ? 1 : 15); ++b) {
             const bool below = (b < 2 * nb - 1) && (P[b] < U);
             startP = below ? P[b] : startP;
+            mid = below ? S8[b + 1] : mid;
             bstar = below ? b + 1 : bstar;
+        }
+        // ... and the half of that run: the running sum after its first eight terms is startP + mid, as sweep 1 formed it
+        {
+            const double midP = startP + (double)mid;
+            const bool second = midP < U;
+            startP = second ? midP : startP;
+            bstar = 2 * bstar + (second ? 1 : 0);   // from here on: a run of EIGHT codewords
         }
         f32x4 ve[KQ], vo[KQ];
         {
@@ -606,8 +620,8 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_walk_kernel(const floa
         int cnt_lo = 0, cnt_hi = 0;
         float amin = INFINITY;
         {
-            // the run's 16 codeword rows, each fetched one projection ahead of its use
-            const float *crow = s_cb + bstar * RS;
+            // the run's 8 codeword rows, each fetched one projection ahead of its use
+            const float *crow = s_cb + (bstar >> 1) * RS + (bstar & 1) * 8 * SI;
             f32x4 ce[2][KQ], co[2][KQ];
             auto fetch_row = [&](int i, int buf) {
 #pragma unroll
@@ -618,8 +632,8 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_walk_kernel(const floa
             };
             fetch_row(0, 0);
 #pragma unroll
-            for (int i = 0; i < ((PVQ_DIAG & 1) ? 1 : 16); ++i) {
-                if (i + 1 < 16) fetch_row(i + 1, (i + 1) & 1);
+            for (int i = 0; i < ((PVQ_DIAG & 1) ? 1 : 8); ++i) {
+                if (i + 1 < 8) fetch_row(i + 1, (i + 1) & 1);
                 float acc = 0.0f;
 #pragma unroll
                 for (int k = 0; k < KQ; ++k) {
@@ -636,9 +650,9 @@ __global__ __launch_bounds__(ENC_THREADS) void pvq_encode_walk_kernel(const floa
                 cnt_hi += (cum < Thi) ? 1 : 0;
             }
         }
-        int count = bstar * 16 + cnt_lo;
+        int count = bstar * 8 + cnt_lo;
         bool settled = l1 >= 0x1p-80f && l1 <= 0x1p20f && amin >= 0x1p-102f && start_ok && cnt_lo == cnt_hi &&
-                       (cnt_lo < 16 || bstar == 2 * nb - 1);
+                       (cnt_lo < 8 || bstar == 4 * nb - 1);
         if (l1 == 0.0f) {   // an all-zero subvector: every term is 0 / 0, every comparison with NaN fails, all K terms count
             count = K;
             settled = true;
