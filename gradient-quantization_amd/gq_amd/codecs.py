@@ -744,14 +744,23 @@ class BatchedQSGD(_BatchedBase):
 
     takes_tail = True      # gq_qsgd_decode_sum_batched_tail (the library runs gq_mean_rows behind a decode path without the in-kernel form)
     WIDE_MIN = 4096
+    LONE_MIN = 256         # a tensor that is ONE bucket goes to the chunked kernels from here on (see is_wide)
 
     @staticmethod
     def eligible(codec):
         return type(codec) is QSGDCodec and codec.bits != 0
 
     @staticmethod
+    def is_wide(codec):
+        """The bucketed kernel gives a bucket to 16 lanes; above 256 elements those walk it twice, an element pair per lane
+        and trip.  Fine for the thousands of buckets of a bucketed tensor -- a latency chain for a tensor that IS one bucket
+        (TernGrad's 1,024 ... 4,096-element tensors: ~60 such buckets of the ResNet-50 list kept one launch busy for 100 us,
+        half of the step).  Those go with the wide ones, a chunk of 1,024 elements per wave."""
+        return codec.d > BatchedQSGD.WIDE_MIN or (codec.Mb == 1 and codec.d > BatchedQSGD.LONE_MIN)
+
+    @staticmethod
     def group_key(codec):
-        return (codec.bits, codec.c.bit, int(codec.d > BatchedQSGD.WIDE_MIN))
+        return (codec.bits, codec.c.bit, int(BatchedQSGD.is_wide(codec)))
 
     def __init__(self, codecs, offsets, idxs, device, slots, user_bytes, dense=None):
         self.idxs = list(idxs)
@@ -760,9 +769,8 @@ class BatchedQSGD(_BatchedBase):
         self.n_bit, self.bits, self.random = c0.c.bit, c0.bits, bool(c0.c.random)
         self.keyed = bool(self.random and c0.c._rng == "keyed")
         self.counter = bool(self.random and c0.c._rng == "device")
-        self.wide = c0.d > self.WIDE_MIN
-        assert all(cd.bits == self.bits and cd.c.bit == self.n_bit and (cd.d > self.WIDE_MIN) == self.wide
-                   for cd in self.codecs)
+        self.wide = self.is_wide(c0)
+        assert all(cd.bits == self.bits and cd.c.bit == self.n_bit and self.is_wide(cd) == self.wide for cd in self.codecs)
         nseg = len(self.idxs)
         table = torch.zeros((nseg, 8), dtype=torch.int64)
         item_seg = []
