@@ -739,12 +739,13 @@ class BatchedHSQ(_BatchedBase):
 
 class BatchedQSGD(_BatchedBase):
     """All packed-form QSGD tensors in ONE gq_qsgd_compress_batched / gq_qsgd_decode_sum_batched launch.
-    Tensors with WIDE buckets (TernGrad's `--c-dim 0`: the tensor is one bucket; any bucket above WIDE_MIN
-    elements) form their own group on the chunked kernels (gq_qsgd_wide_*: bucket norms, codes, decode)."""
+    Tensors with WIDE buckets (TernGrad's `--c-dim 0`: the tensor is one bucket; any bucket of WIDE_MIN elements
+    or more; see place_lone_buckets) form their own group on the chunked kernels (gq_qsgd_wide_*: bucket norms, codes, decode)."""
 
     takes_tail = True      # gq_qsgd_decode_sum_batched_tail (the library runs gq_mean_rows behind a decode path without the in-kernel form)
-    WIDE_MIN = 4096
-    LONE_MIN = 256         # a tensor that is ONE bucket goes to the chunked kernels from here on (see is_wide)
+    WIDE_MIN = 1024        # buckets from here on go to the chunked kernels (place_lone_buckets)
+    LONE_MIN = 256         # ... and a tensor that is ONE bucket may from here on
+    NARROW_MAX = 4096      # the largest bucket the bucketed kernel is asked to walk
 
     @staticmethod
     def eligible(codec):
@@ -752,15 +753,46 @@ class BatchedQSGD(_BatchedBase):
 
     @staticmethod
     def is_wide(codec):
-        """The bucketed kernel gives a bucket to 16 lanes; above 256 elements those walk it twice, an element pair per lane
-        and trip.  Fine for the thousands of buckets of a bucketed tensor -- a latency chain for a tensor that IS one bucket
-        (TernGrad's 1,024 ... 4,096-element tensors: ~60 such buckets of the ResNet-50 list kept one launch busy for 100 us,
-        half of the step).  Those go with the wide ones, a chunk of 1,024 elements per wave."""
-        return codec.d > BatchedQSGD.WIDE_MIN or (codec.Mb == 1 and codec.d > BatchedQSGD.LONE_MIN)
+        return bool(getattr(codec, "_wide", codec.d >= BatchedQSGD.WIDE_MIN))
 
     @staticmethod
     def group_key(codec):
         return (codec.bits, codec.c.bit, int(BatchedQSGD.is_wide(codec)))
+
+    @staticmethod
+    def place_lone_buckets(codecs):
+        """Which tensors go to the chunked (wide) kernels -- a chunk of 1,024 elements per wave, the bucket's max in a pass of
+        its own -- and which to the bucketed kernel, which gives a bucket to 16 lanes (in registers up to 256 elements; above
+        that the 16 lanes walk the bucket twice, an element pair per lane and trip):
+          * buckets of at least WIDE_MIN = 1,024 elements are wide (whole chunks; ResNet-50 at c_dim 2048: 0.092 against 0.112 ms
+            per step with the bucketed kernel's walk);
+          * a tensor that IS one bucket of more than 256 elements joins them when there are wide tensors of its code format
+            already, or two such tensors: for the bucketed kernel it is a latency chain, not throughput (TernGrad's
+            1,024 ... 4,096-element tensors, ~60 buckets of the ResNet-50 list, kept one launch busy for 100 us: half of the step);
+          * but a single wide tensor next to bucketed ones stays with them (up to 4,096 elements): a group of one is not
+            batched at all (c_dim 512: the one 1,728-element tensor cost 0.12 ms per step as a group of its own)."""
+        lone, wide, narrow = {}, {}, {}
+        for cd in codecs:
+            if not BatchedQSGD.eligible(cd):
+                continue
+            cd._wide = cd.d >= BatchedQSGD.WIDE_MIN
+            fmt = (cd.bits, cd.c.bit)
+            if cd._wide:
+                wide.setdefault(fmt, []).append(cd)
+            elif cd.Mb == 1 and cd.d > BatchedQSGD.LONE_MIN:
+                lone.setdefault(fmt, []).append(cd)
+            else:
+                narrow.setdefault(fmt, []).append(cd)
+        for fmt, cds in lone.items():
+            if fmt in wide or len(cds) >= 2:
+                for cd in cds:
+                    cd._wide = True
+                wide.setdefault(fmt, []).extend(cds)
+            else:
+                narrow.setdefault(fmt, []).extend(cds)
+        for fmt, cds in wide.items():
+            if len(cds) == 1 and narrow.get(fmt) and cds[0].d <= BatchedQSGD.NARROW_MAX:
+                cds[0]._wide = False
 
     def __init__(self, codecs, offsets, idxs, device, slots, user_bytes, dense=None):
         self.idxs = list(idxs)

@@ -114,6 +114,7 @@ class PSQuantizer(object):
         self.user_bytes = _up(off)          # one user's payload (all tensors)
         # tensors served by multi-tensor kernels: (class, parameter indices), built at the first record()
         self._groups = []
+        BatchedQSGD.place_lone_buckets(self.codecs)
         for cls in (BatchedHSQ, BatchedQSGD):
             keyed = {}
             for i, c in enumerate(self.codecs):
