@@ -257,7 +257,7 @@ GQ_API int gq_qsgd_compress_batched(const gq_qsgd_batch *b, uint8_t *wire, int r
         return gqi_qsgd_wide_compress(b->seg_table, b->item_seg, b->nseg, b->nitems, b->n_bit, random_mode, seed, ef, scale,
                                       b->norm_bits, wire, b->dense_table, b->ndense, stream);
     return gqi_qsgd_compress_batched(b->seg_table, b->item_seg, b->nseg, b->nitems, b->n_bit, random_mode, seed, ef, scale, wire,
-                                     b->dense_table, b->ndense, stream);
+                                     b->dense_table, b->ndense, b->bucket_hint, stream);
 }
 
 namespace gq {
@@ -270,7 +270,7 @@ static int qsgd_decode_sum_batched(const gq_qsgd_batch *b, const uint8_t *gather
         return gqi_qsgd_wide_decode_sum(b->seg_table, b->item_seg, b->nseg, b->nitems, b->n_bit, b->bits, gathered,
                                         user_stride_bytes, R, out, plain, stream);
     return gqi_qsgd_decode_sum_batched(b->seg_table, b->item_seg, b->nseg, b->nitems, b->n_bit, b->bits, gathered,
-                                       user_stride_bytes, R, out, plain, tail, tail_taken, stream);
+                                       user_stride_bytes, R, out, plain, tail, tail_taken, b->bucket_hint, stream);
 }
 }  // namespace gq
 

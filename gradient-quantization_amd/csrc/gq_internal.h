@@ -61,10 +61,11 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_any(const int64_t *seg_table, const i
 // QSGD on the packed wire (qsgd_batched.hip, qsgd_wide.hip)
 GQ_INTERNAL int gqi_qsgd_compress_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
                                           int n_bit, int random_mode, uint64_t seed, int ef, float ef_scale, uint8_t *wire, const int64_t *dense_table, int ndense,
-                                          void *stream);
+                                          int bucket_hint, void *stream);
 GQ_INTERNAL int gqi_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
                                             int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                            float *out, int plain, const gq::StepTail *tail_or_null, int *tail_taken, void *stream);
+                                            float *out, int plain, const gq::StepTail *tail_or_null, int *tail_taken, int bucket_hint,
+                                            void *stream);
 GQ_INTERNAL int gqi_qsgd_wide_compress(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks,
                                        int n_bit, int random_mode, uint64_t seed, int ef, float ef_scale,
                                        uint32_t *norm_bits, uint8_t *wire, const int64_t *dense_table, int ndense, void *stream);

@@ -111,7 +111,12 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
 // item is fetched an item ahead: looked up in global memory, bucket -> tensor -> record -> data is three dependent
 // round trips per item and the kernel was bound by that latency (41 us for the ResNet-50 list, the same with the
 // division taken out).
-template <bool EF, bool SEGLDS>
+// BITS: 4, 8 or 16 per code (round 5: the 8- and 16-bit wires, n_bit 3 ... 8, ran on the wave-per-bucket kernel above --
+// 0.114 against 0.064 ms per ResNet-50 step).  A lane's 8 codes are one dword, two or four.
+// LPB: lanes per bucket (16, 8 or 4: a wave takes 4, 8 or 16 buckets).  A bucket of d elements keeps d / 8 lanes busy: at the
+// reference's default --c-dim 32, 16 lanes per bucket left three quarters of every wave idle (0.158 ms per ResNet-50 step
+// against 0.064 at c_dim 128).  The launcher picks LPB from the descriptor's bucket-width hint; any LPB is correct for any d.
+template <bool EF, bool SEGLDS, int BITS = 4, int LPB = 16>
 __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int nseg, int64_t nbuckets, int n_bit,
     int random_mode, uint64_t seed, float ef_scale, uint8_t *__restrict__ wire, const int64_t *__restrict__ dense_table, int ndense) {
@@ -122,18 +127,21 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
         for (int i = threadIdx.x; i < nseg * 8; i += QB_THREADS) s_seg[i] = seg_table[i];
         __syncthreads();
     }
-    const int lane = threadIdx.x & 63, sub = lane >> 4, c0 = lane & 15;
+    constexpr int BPW = 64 / LPB;   // buckets per wave
+    const int lane = threadIdx.x & 63, sub = lane / LPB, c0 = lane & (LPB - 1);
+    constexpr unsigned LMASK = (1u << (BITS - 1)) - 1u;   // level bits of a code; the sign sits above them
+    constexpr int SB = BITS - 1;
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float s = (float)(1 << n_bit), smax = s - 1.0f, inv_s = 1.0f / s;
-    const int64_t nquads = (nbuckets + 3) >> 2;
+    const int64_t nquads = (nbuckets + BPW - 1) / BPW;
     int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int seg_next = (qd < nquads && 4 * qd + sub < nbuckets) ? bucket_seg[4 * qd + sub] : 0;
+    int seg_next = (qd < nquads && BPW * qd + sub < nbuckets) ? bucket_seg[BPW * qd + sub] : 0;
     for (; qd < nquads; qd += nw) {
-        const int64_t b = 4 * qd + sub;
+        const int64_t b = BPW * qd + sub;
         const bool live = b < nbuckets;
         const int seg = seg_next;
         {
-            const int64_t bn = 4 * (qd + nw) + sub;
+            const int64_t bn = BPW * (qd + nw) + sub;
             seg_next = (qd + nw < nquads && bn < nbuckets) ? bucket_seg[bn] : 0;   // the next item's tensor
         }
         int64_t recv[8];
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
         typedef f32x4 __attribute__((address_space(1))) *gv_ptr;
         const gf_ptr v = (gf_ptr)(uintptr_t)rec[0] + lb * d;
         const gf_ptr err = (EF && rec[7]) ? (gf_ptr)(uintptr_t)rec[7] + lb * d : (gf_ptr)0;
-        if (live && (d > 256 || (d & 7) != 0)) {
+        if (live && (d > 16 * LPB || (d & 7) != 0)) {
             // other bucket widths: the 16 lanes walk the bucket twice, an element pair at a time
             auto load = [&](int e) {
                 const v2f pv = *(gf2_ptr)(v + e);
@@ -171,23 +179,31 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
                 return p;
             };
             float m2 = 0.0f;
-            for (int e = 2 * c0; e < d; e += 32) {
+            for (int e = 2 * c0; e < d; e += 2 * LPB) {
                 const float2 p = load(e);
                 m2 = absmax3_nan(m2, p.x, p.y);   // NaN-propagating, like torch.max
             }
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) m2 = max_nan(m2, __shfl_xor(m2, o, 64));
+            for (int o = LPB / 2; o > 0; o >>= 1) m2 = max_nan(m2, __shfl_xor(m2, o, 64));
             if (c0 == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = m2;
-            uint8_t *dst2 = wire + rec[4] + ((lb * d) >> 1);
+            uint8_t *dst2 = wire + rec[4] + ((lb * d * BITS) >> 3);
             const uint64_t sd2 = random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, m2, m2) : seed;
-            for (int e = 2 * c0; e < d; e += 32) {
+            for (int e = 2 * c0; e < d; e += 2 * LPB) {
                 const float2 p = load(e);
-                const unsigned k0 = qsgd_code(p.x, m2, s, smax, random_mode, sd2, ((uint64_t)b << 20) + e, 4);
-                const unsigned k1 = qsgd_code(p.y, m2, s, smax, random_mode, sd2, ((uint64_t)b << 20) + e + 1, 4);
-                dst2[e >> 1] = (uint8_t)(k0 | (k1 << 4));
+                const unsigned k0 = qsgd_code(p.x, m2, s, smax, random_mode, sd2, ((uint64_t)b << 20) + e, BITS);
+                const unsigned k1 = qsgd_code(p.y, m2, s, smax, random_mode, sd2, ((uint64_t)b << 20) + e + 1, BITS);
+                if (BITS == 4) {
+                    dst2[e >> 1] = (uint8_t)(k0 | (k1 << 4));
+                } else if (BITS == 8) {
+                    dst2[e] = (uint8_t)k0;
+                    dst2[e + 1] = (uint8_t)k1;
+                } else {
+                    reinterpret_cast<uint16_t *>(dst2)[e] = (uint16_t)k0;
+                    reinterpret_cast<uint16_t *>(dst2)[e + 1] = (uint16_t)k1;
+                }
                 if (EF && err) {
-                    float t0 = (float)(k0 & 7u) * (2.0f * (float)(k0 >> 3) - 1.0f);
-                    float t1 = (float)(k1 & 7u) * (2.0f * (float)(k1 >> 3) - 1.0f);
+                    float t0 = (float)(k0 & LMASK) * (2.0f * (float)(k0 >> SB) - 1.0f);
+                    float t1 = (float)(k1 & LMASK) * (2.0f * (float)(k1 >> SB) - 1.0f);
                     t0 = t0 * m2;
                     t1 = t1 * m2;
                     t0 = t0 * inv_s;
@@ -198,12 +214,12 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
             }
             continue;   // (the other buckets of this wave take the register path below on their own lanes)
         }
-        // chunk j of this lane covers elements [8 (c0 + 16 j), + 8)
+        // chunk j of this lane covers elements [8 (c0 + LPB j), + 8)
         f32x4 x[2][2];
         float mx = 0.0f;
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc) {
-            const int e = 8 * (c0 + 16 * jc);
+            const int e = 8 * (c0 + LPB * jc);
             if (e < d) {
                 x[jc][0] = *(gv_ptr)(v + e);
                 x[jc][1] = *(gv_ptr)(v + e + 4);
@@ -218,30 +234,41 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
             }
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) mx = max_nan(mx, __shfl_xor(mx, o, 64));   // the bucket's 16 lanes
+        for (int o = LPB / 2; o > 0; o >>= 1) mx = max_nan(mx, __shfl_xor(mx, o, 64));   // the bucket's LPB lanes
         if (live && c0 == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = mx;
         const uint64_t g0 = (uint64_t)b << 20;  // RNG stream index: unique per (bucket, element)
         const uint64_t sd = random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, mx, mx) : seed;   // keyed by the bucket's norm
-        uint8_t *dst = wire + rec[4] + ((lb * d) >> 1);
+        uint8_t *dst = wire + rec[4] + ((lb * d * BITS) >> 3);
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc) {
-            const int e = 8 * (c0 + 16 * jc);
+            const int e = 8 * (c0 + LPB * jc);
             if (e < d) {
-                unsigned word = 0;
+                unsigned code[8];
                 f32x4 dec[2];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const float val = x[jc][k >> 2][k & 3];
-                    const unsigned c = qsgd_code(val, mx, s, smax, random_mode, sd, g0 + e + k, 4);
-                    word |= c << (4 * k);
+                    const unsigned c = qsgd_code(val, mx, s, smax, random_mode, sd, g0 + e + k, BITS);
+                    code[k] = c;
                     if (EF) {
                         // qsgd_compressor.py:69-70 on this element's own code (sign on the float's sign bit)
-                        float t = __uint_as_float(__float_as_uint((float)(c & 7u)) | (((c >> 3) ^ 1u) << 31));
+                        float t = __uint_as_float(__float_as_uint((float)(c & LMASK)) | (((c >> SB) ^ 1u) << 31));
                         t = t * mx;
                         dec[k >> 2][k & 3] = t * inv_s;
                     }
                 }
-                *reinterpret_cast<unsigned *>(dst + 4 * (c0 + 16 * jc)) = word;
+                if (BITS == 4) {
+                    unsigned word = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) word |= code[k] << (4 * k);
+                    *reinterpret_cast<unsigned *>(dst + 4 * (c0 + LPB * jc)) = word;
+                } else if (BITS == 8) {
+                    *reinterpret_cast<uint2 *>(dst + e) = make_uint2(code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24),
+                                                                     code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24));
+                } else {
+                    *reinterpret_cast<uint4 *>(dst + 2 * e) = make_uint4(code[0] | (code[1] << 16), code[2] | (code[3] << 16),
+                                                                         code[4] | (code[5] << 16), code[6] | (code[7] << 16));
+                }
                 if (EF && err) {
                     *(gv_ptr)(v + e) = x[jc][0];
                     *(gv_ptr)(v + e + 4) = x[jc][1];
@@ -396,21 +423,58 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_kernel(
 // not a multiple of 8 finish through the plain code inside the item.
 constexpr int QB4_RMAX = 8;
 
-template <int R>
+// (+-level) as a float: the sign bit of the code is 1 for positive values, applied to the float's sign bit (a zero level
+// with a cleared sign bit decodes to -0 like the reference's 0 * -1); a lane's unit of 8 codes is BITS / 4 dwords, codes in
+// ascending element order from the low end
+// ... of code k of a unit, straight from the unit's dwords `w` and their complements `nw` (two bit-field extracts per element)
+template <int BITS>
+__device__ __forceinline__ float unit_signed_level(const unsigned (&w)[BITS / 4], const unsigned (&nw)[BITS / 4], int k) {
+    constexpr int PER = 32 / BITS;   // codes per dword
+    const int word = k / PER, sh = BITS * (k % PER);
+    const float lf = (float)((w[word] >> sh) & ((1u << (BITS - 1)) - 1u));
+    const unsigned sgn = (nw[word] >> (sh + BITS - 1)) & 1u;          // 1: negative
+    return __uint_as_float(__float_as_uint(lf) | (sgn << 31));
+}
+template <int BITS>
+__device__ __forceinline__ void load_unit(const uint8_t *p, unsigned (&w)[BITS / 4]) {
+    if (BITS == 4) {
+        w[0] = *reinterpret_cast<const unsigned *>(p);
+    } else if (BITS == 8) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p);
+        w[0] = v.x;
+        w[BITS == 8 ? 1 : 0] = v.y;
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p);
+        w[0] = v.x;
+        w[BITS == 16 ? 1 : 0] = v.y;
+        w[BITS == 16 ? 2 : 0] = v.z;
+        w[BITS == 16 ? 3 : 0] = v.w;
+    }
+}
+
+template <int R, int BITS = 4, int LPBL = -1>   // LPBL: log2 of the lanes per bucket when it is known at compile time (16: the 4-bit wire's common case)
 __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_r_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ bucket_seg, int64_t nbuckets, int nseg, int n_bit,
-    const uint8_t *__restrict__ gathered, int64_t user_stride, float *__restrict__ out, int plain, const StepTail tail) {
+    const uint8_t *__restrict__ gathered, int64_t user_stride, float *__restrict__ out, int plain, const StepTail tail, int lpb_log2) {
     __shared__ int64_t s_seg[QB_LDS_SEGS * 8];
     step_tail_run(tail);      // the aggregate's small per-step work (gq_qsgd_decode_sum_batched_tail)
     for (int i = threadIdx.x; i < nseg * 8; i += QB_THREADS) s_seg[i] = seg_table[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63, sub = lane >> 4, c0 = lane & 15;
+    // lanes per bucket (16, 8 or 4; qsgd_compress_batched4_kernel's LPB): here it only moves indices, a kernel argument
+    const int lpbl = LPBL >= 0 ? LPBL : lpb_log2;
+    const int lpb = 1 << lpbl, bpw = 64 >> lpbl;
+    const int lane = threadIdx.x & 63, sub = lane >> lpbl, c0 = lane & (lpb - 1);
     const int64_t nw = (int64_t)gridDim.x * (QB_THREADS / 64);
     const float inv_s = 1.0f / (float)(1 << n_bit);
     const MeanDiv md = mean_div_of(R, !plain);
-    const int64_t nquads = (nbuckets + 3) >> 2;
+    const int64_t nquads = (nbuckets + bpw - 1) / bpw;
     typedef const uint8_t __attribute__((address_space(1))) gbyte;
     typedef const unsigned __attribute__((address_space(1))) gword;
+    typedef unsigned uv2 __attribute__((ext_vector_type(2)));
+    typedef unsigned uv4 __attribute__((ext_vector_type(4)));
+    typedef const uv2 __attribute__((address_space(1))) gword2;
+    typedef const uv4 __attribute__((address_space(1))) gword4;
+    constexpr int W = BITS / 4;   // dwords of a lane's unit of 8 codes
     typedef const float __attribute__((address_space(1))) gfloat;
     const uint64_t wire0 = reinterpret_cast<uint64_t>(gathered);
     struct Item {
@@ -421,7 +485,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_r_kernel(
         int seg;
     };
     auto bucket_of = [&](int64_t qd) {   // lanes past the last bucket redo it (nothing is stored for them)
-        const int64_t b = 4 * qd + sub;
+        const int64_t b = (int64_t)bpw * qd + sub;
         return b < nbuckets ? b : nbuckets - 1;
     };
     auto item_of = [&](int64_t b, int seg) {
@@ -431,17 +495,29 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_r_kernel(
         it.d = (int)rec[1];
         it.lb = b - rec[2];
         it.norm_off = (unsigned)(rec[3] + 4 * it.lb);
-        it.code_off = (unsigned)(rec[4] + ((it.lb * it.d) >> 1) + 4 * c0);
+        it.code_off = (unsigned)(rec[4] + ((it.lb * it.d * BITS) >> 3) + BITS * c0);
         it.out_off = rec[5] + it.lb * it.d + 8 * c0;
         return it;
     };
-    unsigned w[R];
+    unsigned w[R][W];
     float nm[R];
     auto request = [&](const Item &it, unsigned guard, int r) {
         const uint64_t base = wire0 + (uint64_t)r * (uint64_t)user_stride;
         // a lane without a unit in this bucket (8 * c0 >= d) reads the bucket's first word instead of one past its codes
-        const unsigned co = (8 * c0 < it.d ? it.code_off : it.code_off - 4u * (unsigned)c0) + guard;
-        w[r] = *reinterpret_cast<gword *>(reinterpret_cast<gbyte *>(base) + co);
+        const unsigned co = (8 * c0 < it.d ? it.code_off : it.code_off - (unsigned)BITS * (unsigned)c0) + guard;
+        if constexpr (BITS == 4) {
+            w[r][0] = *reinterpret_cast<gword *>(reinterpret_cast<gbyte *>(base) + co);
+        } else if constexpr (BITS == 8) {
+            const uv2 v = *reinterpret_cast<gword2 *>(reinterpret_cast<gbyte *>(base) + co);
+            w[r][0] = v[0];
+            w[r][1] = v[1];
+        } else {
+            const uv4 v = *reinterpret_cast<gword4 *>(reinterpret_cast<gbyte *>(base) + co);
+            w[r][0] = v[0];
+            w[r][1] = v[1];
+            w[r][2] = v[2];
+            w[r][3] = v[3];
+        }
         nm[r] = *reinterpret_cast<gfloat *>(reinterpret_cast<gbyte *>(base) + (it.norm_off + guard));
     };
     int64_t qd = (int64_t)blockIdx.x * (QB_THREADS / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -455,16 +531,16 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_r_kernel(
         const int64_t q2 = qn + nw < nquads ? qn + nw : qn;
         const int seg_2 = bucket_seg[bucket_of(q2)];            // consumed a whole item later
         const Item nxt = item_of(bucket_of(qn), seg_n);
-        const bool mine = 4 * qd + sub < nbuckets;
+        const bool mine = (int64_t)bpw * qd + sub < nbuckets;
         f32x4 acc[2];
         unsigned guard = 0;
-        auto payload = [&](unsigned ww, float norm, auto first) {
-            const unsigned nw_ = ~ww;
+        auto payload = [&](const unsigned (&ww)[W], float norm, auto first) {
+            unsigned nww[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) nww[i] = ~ww[i];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float lf = (float)((ww >> (4 * k)) & 7u);
-                const unsigned sgn = (nw_ >> (4 * k + 3)) & 1u;          // 1: negative
-                float t = __uint_as_float(__float_as_uint(lf) | (sgn << 31));
+                float t = unit_signed_level<BITS>(ww, nww, k);
                 t = t * norm;
                 t = t * inv_s;
                 if constexpr (decltype(first)::value) {
@@ -495,19 +571,19 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_r_kernel(
                 *reinterpret_cast<f32x4 *>(o) = acc[0];
                 *reinterpret_cast<f32x4 *>(o + 4) = acc[1];
             }
-            if (cur.d > 128 && mine) {   // further units of a wide bucket: the plain form
-                for (int c = c0 + 16; 8 * c < cur.d; c += 16) {
+            if (cur.d > 8 * lpb && mine) {   // further units of a wide bucket: the plain form
+                for (int c = c0 + lpb; 8 * c < cur.d; c += lpb) {
                     f32x4 a2[2];
                     for (int r = 0; r < R; ++r) {
                         const uint8_t *p = gathered + (int64_t)r * user_stride;
                         const float norm = *reinterpret_cast<const float *>(p + cur.norm_off);
-                        const unsigned ww = *reinterpret_cast<const unsigned *>(p + cur.code_off + 4 * (c - c0));
-                        const unsigned nw_ = ~ww;
+                        unsigned ww[W], nww[W];
+                        load_unit<BITS>(p + cur.code_off + BITS * (c - c0), ww);
+#pragma unroll
+                        for (int i = 0; i < W; ++i) nww[i] = ~ww[i];
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
-                            const float lf = (float)((ww >> (4 * k)) & 7u);
-                            const unsigned sgn = (nw_ >> (4 * k + 3)) & 1u;
-                            float t = __uint_as_float(__float_as_uint(lf) | (sgn << 31));
+                            float t = unit_signed_level<BITS>(ww, nww, k);
                             t = t * norm;
                             t = t * inv_s;
                             a2[k >> 2][k & 3] = r == 0 ? t : a2[k >> 2][k & 3] + t;
@@ -522,17 +598,28 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_r_kernel(
                 }
             }
         } else if (mine) {   // odd bucket widths: an element pair (one byte) at a time, as in the kernel above
-            const int64_t code0 = (int64_t)cur.code_off - 4 * c0;
+            const int64_t code0 = (int64_t)cur.code_off - BITS * c0;
             float *ob = o - 8 * c0;
-            for (int e = 2 * c0; e < cur.d; e += 32) {
+            for (int e = 2 * c0; e < cur.d; e += 2 * lpb) {
                 float a0 = 0.0f, a1 = 0.0f;
                 for (int r = 0; r < R; ++r) {
                     const uint8_t *p = gathered + (int64_t)r * user_stride;
                     const float norm = *reinterpret_cast<const float *>(p + cur.norm_off);
-                    const unsigned byte = p[code0 + (e >> 1)];
-                    const unsigned c0_ = byte & 15u, c1_ = byte >> 4;
-                    float t0 = (float)(c0_ & 7u) * (2.0f * (float)(c0_ >> 3) - 1.0f);
-                    float t1 = (float)(c1_ & 7u) * (2.0f * (float)(c1_ >> 3) - 1.0f);
+                    unsigned c0_, c1_;
+                    if (BITS == 4) {
+                        const unsigned byte = p[code0 + (e >> 1)];
+                        c0_ = byte & 15u;
+                        c1_ = byte >> 4;
+                    } else if (BITS == 8) {
+                        c0_ = p[code0 + e];
+                        c1_ = p[code0 + e + 1];
+                    } else {
+                        c0_ = reinterpret_cast<const uint16_t *>(p + code0)[e];
+                        c1_ = reinterpret_cast<const uint16_t *>(p + code0)[e + 1];
+                    }
+                    constexpr unsigned LM = (1u << (BITS - 1)) - 1u;
+                    float t0 = (float)(c0_ & LM) * (2.0f * (float)(c0_ >> (BITS - 1)) - 1.0f);
+                    float t1 = (float)(c1_ & LM) * (2.0f * (float)(c1_ >> (BITS - 1)) - 1.0f);
                     t0 = t0 * norm;
                     t1 = t1 * norm;
                     t0 = t0 * inv_s;
@@ -555,9 +642,9 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_decode_sum_batched4_r_kernel(
     }
 }
 
-template <int R>
+template <int R, int BITS>
 static void launch_qb4_r(const int64_t *seg_table, const int32_t *bucket_seg, int64_t nbuckets, int nseg, int n_bit,
-                         const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st, const StepTail &tail);
+                         const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st, const StepTail &tail, int lpb_log2);
 
 // One resident wave of workgroups for `kernel` (the occupancy API) instead of a fixed 8 per CU: the 4-bit compress kernel
 // holds 5-6 waves per SIMD (74-84 registers), so a quarter of an 8-per-CU grid queued behind the resident workgroups.
@@ -585,20 +672,36 @@ static inline int64_t qb_grid(int64_t nbuckets) {
     return blocks < 1 ? 1 : blocks;
 }
 
-template <int R>
+template <int R, int BITS>
 static void launch_qb4_r(const int64_t *seg_table, const int32_t *bucket_seg, int64_t nbuckets, int nseg, int n_bit,
-                         const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st, const StepTail &tail) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_decode_sum_batched4_r_kernel<R>),
-                       dim3((unsigned)qb_grid_resident(qsgd_decode_sum_batched4_r_kernel<R>, (nbuckets + 3) / 4)),
-                       dim3(QB_THREADS), 0, st, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride, out, plain, tail);
+                         const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st, const StepTail &tail, int lpb_log2) {
+    const int bpw = 64 >> lpb_log2;
+    if (BITS == 4 && lpb_log2 == 4) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_decode_sum_batched4_r_kernel<R, BITS, 4>),
+                           dim3((unsigned)qb_grid_resident(qsgd_decode_sum_batched4_r_kernel<R, BITS, 4>, (nbuckets + bpw - 1) / bpw)),
+                           dim3(QB_THREADS), 0, st, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride, out, plain, tail, lpb_log2);
+        return;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_decode_sum_batched4_r_kernel<R, BITS>),
+                       dim3((unsigned)qb_grid_resident(qsgd_decode_sum_batched4_r_kernel<R, BITS>, (nbuckets + bpw - 1) / bpw)),
+                       dim3(QB_THREADS), 0, st, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride, out, plain, tail, lpb_log2);
 }
 
+// lanes per bucket for a bucket-width hint: d / 8 lanes, a power of two between 4 and 16 (log2)
+static inline int lpb_log2_of(int bucket_hint) {
+    if (bucket_hint > 0 && bucket_hint <= 32) return 2;
+    if (bucket_hint > 0 && bucket_hint <= 64) return 3;
+    return 4;
+}
+
+template <int BITS>
 static bool launch_qb4_fixed_r(int R, const int64_t *seg_table, const int32_t *bucket_seg, int64_t nbuckets, int nseg, int n_bit,
-                               const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st, const StepTail &tail) {
+                               const uint8_t *gathered, int64_t user_stride, float *out, int plain, hipStream_t st, const StepTail &tail,
+                               int lpb_log2) {
     // byte offsets inside a payload are 32-bit in this kernel, the table sits in LDS
     if (nseg > QB_LDS_SEGS || user_stride >= ((int64_t)1 << 31)) return false;
     switch (R) {
-#define GQ_QB4_CASE(N) case N: launch_qb4_r<N>(seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride, out, plain, st, tail); return true;
+#define GQ_QB4_CASE(N) case N: launch_qb4_r<N, BITS>(seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride, out, plain, st, tail, lpb_log2); return true;
         GQ_QB4_CASE(1) GQ_QB4_CASE(2) GQ_QB4_CASE(3) GQ_QB4_CASE(4)
         GQ_QB4_CASE(5) GQ_QB4_CASE(6) GQ_QB4_CASE(7) GQ_QB4_CASE(8)
 #undef GQ_QB4_CASE
@@ -621,7 +724,7 @@ namespace gq {
 template <bool EF>
 static int qsgd_compress_batched(const char *what, const int64_t *seg_table, const int32_t *bucket_seg, int nseg,
                                  int64_t nbuckets, int n_bit, int random_mode, uint64_t seed, float ef_scale,
-                                 uint8_t *wire, const int64_t *dense_table, int ndense, void *stream) {
+                                 uint8_t *wire, const int64_t *dense_table, int ndense, int bucket_hint, void *stream) {
     if (nseg < 1 || nbuckets < 1 || n_bit < 1) return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes", what);
     if (!seg_table || !bucket_seg || !wire) return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
     if (random_mode != GQ_RANDOM_OFF && random_mode != GQ_RANDOM_DEVICE && random_mode != GQ_RANDOM_DEVICE_KEYED &&
@@ -629,11 +732,27 @@ static int qsgd_compress_batched(const char *what, const int64_t *seg_table, con
         return fail(GQ_ERR_UNSUPPORTED, "%s: random_mode must be OFF, DEVICE, DEVICE_KEYED or DEVICE_COUNTER", what);
     const int bits = gq_qsgd_code_bits(n_bit, random_mode);
     if (!bits) return fail(GQ_ERR_UNSUPPORTED, "%s: n_bit %d has no packed format", what, n_bit);
+    const int lpb_log2 = lpb_log2_of(bucket_hint);
+#define GQ_QC_LAUNCH(BITSV, LPBV)                                                                                                     \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched4_kernel<EF, true, BITSV, LPBV>),                                         \
+                       dim3((unsigned)qb_grid_resident(qsgd_compress_batched4_kernel<EF, true, BITSV, LPBV>,                          \
+                                                       (nbuckets + 64 / LPBV - 1) / (64 / LPBV))),                                   \
+                       dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nseg, nbuckets, n_bit, random_mode, seed,      \
+                       ef_scale, wire, dense_table, ndense)
+#define GQ_QC_BITS(BITSV)                                  \
+    do {                                                   \
+        if (lpb_log2 == 2) GQ_QC_LAUNCH(BITSV, 4);         \
+        else if (lpb_log2 == 3) GQ_QC_LAUNCH(BITSV, 8);    \
+        else GQ_QC_LAUNCH(BITSV, 16);                      \
+    } while (0)
     if (bits == 4 && nseg <= QB_LDS_SEGS) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched4_kernel<EF, true>),
-                           dim3((unsigned)qb_grid_resident(qsgd_compress_batched4_kernel<EF, true>, (nbuckets + 3) / 4)),
-                           dim3(QB_THREADS), 0, as_stream(stream), seg_table, bucket_seg, nseg, nbuckets, n_bit,
-                           random_mode, seed, ef_scale, wire, dense_table, ndense);
+        GQ_QC_BITS(4);
+    } else if (bits == 8 && nseg <= QB_LDS_SEGS) {
+        GQ_QC_BITS(8);
+    } else if (bits == 16 && nseg <= QB_LDS_SEGS) {
+        GQ_QC_BITS(16);
+#undef GQ_QC_BITS
+#undef GQ_QC_LAUNCH
     } else if (bits == 4) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(qsgd_compress_batched4_kernel<EF, false>),
                            dim3((unsigned)qb_grid_resident(qsgd_compress_batched4_kernel<EF, false>, (nbuckets + 3) / 4)),
@@ -651,18 +770,20 @@ static int qsgd_compress_batched(const char *what, const int64_t *seg_table, con
 
 GQ_INTERNAL int gqi_qsgd_compress_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
                                           int n_bit, int random_mode, uint64_t seed, int ef, float ef_scale, uint8_t *wire, const int64_t *dense_table, int ndense,
-                                          void *stream) {
+                                          int bucket_hint, void *stream) {
     if (ef)
         return gq::qsgd_compress_batched<true>("gq_qsgd_compress_batched", seg_table, bucket_seg, nseg, nbuckets, n_bit,
-                                               random_mode, seed, ef_scale, wire, dense_table, ndense, stream);
+                                               random_mode, seed, ef_scale, wire, dense_table, ndense, bucket_hint, stream);
     return gq::qsgd_compress_batched<false>("gq_qsgd_compress_batched", seg_table, bucket_seg, nseg, nbuckets, n_bit,
-                                            random_mode, seed, 0.0f, wire, dense_table, ndense, stream);
+                                            random_mode, seed, 0.0f, wire, dense_table, ndense, bucket_hint, stream);
 }
 
 GQ_INTERNAL int gqi_qsgd_decode_sum_batched(const int64_t *seg_table, const int32_t *bucket_seg, int nseg, int64_t nbuckets,
                                             int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                            float *out, int plain, const gq::StepTail *tail_or_null, int *tail_taken, void *stream) {
+                                            float *out, int plain, const gq::StepTail *tail_or_null, int *tail_taken, int bucket_hint,
+                                            void *stream) {
     plain = plain ? 1 : 0;
+    const int lpb_log2 = gq::lpb_log2_of(bucket_hint);
     if (tail_taken) *tail_taken = 0;
     if (nseg < 1 || nbuckets < 1 || n_bit < 1 || R < 1 || (bits != 4 && bits != 8 && bits != 16))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: bad sizes");
@@ -670,8 +791,8 @@ GQ_INTERNAL int gqi_qsgd_decode_sum_batched(const int64_t *seg_table, const int3
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched: null pointer");
     if (bits == 4 && (user_stride_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-        if (gq::launch_qb4_fixed_r(R, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride_bytes, out, plain,
-                                   gq::as_stream(stream), tail_or_null ? *tail_or_null : gq::StepTail{})) {
+        if (gq::launch_qb4_fixed_r<4>(R, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride_bytes, out, plain,
+                                      gq::as_stream(stream), tail_or_null ? *tail_or_null : gq::StepTail{}, lpb_log2)) {
             GQ_CHECK_LAUNCH("gq_qsgd_decode_sum_batched");
             if (tail_taken) *tail_taken = 1;
             return GQ_OK;
@@ -679,6 +800,16 @@ GQ_INTERNAL int gqi_qsgd_decode_sum_batched(const int64_t *seg_table, const int3
         hipLaunchKernelGGL(gq::qsgd_decode_sum_batched4_kernel, dim3((unsigned)gq::qb_grid((nbuckets + 3) / 4)),
                            dim3(gq::QB_THREADS), 0, gq::as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit,
                            gathered, user_stride_bytes, R, out, plain);
+    } else if (bits != 4 && (user_stride_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(gathered) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+               (bits == 8 ? gq::launch_qb4_fixed_r<8>(R, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride_bytes, out,
+                                                     plain, gq::as_stream(stream), tail_or_null ? *tail_or_null : gq::StepTail{}, lpb_log2)
+                          : gq::launch_qb4_fixed_r<16>(R, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride_bytes, out,
+                                                      plain, gq::as_stream(stream), tail_or_null ? *tail_or_null : gq::StepTail{}, lpb_log2))) {
+        // the 16-lanes-per-bucket kernel on 8- / 16-bit codes (R <= 8, the table in LDS); everything else: the generic kernel below
+        GQ_CHECK_LAUNCH("gq_qsgd_decode_sum_batched");
+        if (tail_taken) *tail_taken = 1;
+        return GQ_OK;
     } else {
         hipLaunchKernelGGL(gq::qsgd_decode_sum_batched_kernel, dim3((unsigned)gq::qb_grid(nbuckets)),
                            dim3(gq::QB_THREADS), 0, gq::as_stream(stream), seg_table, bucket_seg, nbuckets, n_bit, bits,

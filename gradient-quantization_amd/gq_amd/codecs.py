@@ -827,9 +827,15 @@ class BatchedQSGD(_BatchedBase):
         # wide: max |v| per bucket is folded into words that the per-step header resets to zero
         extra = torch.zeros((word + 1) // 2, dtype=torch.int64) if self.wide else None
         self._setup(table, extra, device, slots, user_bytes, dense)
+        # the bucket width most elements have: the bucketed kernels give a bucket d / 8 lanes (4 ... 16)
+        by_width = {}
+        for cd in self.codecs:
+            by_width[cd.d] = by_width.get(cd.d, 0) + cd.numel
+        hint = 0 if self.wide else max(by_width, key=by_width.get)
         self._batch = native.QSGDBatch(self._dev[:self._table_words], self.bucket_seg, self.nseg, self.nbuckets, self.n_bit,
                                        self.bits, self.wide,
-                                       self._dev[self._table_words:self._dense_at].view(torch.int32) if self.wide else None)
+                                       self._dev[self._table_words:self._dense_at].view(torch.int32) if self.wide else None,
+                                       bucket_hint=hint)
 
     def graphable(self):
         """The compress launch takes a fresh seed per record when it rounds stochastically: only the deterministic form

@@ -439,7 +439,7 @@ def rng_step(rng_state, reset=None):
 
 class _QSGDBatchStruct(ctypes.Structure):     # gq_qsgd_batch (include/gq_hsq.h)
     _fields_ = [("struct_bytes", ctypes.c_uint32), ("n_bit", ctypes.c_int32), ("bits", ctypes.c_int32),
-                ("wide", ctypes.c_int32), ("nseg", ctypes.c_int32), ("reserved", ctypes.c_int32), ("nitems", ctypes.c_int64),
+                ("wide", ctypes.c_int32), ("nseg", ctypes.c_int32), ("bucket_hint", ctypes.c_int32), ("nitems", ctypes.c_int64),
                 ("seg_table", ctypes.c_void_p), ("item_seg", ctypes.c_void_p), ("norm_bits", ctypes.c_void_p),
                 ("dense_table", ctypes.c_void_p), ("ndense", ctypes.c_int32), ("reserved2", ctypes.c_int32)]
 
@@ -447,10 +447,11 @@ class _QSGDBatchStruct(ctypes.Structure):     # gq_qsgd_batch (include/gq_hsq.h)
 class QSGDBatch(object):
     """The multi-tensor QSGD launches on the packed wire (buckets, or chunks of wide buckets: `wide`)."""
 
-    def __init__(self, seg_table, item_seg, nseg, nitems, n_bit, bits, wide=False, norm_bits=None):
+    def __init__(self, seg_table, item_seg, nseg, nitems, n_bit, bits, wide=False, norm_bits=None, bucket_hint=0):
+        """bucket_hint: the bucket width most elements have (0: unknown) -- picks the lanes the bucketed kernels give a bucket."""
         self.L = lib()
         self.keep = (seg_table, item_seg, norm_bits)
-        self.s = _QSGDBatchStruct(ctypes.sizeof(_QSGDBatchStruct), int(n_bit), int(bits), 1 if wide else 0, int(nseg), 0,
+        self.s = _QSGDBatchStruct(ctypes.sizeof(_QSGDBatchStruct), int(n_bit), int(bits), 1 if wide else 0, int(nseg), int(bucket_hint),
                                   int(nitems), _dev_ptr(seg_table, torch.int64, "seg_table").value,
                                   _dev_ptr(item_seg, torch.int32, "item_seg").value,
                                   _dev_ptr(norm_bits, torch.int32, "norm_bits").value if norm_bits is not None else None, None, 0, 0)
@@ -468,7 +469,7 @@ class QSGDBatch(object):
         self.s.ndense = int(ndense) if dense_table is not None else 0
 
     def part(self, seg_table, item_seg, nseg, nitems):
-        return QSGDBatch(seg_table, item_seg, nseg, nitems, self.s.n_bit, self.s.bits, bool(self.s.wide), self.keep[2])
+        return QSGDBatch(seg_table, item_seg, nseg, nitems, self.s.n_bit, self.s.bits, bool(self.s.wide), self.keep[2], self.s.bucket_hint)
 
     def compress(self, wire, random_mode, seed, ef_scale=None):
         """ef_scale given: error feedback in the same pass (seg_table[:, 7] = error buffers)."""
