@@ -113,7 +113,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
 // division taken out).
 // BITS: 4, 8 or 16 per code (round 5: the 8- and 16-bit wires, n_bit 3 ... 8, ran on the wave-per-bucket kernel above --
 // 0.114 against 0.064 ms per ResNet-50 step).  A lane's 8 codes are one dword, two or four.
-// LPB: lanes per bucket (16, 8 or 4: a wave takes 4, 8 or 16 buckets).  A bucket of d elements keeps d / 8 lanes busy: at the
+// LPB: lanes per bucket (16, 8, 4 or 2: a wave takes 4 ... 32 buckets).  A bucket of d elements keeps d / 8 lanes busy: at the
 // reference's default --c-dim 32, 16 lanes per bucket left three quarters of every wave idle (0.158 ms per ResNet-50 step
 // against 0.064 at c_dim 128).  The launcher picks LPB from the descriptor's bucket-width hint; any LPB is correct for any d.
 template <bool EF, bool SEGLDS, int BITS = 4, int LPB = 16>
@@ -687,8 +687,9 @@ static void launch_qb4_r(const int64_t *seg_table, const int32_t *bucket_seg, in
                        dim3(QB_THREADS), 0, st, seg_table, bucket_seg, nbuckets, nseg, n_bit, gathered, user_stride, out, plain, tail, lpb_log2);
 }
 
-// lanes per bucket for a bucket-width hint: d / 8 lanes, a power of two between 4 and 16 (log2)
+// lanes per bucket for a bucket-width hint: d / 8 lanes, a power of two between 2 and 16 (log2)
 static inline int lpb_log2_of(int bucket_hint) {
+    if (bucket_hint > 0 && bucket_hint <= 16) return 1;
     if (bucket_hint > 0 && bucket_hint <= 32) return 2;
     if (bucket_hint > 0 && bucket_hint <= 64) return 3;
     return 4;
@@ -741,7 +742,8 @@ static int qsgd_compress_batched(const char *what, const int64_t *seg_table, con
                        ef_scale, wire, dense_table, ndense)
 #define GQ_QC_BITS(BITSV)                                  \
     do {                                                   \
-        if (lpb_log2 == 2) GQ_QC_LAUNCH(BITSV, 4);         \
+        if (lpb_log2 == 1) GQ_QC_LAUNCH(BITSV, 2);         \
+        else if (lpb_log2 == 2) GQ_QC_LAUNCH(BITSV, 4);    \
         else if (lpb_log2 == 3) GQ_QC_LAUNCH(BITSV, 8);    \
         else GQ_QC_LAUNCH(BITSV, 16);                      \
     } while (0)

@@ -379,7 +379,7 @@ typedef struct gq_qsgd_batch {
     int32_t wide;
     int32_t nseg;
     int32_t bucket_hint;       /* the bucket width most elements have, 0 = unknown (was `reserved`): picks how many lanes the
-                                  bucketed kernels give a bucket (d / 8, between 4 and 16); every value gives the same results */
+                                  bucketed kernels give a bucket (d / 8, between 2 and 16); every value gives the same results */
     int64_t nitems;
     const int64_t *seg_table;
     const int32_t *item_seg;

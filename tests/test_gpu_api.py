@@ -838,14 +838,18 @@ def test_batched_qsgd_compress_divides_like_the_reference_at_every_scale(span, o
         assert np.array_equal(gb[k].cpu().numpy().reshape(-1), want), s
 
 
-@pytest.mark.parametrize("kw", [dict(n_bit=8), dict(n_bit=8, c_dim=512, ef=True), dict(n_bit=5)])
+@pytest.mark.parametrize("kw", [dict(n_bit=8), dict(n_bit=8, c_dim=512, ef=True), dict(n_bit=5), dict(n_bit=8, c_dim=32), dict(n_bit=2, c_dim=32),
+                                dict(n_bit=5, c_dim=64), dict(n_bit=2, c_dim=16), dict(n_bit=8, c_dim=16, ef=True), dict(n_bit=4, c_dim=256),
+                                dict(n_bit=2, c_dim=8), dict(n_bit=8, c_dim=64, ef=True)])
 def test_batched_packed_qsgd_wider_codes(kw, oracle):
-    """8- and 16-bit packed codes (e.g. the usual "8-bit QSGD"): batched launch == per-tensor path and, for the
-    deterministic rounding, the mean of the oracle's decompress(compress(g))."""
+    """8- and 16-bit packed codes (e.g. the usual "8-bit QSGD") and every lanes-per-bucket form of the bucketed kernels
+    (bucket widths 8 ... 256: 2, 4, 8 or 16 lanes per bucket, picked from the descriptor's bucket_hint; the list's 1,728-element
+    tensor brings widths that are no power of two): batched launch == per-tensor path and, for the deterministic
+    rounding, the mean of the oracle's decompress(compress(g))."""
     shapes = RESNET50_COMPRESSED[:10] + RESNET50_SMALL[:3]
     qb, gb = _run_qsgd(shapes, 2, 5, **kw)
     qp, gp = _run_qsgd(shapes, 2, 5, gq_no_batch=True, **kw)
-    assert qb._groups and qb._groups[0][2].ready and qb.codecs[0].bits == (16 if kw["n_bit"] == 8 else 8)
+    assert qb._groups and qb._groups[0][2].ready and qb.codecs[0].bits == (16 if kw["n_bit"] == 8 else 8 if kw["n_bit"] > 2 else 4)
     for a, b in zip(gb, gp):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     if kw.get("ef"):
