@@ -840,7 +840,7 @@ def test_batched_qsgd_compress_divides_like_the_reference_at_every_scale(span, o
 
 @pytest.mark.parametrize("kw", [dict(n_bit=8), dict(n_bit=8, c_dim=512, ef=True), dict(n_bit=5), dict(n_bit=8, c_dim=32), dict(n_bit=2, c_dim=32),
                                 dict(n_bit=5, c_dim=64), dict(n_bit=2, c_dim=16), dict(n_bit=8, c_dim=16, ef=True), dict(n_bit=4, c_dim=256),
-                                dict(n_bit=2, c_dim=8), dict(n_bit=8, c_dim=64, ef=True)])
+                                dict(n_bit=2, c_dim=8), dict(n_bit=8, c_dim=64, ef=True), dict(n_bit=2, c_dim=512), dict(n_bit=4, c_dim=512, ef=True)])
 def test_batched_packed_qsgd_wider_codes(kw, oracle):
     """8- and 16-bit packed codes (e.g. the usual "8-bit QSGD") and every lanes-per-bucket form of the bucketed kernels
     (bucket widths 8 ... 256: 2, 4, 8 or 16 lanes per bucket, picked from the descriptor's bucket_hint; the list's 1,728-element
