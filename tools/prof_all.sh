@@ -38,8 +38,10 @@ python tools/time_generic.py > $O/time_generic.txt 2>&1
 python tools/time_pf_d.py 32 8 16 >> $O/time_generic.txt 2>&1
 python tools/pvq_time.py > $O/pvq_time.txt 2>&1
 python tools/qsgd_r.py > $O/qsgd_r.txt 2>&1
-python tools/bench_resnet50.py > $O/resnet50_steps.txt 2>&1
+python tools/bench_resnet50.py 2>&1 | grep -v 'alternate dimension' > $O/resnet50_steps.txt
 python tools/host_breakdown.py > $O/host_breakdown.txt 2>&1
+python tools/config_sweep.py > $O/config_sweep.txt 2>/dev/null
+(GQ_AB_ROUNDS=1 python tools/pvq_ab.py product; GQ_AB_D=32 GQ_AB_ROUNDS=1 python tools/pvq_ab.py product; GQ_AB_D=8 GQ_AB_ROUNDS=1 python tools/pvq_ab.py product; GQ_PVQ_TWO_SWEEPS=1 GQ_AB_ROUNDS=1 python tools/pvq_ab.py product) > $O/pvq_ab.txt 2>&1
 python tools/cpu_scaling.py > $O/cpu_scaling.txt 2>&1
 python tools/graph_pieces.py > $O/graph_pieces.txt 2>&1
 python tools/batched_vs_flat.py > $O/batched_vs_flat.txt 2>&1
