@@ -70,7 +70,7 @@ while time.time() - t0 < budget:
                 codebook(16, 256)
         comp = NearestNeighborCompressor
     else:
-        d = int(rng.choice([0, 128, 64, 512, 4098, 8192, 2]))
+        d = int(rng.choice([0, 128, 64, 512, 4098, 8192, 2, 8, 16, 32, 256, 1024, 2048]))
         kw = dict(c_dim=d, n_bit=int(rng.choice([1, 2, 4, 6, 8, 9])))
         comp = QSGDCompressor
         d = d or 2
