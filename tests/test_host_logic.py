@@ -739,3 +739,36 @@ def test_bench_watchdog_exits_with_its_code_and_says_what_was_in_flight():
             "w = bench.Watchdog(0, 1, 0.5); w.enter('x'); time.sleep(2.0); print('one rank: no watchdog')\n" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "no watchdog" in r.stdout
+
+
+def test_qsgd_bucket_placement_rules(monkeypatch):
+    """BatchedQSGD.place_lone_buckets (codecs.py): buckets of 1,024 elements or more go to the chunked kernels; a tensor that is one
+    bucket of more than 256 elements joins them when that does not make a group of one; a single wide tensor next to bucketed
+    ones stays with them (a group of one would not be batched at all)."""
+    from gq_amd import codecs
+
+    monkeypatch.setattr(codecs.BatchedQSGD, "eligible", staticmethod(lambda c: True))
+
+    class C(object):      # the attributes the rule reads, without a device
+        def __init__(self, d, Mb, bits=4, n_bit=2):
+            self.d, self.Mb, self.bits = d, Mb, bits
+            self.c = type("c", (), {"bit": n_bit})()
+
+    def place(*cds):
+        codecs.BatchedQSGD.place_lone_buckets(cds)
+        return [codecs.BatchedQSGD.is_wide(c) for c in cds]
+
+    # TernGrad on a model: every tensor one bucket; the 1,024 ... 4,096-element ones go with the big ones
+    assert place(C(2359296, 1), C(1024, 1), C(2048, 1), C(1728, 1), C(4096, 1)) == [True] * 5
+    # ... and a 1,001-element tensor with them (wide tensors of its format exist)
+    assert place(C(2359296, 1), C(1001, 1)) == [True, True]
+    # bucketed tensors only: nothing is wide; one lone 1,728-element bucket stays with them, two form a group
+    assert place(C(128, 1000), C(128, 8), C(192, 9)) == [False] * 3
+    assert place(C(512, 1000), C(512, 2), C(1728, 1)) == [False] * 3
+    assert place(C(512, 1000), C(600, 1), C(700, 1)) == [False, True, True]
+    # buckets of 1,024 and more are wide; a single such tensor next to bucketed ones is not (up to 4,096 elements)
+    assert place(C(2048, 500), C(2048, 3), C(1024, 1)) == [True] * 3
+    assert place(C(128, 1000), C(4096, 1)) == [False, False]
+    assert place(C(128, 1000), C(8192, 1)) == [False, True]
+    # formats do not mix: an 8-bit wide tensor does not pull a 4-bit lone bucket over
+    assert place(C(2359296, 1, bits=8, n_bit=5), C(512, 100), C(1500, 1)) == [True, False, False]
