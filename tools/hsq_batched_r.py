@@ -1,5 +1,5 @@
-"""HSQ (c_dim 16, k_bit 8, n_bit 6) on the ResNet-50 tensor list: kernel times of the batched
-compress and of the decode-mean as a function of the number of payloads R (BASELINE configs 3-4)."""
+"""HSQ (c_dim 16, k_bit 8, n_bit 6; $GQ_R_CDIM / $GQ_R_NBIT: others, e.g. main.py's defaults 32 / 8) on the ResNet-50 tensor list:
+kernel times of the batched compress and of the decode-mean as a function of the number of payloads R (BASELINE configs 3-4)."""
 import json, os, sys
 from argparse import Namespace
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +18,7 @@ def ev_time(fn, reps=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps * 1e3
 for R in ([int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]):
-    args = Namespace(c_dim=16, k_bit=8, n_bit=6, no_cuda=False, random=1, ef=False, two_phase=False, scale="exp",
+    args = Namespace(c_dim=int(os.environ.get("GQ_R_CDIM", "16")), k_bit=8, n_bit=int(os.environ.get("GQ_R_NBIT", "6")), no_cuda=False, random=1, ef=False, two_phase=False, scale="exp",
                      num_users=R, mode="ps", cr=256)
     params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in shapes]
     q = Quantizer(NearestNeighborCompressor, params, args)
