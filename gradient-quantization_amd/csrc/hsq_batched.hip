@@ -703,13 +703,16 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_d_kernel(
 constexpr int DT_THREADS = 512;
 constexpr int DT_WAVES = DT_THREADS / 64;
 constexpr int DT_RCH = 8;   // payloads staged per chunk
+constexpr int DT_RB = 4;    // ... of which this many are read back from LDS together in a pass
 // gq_step_tail.ticket of gq_hsq_levels_decode_batched: (1 + GQ_TICKET_SHARDS) counters GQ_TICKET_STRIDE words apart (include/gq_hsq.h: GQ_TICKET_WORDS)
 #define GQ_TICKET_SHARDS 16
 #define GQ_TICKET_STRIDE 32
 #ifndef GQ_EF_LEVELS_TILE
 #define GQ_EF_LEVELS_TILE 1   // 0: round 4's one-thread-per-unit error-feedback level kernels (A/B builds)
 #endif
-template <int D, typename LevelT>
+// BATCH: DT_RB payloads' loads together (R >= DT_RB); without it the loops are the one-by-one ones alone (fewer registers:
+// R = 1 ... 3 ran 3-8 % slower with the batch code merely present).
+template <int D, typename LevelT, bool BATCH>
 __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
@@ -743,34 +746,80 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel
         f32x4 acc[UPS];
         for (int r0 = 0; r0 < R; r0 += DT_RCH) {
             const int nr = R - r0 < DT_RCH ? R - r0 : DT_RCH;
-            // lane = subvector: this chunk's (code, norm) pairs into the wave's slots
-            for (int rr = 0; rr < nr; ++rr) {
-                const uint8_t *p = gathered + (int64_t)(r0 + rr) * user_stride;
+            // lane = subvector: this chunk's (code, norm) pairs into the wave's slots, DT_RB payloads' loads requested together
+            // (payload by payload, a tile paid R round trips to memory in a row: 43.7 us at R = 8 where one payload takes 20.9)
+            int rb = 0;
+            for (; BATCH && rb + DT_RB <= nr; rb += DT_RB) {
+                unsigned code_[DT_RB];
+                float lvl_[DT_RB], lb_[DT_RB], ub_[DT_RB];
+#pragma unroll
+                for (int k = 0; k < DT_RB; ++k) {
+                    const uint8_t *p = gathered + (int64_t)(r0 + rb + k) * user_stride;
+                    const float *lbub = reinterpret_cast<const float *>(p + lbub_off);
+                    lb_[k] = lbub[0];
+                    ub_[k] = lbub[1];
+                    lvl_[k] = (float)reinterpret_cast<const LevelT *>(p + level_off)[sv0 + lsv];
+                    code_[k] = p[code_off + lsv];
+                }
+#pragma unroll
+                for (int k = 0; k < DT_RB; ++k) {
+                    const float lb = lb_[k], range = ub_[k] - lb;
+                    float n = lvl_[k] * range;   // prob_scalar:31-32, unfused
+                    n = n * inv_s;               // == / 2^n_bit exactly
+                    n = n + lb;
+                    *reinterpret_cast<uint2 *>(pairs + ((rb + k) * 64 + lane) * 2) = make_uint2(code_[k], __float_as_uint(n));
+                }
+            }
+            for (; rb < nr; ++rb) {   // the payloads that do not fill a batch (all of them for R < DT_RB), one by one
+                const uint8_t *p = gathered + (int64_t)(r0 + rb) * user_stride;
                 const float *lbub = reinterpret_cast<const float *>(p + lbub_off);
                 const float lb = lbub[0], range = lbub[1] - lb;
-                float n = (float)reinterpret_cast<const LevelT *>(p + level_off)[sv0 + lsv] * range;   // prob_scalar:31-32, unfused
-                n = n * inv_s;                                                                        // == / 2^n_bit exactly
+                float n = (float)reinterpret_cast<const LevelT *>(p + level_off)[sv0 + lsv] * range;
+                n = n * inv_s;
                 n = n + lb;
                 const unsigned code = p[code_off + lsv];
-                *reinterpret_cast<uint2 *>(pairs + (rr * 64 + lane) * 2) = make_uint2(code, __float_as_uint(n));
+                *reinterpret_cast<uint2 *>(pairs + (rb * 64 + lane) * 2) = make_uint2(code, __float_as_uint(n));
             }
             __builtin_amdgcn_wave_barrier();   // (written and read by this wave only: LDS operations of a wave stay in order)
-            // lane = unit of a pass: products in payload order
+            // lane = unit of a pass: products in payload order; DT_RB pairs, then their rows, are read together (one after the
+            // other, every payload waited for two dependent LDS round trips)
 #pragma unroll
             for (int pss = 0; pss < UPS; ++pss) {
                 const int s = pss * (64 / UPS) + ls;
-                for (int rr = 0; rr < nr; ++rr) {
+                auto one = [&](int rr, bool first) {
                     const uint2 cn = *reinterpret_cast<const uint2 *>(pairs + (rr * 64 + s) * 2);
                     const f32x4 c = *reinterpret_cast<const f32x4 *>(s_cb + cn.x * RS + 4 * q);
                     const float n = __uint_as_float(cn.y);
                     const f32x4 n4 = {n, n, n, n};
                     const f32x4 dec = c * n4;
-                    if (r0 == 0 && rr == 0) {
+                    if (first) {   // (wave-uniform: a scalar branch, not four selects per payload)
                         acc[pss] = dec;
                     } else {
                         acc[pss] = acc[pss] + dec;
                     }
+                };
+                int rr = 0;
+                for (; BATCH && rr + DT_RB <= nr; rr += DT_RB) {
+                    uint2 cn[DT_RB];
+                    f32x4 c[DT_RB];
+#pragma unroll
+                    for (int k = 0; k < DT_RB; ++k) cn[k] = *reinterpret_cast<const uint2 *>(pairs + ((rr + k) * 64 + s) * 2);
+#pragma unroll
+                    for (int k = 0; k < DT_RB; ++k) c[k] = *reinterpret_cast<const f32x4 *>(s_cb + cn[k].x * RS + 4 * q);
+                    const bool first = r0 == 0 && rr == 0;   // (wave-uniform)
+#pragma unroll
+                    for (int k = 0; k < DT_RB; ++k) {
+                        const float n = __uint_as_float(cn[k].y);
+                        const f32x4 n4 = {n, n, n, n};
+                        const f32x4 dec = c[k] * n4;
+                        if (k == 0 && first) {
+                            acc[pss] = dec;
+                        } else {
+                            acc[pss] = acc[pss] + dec;
+                        }
+                    }
                 }
+                for (; rr < nr; ++rr) one(rr, r0 == 0 && rr == 0);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -1143,11 +1192,19 @@ template <int D, typename LevelT>
 static void launch_decode_tile(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
                                int64_t user_stride_bytes, int R, const float *codebook, int n_bit, float *out, int plain,
                                hipStream_t st, const StepTail &tail) {
-    static const int bpc = resident_blocks_per_cu(hsq_decode_sum_batched_tile_kernel<D, LevelT>, DT_THREADS, 0);
     int64_t blocks = (ntiles + DT_WAVES - 1) / DT_WAVES;
+    if (R >= DT_RB) {
+        static const int bpc = resident_blocks_per_cu(hsq_decode_sum_batched_tile_kernel<D, LevelT, true>, DT_THREADS, 0);
+        const int64_t cap = (int64_t)cu_count() * bpc;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched_tile_kernel<D, LevelT, true>), dim3((unsigned)(blocks < 1 ? 1 : blocks)),
+                           dim3(DT_THREADS), 0, st, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, R, codebook, n_bit, out, plain, tail);
+        return;
+    }
+    static const int bpc = resident_blocks_per_cu(hsq_decode_sum_batched_tile_kernel<D, LevelT, false>, DT_THREADS, 0);
     const int64_t cap = (int64_t)cu_count() * bpc;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched_tile_kernel<D, LevelT>), dim3((unsigned)(blocks < 1 ? 1 : blocks)),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched_tile_kernel<D, LevelT, false>), dim3((unsigned)(blocks < 1 ? 1 : blocks)),
                        dim3(DT_THREADS), 0, st, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, R, codebook, n_bit, out, plain, tail);
 }
 }  // namespace gq
