@@ -13,7 +13,7 @@ shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "resnet50_cifar_sh
 n = sum(int(torch.Size(s).numel()) for s in shapes)
 
 
-def run(tag, comp, users=1, steps=40, **kw):
+def run(tag, comp, users=1, steps=100, **kw):
     base = dict(c_dim=16, k_bit=8, n_bit=6, no_cuda=False, random=1, ef=False, two_phase=False, scale="exp",
                 num_users=users, mode="ps", cr=256)
     base.update(kw)
@@ -27,7 +27,7 @@ def run(tag, comp, users=1, steps=40, **kw):
                 p.grad = g
             q.record(u, epoch=1)
         q.apply()
-    for _ in range(14):      # (the graph captures of the default configuration happen in the first dozen steps)
+    for _ in range(40):      # (the graph captures of the default configuration happen in the first dozen steps; the clock settles later)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
