@@ -886,37 +886,65 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_levels_ef_tile_kernel(
     };
     unsigned *const pairs = s_pair + wave * (64 * 2);
     const int q = lane % UPS, ls = lane / UPS;
-    for (int64_t tile = (int64_t)blockIdx.x * DT_WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * DT_WAVES) {
-        const int seg = __builtin_amdgcn_readfirstlane(tile_seg[tile]);
-        const int64_t *rec = seg_table + 8 * (int64_t)seg;
-        const int64_t m = uniform64(rec[1]), sv0 = (tile - uniform64(rec[2])) * 64;
+    // A tile's chain of dependent round trips was  tile -> tensor  ->  the tensor's record  ->  (lb, ub), u, code: three or four
+    // latencies per tile and wave.  The record stays in scalar registers while a wave's tiles stay with one tensor (they do,
+    // thousands of tiles long), and the next tile's tensor word and u are requested while the current tile is worked on.
+    const int64_t tstride = (int64_t)gridDim.x * DT_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * DT_WAVES + wave;
+    int seg = -1;
+    int64_t r_grad = 0, r_m = 0, r_tile0 = 0, r_codes = 0, r_levels = 0, r_lbub = 0, r_out = 0, r_err = 0;
+    float lb = 0.0f, ub = 0.0f;
+    int seg_nv = tile < ntiles ? tile_seg[tile] : 0;                    // (vector registers until they are needed)
+    float u_nv = tile < ntiles ? u_flat[tile * 64 + lane] : 0.0f;       // u_flat is padded to whole tiles
+    for (; tile < ntiles; tile += tstride) {
+        const int seg_t = __builtin_amdgcn_readfirstlane(seg_nv);
+        const float u_t = u_nv;
+        if (seg_t != seg) {   // (wave-uniform) a new tensor: its record and its (lb, ub)
+            seg = seg_t;
+            const int64_t *rec = seg_table + 8 * (int64_t)seg;
+            r_grad = uniform64(rec[0]);
+            r_m = uniform64(rec[1]);
+            r_tile0 = uniform64(rec[2]);
+            r_codes = uniform64(rec[3]);
+            r_levels = uniform64(rec[4]);
+            r_lbub = uniform64(rec[5]);
+            r_out = uniform64(rec[6]);
+            r_err = uniform64(rec[7]);
+            lb = order_unmap_f(seg_minmax[2 * seg]);
+            ub = order_unmap_f(seg_minmax[2 * seg + 1]);
+        }
+        const int64_t m = r_m, sv0 = (tile - r_tile0) * 64;
         const int valid = (int)(m - sv0 < 64 ? m - sv0 : 64);
-        const float lb = order_unmap_f(seg_minmax[2 * seg]), ub = order_unmap_f(seg_minmax[2 * seg + 1]);
+        float *const err = write_error ? reinterpret_cast<float *>(r_err) : nullptr;
+        // this tile's code (needed after the level) and the next tile's words, requested before the level arithmetic
+        const unsigned code = (OUT || err) ? wire[r_codes + sv0 + (lane < valid ? lane : valid - 1)] : 0u;
+        if (tile + tstride < ntiles) {
+            seg_nv = tile_seg[tile + tstride];
+            u_nv = u_flat[(tile + tstride) * 64 + lane];
+        }
         const LevelQuant lq(lb, ub, n_bit, random_mode == GQ_RANDOM_DEVICE_KEYED ? GQ_RANDOM_DEVICE : random_mode, r_flat,
                             random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, lb, ub) : seed);
         const int64_t flat = tile * 64 + lane;            // index into u_flat / r_flat and of this subvector's draw
         int l = 0;
         if (lane < valid) {
-            l = lq.level(u_flat[flat], flat);
-            reinterpret_cast<LevelT *>(wire + uniform64(rec[4]))[sv0 + lane] = (LevelT)l;
+            l = lq.level(u_t, flat);
+            reinterpret_cast<LevelT *>(wire + r_levels)[sv0 + lane] = (LevelT)l;
             if (sv0 == 0 && lane == 0) {
-                float *lbub = reinterpret_cast<float *>(wire + uniform64(rec[5]));
+                float *lbub = reinterpret_cast<float *>(wire + r_lbub);
                 lbub[0] = lb;
                 lbub[1] = ub;
             }
         }
-        float *const err = write_error ? reinterpret_cast<float *>(uniform64(rec[7])) : nullptr;
         if (!OUT && !err) continue;                        // (wave-uniform: a tensor without an error buffer gets its levels only)
         const float range = ub - lb;
         float n = (float)l * range;   // prob_scalar:31-32, unfused
         n = n / s;
         n = n + lb;
-        const unsigned code = wire[uniform64(rec[3]) + sv0 + (lane < valid ? lane : valid - 1)];
         *reinterpret_cast<uint2 *>(pairs + lane * 2) = make_uint2(code, __float_as_uint(n));
         __builtin_amdgcn_wave_barrier();   // (written and read by this wave only: LDS operations of a wave stay in order)
-        const float *const grad = reinterpret_cast<const float *>(uniform64(rec[0])) + sv0 * D;
+        const float *const grad = reinterpret_cast<const float *>(r_grad) + sv0 * D;
         float *const edst = err + sv0 * D;
-        float *const odst = OUT ? out + uniform64(rec[6]) + sv0 * D : nullptr;
+        float *const odst = OUT ? out + r_out + sv0 * D : nullptr;
 #pragma unroll
         for (int pss = 0; pss < UPS; ++pss) {
             const int sv = pss * (64 / UPS) + ls;
