@@ -735,12 +735,29 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel
     };
     unsigned *const pairs = s_pair + wave * (DT_RCH * 64 * 2);
     const int q = lane % UPS, ls = lane / UPS;               // this lane's unit inside a subvector / subvector inside a pass
-    for (int64_t tile = (int64_t)blockIdx.x * DT_WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * DT_WAVES) {
-        const int seg = __builtin_amdgcn_readfirstlane(tile_seg[tile]);
-        const int64_t *rec = seg_table + 8 * (int64_t)seg;
-        const int64_t m = uniform64(rec[1]), sv0 = (tile - uniform64(rec[2])) * 64;
-        const int64_t code_off = uniform64(rec[3]) + sv0, level_off = uniform64(rec[4]), lbub_off = uniform64(rec[5]);
-        float *const dst = out + uniform64(rec[6]) + sv0 * D;
+    // (the tensor's record stays in scalar registers while a wave's tiles stay with one tensor; the next tile's tensor word is
+    // requested a tile ahead: as in hsq_levels_ef_tile_kernel)
+    const int64_t tstride = (int64_t)gridDim.x * DT_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * DT_WAVES + wave;
+    int seg = -1;
+    int64_t r_m = 0, r_tile0 = 0, r_codes = 0, r_levels = 0, r_lbub = 0, r_out = 0;
+    int seg_nv = tile < ntiles ? tile_seg[tile] : 0;
+    for (; tile < ntiles; tile += tstride) {
+        const int seg_t = __builtin_amdgcn_readfirstlane(seg_nv);
+        if (tile + tstride < ntiles) seg_nv = tile_seg[tile + tstride];
+        if (seg_t != seg) {   // (wave-uniform)
+            seg = seg_t;
+            const int64_t *rec = seg_table + 8 * (int64_t)seg;
+            r_m = uniform64(rec[1]);
+            r_tile0 = uniform64(rec[2]);
+            r_codes = uniform64(rec[3]);
+            r_levels = uniform64(rec[4]);
+            r_lbub = uniform64(rec[5]);
+            r_out = uniform64(rec[6]);
+        }
+        const int64_t m = r_m, sv0 = (tile - r_tile0) * 64;
+        const int64_t code_off = r_codes + sv0, level_off = r_levels, lbub_off = r_lbub;
+        float *const dst = out + r_out + sv0 * D;
         const int valid = (int)(m - sv0 < 64 ? m - sv0 : 64);      // subvectors of this tile that exist (>= 1)
         const int lsv = lane < valid ? lane : valid - 1;           // (a padding lane re-reads the last one; its units are not stored)
         f32x4 acc[UPS];
