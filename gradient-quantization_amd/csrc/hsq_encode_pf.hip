@@ -1094,9 +1094,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         if (threadIdx.x < PF_MM_SEGS) {
             const unsigned lo = s_mm[2 * threadIdx.x], hi = s_mm[2 * threadIdx.x + 1];
             if (lo != 0xFFFFFFFFu || hi != 0u) {
+                // look before the atomic (as mm_fold does): every workgroup that met the tensor comes here at the end of the
+                // launch, all within a microsecond or two, and the words only ever move towards the extremes -- a value
+                // already as good as ours, however stale, makes ours redundant.  (Two 12 M-element tensors: 256 workgroups
+                // on four words, 42.0 us against 39.3 for the same elements as 76 tensors.)
                 unsigned *mm = a.seg_minmax + 2 * (seg_first + (int)threadIdx.x);
-                atomicMin(mm, lo);
-                atomicMax(mm + 1, hi);
+                if (lo < __hip_atomic_load(mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(mm, lo);
+                if (hi > __hip_atomic_load(mm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(mm + 1, hi);
             }
         }
         return;
