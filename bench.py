@@ -904,12 +904,14 @@ def gradient_feeder(torch, params, lists):
 
 # the compact `workloads` object of the default line: BASELINE configs[2] / [4] under the driver's clock
 # ------------------------------------------------------------------------------------------------------
-def list_workloads(args, torch, np, native, dev, steps=150, warm=40):
+def list_workloads(args, torch, np, native, dev, steps=400, warm=600):
     """The ResNet-50/CIFAR parameter list (161 tensors, 23.5 M elements) through PSQuantizer.record + apply, three ways:
     resnet50 (HSQ c_dim 16 k_bit 8 n_bit 6 random 1, N(0,1) x 1e-3 inputs), qsgd (QSGD c_dim 128 n_bit 2 random 1, same inputs) and
     resnet50_real (HSQ on BACK-PROPAGATED gradients: one forward / backward of driver.ResNet50 per input list on a seeded
     synthetic CIFAR batch of 128 -- real gradient statistics: dead units' all-zero subvectors, heavy tails).  Each with the
-    library's default launches (HIP graph replay) and with eager launches, `steps` timed steps after `warm`."""
+    library's default launches (HIP graph replay) and with eager launches, `steps` timed steps after `warm` (600: ~50 ms of load --
+    with 40 the clocks had not come back up after the idle gap in which the lists are built, and the default line's
+    `workloads` read 0.074 ms where `--workload resnet50`, with its own pre-warm, reads 0.067)."""
     import contextlib
     from argparse import Namespace
     from gq_amd.compressors import NearestNeighborCompressor, QSGDCompressor
