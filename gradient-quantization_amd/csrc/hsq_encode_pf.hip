@@ -222,8 +222,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
 
     const int64_t ntiles = BATCHED ? a.ntiles : ((M + 63) >> 6);
     // Tiles: every workgroup owns one contiguous run [lo, hi) of them and its 8 waves draw from it through an
-    // LDS counter (ds_add_rtn: ~100 cycles, so a wave is committed to one tile beyond the one it works on --
-    // two in the batched form, which wants the tile -> tensor word a tile early).  The two waves of a SIMD do
+    // LDS counter (ds_add_rtn: ~100 cycles, so a wave is committed to one tile beyond the one it works on).
+    // The two waves of a SIMD do
     // not run at one speed (the older one wins VALU arbitration, ~1.6x; profiles/r01_e_pf_kernel_stamps.txt)
     // and a static split between them, however tuned, left the slowest wave ~15 % behind the mean; drawn from
     // a shared counter the tiles go to whoever is free.  (Ticket counters in global memory cost an atomic round
@@ -272,6 +272,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         gcf_ptr base;
         int64_t m, sv0;
         int64_t tile0;   // batched: the tensor's first tile
+        int64_t tiles_end;   // batched: the tile behind the tensor's last one
         int rem;       // index of the tile's last valid subvector (0..63): m - 1 - sv0, capped at 63
         int seg;
         gcode_ptr codes;
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             ti.base = (gcf_ptr)(uintptr_t)uniform64(r0);
             ti.m = uniform64(r1);
             ti.tile0 = uniform64(r2);
+            ti.tiles_end = ti.tile0 + ((ti.m + 63) >> 6);
             ti.sv0 = (tile - ti.tile0) * 64;
             ti.codes = (gcode_ptr)((uintptr_t)a.wire + (uintptr_t)uniform64(r3));
             ti.err = EF ? (gcf_ptr)(uintptr_t)uniform64(r7) : (gcf_ptr)0;
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         } else {
             ti.seg = 0;
             ti.tile0 = 0;
+            ti.tiles_end = 0;
             ti.base = (gcf_ptr)a.grad;
             ti.m = M;
             ti.sv0 = tile * 64;
@@ -410,9 +413,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     half8 vh[2 * KS];   // [block * KS + k-step]
     float n2p[2] = {0.0f, 0.0f};
     Tile ti = {};
-    auto seg_of = [&](int64_t tile) {   // batched: tile -> tensor, one global word (0 beyond the end)
-        return (BATCHED && tile < tile_end) ? a.tile_seg[tile] : 0;
-    };
 
     // ---- prologue.  Everything the workgroup needs from memory is requested first, in the order it is used
     // (vector-memory results return in order): the codebook words for the LDS image, this wave's row block of
@@ -516,8 +516,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     const float err2_rel = cb_ok ? c2 * SH::ERR2_REL + SH::ERR2_SUB : INFINITY;   // the second pass (three MFMAs per chain and k-step)
 
     int64_t tn = draw();                // the tile after this wave's first one
-    int seg_n = seg_of(tn);             // in flight while the first tile is set up
-    int seg_next = 0;                   // its value, read back BEFORE a tile's stores (see the consume point)
     // sigma: the power of two the tile in flight was multiplied by before its conversion to f16 (wave-uniform, an SGPR).
     // First tile: the largest |element| of the tile goes to [2^4, 2^5); afterwards every tile's scale follows the norms
     // the previous tile showed (four sampled lanes, below).  A subvector that ends up outside the window of the error
@@ -526,7 +524,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // lane-dependent -- t starts from the wave's index -- so the value is read back through readfirstlane where it changes)
     float sigma_t = 1.0f;
     if (t < tile_end) {
-        seg_next = BATCHED ? __builtin_amdgcn_readfirstlane(seg_n) : 0;
         fold_err(ti, cur, nxte);
         float m = 0.0f;
 #pragma unroll
@@ -768,23 +765,24 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     GQ_STAMPS_ONLY(const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(); unsigned long long ntl = 0, stamp_acc[6] = {0, 0, 0, 0, 0, 0}, ts_prev;
                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_prev)::"memory");)
     while (t < tile_end) {
-        // single tensor: tn was drawn at the end of the previous tile; batched: a whole tile ago
-        const int64_t tnn = BATCHED ? draw() : 0;
+        // tn was drawn at the end of the previous tile.  (The multi-tensor form used to draw a tile earlier still, to have the
+        // tile -> tensor word of the tile after next in flight for a whole tile: a wave was committed to TWO tiles beyond its
+        // own, and the ends of the workgroups' runs were that much more ragged -- the same elements as one flat tensor ran
+        // 35.4 us, as two tensors 40.4.  A tensor's tiles are one contiguous range: the word is only looked up when tn leaves it.)
         Tile tin = ti;
         if (tn < tile_end) {
             // a wave's consecutive tiles mostly stay with one tensor (contiguous runs): its record is already in scalar
             // registers -- the LDS reads and the eight v_readfirstlane of a look-up only when the tensor changes
-            if (BATCHED && seg_next == ti.seg) {
+            if (BATCHED && tn >= ti.tile0 && tn < ti.tiles_end) {
                 tin.sv0 = (tn - ti.tile0) * 64;
                 const int64_t rem = ti.m - 1 - tin.sv0;
                 tin.rem = rem > 63 ? 63 : (int)rem;
             } else {
-                tin = tile_info(tn, seg_next, std::false_type{});
+                tin = tile_info(tn, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[tn]) : 0, std::false_type{});
             }
             load_tile(tin, nxt);  // prefetch the next tile
             load_err(tin, nxte);
         }
-        seg_n = seg_of(tnn);
         if (BATCHED && ti.seg != cur_seg) {
             flush_minmax();
             cur_seg = ti.seg;
@@ -968,9 +966,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         // behind the just-issued stores and every tile eats a store round trip.
         half8 nvh[2 * KS];
         float nn2p[2] = {0.0f, 0.0f};
-        // the tile -> tensor word of the tile after next was requested at the top of this tile: read it
-        // back here, with the prefetch, not behind the stores
-        if (BATCHED) seg_next = __builtin_amdgcn_readfirstlane(seg_n);
         if (EF && tn < tile_end) fold_err(tin, nxt, nxte);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
@@ -1027,7 +1022,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         }
         ti = tin;
         t = tn;
-        tn = BATCHED ? tnn : draw();
+        tn = draw();
         sigma_t = sigma_n;
         GQ_STAMP(5)
         GQ_STAMPS_ONLY(++ntl;)
