@@ -268,7 +268,7 @@ static int qsgd_decode_sum_batched(const gq_qsgd_batch *b, const uint8_t *gather
     if (rc != GQ_OK) return rc;
     if (b->wide)
         return gqi_qsgd_wide_decode_sum(b->seg_table, b->item_seg, b->nseg, b->nitems, b->n_bit, b->bits, gathered,
-                                        user_stride_bytes, R, out, plain, stream);
+                                        user_stride_bytes, R, out, plain, tail, tail_taken, stream);
     return gqi_qsgd_decode_sum_batched(b->seg_table, b->item_seg, b->nseg, b->nitems, b->n_bit, b->bits, gathered,
                                        user_stride_bytes, R, out, plain, tail, tail_taken, b->bucket_hint, stream);
 }

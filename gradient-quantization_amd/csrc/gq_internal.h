@@ -71,4 +71,4 @@ GQ_INTERNAL int gqi_qsgd_wide_compress(const int64_t *seg_table, const int32_t *
                                        uint32_t *norm_bits, uint8_t *wire, const int64_t *dense_table, int ndense, void *stream);
 GQ_INTERNAL int gqi_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks,
                                          int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                         float *out, int plain, void *stream);
+                                         float *out, int plain, const gq::StepTail *tail_or_null, int *tail_taken, void *stream);

@@ -250,7 +250,8 @@ __global__ __launch_bounds__(QW_THREADS) void qsgd_wide_decode_kernel(const int6
                                                                      int64_t nchunks, int n_bit,
                                                                      const uint8_t *__restrict__ gathered,
                                                                      int64_t user_stride, int R,
-                                                                     float *__restrict__ out, int plain) {
+                                                                     float *__restrict__ out, int plain, const StepTail tail) {
+    step_tail_run(tail);      // the aggregate's small per-step work (gq_qsgd_decode_sum_batched_tail)
     const int lane = threadIdx.x & 63;
     const float inv_s = 1.0f / (float)(1 << n_bit);
     const MeanDiv md = mean_div_of(R, !plain);   // the aggregate of R users (ps_quantizer.py:48)
@@ -372,8 +373,10 @@ GQ_INTERNAL int gqi_qsgd_wide_compress(const int64_t *seg_table, const int32_t *
 
 GQ_INTERNAL int gqi_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t *chunk_seg, int nseg, int64_t nchunks,
                                          int n_bit, int bits, const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                         float *out, int plain, void *stream) {
+                                         float *out, int plain, const gq::StepTail *tail_or_null, int *tail_taken, void *stream) {
     plain = plain ? 1 : 0;
+    if (tail_taken) *tail_taken = 0;
+    const gq::StepTail tail = tail_or_null ? *tail_or_null : gq::StepTail{};
     if (nseg < 1 || nchunks < 1 || n_bit < 1 || R < 1 || (bits != 4 && bits != 8 && bits != 16))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_qsgd_decode_sum_batched (wide): bad sizes");
     if (!seg_table || !chunk_seg || !gathered || !out)
@@ -384,13 +387,14 @@ GQ_INTERNAL int gqi_qsgd_wide_decode_sum(const int64_t *seg_table, const int32_t
     const dim3 grid((unsigned)gq::qw_grid(nchunks)), block(gq::QW_THREADS);
     if (bits == 4)
         hipLaunchKernelGGL(gq::qsgd_wide_decode_kernel<4>, grid, block, 0, gq::as_stream(stream), seg_table, chunk_seg,
-                           nchunks, n_bit, gathered, user_stride_bytes, R, out, plain);
+                           nchunks, n_bit, gathered, user_stride_bytes, R, out, plain, tail);
     else if (bits == 16)
         hipLaunchKernelGGL(gq::qsgd_wide_decode_kernel<16>, grid, block, 0, gq::as_stream(stream), seg_table, chunk_seg,
-                           nchunks, n_bit, gathered, user_stride_bytes, R, out, plain);
+                           nchunks, n_bit, gathered, user_stride_bytes, R, out, plain, tail);
     else
         hipLaunchKernelGGL(gq::qsgd_wide_decode_kernel<8>, grid, block, 0, gq::as_stream(stream), seg_table, chunk_seg,
-                           nchunks, n_bit, gathered, user_stride_bytes, R, out, plain);
+                           nchunks, n_bit, gathered, user_stride_bytes, R, out, plain, tail);
     GQ_CHECK_LAUNCH("gq_qsgd_decode_sum_batched (wide)");
+    if (tail_taken) *tail_taken = 1;
     return GQ_OK;
 }
