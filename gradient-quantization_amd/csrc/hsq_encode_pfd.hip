@@ -1,7 +1,11 @@
-// HSQ encode, K = 256, sub-dimension D = 8 or 32: the bf16x3 matrix-core prefilter + exact f32 rescoring
-// of hsq_encode_pf.hip (read its header first: same error bound, same keys, same exactness argument) for
-// the other sub-dimensions the reference's CLI reaches with 256 codewords (main.py's default is
-// --c-dim 32).  Single tensor only.  What differs from the d = 16 kernel:
+// HSQ encode, sub-dimension D = 8 or 32: round 3's bf16x3 matrix-core prefilter + exact f32 rescoring (three bf16 MFMAs per
+// chain and k-step: hi x hi, hi x lo, lo x hi; keys and exactness argument as in hsq_encode_pf.hip's header, its error
+// bound the bf16x3 one stated below).  Since round 5 the product path for K = 256 is hsq_encode_pf.hip's one-f16-MFMA kernel,
+// a template over D = 8 / 16 / 32; what this file still serves:
+//   * gq_hsq_encode_ex's impl 6 (GQ_ENCODE_PREFILTER_BF16X3): the single-tensor K = 256 form, an independent cross-check of
+//     the f16 kernel in the tests and in tools/time_pf_d.py (d = 32 / 8: 42.1 / 68.7 us against 30.5 / 54.6);
+//   * the PAGED form, K = 512 ... 65536 (codebook pages of 256 rows, int32 codes), single- and multi-tensor.
+// What differs from the d = 16 kernel of round 3:
 //   * a chain is 3 * KS v_mfma_f32_32x32x16_bf16 with KS = ceil(D / 16) k-steps; D = 8 feeds zeros for the
 //     upper half of the one k-step;
 //   * the A fragments (codebook hi / lo bf16 parts) do not fit the register file next to everything else
