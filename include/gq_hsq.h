@@ -360,7 +360,8 @@ int gq_qsgd_decode_sum(const float *norm, const uint8_t *signs, const void *leve
  *   bucket, byte offset of the f32 norms / of the codes inside ONE user's wire, float offset of the tensor in `out`
  *   (a multiple of 4), buckets, error buffer (float *, 0 = none) }.
  * wide != 0: WIDE buckets -- the reference's TernGrad command (`--quantizer qsgd --c-dim 0 --n-bit 1`: one bucket
- *   spans the tensor, qsgd_compressor.py:15-16) or any c_dim of a few thousand and more.  The unit of work is a chunk
+ *   spans the tensor, qsgd_compressor.py:15-16) or any bucket of about a thousand elements and more (the caller's choice:
+ *   both forms take any d; gq_amd/codecs.py sends buckets of >= 1,024 elements here).  The unit of work is a chunk
  *   of GQ_QSGD_WIDE_CHUNK consecutive elements of one bucket (the last chunk of a bucket may be shorter; d must be
  *   even): item_seg names the tensor of each chunk, ascending; seg_table int64[nseg][8] = { grad pointer, d, first
  *   chunk, byte offset of the norms / of the codes, float offset in `out`, first word of the tensor's buckets in
