@@ -54,8 +54,11 @@ for p, g in zip(params, grads):
     p.grad = g
 q.record(0, epoch=1); q.apply()
 grp = q._groups[0][2]
+# (apply() rebinds the gradient OBJECTS to the decoded tensors: `grads` holds codeword multiples by now, on which nothing is
+# ever unsettled -- fresh draws for what is timed)
+grads = [torch.randn(s, device=dev) * 1e-3 for s in shapes]
 for p, g in zip(params, grads):
-    p.grad = g.view(g.shape)
+    p.grad = g
 gl = [params[i].grad.data for i in grp.idxs]
 n = sum(g.numel() for g in gl)
 grp.encode(gl, q._wire[0], 0, 0)

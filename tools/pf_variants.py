@@ -251,7 +251,20 @@ def w12(s, waves=12, aregs=False):
     return s
 
 
+def counts(s):
+    """Diagnostic: every wave adds its second-pass entries, exact scans, passes and tiles to four words behind the workspace's
+    (min, max) pairs (flat AND multi-tensor form) -- how often do the rare paths run?  Built with -DGQ_PF_STAMPS."""
+    s = rep(s, "        GQ_STAMPS_ONLY(npassed += n;)", "        GQ_STAMPS_ONLY(npassed += n; npasses += 1;)")
+    s = rep(s, "unsigned long long nscanned = 0, npassed = 0;)", "unsigned long long nscanned = 0, npassed = 0, npasses = 0;)")
+    s = rep(s, "#ifdef GQ_PF_STAMPS\n    if (!BATCHED && lane == 0 && blockIdx.x < 256) {",
+            "#ifdef GQ_PF_STAMPS\n    if (lane == 0) {\n        int *cnt_ = reinterpret_cast<int *>(ws) + 2 * GQ_MAX_PARTIALS + 4;   // (the first words of the fix-up log: unused by this kernel)\n"
+            "        atomicAdd(cnt_, (int)npassed); atomicAdd(cnt_ + 1, (int)nscanned); atomicAdd(cnt_ + 2, (int)npasses); atomicAdd(cnt_ + 3, (int)ntl);\n    }\n"
+            "    if (!BATCHED && lane == 0 && blockIdx.x < 256) {")
+    return s
+
+
 VARIANTS = {
+    "counts": counts,
     "w12": w12,
     "w12a": lambda s: w12(s, 12, True),
     "w16": lambda s: w12(s, 16, False),
@@ -275,7 +288,7 @@ VARIANTS = {
 }
 
 # variants that are a compile-time switch of the shipped source: name -> extra hipcc flags (the source is taken as it is)
-EXTRA_FLAGS = {"r16": ["-DGQ_RESCORE_BATCH=16"],
+EXTRA_FLAGS = {"counts": ["-DGQ_PF_STAMPS"], "r16": ["-DGQ_RESCORE_BATCH=16"],
                # round 5's early ring flush (hsq_encode_pf.hip, PF_FLUSH_AHEAD): off / other distances from the end of the run
                "nopair": ["-DGQ_PF_PAIR=0"], "pair": ["-DGQ_PF_PAIR=1"], "tail0": ["-DGQ_PF_TAIL=0"], "tail1": ["-DGQ_PF_TAIL=1"], "tail2": ["-DGQ_PF_TAIL=2"], "tail3": ["-DGQ_PF_TAIL=3"], "tail6": ["-DGQ_PF_TAIL=6"], "fa16": ["-DGQ_PF_FLUSH_AHEAD=16"],
                "fa0": ["-DGQ_PF_FLUSH_AHEAD=0"], "fa8": ["-DGQ_PF_FLUSH_AHEAD=8"], "fa12": ["-DGQ_PF_FLUSH_AHEAD=12"],
