@@ -8,6 +8,8 @@ sys.path.insert(0, os.path.join(ROOT, "gradient-quantization_amd"))
 import torch
 from gq_amd.compressors import NearestNeighborCompressor, QSGDCompressor
 from gq_amd.quantizers import Quantizer
+sys.path.insert(0, ROOT)
+from bench import gradient_feeder      # fresh gradients under the same objects every step, set by the C++ helper
 
 shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "resnet50_cifar_shapes.json")))["parameter_shapes"]
 n = sum(int(torch.Size(s).numel()) for s in shapes)
@@ -19,12 +21,16 @@ def run(tag, comp, users=1, steps=100, **kw):
     base.update(kw)
     params = [torch.nn.Parameter(torch.zeros(*s, device="cuda")) for s in shapes]
     q = Quantizer(comp, params, Namespace(**base))
-    grads = [torch.randn(p.shape, device="cuda") * 1e-3 for p in params]
+    # apply() rebinds the gradient OBJECTS to the decoded tensors: re-using one list would time the codec on its own output
+    # (codeword multiples: nothing is ever unsettled) from the second step on
+    lists = [[torch.randn(p.shape, device="cuda") * 1e-3 for p in params] for _ in range(3)]
+    feed = gradient_feeder(torch, params, lists)
+    tick = [0]
 
     def step():
         for u in range(users):
-            for p, g in zip(params, grads):
-                p.grad = g
+            feed(tick[0])
+            tick[0] += 1
             q.record(u, epoch=1)
         q.apply()
     for _ in range(40):      # (the graph captures of the default configuration happen in the first dozen steps; the clock settles later)

@@ -8,11 +8,13 @@ os.environ.setdefault("GQ_CODEBOOK_DIR", os.path.join(ROOT, "tests", "golden", "
 import torch
 from gq_amd.compressors import NearestNeighborCompressor, QSGDCompressor
 from gq_amd.quantizers import Quantizer
+sys.path.insert(0, ROOT)
+from bench import gradient_feeder      # fresh gradients under the same objects every step, set by the C++ helper
 
 shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "resnet50_cifar_shapes.json")))["parameter_shapes"]
 
 
-def run(comp, users=1, steps=20, **kw):
+def run(comp, users=1, steps=60, **kw):
     base = dict(c_dim=16, k_bit=8, n_bit=6, no_cuda=False, random=1, ef=False, two_phase=False, scale="exp",
                 num_users=users, mode="ps", cr=256)
     base.update(kw)
@@ -20,15 +22,19 @@ def run(comp, users=1, steps=20, **kw):
     import io, contextlib
     with contextlib.redirect_stdout(io.StringIO()):
         q = Quantizer(comp, params, Namespace(**base))
-    grads = [torch.randn(p.shape, device="cuda") * 1e-3 for p in params]
+    # apply() rebinds the gradient OBJECTS to the decoded tensors: re-using one list would time the codec on its own output
+    # (codeword multiples: nothing is ever unsettled) from the second step on
+    lists = [[torch.randn(p.shape, device="cuda") * 1e-3 for p in params] for _ in range(3)]
+    feed = gradient_feeder(torch, params, lists)
+    tick = [0]
 
     def step():
         for u in range(users):
-            for p, g in zip(params, grads):
-                p.grad = g
+            feed(tick[0])
+            tick[0] += 1
             q.record(u, epoch=1)
         q.apply()
-    for _ in range(14):      # (graph replay is the default: its captures happen in the first dozen steps)
+    for _ in range(45):      # (graph replay is the default: its captures happen in the first dozen steps PER address set, three sets)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
