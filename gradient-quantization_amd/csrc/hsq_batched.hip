@@ -710,14 +710,15 @@ constexpr int DT_RB = 4;    // ... of which this many are read back from LDS tog
 #ifndef GQ_EF_LEVELS_TILE
 #define GQ_EF_LEVELS_TILE 1   // 0: round 4's one-thread-per-unit error-feedback level kernels (A/B builds)
 #endif
-// BATCH: DT_RB payloads' loads together (R >= DT_RB); without it the loops are the one-by-one ones alone (fewer registers:
-// R = 1 ... 3 ran 3-8 % slower with the batch code merely present).
-template <int D, typename LevelT, bool BATCH>
+// RB: payloads whose loads go out together (4 for R >= 4, 2 for R = 2 / 3); 0: the one-by-one loops alone (fewer registers:
+// R = 1 ran 3-8 % slower with the batch code merely present).
+template <int D, typename LevelT, int RB>
 __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
     float *__restrict__ out, int plain, const StepTail tail) {
     step_tail_run(tail);
+    constexpr int DT_RBK = RB > 0 ? RB : 1;
     constexpr int UPS = D / 4;                               // 16-byte units per subvector = passes per tile
     constexpr int RS = ((D / 4) & 1) ? D : D + 4;            // LDS row stride in floats: an odd number of 16-byte units
     __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];
@@ -766,11 +767,11 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel
             // lane = subvector: this chunk's (code, norm) pairs into the wave's slots, DT_RB payloads' loads requested together
             // (payload by payload, a tile paid R round trips to memory in a row: 43.7 us at R = 8 where one payload takes 20.9)
             int rb = 0;
-            for (; BATCH && rb + DT_RB <= nr; rb += DT_RB) {
-                unsigned code_[DT_RB];
-                float lvl_[DT_RB], lb_[DT_RB], ub_[DT_RB];
+            for (; RB > 0 && rb + DT_RBK <= nr; rb += DT_RBK) {
+                unsigned code_[DT_RBK];
+                float lvl_[DT_RBK], lb_[DT_RBK], ub_[DT_RBK];
 #pragma unroll
-                for (int k = 0; k < DT_RB; ++k) {
+                for (int k = 0; k < DT_RBK; ++k) {
                     const uint8_t *p = gathered + (int64_t)(r0 + rb + k) * user_stride;
                     const float *lbub = reinterpret_cast<const float *>(p + lbub_off);
                     lb_[k] = lbub[0];
@@ -779,7 +780,7 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel
                     code_[k] = p[code_off + lsv];
                 }
 #pragma unroll
-                for (int k = 0; k < DT_RB; ++k) {
+                for (int k = 0; k < DT_RBK; ++k) {
                     const float lb = lb_[k], range = ub_[k] - lb;
                     float n = lvl_[k] * range;   // prob_scalar:31-32, unfused
                     n = n * inv_s;               // == / 2^n_bit exactly
@@ -816,16 +817,16 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel
                     }
                 };
                 int rr = 0;
-                for (; BATCH && rr + DT_RB <= nr; rr += DT_RB) {
-                    uint2 cn[DT_RB];
-                    f32x4 c[DT_RB];
+                for (; RB > 0 && rr + DT_RBK <= nr; rr += DT_RBK) {
+                    uint2 cn[DT_RBK];
+                    f32x4 c[DT_RBK];
 #pragma unroll
-                    for (int k = 0; k < DT_RB; ++k) cn[k] = *reinterpret_cast<const uint2 *>(pairs + ((rr + k) * 64 + s) * 2);
+                    for (int k = 0; k < DT_RBK; ++k) cn[k] = *reinterpret_cast<const uint2 *>(pairs + ((rr + k) * 64 + s) * 2);
 #pragma unroll
-                    for (int k = 0; k < DT_RB; ++k) c[k] = *reinterpret_cast<const f32x4 *>(s_cb + cn[k].x * RS + 4 * q);
+                    for (int k = 0; k < DT_RBK; ++k) c[k] = *reinterpret_cast<const f32x4 *>(s_cb + cn[k].x * RS + 4 * q);
                     const bool first = r0 == 0 && rr == 0;   // (wave-uniform)
 #pragma unroll
-                    for (int k = 0; k < DT_RB; ++k) {
+                    for (int k = 0; k < DT_RBK; ++k) {
                         const float n = __uint_as_float(cn[k].y);
                         const f32x4 n4 = {n, n, n, n};
                         const f32x4 dec = c[k] * n4;
@@ -1238,19 +1239,19 @@ static void launch_decode_tile(const int64_t *seg_table, const int32_t *tile_seg
                                int64_t user_stride_bytes, int R, const float *codebook, int n_bit, float *out, int plain,
                                hipStream_t st, const StepTail &tail) {
     int64_t blocks = (ntiles + DT_WAVES - 1) / DT_WAVES;
-    if (R >= DT_RB) {
-        static const int bpc = resident_blocks_per_cu(hsq_decode_sum_batched_tile_kernel<D, LevelT, true>, DT_THREADS, 0);
-        const int64_t cap = (int64_t)cu_count() * bpc;
-        if (blocks > cap) blocks = cap;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched_tile_kernel<D, LevelT, true>), dim3((unsigned)(blocks < 1 ? 1 : blocks)),
-                           dim3(DT_THREADS), 0, st, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, R, codebook, n_bit, out, plain, tail);
-        return;
-    }
-    static const int bpc = resident_blocks_per_cu(hsq_decode_sum_batched_tile_kernel<D, LevelT, false>, DT_THREADS, 0);
-    const int64_t cap = (int64_t)cu_count() * bpc;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched_tile_kernel<D, LevelT, false>), dim3((unsigned)(blocks < 1 ? 1 : blocks)),
-                       dim3(DT_THREADS), 0, st, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, R, codebook, n_bit, out, plain, tail);
+#define GQ_DT_LAUNCH(RBV)                                                                                                        \
+    do {                                                                                                                         \
+        static const int bpc = resident_blocks_per_cu(hsq_decode_sum_batched_tile_kernel<D, LevelT, RBV>, DT_THREADS, 0);        \
+        const int64_t cap = (int64_t)cu_count() * bpc;                                                                           \
+        if (blocks > cap) blocks = cap;                                                                                          \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched_tile_kernel<D, LevelT, RBV>),                                  \
+                           dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(DT_THREADS), 0, st, seg_table, tile_seg, ntiles,      \
+                           gathered, user_stride_bytes, R, codebook, n_bit, out, plain, tail);                                   \
+    } while (0)
+    if (R >= DT_RB) GQ_DT_LAUNCH(DT_RB);
+    else if (R >= 2) GQ_DT_LAUNCH(2);
+    else GQ_DT_LAUNCH(0);
+#undef GQ_DT_LAUNCH
 }
 }  // namespace gq
 
