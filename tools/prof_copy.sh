@@ -17,7 +17,7 @@ done
 [ -f $O/bench_2ranks_gloo.json ] && cp $O/bench_2ranks_gloo.json $P/${TAG}_bench_2ranks_gloo_one_gpu.json
 for d in stats:kernel_stats stats_qsgd:qsgd_kernel_stats stats_resnet50:resnet50_kernel_stats stats_resnet50_ef:resnet50_ef_kernel_stats stats_resnet50_ef_twophase:resnet50_ef_twophase_kernel_stats stats_resnet50_main_defaults:resnet50_main_defaults_kernel_stats; do
     src=${d%%:*}; dst=${d##*:}
-    f=$(ls $O/$src/*/*kernel_stats.csv 2>/dev/null | head -1)
+    f=$(ls -t $O/$src/*/*kernel_stats.csv 2>/dev/null | head -1)      # (the newest: gpurun merges a run into what earlier runs left)
     [ -n "$f" ] && cp $f $P/${TAG}_$dst.csv
 done
 ls $P | grep "^${TAG}_" | wc -l
