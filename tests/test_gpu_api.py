@@ -1792,3 +1792,16 @@ def test_two_ranks_on_one_gpu_with_graph_replay(tmp_path, quant, ef):
     assert len(single) == len(r0.files)
     for k in single:
         assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
+
+
+def test_rccl_single_rank_exchange_calls():
+    """The non-staged exchange on the REAL collective library (RCCL cannot put two ranks on one GPU, so: one rank): an
+    all_gather_into_tensor of uint8 wire rows -- out of place for fewer rows than slots, in place for all of them -- queued
+    behind a kernel of the current stream, Work.wait(), a kernel reading the result, forty times over 3 MB rows; the grouped
+    point-to-point transport with no peers; the collectives bench.py uses around its windows (tests/_rccl_one_rank.py)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    port = 29500 + (os.getpid() % 400)
+    r = subprocess.run([sys.executable, os.path.join(here, "_rccl_one_rank.py"), str(port)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl one rank ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
