@@ -288,7 +288,7 @@ VARIANTS = {
 }
 
 # variants that are a compile-time switch of the shipped source: name -> extra hipcc flags (the source is taken as it is)
-EXTRA_FLAGS = {"counts": ["-DGQ_PF_STAMPS"], "r16": ["-DGQ_RESCORE_BATCH=16"],
+EXTRA_FLAGS = {"counts": ["-DGQ_PF_STAMPS"], "skew0": ["-DGQ_PF_SKEW_PERMILLE=0"], "skew5": ["-DGQ_PF_SKEW_PERMILLE=5"], "skew20": ["-DGQ_PF_SKEW_PERMILLE=20"], "skew30": ["-DGQ_PF_SKEW_PERMILLE=30"], "r16": ["-DGQ_RESCORE_BATCH=16"],
                # round 5's early ring flush (hsq_encode_pf.hip, PF_FLUSH_AHEAD): off / other distances from the end of the run
                "nopair": ["-DGQ_PF_PAIR=0"], "pair": ["-DGQ_PF_PAIR=1"], "tail0": ["-DGQ_PF_TAIL=0"], "tail1": ["-DGQ_PF_TAIL=1"], "tail2": ["-DGQ_PF_TAIL=2"], "tail3": ["-DGQ_PF_TAIL=3"], "tail6": ["-DGQ_PF_TAIL=6"], "fa16": ["-DGQ_PF_FLUSH_AHEAD=16"],
                "fa0": ["-DGQ_PF_FLUSH_AHEAD=0"], "fa8": ["-DGQ_PF_FLUSH_AHEAD=8"], "fa12": ["-DGQ_PF_FLUSH_AHEAD=12"],
