@@ -17,20 +17,45 @@ namespace gq {
 constexpr int QB_THREADS = 256;
 constexpr int QB_LDS_SEGS = 256;   // segment records kept in LDS by the 4-bit compress kernel (16 KiB)
 
-__device__ __forceinline__ unsigned qsgd_code(float v, float norm, float s, float smax, int random_mode,
-                                              uint64_t seed, uint64_t gidx, int bits) {
-    const float q = v / norm;
-    const float x = fabsf(q) * s;
+// The draws of this file's kernels (GQ_RANDOM_DEVICE*: the library's own numbers, only their distribution is specified):
+// element e of bucket b draws  u = top 24 bits of mix(key(seed, b) + e * phi) * 2^-24  with key = the library's three-round
+// hash of (seed, b), taken ONCE per bucket and lane, and mix = one multiply-xorshift round.  The elements of a bucket walk a
+// Weyl sequence through a bijective mixer; buckets and steps are separated by the full hash.  Round 5 ran the three-round hash
+// (and a 64-bit index) per ELEMENT: ~20 of the ~46 vector instructions an element cost.
+__device__ __forceinline__ uint32_t bucket_draw_key(uint64_t seed, int64_t b) { return uniform_bits(seed, (uint64_t)b); }
+__device__ __forceinline__ float bucket_draw(uint32_t key, uint32_t e) {
+    uint32_t h = key + e * 0x9E3779B1u;
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    return (float)(h >> 8) * 5.9604644775390625e-08f;   // k * 2^-24, the grid torch.rand uses for float32
+}
+
+// qsgd_compressor.py:50-61 for one element: |v / norm| * s, clamp, truncate, stochastic round up; the sign above the level bits.
+// FAST: |v| / norm from the bucket's ONE reciprocal y = RN(1 / norm) by Markstein's correction (shared_quotient: the correctly
+// rounded quotient, bit for bit what v_div_* gives, in three operations instead of ~11).  The caller has checked the operand
+// window 2^-80 <= norm <= 2^20 and (|v| == 0 or 2^-102 <= |v| <= norm) for every element of the lane; then no NaN can occur and
+// the quotient is >= 0: the NaN test and the lower clamp go too.
+template <bool FAST>
+__device__ __forceinline__ unsigned qsgd_code(float v, float norm, float y, float s, float smax, int random_mode, uint32_t key, uint32_t e,
+                                              int bits) {
+    const float q = FAST ? shared_quotient(fabsf(v), norm, y) : fabsf(v / norm);
+    const float x = q * s;
     unsigned l = 0;
-    if (x == x) {  // NaN (zero bucket) -> level 0
-        const float c = fminf(fmaxf(x, 0.0f), smax);
+    if (FAST || x == x) {  // NaN (zero bucket) -> level 0
+        const float c = FAST ? fminf(x, smax) : fminf(fmaxf(x, 0.0f), smax);
         l = (unsigned)(int)c;
         if (random_mode >= GQ_RANDOM_DEVICE) {   // DEVICE, or DEVICE_KEYED with the bucket's keyed seed handed in
             const float prob = x - (float)l;
-            l += (prob > uniform01(seed, gidx)) ? 1u : 0u;
+            l += (prob > bucket_draw(key, e)) ? 1u : 0u;
         }
     }
     return l | ((v > 0.0f ? 1u : 0u) << (bits - 1));
+}
+// the operand window of the FAST form for a bucket norm and the smallest |v| of the lane's elements (a lane that holds an exact
+// zero next to non-zero elements takes the division: rare outside all-zero buckets, whose norm is outside the window anyway)
+__device__ __forceinline__ bool quotient_window(float norm, float min_abs) {
+    return norm >= 0x1p-80f && norm <= 0x1p20f && min_abs >= 0x1p-102f;
 }
 
 // one wave per bucket; lane handles element pairs (2*lane, 2*lane+1), strided by 128.
@@ -72,13 +97,13 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched_kernel(
         }
         mx = wave_max_nan(mx);
         if (lane == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = mx;
-        const uint64_t g0 = (uint64_t)b << 20;  // RNG stream index: unique per (bucket, element)
         const uint64_t sd = random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, mx, mx) : seed;   // keyed by the bucket's norm
+        const uint32_t key = bucket_draw_key(sd, b);   // the draws' stream of this bucket (element index inside the bucket)
         uint8_t *dst = wire + rec[4] + ((lb * d * bits) >> 3);
         for (int e = 2 * lane; e < d; e += 128) {
             const float2 p = load(e);
-            const unsigned c0 = qsgd_code(p.x, mx, s, smax, random_mode, sd, g0 + e, bits);
-            const unsigned c1 = qsgd_code(p.y, mx, s, smax, random_mode, sd, g0 + e + 1, bits);
+            const unsigned c0 = qsgd_code<false>(p.x, mx, 0.0f, s, smax, random_mode, key, (uint32_t)e, bits);
+            const unsigned c1 = qsgd_code<false>(p.y, mx, 0.0f, s, smax, random_mode, key, (uint32_t)e + 1u, bits);
             if (bits == 4) {
                 dst[e >> 1] = (uint8_t)(c0 | (c1 << 4));
             } else if (bits == 8) {
@@ -178,7 +203,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
                     b2 = b2 + q1 * ef_scale;
                 }
             };
-            float m2 = 0.0f;
+            float m2 = 0.0f, n2 = __builtin_inff();
             for (int c = c0; 8 * c < d; c += LPB) {
                 f32x4 a, b2;
                 load8(8 * c, a, b2);
@@ -186,12 +211,19 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
                 m2 = absmax3_nan(m2, a[2], a[3]);
                 m2 = absmax3_nan(m2, b2[0], b2[1]);
                 m2 = absmax3_nan(m2, b2[2], b2[3]);
+                n2 = fminf(fminf(n2, fabsf(a[0])), fabsf(a[1]));
+                n2 = fminf(fminf(n2, fabsf(a[2])), fabsf(a[3]));
+                n2 = fminf(fminf(n2, fabsf(b2[0])), fabsf(b2[1]));
+                n2 = fminf(fminf(n2, fabsf(b2[2])), fabsf(b2[3]));
             }
 #pragma unroll
             for (int o = LPB / 2; o > 0; o >>= 1) m2 = max_nan(m2, __shfl_xor(m2, o, 64));
             if (c0 == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = m2;
             uint8_t *dst2 = wire + rec[4] + ((lb * d * BITS) >> 3);
             const uint64_t sd2 = random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, m2, m2) : seed;
+            const uint32_t key2 = bucket_draw_key(sd2, b);
+            const float y2 = 1.0f / m2;
+            const bool fast2 = quotient_window(m2, n2);
             for (int c = c0; 8 * c < d; c += LPB) {
                 f32x4 xx[2];
                 load8(8 * c, xx[0], xx[1]);
@@ -199,7 +231,8 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
                 f32x4 dec[2];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const unsigned cc = qsgd_code(xx[k >> 2][k & 3], m2, s, smax, random_mode, sd2, ((uint64_t)b << 20) + 8 * c + k, BITS);
+                    const unsigned cc = fast2 ? qsgd_code<true>(xx[k >> 2][k & 3], m2, y2, s, smax, random_mode, key2, (uint32_t)(8 * c + k), BITS)
+                                              : qsgd_code<false>(xx[k >> 2][k & 3], m2, y2, s, smax, random_mode, key2, (uint32_t)(8 * c + k), BITS);
                     code[k] = cc;
                     if (EF) {
                         float t = __uint_as_float(__float_as_uint((float)(cc & LMASK)) | (((cc >> SB) ^ 1u) << 31));
@@ -252,10 +285,11 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
             if (c0 == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = m2;
             uint8_t *dst2 = wire + rec[4] + ((lb * d * BITS) >> 3);
             const uint64_t sd2 = random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, m2, m2) : seed;
+            const uint32_t key2 = bucket_draw_key(sd2, b);
             for (int e = 2 * c0; e < d; e += 2 * LPB) {
                 const float2 p = load(e);
-                const unsigned k0 = qsgd_code(p.x, m2, s, smax, random_mode, sd2, ((uint64_t)b << 20) + e, BITS);
-                const unsigned k1 = qsgd_code(p.y, m2, s, smax, random_mode, sd2, ((uint64_t)b << 20) + e + 1, BITS);
+                const unsigned k0 = qsgd_code<false>(p.x, m2, 0.0f, s, smax, random_mode, key2, (uint32_t)e, BITS);
+                const unsigned k1 = qsgd_code<false>(p.y, m2, 0.0f, s, smax, random_mode, key2, (uint32_t)e + 1u, BITS);
                 if (BITS == 4) {
                     dst2[e >> 1] = (uint8_t)(k0 | (k1 << 4));
                 } else if (BITS == 8) {
@@ -280,7 +314,7 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
         }
         // chunk j of this lane covers elements [8 (c0 + LPB j), + 8)
         f32x4 x[2][2];
-        float mx = 0.0f;
+        float mx = 0.0f, mn = __builtin_inff();
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc) {
             const int e = 8 * (c0 + LPB * jc);
@@ -294,14 +328,19 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
                     x[jc][1] = x[jc][1] + q1 * ef_scale;
                 }
 #pragma unroll
-                for (int k = 0; k < 8; k += 2) mx = absmax3_nan(mx, x[jc][k >> 2][k & 3], x[jc][(k + 1) >> 2][(k + 1) & 3]);   // NaN-propagating
+                for (int k = 0; k < 8; k += 2) {
+                    mx = absmax3_nan(mx, x[jc][k >> 2][k & 3], x[jc][(k + 1) >> 2][(k + 1) & 3]);   // NaN-propagating
+                    mn = fminf(fminf(mn, fabsf(x[jc][k >> 2][k & 3])), fabsf(x[jc][(k + 1) >> 2][(k + 1) & 3]));   // (v_min3_f32: the lane's smallest |v|)
+                }
             }
         }
 #pragma unroll
         for (int o = LPB / 2; o > 0; o >>= 1) mx = max_nan(mx, __shfl_xor(mx, o, 64));   // the bucket's LPB lanes
         if (live && c0 == 0) reinterpret_cast<float *>(wire + rec[3])[lb] = mx;
-        const uint64_t g0 = (uint64_t)b << 20;  // RNG stream index: unique per (bucket, element)
         const uint64_t sd = random_mode == GQ_RANDOM_DEVICE_KEYED ? keyed_seed(seed, mx, mx) : seed;   // keyed by the bucket's norm
+        const uint32_t key = bucket_draw_key(sd, b);   // the draws' stream of this bucket
+        const float y = 1.0f / mx;                     // the bucket's ONE division (FAST: see qsgd_code)
+        const bool fast = quotient_window(mx, mn);
         uint8_t *dst = wire + rec[4] + ((lb * d * BITS) >> 3);
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc) {
@@ -309,11 +348,16 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
             if (e < d) {
                 unsigned code[8];
                 f32x4 dec[2];
+                if (fast) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) code[k] = qsgd_code<true>(x[jc][k >> 2][k & 3], mx, y, s, smax, random_mode, key, (uint32_t)(e + k), BITS);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) code[k] = qsgd_code<false>(x[jc][k >> 2][k & 3], mx, y, s, smax, random_mode, key, (uint32_t)(e + k), BITS);
+                }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float val = x[jc][k >> 2][k & 3];
-                    const unsigned c = qsgd_code(val, mx, s, smax, random_mode, sd, g0 + e + k, BITS);
-                    code[k] = c;
+                    const unsigned c = code[k];
                     if (EF) {
                         // qsgd_compressor.py:69-70 on this element's own code (sign on the float's sign bit)
                         float t = __uint_as_float(__float_as_uint((float)(c & LMASK)) | (((c >> SB) ^ 1u) << 31));

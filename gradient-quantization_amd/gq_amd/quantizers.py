@@ -114,6 +114,9 @@ class PSQuantizer(object):
         self.user_bytes = _up(off)          # one user's payload (all tensors)
         # tensors served by multi-tensor kernels: (class, parameter indices), built at the first record()
         self._groups = []
+        g = getattr(args, "gq_graph", None)
+        self.use_graphs = bool(int(os.environ.get("GQ_GRAPH", "1"))) if g is None else bool(g)      # (see below: gq_graph)
+        self._fuse_steps = type(self) is PSQuantizer and os.environ.get("GQ_FUSE_STEP", "1") != "0"   # (see below: _step_graphs)
         BatchedQSGD.place_lone_buckets(self.codecs)
         for cls in (BatchedHSQ, BatchedQSGD):
             keyed = {}
@@ -123,15 +126,14 @@ class PSQuantizer(object):
             for key in sorted(keyed):
                 idx = keyed[key]
                 if len(idx) >= 2 and not getattr(args, "gq_no_batch", False):
-                    self._groups.append([cls, idx, None])
+                    for part in self._overlap_chunks(idx, args):
+                        self._groups.append([cls, part, None])
         self.batch_idx = [i for g in self._groups for i in g[1]]
         self._pick_dense = operator.itemgetter(*self.dense_idx) if len(self.dense_idx) >= 2 else None
         self._pick_group = {}
         # gq_graph (args.gq_graph or $GQ_GRAPH=1): the device work of a record() for a set of gradient addresses seen before
         # is replayed as ONE HIP graph launch (the step is a launch-bound loop: ten launches and copies against ~85 us of
         # kernels).  Needs launches whose arguments do not change between records: deterministic rounding or gq_rng="keyed".
-        g = getattr(args, "gq_graph", None)
-        self.use_graphs = bool(int(os.environ.get("GQ_GRAPH", "1"))) if g is None else bool(g)
         # gq_rng = "device" (the default): the multi-tensor launches draw from streams keyed by { seed, step } pairs in device
         # memory, one pair per (tensor group, user slot) (GQ_RANDOM_DEVICE_COUNTER); every aggregate adds one to the step
         # words.  The launches' arguments never change -- they replay from a HIP graph -- and the draws are fresh every
@@ -146,7 +148,7 @@ class PSQuantizer(object):
         # $GQ_FUSE_STEP=0 keeps the two graphs.
         self._step_graphs = {}       # (record key, apply key) -> [sightings, graph or None, decoded list]
         self._fused = None           # the decoded list of a step whose record() has already replayed its apply()
-        self._fuse_steps = type(self) is PSQuantizer and os.environ.get("GQ_FUSE_STEP", "1") != "0"
+        self._side_stream = None     # the second branch of a chunked step's graph (_overlap_fractions)
         # gq_rng = "reference": the reference draws r = torch.rand(M) per compressed tensor, in parameter order, from
         # the CPU generator (probabilistic_scalar_compressor.py:23).  torch.rand is one sequential stream, so ONE
         # torch.rand(sum of M) per record (and one per two-phase apply) gives every tensor the same numbers; the
@@ -181,6 +183,58 @@ class PSQuantizer(object):
                 if c not in self.cuts:
                     self.cuts.append(c)
         self.cuts.sort()
+
+    # ---- overlap: the tensor list in chunks, a chunk's level / decode launch under the next chunk's encode ----------------
+    OVERLAP_MIN_ELEMENTS = 4 << 20      # below this a step is launch-bound: one group, as before
+
+    def _overlap_fractions(self, args):
+        """The shares of the compressed elements that the chunks of a tensor group take, or None (one group).
+        args.gq_overlap / $GQ_OVERLAP: "0" off; "auto" (the default); or the shares themselves, "0.6,0.4".
+        The compress of a tensor list is VALU-bound (HBM two thirds idle), its level / decode launch HBM-bound (VALU idle)
+        and a tensor's levels need only THAT tensor's (lb, ub) (ps_quantizer.py:33-44 treats the tensors as independent): with
+        the list in chunks, chunk i's level + decode launch runs on a second stream -- a parallel branch of the step's graph --
+        while chunk i + 1 is encoded.  Only where a whole step replays as one graph (one rank, one user per step, no
+        second phase): everywhere else more groups are just more launches."""
+        spec = getattr(args, "gq_overlap", None)
+        spec = os.environ.get("GQ_OVERLAP", "auto") if spec is None else str(spec)
+        if spec in ("0", "off", "") or not self._fuse_steps or not self.use_graphs or self.two_phase:
+            return None
+        if int(args.num_users) != 1 or _dist_world(self.process_group)[0] != 1:
+            return None
+        if spec == "auto":
+            if self.error_feedback:
+                return None
+            return [0.58, 0.42]
+        fr = [float(x) for x in spec.split(",")]
+        if len(fr) < 2 or min(fr) <= 0:
+            return None
+        return [f / sum(fr) for f in fr]
+
+    def _overlap_chunks(self, idx, args):
+        """`idx` (parameter indices of one tensor group, in wire order) cut at tensor boundaries into runs whose element counts
+        are nearest to the configured shares; every run keeps at least two tensors."""
+        fr = self._overlap_fractions(args)
+        sizes = [self.codecs[i].numel for i in idx]
+        total = sum(sizes)
+        if fr is None or total < self.OVERLAP_MIN_ELEMENTS or len(idx) < 2 * len(fr):
+            return [idx]
+        cum, acc = [], 0
+        for n in sizes:
+            acc += n
+            cum.append(acc)
+        cuts, target = [], 0.0
+        for f in fr[:-1]:
+            target += f * total
+            lo = (cuts[-1] if cuts else 0) + 2
+            cand = [k for k in range(lo, len(idx) - 1) if len(idx) - k >= 2]
+            if not cand:
+                return [idx]
+            cuts.append(min(cand, key=lambda k: abs(cum[k - 1] - target)))
+        parts, a = [], 0
+        for c in cuts + [len(idx)]:
+            parts.append(idx[a:c])
+            a = c
+        return parts if all(len(p) >= 2 for p in parts) else [idx]
 
     # ---- buffers -------------------------------------------------------------------------
     def _ensure_wire(self, device, slots):
@@ -347,14 +401,28 @@ class PSQuantizer(object):
                  if (grp is self._groups[0] and len(self.dense_idx) >= 2) else None)
         obj = grp[2] = cls(self.codecs, self.offsets, idxs, dev, self.capacity, self.user_bytes, dense=dense)
         obj.fma = bool(self.aggregate_fma and cls is BatchedHSQ)
+        if dev.type == "cuda":
+            self._ticket_for(dev, 0)      # (allocated and zeroed HERE, eagerly: a first use under stream capture would put it in a graph's pool)
         if getattr(obj, "counter", False) and len(self._groups) * self.RNG_SLOTS <= 256:
             obj.rng_pairs = self._rng_pairs_for(dev, self._groups.index(grp))
         return obj
 
-    def _record_launches(self, all_grads, wire, slot, user, salt, scale, draws, dev, headers=None, defer_resets=None, fuse_levels=False):
+    def _ticket_for(self, dev, gi):
+        """Group gi's last-workgroup counters (gq_step_tail.ticket: zero between launches; one set per group -- the groups of a
+        chunked step run their launches side by side)."""
+        if self._ticket is None or self._ticket.device != dev:
+            assert not torch.cuda.is_current_stream_capturing(), "the ticket words are made by the first eager record (_make_group)"
+            self._ticket = torch.zeros((max(1, len(self._groups)), native.TICKET_WORDS), dtype=torch.int32, device=dev)
+        return self._ticket[gi]
+
+    def _record_launches(self, all_grads, wire, slot, user, salt, scale, draws, dev, headers=None, defer_resets=None, fuse_levels=False,
+                         overlap=None):
         """The multi-tensor launches of a record (+ the dense tensors' copy into the wire) -> the set of parameters served.
         headers (stream capture): one device-resident header per group, see BatchedHSQ.encode.
-        fuse_levels (whole-step capture, _can_fuse_levels): the group's level launch is left to the aggregate's decode."""
+        fuse_levels (whole-step capture, _can_fuse_levels): the group's level launch is left to the aggregate's decode.
+        overlap (whole-step capture of a chunked list, a dict): an event is recorded behind every group's compress
+        (overlap["events"][group]) and its accumulators' reset is kept per group (overlap["resets"][group]): _decode_all puts
+        the group's level / decode launch on the side stream behind that event."""
         skip = set()
         skip_groups = []
         for grp in (self._groups if dev.type == "cuda" else []):
@@ -372,10 +440,16 @@ class PSQuantizer(object):
             skip_groups.append(obj)
             dense = list(self._pick_dense(all_grads)) if obj.ndense else None
             kw = {"skip_levels": True} if fuse_levels else {}
-            if obj.encode(grads, wire, slot, salt, errs, scale, draws=draws, graph_header=hdr, dense=dense, defer_reset=defer_resets, **kw):
+            mine = [] if overlap is not None else defer_resets
+            if obj.encode(grads, wire, slot, salt, errs, scale, draws=draws, graph_header=hdr, dense=dense, defer_reset=mine, **kw):
                 skip.update(idxs)
                 if dense is not None:
                     skip.update(self.dense_idx)      # (copied by that launch)
+                if overlap is not None:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    overlap["events"][id(obj)] = ev
+                    overlap["resets"][id(obj)] = mine
         if len(self.dense_idx) >= 2 and self.dense_idx[0] not in skip:
             # all small tensors with one concatenation straight into the packed wire region.  Under
             # error feedback their residual is identically zero (decoded == grad), so nothing else to do.
@@ -439,12 +513,24 @@ class PSQuantizer(object):
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 resets = []      # the groups' accumulator resets ride in the step's last launch
                 fuse = self._can_fuse_levels()      # one rank, one user: level launch + decode of that payload as ONE launch
+                overlap = None
+                if len(self._groups) >= 2 and all(g[2].takes_tail for g in self._groups) and os.environ.get("GQ_STEP_TAIL", "1") != "0":
+                    # a chunked list (_overlap_fractions): every group's level / decode launch (with the group's OWN tail) on the
+                    # side stream behind its compress -- a parallel branch of this graph
+                    if self._side_stream is None:
+                        self._side_stream = torch.cuda.Stream(device=dev)
+                    overlap = {"events": {}, "resets": {}, "side": self._side_stream if os.environ.get("GQ_OVERLAP_STREAMS", "1") != "0" else None}
                 self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers, defer_resets=resets,
-                                      fuse_levels=fuse)
-                decoded = self._decode_all(self._wire[:1], False, (), resets=resets, fused_levels=fuse)
+                                      fuse_levels=fuse, overlap=overlap)
+                decoded = self._decode_all(self._wire[:1], False, (), resets=resets, fused_levels=fuse, overlap=overlap)
             fent[1], fent[2] = graph, decoded
         except Exception as e:      # the two-graph replay keeps working
             self._fuse_steps = False
+            for g in self._groups:      # a launch that failed between a group's encode and its level launch: back to the shared header
+                if g[2] is not None:
+                    g[2]._graph_tables_abort()
+                    if getattr(g[2], "_pending_levels", None) is not None:
+                        g[2]._pending_levels = None
             import warnings
             warnings.warn("gq_graph: capturing a whole step failed (%s); record and apply keep their own graphs" % (e,))
         finally:
@@ -455,14 +541,15 @@ class PSQuantizer(object):
     def _can_fuse_levels(self):
         """A whole step of one rank and one user whose tensors all go through ONE HSQ group (+ the dense tensors riding in
         its launches): encode, then gq_hsq_levels_decode_batched.  $GQ_FUSE_LEVELS=0 keeps the three launches."""
-        if os.environ.get("GQ_FUSE_LEVELS", "1") == "0" or len(self._groups) != 1:
+        if os.environ.get("GQ_FUSE_LEVELS", "1") == "0" or not self._groups:
             return False
         if self.error_feedback and os.environ.get("GQ_FUSE_LEVELS") != "ef":
             # measured (profiles/r05_experiments.txt, 2): with error feedback the one launch moves three streams (updated gradient in,
             # residual and decoded tensor out) and is SLOWER than the level launch + the decode (0.1233 against 0.1158 ms per step)
             return False
-        obj = self._groups[0][2]
-        return (isinstance(obj, BatchedHSQ) and obj.fusable_levels() and (not self.dense_idx or (len(self.dense_idx) >= 2 and obj.ndense))
+        obj = self._groups[0][2]      # (several groups: the chunks of ONE tensor group, _overlap_chunks; the first carries the dense tensors)
+        return (all(isinstance(g[2], BatchedHSQ) and g[2].fusable_levels() for g in self._groups)
+                and (not self.dense_idx or (len(self.dense_idx) >= 2 and obj.ndense))
                 and os.environ.get("GQ_STEP_TAIL", "1") != "0")
 
     def _apply_key(self, gathered):
@@ -478,7 +565,7 @@ class PSQuantizer(object):
         o = self._draw_off[i]
         return {"r": draws[0][o:o + self.codecs[i].M]}
 
-    def _decode_all(self, gathered, two_phase, pending=(), plain=False, resets=None, fused_levels=False):
+    def _decode_all(self, gathered, two_phase, pending=(), plain=False, resets=None, fused_levels=False, overlap=None):
         """Mean of the R = gathered.shape[0] user payloads for every parameter (ps_quantizer.py:47-61),
         as a list of tensors in parameter order.  `pending`: the transfers that fill `gathered`
         (exchange.WireExchange.start) -- one, or one per byte range for a split / pipelined exchange, in which case the
@@ -523,20 +610,43 @@ class PSQuantizer(object):
                 self._dense_mean[k], self._dense_views[k] = mean, views
             dense_job = (rows, k)
         tail, tail_group = None, -1
-        if on_gpu and not chunked and not two_phase and os.environ.get("GQ_STEP_TAIL", "1") != "0":
+        tails = None
+        if overlap is not None:
+            # whole-step capture of a chunked list: every group's launch carries its OWN tail -- the step of its own draws' words,
+            # the reset of its own accumulators (both behind the group's last reader, whatever the other branch is doing), and the
+            # first group's also the mean of the dense tensors its compress launch copied into the wire
+            assert on_gpu and not chunked and not two_phase and [g[2] for g in groups] == [g[2] for g in self._groups]
+            mean_in_tail = dense_job is not None and not (plain and R == 1)
+            tails = {}
+            for gi, g in enumerate(groups):
+                obj = g[2]
+                rs = overlap["resets"].get(id(obj)) or []
+                pairs = (self._rng_state[gi * self.RNG_SLOTS:(gi + 1) * self.RNG_SLOTS]
+                         if (step_rng and obj.rng_pairs is not None) else None)
+                first = gi == 0 and mean_in_tail
+                if first or pairs is not None or rs:
+                    tails[gi] = native.StepTail(rows=dense_job[0] if first else None, out=self._dense_mean[dense_job[1]] if first else None,
+                                                rng_state=pairs, reset=rs[0] if rs else None, ticket=self._ticket_for(gathered.device, gi))
+                for extra in rs[1:]:
+                    resets.append(extra)
+            if step_rng and all(g[2].rng_pairs is not None for g in groups):
+                step_rng = False
+            if mean_in_tail:
+                dense_job = (None, dense_job[1])
+        elif on_gpu and not chunked and not two_phase and os.environ.get("GQ_STEP_TAIL", "1") != "0":
             takers = [gi for gi, g in enumerate(groups) if g[2].takes_tail]
             mean_in_tail = dense_job is not None and not (plain and R == 1)
             if takers and (mean_in_tail or step_rng or resets):
                 tail_group = takers[-1]
-                if self._ticket is None or self._ticket.device != gathered.device:
-                    self._ticket = torch.zeros(native.TICKET_WORDS, dtype=torch.int32, device=gathered.device)
                 tail = native.StepTail(rows=dense_job[0] if mean_in_tail else None,
                                        out=self._dense_mean[dense_job[1]] if mean_in_tail else None,
                                        rng_state=self._rng_state if step_rng else None, reset=resets.pop(0) if resets else None,
-                                       ticket=self._ticket)
+                                       ticket=self._ticket_for(gathered.device, 0))
                 step_rng = False
                 if mean_in_tail:
                     dense_job = (None, dense_job[1])      # (done by the decode launch)
+
+        main_stream = torch.cuda.current_stream() if overlap is not None else None
 
         def decode_range(lo, hi, first):
             """The tensors whose wire section starts in [lo, hi) (None: all of them)."""
@@ -548,10 +658,21 @@ class PSQuantizer(object):
                         part = seg_ranges[(gi, lo, hi)] = (sum(1 for i in idxs if self.offsets[i] < lo),
                                                           sum(1 for i in idxs if self.offsets[i] < hi))
                     part = part + (first,)
-                if fused_levels and lo is None and getattr(obj, "_pending_levels", None) is not None:
-                    group_views[gi] = obj.levels_decode(plain, tail if gi == tail_group else None)      # levels + decode (+ tail): one launch
-                else:
-                    group_views[gi] = obj.decode_mean(gathered, R, part, plain=plain, tail=tail if gi == tail_group else None)
+                t = tails.get(gi) if tails is not None else (tail if gi == tail_group else None)
+                side = overlap["side"] if overlap is not None else None
+                if side is not None:      # this group's branch: behind its compress, next to the following groups' compresses
+                    side.wait_event(overlap["events"][id(obj)])
+                    torch.cuda.set_stream(side)
+                try:
+                    if fused_levels and lo is None and getattr(obj, "_pending_levels", None) is not None:
+                        group_views[gi] = obj.levels_decode(plain, t)      # levels + decode (+ tail): one launch
+                    else:
+                        group_views[gi] = obj.decode_mean(gathered, R, part, plain=plain, tail=t)
+                finally:
+                    if side is not None:
+                        torch.cuda.set_stream(main_stream)
+            if overlap is not None and overlap["side"] is not None:
+                main_stream.wait_stream(overlap["side"])      # the branches join: the step's graph ends behind all of them
             for i in single:
                 if lo is None or lo <= self.offsets[i] < hi:
                     done[i] = self.codecs[i].decode_mean(gathered, self.offsets[i], R, plain=plain)
