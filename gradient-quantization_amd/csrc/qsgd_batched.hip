@@ -26,36 +26,51 @@ __device__ __forceinline__ uint32_t bucket_draw_key(uint64_t seed, int64_t b) { 
 __device__ __forceinline__ float bucket_draw(uint32_t key, uint32_t e) {
     uint32_t h = key + e * 0x9E3779B1u;
     h ^= h >> 16;
-    h *= 0x7FEB352Du;
-    h ^= h >> 15;
+    h *= 0x7FEB352Du;                                   // (the top 24 bits of the product are its best-mixed ones)
     return (float)(h >> 8) * 5.9604644775390625e-08f;   // k * 2^-24, the grid torch.rand uses for float32
 }
 
 // qsgd_compressor.py:50-61 for one element: |v / norm| * s, clamp, truncate, stochastic round up; the sign above the level bits.
-// FAST: |v| / norm from the bucket's ONE reciprocal y = RN(1 / norm) by Markstein's correction (shared_quotient: the correctly
-// rounded quotient, bit for bit what v_div_* gives, in three operations instead of ~11).  The caller has checked the operand
-// window 2^-80 <= norm <= 2^20 and (|v| == 0 or 2^-102 <= |v| <= norm) for every element of the lane; then no NaN can occur and
-// the quotient is >= 0: the NaN test and the lower clamp go too.
-template <bool FAST>
-__device__ __forceinline__ unsigned qsgd_code(float v, float norm, float y, float s, float smax, int random_mode, uint32_t key, uint32_t e,
+// FAST: x = RN(|v| / norm) * s from the bucket's ONE reciprocal by Markstein's correction (shared_quotient: the correctly rounded
+// quotient, bit for bit what v_div_* gives, in three operations instead of ~11) -- taken of |v| and norm / s with the reciprocal
+// y * s: s is a power of two, so RN(|v| / (norm / s)) IS RN(|v| / norm) * s and the multiplication by s goes too.  The caller has
+// checked the operand window (quotient_window) for every element of the lane; then no NaN can occur and the quotient is >= 0:
+// the NaN test and the lower clamp go as well.  The sign bit is clamp(bits(v), 0, 1) (v is finite there: > 0 iff its bits, as a
+// signed integer, are).  FAST: norm_s = norm / s, y_s = RN(1 / norm) * s; otherwise norm_s = norm and y_s is not read.
+// RND: 1 / 0 = the caller has tested random_mode once for all of a lane's elements, -1 = tested here.
+template <bool FAST, int RND = -1>
+__device__ __forceinline__ unsigned qsgd_code(float v, float norm_s, float y_s, float s, float smax, int random_mode, uint32_t key, uint32_t e,
                                               int bits) {
-    const float q = FAST ? shared_quotient(fabsf(v), norm, y) : fabsf(v / norm);
-    const float x = q * s;
-    unsigned l = 0;
-    if (FAST || x == x) {  // NaN (zero bucket) -> level 0
+    const float x = FAST ? shared_quotient(fabsf(v), norm_s, y_s) : fabsf(v / norm_s) * s;
+    unsigned l = 0, sgn;
+    if constexpr (FAST) {
+        // (as inline asm: the compiler turns min(max(bits, 0), 1) back into v_cmp + v_cndmask + v_or through VCC, with the
+        // wait states gfx950 wants between a VALU write of VCC and its VALU read)
+        asm("v_med3_i32 %0, %1, 0, 1" : "=v"(sgn) : "v"(__float_as_uint(v)));
+    } else {
+        sgn = v > 0.0f ? 1u : 0u;
+    }
+    if (!FAST && x != x) {
+        // NaN (a zero bucket's 0 / 0, a NaN norm): the reference's cast makes it INT_MIN, a NEGATIVE level, and decodes
+        // (-2^31) (2 sign - 1) norm / s (qsgd_compressor.py:53,69-70) -- for a zero bucket (-2^31)(-1)(0) = +0.  The wire's level
+        // is 0 and the level's sign goes into the sign bit: a zero bucket decodes to +0 too (round 5 wrote sign 0: -0, which
+        // only a bit-for-bit comparison of a PLAIN decode sees -- the aggregate starts from +0).
+        sgn ^= 1u;
+    } else {
         const float c = FAST ? fminf(x, smax) : fminf(fmaxf(x, 0.0f), smax);
         l = (unsigned)(int)c;
-        if (random_mode >= GQ_RANDOM_DEVICE) {   // DEVICE, or DEVICE_KEYED with the bucket's keyed seed handed in
+        if (RND == 1 || (RND == -1 && random_mode >= GQ_RANDOM_DEVICE)) {   // DEVICE, or DEVICE_KEYED with the bucket's keyed seed handed in
             const float prob = x - (float)l;
             l += (prob > bucket_draw(key, e)) ? 1u : 0u;
         }
     }
-    return l | ((v > 0.0f ? 1u : 0u) << (bits - 1));
+    return l | (sgn << (bits - 1));
 }
-// the operand window of the FAST form for a bucket norm and the smallest |v| of the lane's elements (a lane that holds an exact
-// zero next to non-zero elements takes the division: rare outside all-zero buckets, whose norm is outside the window anyway)
+// the operand window of the FAST form for a bucket norm and the smallest |v| of the lane's elements: shared_quotient needs
+// 2^-80 <= norm / s <= 2^20 (s <= 2^16) and every |v| >= 2^-102 (gq_common.hpp).  A lane that holds an exact zero next to non-zero
+// elements takes the division: rare outside all-zero buckets, whose norm is outside the window anyway.
 __device__ __forceinline__ bool quotient_window(float norm, float min_abs) {
-    return norm >= 0x1p-80f && norm <= 0x1p20f && min_abs >= 0x1p-102f;
+    return norm >= 0x1p-64f && norm <= 0x1p20f && min_abs >= 0x1p-102f;
 }
 
 // one wave per bucket; lane handles element pairs (2*lane, 2*lane+1), strided by 128.
@@ -231,8 +246,8 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
                 f32x4 dec[2];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const unsigned cc = fast2 ? qsgd_code<true>(xx[k >> 2][k & 3], m2, y2, s, smax, random_mode, key2, (uint32_t)(8 * c + k), BITS)
-                                              : qsgd_code<false>(xx[k >> 2][k & 3], m2, y2, s, smax, random_mode, key2, (uint32_t)(8 * c + k), BITS);
+                    const unsigned cc = fast2 ? qsgd_code<true>(xx[k >> 2][k & 3], m2 * inv_s, y2 * s, s, smax, random_mode, key2, (uint32_t)(8 * c + k), BITS)
+                                              : qsgd_code<false>(xx[k >> 2][k & 3], m2, 0.0f, s, smax, random_mode, key2, (uint32_t)(8 * c + k), BITS);
                     code[k] = cc;
                     if (EF) {
                         float t = __uint_as_float(__float_as_uint((float)(cc & LMASK)) | (((cc >> SB) ^ 1u) << 31));
@@ -348,12 +363,15 @@ __global__ __launch_bounds__(QB_THREADS) void qsgd_compress_batched4_kernel(
             if (e < d) {
                 unsigned code[8];
                 f32x4 dec[2];
-                if (fast) {
+                if (fast && random_mode >= GQ_RANDOM_DEVICE) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) code[k] = qsgd_code<true>(x[jc][k >> 2][k & 3], mx, y, s, smax, random_mode, key, (uint32_t)(e + k), BITS);
+                    for (int k = 0; k < 8; ++k) code[k] = qsgd_code<true, 1>(x[jc][k >> 2][k & 3], mx * inv_s, y * s, s, smax, random_mode, key, (uint32_t)(e + k), BITS);
+                } else if (fast) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) code[k] = qsgd_code<true, 0>(x[jc][k >> 2][k & 3], mx * inv_s, y * s, s, smax, random_mode, key, (uint32_t)(e + k), BITS);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) code[k] = qsgd_code<false>(x[jc][k >> 2][k & 3], mx, y, s, smax, random_mode, key, (uint32_t)(e + k), BITS);
+                    for (int k = 0; k < 8; ++k) code[k] = qsgd_code<false>(x[jc][k >> 2][k & 3], mx, 0.0f, s, smax, random_mode, key, (uint32_t)(e + k), BITS);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {

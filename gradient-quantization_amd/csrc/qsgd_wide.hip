@@ -120,8 +120,10 @@ __device__ __forceinline__ unsigned wide_code(float v, float norm, float s, floa
                                               uint64_t gidx, int bits) {
     const float q = v / norm;
     const float x = fabsf(q) * s;
-    unsigned l = 0;
-    if (x == x) {  // NaN (zero bucket) -> level 0
+    unsigned l = 0, sgn = v > 0.0f ? 1u : 0u;
+    if (x != x) {  // NaN (zero bucket) -> level 0 carrying the sign of the reference's INT_MIN level (qsgd_batched.hip: qsgd_code)
+        sgn ^= 1u;
+    } else {
         const float c = fminf(fmaxf(x, 0.0f), smax);
         l = (unsigned)(int)c;
         if (random_mode >= GQ_RANDOM_DEVICE) {   // DEVICE, or DEVICE_KEYED with the keyed seed handed in
@@ -129,7 +131,7 @@ __device__ __forceinline__ unsigned wide_code(float v, float norm, float s, floa
             l += (prob > uniform01(seed, gidx)) ? 1u : 0u;
         }
     }
-    return l | ((v > 0.0f ? 1u : 0u) << (bits - 1));
+    return l | (sgn << (bits - 1));
 }
 
 template <bool EF, int BITS>

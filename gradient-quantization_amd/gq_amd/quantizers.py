@@ -188,23 +188,20 @@ class PSQuantizer(object):
     OVERLAP_MIN_ELEMENTS = 4 << 20      # below this a step is launch-bound: one group, as before
 
     def _overlap_fractions(self, args):
-        """The shares of the compressed elements that the chunks of a tensor group take, or None (one group).
-        args.gq_overlap / $GQ_OVERLAP: "0" off; "auto" (the default); or the shares themselves, "0.6,0.4".
-        The compress of a tensor list is VALU-bound (HBM two thirds idle), its level / decode launch HBM-bound (VALU idle)
-        and a tensor's levels need only THAT tensor's (lb, ub) (ps_quantizer.py:33-44 treats the tensors as independent): with
-        the list in chunks, chunk i's level + decode launch runs on a second stream -- a parallel branch of the step's graph --
-        while chunk i + 1 is encoded.  Only where a whole step replays as one graph (one rank, one user per step, no
-        second phase): everywhere else more groups are just more launches."""
+        """The shares of the compressed elements that the chunks of a tensor group take, or None (one group: the default).
+        args.gq_overlap / $GQ_OVERLAP: the shares, e.g. "0.58,0.42"; "0" (default): off.
+        EXPERIMENT, measured and not the default (profiles/r06_overlap_ab.txt): the compress of a tensor list is VALU-bound, its
+        level / decode launch HBM-bound, and a tensor's levels need only THAT tensor's (lb, ub) (ps_quantizer.py:33-44 treats
+        the tensors as independent), so with the list in chunks, chunk i's level + decode launch can run on a second stream -- a
+        parallel branch of the step's graph -- while chunk i + 1 is encoded.  The kernels do run side by side, but every extra
+        encode launch costs ~10 us of fixed time and every edge between two hardware queues 5-9 us: 94 against 68.5 us per
+        ResNet-50 step.  Only where a whole step replays as one graph (one rank, one user per step, no second phase)."""
         spec = getattr(args, "gq_overlap", None)
-        spec = os.environ.get("GQ_OVERLAP", "auto") if spec is None else str(spec)
+        spec = os.environ.get("GQ_OVERLAP", "0") if spec is None else str(spec)
         if spec in ("0", "off", "") or not self._fuse_steps or not self.use_graphs or self.two_phase:
             return None
         if int(args.num_users) != 1 or _dist_world(self.process_group)[0] != 1:
             return None
-        if spec == "auto":
-            if self.error_feedback:
-                return None
-            return [0.58, 0.42]
         fr = [float(x) for x in spec.split(",")]
         if len(fr) < 2 or min(fr) <= 0:
             return None

@@ -838,6 +838,71 @@ def test_batched_qsgd_compress_divides_like_the_reference_at_every_scale(span, o
         assert np.array_equal(gb[k].cpu().numpy().reshape(-1), want), s
 
 
+@pytest.mark.parametrize("d,n_bit", [(128, 2), (128, 1), (32, 2), (8, 4), (256, 6), (512, 2), (64, 8), (16, 5), (2048, 2), (24, 2)])
+def test_batched_qsgd_shared_quotient_equals_the_division_over_the_exponent_range(d, n_bit, oracle):
+    """Round 6: |v| / norm comes from ONE reciprocal per bucket and Markstein's correction inside the operand window
+    (2^-80 <= norm <= 2^20, every non-zero |v| of the lane >= 2^-102) and from the true division outside it
+    (qsgd_batched.hip: qsgd_code<FAST>, quotient_window).  Buckets with norms from 2^-140 to 2^60 -- the window's two ends to the
+    ulp among them --, elements up to 2^-70 below their bucket's norm, exact zeros, zero buckets, NaN: the wire's
+    decode equals the oracle's decompress(compress(g)) (qsgd_compressor.py:49-53,66-71) bit for bit, NaN for NaN."""
+    from gq_amd.compressors import QSGDCompressor
+    from gq_amd.quantizers import QSGDCodec
+    rng = np.random.RandomState(1000 * d + n_bit)
+    Mb = 6000 if d <= 256 else 700
+    x = rng.standard_normal((Mb, d)).astype(np.float32)
+    x *= np.exp2(rng.uniform(-140, 60, (Mb, 1))).astype(np.float32)                          # the bucket's scale
+    small = rng.random_sample((Mb, d)) < 0.2
+    x = np.where(small, x * np.exp2(-rng.uniform(0, 70, (Mb, d))).astype(np.float32), x)     # elements far below the norm
+    x = np.where(rng.random_sample((Mb, d)) < 0.05, np.float32(0), x).astype(np.float32)     # exact zeros
+    edges = np.array([2.0 ** -80, np.nextafter(np.float32(2.0 ** -80), np.float32(0)), 2.0 ** 20, np.nextafter(np.float32(2.0 ** 20), np.float32(np.inf)),
+                      2.0 ** -102, 2.0 ** -126, 1e-45], dtype=np.float32)
+    for k, e in enumerate(edges):      # a bucket whose norm IS the value, and one that holds it next to a norm of 1 / 2^-80
+        x[k] = np.clip(x[k] / np.abs(x[k]).max(), -1, 1) * e
+        x[k, 0] = e
+        x[20 + k, 1] = e if e <= 1 else 1.0
+        x[20 + k, 0] = 1.0 if k % 2 else np.float32(2.0 ** -80)
+    x[40] = 0.0
+    x[43, 0] = np.nan      # (a bucket with an infinite element: the packed wire has no code for the reference's INT_MIN level -- DESIGN.md section 2)
+    codec = QSGDCodec(QSGDCompressor(x.size, x.shape, make_args(c_dim=d, n_bit=n_bit)), x.size, x.shape)
+    assert codec.bits in (4, 8, 16)
+    got = codec.roundtrip(torch.from_numpy(x).cuda(), 0).cpu().numpy()
+    with np.errstate(all="ignore"):
+        norm, signs, levels = oracle.qsgd_compress(x.reshape(-1), d, n_bit, 0)
+        want = oracle.qsgd_decompress(norm, signs, levels, d, n_bit).reshape(x.shape)
+    assert _same(got, want)
+
+
+def test_batched_qsgd_device_draws_round_without_bias():
+    """The draws of the bucketed kernels (round 6: one full hash per bucket, one multiply-xorshift round per element): the level of
+    every element is floor or floor + 1 of |v| / norm * s, and over many elements the share rounded up equals the mean
+    fractional part -- overall, per position inside the bucket, and for two seeds that share no draws."""
+    from gq_amd.compressors import QSGDCompressor
+    from gq_amd.quantizers import QSGDCodec
+    d, n_bit, Mb = 128, 2, 40000
+    torch.manual_seed(11)
+    x = torch.randn(Mb, d, device="cuda")
+    det = QSGDCodec(QSGDCompressor(x.numel(), x.shape, make_args(c_dim=d, n_bit=n_bit, random=0)), x.numel(), x.shape)
+    rnd = QSGDCodec(QSGDCompressor(x.numel(), x.shape, make_args(c_dim=d, n_bit=n_bit, random=1)), x.numel(), x.shape)
+    norm = x.abs().max(dim=1, keepdim=True)[0]
+    s = float(2 ** n_bit)
+    scaled = (x / norm).abs() * s
+    floor = torch.clamp(scaled, 0, s - 1).floor()
+    frac = (scaled - floor).double()
+    lv0 = (det.roundtrip(x, 0).abs() * s / norm).round()
+    assert torch.equal(lv0, floor)
+    ups = []
+    for salt in (1, 2):
+        lv = (rnd.roundtrip(x, salt).abs() * s / norm).round()
+        up = lv - floor
+        assert float(up.min()) >= 0 and float(up.max()) <= 1
+        assert abs(float(up.double().mean()) - float(frac.mean())) < 2e-3
+        per_pos = (up.double().mean(0) - frac.mean(0)).abs().max()      # 40,000 draws per position: sigma ~ 2e-3
+        assert float(per_pos) < 1.2e-2, float(per_pos)
+        ups.append(up)
+    agree = float((ups[0] == ups[1]).double().mean())
+    assert 0.5 < agree < 0.9, agree      # independent draws agree where both round the same way by chance, not everywhere
+
+
 @pytest.mark.parametrize("kw", [dict(n_bit=8), dict(n_bit=8, c_dim=512, ef=True), dict(n_bit=5), dict(n_bit=8, c_dim=32), dict(n_bit=2, c_dim=32),
                                 dict(n_bit=5, c_dim=64), dict(n_bit=2, c_dim=16), dict(n_bit=8, c_dim=16, ef=True), dict(n_bit=4, c_dim=256),
                                 dict(n_bit=2, c_dim=8), dict(n_bit=8, c_dim=64, ef=True), dict(n_bit=2, c_dim=512), dict(n_bit=4, c_dim=512, ef=True)])
@@ -904,8 +969,8 @@ def test_batched_packed_qsgd_equals_per_tensor_and_reference_arithmetic(kw, orac
 def test_qsgd_extreme_bucket_scales_match_the_oracle(n_bit, oracle):
     """The packed QSGD compress on bucket scales from 1e-38 (subnormal elements) to 1e30, elements 30 orders of magnitude
     below their bucket's norm, zero and single-spike buckets, NaN / inf buckets: levels, signs and norms equal the
-    oracle's (the reference's `v / norm`).  (A three-operation shared-divisor quotient like pvq.hip's was tried here: the
-    per-element domain check it needs costs what it saves, 34 us either way.)"""
+    oracle's (the reference's `v / norm`).  (Round 6: inside its operand window the quotient comes from one reciprocal per bucket
+    and Markstein's correction, with ONE window test per lane -- round 5's per-element test cost what it saved.)"""
     from gq_amd.compressors import QSGDCompressor
     from gq_amd.quantizers import QSGDCodec
     rng = np.random.RandomState(n_bit)
@@ -937,7 +1002,15 @@ def test_qsgd_extreme_bucket_scales_match_the_oracle(n_bit, oracle):
         codes = raw
     lv = np.where(levels < 0, 0, levels)                               # INT_MIN (NaN quotient) is level 0 on the packed wire
     assert np.array_equal(codes & ((1 << (codec.bits - 1)) - 1), lv.astype(np.uint8))
-    assert np.array_equal(codes >> (codec.bits - 1), signs)
+    # a NaN quotient's level (INT_MIN in the reference: negative) carries its sign in the sign bit, so that level 0 decodes to
+    # the zero the reference decodes (-2^31)(2 sign - 1)(norm) / s to: +0 for a zero bucket
+    assert np.array_equal(codes >> (codec.bits - 1), np.where(levels < 0, 1 - signs.astype(np.uint8), signs))
+    dec = torch.empty(x.size, dtype=torch.float32, device="cuda")
+    codec.decode_wire(wire, 0, dec)
+    with np.errstate(all="ignore"):
+        want = oracle.qsgd_decompress(norm, signs, levels, d, n_bit).reshape(-1)
+    finite_norm = np.repeat(np.isfinite(norm), d)      # (an infinite norm: the reference's INT_MIN level times inf has no code on the packed wire)
+    assert _same(dec.cpu().numpy()[finite_norm], want[finite_norm])
 
 
 @pytest.mark.parametrize("kw", [dict(c_dim=128, n_bit=2), dict(c_dim=0, n_bit=1), dict(c_dim=512, n_bit=8)],
