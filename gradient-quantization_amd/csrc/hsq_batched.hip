@@ -873,7 +873,7 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel
 template <int D, typename LevelT, bool OUT>
 __global__ __launch_bounds__(DT_THREADS) void hsq_levels_ef_tile_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
-    const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
+    const float *__restrict__ u_flat, const unsigned *seg_minmax, int n_bit, int random_mode,      // (seg_minmax: NOT restrict -- OUT's last workgroup rewrites these words through ft.reset_dst)
     uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire,
     const int64_t *__restrict__ dense_table, int ndense, int write_error, float *__restrict__ out, int plain, const FusedTail ft) {
     resolve_seed(random_mode, seed);
@@ -1009,6 +1009,7 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_levels_ef_tile_kernel(
         // barrier above is behind every wave's last tile), what comes after the last add are the last workgroup's WRITES.
         // (A __threadfence() here -- buffer_wbl2: the XCD L2's dirty lines, i.e. the launch's own output, written back by
         // every workgroup -- made this a 57 us launch instead of 19.)
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);      // compiler-only: no load of the words may be sunk or re-issued behind the adds below
         if (threadIdx.x == 0) {
             const unsigned shard = blockIdx.x & (GQ_TICKET_SHARDS - 1);
             const unsigned members = (gridDim.x - shard + GQ_TICKET_SHARDS - 1) / GQ_TICKET_SHARDS;      // workgroups b with b % 16 == shard

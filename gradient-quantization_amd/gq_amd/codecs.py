@@ -43,6 +43,11 @@ class DenseCodec(object):
     def roundtrip(self, grad, salt):
         return grad.clone()
 
+    def encode_decode_into(self, grad, wire_user, off, salt, out):
+        """encode_into + the decode of what was written (error feedback, ps_quantizer.py:37: the residual is zero)."""
+        self.encode_into(grad, wire_user, off, salt)
+        out.copy_(grad.reshape(-1))
+
     def decode_mean(self, gathered, off, R, plain=False):
         # [R, numel] view of the gathered wire; stack().mean(0) of the reference (plain: the one payload as it is)
         rows = gathered[:, off:off + self.numel * 4].view(torch.float32)
@@ -79,6 +84,12 @@ class GenericCodec(object):
 
     def encode_into(self, grad, wire_user, off, salt):
         wire_user[off:off + self.numel * 4].view(torch.float32).copy_(self.roundtrip(grad, salt).reshape(-1))
+
+    def encode_decode_into(self, grad, wire_user, off, salt, out):
+        """ONE decompress(compress(grad)) (ps_quantizer.py:37): it is both what travels and what the residual is taken against
+        (a compressor that rounds stochastically must not be asked twice)."""
+        self.encode_into(grad, wire_user, off, salt)
+        out.copy_(wire_user[off:off + self.numel * 4].view(torch.float32))
 
     def decode_mean(self, gathered, off, R, plain=False):
         rows = gathered[:, off:off + self.numel * 4].view(torch.float32)
@@ -505,10 +516,12 @@ class _BatchedBase(object):
         self._events[slot].record()
         return True
 
-    def _counter_seed(self, slot):
+    def _counter_seed(self, slot, reserved=False):
         """GQ_RANDOM_DEVICE_COUNTER: the address of this group's { seed, step } pair of user slot `slot`, or None when the
-        quantizer gave the group no pairs (a codec used on its own) or not enough of them."""
-        if self.rng_pairs is None or not 0 <= slot < self.rng_pairs.shape[0]:
+        quantizer gave the group no pairs (a codec used on its own) or not enough of them.  The LAST pair is reserved for the
+        two-phase re-compress (its seed is the same on every rank): a record() of a user slot that high gets None -- a fresh
+        per-call seed -- unless the caller asks for the reserved pair by name (reserved=True)."""
+        if self.rng_pairs is None or not 0 <= slot < self.rng_pairs.shape[0] - (0 if reserved else 1):
             return None
         return self.rng_pairs.data_ptr() + 16 * slot
 
@@ -683,7 +696,7 @@ class BatchedHSQ(_BatchedBase):
             self._batch.set_dense(self.dense_table_dev() if dense is not None else None, self.ndense)
             self._acc_clean = False
         ef = ef_scale if errs is not None else None
-        rng_slot = slot if rng_slot is None else rng_slot
+        counter_seed = self._counter_seed(slot) if rng_slot is None else self._counter_seed(rng_slot, reserved=True)
         try:
             self._batch.encode(wire_user, ef, self.profile_slot)
             self.profile_slot = -1
@@ -693,8 +706,8 @@ class BatchedHSQ(_BatchedBase):
                 mode, seed, r_flat = native.RANDOM_GIVEN, 0, self._given_draws(draws)
             elif self.keyed:
                 mode, seed, r_flat = native.RANDOM_DEVICE_KEYED, (salt * 0x2545F4914F6CDD1D + 0x5851F42D4C957F2D) & (2 ** 63 - 1), None
-            elif self.counter and self._counter_seed(rng_slot) is not None:
-                mode, seed, r_flat = native.RANDOM_DEVICE_COUNTER, self._counter_seed(rng_slot), None
+            elif self.counter and counter_seed is not None:
+                mode, seed, r_flat = native.RANDOM_DEVICE_COUNTER, counter_seed, None
             elif self.random:
                 mode, seed, r_flat = native.RANDOM_DEVICE, _next_seed() ^ salt, None
             else:
@@ -846,7 +859,7 @@ class BatchedQSGD(_BatchedBase):
                rng_slot=None):
         """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place).
         graph_header, dense, rng_slot: see BatchedHSQ.encode."""
-        rng_slot = slot if rng_slot is None else rng_slot
+        counter_seed = self._counter_seed(slot) if rng_slot is None else self._counter_seed(rng_slot, reserved=True)
         if graph_header is not None:
             self._graph_tables(graph_header, dense)
         elif not self._upload(tensors, slot, 8, errs, dense):
@@ -856,8 +869,8 @@ class BatchedQSGD(_BatchedBase):
             self._acc_clean = False
         if self.keyed:      # gq_rng = "keyed": every bucket's draws keyed by its norm, the seed never changes
             mode, seed = native.RANDOM_DEVICE_KEYED, (salt * 0x2545F4914F6CDD1D + 0x5851F42D4C957F2D) & (2 ** 63 - 1)
-        elif self.counter and self._counter_seed(rng_slot) is not None:      # gq_rng = "device": keyed by the slot's device step word
-            mode, seed = native.RANDOM_DEVICE_COUNTER, self._counter_seed(rng_slot)
+        elif self.counter and counter_seed is not None:      # gq_rng = "device": keyed by the slot's device step word
+            mode, seed = native.RANDOM_DEVICE_COUNTER, counter_seed
         else:
             mode = native.RANDOM_DEVICE if self.random else native.RANDOM_OFF
             seed = (_next_seed() ^ salt) if self.random else 0

@@ -41,11 +41,32 @@ def _rng_mode(args):
     return mode
 
 
+_seed_source = [None]      # a callable that replaces the process-local stream below while it is set (shared_seeds)
+
+
 def _next_seed():
     """A fresh 63-bit seed per call for the in-kernel generator, derived from torch's CPU
     seed so that torch.manual_seed() makes runs reproducible."""
+    if _seed_source[0] is not None:
+        return _seed_source[0]()
     _seed_counter[0] += 1
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0] * 0xD1B54A32D192ED03) & (2 ** 63 - 1)
+
+
+class shared_seeds(object):
+    """with shared_seeds(source): every _next_seed() inside comes from `source()` instead of this process's torch seed and call
+    count.  The parameter-server quantizer wraps the replicated second phase (ps_quantizer.py:52-61) in it with a source all ranks
+    share, so that whatever path the re-compress takes (multi-tensor launches without device step words, per-tensor codecs, any
+    compressor object) the ranks round identically -- whatever their own torch seeds are."""
+
+    def __init__(self, source):
+        self.source = source
+
+    def __enter__(self):
+        self.prev, _seed_source[0] = _seed_source[0], self.source
+
+    def __exit__(self, *exc):
+        _seed_source[0] = self.prev
 
 
 def _require_device(t, what):

@@ -30,7 +30,7 @@ import os
 import torch
 
 from . import exchange, native
-from .compressors import IdenticalCompressor, _next_seed
+from .compressors import IdenticalCompressor, _next_seed, shared_seeds
 
 # The C++ walks of the parameter list (csrc/host_ext.cpp -> gq_amd/_gq_host.so, built by build.py): the grads, their
 # addresses as one bytes key and the "all plain f32" flag in one pass; `.data =` for all parameters in another.  A step
@@ -149,6 +149,8 @@ class PSQuantizer(object):
         self._step_graphs = {}       # (record key, apply key) -> [sightings, graph or None, decoded list]
         self._fused = None           # the decoded list of a step whose record() has already replayed its apply()
         self._side_stream = None     # the second branch of a chunked step's graph (_overlap_fractions)
+        self._phase2_base = None     # the seed base all ranks share for the replicated second phase (_second_phase_base)
+        self._phase2_calls = 0
         # gq_rng = "reference": the reference draws r = torch.rand(M) per compressed tensor, in parameter order, from
         # the CPU generator (probabilistic_scalar_compressor.py:23).  torch.rand is one sequential stream, so ONE
         # torch.rand(sum of M) per record (and one per two-phase apply) gives every tensor the same numbers; the
@@ -262,19 +264,46 @@ class PSQuantizer(object):
 
     def _rng_pairs_for(self, device, group_index):
         """This group's rows of the quantizer's { seed, step } array (made on first use; seeds from torch's seed, the
-        rank, the group and the slot; steps start at 0).  The two-phase slot's seed leaves the rank out: the second
-        phase runs replicated on every rank and must round identically everywhere (ps_quantizer.py:52-61 runs it once,
-        on the server); the step words advance in lockstep on all ranks."""
+        rank, the group and the slot; steps start at 0).  The two-phase slot's seed comes from the base ALL ranks share
+        (_second_phase_base) and leaves the rank out: the second phase runs replicated on every rank and must round identically
+        everywhere (ps_quantizer.py:52-61 runs it once, on the server); the step words advance in lockstep on all ranks."""
         if self._rng_state is None or self._rng_state.device != device:
             world, rank = _dist_world(self.process_group)
             n = max(1, len(self._groups)) * self.RNG_SLOTS
             host = torch.zeros((n, 2), dtype=torch.int64)
             base = _next_seed()
+            shared = self._second_phase_base(device) if self.two_phase else base
             for i in range(n):
-                r = 0 if i % self.RNG_SLOTS == self.TWO_PHASE_RNG_SLOT else rank
-                host[i, 0] = ((base ^ ((r * 1000003 + i + 1) * 0x9E3779B97F4A7C15)) & (2 ** 63 - 1))
+                if i % self.RNG_SLOTS == self.TWO_PHASE_RNG_SLOT:
+                    host[i, 0] = ((shared ^ ((i + 1) * 0x9E3779B97F4A7C15)) & (2 ** 63 - 1))
+                else:
+                    host[i, 0] = ((base ^ ((rank * 1000003 + i + 1) * 0x9E3779B97F4A7C15)) & (2 ** 63 - 1))
             self._rng_state = host.to(device)
         return self._rng_state[group_index * self.RNG_SLOTS:(group_index + 1) * self.RNG_SLOTS]
+
+    def _second_phase_base(self, device):
+        """The seed base of the replicated second phase: rank 0's, broadcast ONCE over the process group (a collective: every
+        rank reaches it at its first two-phase record / apply).  Ranks that seed torch differently -- per-rank data augmentation
+        is the usual reason -- would otherwise round the second phase differently, apply different gradients and carry different
+        server residuals, silently."""
+        if self._phase2_base is None:
+            base = _next_seed()
+            world, rank = _dist_world(self.process_group)
+            if world > 1:
+                import torch.distributed as dist
+                on_gpu = device.type == "cuda" and dist.get_backend(self.process_group) != "gloo"
+                t = torch.tensor([base], dtype=torch.int64, device=device if on_gpu else "cpu")
+                dist.broadcast(t, src=0 if self.process_group is None else dist.get_global_rank(self.process_group, 0),
+                               group=self.process_group)
+                base = int(t.item())
+            self._phase2_base, self._phase2_calls = base, 0
+        return self._phase2_base
+
+    def _second_phase_seed(self):
+        """The _next_seed() of the second phase (shared_seeds): the shared base and a call count that advances in lockstep on all
+        ranks (the second phase makes the same calls everywhere)."""
+        self._phase2_calls += 1
+        return (self._phase2_base * 0x9E3779B97F4A7C15 + self._phase2_calls * 0xD1B54A32D192ED03) & (2 ** 63 - 1)
 
     def _draws(self, device):
         """One torch.rand for all reference-parity tensors of this record / two-phase apply -> (device tensor, offsets)."""
@@ -377,8 +406,9 @@ class PSQuantizer(object):
                     decoded = torch.empty(grad.numel(), dtype=torch.float32, device=grad.device)
                     codec.decode_wire(wire, off, decoded)
                     decoded = decoded.view(param.shape)
-                else:
-                    decoded = codec.roundtrip(grad, salt)
+                else:      # (round 6: such a codec's payload never reached the wire under error feedback -- zeros were aggregated)
+                    raise TypeError("%s has neither encode_decode_into nor decode_wire: under error feedback its payload must be both "
+                                    "written to the wire and decoded (ps_quantizer.py:37)" % type(codec).__name__)
                 if grad.device.type == "cuda" and grad.is_contiguous():
                     err = torch.empty_like(grad)
                     native.sub(grad, decoded.contiguous(), err)
@@ -683,14 +713,17 @@ class PSQuantizer(object):
                 pnd.wait()
                 decode_range(pnd.lo, self.user_bytes if pnd.hi is None else pnd.hi, k == 0)
         draws2 = self._draws(gathered.device) if two_phase else None     # the second phase compresses again: new draws
+        if two_phase:
+            self._second_phase_base(gathered.device)
         sources = []        # the lists of output views this call's result is assembled from (persistent objects, see below)
         for gi, (cls, idxs, obj) in enumerate(groups):
             gs = group_views[gi]
             if two_phase:
-                # ps_quantizer.py:52-61, replicated on every rank (salt 0, same call count); with error
+                # ps_quantizer.py:52-61, replicated on every rank (salt 0, the ranks' shared seed stream); with error
                 # feedback g += server_error and server_error = g - decoded happen inside the launches
                 serr = [self.parameters[i].server_error for i in idxs] if self.error_feedback else None
-                dec = obj.roundtrip(list(gs), self.capacity, 0, serr, 1.0, draws=draws2, rng_slot=self.TWO_PHASE_RNG_SLOT)
+                with shared_seeds(self._second_phase_seed):
+                    dec = obj.roundtrip(list(gs), self.capacity, 0, serr, 1.0, draws=draws2, rng_slot=self.TWO_PHASE_RNG_SLOT)
                 if dec is None:     # not batchable this step: per-tensor second phase below
                     for i, g in zip(idxs, gs):
                         done[i] = g
@@ -737,16 +770,17 @@ class PSQuantizer(object):
                 done[i] = v
         if two_phase:
             for i in single:
-                # ps_quantizer.py:52-61 -- identical on every rank (salt 0, same call count)
+                # ps_quantizer.py:52-61 -- identical on every rank (salt 0, the ranks' shared seed stream)
                 param, codec, g = self.parameters[i], self.codecs[i], done[i]
                 kw = self._slice(draws2, i)
-                if self.error_feedback:
-                    g = g + param.server_error
-                    decoded = codec.roundtrip(g, 0, **kw)
-                    param.server_error = g - decoded
-                    g = decoded
-                else:
-                    g = codec.roundtrip(g, 0, **kw)
+                with shared_seeds(self._second_phase_seed):
+                    if self.error_feedback:
+                        g = g + param.server_error
+                        decoded = codec.roundtrip(g, 0, **kw)
+                        param.server_error = g - decoded
+                        g = decoded
+                    else:
+                        g = codec.roundtrip(g, 0, **kw)
                 done[i] = g
         return [done[i] for i in range(self.num_layers)]
 

@@ -68,7 +68,7 @@ if __name__ == "__main__":
     for kv in (sys.argv[8].split(",") if len(sys.argv) > 8 and sys.argv[8] else []):
         k, v = kv.split("=")
         extra[k] = int(v)
-    torch.manual_seed(1234)     # what "identical on every rank" (ps_quantizer.py:52-61 replicated) presupposes
+    torch.manual_seed(1234 + 31 * rank)     # per-rank seeds: the replicated second phase (ps_quantizer.py:52-61) must not depend on them
     q, params = build(local, mode, quant, ef=ef, **extra)
     res = run(q, params, local, rank * local)
     np.savez(out + "_rank%d.npz" % rank, **res)

@@ -447,6 +447,49 @@ def test_quantizer_ranks_gloo_packed6_levels(tmp_path, oracle, world, users, mod
         assert np.array_equal(single[k].view(np.uint32), r0[k].view(np.uint32)), k
 
 
+@pytest.mark.parametrize("ef", [False, True])
+def test_two_phase_rounds_identically_on_ranks_with_different_torch_seeds(tmp_path, ef):
+    """--two-phase: the second phase (ps_quantizer.py:52-61) runs replicated on every rank.  Its stochastic rounding must not
+    depend on a rank's own torch seed or on how many seeds the rank has drawn before (round-5 advisor): the seeds of the second
+    phase come from rank 0's base, broadcast once (PSQuantizer._second_phase_base), through every path that calls
+    _next_seed().  Two gloo ranks seeded differently, a compressor that seeds its draws from _next_seed(): applied gradients
+    and server residuals are bit-equal on both ranks, step after step -- and the first phase does differ between them."""
+    script = os.path.join(HERE, "_dist_worker_seeds.py")
+    out = str(tmp_path / "res")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() * 3 + 977 + int(ef)) % 2000), OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", out, "1" if ef else "0"], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r0, r1 = np.load(out + "_rank0.npz"), np.load(out + "_rank1.npz")
+    assert len(r0.files) == 3 * 3 * (2 if ef else 1)
+    for k in r0.files:
+        assert np.array_equal(r0[k].view(np.uint32), r1[k].view(np.uint32)), "ranks disagree on " + k
+    assert any(np.abs(r0[k]).max() > 0 for k in r0.files if "_p" in k)
+
+
+def test_shared_seeds_scope_and_reserved_rng_pair():
+    """compressors.shared_seeds replaces _next_seed() inside the block only; a multi-tensor group hands the LAST { seed, step }
+    pair (the two-phase re-compress's, rank-free) to nobody but a caller that names it (round-5 advisor: user slot 16 drew from it)."""
+    from gq_amd import compressors
+    from gq_amd.codecs import _BatchedBase
+    a = compressors._next_seed()
+    with compressors.shared_seeds(lambda: 42):
+        assert compressors._next_seed() == 42 and compressors._next_seed() == 42
+        with compressors.shared_seeds(lambda: 7):
+            assert compressors._next_seed() == 7
+        assert compressors._next_seed() == 42
+    b = compressors._next_seed()
+    assert a != b and b != 42
+    grp = _BatchedBase.__new__(_BatchedBase)
+    grp.rng_pairs = torch.zeros((17, 2), dtype=torch.int64)
+    base = grp.rng_pairs.data_ptr()
+    assert grp._counter_seed(0) == base and grp._counter_seed(15) == base + 16 * 15
+    assert grp._counter_seed(16) is None and grp._counter_seed(17) is None and grp._counter_seed(-1) is None
+    assert grp._counter_seed(16, reserved=True) == base + 16 * 16 and grp._counter_seed(17, reserved=True) is None
+    grp.rng_pairs = None
+    assert grp._counter_seed(0) is None
+
+
 @pytest.mark.parametrize("exchange", ["allgather", "direct", "split"])
 def test_quantizer_ranks_gloo_fewer_records_than_slots(tmp_path, oracle, exchange):
     """args.num_users = 3 wire slots per rank, but only 2 users are recorded per step: the exchange moves the used
