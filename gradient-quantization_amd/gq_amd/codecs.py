@@ -574,13 +574,15 @@ class _BatchedBase(object):
         self._events[0] = ev
         self.ready = True
 
-    def roundtrip(self, tensors, slot, salt, errs=None, ef_scale=None, draws=None, rng_slot=None):
+    def roundtrip(self, tensors, slot, salt, errs=None, ef_scale=None, draws=None, rng_slot=None, graph_header=None, defer_reset=None):
         """decompress(compress(t)) for every batched tensor in a few launches; None if not batchable.
         With `errs`: t <- t + ef_scale*err in place first and err <- t - decoded afterwards.
-        rng_slot: the { seed, step } pair the stochastic rounding draws from (default: the one of `slot`)."""
+        rng_slot: the { seed, step } pair the stochastic rounding draws from (default: the one of `slot`).
+        graph_header, defer_reset (stream capture of a two-phase apply): see encode."""
         if self._tmp_wire is None:
             self._tmp_wire = torch.zeros((1, self.user_bytes), dtype=torch.uint8, device=self.device)
-        if not self.encode(tensors, self._tmp_wire[0], slot, salt, errs, ef_scale, draws=draws, rng_slot=rng_slot):
+        kw = {"graph_header": graph_header, "defer_reset": defer_reset} if graph_header is not None else {}
+        if not self.encode(tensors, self._tmp_wire[0], slot, salt, errs, ef_scale, draws=draws, rng_slot=rng_slot, **kw):
             return None
         return self.decode_mean(self._tmp_wire, 1, plain=True)     # decompress(compress(t)) (ps_quantizer.py:52-61): a -0 stays -0
 

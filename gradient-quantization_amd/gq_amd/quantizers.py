@@ -592,7 +592,7 @@ class PSQuantizer(object):
         o = self._draw_off[i]
         return {"r": draws[0][o:o + self.codecs[i].M]}
 
-    def _decode_all(self, gathered, two_phase, pending=(), plain=False, resets=None, fused_levels=False, overlap=None):
+    def _decode_all(self, gathered, two_phase, pending=(), plain=False, resets=None, fused_levels=False, overlap=None, phase2_headers=None):
         """Mean of the R = gathered.shape[0] user payloads for every parameter (ps_quantizer.py:47-61),
         as a list of tensors in parameter order.  `pending`: the transfers that fill `gathered`
         (exchange.WireExchange.start) -- one, or one per byte range for a split / pipelined exchange, in which case the
@@ -715,6 +715,8 @@ class PSQuantizer(object):
         draws2 = self._draws(gathered.device) if two_phase else None     # the second phase compresses again: new draws
         if two_phase:
             self._second_phase_base(gathered.device)
+        if phase2_headers is not None and resets is None:
+            resets = []     # (capture of a two-phase apply) the second phase's accumulator resets ride in the aggregate's last small launch
         sources = []        # the lists of output views this call's result is assembled from (persistent objects, see below)
         for gi, (cls, idxs, obj) in enumerate(groups):
             gs = group_views[gi]
@@ -722,8 +724,10 @@ class PSQuantizer(object):
                 # ps_quantizer.py:52-61, replicated on every rank (salt 0, the ranks' shared seed stream); with error
                 # feedback g += server_error and server_error = g - decoded happen inside the launches
                 serr = [self.parameters[i].server_error for i in idxs] if self.error_feedback else None
+                hdr = phase2_headers[gi] if phase2_headers is not None else None      # (capture: the device copy of THIS launch's table)
                 with shared_seeds(self._second_phase_seed):
-                    dec = obj.roundtrip(list(gs), self.capacity, 0, serr, 1.0, draws=draws2, rng_slot=self.TWO_PHASE_RNG_SLOT)
+                    dec = obj.roundtrip(list(gs), self.capacity, 0, serr, 1.0, draws=draws2, rng_slot=self.TWO_PHASE_RNG_SLOT,
+                                        graph_header=hdr, defer_reset=resets if hdr is not None else None)
                 if dec is None:     # not batchable this step: per-tensor second phase below
                     for i, g in zip(idxs, gs):
                         done[i] = g
@@ -806,8 +810,9 @@ class PSQuantizer(object):
         fused, self._fused = self._fused, None
         if fused is not None and self.recorded == 1 and world == 1:
             decoded = fused      # record() has replayed this step's decode-mean already (self._step_graphs)
-        elif (self.use_graphs and len(pending) <= 1 and not self.two_phase and gathered.device.type == "cuda"
-                and all(g[2] is not None and g[2].ready for g in self._groups) and not torch.cuda.is_current_stream_capturing()):
+        elif (self.use_graphs and len(pending) <= 1 and gathered.device.type == "cuda"
+                and all(g[2] is not None and g[2].ready for g in self._groups) and not torch.cuda.is_current_stream_capturing()
+                and (not self.two_phase or (not self._draw_total and all(g[2].graphable() for g in self._groups)))):
             # gq_graph: the decode-mean launches (+ the dense tensors' mean) of an apply that has been seen with these buffers
             # before replay as ONE graph launch; the two output buffers are used in turn, so two graphs alternate.  With
             # several ranks the exchange stays outside: its one transfer is waited for first (the split transport, whose
@@ -816,11 +821,18 @@ class PSQuantizer(object):
                 pnd.wait()
             pending = ()
             graph_key = self._apply_key(gathered)
+            if self.two_phase and self.error_feedback:      # (the server residuals' addresses are in the second phase's table)
+                graph_key += (tuple(p.server_error.data_ptr() for p in self.parameters),)
             ent = self._apply_graphs.get(graph_key)
             if ent is not None and ent[1] is not None:
+                if self.two_phase:      # the re-compress folds into the accumulators an eager record() may have left used
+                    for g in self._groups:
+                        g[2].ensure_clean()
                 ent[1].replay()
                 for g in self._groups:
-                    g[2]._out_turn ^= 1
+                    if not self.two_phase:      # (two-phase: decode-mean and the re-decode took one output buffer each -- back to the first)
+                        g[2]._out_turn ^= 1
+                    g[2]._last_ptrs = None      # (two-phase: the last eager upload is not what the device header was last used with)
                 if len(self.dense_idx) >= 2:
                     self._dense_turn ^= 1
                 decoded = ent[2]
@@ -834,13 +846,21 @@ class PSQuantizer(object):
                         for g, t in zip(self._groups, graph_key[2]):      # the capture re-issues the launches of THIS apply
                             g[2]._out_turn = t
                         self._dense_turn = graph_key[3]
+                        # two-phase (ps_quantizer.py:52-61): the second phase's encode reads a device copy of the table its eager run
+                        # has just sent (the decode-mean's output buffers, the server residuals), which belongs to this graph
+                        hdrs2 = [g[2]._host[g[2]._last_slot].to(gathered.device) for g in self._groups] if self.two_phase else None
+                        calls = self._phase2_calls
                         graph = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (other threads -- RCCL's watchdog -- may call into HIP meanwhile)
-                            again = self._decode_all(gathered, False, ())
+                            again = self._decode_all(gathered, self.two_phase, (), phase2_headers=hdrs2)
+                        assert self._phase2_calls == calls, "a captured second phase must not take per-call seeds"
                         if len(again) == len(decoded) and all(a is b for a, b in zip(again, decoded)):
                             ent[1], ent[2] = graph, decoded
+                            ent.append(hdrs2)      # (kept alive with the graph)
                     except Exception as e:      # this apply has already run eagerly
                         self.use_graphs = False
+                        for g in self._groups:
+                            g[2]._graph_tables_abort()
                         import warnings
                         warnings.warn("gq_graph: capturing an apply failed (%s); continuing with eager launches" % (e,))
                     finally:
