@@ -875,7 +875,13 @@ def run_hsq(args, torch, np, dist, native, exchange, dev, rank, world, backend, 
     if world == 1 and not args.no_workloads and not args.traffic_child:
         del grads, out, u, partials      # 500 MB back before the parameter lists are built
         torch.cuda.empty_cache()
-        line["workloads"] = list_workloads(args, torch, np, native, dev)
+        line["workloads"] = w = list_workloads(args, torch, np, native, dev)
+        # the list steps' headline numbers as top-level keys too (BASELINE configs[2] / [4] at one rank): a reader that keeps only
+        # the keys it knows still sees them
+        for name in ("resnet50", "qsgd", "resnet50_real", "resnet50_ef", "resnet50_ef_twophase"):
+            if name in w and "ms_per_step_graph" in w[name]:
+                line["list_%s_ms_per_step" % name] = w[name]["ms_per_step_graph"]
+                line["list_%s_elements_per_s" % name] = w[name]["value_graph"]
     return line
 
 
@@ -968,9 +974,7 @@ def list_workloads(args, torch, np, native, dev, steps=400, warm=600):
             ms = (time.perf_counter() - t0) / steps * 1e3
             res["ms_per_step_graph" if graph else "ms_per_step_eager"] = ms
             if graph:
-                res["graphs_captured"] = {"record": sum(1 for e in q._rec_graphs.values() if e[1] is not None),
-                                          "apply": sum(1 for e in q._apply_graphs.values() if e[1] is not None),
-                                          "whole_step": sum(1 for e in q._step_graphs.values() if e[1] is not None)}
+                res["graphs_captured"] = q.graph_counts()
                 continue
             c0 = native.CALLS[0]
             step(warm + steps)

@@ -511,7 +511,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // rounding seen through ||vh||_2 < 2 sqrt(n2).  A codebook outside the f16 range: +infinity, nothing is ever "safe".
     const float c2 = __builtin_sqrtf(__uint_as_float(c2b)) * 1.0000002f, dc = __builtin_sqrtf(__uint_as_float(dcb)) * 1.0000002f;
     const bool cb_ok = c2b < 0x4E800000u && dcb < 0x4E800000u;
+#ifdef GQ_PF_N2NORM
+    const float err_rel = cb_ok ? c2 * SH::ERR_REL + 1.001f * dc : INFINITY;   // n2 = ||vh||_2^2: ||v'||_2 <= (1 + 2^-11) ||vh||_2 + subnormals (err_abs)
+#else
     const float err_rel = cb_ok ? c2 * SH::ERR_REL + 2.02f * dc : INFINITY;   // (2.02: ||vh||_2 < 2 sqrt(n2) + 2^-12, n2 >= 2^-12)
+#endif
     const float err_abs = cb_ok ? c2 * ERR_ABS : INFINITY;
     const float err2_rel = cb_ok ? c2 * SH::ERR2_REL + SH::ERR2_SUB : INFINITY;   // the second pass (three MFMAs per chain and k-step)
 

@@ -374,8 +374,9 @@ _F32_ONLY = {torch.float32}
 class _BatchedBase(object):
     """Shared plumbing of the multi-tensor kernels: a per-step header (segment table with the
     tensors' current device pointers, plus kernel-specific reset values) goes to the device in ONE
-    pinned H2D copy; a ring of pinned buffers (one per user slot + one) keeps a copy in flight from
-    being overwritten."""
+    pinned H2D copy; a ring of pinned buffers keeps a copy in flight from being overwritten."""
+
+    UPLOAD_RING = 8
 
     def _setup(self, table, extra, device, slots, user_bytes, dense=None):
         """dense: [(byte offset in one user's wire, elements), ...] of the identity-compressed tensors this group's compress
@@ -392,7 +393,11 @@ class _BatchedBase(object):
             for k, (off, numel) in enumerate(dense):
                 dt[k, 1], dt[k, 2] = off, numel
             host = torch.cat([host, dt.view(-1)])
-        self._host = [host.clone().pin_memory() for _ in range(slots + 1)]
+        # a ring of pinned copies of the header: an upload rewrites the OLDEST one, so the copy it has to wait for was queued
+        # UPLOAD_RING uploads ago (round 6: indexed by the user slot, a one-user training loop rewrote the same buffer every step
+        # and waited for the previous step's copy -- the host could never run ahead of the device)
+        self._host = [host.clone().pin_memory() for _ in range(max(slots + 1, self.UPLOAD_RING))]
+        self._up_turn = 0
         self._host_np = [h[:self._table_words].view(self.nseg, 8).numpy() for h in self._host]   # views of the pinned tables
         self._host_dense_np = [h[self._dense_at:].view(self.ndense, 3).numpy() for h in self._host] if self.ndense else None
         self._last_dptrs = None
@@ -401,7 +406,7 @@ class _BatchedBase(object):
         self._acc_init = extra.view(-1).to(device) if extra is not None else None     # the accumulators' empty state, on the device
         self._acc_clean = False             # the device accumulators are in that state right now (see _graph_tables)
         self._last_ptrs = self._last_eptrs = None
-        self._events = [None] * (slots + 1)
+        self._events = [None] * len(self._host)
         self._dev = torch.empty_like(host, device=device)
         self._tmp_wire = None
         self.ready = False      # the device header has been written at least once
@@ -500,9 +505,10 @@ class _BatchedBase(object):
             return False
         if len(eptrs) != len(ptrs):
             return False
-        slot %= len(self._host)
+        slot = self._up_turn      # (the user slot plays no part: any pinned buffer whose last copy is done will do)
+        self._up_turn = (slot + 1) % len(self._host)
         if self._events[slot] is not None:
-            self._events[slot].synchronize()       # the previous copy out of this pinned buffer
+            self._events[slot].synchronize()       # the previous copy out of this pinned buffer (UPLOAD_RING uploads ago)
         tab = self._host_np[slot]
         tab[:, 0] = ptrs
         tab[:, 7] = eptrs
@@ -514,6 +520,14 @@ class _BatchedBase(object):
         if self._events[slot] is None:
             self._events[slot] = torch.cuda.Event()
         self._events[slot].record()
+        return True
+
+    def upload(self, tensors, slot, errs=None, dense=None):
+        """The header of these tensors to the device (pointers, accumulator resets, dense copy table), as the eager encode sends
+        it -- in front of the replay of an address-free graph.  False: a tensor cannot be addressed that way."""
+        if not self._upload(tensors, slot, self.align, errs, dense):
+            return False
+        self._acc_clean = False
         return True
 
     def _counter_seed(self, slot, reserved=False):
@@ -675,7 +689,7 @@ class BatchedHSQ(_BatchedBase):
             and self._batch.path != 0
 
     def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None, dense=None, defer_reset=None,
-               rng_slot=None, skip_levels=False):
+               rng_slot=None, skip_levels=False, table_current=False):
         """Compress `tensors` (one per batched parameter, in order) into one user's wire.
         skip_levels (whole-step capture at one rank and one user): only the encode is launched; the level launch is left to
         decode_mean(..., fused_levels=True), which runs it together with the decode (gq_hsq_levels_decode_batched).
@@ -692,6 +706,11 @@ class BatchedHSQ(_BatchedBase):
             return False
         if graph_header is not None:
             self._graph_tables(graph_header, dense)
+        elif table_current:
+            # (capture of an ADDRESS-FREE graph, PSQuantizer._capture_generic: the launches read the shared device header, which
+            # the caller refreshes by upload() in front of every replay -- pointers and accumulator resets -- as an eager step does)
+            self._batch.set_table(self._dev[:self._table_words])
+            self._batch.set_dense(self.dense_table_dev() if dense is not None else None, self.ndense)
         elif not self._upload(tensors, slot, self.align, errs, dense):
             return False
         else:
@@ -818,6 +837,7 @@ class BatchedQSGD(_BatchedBase):
         self.counter = bool(self.random and c0.c._rng == "device")
         self.wide = self.is_wide(c0)
         assert all(cd.bits == self.bits and cd.c.bit == self.n_bit and self.is_wide(cd) == self.wide for cd in self.codecs)
+        self.align = 8
         nseg = len(self.idxs)
         table = torch.zeros((nseg, 8), dtype=torch.int64)
         item_seg = []
@@ -858,12 +878,15 @@ class BatchedQSGD(_BatchedBase):
         return not self.random or self.keyed or (self.counter and self.rng_pairs is not None)
 
     def encode(self, tensors, wire_user, slot, salt, errs=None, ef_scale=None, draws=None, graph_header=None, dense=None, defer_reset=None,
-               rng_slot=None):
+               rng_slot=None, table_current=False):
         """With `errs`: error feedback in the same launch (t += ef_scale*err, err = t - decoded, both in place).
         graph_header, dense, rng_slot: see BatchedHSQ.encode."""
         counter_seed = self._counter_seed(slot) if rng_slot is None else self._counter_seed(rng_slot, reserved=True)
         if graph_header is not None:
             self._graph_tables(graph_header, dense)
+        elif table_current:      # (see BatchedHSQ.encode)
+            self._batch.set_table(self._dev[:self._table_words])
+            self._batch.set_dense(self.dense_table_dev() if dense is not None else None, self.ndense)
         elif not self._upload(tensors, slot, 8, errs, dense):
             return False
         else:

@@ -177,6 +177,9 @@ def build_parser():
     p.add_argument('--data-root', type=str, default='./data')
     p.add_argument('--test-batch-size', type=int, default=1000)
     p.add_argument('--test-size', type=int, default=0, help='synthetic data: held-out samples for the accuracy loop (0 = none)')
+    p.add_argument('--timing', action='store_true', default=False,
+                   help="log lines carry ms_per_iter as the wall time per iteration since the previous log line (device drained at both "
+                        "ends), quantizer_ms (HIP events around record / apply, summed per iteration) and quantizer_share")
     return p
 
 
@@ -195,17 +198,28 @@ def test(model, loss_func, test_data, test_batch_size):
     return correct / test_data.n, test_loss / test_data.n
 
 
-def one_iter(model, loss_func, optimizer, quantizer, train_data, epoch):
-    """main.py:216-233."""
+def one_iter(model, loss_func, optimizer, quantizer, train_data, epoch, spans=None):
+    """main.py:216-233.  spans (a list, --timing): (start, end) HIP event pairs around every quantizer call of the iteration --
+    the quantizer's share of the iteration's DEVICE time (record per user, apply once)."""
     model.train()
     losses = []
+
+    def timed(fn):
+        if spans is None:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        spans.append((a, b))
+
     for user_id, (data, target) in enumerate(train_data):
         optimizer.zero_grad()
         loss = loss_func(model(data), target)
         losses.append(loss.detach())
         loss.backward()
-        quantizer.record(user_id, epoch=epoch)
-    quantizer.apply()
+        timed(lambda: quantizer.record(user_id, epoch=epoch))
+    timed(quantizer.apply)
     optimizer.step()
     return torch.stack(losses).mean()
 
@@ -243,6 +257,7 @@ def train(args, log=None):
     out = open(args.logfile, "a") if (args.logfile and rank == 0) else None
     history = []
     it = 0
+    timing, mark, mark_it, spans = bool(getattr(args, "timing", False)), None, 0, []
     for epoch in range(1, args.epochs + 1):
         if epoch in steps:
             optimizer = optim.SGD(model.parameters(), lr=steps[epoch], momentum=momentum, weight_decay=5e-4)
@@ -254,11 +269,23 @@ def train(args, log=None):
             users = [(x[u * ub:(u + 1) * ub], y[u * ub:(u + 1) * ub]) for u in range(args.num_users - 1)]
             users.append((x[(args.num_users - 1) * ub:], y[(args.num_users - 1) * ub:]))
             t0 = time.perf_counter()
-            loss = one_iter(model, loss_func, optimizer, quantizer, users, epoch)
+            if timing and mark is None:
+                torch.cuda.synchronize()
+                mark, mark_it, spans = time.perf_counter(), it, []
+            loss = one_iter(model, loss_func, optimizer, quantizer, users, epoch, spans if timing else None)
             it += 1
             if it % args.log_interval == 0 or it == 1:
                 rec = {"iter": it, "epoch": epoch, "loss": float(loss), "ms_per_iter": (time.perf_counter() - t0) * 1e3,
                        "ranks": world, "users_per_rank": args.num_users}
+                if timing:      # the interval since the last log line, device drained at both ends
+                    torch.cuda.synchronize()
+                    n_it = it - mark_it
+                    q_ms = sum(a.elapsed_time(b) for a, b in spans) / n_it
+                    rec["ms_per_iter"] = (time.perf_counter() - mark) * 1e3 / n_it
+                    rec["quantizer_ms"] = q_ms
+                    rec["quantizer_share"] = q_ms / rec["ms_per_iter"]
+                    rec["iters_timed"] = n_it
+                    mark = None
                 if test_data is not None and rank == 0:      # main.py:197-211: loss and test accuracy are logged together (once: rank 0)
                     acc, tl = test(model, loss_func, test_data, getattr(args, "test_batch_size", 1000))
                     rec["accuracy(%)"] = 100.0 * acc

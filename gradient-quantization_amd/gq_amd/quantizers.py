@@ -150,6 +150,7 @@ class PSQuantizer(object):
         self._fused = None           # the decoded list of a step whose record() has already replayed its apply()
         self._side_stream = None     # the second branch of a chunked step's graph (_overlap_fractions)
         self._phase2_base = None     # the seed base all ranks share for the replicated second phase (_second_phase_base)
+        self.record_paths = {"graph": 0, "graph_any_address": 0, "whole_step": 0, "whole_step_any_address": 0, "eager": 0}   # how record() ran, by count
         self._phase2_calls = 0
         # gq_rng = "reference": the reference draws r = torch.rand(M) per compressed tensor, in parameter order, from
         # the CPU generator (probabilistic_scalar_compressor.py:23).  torch.rand is one sequential stream, so ONE
@@ -365,11 +366,13 @@ class PSQuantizer(object):
                         self._dense_turn ^= 1
                     self._fused = fent[2]
                     self.recorded += 1
+                    self.record_paths["whole_step"] += 1
                     return
             if plain_f32:
                 for g in self._groups:
                     g[2].ensure_clean()
                 ent[1].replay()
+                self.record_paths["graph"] += 1
                 for g in self._groups:
                     g[2]._last_ptrs = None      # the device header now holds this graph's table: the next eager call re-sends its own
                 self.recorded += 1
@@ -378,11 +381,56 @@ class PSQuantizer(object):
                     if fent is not None and fent[0] >= 2 and fent[1] is None:
                         self._capture_step(fent, ent[2], all_grads, wire, slot, user, salt, scale, dev)
                 return
+            # No graph for THESE gradient addresses (a training loop whose backward allocates the gradients anew sees a new set
+            # nearly every step: round 6 measured 98 sets in 150 iterations of driver.one_iter, 48 captures that were hardly
+            # ever replayed and eager launches from then on).  The ADDRESS-FREE graph: the same launches reading the shared
+            # device header, which is refreshed -- pointers, accumulator resets -- by one pinned copy in front of the replay,
+            # exactly what an eager step sends.  One graph per (slot, user) serves every address set.
+            generic_key = ("any", slot, user, self._wire.data_ptr()) + ((scale,) if self.error_feedback else ())
+            gent = self._rec_graphs.get(generic_key)
+            if (gent is not None and gent[1] is not None
+                    and (scan[2] if scan is not None else (all(map(_IS_CONTIGUOUS, all_grads)) and set(map(_DTYPE_OF, all_grads)) == _F32_ONLY))
+                    and self._upload_headers(all_grads, slot, user)):
+                # an address set that has come back gets a graph of its own (no header copy in front of its replays); the capture
+                # executes nothing, this step still replays the address-free graph
+                ent = self._graph_entry(self._rec_graphs, graph_key, max_captured=self.MAX_ADDRESS_GRAPHS)
+                if ent is not None and ent[0] >= 2 and ent[1] is None:
+                    self._capture_record(ent, all_grads, wire, slot, user, salt, scale, dev)
+                gstep = None
+                if (self._fuse_steps and world == 1 and slot == 0 and self.capacity == 1 and not self.two_phase
+                        and self._plan is not None and not self._plan[2]):
+                    gstep = (generic_key, self._apply_key(self._wire[:1]))
+                    fent = self._step_graphs.get(gstep)
+                    if fent is not None and fent[1] is not None:
+                        fent[1].replay()
+                        for g in self._groups:
+                            g[2]._out_turn ^= 1
+                        if len(self.dense_idx) >= 2:
+                            self._dense_turn ^= 1
+                        self._fused = fent[2]
+                        self.recorded += 1
+                        self.record_paths["whole_step_any_address"] += 1
+                        return
+                gent[1].replay()
+                self.recorded += 1
+                self.record_paths["graph_any_address"] += 1
+                if gstep is not None:
+                    fent = self._graph_entry(self._step_graphs, gstep)
+                    if fent is not None and fent[0] >= 2 and fent[1] is None:
+                        self._capture_step(fent, None, all_grads, wire, slot, user, salt, scale, dev)
+                return
+        self.record_paths["eager"] += 1
         skip = self._record_launches(all_grads, wire, slot, user, salt, scale, draws, dev)
         if len(skip) == self.num_layers:     # the usual case: everything went through the multi-tensor launches
             self.recorded += 1
             if graph_key is not None:
-                ent = self._graph_entry(self._rec_graphs, graph_key)
+                # the address-free graph first (it serves every later step); a graph of its own for an address set only when
+                # the set has come back (callers whose gradients keep their storage: one copy node less per step)
+                generic_key = ("any", slot, user, self._wire.data_ptr()) + ((scale,) if self.error_feedback else ())
+                gent = self._graph_entry(self._rec_graphs, generic_key, max_captured=1 << 30)
+                if gent is not None and gent[1] is None and gent[0] >= 2 and self._generic_ok():
+                    self._capture_record(gent, all_grads, wire, slot, user, salt, scale, dev, generic=True)
+                ent = self._graph_entry(self._rec_graphs, graph_key, max_captured=self.MAX_ADDRESS_GRAPHS)
                 if ent is not None and ent[0] >= 2 and ent[1] is None:      # the second sighting: worth a capture
                     self._capture_record(ent, all_grads, wire, slot, user, salt, scale, dev)
             return
@@ -419,6 +467,35 @@ class PSQuantizer(object):
                 codec.encode_into(grad, wire, off, salt, **self._slice(draws, i))
         self.recorded += 1
 
+    MAX_ADDRESS_GRAPHS = 8      # graphs tied to one set of gradient addresses (the address-free ones are not counted)
+
+    def graph_counts(self):
+        """Captured graphs by kind: record / whole step tied to a set of gradient addresses, their address-free forms, apply."""
+        def split(cache, pick):
+            keys = [k for k, e in cache.items() if e[1] is not None]
+            free = sum(1 for k in keys if pick(k)[0] == "any")
+            return len(keys) - free, free
+        rec, rec_any = split(self._rec_graphs, lambda k: k)
+        step, step_any = split(self._step_graphs, lambda k: k[0])
+        return {"record": rec, "record_any_address": rec_any, "apply": sum(1 for e in self._apply_graphs.values() if e[1] is not None),
+                "whole_step": step, "whole_step_any_address": step_any}
+
+    def _generic_ok(self):
+        """An address-free record graph holds kernel launches only: the dense tensors must ride in the first group's launch
+        (their own copy is a torch op on the gradients themselves)."""
+        return bool(self._groups) and (len(self.dense_idx) < 2 or bool(self._groups[0][2] is not None and self._groups[0][2].ndense))
+
+    def _upload_headers(self, all_grads, slot, user):
+        """Every group's header for these gradients to the device (in front of an address-free graph's replay)."""
+        for grp in self._groups:
+            cls, idxs, obj = grp
+            grads = list(self._pick_group[id(grp)](all_grads))
+            errs = [self.parameters[i].error[user] for i in idxs] if self.error_feedback else None
+            dense = list(self._pick_dense(all_grads)) if obj.ndense else None
+            if not obj.upload(grads, slot, errs, dense):
+                return False
+        return True
+
     def _make_group(self, grp, dev):
         """The multi-tensor launch object of one group, built the same way whoever needs it first (a record, or a ring rank
         that decodes before it has encoded anything): dense copy table, draws' { seed, step } pairs, aggregate form."""
@@ -443,7 +520,7 @@ class PSQuantizer(object):
         return self._ticket[gi]
 
     def _record_launches(self, all_grads, wire, slot, user, salt, scale, draws, dev, headers=None, defer_resets=None, fuse_levels=False,
-                         overlap=None):
+                         overlap=None, table_current=False):
         """The multi-tensor launches of a record (+ the dense tensors' copy into the wire) -> the set of parameters served.
         headers (stream capture): one device-resident header per group, see BatchedHSQ.encode.
         fuse_levels (whole-step capture, _can_fuse_levels): the group's level launch is left to the aggregate's decode.
@@ -467,6 +544,8 @@ class PSQuantizer(object):
             skip_groups.append(obj)
             dense = list(self._pick_dense(all_grads)) if obj.ndense else None
             kw = {"skip_levels": True} if fuse_levels else {}
+            if table_current:      # (capture of an address-free graph: launches only, the shared device header is current)
+                kw["table_current"] = True
             mine = [] if overlap is not None else defer_resets
             if obj.encode(grads, wire, slot, salt, errs, scale, draws=draws, graph_header=hdr, dense=dense, defer_reset=mine, **kw):
                 skip.update(idxs)
@@ -505,24 +584,26 @@ class PSQuantizer(object):
         ent = cache.get(key)
         if ent is None:
             counting = [k for k, e in cache.items() if e[1] is None]
-            if len(cache) - len(counting) >= max_captured:
-                return None
+            if sum(1 for k, e in cache.items() if e[1] is not None and not (type(k) is tuple and k and k[0] == "any")) >= max_captured:
+                return None      # (address-free graphs, keys ("any", ...), are not counted)
             if len(counting) >= max_counting:
                 cache.pop(counting[0])
             ent = cache[key] = [0, None, None]
         ent[0] += 1
         return ent
 
-    def _capture_record(self, ent, all_grads, wire, slot, user, salt, scale, dev):
+    def _capture_record(self, ent, all_grads, wire, slot, user, salt, scale, dev, generic=False):
         """Stream-capture the launches the record just made eagerly, with copies of the headers it has just sent
-        (the shared pinned buffers are rewritten by later records, a graph's memcpy node reads its source at every replay)."""
+        (the shared pinned buffers are rewritten by later records, a graph's memcpy node reads its source at every replay).
+        generic: the address-free form -- the launches read the SHARED device header (record() refreshes it in front of every
+        replay), so the graph holds no pointer of these gradients."""
         try:
             # (device-resident: the graph's copy node is device-to-device.  A host-to-device node -- pinned memory over PCIe --
             # cost 15 us of every replayed step, tools/graph_pieces.py; the 5 KB header per captured graph is nothing)
-            headers = [g[2]._host[g[2]._last_slot].to(dev) for g in self._groups]
+            headers = None if generic else [g[2]._host[g[2]._last_slot].to(dev) for g in self._groups]
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (other threads -- RCCL's watchdog -- may call into HIP meanwhile)
-                self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers)
+                self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers, table_current=generic)
         except Exception as e:      # a capture that fails leaves the eager path as it was (this record has already run eagerly)
             self.use_graphs = False
             import warnings
@@ -548,7 +629,7 @@ class PSQuantizer(object):
                         self._side_stream = torch.cuda.Stream(device=dev)
                     overlap = {"events": {}, "resets": {}, "side": self._side_stream if os.environ.get("GQ_OVERLAP_STREAMS", "1") != "0" else None}
                 self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers, defer_resets=resets,
-                                      fuse_levels=fuse, overlap=overlap)
+                                      fuse_levels=fuse, overlap=overlap, table_current=headers is None)
                 decoded = self._decode_all(self._wire[:1], False, (), resets=resets, fused_levels=fuse, overlap=overlap)
             fent[1], fent[2] = graph, decoded
         except Exception as e:      # the two-graph replay keeps working
