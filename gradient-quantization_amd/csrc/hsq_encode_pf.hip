@@ -21,15 +21,15 @@
 //     settled by it, and what makes that affordable is the batched exact scan of (4).
 //     Error against the reference's p_k (fmaf chain), in scaled units:
 //       s'_k - s~_k = (c_k - ch_k) . v'  +  ch_k . (v' - vh)
-//       |ch_k . (v' - vh)| <= ||ch_k||_2 * 2^-11 sqrt(n2),  n2 = sum_j 4^e_j, e_j the exponent of vh_j: the rounding error
-//                             of element j is at most half an ulp = 2^-11 2^e_j (subnormal vh_j: 2^-25, in err_abs)
+//       |ch_k . (v' - vh)| <= ||ch_k||_2 * 2^-11 sqrt(n2),  n2 = ||vh||_2^2: the rounding error of element j is at most half an
+//                             ulp <= 2^-11 |vh_j| (subnormal or zero vh_j: 2^-25, in err_abs)
 //       |(c_k - ch_k) . v'| <= dc ||v'||_2,   dc = max_k ||c_k - ch_k||_2 -- the codebook's rounding residuals as they are,
-//                             measured in the prologue (~0.6 x 2^-11 for unit rows) --,  ||v'||_2 < 2.02 sqrt(n2)
-//       E' := sqrt(n2) * (1.03 * 2^-11 * c2 + 2.02 dc) + 2^-21 * c2,    c2 = max_k ||c_k||_2 (measured too);
-//     the 1.03 covers the accumulation roundings of the MFMA and of the reference's chain (< 1 % of the first term).
-//     Valid while 2^-12 <= n2 <= 2^24 (no f16 overflow; the subnormal terms stay small): outside that window
-//     -- a subvector far off the wave's scale -- the subvector goes to the exact scan.  n2 costs four v_and_b32 and
-//     four v_dot2_f32_f16 per fragment.
+//                             measured in the prologue (~0.6 x 2^-11 for unit rows) --,  ||v'||_2 <= (1 + 2^-11) sqrt(n2)
+//       E' := sqrt(n2) * (1.03 * 2^-11 * c2 + 1.001 dc) + 2^-21 * c2,    c2 = max_k ||c_k||_2 (measured too);
+//     the 1.03 covers the accumulation roundings of the MFMA, of the reference's chain and of n2 itself (< 1 % of the first term).
+//     Valid while 2^-12 <= n2 <= 2^24 (every |vh_j| <= 2^12: no f16 overflow -- an overflowed element makes n2 infinite):
+//     outside that window -- a subvector far off the wave's scale -- the subvector goes to the exact scan.  n2 costs four
+//     v_dot2_f32_f16 per fragment.  (Rounds 4-5: n2 = sum of 4^exponent, four v_and_b32 more; see scale8_f16.)
 //  2. The 16 scores a lane gets per chain are 4 GROUPS of 4 consecutive codewords (accumulator registers 4q..4q+3).
 //     Per group the VALU takes g = max |s~| (v_max3_f32 + v_max_f32 with |.| modifiers) and forms ONE key
 //       key = (bits(g) & 0x7FFFFFE0) | group_id ,
@@ -127,9 +127,10 @@ struct PfShape {
     // the two waves of a SIMD end their runs as a pair (the end of the kernel).  Measured (profiles/r05_encode_ab.txt, block C):
     // D = 32 30.52 against 31.24 us, D = 16 33.83 against 32.96, D = 8 55.4 against 54.6 -- on for D = 32 only
     static constexpr bool PAIR = GQ_PF_PAIR < 0 ? D > 16 : GQ_PF_PAIR != 0;
-    // Error bound of the f16 prefilter (header, 1): E' = sqrt(n2) * (ERR_REL * c2 + 2.02 dc) + ERR_ABS * c2 inside the window of n2.
+    // Error bound of the f16 prefilter (header, 1): E' = sqrt(n2) * (ERR_REL * c2 + 1.001 dc) + ERR_ABS * c2 inside the window of n2.
     // The factor over 2^-11 covers the accumulation roundings of the MFMA and of the reference's chain, 2 D 2^-24 of
-    // sum |c_j v_j| <= c2 ||v'||_2 < 2.02 c2 sqrt(n2) together: 0.8 % of the first term for D = 16, 1.6 % for D = 32.
+    // sum |c_j v_j| <= c2 ||v'||_2 <= 1.001 c2 sqrt(n2) together (0.4 % of the first term for D = 16, 0.8 % for D = 32), the
+    // rounding of n2's own sum and square root (< 0.001 %) and ||ch_k||_2 <= c2 + dc (0.03 %).
     static constexpr float ERR_REL = (D > 16 ? 1.05f : 1.03f) * 4.8828125e-04f;     // x 2^-11
     // second pass (ch.vh + ch.vl + cl.vh): cl.vl and the splits' remainders (3 x 2^-22 x 2.02) + 4 D accumulated products
     // (x 2^-24 x 2.02): 1.19 x 2^-17 for D = 16, 2.21 x 2^-17 for D = 32; the codebook split's subnormal grid on top (ERR2_SUB)
@@ -138,7 +139,7 @@ struct PfShape {
 };
 constexpr float ERR_ABS = 4.76837158203125e-07f;      // 2^-21 (subnormal f16 results: sqrt(D) 2^-25 per subvector)
 constexpr unsigned N2_LO_BITS = 0x39800000u;          // 2^-12
-constexpr unsigned N2_HI_BITS = 0x4B800000u;          // 2^24  (||vh||_2^2 < 4 n2 <= 2^26: every |vh_j| < 2^13)
+constexpr unsigned N2_HI_BITS = 0x4B800000u;          // 2^24  (n2 = ||vh||_2^2: every |vh_j| <= 2^12)
 constexpr int SIGMA_TARGET_EXP2 = 10;                 // the largest sampled n2 of a tile is steered to ~2^10 (norm 2^5 .. 2^6)
 
 // Arguments of the prefilter kernels.  Single-tensor form: grad/M/codes/u.  Batched form
@@ -511,11 +512,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // rounding seen through ||vh||_2 < 2 sqrt(n2).  A codebook outside the f16 range: +infinity, nothing is ever "safe".
     const float c2 = __builtin_sqrtf(__uint_as_float(c2b)) * 1.0000002f, dc = __builtin_sqrtf(__uint_as_float(dcb)) * 1.0000002f;
     const bool cb_ok = c2b < 0x4E800000u && dcb < 0x4E800000u;
-#ifdef GQ_PF_N2NORM
-    const float err_rel = cb_ok ? c2 * SH::ERR_REL + 1.001f * dc : INFINITY;   // n2 = ||vh||_2^2: ||v'||_2 <= (1 + 2^-11) ||vh||_2 + subnormals (err_abs)
-#else
-    const float err_rel = cb_ok ? c2 * SH::ERR_REL + 2.02f * dc : INFINITY;   // (2.02: ||vh||_2 < 2 sqrt(n2) + 2^-12, n2 >= 2^-12)
-#endif
+    const float err_rel = cb_ok ? c2 * SH::ERR_REL + 1.001f * dc : INFINITY;   // n2 = ||vh||_2^2: ||v'||_2 <= (1 + 2^-11) sqrt(n2) (+ the subnormal grid: err_abs)
     const float err_abs = cb_ok ? c2 * ERR_ABS : INFINITY;
     const float err2_rel = cb_ok ? c2 * SH::ERR2_REL + SH::ERR2_SUB : INFINITY;   // the second pass (three MFMAs per chain and k-step)
 
@@ -1082,7 +1079,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         }
     }
 #ifdef GQ_PF_STAMPS
-    if (!BATCHED && lane == 0 && blockIdx.x < 256) {   // 12 words per wave behind the log (which this build does not write)
+    if (lane == 0 && blockIdx.x < 256) {   // 12 words per wave behind the log (which this build does not write); batched form: M = ntiles * 64 (tools/stamp_batched.py)
         unsigned long long *o = reinterpret_cast<unsigned long long *>(ws_worklist(ws) + (M - 65536)) + (blockIdx.x * 8 + wave) * 12;
         for (int i = 0; i < 6; ++i) o[i] = stamp_acc[i];
         o[6] = rt_entry, o[7] = rt0, o[8] = rt1, o[9] = ntl, o[10] = __builtin_amdgcn_s_memrealtime(), o[11] = 1000 * nscanned + npassed;

@@ -56,10 +56,11 @@ __device__ __forceinline__ void split8_f16(const f32x4 &q0, const f32x4 &q1, hal
 }
 // 8 consecutive floats of a subvector, times the wave's power of two `scale` (an SGPR), -> ONE f16 fragment: one
 // v_fma_mix per element (the product is exact in f32, the conversion rounds once), no lo part.
-// n2 += sum of 4^e_j over the eight values, e_j = the exponent of the f16 value (its mantissa masked off: one v_and_b32
-// per pair, then v_dot2_f32_f16): the rounding error of element j is at most half an ulp = 2^-11 * 2^e_j (subnormal
-// results: 2^-25, counted separately), so 2^-11 sqrt(n2) bounds the L2 norm of the tile's rounding error -- ~1.5 x
-// tighter than 2^-11 ||vh||_2 for the price of the mask.
+// n2 += ||vh||_2^2 of the eight values (v_dot2_f32_f16 per pair): the rounding error of element j is at most half an ulp
+// <= 2^-11 |vh_j| (subnormal or zero results: 2^-25, counted separately), so 2^-11 sqrt(n2) bounds the L2 norm of the tile's
+// rounding error, and (1 + 2^-11) sqrt(n2) bounds ||v'||_2 for the codebook-rounding term.  (Rounds 4-5 summed 4^exponent
+// instead -- one v_and_b32 per pair for a first term up to 2x tighter and a second term 2x looser: 23,621 unsettled subvectors
+// per 25 M-element launch against 22,508 with the plain norm, profiles/r06_encode_ab.txt block I.)
 __device__ __forceinline__ void scale8_f16(const f32x4 &q0, const f32x4 &q1, float scale, half8 &hi, float &n2) {
     u32x4 H = {0, 0, 0, 0};
 #pragma unroll
@@ -71,17 +72,7 @@ __device__ __forceinline__ void scale8_f16(const f32x4 &q0, const f32x4 &q1, flo
         H[i] = r;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#ifdef GQ_PF_N2NORM
-        // A/B (profiles/r06_encode_ab.txt, block I): n2 := ||vh||^2 itself -- no mask.  Half an ulp of element j is at most
-        // 2^-11 |vh_j|, so 2^-11 ||vh||_2 bounds the conversion's error too (up to 2x looser than the masked sum) and
-        // ||v'||_2 <= (1 + 2^-11) ||vh||_2 bounds the codebook-rounding term (2x TIGHTER than 2.02 sqrt(n2)): see the kernel's E'.
-        asm("v_dot2_f32_f16 %0, %1, %1, %0" : "+v"(n2) : "v"(H[i]));
-#else
-        const unsigned e = H[i] & 0x7C007C00u;
-        asm("v_dot2_f32_f16 %0, %1, %1, %0" : "+v"(n2) : "v"(e));
-#endif
-    }
+    for (int i = 0; i < 4; ++i) asm("v_dot2_f32_f16 %0, %1, %1, %0" : "+v"(n2) : "v"(H[i]));
     hi = __builtin_bit_cast(half8, H);
 }
 
@@ -120,36 +111,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef GQ_RESCORE_BATCH
 #define GQ_RESCORE_BATCH 8
 #endif
-#ifdef GQ_PF_PKFMA
-// A/B (block J): the four chains as two v_pk_fma_f32 per element -- the same IEEE fma in each half, the subvector's element
-// broadcast to both halves by op_sel (v[2p] / v[2p + 1] are the halves of one register pair).  Needs the TU built WITH packed f32.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int D>
-__device__ __forceinline__ f32x4 exact_score_quad(const float *__restrict__ quad, const float (&v)[D]) {
-    f32x2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
-    constexpr int B = D < GQ_RESCORE_BATCH ? D : GQ_RESCORE_BATCH;
-#pragma unroll
-    for (int j0 = 0; j0 < D; j0 += B) {
-        f32x4 c[B];
-#pragma unroll
-        for (int jj = 0; jj < B; ++jj) c[jj] = *reinterpret_cast<const f32x4 *>(quad + 4 * (j0 + jj));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int jj = 0; jj < B; jj += 2) {
-            const f32x2 vp = {v[j0 + jj], v[j0 + jj + 1]};
-            const f32x2 c01 = {c[jj][0], c[jj][1]}, c23 = {c[jj][2], c[jj][3]};
-            const f32x2 d01 = {c[jj + 1][0], c[jj + 1][1]}, d23 = {c[jj + 1][2], c[jj + 1][3]};
-            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a01) : "v"(c01), "v"(vp));
-            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a23) : "v"(c23), "v"(vp));
-            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a01) : "v"(d01), "v"(vp));
-            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a23) : "v"(d23), "v"(vp));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    const f32x4 r = {a01[0], a01[1], a23[0], a23[1]};
-    return r;
-}
-#else
 template <int D>
 __device__ __forceinline__ f32x4 exact_score_quad(const float *__restrict__ quad, const float (&v)[D]) {
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
@@ -174,7 +135,6 @@ __device__ __forceinline__ f32x4 exact_score_quad(const float *__restrict__ quad
     const f32x4 r = {a0, a1, a2, a3};
     return r;
 }
-#endif
 
 // order-preserving float -> uint32 map for integer atomic min/max
 __device__ __forceinline__ unsigned order_map(float f) {
