@@ -668,11 +668,6 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
             return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: K > 256 needs int32 codes");
         }
     }
-    if (impl == 6) {   // round 3's bf16 x 3 prefilter for d = 8 / 32 (hsq_encode_pfd.hip's single-page form): kept as a cross-check
-        if (K != 256 || (d != 8 && d != 32)) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 6 needs K=256 and d in {8, 32}");
-        if (!pf_ok) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: grad must be 16-byte aligned");
-        return launch_encode_pfd<CodeT>(grad, codebook, M, d, codes, u, partials, st);
-    }
     if (impl == 5) {
         if (!lds_ok) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: impl 5 needs d <= 128 (d=%d K=%d)", d, K);
         static bool attr_set = false;

@@ -194,10 +194,6 @@ static int resident_blocks_per_cu(KernelT kernel, int threads, size_t lds) {
 template <typename CodeT>
 int launch_encode_pf(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u, float *workspace,
                      hipStream_t st, int profile_slot = -1);
-// hsq_encode_pfd.hip: round 3's bf16 x 3 prefilter for d = 8 and d = 32 (K = 256): gq_hsq_encode_ex's impl 6, a cross-check.
-template <typename CodeT>
-int launch_encode_pfd(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u,
-                      float *workspace, hipStream_t st);
 
 // LDS plan of the operand-staging kernels (hsq_encode_lds_kernel, pvq_encode_lds_kernel): false if (d, K) does not fit
 constexpr int LDS_ROW_PAD = 4;

@@ -1,10 +1,9 @@
 // HSQ encode, sub-dimension D = 8 or 32: round 3's bf16x3 matrix-core prefilter + exact f32 rescoring (three bf16 MFMAs per
 // chain and k-step: hi x hi, hi x lo, lo x hi; keys and exactness argument as in hsq_encode_pf.hip's header, its error
 // bound the bf16x3 one stated below).  Since round 5 the product path for K = 256 is hsq_encode_pf.hip's one-f16-MFMA kernel,
-// a template over D = 8 / 16 / 32; what this file still serves:
-//   * gq_hsq_encode_ex's impl 6 (GQ_ENCODE_PREFILTER_BF16X3): the single-tensor K = 256 form, an independent cross-check of
-//     the f16 kernel in the tests and in tools/time_pf_d.py (d = 32 / 8: 42.1 / 68.7 us against 30.5 / 54.6);
-//   * the PAGED form, K = 512 ... 65536 (codebook pages of 256 rows, int32 codes), single- and multi-tensor.
+// a template over D = 8 / 16 / 32; what this file serves is the PAGED form, K = 512 ... 65536 (codebook pages of 256 rows,
+// int32 codes), single- and multi-tensor.  (Its single-page K = 256 form was gq_hsq_encode_ex's impl 6 until round 6, a
+// cross-check of the f16 kernel that the exact kernels -- impl 1 / 2 / 5 -- cover: d = 32 / 8 ran 42.1 / 68.7 us against 30.5 / 54.6.)
 // What differs from the d = 16 kernel of round 3:
 //   * a chain is 3 * KS v_mfma_f32_32x32x16_bf16 with KS = ceil(D / 16) k-steps; D = 8 feeds zeros for the
 //     upper half of the one k-step;
@@ -650,34 +649,6 @@ static int64_t pfd_grid(int64_t ntiles, int bpc, int waves) {
     return blocks < 1 ? 1 : blocks;
 }
 
-template <typename CodeT, int D>
-static int launch_pfd(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *ws,
-                      hipStream_t st) {
-    constexpr int KS = D > 16 ? D / 16 : 1;
-    constexpr int WAVES = D == 32 ? GQ_W32 : GQ_W8, THREADS = WAVES * 64;
-    constexpr size_t lds = (size_t)64 * (4 * D + 4) * sizeof(float) + (size_t)8 * KS * 2 * 64 * 16;
-    static const int bpc = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_encode_pfd_kernel<CodeT, D>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipGetLastError();
-        return resident_blocks_per_cu(hsq_encode_pfd_kernel<CodeT, D>, THREADS, lds);
-    }();
-    PfdArgs a = {};
-    a.grad = grad;
-    a.M = M;
-    a.codes = codes;
-    a.u = u;
-    a.cb = codebook;
-    a.ws = ws;
-    const int64_t ntiles = (M + 63) / 64;
-    const int64_t blocks = pfd_grid(ntiles, bpc, WAVES);
-    pfd_split(a, ntiles, blocks);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pfd_kernel<CodeT, D>), dim3((unsigned)blocks), dim3(THREADS), lds,
-                       st, a);
-    GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter, d = 8 / 32)");
-    return GQ_OK;
-}
-
 // LDS of a launch that keeps `pages` pages resident: the f32 image for the exact rescoring + the bf16 fragments
 template <int D>
 static constexpr size_t pfd_lds_bytes(int pages) {
@@ -735,20 +706,6 @@ int launch_encode_pfd_paged(const float *grad, const float *codebook, int64_t M,
     if (d == 32) return launch_pfd_paged<32>(grad, codebook, M, K, codes, u, ws, st);
     return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: the paged prefilter kernel was asked for d = %d", d);
 }
-
-template <typename CodeT>
-int launch_encode_pfd(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u, float *ws,
-                      hipStream_t st) {
-    if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
-    if (d == 8) return launch_pfd<CodeT, 8>(grad, codebook, M, codes, u, ws, st);
-    if (d == 32) return launch_pfd<CodeT, 32>(grad, codebook, M, codes, u, ws, st);
-    return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: the d = 8 / 32 prefilter kernel was asked for d = %d", d);
-}
-
-template int launch_encode_pfd<uint8_t>(const float *, const float *, int64_t, int, uint8_t *, float *, float *,
-                                        hipStream_t);
-template int launch_encode_pfd<int32_t>(const float *, const float *, int64_t, int, int32_t *, float *, float *,
-                                        hipStream_t);
 
 template <int D>
 static int pfd_batched_paged(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,

@@ -125,10 +125,24 @@ class ProbabilisticScalarCompressor(object):
         return lb_ub[0], lb_ub[1], levels.view(vec.shape)
 
     def decompress(self, signature):
+        """probabilistic_scalar_compressor.py:29-33 on the library's decode: float(l) * (ub - lb) / 2^n + lb, each step rounded on
+        its own, is what gq_hsq_decode_sum computes for the norm of a subvector -- here times a one-by-one codebook holding 1.0
+        (exact).  (Until round 6: three torch elementwise launches.)"""
         lower_bound, upper_bound, l = signature
-        # host-language mirror of prob_scalar:31-32 (the fused path is gq_hsq_decode_sum)
-        scaled_vec = l.type(dtype=torch.float32)
-        return scaled_vec * (upper_bound - lower_bound) / self.s + lower_bound
+        _require_device(l, "ProbabilisticScalarCompressor.decompress")
+        dev = l.device
+        flat = l.contiguous().view(-1)
+        if flat.dtype not in (torch.uint8, torch.int16, torch.int32):
+            flat = flat.to(torch.int32)
+        M = flat.numel()
+        unit = getattr(self, "_unit", None)
+        if unit is None or unit[0].device != dev or unit[1].numel() < M:
+            unit = self._unit = (torch.ones((1, 1), dtype=torch.float32, device=dev), torch.zeros(M, dtype=torch.uint8, device=dev))
+        lb_ub = torch.stack([torch.as_tensor(lower_bound, dtype=torch.float32, device=dev).reshape(()),
+                             torch.as_tensor(upper_bound, dtype=torch.float32, device=dev).reshape(())])
+        out = torch.empty(M, dtype=torch.float32, device=dev)
+        native.hsq_decode_sum(unit[1][:M], flat, lb_ub, unit[0], self.n_bit, out, R=1)
+        return out.view(l.shape)
 
 
 class NearestNeighborCompressor(object):

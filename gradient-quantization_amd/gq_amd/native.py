@@ -18,7 +18,7 @@ WS_LOG_FIRST = 2 * GQ_MAX_PARTIALS + 4      # f32-sized words in front of the wo
 GQ_FIXUP_PARTIALS = 256
 RANDOM_OFF, RANDOM_GIVEN, RANDOM_DEVICE, RANDOM_DEVICE_KEYED, RANDOM_DEVICE_COUNTER = 0, 1, 2, 3, 4
 ENCODE_AUTO, ENCODE_MFMA_D16K256, ENCODE_MFMA_GENERIC, ENCODE_VALU, ENCODE_PREFILTER_D16K256 = 0, 1, 2, 3, 4
-ENCODE_MFMA_LDS, ENCODE_PREFILTER_BF16X3 = 5, 6
+ENCODE_MFMA_LDS = 5
 TICKET_WORDS = 544      # GQ_TICKET_WORDS: int32 words of gq_step_tail.ticket (StepTail(ticket=...))
 
 EXPORTS = [     # every entry point include/gq_hsq.h declares (tests/test_host_logic.py compares the two lists)

@@ -651,9 +651,10 @@ class PSQuantizer(object):
         its launches): encode, then gq_hsq_levels_decode_batched.  $GQ_FUSE_LEVELS=0 keeps the three launches."""
         if os.environ.get("GQ_FUSE_LEVELS", "1") == "0" or not self._groups:
             return False
-        if self.error_feedback and os.environ.get("GQ_FUSE_LEVELS") != "ef":
-            # measured (profiles/r05_experiments.txt, 2): with error feedback the one launch moves three streams (updated gradient in,
-            # residual and decoded tensor out) and is SLOWER than the level launch + the decode (0.1233 against 0.1158 ms per step)
+        if self.error_feedback:
+            # measured twice (profiles/r05_experiments.txt, 2 and 8): with error feedback the one launch moves three streams (updated
+            # gradient in, residual and decoded tensor out) and is SLOWER than the level launch + the decode (0.1203 against
+            # 0.1175 ms per step); the opt-in that forced it ($GQ_FUSE_LEVELS=ef) went in round 6
             return False
         obj = self._groups[0][2]      # (several groups: the chunks of ONE tensor group, _overlap_chunks; the first carries the dense tensors)
         return (all(isinstance(g[2], BatchedHSQ) and g[2].fusable_levels() for g in self._groups)

@@ -125,7 +125,7 @@ int gq_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, in
  * of what is left, for K = 256 and d in {8, 16, 32} (the default for those shapes; bit-identical output; K > 256 in
  * pages of 256: round 3's bf16 x 3 scheme), 5 = exact f32 MFMA with the codebook (chunked when it does not fit) and the
  * subvector tiles staged in LDS, any d <= 128 and any K (the default for every other shape; 2 remains the fallback for
- * d > 128), 6 = round 3's bf16 x 3 prefilter for K = 256 and d in {8, 32} (a cross-check of 4).
+ * d > 128).  (6, round 3's bf16 x 3 prefilter for K = 256, was removed in round 6: GQ_ERR_INVALID_ARG.)
  * profile_slot: see gq_profile_read. */
 #define GQ_ENCODE_AUTO 0
 #define GQ_ENCODE_MFMA_D16K256 1
@@ -133,7 +133,6 @@ int gq_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, in
 #define GQ_ENCODE_VALU 3
 #define GQ_ENCODE_PREFILTER_D16K256 4
 #define GQ_ENCODE_MFMA_LDS 5
-#define GQ_ENCODE_PREFILTER_BF16X3 6
 int gq_hsq_encode_ex(const float *grad, const float *codebook, int64_t M, int d, int K, void *codes, int code_bytes,
                      float *u, float *workspace, int impl, int profile_slot, void *stream);
 

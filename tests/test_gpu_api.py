@@ -465,7 +465,7 @@ def test_step_tail_in_the_decode_launch_equals_a_launch_of_its_own(monkeypatch, 
 
     def run(tail, fuse_levels=False):
         monkeypatch.setenv("GQ_STEP_TAIL", "1" if tail else "0")
-        monkeypatch.setenv("GQ_FUSE_LEVELS", ("ef" if kw.get("ef") else "1") if fuse_levels else "0")      # ("ef": the fused form is off by default under error feedback)
+        monkeypatch.setenv("GQ_FUSE_LEVELS", "1" if fuse_levels else "0")      # (under error feedback the step keeps its level launch and its decode either way)
         torch.manual_seed(77)
         from gq_amd import compressors
         compressors._seed_counter[0] = 0      # (the pairs' seeds come from torch's seed and a per-process call counter)

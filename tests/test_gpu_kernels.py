@@ -77,10 +77,10 @@ def gpu_decode(nat, res, n_bit):
     return out.cpu().numpy()
 
 
-IMPLS = {"auto": 0, "mfma_exact_d16k256": 1, "mfma_generic": 2, "valu": 3, "prefilter_d16k256": 4, "mfma_lds": 5, "prefilter_bf16x3": 6}
+IMPLS = {"auto": 0, "mfma_exact_d16k256": 1, "mfma_generic": 2, "valu": 3, "prefilter_d16k256": 4, "mfma_lds": 5}
 
 
-@pytest.mark.parametrize("impl", ["auto", "mfma_exact_d16k256", "mfma_generic", "valu", "prefilter_d16k256", "mfma_lds", "prefilter_bf16x3"])
+@pytest.mark.parametrize("impl", ["auto", "mfma_exact_d16k256", "mfma_generic", "valu", "prefilter_d16k256", "mfma_lds"])
 @pytest.mark.parametrize("name", HSQ_CASES)
 def test_hsq_matches_reference_golden(nat, name, impl):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
@@ -91,8 +91,6 @@ def test_hsq_matches_reference_golden(nat, name, impl):
         pytest.skip("d16/K256 specialisation")
     if impl == "prefilter_d16k256" and not (K == 256 and d in (8, 16, 32)):
         pytest.skip("the prefilter kernels are built for K = 256 and d in {8, 16, 32}")
-    if impl == "prefilter_bf16x3" and not (K == 256 and d in (8, 32)):
-        pytest.skip("round 3's bf16 x 3 prefilter is kept for K = 256 and d in {8, 32}")
     cb = _cb(d, K)
     r = g["r"] if random else None
     res = gpu_compress(nat, g["x"], cb, n_bit, random, r, impl=IMPLS[impl])

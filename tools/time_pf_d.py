@@ -1,6 +1,6 @@
 """gq_hsq_encode on 25 M elements for d = 8 / 16 / 32 (K = 256, the packaged codebooks): the f16 prefilter kernel (impl 4,
-hsq_encode_pf.hip) next to round 3's bf16 x 3 kernel (impl 6, hsq_encode_pfd.hip; d = 8 / 32 only), 1000 untimed + 1000 timed
-launches each, outputs compared bit for bit.    python tools/time_pf_d.py [d ...]"""
+hsq_encode_pf.hip) next to the exact f32 MFMA kernel (impl 1 for d = 16, impl 5 otherwise), 1000 untimed + 1000 timed launches
+of the prefilter (50 of the exact kernel), outputs compared bit for bit.    python tools/time_pf_d.py [d ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gradient-quantization_amd"))
@@ -17,11 +17,11 @@ for d in dims:
     cb = torch.from_numpy(load_codebook(d, 256)).to(dev)
     M = n // d
     out = {}
-    for impl in ((4, 6) if d != 16 else (4, 1)):
+    for impl in ((4, 5) if d != 16 else (4, 1)):
         codes = torch.empty(M, dtype=torch.uint8, device=dev)
         u = torch.empty(M, dtype=torch.float32, device=dev)
         ws = native.new_workspace(dev, M)
-        reps = 1000 if impl != 1 else 50
+        reps = 1000 if impl == 4 else 50
         for _ in range(reps):
             native.hsq_encode(g, cb, codes, u, ws, impl=impl)
         torch.cuda.synchronize()
