@@ -28,11 +28,12 @@ static int check_batch(const gq_hsq_batch *b, const char *what) {
     return GQ_OK;
 }
 
-static bool pf_dim(int d) { return d == 8 || d == 16 || d == 32; }
+static bool pf_dim(int d) { return d == 8 || d == 16 || d == 32; }      // shapes of the specialised level / decode kernels and of the paged encode
+static bool pf_encode_dim(int d) { return pf_dim(d) || d == 12 || d == 24; }   // ... of the K = 256 prefilter encode (12 / 24: the reference's repaired dimensions, padded to 16 / 32)
 
 // Which encode serves the descriptor (see gq_hsq_batched_path in the header); 0 + an error text if none.
 static int batch_path(const gq_hsq_batch *b) {
-    if (pf_dim(b->d) && b->K == 256 && b->code_bytes == 1) {
+    if (pf_encode_dim(b->d) && b->K == 256 && b->code_bytes == 1) {
         return GQ_BATCH_PREFILTER;   // (any number of tensors: beyond 384 the segment records are read from global memory)
     } else if (pf_dim(b->d) && b->K > 256 && (b->K & 255) == 0 && b->code_bytes == 4 && b->nseg <= 384) {
         return GQ_BATCH_PAGED;

@@ -183,9 +183,14 @@ static void pf_split(PfArgs &a, int64_t ntiles, int64_t blocks) {
 // SEGLDS (batched only): the segment records are read from their LDS copy (nseg <= PF_LDS_SEGS) or, for
 // longer tensor lists, from global memory -- as two instantiations, because a run-time choice between
 // the two sources turns the record pointer into a flat pointer (see tile_info).
-template <typename CodeT, int D, bool BATCHED, bool EF = false, bool SEGLDS = true>
+// DR (round 6): the tensors' REAL sub-dimension when the reference repaired it to one this kernel has no shape for
+// (nearest_neighbor_compressor.py:23-29: 16 -> 24, 8 -> 12): rows of DR floats in memory (gradient, error buffer, codebook), D = the
+// next of 16 / 32 everywhere else -- the missing elements are zeros in the fragments, in the LDS image and in the lane's subvector,
+// and fmaf(0, 0, acc) == acc bit for bit (acc starts at +0 and can never become -0), so scores, codes and u are the exact kernels'.
+template <typename CodeT, int D, bool BATCHED, bool EF = false, bool SEGLDS = true, int DR = D>
 __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfArgs a) {
     typedef PfShape<D> SH;
+    static_assert(DR == D || (D == 16 && DR == 12) || (D == 32 && DR == 24), "padded shapes: 12 -> 16, 24 -> 32");
     constexpr int KS = SH::KS, QS = SH::QS, QCAP = SH::QCAP, NF = SH::NF;
     constexpr bool HALF = SH::HALF, PF_PAIR = SH::PAIR;
     GQ_STAMPS_ONLY(const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime(); unsigned long long nscanned = 0, npassed = 0;)
@@ -340,8 +345,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // each block, clamped to the tile's last valid one (tail: re-read it, the result is masked).
     auto lane_off = [&](const Tile &ti, int blk) {   // float offset of v[8h..] of subvector blk*32+j from the tile's first float
         const unsigned li = min((unsigned)(blk * 32 + j), (unsigned)ti.rem);
-        return li * (unsigned)D + (HALF ? 0u : 8u * (unsigned)h);
+        return li * (unsigned)DR + (HALF ? 0u : 8u * (unsigned)h);
     };
+    // floats [16 s + 8 h + 4 q, + 4) of a row exist (DR < D: the upper lanes' last fragments do not -- they stay zero and are
+    // neither read nor written: the row behind the tensor's last one is not ours)
+    auto frag_ok = [&](int s_, int q_) { return DR == D || 16 * s_ + 4 * q_ + 4 + 8 * h <= DR; };
     const bool loads_here = !HALF || h == 0;   // D = 8: the lower lanes hold the subvectors, the upper ones zeros
     auto load_rows = [&](gcf_ptr tb, const Tile &ti, f32x4(&dst)[NF]) {
         if (loads_here) {
@@ -350,20 +358,21 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
                 const gcv_ptr p = (gcv_ptr)(tb + lane_off(ti, blk));
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    dst[(blk * KS + s) * 2] = p[4 * s];
-                    dst[(blk * KS + s) * 2 + 1] = p[4 * s + 1];
+                    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                    dst[(blk * KS + s) * 2] = frag_ok(s, 0) ? p[4 * s] : z;
+                    dst[(blk * KS + s) * 2 + 1] = frag_ok(s, 1) ? p[4 * s + 1] : z;
                 }
             }
         }
     };
-    auto load_tile = [&](const Tile &ti, f32x4(&dst)[NF]) { load_rows(ti.base + ti.sv0 * D, ti, dst); };
+    auto load_tile = [&](const Tile &ti, f32x4(&dst)[NF]) { load_rows(ti.base + ti.sv0 * DR, ti, dst); };
     auto load_err = [&](const Tile &ti, f32x4(&dst)[NF]) {
-        if (EF && ti.err) load_rows(ti.err + ti.sv0 * D, ti, dst);
+        if (EF && ti.err) load_rows(ti.err + ti.sv0 * DR, ti, dst);
     };
     // v = grad + scale*error, written back over grad (valid subvectors only)
     auto fold_err = [&](const Tile &ti, f32x4(&g)[NF], const f32x4(&e)[NF]) {
         if (EF && ti.err) {
-            const gf_ptr tb = (gf_ptr)(ti.base + ti.sv0 * D);
+            const gf_ptr tb = (gf_ptr)(ti.base + ti.sv0 * DR);
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
@@ -377,11 +386,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
                     }
                 }
                 if (blk * 32 + j <= ti.rem && loads_here) {
-                    const gv_ptr p = (gv_ptr)(tb + (unsigned)((blk * 32 + j) * D + (HALF ? 0 : 8 * h)));
+                    const gv_ptr p = (gv_ptr)(tb + (unsigned)((blk * 32 + j) * DR + (HALF ? 0 : 8 * h)));
 #pragma unroll
                     for (int s = 0; s < KS; ++s) {
-                        p[4 * s] = g[(blk * KS + s) * 2];
-                        p[4 * s + 1] = g[(blk * KS + s) * 2 + 1];
+                        if (frag_ok(s, 0)) p[4 * s] = g[(blk * KS + s) * 2];
+                        if (frag_ok(s, 1)) p[4 * s + 1] = g[(blk * KS + s) * 2 + 1];
                     }
                 }
             }
@@ -421,17 +430,17 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // through LDS -- each wave splitting all 8 cost 0.8 us of VALU time per SIMD), and the wave's first tile,
     // whose HBM latency then hides behind the staging.  One barrier.  (Before: staging, fragments, barrier,
     // ||c||_1, barrier and only then the first tile's loads: 5.2 us; profiles/r02_b_pf_prologue_stamps.txt.)
-    float cbv[256 * D / PF_THREADS];
+    float cbv[256 * DR / PF_THREADS];
 #pragma unroll
-    for (int n = 0; n < 256 * D / PF_THREADS; ++n) cbv[n] = cb[threadIdx.x + n * PF_THREADS];
+    for (int n = 0; n < 256 * DR / PF_THREADS; ++n) cbv[n] = cb[threadIdx.x + n * PF_THREADS];
     f32x4 aq[2 * KS];   // row wave*32 + j, k-step s: floats [16 s + 8 h, + 8)
 #pragma unroll
     for (int i = 0; i < 2 * KS; ++i) aq[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (loads_here) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            aq[2 * s] = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * D + 16 * s + (HALF ? 0 : 8 * h));
-            aq[2 * s + 1] = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * D + 16 * s + (HALF ? 0 : 8 * h) + 4);
+            if (frag_ok(s, 0)) aq[2 * s] = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * DR + 16 * s + (HALF ? 0 : 8 * h));
+            if (frag_ok(s, 1)) aq[2 * s + 1] = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * DR + 16 * s + (HALF ? 0 : 8 * h) + 4);
         }
     }
     const int seg_first_v = (BATCHED && lo_tile < ntiles) ? a.tile_seg[lo_tile] : 0;   // (requested with the first tile's word)
@@ -450,9 +459,16 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         s_mm[2 * threadIdx.x + 1] = 0u;
     }
 #pragma unroll
-    for (int n = 0; n < 256 * D / PF_THREADS; ++n) {
-        const int i = threadIdx.x + n * PF_THREADS, k = i / D, jj = i % D;
+    for (int n = 0; n < 256 * DR / PF_THREADS; ++n) {
+        const int i = threadIdx.x + n * PF_THREADS, k = i / DR, jj = i % DR;
         s_cb[(k >> 2) * QS + 4 * jj + (k & 3)] = cbv[n];
+    }
+    if constexpr (DR != D) {      // the image's padding columns: zeros (the rescoring multiplies them with the subvector's zeros)
+#pragma unroll
+        for (int n = 0; n < 256 * (D - DR) / PF_THREADS; ++n) {
+            const int i = threadIdx.x + n * PF_THREADS, k = i / (D - DR), jj = DR + i % (D - DR);
+            s_cb[(k >> 2) * QS + 4 * jj + (k & 3)] = 0.0f;
+        }
     }
     if (BATCHED && SEGLDS) {
         const int n = (a.nseg < PF_LDS_SEGS ? a.nseg : PF_LDS_SEGS) * 8;
@@ -1113,11 +1129,11 @@ static int64_t pf16_grid(int64_t ntiles, int bpc) {
     return blocks < 1 ? 1 : blocks;
 }
 
-template <typename CodeT, int D>
+template <typename CodeT, int D, int DR = D>
 static int launch_pf(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *ws,
                      hipStream_t st, int profile_slot) {
     if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
-    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<CodeT, D, false>, PF_THREADS, 0);
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<CodeT, D, false, false, true, DR>, PF_THREADS, 0);
     PfArgs a = {};
     a.grad = grad;
     a.M = M;
@@ -1129,23 +1145,25 @@ static int launch_pf(const float *grad, const float *codebook, int64_t M, CodeT 
     pf_split(a, (M + 63) / 64, blocks);
     hipEvent_t ev_start, ev_stop;
     if (profile_events(profile_slot, &ev_start, &ev_stop)) {   // events attached to this dispatch (gq_profile_read)
-        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, D, false>), dim3((unsigned)blocks),
+        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, D, false, false, true, DR>), dim3((unsigned)blocks),
                               dim3(PF_THREADS), 0, st, ev_start, ev_stop, 0, a);
     } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, D, false>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, D, false, false, true, DR>), dim3((unsigned)blocks),
                            dim3(PF_THREADS), 0, st, a);
     }
     GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter)");
     return GQ_OK;
 }
 
-// d = 8, 16 or 32 (K = 256)
+// d = 8, 16 or 32 (K = 256); d = 12 / 24 (the reference's repaired dimensions) as the D = 16 / 32 kernels over rows of 12 / 24 floats
 template <typename CodeT>
 int launch_encode_pf(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u, float *ws,
                      hipStream_t st, int profile_slot) {
     if (d == 16) return launch_pf<CodeT, 16>(grad, codebook, M, codes, u, ws, st, profile_slot);
     if (d == 32) return launch_pf<CodeT, 32>(grad, codebook, M, codes, u, ws, st, profile_slot);
     if (d == 8) return launch_pf<CodeT, 8>(grad, codebook, M, codes, u, ws, st, profile_slot);
+    if (d == 12) return launch_pf<CodeT, 16, 12>(grad, codebook, M, codes, u, ws, st, profile_slot);
+    if (d == 24) return launch_pf<CodeT, 32, 24>(grad, codebook, M, codes, u, ws, st, profile_slot);
     return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: the prefilter kernel was asked for d = %d", d);
 }
 
@@ -1155,7 +1173,7 @@ template int launch_encode_pf<int32_t>(const float *, const float *, int64_t, in
 }  // namespace gq
 
 namespace gq {
-template <int D, bool EF>
+template <int D, bool EF, int DR = D>
 static int encode_batched(const char *what, const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                           const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax, float *workspace,
                           float ef_scale, int profile_slot, void *stream) {
@@ -1163,7 +1181,7 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
         return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes nseg=%d ntiles=%lld", what, nseg, (long long)ntiles);
     if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
         return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
-    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<uint8_t, D, true, EF, true>, PF_THREADS, 0);
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<uint8_t, D, true, EF, true, DR>, PF_THREADS, 0);
     PfArgs a = {};
     a.M = ntiles * 64;
     a.u = u_flat;
@@ -1181,13 +1199,13 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
     pf_split(a, ntiles, blocks);
     hipEvent_t ev_start, ev_stop;
     if (nseg <= PF_LDS_SEGS && profile_events(profile_slot, &ev_start, &ev_stop)) {   // events attached to this dispatch
-        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, true>), dim3((unsigned)blocks),
+        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, true, DR>), dim3((unsigned)blocks),
                               dim3(PF_THREADS), 0, st, ev_start, ev_stop, 0, a);
     } else if (nseg <= PF_LDS_SEGS) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, true>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, true, DR>), dim3((unsigned)blocks),
                            dim3(PF_THREADS), 0, st, a);
     } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, false>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, false, DR>), dim3((unsigned)blocks),
                            dim3(PF_THREADS), 0, st, a);
     }
     GQ_CHECK_LAUNCH(what);
@@ -1224,15 +1242,17 @@ GQ_INTERNAL int gqi_hsq_encode_batched_pf(const int64_t *seg_table, const int32_
                                           const float *codebook, int d, int ef, float ef_scale, uint8_t *wire, float *u_flat,
                                           uint32_t *seg_minmax, float *workspace, int profile_slot, void *stream) {
     const char *what = "gq_hsq_encode_batched";
-#define GQ_PF_BATCHED(DD)                                                                                                 \
+#define GQ_PF_BATCHED(DD, DP)                                                                                             \
     if (d == DD)                                                                                                          \
-        return ef ? gq::encode_batched<DD, true>(what, seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, \
-                                                 workspace, ef_scale, profile_slot, stream)                               \
-                  : gq::encode_batched<DD, false>(what, seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, \
-                                                  workspace, 0.0f, profile_slot, stream);
-    GQ_PF_BATCHED(16)
-    GQ_PF_BATCHED(32)
-    GQ_PF_BATCHED(8)
+        return ef ? gq::encode_batched<DP, true, DD>(what, seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, \
+                                                     workspace, ef_scale, profile_slot, stream)                           \
+                  : gq::encode_batched<DP, false, DD>(what, seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, \
+                                                      workspace, 0.0f, profile_slot, stream);
+    GQ_PF_BATCHED(16, 16)
+    GQ_PF_BATCHED(32, 32)
+    GQ_PF_BATCHED(8, 8)
+    GQ_PF_BATCHED(12, 16)
+    GQ_PF_BATCHED(24, 32)
 #undef GQ_PF_BATCHED
-    return gq::fail(GQ_ERR_UNSUPPORTED, "%s: d must be 8, 16 or 32 (K = 256)", what);
+    return gq::fail(GQ_ERR_UNSUPPORTED, "%s: d must be 8, 12, 16, 24 or 32 (K = 256)", what);
 }

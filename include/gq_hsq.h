@@ -122,7 +122,7 @@ int gq_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, in
  * identical for every impl):  0 = auto, 1 = exact f32 MFMA, d16/K256, register-resident
  * codebook, 2 = exact f32 MFMA generic (any d, K), 3 = VALU fmaf chain with the codebook in
  * LDS, 4 = f16 MFMA prefilter (one MFMA per chain and 16 dimensions) + exact f32 rescoring + second pass + exact scan
- * of what is left, for K = 256 and d in {8, 16, 32} (the default for those shapes; bit-identical output; K > 256 in
+ * of what is left, for K = 256 and d in {8, 12, 16, 24, 32} (the default for those shapes; bit-identical output; K > 256 in
  * pages of 256: round 3's bf16 x 3 scheme), 5 = exact f32 MFMA with the codebook (chunked when it does not fit) and the
  * subvector tiles staged in LDS, any d <= 128 and any K (the default for every other shape; 2 remains the fallback for
  * d > 128).  (6, round 3's bf16 x 3 prefilter for K = 256, was removed in round 6: GQ_ERR_INVALID_ARG.)
@@ -208,7 +208,9 @@ int gq_hsq_levels_decode(const float *u, int64_t M, int n_bit, int random_mode, 
  *              gq_hsq_batched_path() says GQ_BATCH_EXACT
  *
  * gq_hsq_batched_path(b): which kernels serve (d, K, code_bytes, level_bytes, nseg) --
- *   GQ_BATCH_PREFILTER  K = 256, d in {8, 16, 32}, byte codes: f16 prefilter + exact rescoring + second pass (any number of tensors)
+ *   GQ_BATCH_PREFILTER  K = 256, d in {8, 16, 32}, byte codes: f16 prefilter + exact rescoring + second pass (any number of tensors);
+ *                       round 6: d = 12 / 24 too (the reference's repaired dimensions, nearest_neighbor_compressor.py:23-29) as
+ *                       rows of 12 / 24 floats through the d = 16 / 32 kernels; their level / decode launches are the generic ones
  *   GQ_BATCH_PAGED      d in {8, 16, 32}, K = 512, 768, ... 65536, int32 codes, <= 384 tensors: the prefilter with the
  *                       pages of 256 codewords resident in LDS (an earlier page keeps a tie: the first maximum)
  *   GQ_BATCH_EXACT      any other d <= 104 and K: exact f32 MFMA scoring, codebook chunked in LDS when large

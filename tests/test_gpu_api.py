@@ -50,7 +50,7 @@ def _args_for(g, name):
     kw = dict(n_bit=int(g["n_bit"]), random=int(g["random"]), gq_rng="reference")
     if name.startswith("hsq"):
         kw["k_bit"] = int(np.log2(K))
-        kw["c_dim"] = {"hsq_d24_k64_repair_det": 16}.get(name, d)
+        kw["c_dim"] = {"hsq_d24_k64_repair_det": 16, "hsq_d24_k256_repair_det": 16, "hsq_d12_k256_repair_det": 8}.get(name, d)
     return make_args(**kw)
 
 
@@ -65,7 +65,8 @@ def test_nearest_neighbor_compressor_signature_and_values(name):
     if args.random:
         # reference-parity RNG: the same CPU draw the fixture recorded
         seeds = {"hsq_randn_s1_rand": 4321, "hsq_randn_s1_n2_rand": 99, "hsq_randn_s1e-3_rand": 777,
-                 "hsq_small_48_rand": 5, "hsq_zeros_rand": 1, "hsq_constant_u_rand": 2, "hsq_d8_k256_rand": 11}
+                 "hsq_small_48_rand": 5, "hsq_zeros_rand": 1, "hsq_constant_u_rand": 2, "hsq_d8_k256_rand": 11,
+                 "hsq_d12_k256_rand": 61, "hsq_d24_k256_rand": 62}
         torch.manual_seed(seeds[name])
     sig = comp.compress(x)
     norms, codes = sig
@@ -582,6 +583,52 @@ def test_batched_quantizer_other_subdimensions_equal_per_tensor_path(c_dim):
                 assert torch.equal(eb, ep)
             if kw.get("two_phase"):
                 assert torch.equal(pb.server_error, pp.server_error)
+
+
+@pytest.mark.parametrize("c_dim,repaired", [(16, 24), (8, 12)])
+def test_repaired_dimensions_run_on_the_prefilter_kernels_and_equal_the_reference(c_dim, repaired, oracle):
+    """nearest_neighbor_compressor.py:23-29: a tensor whose size --c-dim does not divide gets c_dim * 3 / 2 (16 -> 24, 8 -> 12).
+    Round 6: K = 256 with d = 12 / 24 runs on the f16 prefilter encode (rows of 12 / 24 floats through the d = 16 / 32 kernels, the
+    missing elements zeros) instead of the exact f32 MFMA kernel -- multi-tensor and per-tensor forms, error feedback and
+    two-phase included -- and the wire's codes and projections equal the oracle's, bit for bit."""
+    from gq_amd import native
+    from gq_amd.quantizers import BatchedHSQ
+    shapes = [(repaired * 501,), (repaired, 3, 43), (c_dim * 1024,), (repaired * 64 * 9 + repaired,), (c_dim, 130), (10,), (repaired * 3,), (64,)]
+    assert all(int(np.prod(s)) % c_dim != 0 or i in (2, 4, 7) for i, s in enumerate(shapes))
+    qb, gb = _run_quantizer(shapes, 2, 13, c_dim=c_dim)
+    qp, gp = _run_quantizer(shapes, 2, 13, c_dim=c_dim, gq_no_batch=True)
+    dims = sorted({c.c.dim for c in qb.codecs if hasattr(c, "c")})
+    assert dims == [c_dim, repaired], dims
+    grp = [g[2] for g in qb._groups if isinstance(g[2], BatchedHSQ) and g[2].codecs[0].c.dim == repaired]
+    assert grp and grp[0].ready and grp[0]._batch.path == native.BATCH_PREFILTER and not qp._groups
+    for a, b, sh in zip(gb, gp, shapes):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), sh
+    assert torch.equal(qb._wire, qp._wire)
+    # codes and lb / ub of every repaired tensor on the wire against the oracle (one user's last record)
+    g = torch.Generator(device="cuda").manual_seed(13)
+    grads = [[[torch.randn(sh, device="cuda", generator=g) * 1e-2 for sh in shapes] for _ in range(2)] for _ in range(2)][1]
+    cbn = qb.codecs[0].c._codebook_on(torch.device("cuda:0")).cpu().numpy()
+    for u in range(2):
+        for i, sh in enumerate(shapes):
+            cd = qb.codecs[i]
+            if not hasattr(cd, "c") or cd.c.dim != repaired:
+                continue
+            codes, levels, lb_ub = cd._views(qb._wire[u], qb.offsets[i])
+            ref = oracle.hsq_compress(grads[u][i].cpu().numpy().reshape(-1), cd.c._codebook_on(torch.device("cuda:0")).cpu().numpy(), 6, 0)
+            assert np.array_equal(codes.cpu().numpy().astype(np.int32), ref["codes"]), (u, sh)
+            assert np.array_equal(levels.cpu().numpy().astype(np.int32), ref["levels"]), (u, sh)
+            assert _bits(lb_ub[0].item()) == _bits(ref["lb"]) and _bits(lb_ub[1].item()) == _bits(ref["ub"])
+    for kw in (dict(ef=True), dict(ef=True, two_phase=True, scale="0.5"), dict(random=1, gq_rng="reference")):
+        torch.manual_seed(99)      # (gq_rng = "reference": the draws are torch.rand's, per tensor in parameter order)
+        qe, ge = _run_quantizer(shapes, 2, 13, c_dim=c_dim, **kw)
+        torch.manual_seed(99)
+        qf, gf = _run_quantizer(shapes, 2, 13, c_dim=c_dim, gq_no_batch=True, **kw)
+        for a, b in zip(ge, gf):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        if kw.get("ef"):
+            for pb, pp in zip(qe.parameters, qf.parameters):
+                for eb, ep in zip(pb.error, pp.error):
+                    assert torch.equal(eb, ep)
 
 
 def _shapes_for(d):

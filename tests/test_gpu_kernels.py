@@ -89,8 +89,8 @@ def test_hsq_matches_reference_golden(nat, name, impl):
         pytest.skip("valu cross-check kernel not built for this shape")
     if impl == "mfma_exact_d16k256" and (d, K) != (16, 256):
         pytest.skip("d16/K256 specialisation")
-    if impl == "prefilter_d16k256" and not (K == 256 and d in (8, 16, 32)):
-        pytest.skip("the prefilter kernels are built for K = 256 and d in {8, 16, 32}")
+    if impl == "prefilter_d16k256" and not (K == 256 and d in (8, 12, 16, 24, 32)):
+        pytest.skip("the prefilter kernels are built for K = 256 and d in {8, 16, 32} (12 / 24, the repaired dimensions, as padded 16 / 32)")
     cb = _cb(d, K)
     r = g["r"] if random else None
     res = gpu_compress(nat, g["x"], cb, n_bit, random, r, impl=IMPLS[impl])
@@ -590,9 +590,10 @@ def test_full_size_decode_mean_of_eight_and_sixteen_payloads_equals_the_oracle(n
     assert np.array_equal(_bits(out.cpu().numpy()), _bits(want))
 
 
-@pytest.mark.parametrize("d", [16, 8, 32])
+@pytest.mark.parametrize("d", [16, 8, 32, 12, 24])
 def test_prefilter_equals_exact_mfma_at_full_size_and_fixup_rate(nat, d):
-    """The f16 prefilter path (d = 16, 8 and 32) must reproduce the exact f32 MFMA kernel bit for bit on 25M
+    """The f16 prefilter path (d = 16, 8 and 32; round 6: 12 and 24, the reference's repaired dimensions, as rows of 12 / 24
+    floats through the d = 16 / 32 kernels) must reproduce the exact f32 MFMA kernel bit for bit on 25M
     elements (randn and randn*1e-3), and only a small fraction may need the second pass / exact scan."""
     dev = torch.device("cuda:0")
     cb = torch.from_numpy(_cb(d, 256)).to(dev)
@@ -624,7 +625,7 @@ def test_prefilter_equals_exact_mfma_at_full_size_and_fixup_rate(nat, d):
         print("scale %g: fix-up worklist %d of %d subvectors (%.4f%%)" % (scale, n_fix, M, 100.0 * n_fix / M))
 
 
-@pytest.mark.parametrize("d", [16, 8, 32])
+@pytest.mark.parametrize("d", [16, 8, 32, 12, 24])
 @pytest.mark.parametrize("case", ["zeros", "constant", "ties", "huge", "tiny", "mixed_scales"])
 def test_prefilter_degenerate_inputs_match_exact(nat, oracle, case, d):
     rng = np.random.RandomState(11)
