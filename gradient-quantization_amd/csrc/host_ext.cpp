@@ -46,6 +46,32 @@ static py::tuple scan_grads(const py::list &parameters) {
     return py::make_tuple(grads, py::bytes(key), ok);
 }
 
+// scan_key(parameters) -> (key, ok, device index): scan_grads without the list of Python objects -- what a record() that replays a
+// whole-step graph needs to know (161 object look-ups less per step on a path the host bounds); device index -1: no CUDA gradient.
+static py::tuple scan_key(const py::list &parameters) {
+    const size_t n = parameters.size();
+    std::string key(n * sizeof(int64_t), '\0');
+    bool ok = n > 0;
+    c10::Device dev(c10::DeviceType::CPU);
+    for (size_t i = 0; i < n; ++i) {
+        if (!THPVariable_Check(parameters[i].ptr())) throw py::type_error("scan_key: the list holds something that is not a tensor");
+        const at::Tensor &g = THPVariable_Unpack(parameters[i].ptr()).grad();
+        int64_t ptr = 0;
+        if (g.defined()) {
+            ptr = reinterpret_cast<int64_t>(g.data_ptr());
+            ok = ok && g.scalar_type() == at::kFloat && g.is_contiguous();
+            if (i == 0)
+                dev = g.device();
+            else
+                ok = ok && g.device() == dev;
+        } else {
+            ok = false;
+        }
+        std::memcpy(&key[i * sizeof(int64_t)], &ptr, sizeof(int64_t));
+    }
+    return py::make_tuple(py::bytes(key), ok, dev.is_cuda() ? (int)dev.index() : -1);
+}
+
 // set_data(objects, values): objects[i].data = values[i]  (ps_quantizer.py:63 for every parameter)
 static void set_data(const py::list &objects, const py::list &values) {
     const size_t n = objects.size();
@@ -80,4 +106,5 @@ PYBIND11_MODULE(_gq_host, m) {
     m.def("set_grad_data", &set_grad_data, "parameters[i].grad.data = values[i], .grad evaluated at the call");
     m.def("scan_grads", &scan_grads, "The .grad tensors of a parameter list, their addresses as a bytes key, and whether all are plain f32");
     m.def("set_data", &set_data, "objects[i].data = values[i]");
+    m.def("scan_key", &scan_key, "The parameters' gradient addresses as a bytes key, whether all are plain f32 on one device, that device's index");
 }

@@ -411,6 +411,7 @@ class _BatchedBase(object):
         self._tmp_wire = None
         self.ready = False      # the device header has been written at least once
         self._outs, self._out_views, self._out_turn = [None, None], [None, None], 0
+        self._out_gen = 0               # output-buffer allocations so far (PSQuantizer._apply_key_for remembers the buffers' addresses per count)
         self._layout = table.clone()    # host copy of the segment table without pointers (decode needs no pointers)
         self._parts = {}                # (first tensor, end) -> launch descriptor of one chunk of a split / pipelined decode
         self.rng_pairs = None           # this group's { seed, step } pairs, one per user slot (PSQuantizer._rng_pairs_for)
@@ -429,6 +430,7 @@ class _BatchedBase(object):
             out = torch.empty(self.out_floats, dtype=torch.float32, device=device)
             self._outs[k] = out
             self._out_views[k] = [out[o:o + cd.numel].view(cd.shape) for o, cd in zip(self.out_off, self.codecs)]
+            self._out_gen += 1
         return self._outs[k], self._out_views[k]
 
     def dense_table_dev(self):

@@ -686,6 +686,8 @@ def test_host_helper_walks_match_the_python_walks():
     grads, key, ok = H.scan_grads(params)
     assert ok and all(g is p.grad for g, p in zip(grads, params))
     assert struct.unpack("%dq" % len(params), key) == tuple(p.grad.data_ptr() for p in params)
+    assert H.scan_key(params) == (key, True, -1)      # the same key and verdict without the list of objects; -1: no device gradients
+    assert H.scan_key([]) == (b"", False, -1)
     new = [torch.randn_like(p) for p in params]
     objs = [p.grad for p in params]
     H.set_data(grads, new)
@@ -698,10 +700,11 @@ def test_host_helper_walks_match_the_python_walks():
     with pytest.raises(TypeError):
         H.set_data(grads, new[:-1] + [3])
     params[3].grad = torch.zeros(2, 7).t()            # same shape, not contiguous
-    assert not H.scan_grads(params)[2]
+    assert not H.scan_grads(params)[2] and not H.scan_key(params)[1]
     params[3].grad = None
     g3 = H.scan_grads(params)
     assert not g3[2] and g3[0][3] is None and struct.unpack("4q", g3[1])[3] == 0
+    assert H.scan_key(params)[:2] == (g3[1], False)
     params[3].grad = torch.zeros(7, 2)
     assert H.scan_grads(params)[2]
     params[1].grad_dtype = None
