@@ -467,6 +467,45 @@ def test_two_phase_rounds_identically_on_ranks_with_different_torch_seeds(tmp_pa
     assert any(np.abs(r0[k]).max() > 0 for k in r0.files if "_p" in k)
 
 
+def test_overlap_chunks_cut_the_tensor_list_at_tensor_boundaries(monkeypatch):
+    """PSQuantizer._overlap_chunks (round 6's experiment, GQ_OVERLAP; off by default): the tensors of a group in runs whose element
+    counts are nearest to the configured shares, every tensor in exactly one run, order kept, at least two tensors per run; one
+    group when the switch is off, when there are several users, a second phase, or too few elements."""
+    import json
+    from argparse import Namespace
+    from gq_amd.compressors import NearestNeighborCompressor
+    from gq_amd.quantizers import PSQuantizer
+    shapes = json.load(open(os.path.join(GOLDEN, "resnet50_cifar_shapes.json")))["parameter_shapes"]
+    monkeypatch.setenv("GQ_CODEBOOK_DIR", os.path.join(GOLDEN, "codebooks"))
+    monkeypatch.delenv("GQ_OVERLAP", raising=False)
+
+    def groups(**kw):
+        base = dict(c_dim=16, k_bit=8, n_bit=6, no_cuda=True, random=0, ef=False, two_phase=False, scale="exp", num_users=1, mode="ps", cr=256)
+        base.update(kw)
+        params = [torch.nn.Parameter(torch.zeros(*s)) for s in shapes]
+        q = PSQuantizer(NearestNeighborCompressor, params, Namespace(**base))
+        return q, [g[1] for g in q._groups]
+    q, one = groups()
+    assert len(one) == 1 and len(one[0]) == 76
+    for spec, n in (("0.58,0.42", 2), ("0.45,0.35,0.2", 3), ("1,1,1,1", 4)):
+        q, parts = groups(gq_overlap=spec)
+        assert len(parts) == n and [i for p in parts for i in p] == one[0] and all(len(p) >= 2 for p in parts)
+        sizes = [sum(q.codecs[i].numel for i in p) for p in parts]
+        want = [float(x) for x in spec.split(",")]
+        for sz, w in zip(sizes, want):
+            assert abs(sz / sum(sizes) - w / sum(want)) < 0.06, (spec, sizes)
+    assert len(groups(gq_overlap="0")[1]) == 1
+    assert len(groups(gq_overlap="0.5,0.5", num_users=2)[1]) == 1          # whole-step graphs need one user per step
+    assert len(groups(gq_overlap="0.5,0.5", two_phase=True)[1]) == 1
+    assert len(groups(gq_overlap="0.5,0.5", gq_graph=False)[1]) == 1
+    monkeypatch.setenv("GQ_OVERLAP", "0.6,0.4")
+    assert len(groups()[1]) == 2
+    small = [(16, 64)] * 6
+    qs = PSQuantizer(NearestNeighborCompressor, [torch.nn.Parameter(torch.zeros(*s)) for s in small],
+                     Namespace(c_dim=16, k_bit=8, n_bit=6, no_cuda=True, random=0, ef=False, two_phase=False, scale="exp", num_users=1, mode="ps", cr=256))
+    assert len(qs._groups) == 1       # a few thousand elements: one group
+
+
 def test_shared_seeds_scope_and_reserved_rng_pair():
     """compressors.shared_seeds replaces _next_seed() inside the block only; a multi-tensor group hands the LAST { seed, step }
     pair (the two-phase re-compress's, rank-free) to nobody but a caller that names it (round-5 advisor: user slot 16 drew from it)."""
