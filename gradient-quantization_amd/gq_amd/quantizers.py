@@ -343,7 +343,8 @@ class PSQuantizer(object):
             self._fast_misses += 1
             if self._fast_misses & 31:
                 return False
-        if self.recorded != 0 or torch.cuda.is_current_stream_capturing() or _dist_world(self.process_group)[0] != 1:
+        if (self.recorded != 0 or not self.use_graphs or not self._fuse_steps or torch.cuda.is_current_stream_capturing()
+                or _dist_world(self.process_group)[0] != 1):      # (use_graphs / _fuse_steps: a failed capture, or a caller, may switch them off)
             return False
         key, ok, index = _HOST.scan_key(self.parameters)
         wire = self._wire

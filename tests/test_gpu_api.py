@@ -1711,6 +1711,42 @@ def test_record_replayed_from_a_hip_graph_equals_the_eager_launches(kw):
             assert torch.equal(pg.error[0], pe.error[0])
 
 
+def test_switching_graphs_off_after_captures_runs_eager_launches_again():
+    """`q.use_graphs = False` on a quantizer that has been replaying whole-step graphs (bench.py does it to arm the encode's profile
+    events; a failed capture does it too): the next records run their launches eagerly -- the short way through record()
+    (PSQuantizer._replay_known_step) looks at the switch every time -- and give the replayed steps' bits."""
+    from gq_amd.compressors import NearestNeighborCompressor
+    from gq_amd.quantizers import Quantizer
+    shapes = RESNET50_COMPRESSED[:8] + RESNET50_SMALL[:3]
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    store = [torch.randn(s, device=dev) * 1e-2 for s in shapes]
+    fills = [[torch.randn(s, device=dev) * 1e-2 for s in shapes] for _ in range(16)]
+
+    def run(switch_at):
+        params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
+        q = Quantizer(NearestNeighborCompressor, params, make_args(num_users=1, random=0))
+        outs = []
+        for step in range(16):
+            if step == switch_at:
+                q.use_graphs = False
+            for t, f in zip(store, fills[step]):
+                t.copy_(f)
+            for p, t in zip(params, store):
+                p.grad = t.view(t.shape)
+            q.record(0, epoch=1)
+            q.apply()
+            outs.append([p.grad.data.clone() for p in params])
+        return q, outs
+    qa, oa = run(None)
+    qb, ob = run(10)
+    assert qa.record_paths["whole_step"] >= 8 and qa.record_paths["eager"] <= 3
+    assert qb.record_paths["eager"] >= 6 + 2, qb.record_paths      # the six steps after the switch ran eagerly
+    for a, b in zip(oa, ob):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+
+
 @pytest.mark.parametrize("kw", [dict(random=1), dict(random=0, ef=True, scale="0.5"), dict(qsgd=True, c_dim=128, n_bit=2, random=1),
                                 dict(random=1, num_users=3), dict(random=0, two_phase=True)])
 def test_gradients_at_new_addresses_every_step_replay_the_address_free_graph(kw):
