@@ -1105,8 +1105,11 @@ class RingQuantizer(PSQuantizer):
             if rank != world - 1:
                 self.running = self._decode_all(final, False, plain=True)
         if self.running is not None:     # ring_quantizer.py:45-46
-            for param, g in zip(self.parameters, self.running):
-                param.grad.data = g
+            if _HOST is not None and type(self.running) is list and len(self.running) == len(self.parameters):
+                _HOST.set_grad_data(self.parameters, self.running)      # (the C++ walk: 30 -> ~18 us for 161 parameters)
+            else:
+                for param, g in zip(self.parameters, self.running):
+                    param.grad.data = g
         self.running = None
         self.recorded = 0
 
