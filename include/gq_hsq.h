@@ -89,7 +89,7 @@ size_t gq_hsq_workspace_bytes(int64_t M);
 #define GQ_AGGREGATE_FMA 0x100
 
 /* Library / device identification. */
-int gq_abi_version(void);            /* 4: round 5 (gq_hsq_decode_sum_batched_tail, gq_qsgd_decode_sum_batched_tail, gq_hsq_levels_decode_batched, gq_step_tail; impl 6 of gq_hsq_encode_ex; gq_qsgd_batch.reserved became bucket_hint: zero, what older callers pass, still means "unknown"); 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words and takes reset words; gq_hsq_batch / gq_qsgd_batch carry the dense table); 2: the round-3 descriptor form of the multi-tensor entry points */
+int gq_abi_version(void);            /* 4 (round 6 changed no prototype or struct: impl 6 of gq_hsq_encode_ex went -- GQ_ERR_INVALID_ARG -- and d = 12 / 24 joined the prefilter path): round 5 (gq_hsq_decode_sum_batched_tail, gq_qsgd_decode_sum_batched_tail, gq_hsq_levels_decode_batched, gq_step_tail; impl 6 of gq_hsq_encode_ex; gq_qsgd_batch.reserved became bucket_hint: zero, what older callers pass, still means "unknown"); 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words and takes reset words; gq_hsq_batch / gq_qsgd_batch carry the dense table); 2: the round-3 descriptor form of the multi-tensor entry points */
 const char *gq_last_error(void);     /* text of the calling thread's last failure (the library's only per-thread state) */
 /* Fills CU count and the gcnArchName (e.g. "gfx950:sramecc+:xnack-") of `device`. */
 int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
