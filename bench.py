@@ -344,7 +344,7 @@ def traffic_for(args, world, workload, kernel_match, file_key):
 
 
 CLOCK_LIB = os.path.join(ROOT, "gradient-quantization_amd", "libgq_hsq_clock.so")
-ISA_FILE = os.path.join("profiles", "r05_encode_isa_floor.json")
+ISA_FILE = os.path.join("profiles", "r06_encode_isa_floor.json")
 
 
 def clock_child():

@@ -237,11 +237,14 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // Contiguous runs also keep a wave's running (min,max) with one tensor for many tiles in the batched form.
     const int b = (int)blockIdx.x;
     const bool skewed = b < a.skew_blocks;
-    const int64_t lo_tile = (int64_t)b * a.tiles_q + (b < a.tiles_r ? b : a.tiles_r) + ((skewed && (b & 1)) ? a.tiles_skew : 0);
-    const int64_t tile_end = lo_tile + a.tiles_q + (b < a.tiles_r ? 1 : 0) + (skewed ? ((b & 1) ? -a.tiles_skew : a.tiles_skew) : 0);
+    // (tile indices are 32-bit: the launchers refuse more than 2^31 subvectors = 2^25 tiles.  As 64-bit integers every comparison
+    // of the loop top was a VECTOR compare -- the scalar unit has no ordered 64-bit compare -- whose result the scalar branch
+    // then waited for: profiles/r06_encode_ab.txt, block L)
+    const int lo_tile = b * a.tiles_q + (b < a.tiles_r ? b : a.tiles_r) + ((skewed && (b & 1)) ? a.tiles_skew : 0);
+    const int tile_end = lo_tile + a.tiles_q + (b < a.tiles_r ? 1 : 0) + (skewed ? ((b & 1) ? -a.tiles_skew : a.tiles_skew) : 0);
     // The second wave of a SIMD (waves 4-7: the slower of the pair) leaves the last PF_TAIL tiles of the run to
     // the first one: a tile it started that late would finish ~1.5 us after everybody else.
-    const int tail_from = (int)(tile_end - lo_tile) - (wave >= PF_WAVES / 2 ? PF_TAIL : 0);
+    const int tail_from = (tile_end - lo_tile) - (wave >= PF_WAVES / 2 ? PF_TAIL : 0);
     auto draw = [&]() {   // the next tile of this workgroup's run (may lie beyond tile_end)
         int k = 0x3FFFFFFF;
         if (lane == 0) {
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         }
         return lo_tile + __builtin_amdgcn_readfirstlane(k);
     };
-    int64_t t = lo_tile + wave;
+    int t = lo_tile + wave;
     int *const worklist = ws_worklist(ws);
 
     float lmin = INFINITY, lmax = -INFINITY;
@@ -277,8 +280,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     struct Tile {
         gcf_ptr base;
         int64_t m, sv0;
-        int64_t tile0;   // batched: the tensor's first tile
-        int64_t tiles_end;   // batched: the tile behind the tensor's last one
+        int tile0;       // batched: the tensor's first tile
+        int tiles_end;   // batched: the tile behind the tensor's last one
         int rem;       // index of the tile's last valid subvector (0..63): m - 1 - sv0, capped at 63
         int seg;
         gcode_ptr codes;
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     };
     // FROM_GLOBAL: the record comes from global memory even in the SEGLDS form (the first tile is set up
     // before the LDS copy of the table exists)
-    auto tile_info = [&](int64_t tile, int seg, auto from_global) {   // seg: the tile's tensor (batched; fetched ahead by the caller)
+    auto tile_info = [&](int tile, int seg, auto from_global) {   // seg: the tile's tensor (batched; fetched ahead by the caller)
         constexpr bool FROM_GLOBAL = decltype(from_global)::value;
         Tile ti;
         if (BATCHED) {
@@ -318,24 +321,24 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             }
             ti.base = (gcf_ptr)(uintptr_t)uniform64(r0);
             ti.m = uniform64(r1);
-            ti.tile0 = uniform64(r2);
-            ti.tiles_end = ti.tile0 + ((ti.m + 63) >> 6);
-            ti.sv0 = (tile - ti.tile0) * 64;
+            ti.tile0 = (int)uniform64(r2);
+            ti.tiles_end = ti.tile0 + (int)((ti.m + 63) >> 6);
+            ti.sv0 = (int64_t)(tile - ti.tile0) * 64;
             ti.codes = (gcode_ptr)((uintptr_t)a.wire + (uintptr_t)uniform64(r3));
             ti.err = EF ? (gcf_ptr)(uintptr_t)uniform64(r7) : (gcf_ptr)0;
-            const int64_t rem = ti.m - 1 - ti.sv0;
-            ti.rem = rem > 63 ? 63 : (int)rem;
+            const int rem = (int)ti.m - 1 - (int)ti.sv0;      // (both below 2^31: 32-bit, a scalar compare)
+            ti.rem = rem > 63 ? 63 : rem;
         } else {
             ti.seg = 0;
             ti.tile0 = 0;
             ti.tiles_end = 0;
             ti.base = (gcf_ptr)a.grad;
             ti.m = M;
-            ti.sv0 = tile * 64;
+            ti.sv0 = (int64_t)tile * 64;
             ti.codes = (gcode_ptr)static_cast<CodeT *>(a.codes);
             ti.err = (gcf_ptr)0;
-            const int64_t rem = M - 1 - ti.sv0;
-            ti.rem = rem > 63 ? 63 : (int)rem;
+            const int rem = (int)M - 1 - (int)ti.sv0;      // (M < 2^31: the launcher refuses more)
+            ti.rem = rem > 63 ? 63 : rem;
         }
         return ti;
     };
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     const float err_abs = cb_ok ? c2 * ERR_ABS : INFINITY;
     const float err2_rel = cb_ok ? c2 * SH::ERR2_REL + SH::ERR2_SUB : INFINITY;   // the second pass (three MFMAs per chain and k-step)
 
-    int64_t tn = draw();                // the tile after this wave's first one
+    int tn = draw();                    // the tile after this wave's first one
     // sigma: the power of two the tile in flight was multiplied by before its conversion to f16 (wave-uniform, an SGPR).
     // First tile: the largest |element| of the tile goes to [2^4, 2^5); afterwards every tile's scale follows the norms
     // the previous tile showed (four sampled lanes, below).  A subvector that ends up outside the window of the error
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     };
     int qhead = 0, qcnt = 0;   // this wave's ring: first entry, entries (wave-uniform)
     bool flushed = false;      // the early flush has run (wave-uniform)
-    const int64_t run_len = tile_end - lo_tile;
+    const int run_len = tile_end - lo_tile;
     // Exact scan of ONE ring entry by the whole wave: lane l scores codewords 4l .. 4l+3 (its own quad of the LDS image: 64
     // different quads, conflict-free; the entry's floats are a broadcast read), first maximum inside the lane in index order,
     // then across the wave by DPP moves (wave_first_max_nan_dpp: lower lanes hold lower indices).  ~450 cycles; for the one
@@ -786,14 +789,35 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         // tile -> tensor word of the tile after next in flight for a whole tile: a wave was committed to TWO tiles beyond its
         // own, and the ends of the workgroups' runs were that much more ragged -- the same elements as one flat tensor ran
         // 35.4 us, as two tensors 40.4.  A tensor's tiles are one contiguous range: the word is only looked up when tn leaves it.)
+        // Chain order.  D <= 16 (A fragments in registers): block 0's eight row blocks, then block 1's.  D = 32 (A fragments
+        // from LDS): (rb, block 0), (rb, block 1), so that both blocks share a row block's fragments, fetched a row block ahead.
+        auto chain_rb = [](int c) { return SH::A_REGS ? (c & 7) : (c >> 1); };
+        auto chain_blk = [](int c) { return SH::A_REGS ? (c >> 3) : (c & 1); };
+        half8 af[2][KS];   // D = 32: the row block in use / the next one
+        if constexpr (!SH::A_REGS) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) af[0][s] = frag_hi(0, s);
+        }
+        auto chain = [&](int c, f32x16 x) {
+            const int rb = chain_rb(c), blk = chain_blk(c);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                x = __builtin_amdgcn_mfma_f32_32x32x16_f16(SH::A_REGS ? ch[SH::A_REGS ? rb : 0] : af[rb & 1][s], vh[blk * KS + s], x, 0, 0, 0);
+            return x;
+        };
+        // The FIRST chain's MFMA goes out before the tile's bookkeeping (round 6): its 16 passes run under the scalar work and the
+        // issue of the next tile's loads instead of under a row of s_nop in front of the first key operation.
+        f32x16 acc = {0};
+        acc = chain(0, acc);
+        __builtin_amdgcn_sched_barrier(0);
         Tile tin = ti;
         if (tn < tile_end) {
             // a wave's consecutive tiles mostly stay with one tensor (contiguous runs): its record is already in scalar
             // registers -- the LDS reads and the eight v_readfirstlane of a look-up only when the tensor changes
             if (BATCHED && tn >= ti.tile0 && tn < ti.tiles_end) {
-                tin.sv0 = (tn - ti.tile0) * 64;
-                const int64_t rem = ti.m - 1 - tin.sv0;
-                tin.rem = rem > 63 ? 63 : (int)rem;
+                tin.sv0 = (int64_t)(tn - ti.tile0) * 64;
+                const int rem = (int)ti.m - 1 - (int)tin.sv0;
+                tin.rem = rem > 63 ? 63 : rem;
             } else {
                 tin = tile_info(tn, BATCHED ? __builtin_amdgcn_readfirstlane(a.tile_seg[tn]) : 0, std::false_type{});
             }
@@ -830,24 +854,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             best[trk] = max3u(trk_t, k2, k3);
             second[trk] = max3u(second[trk], trk_a, b);
         };
-        // Chain order.  D <= 16 (A fragments in registers): block 0's eight row blocks, then block 1's.  D = 32 (A fragments
-        // from LDS): (rb, block 0), (rb, block 1), so that both blocks share a row block's fragments, fetched a row block ahead.
-        auto chain_rb = [](int c) { return SH::A_REGS ? (c & 7) : (c >> 1); };
-        auto chain_blk = [](int c) { return SH::A_REGS ? (c >> 3) : (c & 1); };
-        half8 af[2][KS];   // D = 32: the row block in use / the next one
-        if constexpr (!SH::A_REGS) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) af[0][s] = frag_hi(0, s);
-        }
-        auto chain = [&](int c, f32x16 x) {
-            const int rb = chain_rb(c), blk = chain_blk(c);
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-                x = __builtin_amdgcn_mfma_f32_32x32x16_f16(SH::A_REGS ? ch[SH::A_REGS ? rb : 0] : af[rb & 1][s], vh[blk * KS + s], x, 0, 0, 0);
-            return x;
-        };
-        f32x16 acc = {0};
-        acc = chain(0, acc);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int rb = chain_rb(c), trk = chain_blk(c) * 2 + (rb >> 2);
@@ -1014,7 +1020,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
                 for (int q = 0; q < D / 4; ++q) qv[q] = f32x4{vf[4 * q], vf[4 * q + 1], vf[4 * q + 2], vf[4 * q + 3]};
                 const uint64_t ca = (uint64_t)(uintptr_t)(ti.codes + ti.sv0) + (uint64_t)sizeof(CodeT) * (unsigned)lane;
                 *reinterpret_cast<u32x4 *>(s_qm + 4 * slot) =
-                    u32x4{(unsigned)ca, (unsigned)(ca >> 32), (unsigned)((BATCHED ? t * 64 : ti.sv0) + lane), (unsigned)ti.seg};
+                    u32x4{(unsigned)ca, (unsigned)(ca >> 32), (unsigned)((BATCHED ? (int64_t)t * 64 : ti.sv0) + lane), (unsigned)ti.seg};
             }
             const uint64_t took = __ballot(mine);
             qcnt += (int)__builtin_popcountll(took);
@@ -1033,7 +1039,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
 
         if (valid && safe) {   // uniform bases (the tile's first code / projection) + the lane index
             (ti.codes + ti.sv0)[(unsigned)lane] = (CodeT)idx;
-            ((gf_ptr)u + (BATCHED ? t * 64 : ti.sv0))[(unsigned)lane] = val;
+            ((gf_ptr)u + (BATCHED ? (int64_t)t * 64 : ti.sv0))[(unsigned)lane] = val;
             lmin = fminf(lmin, val);
             lmax = fmaxf(lmax, val);
         }
