@@ -29,8 +29,9 @@ EXPORTS = [     # every entry point include/gq_hsq.h declares (tests/test_host_l
     "gq_hsq_levels_decode_batched",
     "gq_axpy_inplace", "gq_sub", "gq_mean_rows", "gq_qsgd_compress", "gq_qsgd_decode_sum", "gq_qsgd_code_bits",
     "gq_qsgd_compress_batched", "gq_qsgd_decode_sum_batched", "gq_qsgd_decode_sum_batched_tail", "gq_pvq_encode",
+    "gq_launch_plan_create", "gq_launch_plan_run", "gq_launch_plan_destroy",
 ]
-ABI_VERSION = 4
+ABI_VERSION = 5
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3      # GQ_ERR_* of include/gq_hsq.h
 
 _lib = None
@@ -52,6 +53,7 @@ def lib():
         L.gq_last_error.restype = ctypes.c_char_p
         L.gq_abi_version.restype = ctypes.c_int
         L.gq_hsq_workspace_bytes.restype = ctypes.c_size_t
+        L.gq_launch_plan_destroy.restype = None
         for name in EXPORTS:
             getattr(L, name)  # AttributeError if the library is stale
         if L.gq_abi_version() != ABI_VERSION:
@@ -522,6 +524,35 @@ def pvq_encode(grad, c_dagger, codes, u, workspace, random_mode, r, seed, stage1
 
 def pvq_encode_residual(grad, codes1, norm1, codebook1, c_dagger, codes, u, workspace, random_mode, r, seed):
     pvq_encode(grad, c_dagger, codes, u, workspace, random_mode, r, seed, stage1=(codes1, norm1, codebook1))
+
+
+class LaunchPlan(object):
+    """gq_launch_plan_*: the kernel nodes of a captured graph (torch.cuda.CUDAGraph(keep_graph=True)) as plain launches on torch's
+    current stream.  `replay()` like the graph's own; raises GQNativeError at construction when the graph is not one chain of
+    kernel launches (the caller keeps the graph's replay)."""
+
+    def __init__(self, graph):
+        self.graph = graph          # the owner of the launches' argument storage
+        self.L = lib()
+        self.plan, n = ctypes.c_void_p(0), ctypes.c_int(0)
+        rc = self.L.gq_launch_plan_create(ctypes.c_void_p(int(graph.raw_cuda_graph())), ctypes.byref(self.plan), ctypes.byref(n))
+        if rc != 0:
+            raise GQNativeError("gq_launch_plan_create failed (%d): %s" % (rc, self.L.gq_last_error().decode()))
+        self.nodes = n.value
+        self._run = self.L.gq_launch_plan_run
+
+    def replay(self):
+        rc = self._run(self.plan, _stream())
+        if rc != 0:
+            raise GQNativeError("gq_launch_plan_run failed (%d): %s" % (rc, self.L.gq_last_error().decode()))
+
+    def __del__(self):
+        try:
+            if self.plan:
+                self.L.gq_launch_plan_destroy(self.plan)
+                self.plan = ctypes.c_void_p(0)
+        except Exception:
+            pass
 
 
 def qsgd_code_bits(n_bit, random_mode):

@@ -637,6 +637,34 @@ class PSQuantizer(object):
         return skip
 
     @staticmethod
+    def _new_graph():
+        """The graph object of a capture.  $GQ_DIRECT_REPLAY (default 1): kept as a graph (keep_graph) so that _replayable can read its
+        kernel nodes back."""
+        if os.environ.get("GQ_DIRECT_REPLAY", "1") != "0":
+            try:
+                return torch.cuda.CUDAGraph(keep_graph=True)
+            except TypeError:      # (a torch without keep_graph: the graph's own replay)
+                pass
+        return torch.cuda.CUDAGraph()
+
+    @staticmethod
+    def _replayable(graph):
+        """What an entry's replay() runs: the captured kernel nodes as PLAIN launches on the current stream (native.LaunchPlan --
+        a replayed graph pays 4-5 us of boundary between two replays that launches on a stream do not: 62.4 against 57.6 us per
+        two-kernel ResNet-50 step, tools/direct_vs_graph.py), or the graph itself where it is not one chain of kernel launches
+        (two branches, a torch without raw graph access) or $GQ_DIRECT_REPLAY=0."""
+        if os.environ.get("GQ_DIRECT_REPLAY", "1") != "0" and hasattr(graph, "raw_cuda_graph"):
+            try:
+                return native.LaunchPlan(graph)
+            except Exception:
+                pass
+        try:
+            graph.instantiate()      # (keep_graph: not instantiated by capture_end)
+        except Exception:
+            pass
+        return graph
+
+    @staticmethod
     def _graph_entry(cache, key, max_captured=48, max_counting=64):
         """[sightings, graph or None, keep-alive] of `key`, its sighting counted.  A few address sets recur (the allocator
         hands the same blocks out again); captured graphs are never evicted -- once max_captured of them exist, new sets keep
@@ -662,9 +690,10 @@ class PSQuantizer(object):
             # (device-resident: the graph's copy node is device-to-device.  A host-to-device node -- pinned memory over PCIe --
             # cost 15 us of every replayed step, tools/graph_pieces.py; the 5 KB header per captured graph is nothing)
             headers = None if generic else [g[2]._host[g[2]._last_slot].to(dev) for g in self._groups]
-            graph = torch.cuda.CUDAGraph()
+            graph = self._new_graph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (other threads -- RCCL's watchdog -- may call into HIP meanwhile)
                 self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers, table_current=generic)
+            graph = self._replayable(graph)
         except Exception as e:      # a capture that fails leaves the eager path as it was (this record has already run eagerly)
             self.use_graphs = False
             import warnings
@@ -678,7 +707,7 @@ class PSQuantizer(object):
         executes here; the output-buffer turns the capture advances are put back for the apply() that is still to come."""
         after = ([g[2]._out_turn for g in self._groups], self._dense_turn)
         try:
-            graph = torch.cuda.CUDAGraph()
+            graph = self._new_graph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 resets = []      # the groups' accumulator resets ride in the step's last launch
                 fuse = self._can_fuse_levels()      # one rank, one user: level launch + decode of that payload as ONE launch
@@ -692,7 +721,7 @@ class PSQuantizer(object):
                 self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers, defer_resets=resets,
                                       fuse_levels=fuse, overlap=overlap, table_current=headers is None)
                 decoded = self._decode_all(self._wire[:1], False, (), resets=resets, fused_levels=fuse, overlap=overlap)
-            fent[1], fent[2] = graph, decoded
+            fent[1], fent[2] = self._replayable(graph), decoded
         except Exception as e:      # the two-graph replay keeps working
             self._fuse_steps = False
             for g in self._groups:      # a launch that failed between a group's encode and its level launch: back to the shared header
@@ -1004,12 +1033,12 @@ class PSQuantizer(object):
                         # has just sent (the decode-mean's output buffers, the server residuals), which belongs to this graph
                         hdrs2 = [g[2]._host[g[2]._last_slot].to(gathered.device) for g in self._groups] if self.two_phase else None
                         calls = self._phase2_calls
-                        graph = torch.cuda.CUDAGraph()
+                        graph = self._new_graph()
                         with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (other threads -- RCCL's watchdog -- may call into HIP meanwhile)
                             again = self._decode_all(gathered, self.two_phase, (), phase2_headers=hdrs2)
                         assert self._phase2_calls == calls, "a captured second phase must not take per-call seeds"
                         if len(again) == len(decoded) and all(a is b for a, b in zip(again, decoded)):
-                            ent[1], ent[2] = graph, decoded
+                            ent[1], ent[2] = self._replayable(graph), decoded
                             ent.append(hdrs2)      # (kept alive with the graph)
                     except Exception as e:      # this apply has already run eagerly
                         self.use_graphs = False

@@ -89,7 +89,7 @@ size_t gq_hsq_workspace_bytes(int64_t M);
 #define GQ_AGGREGATE_FMA 0x100
 
 /* Library / device identification. */
-int gq_abi_version(void);            /* 4 (round 6 changed no prototype or struct: impl 6 of gq_hsq_encode_ex went -- GQ_ERR_INVALID_ARG -- and d = 12 / 24 joined the prefilter path): round 5 (gq_hsq_decode_sum_batched_tail, gq_qsgd_decode_sum_batched_tail, gq_hsq_levels_decode_batched, gq_step_tail; impl 6 of gq_hsq_encode_ex; gq_qsgd_batch.reserved became bucket_hint: zero, what older callers pass, still means "unknown"); 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words and takes reset words; gq_hsq_batch / gq_qsgd_batch carry the dense table); 2: the round-3 descriptor form of the multi-tensor entry points */
+int gq_abi_version(void);            /* 5: round 6 (gq_launch_plan_create / _run / _destroy; no other prototype or struct changed: impl 6 of gq_hsq_encode_ex went -- GQ_ERR_INVALID_ARG -- and d = 12 / 24 joined the prefilter path); 4: round 5 (gq_hsq_decode_sum_batched_tail, gq_qsgd_decode_sum_batched_tail, gq_hsq_levels_decode_batched, gq_step_tail; impl 6 of gq_hsq_encode_ex; gq_qsgd_batch.reserved became bucket_hint: zero, what older callers pass, still means "unknown"); 3: round 4 (gq_mean_rows steps the GQ_RANDOM_DEVICE_COUNTER words and takes reset words; gq_hsq_batch / gq_qsgd_batch carry the dense table); 2: the round-3 descriptor form of the multi-tensor entry points */
 const char *gq_last_error(void);     /* text of the calling thread's last failure (the library's only per-thread state) */
 /* Fills CU count and the gcnArchName (e.g. "gfx950:sramecc+:xnack-") of `device`. */
 int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
@@ -103,6 +103,19 @@ int gq_device_info(int device, int *cu_count, char *arch, size_t arch_len);
  */
 #define GQ_PROFILE_SLOTS 64
 int gq_profile_read(int slot, float *kernel_ms);
+
+/*
+ * Launch plans: the kernel launches of a captured HIP graph, issued as plain launches on a stream.  Not a piece of the reference's
+ * arithmetic but of its LOOP (ps_quantizer.py:27-65 runs a step's operations one after the other on one stream): the quantizer
+ * captures a step's launches once with stream capture -- whatever the configuration makes them -- and gq_launch_plan_run issues the
+ * captured kernel nodes again, in order, with the arguments the graph holds.  Replaying the graph itself costs a boundary between
+ * two replays that two launches on a stream do not have: 62.4 us per replay against 57.6 us for the two launches of the ResNet-50
+ * step (tools/direct_vs_graph.py).  `hip_graph` is a hipGraph_t that must outlive the plan (it owns the argument storage);
+ * GQ_ERR_UNSUPPORTED when the graph is not ONE chain of at most 64 kernel nodes (the caller then replays the graph as it is).
+ */
+int gq_launch_plan_create(void *hip_graph, void **plan, int *nodes);
+int gq_launch_plan_run(void *plan, void *stream);
+void gq_launch_plan_destroy(void *plan);
 
 /*
  * HSQ encode -- replaces nearest_neighbor_compressor.py:65-73 (view(-1,d); mm;

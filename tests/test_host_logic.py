@@ -56,9 +56,11 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libgq_hsq.so does not export %s declared in include/gq_hsq.h" % n
     assert set(native.EXPORTS) == set(names), "the binding's list and the header differ"
-    assert len(names) <= 28, "the ABI was collapsed to <= 25 entry points in round 3 (descriptor structs instead of variants); round 5 added gq_hsq_decode_sum_batched_tail, gq_qsgd_decode_sum_batched_tail and gq_hsq_levels_decode_batched"
+    assert len(names) <= 31, ("the ABI was collapsed to <= 25 entry points in round 3 (descriptor structs instead of variants); round 5 added "
+                              "gq_hsq_decode_sum_batched_tail, gq_qsgd_decode_sum_batched_tail and gq_hsq_levels_decode_batched, round 6 the three "
+                              "gq_launch_plan_* helpers")
     lib.gq_abi_version.restype = ctypes.c_int
-    assert lib.gq_abi_version() == native.ABI_VERSION == 4
+    assert lib.gq_abi_version() == native.ABI_VERSION == 5
     # nothing but the declared entry points leaves the library (the per-variant launchers are hidden)
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True).stdout
