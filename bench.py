@@ -106,6 +106,7 @@ def parse_args():
     ap.add_argument("--ef", action="store_true", help="--workload resnet50: error feedback (ps_quantizer.py:34-39)")
     ap.add_argument("--two-phase", action="store_true", help="--workload resnet50: the second phase (ps_quantizer.py:52-61)")
     ap.add_argument("--c-dim", type=int, default=0, help="--workload resnet50: sub-dimension (default 16; main.py's own default is 32)")
+    ap.add_argument("--k-bit", type=int, default=0, help="--workload resnet50: codebook bits (default 8; 5 / 6: K = 32 / 64, the codebook files from tests/golden/codebooks)")
     ap.add_argument("--n-bit", type=int, default=0, help="--workload resnet50: level bits (default 6; main.py's own default is 8)")
     ap.add_argument("--no-variants", action="store_true", help="skip the untimed random=2 / 1e-3-scale side measurements")
     return ap.parse_args()
@@ -1061,7 +1062,9 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
     shapes = [tuple(p.shape) for p in ResNet50(num_classes=10).parameters()]
     n = sum(int(np.prod(s)) for s in shapes)
     if hsq:     # README: --quantizer hsq --network resnet50 --c-dim 16 --k-bit 8 --n-bit 6 (--random defaults to True)
-        qargs = Namespace(c_dim=args.c_dim or C_DIM, k_bit=K_BIT, n_bit=args.n_bit or N_BIT, no_cuda=False, random=1, ef=bool(args.ef),
+        if args.k_bit and args.k_bit != 8:      # (the package ships the K = 256 codebooks; the others it finds where the reference keeps them or here)
+            os.environ.setdefault("GQ_CODEBOOK_DIR", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "codebooks"))
+        qargs = Namespace(c_dim=args.c_dim or C_DIM, k_bit=args.k_bit or K_BIT, n_bit=args.n_bit or N_BIT, no_cuda=False, random=1, ef=bool(args.ef),
                           two_phase=bool(args.two_phase), scale=EF_BENCH_SCALE if args.ef else "exp", num_users=1, mode="ps", cr=256)
 
         Comp = NearestNeighborCompressor
@@ -1153,9 +1156,9 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
                   "tensors: prefilter, exact rescoring, in-place fix-up, per-tensor lb/ub by atomics)")
         match, metric = "hsq_encode_pf_kernel", "gradient elements quantized/sec (HSQ d=%d k=8, ResNet-50 list)" % dd
         cfg = ("ResNet-50/CIFAR parameter list (161 tensors, %d elements) per rank through PSQuantizer.record + apply, HSQ c_dim=%d "
-               "k_bit=8 n_bit=%d random=1 on-device draws%s%s (%s), byte wire, multi-tensor kernels"
-               % (n, dd, qargs.n_bit, ", error feedback" if args.ef else "", ", two-phase" if args.two_phase else "",
-                  "BASELINE configs[2]; the README's hsq command" if (dd == 16 and qargs.n_bit == 6) else "main.py:90-92's own defaults" if (dd == 32 and qargs.n_bit == 8) else "a variant"))
+               "k_bit=%d n_bit=%d random=1 on-device draws%s%s (%s), byte wire, multi-tensor kernels"
+               % (n, dd, qargs.k_bit, qargs.n_bit, ", error feedback" if args.ef else "", ", two-phase" if args.two_phase else "",
+                  "BASELINE configs[2]; the README's hsq command" if (dd == 16 and qargs.n_bit == 6 and qargs.k_bit == 8) else "main.py:90-92's own defaults" if (dd == 32 and qargs.n_bit == 8 and qargs.k_bit == 8) else "a variant"))
         note = ("kernel_ms: HIP start/stop events attached to the encode's dispatch on %d %s; compress_ms = encode + "
                 "levels launches back to back after the timed region; the step itself is host-bound (per-parameter torch work)"
                 % (len(armed), "eager steps run after the timed region (a replayed graph has no armed dispatch)" if args.graph

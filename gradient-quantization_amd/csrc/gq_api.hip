@@ -20,8 +20,8 @@ static int check_batch(const gq_hsq_batch *b, const char *what) {
     if (b->level_bytes != 0 && b->level_bytes != 1 && b->level_bytes != 2 && b->level_bytes != 4 &&
         b->level_bytes != GQ_LEVELS_PACKED6)
         return fail(GQ_ERR_INVALID_ARG, "%s: level_bytes must be 0 (f32 projections), 1, 2, 4 or GQ_LEVELS_PACKED6", what);
-    if (b->level_bytes == GQ_LEVELS_PACKED6 && !(b->d == 16 && b->K == 256 && b->code_bytes == 1 && b->n_bit <= 6))
-        return fail(GQ_ERR_UNSUPPORTED, "%s: the multi-tensor kernels take GQ_LEVELS_PACKED6 for d = 16, K = 256, byte codes, n_bit <= 6", what);
+    if (b->level_bytes == GQ_LEVELS_PACKED6 && !(b->d == 16 && b->K <= 256 && b->code_bytes == 1 && b->n_bit <= 6))
+        return fail(GQ_ERR_UNSUPPORTED, "%s: the multi-tensor kernels take GQ_LEVELS_PACKED6 for d = 16, K <= 256, byte codes, n_bit <= 6", what);
     if (!b->seg_table || !b->tile_seg || !b->codebook) return fail(GQ_ERR_INVALID_ARG, "%s: null pointer in the descriptor", what);
     if (b->profile_slot >= GQ_PROFILE_SLOTS) return fail(GQ_ERR_INVALID_ARG, "%s: profile_slot %d", what, b->profile_slot);
     if (b->ndense < 0 || (b->ndense > 0 && !b->dense_table)) return fail(GQ_ERR_INVALID_ARG, "%s: ndense = %d without a dense_table", what, b->ndense);
@@ -29,11 +29,11 @@ static int check_batch(const gq_hsq_batch *b, const char *what) {
 }
 
 static bool pf_dim(int d) { return d == 8 || d == 16 || d == 32; }      // shapes of the specialised level / decode kernels and of the paged encode
-static bool pf_encode_dim(int d) { return pf_dim(d) || d == 12 || d == 24; }   // ... of the K = 256 prefilter encode (12 / 24: the reference's repaired dimensions, padded to 16 / 32)
+static bool pf_encode_dim(int d) { return pf_dim(d) || d == 12 || d == 24; }   // ... of the prefilter encode (K <= 256, a multiple of 4) (12 / 24: the reference's repaired dimensions, padded to 16 / 32)
 
 // Which encode serves the descriptor (see gq_hsq_batched_path in the header); 0 + an error text if none.
 static int batch_path(const gq_hsq_batch *b) {
-    if (pf_encode_dim(b->d) && b->K == 256 && b->code_bytes == 1) {
+    if (pf_encode_dim(b->d) && b->K >= 4 && b->K <= 256 && (b->K & 3) == 0 && b->code_bytes == 1) {
         return GQ_BATCH_PREFILTER;   // (any number of tensors: beyond 384 the segment records are read from global memory)
     } else if (pf_dim(b->d) && b->K > 256 && (b->K & 255) == 0 && b->code_bytes == 4 && b->nseg <= 384) {
         return GQ_BATCH_PAGED;
@@ -46,8 +46,8 @@ static int batch_path(const gq_hsq_batch *b) {
 
 // byte codes AND byte levels on a prefilter shape: the specialised level / decode kernels (fused error feedback)
 static bool byte_wire(const gq_hsq_batch *b) {
-    if (b->level_bytes == GQ_LEVELS_PACKED6) return b->d == 16 && b->K == 256 && b->code_bytes == 1 && b->n_bit >= 1 && b->n_bit <= 6;
-    return pf_dim(b->d) && b->K == 256 && b->code_bytes == 1 && b->level_bytes == 1 && b->n_bit >= 1 && b->n_bit <= 8;
+    if (b->level_bytes == GQ_LEVELS_PACKED6) return b->d == 16 && b->K <= 256 && b->code_bytes == 1 && b->n_bit >= 1 && b->n_bit <= 6;
+    return pf_dim(b->d) && b->K <= 256 && b->code_bytes == 1 && b->level_bytes == 1 && b->n_bit >= 1 && b->n_bit <= 8;
 }
 
 }  // namespace gq
@@ -66,7 +66,7 @@ GQ_API int gq_hsq_encode_batched(const gq_hsq_batch *b, uint8_t *wire, float ef_
     switch (gq::batch_path(b)) {
         case GQ_BATCH_PREFILTER:
             if (!b->workspace) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched: the prefilter path needs a workspace");
-            return gqi_hsq_encode_batched_pf(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->codebook, b->d, ef, scale, wire,
+            return gqi_hsq_encode_batched_pf(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->codebook, b->d, b->K, ef, scale, wire,
                                              b->u_flat, b->seg_minmax, b->workspace, b->profile_slot, stream);
         case GQ_BATCH_PAGED:
             if (!b->workspace) return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode_batched: the paged prefilter path needs a workspace");
@@ -94,17 +94,17 @@ GQ_API int gq_hsq_levels_batched(const gq_hsq_batch *b, uint8_t *wire, int rando
     if (gq::byte_wire(b)) {
         if (write_error && b->d != 16)
             return gqi_hsq_levels_batched_ef_d(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->u_flat, b->seg_minmax, b->n_bit,
-                                               random_mode, seed, r_flat, b->codebook, b->d, wire, b->dense_table, b->ndense, stream);
+                                               random_mode, seed, r_flat, b->codebook, b->d, b->K, wire, b->dense_table, b->ndense, stream);
         return gqi_hsq_levels_batched_d16(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->u_flat, b->seg_minmax, b->n_bit,
-                                          random_mode, seed, r_flat, (write_error && b->d == 16) ? b->codebook : nullptr,
+                                          random_mode, seed, r_flat, (write_error && b->d == 16) ? b->codebook : nullptr, b->K,
                                           b->level_bytes == GQ_LEVELS_PACKED6, wire, b->dense_table, b->ndense, stream);
     }
     if (b->level_bytes == GQ_LEVELS_PACKED6)
-        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched: GQ_LEVELS_PACKED6 needs d = 16, K = 256, n_bit <= 6");
+        return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched: GQ_LEVELS_PACKED6 needs d = 16, K <= 256, n_bit <= 6");
     // error feedback with 16-bit levels on a prefilter shape (main.py's own defaults with --ef): levels and residual in one pass
-    if (write_error && gq::pf_dim(b->d) && b->K == 256 && b->code_bytes == 1 && b->level_bytes == 2 && b->n_bit >= 1 && b->n_bit <= 15)
+    if (write_error && gq::pf_dim(b->d) && b->K <= 256 && b->code_bytes == 1 && b->level_bytes == 2 && b->n_bit >= 1 && b->n_bit <= 15)
         return gqi_hsq_levels_batched_ef16(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->u_flat, b->seg_minmax, b->n_bit,
-                                           random_mode, seed, r_flat, b->codebook, b->d, wire, b->dense_table, b->ndense, stream);
+                                           random_mode, seed, r_flat, b->codebook, b->d, b->K, wire, b->dense_table, b->ndense, stream);
     rc = gqi_hsq_levels_batched_any(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->u_flat, b->seg_minmax, b->n_bit,
                                     random_mode, seed, r_flat, b->level_bytes, wire, b->dense_table, b->ndense, stream);
     if (rc != GQ_OK || !write_error) return rc;
@@ -152,7 +152,7 @@ GQ_API int gq_hsq_levels_decode_batched(const gq_hsq_batch *b, uint8_t *wire, in
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode_batched: the tail of a one-payload step has rows_R = 1 and, with rng_state or reset words, a ticket word");
     if (t && t->n > 0 && (static_cast<const uint8_t *>(t->rows) < wire || (static_cast<const uint8_t *>(t->rows) - wire) % 4 != 0))
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_decode_batched: tail.rows must point into `wire` (its dense region)");
-    const bool served = gq::pf_dim(b->d) && b->K == 256 && b->code_bytes == 1 && (b->level_bytes == 1 || b->level_bytes == 2) &&
+    const bool served = gq::pf_dim(b->d) && b->K <= 256 && b->code_bytes == 1 && (b->level_bytes == 1 || b->level_bytes == 2) &&
                         b->n_bit >= 1 && b->n_bit <= (b->level_bytes == 1 ? 8 : 15) &&
                         (random_mode == GQ_RANDOM_OFF || random_mode == GQ_RANDOM_GIVEN || random_mode == GQ_RANDOM_DEVICE ||
                          random_mode == GQ_RANDOM_DEVICE_KEYED || random_mode == GQ_RANDOM_DEVICE_COUNTER) &&
@@ -177,7 +177,7 @@ GQ_API int gq_hsq_levels_decode_batched(const gq_hsq_batch *b, uint8_t *wire, in
         ft.ticket = t->ticket;
     }
     return gqi_hsq_levels_decode_batched(b->seg_table, b->tile_seg, b->nseg, b->ntiles, b->u_flat, b->seg_minmax, b->n_bit, random_mode,
-                                         seed, r_flat, b->codebook, b->d, b->level_bytes, wire, b->dense_table, b->ndense, write_error,
+                                         seed, r_flat, b->codebook, b->d, b->K, b->level_bytes, wire, b->dense_table, b->ndense, write_error,
                                          out, plain, &ft, stream);
 }
 
@@ -192,17 +192,17 @@ static int decode_sum_batched(const gq_hsq_batch *b, const uint8_t *gathered, in
     if (byte_wire(b)) {
         if (b->d == 16)
             return gqi_hsq_decode_sum_batched_d16(b->seg_table, b->tile_seg, b->nseg, b->ntiles, gathered, user_stride_bytes, R,
-                                                  b->codebook, b->n_bit, b->level_bytes == GQ_LEVELS_PACKED6, out, plain, tail,
+                                                  b->codebook, b->K, b->n_bit, b->level_bytes == GQ_LEVELS_PACKED6, out, plain, tail,
                                                   tail_taken, stream);
         return gqi_hsq_decode_sum_batched_d(b->seg_table, b->tile_seg, b->nseg, b->ntiles, gathered, user_stride_bytes, R,
-                                            b->codebook, b->d, 1, b->n_bit, out, plain, tail, tail_taken, stream);
+                                            b->codebook, b->d, b->K, 1, b->n_bit, out, plain, tail, tail_taken, stream);
     }
     // 16-bit levels on a prefilter shape (main.py's own defaults: n_bit 8 with stochastic rounding reaches level 256)
-    if (pf_dim(b->d) && b->K == 256 && b->code_bytes == 1 && b->level_bytes == 2 && b->n_bit >= 1 && b->n_bit <= 15 && !(plain & 2))
+    if (pf_dim(b->d) && b->K <= 256 && b->code_bytes == 1 && b->level_bytes == 2 && b->n_bit >= 1 && b->n_bit <= 15 && !(plain & 2))
         return gqi_hsq_decode_sum_batched_d(b->seg_table, b->tile_seg, b->nseg, b->ntiles, gathered, user_stride_bytes, R,
-                                            b->codebook, b->d, 2, b->n_bit, out, plain, tail, tail_taken, stream);
+                                            b->codebook, b->d, b->K, 2, b->n_bit, out, plain, tail, tail_taken, stream);
     if (b->level_bytes == GQ_LEVELS_PACKED6)
-        return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched: GQ_LEVELS_PACKED6 needs d = 16, K = 256, n_bit <= 6");
+        return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_decode_sum_batched: GQ_LEVELS_PACKED6 needs d = 16, K <= 256, n_bit <= 6");
     return gqi_hsq_decode_sum_batched_any(b->seg_table, b->tile_seg, b->nseg, b->ntiles, gathered, user_stride_bytes, R,
                                           b->codebook, b->d, b->K, b->code_bytes, b->level_bytes, b->n_bit, out, plain, stream);
 }

@@ -100,12 +100,12 @@ template <bool PACKED6>
 __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
-    uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire, const int64_t *__restrict__ dense_table, int ndense) {
+    uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, int K, uint8_t *__restrict__ wire, const int64_t *__restrict__ dense_table, int ndense) {
     resolve_seed(random_mode, seed);
     copy_dense_segments(dense_table, ndense, wire);
     // rows 20 floats apart: an odd number of 16-byte units spreads the random-row gathers over the banks
     __shared__ __attribute__((aligned(16))) float s_cb[256 * 20];
-    for (int i = threadIdx.x; i < 256 * 16 / 4; i += BT_THREADS)
+    for (int i = threadIdx.x; i < K * 16 / 4; i += BT_THREADS)   // (K <= 256 rows; codes stay below K)
         *reinterpret_cast<f32x4 *>(s_cb + (i >> 2) * 20 + 4 * (i & 3)) = reinterpret_cast<const f32x4 *>(cb)[i];
     __syncthreads();
     const float s = (float)(1 << n_bit), smax = s - 1.0f;
@@ -171,11 +171,11 @@ __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_kernel(
 // One thread per 4 output floats of the padded space; payload r starts at gathered + r*user_stride.
 __global__ __launch_bounds__(BT_THREADS) void hsq_decode_sum_batched_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
-    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
+    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int K, int n_bit,
     float *__restrict__ out, int plain) {
     // rows 20 floats apart: an odd number of 16-byte units spreads the random-row gathers over the banks
     __shared__ __attribute__((aligned(16))) float s_cb[256 * 20];
-    for (int i = threadIdx.x; i < 256 * 16 / 4; i += BT_THREADS)
+    for (int i = threadIdx.x; i < K * 16 / 4; i += BT_THREADS)   // (K <= 256 rows; codes stay below K)
         *reinterpret_cast<f32x4 *>(s_cb + (i >> 2) * 20 + 4 * (i & 3)) = reinterpret_cast<const f32x4 *>(cb)[i];
     __syncthreads();
     const float s = (float)(1 << n_bit);
@@ -325,7 +325,7 @@ template <int R, bool PACKED6, bool FMA = false>
 __global__ __launch_bounds__(bt4r_threads(R)) __attribute__((amdgpu_waves_per_eu(bt4r_waves(R), bt4r_waves(R))))
 void hsq_decode_sum_batched4_r_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
-    const uint8_t *__restrict__ gathered, int64_t user_stride, const float *__restrict__ cb, int n_bit,
+    const uint8_t *__restrict__ gathered, int64_t user_stride, const float *__restrict__ cb, int K, int n_bit,
     float *__restrict__ out, int plain, const StepTail tail) {
     extern __shared__ __attribute__((aligned(16))) float s_cb4[];   // [256][4 copies][16] at LDS address 0 (bt4_payload<.., ABS0>)
     step_tail_run(tail);
@@ -388,13 +388,13 @@ void hsq_decode_sum_batched4_r_kernel(
 #pragma unroll
         for (int n = 0; n < STAGE; ++n) {
             const int e = threadIdx.x + n * THREADS;   // (row, copy, quarter)
-            if (e < 256 * 16) stage[n] = *reinterpret_cast<const f32x4 *>(cb + (e >> 4) * 16 + 4 * (e & 3));
+            if (e < K * 16) stage[n] = *reinterpret_cast<const f32x4 *>(cb + (e >> 4) * 16 + 4 * (e & 3));
         }
 #pragma unroll
         for (int n = 0; n < STAGE; ++n) {
             const int e = threadIdx.x + n * THREADS;
             const int row = e >> 4, c = (e >> 2) & 3, qq = e & 3;
-            if (e < 256 * 16) *reinterpret_cast<f32x4 *>(s_cb4 + row * 64 + c * 16 + 4 * qq) = stage[n];
+            if (e < K * 16) *reinterpret_cast<f32x4 *>(s_cb4 + row * 64 + c * 16 + 4 * qq) = stage[n];
         }
     }
     __syncthreads();
@@ -449,7 +449,7 @@ void hsq_decode_sum_batched4_r_kernel(
 
 template <int R, bool P6, bool FMA = false>
 static void launch_bt4_r(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
-                         int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st, const StepTail &tail) {
+                         int64_t user_stride, const float *cb, int K, int n_bit, float *out, int plain, hipStream_t st, const StepTail &tail) {
     static const int bpc = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_batched4_r_kernel<R, P6, FMA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -463,7 +463,7 @@ static void launch_bt4_r(const int64_t *seg_table, const int32_t *tile_seg, int6
     int64_t blocks = (ntiles * 64 + bt4r_threads(R) - 1) / bt4r_threads(R);
     if (blocks > (int64_t)cu_count() * bpc) blocks = (int64_t)cu_count() * bpc;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched4_r_kernel<R, P6, FMA>), dim3((unsigned)blocks), dim3(bt4r_threads(R)),
-                       (size_t)64 * 1024, st, seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, tail);
+                       (size_t)64 * 1024, st, seg_table, tile_seg, ntiles, gathered, user_stride, cb, K, n_bit, out, plain, tail);
 }
 
 // Any R above BT4_RMAX: the same pipeline in chunks of BT4_RMAX payloads (see hsq_decode_sum_d16u8_rc_kernel): the words of
@@ -476,7 +476,7 @@ template <bool PACKED6>
 __global__ __launch_bounds__(BT4_RC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))   // 16 word registers + 16 sums + rows + two tile records: ~90 VGPRs
 void hsq_decode_sum_batched4_rc_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
-    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
+    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int K, int n_bit,
     float *__restrict__ out, int plain, const StepTail tail) {
     extern __shared__ __attribute__((aligned(16))) float s_cb4[];   // [256][4 copies][16] at LDS address 0
     step_tail_run(tail);
@@ -520,13 +520,13 @@ void hsq_decode_sum_batched4_rc_kernel(
 #pragma unroll
         for (int n = 0; n < STAGE; ++n) {
             const int e = threadIdx.x + n * THREADS;
-            if (e < 256 * 16) stage[n] = *reinterpret_cast<const f32x4 *>(cb + (e >> 4) * 16 + 4 * (e & 3));
+            if (e < K * 16) stage[n] = *reinterpret_cast<const f32x4 *>(cb + (e >> 4) * 16 + 4 * (e & 3));
         }
 #pragma unroll
         for (int n = 0; n < STAGE; ++n) {
             const int e = threadIdx.x + n * THREADS;
             const int row = e >> 4, c = (e >> 2) & 3, qq = e & 3;
-            if (e < 256 * 16) *reinterpret_cast<f32x4 *>(s_cb4 + row * 64 + c * 16 + 4 * qq) = stage[n];
+            if (e < K * 16) *reinterpret_cast<f32x4 *>(s_cb4 + row * 64 + c * 16 + 4 * qq) = stage[n];
         }
     }
     __syncthreads();
@@ -581,7 +581,7 @@ void hsq_decode_sum_batched4_rc_kernel(
 
 template <bool P6>
 static void launch_bt4_rc(int R, const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
-                          int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st, const StepTail &tail) {
+                          int64_t user_stride, const float *cb, int K, int n_bit, float *out, int plain, hipStream_t st, const StepTail &tail) {
     static const int bpc = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hsq_decode_sum_batched4_rc_kernel<P6>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -595,33 +595,33 @@ static void launch_bt4_rc(int R, const int64_t *seg_table, const int32_t *tile_s
     int64_t blocks = (ntiles * 64 + BT4_RC_THREADS - 1) / BT4_RC_THREADS;
     if (blocks > (int64_t)cu_count() * bpc) blocks = (int64_t)cu_count() * bpc;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched4_rc_kernel<P6>), dim3((unsigned)blocks), dim3(BT4_RC_THREADS), (size_t)64 * 1024, st,
-                       seg_table, tile_seg, ntiles, gathered, user_stride, R, cb, n_bit, out, plain, tail);
+                       seg_table, tile_seg, ntiles, gathered, user_stride, R, cb, K, n_bit, out, plain, tail);
 }
 
 template <bool P6>
 static void launch_bt4_fixed_r(int R, const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
-                               int64_t user_stride, const float *cb, int n_bit, float *out, int plain, hipStream_t st, bool fma,
+                               int64_t user_stride, const float *cb, int K, int n_bit, float *out, int plain, hipStream_t st, bool fma,
                                const StepTail &tail) {
     // (the lane's payload inside a group of four travels in the 32-bit offset of its loads: 3 strides + a payload must fit;
     // wires of a gigabyte and more per user take the chunked kernel, whose bases are 64-bit)
     const bool fits32 = user_stride >= 0 && 4 * user_stride < ((int64_t)1 << 32);
     if (fma && fits32 && !plain) {   // GQ_AGGREGATE_FMA: the power-of-two payload counts; every other R keeps the exact kernels
         switch (R) {
-#define GQ_BT4_FMA(N) case N: launch_bt4_r<N, P6, true>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st, tail); return;
+#define GQ_BT4_FMA(N) case N: launch_bt4_r<N, P6, true>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, K, n_bit, out, plain, st, tail); return;
             GQ_BT4_FMA(2) GQ_BT4_FMA(4) GQ_BT4_FMA(8) GQ_BT4_FMA(16)
 #undef GQ_BT4_FMA
             default: break;
         }
     }
     switch (fits32 ? R : 0) {
-#define GQ_BT4_CASE(N) case N: launch_bt4_r<N, P6>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st, tail); return;
+#define GQ_BT4_CASE(N) case N: launch_bt4_r<N, P6>(seg_table, tile_seg, ntiles, gathered, user_stride, cb, K, n_bit, out, plain, st, tail); return;
         GQ_BT4_CASE(1) GQ_BT4_CASE(2) GQ_BT4_CASE(3) GQ_BT4_CASE(4)
         GQ_BT4_CASE(5) GQ_BT4_CASE(6) GQ_BT4_CASE(7) GQ_BT4_CASE(8)
         GQ_BT4_CASE(9) GQ_BT4_CASE(10) GQ_BT4_CASE(11) GQ_BT4_CASE(12)
         GQ_BT4_CASE(13) GQ_BT4_CASE(14) GQ_BT4_CASE(15) GQ_BT4_CASE(16)
 #undef GQ_BT4_CASE
         default:
-            launch_bt4_rc<P6>(R, seg_table, tile_seg, ntiles, gathered, user_stride, cb, n_bit, out, plain, st, tail);
+            launch_bt4_rc<P6>(R, seg_table, tile_seg, ntiles, gathered, user_stride, cb, K, n_bit, out, plain, st, tail);
             return;
     }
 }
@@ -632,13 +632,13 @@ template <int D>
 __global__ __launch_bounds__(BT_THREADS) void hsq_levels_ef_batched_d_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *__restrict__ seg_minmax, int n_bit, int random_mode,
-    uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire, const int64_t *__restrict__ dense_table, int ndense) {
+    uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, int K, uint8_t *__restrict__ wire, const int64_t *__restrict__ dense_table, int ndense) {
     resolve_seed(random_mode, seed);
     copy_dense_segments(dense_table, ndense, wire);
     constexpr int UPS = D / 4;
     constexpr int RS = ((D / 4) & 1) ? D : D + 4;
     __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];
-    for (int i = threadIdx.x; i < 256 * UPS; i += BT_THREADS)
+    for (int i = threadIdx.x; i < K * UPS; i += BT_THREADS)   // (K <= 256 rows; codes stay below K)
         *reinterpret_cast<f32x4 *>(s_cb + (i / UPS) * RS + 4 * (i % UPS)) = reinterpret_cast<const f32x4 *>(cb)[i];
     __syncthreads();
     const float s = (float)(1 << n_bit), smax = s - 1.0f;
@@ -715,7 +715,7 @@ constexpr int DT_RB = 4;    // ... of which this many are read back from LDS tog
 template <int D, typename LevelT, int RB>
 __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
-    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int n_bit,
+    const uint8_t *__restrict__ gathered, int64_t user_stride, int R, const float *__restrict__ cb, int K, int n_bit,
     float *__restrict__ out, int plain, const StepTail tail) {
     step_tail_run(tail);
     constexpr int DT_RBK = RB > 0 ? RB : 1;
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_decode_sum_batched_tile_kernel
     constexpr int RS = ((D / 4) & 1) ? D : D + 4;            // LDS row stride in floats: an odd number of 16-byte units
     __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];
     __shared__ __attribute__((aligned(8))) unsigned s_pair[DT_WAVES * DT_RCH * 64 * 2];   // { code, bits of the norm } per (wave, payload of the chunk, subvector)
-    for (int i = threadIdx.x; i < 256 * UPS; i += DT_THREADS)
+    for (int i = threadIdx.x; i < K * UPS; i += DT_THREADS)   // (K <= 256 rows; codes stay below K)
         *reinterpret_cast<f32x4 *>(s_cb + (i / UPS) * RS + 4 * (i % UPS)) = reinterpret_cast<const f32x4 *>(cb)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -874,7 +874,7 @@ template <int D, typename LevelT, bool OUT>
 __global__ __launch_bounds__(DT_THREADS) void hsq_levels_ef_tile_kernel(
     const int64_t *__restrict__ seg_table, const int32_t *__restrict__ tile_seg, int64_t ntiles,
     const float *__restrict__ u_flat, const unsigned *seg_minmax, int n_bit, int random_mode,      // (seg_minmax: NOT restrict -- OUT's last workgroup rewrites these words through ft.reset_dst)
-    uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, uint8_t *__restrict__ wire,
+    uint64_t seed, const float *__restrict__ r_flat, const float *__restrict__ cb, int K, uint8_t *__restrict__ wire,
     const int64_t *__restrict__ dense_table, int ndense, int write_error, float *__restrict__ out, int plain, const FusedTail ft) {
     resolve_seed(random_mode, seed);
     copy_dense_segments(dense_table, ndense, wire);
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(DT_THREADS) void hsq_levels_ef_tile_kernel(
     constexpr int RS = ((D / 4) & 1) ? D : D + 4;
     __shared__ __attribute__((aligned(16))) float s_cb[256 * RS];
     __shared__ __attribute__((aligned(8))) unsigned s_pair[DT_WAVES * 64 * 2];   // { code, bits of the norm } per (wave, subvector)
-    for (int i = threadIdx.x; i < 256 * UPS; i += DT_THREADS)
+    for (int i = threadIdx.x; i < K * UPS; i += DT_THREADS)   // (K <= 256 rows; codes stay below K)
         *reinterpret_cast<f32x4 *>(s_cb + (i / UPS) * RS + 4 * (i % UPS)) = reinterpret_cast<const f32x4 *>(cb)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1155,21 +1155,21 @@ namespace gq {
 template <int D, typename LevelT, bool OUT = false>
 static void launch_levels_ef_tile(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const float *u_flat,
                                   const uint32_t *seg_minmax, int n_bit, int random_mode, uint64_t seed, const float *r_flat,
-                                  const float *cb, uint8_t *wire, const int64_t *dense_table, int ndense, hipStream_t st,
+                                  const float *cb, int K, uint8_t *wire, const int64_t *dense_table, int ndense, hipStream_t st,
                                   int write_error = 1, float *out = nullptr, int plain = 0, const FusedTail &ft = FusedTail{}) {
     static const int bpc = resident_blocks_per_cu(hsq_levels_ef_tile_kernel<D, LevelT, OUT>, DT_THREADS, 0);
     int64_t blocks = (ntiles + DT_WAVES - 1) / DT_WAVES;
     const int64_t cap = (int64_t)cu_count() * bpc;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_levels_ef_tile_kernel<D, LevelT, OUT>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(DT_THREADS), 0,
-                       st, seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, cb, wire, dense_table, ndense,
+                       st, seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, cb, K, wire, dense_table, ndense,
                        write_error, out, plain, ft);
 }
 }  // namespace gq
 
 GQ_INTERNAL int gqi_hsq_levels_batched_d16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                            const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                                           uint64_t seed, const float *r_flat, const float *ef_codebook, int packed6,
+                                           uint64_t seed, const float *r_flat, const float *ef_codebook, int K, int packed6,
                                            uint8_t *wire, const int64_t *dense_table, int ndense, void *stream) {
     // ef_codebook != NULL: additionally error = v - decode(wire) for the rows that have an error buffer (d = 16)
     if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > 8)
@@ -1184,13 +1184,13 @@ GQ_INTERNAL int gqi_hsq_levels_batched_d16(const int64_t *seg_table, const int32
     hipStream_t st = gq::as_stream(stream);
     if (ef_codebook && packed6)
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_kernel<true>, dim3((unsigned)gq::bt_grid(ntiles * 256)), block, 0, st,
-                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, wire, dense_table, ndense);
+                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, K, wire, dense_table, ndense);
     else if (ef_codebook && GQ_EF_LEVELS_TILE)
-        gq::launch_levels_ef_tile<16, uint8_t>(seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, wire,
+        gq::launch_levels_ef_tile<16, uint8_t>(seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, K, wire,
                                                dense_table, ndense, st);
     else if (ef_codebook)
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_kernel<false>, dim3((unsigned)gq::bt_grid(ntiles * 256)), block, 0, st,
-                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, wire, dense_table, ndense);
+                           seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, ef_codebook, K, wire, dense_table, ndense);
     else if (packed6)
         hipLaunchKernelGGL(gq::hsq_levels_batched_kernel<gq::Packed6>, dim3((unsigned)gq::bt_grid(ntiles * 16)), block, 0, st,
                            seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, wire, dense_table, ndense);
@@ -1203,7 +1203,7 @@ GQ_INTERNAL int gqi_hsq_levels_batched_d16(const int64_t *seg_table, const int32
 
 GQ_INTERNAL int gqi_hsq_decode_sum_batched_d16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                                const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                               const float *codebook, int n_bit, int packed6, float *out, int plain,
+                                               const float *codebook, int K, int n_bit, int packed6, float *out, int plain,
                                                const gq::StepTail *tail_or_null, int *tail_taken, void *stream) {
     if (tail_taken) *tail_taken = 0;
     if (nseg < 1 || ntiles < 1 || R < 1 || n_bit < 1 || n_bit > 8)
@@ -1216,10 +1216,10 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_d16(const int64_t *seg_table, const i
         // compile-time-R kernels up to BT4_RMAX payloads, the chunked one above: every R is served
         const gq::StepTail tail = tail_or_null ? *tail_or_null : gq::StepTail{};
         if (packed6)
-            gq::launch_bt4_fixed_r<true>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, n_bit, out, plain,
+            gq::launch_bt4_fixed_r<true>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, K, n_bit, out, plain,
                                          gq::as_stream(stream), fma, tail);
         else
-            gq::launch_bt4_fixed_r<false>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, n_bit, out, plain,
+            gq::launch_bt4_fixed_r<false>(R, seg_table, tile_seg, ntiles, gathered, user_stride_bytes, codebook, K, n_bit, out, plain,
                                           gq::as_stream(stream), fma, tail);
         if (tail_taken) *tail_taken = 1;
     } else if (packed6) {
@@ -1227,7 +1227,7 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_d16(const int64_t *seg_table, const i
     } else {
         hipLaunchKernelGGL(gq::hsq_decode_sum_batched_kernel, dim3((unsigned)gq::bt_grid(ntiles * 256)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, gathered,
-                           user_stride_bytes, R, codebook, n_bit, out, plain);
+                           user_stride_bytes, R, codebook, K, n_bit, out, plain);
     }
     GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched");
     return GQ_OK;
@@ -1237,7 +1237,7 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_d16(const int64_t *seg_table, const i
 namespace gq {
 template <int D, typename LevelT>
 static void launch_decode_tile(const int64_t *seg_table, const int32_t *tile_seg, int64_t ntiles, const uint8_t *gathered,
-                               int64_t user_stride_bytes, int R, const float *codebook, int n_bit, float *out, int plain,
+                               int64_t user_stride_bytes, int R, const float *codebook, int K, int n_bit, float *out, int plain,
                                hipStream_t st, const StepTail &tail) {
     int64_t blocks = (ntiles + DT_WAVES - 1) / DT_WAVES;
 #define GQ_DT_LAUNCH(RBV)                                                                                                        \
@@ -1247,7 +1247,7 @@ static void launch_decode_tile(const int64_t *seg_table, const int32_t *tile_seg
         if (blocks > cap) blocks = cap;                                                                                          \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_decode_sum_batched_tile_kernel<D, LevelT, RBV>),                                  \
                            dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(DT_THREADS), 0, st, seg_table, tile_seg, ntiles,      \
-                           gathered, user_stride_bytes, R, codebook, n_bit, out, plain, tail);                                   \
+                           gathered, user_stride_bytes, R, codebook, K, n_bit, out, plain, tail);                                   \
     } while (0)
     if (R >= DT_RB) GQ_DT_LAUNCH(DT_RB);
     else if (R >= 2) GQ_DT_LAUNCH(2);
@@ -1258,7 +1258,7 @@ static void launch_decode_tile(const int64_t *seg_table, const int32_t *tile_seg
 
 GQ_INTERNAL int gqi_hsq_decode_sum_batched_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                              const uint8_t *gathered, int64_t user_stride_bytes, int R,
-                                             const float *codebook, int d, int level_bytes, int n_bit, float *out, int plain,
+                                             const float *codebook, int d, int K, int level_bytes, int n_bit, float *out, int plain,
                                              const gq::StepTail *tail_or_null, int *tail_taken, void *stream) {
     const gq::StepTail tail = tail_or_null ? *tail_or_null : gq::StepTail{};
     if (tail_taken) *tail_taken = 0;
@@ -1270,7 +1270,7 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_d(const int64_t *seg_table, const int
     hipStream_t st = gq::as_stream(stream);
 #define GQ_DT_CASE(DD, LB, LT)                                                                                          \
     if (d == DD && level_bytes == LB) {                                                                                 \
-        gq::launch_decode_tile<DD, LT>(seg_table, tile_seg, ntiles, gathered, user_stride_bytes, R, codebook, n_bit, out, \
+        gq::launch_decode_tile<DD, LT>(seg_table, tile_seg, ntiles, gathered, user_stride_bytes, R, codebook, K, n_bit, out, \
                                        plain, st, tail);                                                                \
         GQ_CHECK_LAUNCH("gq_hsq_decode_sum_batched");                                                                   \
         if (tail_taken) *tail_taken = 1;                                                                                \
@@ -1288,7 +1288,7 @@ GQ_INTERNAL int gqi_hsq_decode_sum_batched_d(const int64_t *seg_table, const int
 // error-feedback level kernel of d = 8 / 32 (K = 256): levels + error = v - decode(wire) in one launch
 GQ_INTERNAL int gqi_hsq_levels_batched_ef_d(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                             const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                                            uint64_t seed, const float *r_flat, const float *codebook, int d, uint8_t *wire, const int64_t *dense_table, int ndense,
+                                            uint64_t seed, const float *r_flat, const float *codebook, int d, int K, uint8_t *wire, const int64_t *dense_table, int ndense,
                                             void *stream) {
     if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > 8)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: bad sizes");
@@ -1300,19 +1300,19 @@ GQ_INTERNAL int gqi_hsq_levels_batched_ef_d(const int64_t *seg_table, const int3
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: levels do not fit uint8");
     if (GQ_EF_LEVELS_TILE && (d == 8 || d == 32)) {
         if (d == 8)
-            gq::launch_levels_ef_tile<8, uint8_t>(seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, codebook, wire,
+            gq::launch_levels_ef_tile<8, uint8_t>(seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, codebook, K, wire,
                                                   dense_table, ndense, gq::as_stream(stream));
         else
-            gq::launch_levels_ef_tile<32, uint8_t>(seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, codebook, wire,
+            gq::launch_levels_ef_tile<32, uint8_t>(seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, codebook, K, wire,
                                                    dense_table, ndense, gq::as_stream(stream));
     } else if (d == 8) {
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_d_kernel<8>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 2)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
-                           n_bit, random_mode, seed, r_flat, codebook, wire, dense_table, ndense);
+                           n_bit, random_mode, seed, r_flat, codebook, K, wire, dense_table, ndense);
     } else if (d == 32) {
         hipLaunchKernelGGL(gq::hsq_levels_ef_batched_d_kernel<32>, dim3((unsigned)gq::bt_grid(ntiles * 64 * 8)),
                            dim3(gq::BT_THREADS), 0, gq::as_stream(stream), seg_table, tile_seg, ntiles, u_flat, seg_minmax,
-                           n_bit, random_mode, seed, r_flat, codebook, wire, dense_table, ndense);
+                           n_bit, random_mode, seed, r_flat, codebook, K, wire, dense_table, ndense);
     } else {
         return gq::fail(GQ_ERR_UNSUPPORTED, "gq_hsq_levels_batched: the fused error-feedback form serves d = 8, 16 or 32 (K = 256)");
     }
@@ -1322,7 +1322,7 @@ GQ_INTERNAL int gqi_hsq_levels_batched_ef_d(const int64_t *seg_table, const int3
 
 GQ_INTERNAL int gqi_hsq_levels_batched_ef16(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                             const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                                            uint64_t seed, const float *r_flat, const float *codebook, int d, uint8_t *wire,
+                                            uint64_t seed, const float *r_flat, const float *codebook, int d, int K, uint8_t *wire,
                                             const int64_t *dense_table, int ndense, void *stream) {
     if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > 15)
         return gq::fail(GQ_ERR_INVALID_ARG, "gq_hsq_levels_batched: bad sizes");
@@ -1334,7 +1334,7 @@ GQ_INTERNAL int gqi_hsq_levels_batched_ef16(const int64_t *seg_table, const int3
 #define GQ_EF16_CASE(DD)                                                                                                       \
     if (d == DD) {                                                                                                             \
         gq::launch_levels_ef_tile<DD, uint16_t>(seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat, \
-                                                codebook, wire, dense_table, ndense, st);                                      \
+                                                codebook, K, wire, dense_table, ndense, st);                                      \
         GQ_CHECK_LAUNCH("gq_hsq_levels_batched");                                                                              \
         return GQ_OK;                                                                                                          \
     }
@@ -1348,7 +1348,7 @@ GQ_INTERNAL int gqi_hsq_levels_batched_ef16(const int64_t *seg_table, const int3
 // levels (+ residual) + decode of the finished payload + the step's tail in ONE launch (K = 256, d = 8 / 16 / 32, byte or 16-bit levels)
 GQ_INTERNAL int gqi_hsq_levels_decode_batched(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
                                               const float *u_flat, const uint32_t *seg_minmax, int n_bit, int random_mode,
-                                              uint64_t seed, const float *r_flat, const float *codebook, int d, int level_bytes,
+                                              uint64_t seed, const float *r_flat, const float *codebook, int d, int K, int level_bytes,
                                               uint8_t *wire, const int64_t *dense_table, int ndense, int write_error, float *out,
                                               int plain, const gq::FusedTail *ft, void *stream) {
     if (nseg < 1 || ntiles < 1 || n_bit < 1 || n_bit > (level_bytes == 1 ? 8 : 15))
@@ -1364,7 +1364,7 @@ GQ_INTERNAL int gqi_hsq_levels_decode_batched(const int64_t *seg_table, const in
 #define GQ_LD_CASE(DD, LB, LT)                                                                                                       \
     if (d == DD && level_bytes == LB) {                                                                                              \
         gq::launch_levels_ef_tile<DD, LT, true>(seg_table, tile_seg, ntiles, u_flat, seg_minmax, n_bit, random_mode, seed, r_flat,    \
-                                                codebook, wire, dense_table, ndense, st, write_error, out, plain & 1, tail);         \
+                                                codebook, K, wire, dense_table, ndense, st, write_error, out, plain & 1, tail);         \
         GQ_CHECK_LAUNCH("gq_hsq_levels_decode_batched");                                                                             \
         return GQ_OK;                                                                                                                \
     }

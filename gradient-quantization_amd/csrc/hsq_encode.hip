@@ -654,7 +654,7 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
     size_t lds_bytes = 0;
     int lds_waves = ENC_WAVES;
     const bool lds_ok = lds_plan(d, K, &dpad, &chunk_rows, &lds_bytes, &lds_waves);
-    const bool pf_ok = K == 256 && (d == 8 || d == 12 || d == 16 || d == 24 || d == 32) && (reinterpret_cast<uintptr_t>(grad) & 15) == 0;   // (12 / 24: the reference's repaired dimensions, on the d = 16 / 32 kernels)
+    const bool pf_ok = K >= 4 && K <= 256 && (K & 3) == 0 && (d == 8 || d == 12 || d == 16 || d == 24 || d == 32) && (reinterpret_cast<uintptr_t>(grad) & 15) == 0;   // (12 / 24: the reference's repaired dimensions, on the d = 16 / 32 kernels)
     // larger codebooks of the d = 16 family: the prefilter kernel once per page of 256 codewords
     const bool paged_ok = std::is_same<CodeT, int32_t>::value && (d == 8 || d == 16 || d == 32) && K > 256 &&
                           (K & 255) == 0 && (reinterpret_cast<uintptr_t>(grad) & 15) == 0;
@@ -689,10 +689,10 @@ static int launch_encode(const float *grad, const float *codebook, int64_t M, in
         return GQ_OK;
     }
     if (impl == 4) {
-        if (!(d == 8 || d == 12 || d == 16 || d == 24 || d == 32) || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 4 needs K=256 and d in {8, 12, 16, 24, 32}");
+        if (!(d == 8 || d == 12 || d == 16 || d == 24 || d == 32) || K < 4 || K > 256 || (K & 3)) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 4 needs K <= 256 (a multiple of 4) and d in {8, 12, 16, 24, 32}");
         if ((reinterpret_cast<uintptr_t>(grad) & 15) != 0)
             return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: grad must be 16-byte aligned");
-        return launch_encode_pf<CodeT>(grad, codebook, M, d, codes, u, partials, st, profile_slot);
+        return launch_encode_pf<CodeT>(grad, codebook, M, d, K, codes, u, partials, st, profile_slot);
     }
     if (impl == 1) {
         if (d != 16 || K != 256) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: impl 1 needs d=16, K=256");

@@ -190,9 +190,9 @@ static int resident_blocks_per_cu(KernelT kernel, int threads, size_t lds) {
     return n;
 }
 
-// hsq_encode_pf.hip: f16 MFMA prefilter + exact f32 rescoring + second pass + exact scans (d = 8 / 16 / 32, K = 256).
+// hsq_encode_pf.hip: f16 MFMA prefilter + exact f32 rescoring + second pass + exact scans (d = 8 / 12 / 16 / 24 / 32, K <= 256 and a multiple of 4).
 template <typename CodeT>
-int launch_encode_pf(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u, float *workspace,
+int launch_encode_pf(const float *grad, const float *codebook, int64_t M, int d, int K, CodeT *codes, float *u, float *workspace,
                      hipStream_t st, int profile_slot = -1);
 
 // LDS plan of the operand-staging kernels (hsq_encode_lds_kernel, pvq_encode_lds_kernel): false if (d, K) does not fit

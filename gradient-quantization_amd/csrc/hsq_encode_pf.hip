@@ -159,6 +159,7 @@ struct PfArgs {
     unsigned *seg_minmax;     // batched: order-mapped (min, max) per segment
     int64_t ntiles;
     int nseg;                 // batched: segments in seg_table
+    int K;                    // codewords (<= 32 NRB; a multiple of 4): rows K .. 255 of the image and of the fragments are zeros
     float ef_scale;           // EF kernels: grad <- grad + ef_scale * error (error pointer = seg_table[seg][7], 0 = none)
     int tiles_q, tiles_r;     // tiles per workgroup: the first tiles_r workgroups take tiles_q + 1, the others tiles_q
     int tiles_skew, skew_blocks;   // ... and of the first skew_blocks (even) workgroups the even ones take tiles_skew more, the odd ones as many fewer
@@ -187,10 +188,16 @@ static void pf_split(PfArgs &a, int64_t ntiles, int64_t blocks) {
 // (nearest_neighbor_compressor.py:23-29: 16 -> 24, 8 -> 12): rows of DR floats in memory (gradient, error buffer, codebook), D = the
 // next of 16 / 32 everywhere else -- the missing elements are zeros in the fragments, in the LDS image and in the lane's subvector,
 // and fmaf(0, 0, acc) == acc bit for bit (acc starts at +0 and can never become -0), so scores, codes and u are the exact kernels'.
-template <typename CodeT, int D, bool BATCHED, bool EF = false, bool SEGLDS = true, int DR = D>
+// NRB (round 6): row blocks of 32 codewords that are scored -- 8 for K = 256 (and any K above 64), 2 for K <= 64, 1 for K <= 32
+// (--k-bit 5 / 6, and K == dim: nearest_neighbor_compressor.py:40-47): 2 NRB chains per tile instead of 16.  Rows K .. 32 NRB - 1
+// are zeros (image and fragments): their scores are +0 for every finite subvector, so they lose every comparison against a real
+// row or tie with one of a lower index; the exact scan (where the non-finite subvectors end up) looks at rows below K only.
+template <typename CodeT, int D, bool BATCHED, bool EF = false, bool SEGLDS = true, int DR = D, int NRB = 8>
 __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfArgs a) {
     typedef PfShape<D> SH;
     static_assert(DR == D || (D == 16 && DR == 12) || (D == 32 && DR == 24), "padded shapes: 12 -> 16, 24 -> 32");
+    static_assert(NRB == 1 || NRB == 2 || NRB == 4 || NRB == 8, "row blocks: 1, 2, 4 or 8");
+    const int K = a.K;
     constexpr int KS = SH::KS, QS = SH::QS, QCAP = SH::QCAP, NF = SH::NF;
     constexpr bool HALF = SH::HALF, PF_PAIR = SH::PAIR;
     GQ_STAMPS_ONLY(const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime(); unsigned long long nscanned = 0, npassed = 0;)
@@ -435,11 +442,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
     // ||c||_1, barrier and only then the first tile's loads: 5.2 us; profiles/r02_b_pf_prologue_stamps.txt.)
     float cbv[256 * DR / PF_THREADS];
 #pragma unroll
-    for (int n = 0; n < 256 * DR / PF_THREADS; ++n) cbv[n] = cb[threadIdx.x + n * PF_THREADS];
+    for (int n = 0; n < 256 * DR / PF_THREADS; ++n) cbv[n] = (int)threadIdx.x + n * PF_THREADS < K * DR ? cb[threadIdx.x + n * PF_THREADS] : 0.0f;
     f32x4 aq[2 * KS];   // row wave*32 + j, k-step s: floats [16 s + 8 h, + 8)
 #pragma unroll
     for (int i = 0; i < 2 * KS; ++i) aq[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (loads_here) {
+    if (loads_here && wave * 32 + j < K) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             if (frag_ok(s, 0)) aq[2 * s] = *reinterpret_cast<const f32x4 *>(cb + (wave * 32 + j) * DR + 16 * s + (HALF ? 0 : 8 * h));
@@ -589,7 +596,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
                 w[4 * q + 3] = x[3];
             }
         }
-        const f32x4 p = exact_score_quad<D>(s_cb + lane * QS, w);
+        f32x4 p = exact_score_quad<D>(s_cb + lane * QS, w);
+        if (4 * lane >= K) p = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // rows behind the codebook (K is a multiple of 4): +0, whatever 0 x inf gave -- never the first maximum
         float bv = p[0];
         int bi = 4 * lane;
         take_if_greater_nan(bv, bi, p[1], 4 * lane + 1);
@@ -705,14 +713,14 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         frags_of(0);
         f32x16 acc = {0};
         acc = chain3(acc);
-        frags_of(1);
+        if (NRB > 1) frags_of(1);
 #pragma unroll
-        for (int rb = 0; rb < 8; ++rb) {
+        for (int rb = 0; rb < NRB; ++rb) {
             f32x16 nacc = {0};
-            if (rb + 1 < 8) {
+            if (rb + 1 < NRB) {
                 __builtin_amdgcn_sched_barrier(0);
                 nacc = chain3(nacc);
-                if (rb + 2 < 8) frags_of(rb + 2);
+                if (rb + 2 < NRB) frags_of(rb + 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
             unsigned k[4];
@@ -791,8 +799,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         // 35.4 us, as two tensors 40.4.  A tensor's tiles are one contiguous range: the word is only looked up when tn leaves it.)
         // Chain order.  D <= 16 (A fragments in registers): block 0's eight row blocks, then block 1's.  D = 32 (A fragments
         // from LDS): (rb, block 0), (rb, block 1), so that both blocks share a row block's fragments, fetched a row block ahead.
-        auto chain_rb = [](int c) { return SH::A_REGS ? (c & 7) : (c >> 1); };
-        auto chain_blk = [](int c) { return SH::A_REGS ? (c >> 3) : (c & 1); };
+        auto chain_rb = [](int c) { return SH::A_REGS ? (c % NRB) : (c >> 1); };
+        auto chain_blk = [](int c) { return SH::A_REGS ? (c / NRB) : (c & 1); };
         half8 af[2][KS];   // D = 32: the row block in use / the next one
         if constexpr (!SH::A_REGS) {
 #pragma unroll
@@ -855,15 +863,15 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
             second[trk] = max3u(second[trk], trk_a, b);
         };
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        for (int c = 0; c < 2 * NRB; ++c) {
             const int rb = chain_rb(c), trk = chain_blk(c) * 2 + (rb >> 2);
             if constexpr (!SH::A_REGS) {
-                if (chain_blk(c) == 0 && rb + 1 < 8) {
+                if (chain_blk(c) == 0 && rb + 1 < NRB) {
 #pragma unroll
                     for (int s = 0; s < KS; ++s) af[(rb + 1) & 1][s] = frag_hi(rb + 1, s);
                 }
             }
-            if (c + 1 < 16) {
+            if (c + 1 < 2 * NRB) {
                 f32x16 nacc = {0};
                 __builtin_amdgcn_sched_barrier(0);
                 nacc = chain(c + 1, nacc);
@@ -1135,11 +1143,11 @@ static int64_t pf16_grid(int64_t ntiles, int bpc) {
     return blocks < 1 ? 1 : blocks;
 }
 
-template <typename CodeT, int D, int DR = D>
-static int launch_pf(const float *grad, const float *codebook, int64_t M, CodeT *codes, float *u, float *ws,
-                     hipStream_t st, int profile_slot) {
+template <typename CodeT, int D, int DR, int NRB>
+static int launch_pf_rows(const float *grad, const float *codebook, int64_t M, int K, CodeT *codes, float *u, float *ws,
+                          hipStream_t st, int profile_slot) {
     if (M > 0x7FFFFFFFLL) return fail(GQ_ERR_UNSUPPORTED, "gq_hsq_encode: prefilter path needs M < 2^31");
-    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<CodeT, D, false, false, true, DR>, PF_THREADS, 0);
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<CodeT, D, false, false, true, DR, NRB>, PF_THREADS, 0);
     PfArgs a = {};
     a.grad = grad;
     a.M = M;
@@ -1147,48 +1155,62 @@ static int launch_pf(const float *grad, const float *codebook, int64_t M, CodeT 
     a.u = u;
     a.cb = codebook;
     a.ws = ws;
+    a.K = K;
     const int64_t blocks = pf16_grid((M + 63) / 64, bpc);
     pf_split(a, (M + 63) / 64, blocks);
     hipEvent_t ev_start, ev_stop;
     if (profile_events(profile_slot, &ev_start, &ev_stop)) {   // events attached to this dispatch (gq_profile_read)
-        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, D, false, false, true, DR>), dim3((unsigned)blocks),
+        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, D, false, false, true, DR, NRB>), dim3((unsigned)blocks),
                               dim3(PF_THREADS), 0, st, ev_start, ev_stop, 0, a);
     } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, D, false, false, true, DR>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<CodeT, D, false, false, true, DR, NRB>), dim3((unsigned)blocks),
                            dim3(PF_THREADS), 0, st, a);
     }
     GQ_CHECK_LAUNCH("gq_hsq_encode (prefilter)");
     return GQ_OK;
 }
 
-// d = 8, 16 or 32 (K = 256); d = 12 / 24 (the reference's repaired dimensions) as the D = 16 / 32 kernels over rows of 12 / 24 floats
-template <typename CodeT>
-int launch_encode_pf(const float *grad, const float *codebook, int64_t M, int d, CodeT *codes, float *u, float *ws,
+// K <= 32 / <= 64 (byte codes): the kernels that score one / two row blocks; everything else up to 256 rows: all eight
+template <typename CodeT, int D, int DR = D>
+static int launch_pf(const float *grad, const float *codebook, int64_t M, int K, CodeT *codes, float *u, float *ws,
                      hipStream_t st, int profile_slot) {
-    if (d == 16) return launch_pf<CodeT, 16>(grad, codebook, M, codes, u, ws, st, profile_slot);
-    if (d == 32) return launch_pf<CodeT, 32>(grad, codebook, M, codes, u, ws, st, profile_slot);
-    if (d == 8) return launch_pf<CodeT, 8>(grad, codebook, M, codes, u, ws, st, profile_slot);
-    if (d == 12) return launch_pf<CodeT, 16, 12>(grad, codebook, M, codes, u, ws, st, profile_slot);
-    if (d == 24) return launch_pf<CodeT, 32, 24>(grad, codebook, M, codes, u, ws, st, profile_slot);
+    if constexpr (sizeof(CodeT) == 1) {
+        if (K <= 32) return launch_pf_rows<CodeT, D, DR, 1>(grad, codebook, M, K, codes, u, ws, st, profile_slot);
+        if (K <= 64) return launch_pf_rows<CodeT, D, DR, 2>(grad, codebook, M, K, codes, u, ws, st, profile_slot);
+    }
+    return launch_pf_rows<CodeT, D, DR, 8>(grad, codebook, M, K, codes, u, ws, st, profile_slot);
+}
+
+// d = 8, 16 or 32, K <= 256 (a multiple of 4); d = 12 / 24 (the reference's repaired dimensions) as the D = 16 / 32 kernels over rows of 12 / 24 floats
+template <typename CodeT>
+int launch_encode_pf(const float *grad, const float *codebook, int64_t M, int d, int K, CodeT *codes, float *u, float *ws,
+                     hipStream_t st, int profile_slot) {
+    if (K < 4 || K > 256 || (K & 3)) return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: the prefilter kernel was asked for K = %d", K);
+    if (d == 16) return launch_pf<CodeT, 16>(grad, codebook, M, K, codes, u, ws, st, profile_slot);
+    if (d == 32) return launch_pf<CodeT, 32>(grad, codebook, M, K, codes, u, ws, st, profile_slot);
+    if (d == 8) return launch_pf<CodeT, 8>(grad, codebook, M, K, codes, u, ws, st, profile_slot);
+    if (d == 12) return launch_pf<CodeT, 16, 12>(grad, codebook, M, K, codes, u, ws, st, profile_slot);
+    if (d == 24) return launch_pf<CodeT, 32, 24>(grad, codebook, M, K, codes, u, ws, st, profile_slot);
     return fail(GQ_ERR_INVALID_ARG, "gq_hsq_encode: the prefilter kernel was asked for d = %d", d);
 }
 
-template int launch_encode_pf<uint8_t>(const float *, const float *, int64_t, int, uint8_t *, float *, float *, hipStream_t, int);
-template int launch_encode_pf<int32_t>(const float *, const float *, int64_t, int, int32_t *, float *, float *, hipStream_t, int);
+template int launch_encode_pf<uint8_t>(const float *, const float *, int64_t, int, int, uint8_t *, float *, float *, hipStream_t, int);
+template int launch_encode_pf<int32_t>(const float *, const float *, int64_t, int, int, int32_t *, float *, float *, hipStream_t, int);
 
 }  // namespace gq
 
 namespace gq {
-template <int D, bool EF, int DR = D>
-static int encode_batched(const char *what, const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                          const float *codebook, uint8_t *wire, float *u_flat, uint32_t *seg_minmax, float *workspace,
-                          float ef_scale, int profile_slot, void *stream) {
+template <int D, bool EF, int DR, int NRB>
+static int encode_batched_rows(const char *what, const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                               const float *codebook, int K, uint8_t *wire, float *u_flat, uint32_t *seg_minmax, float *workspace,
+                               float ef_scale, int profile_slot, void *stream) {
     if (nseg < 1 || ntiles < 1 || ntiles * 64 > 0x7FFFFFFFLL)
         return fail(GQ_ERR_INVALID_ARG, "%s: bad sizes nseg=%d ntiles=%lld", what, nseg, (long long)ntiles);
     if (!seg_table || !tile_seg || !codebook || !wire || !u_flat || !seg_minmax || !workspace)
         return fail(GQ_ERR_INVALID_ARG, "%s: null pointer", what);
-    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<uint8_t, D, true, EF, true, DR>, PF_THREADS, 0);
+    static const int bpc = resident_blocks_per_cu(hsq_encode_pf_kernel<uint8_t, D, true, EF, true, DR, NRB>, PF_THREADS, 0);
     PfArgs a = {};
+    a.K = K;
     a.M = ntiles * 64;
     a.u = u_flat;
     a.cb = codebook;
@@ -1205,17 +1227,28 @@ static int encode_batched(const char *what, const int64_t *seg_table, const int3
     pf_split(a, ntiles, blocks);
     hipEvent_t ev_start, ev_stop;
     if (nseg <= PF_LDS_SEGS && profile_events(profile_slot, &ev_start, &ev_stop)) {   // events attached to this dispatch
-        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, true, DR>), dim3((unsigned)blocks),
+        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, true, DR, NRB>), dim3((unsigned)blocks),
                               dim3(PF_THREADS), 0, st, ev_start, ev_stop, 0, a);
     } else if (nseg <= PF_LDS_SEGS) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, true, DR>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, true, DR, NRB>), dim3((unsigned)blocks),
                            dim3(PF_THREADS), 0, st, a);
-    } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, false, DR>), dim3((unsigned)blocks),
+    } else {   // (longer lists: the records from global memory; built for all eight row blocks only)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hsq_encode_pf_kernel<uint8_t, D, true, EF, false, DR, 8>), dim3((unsigned)blocks),
                            dim3(PF_THREADS), 0, st, a);
     }
     GQ_CHECK_LAUNCH(what);
     return GQ_OK;
+}
+
+template <int D, bool EF, int DR = D>
+static int encode_batched(const char *what, const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
+                          const float *codebook, int K, uint8_t *wire, float *u_flat, uint32_t *seg_minmax, float *workspace,
+                          float ef_scale, int profile_slot, void *stream) {
+    if (K <= 32 && nseg <= PF_LDS_SEGS)
+        return encode_batched_rows<D, EF, DR, 1>(what, seg_table, tile_seg, nseg, ntiles, codebook, K, wire, u_flat, seg_minmax, workspace, ef_scale, profile_slot, stream);
+    if (K <= 64 && nseg <= PF_LDS_SEGS)
+        return encode_batched_rows<D, EF, DR, 2>(what, seg_table, tile_seg, nseg, ntiles, codebook, K, wire, u_flat, seg_minmax, workspace, ef_scale, profile_slot, stream);
+    return encode_batched_rows<D, EF, DR, 8>(what, seg_table, tile_seg, nseg, ntiles, codebook, K, wire, u_flat, seg_minmax, workspace, ef_scale, profile_slot, stream);
 }
 }  // namespace gq
 
@@ -1243,16 +1276,17 @@ GQ_INTERNAL int gqi_hsq_encode_batched_paged(const int64_t *seg_table, const int
                                         seg_minmax, workspace, st);
 }
 
-// K = 256, d = 8 / 16 / 32, byte codes: the multi-tensor prefilter launch (gq_hsq_encode_batched)
+// K <= 256 (a multiple of 4), d = 8 / 12 / 16 / 24 / 32, byte codes: the multi-tensor prefilter launch (gq_hsq_encode_batched)
 GQ_INTERNAL int gqi_hsq_encode_batched_pf(const int64_t *seg_table, const int32_t *tile_seg, int nseg, int64_t ntiles,
-                                          const float *codebook, int d, int ef, float ef_scale, uint8_t *wire, float *u_flat,
+                                          const float *codebook, int d, int K, int ef, float ef_scale, uint8_t *wire, float *u_flat,
                                           uint32_t *seg_minmax, float *workspace, int profile_slot, void *stream) {
     const char *what = "gq_hsq_encode_batched";
+    if (K < 4 || K > 256 || (K & 3)) return gq::fail(GQ_ERR_UNSUPPORTED, "%s: the prefilter launch takes K <= 256, a multiple of 4 (K = %d)", what, K);
 #define GQ_PF_BATCHED(DD, DP)                                                                                             \
     if (d == DD)                                                                                                          \
-        return ef ? gq::encode_batched<DP, true, DD>(what, seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, \
+        return ef ? gq::encode_batched<DP, true, DD>(what, seg_table, tile_seg, nseg, ntiles, codebook, K, wire, u_flat, seg_minmax, \
                                                      workspace, ef_scale, profile_slot, stream)                           \
-                  : gq::encode_batched<DP, false, DD>(what, seg_table, tile_seg, nseg, ntiles, codebook, wire, u_flat, seg_minmax, \
+                  : gq::encode_batched<DP, false, DD>(what, seg_table, tile_seg, nseg, ntiles, codebook, K, wire, u_flat, seg_minmax, \
                                                       workspace, 0.0f, profile_slot, stream);
     GQ_PF_BATCHED(16, 16)
     GQ_PF_BATCHED(32, 32)
@@ -1260,5 +1294,5 @@ GQ_INTERNAL int gqi_hsq_encode_batched_pf(const int64_t *seg_table, const int32_
     GQ_PF_BATCHED(12, 16)
     GQ_PF_BATCHED(24, 32)
 #undef GQ_PF_BATCHED
-    return gq::fail(GQ_ERR_UNSUPPORTED, "%s: d must be 8, 12, 16, 24 or 32 (K = 256)", what);
+    return gq::fail(GQ_ERR_UNSUPPORTED, "%s: d must be 8, 12, 16, 24 or 32 (K <= 256)", what);
 }

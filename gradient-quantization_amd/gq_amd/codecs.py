@@ -114,7 +114,7 @@ def aggregate_fma(args=None):
 
 def wire_levels_mode(args=None, world=1):
     """How byte-sized levels travel: "bytes" (one per level) or "packed6" (four 6-bit levels per three bytes, for the
-    configurations whose top level is <= 63 with d = 16, K = 256).  args.gq_wire_levels, else $GQ_WIRE_LEVELS, else
+    configurations whose top level is <= 63 with d = 16, K <= 256).  args.gq_wire_levels, else $GQ_WIRE_LEVELS, else
     "auto": packed6 when there is an exchange to shorten (more than one rank), bytes on a single rank -- the packed form is
     bit-identical in its result and costs < 1 % of a single-rank step."""
     mode = getattr(args, "gq_wire_levels", None) or os.environ.get("GQ_WIRE_LEVELS", "auto")
@@ -147,11 +147,11 @@ class HSQCodec(object):
 
     @staticmethod
     def can_pack6(compressor):
-        """The packed form is used for d = 16, K = 256 (what the multi-tensor level / decode kernels with packed levels are
+        """The packed form is used for d = 16, K <= 256 (what the multi-tensor level / decode kernels with packed levels are
         built for; the per-tensor entry points would take any K <= 256) when no level exceeds 63: n_bit <= 6 without
         stochastic rounding (probabilistic_scalar_compressor.py:18: levels up to 2^n_bit - 1), n_bit <= 5 with it (:25: up
         to 2^n_bit).  Every other configuration keeps one byte (or more) per level."""
-        if not compressor.compressed_norm or compressor.dim != 16 or compressor.K != 256:
+        if not compressor.compressed_norm or compressor.dim != 16 or compressor.K > 256:
             return False
         nc = compressor.norm_compressor
         return (1 << nc.n_bit) - (0 if nc.random else 1) <= 63
@@ -607,7 +607,7 @@ class BatchedHSQ(_BatchedBase):
     """All NearestNeighborCompressor tensors that share a codebook are encoded by ONE encode + ONE levels
     launch and decoded by ONE decode-mean launch (per-tensor lb / ub, identical results).  The reference
     walks the parameter list in Python (ps_quantizer.py:33,47); ResNet-50 has 76 such tensors.
-    The library decides which kernels serve the group's shape (include/gq_hsq.h, gq_hsq_batched_path): K = 256 with
+    The library decides which kernels serve the group's shape (include/gq_hsq.h, gq_hsq_batched_path): K <= 256 with
     d = 8 / 16 / 32 and byte-sized codes the prefilter encode and the specialised levels / decode kernels, larger
     codebooks of those dimensions the paged prefilter, every other shape exact scoring."""
 
@@ -662,8 +662,8 @@ class BatchedHSQ(_BatchedBase):
         self.code_dtype, self.level_dtype = cd0.code_dtype, cd0.level_dtype
         self.align = 16 if c0.dim % 4 == 0 else 4
         self.ws = native.new_workspace(device, self.ntiles * 64)
-        # ONE launch descriptor for the group (gq_hsq_batch): the library picks the kernels -- prefilter (K = 256,
-        # d = 8 / 16 / 32), the same with the pages of a larger codebook resident, or exact scoring for every other shape
+        # ONE launch descriptor for the group (gq_hsq_batch): the library picks the kernels -- prefilter (K <= 256,
+        # d = 8 / 12 / 16 / 24 / 32), the same with the pages of a larger codebook resident, or exact scoring for every other shape
         self._batch = native.HSQBatch(self._dev[:self._table_words], self.tile_seg, self.nseg, self.ntiles, self.codebook,
                                       self.code_dtype, cd0.wire_level_kind(), self.n_bit, self.u_flat,
                                       self._dev[self._table_words:self._dense_at].view(torch.int32), self.ws)

@@ -72,7 +72,7 @@ size_t gq_hsq_workspace_bytes(int64_t M);
  *     l[4g] | l[4g+1] << 6 | l[4g+2] << 12 | l[4g+3] << 18      at byte 3g of the section (3 * ceil(M / 4) bytes),
  * for configurations whose top level is <= 63 (n_bit <= 6 without stochastic rounding, <= 5 with).  A byte per level
  * spends 8 bits on 6: this form takes 12.5 % off the (codes, levels) payload of the BASELINE configuration.  Served
- * for d = 16 with byte codes: K <= 256 by the per-tensor entry points, K = 256 by the multi-tensor ones; the decode is
+ * for d = 16 with byte codes and K <= 256 (round 6: by the multi-tensor entry points too, which took K = 256 only); the decode is
  * the same arithmetic on the same integers (bit-identical).
  * The decode kernels fetch every group as ONE unaligned 32-bit word (three bytes of the group + the byte behind it), so a
  * packed section that is READ (gq_hsq_decode_sum, gq_hsq_decode_sum_strided, gq_hsq_batch_decode) must be followed by at
@@ -135,7 +135,9 @@ int gq_hsq_encode(const float *grad, const float *codebook, int64_t M, int d, in
  * identical for every impl):  0 = auto, 1 = exact f32 MFMA, d16/K256, register-resident
  * codebook, 2 = exact f32 MFMA generic (any d, K), 3 = VALU fmaf chain with the codebook in
  * LDS, 4 = f16 MFMA prefilter (one MFMA per chain and 16 dimensions) + exact f32 rescoring + second pass + exact scan
- * of what is left, for K = 256 and d in {8, 12, 16, 24, 32} (the default for those shapes; bit-identical output; K > 256 in
+ * of what is left, for d in {8, 12, 16, 24, 32} and K <= 256 in multiples of 4 (the default for those shapes; bit-identical output.
+ * Round 6: K <= 32 / <= 64 -- --k-bit 5 / 6 and K == dim, nearest_neighbor_compressor.py:40-47 -- score one / two row blocks
+ * of 32 codewords instead of eight; every other K below 256 runs the eight-block kernel over zero rows.  K > 256 in
  * pages of 256: round 3's bf16 x 3 scheme), 5 = exact f32 MFMA with the codebook (chunked when it does not fit) and the
  * subvector tiles staged in LDS, any d <= 128 and any K (the default for every other shape; 2 remains the fallback for
  * d > 128).  (6, round 3's bf16 x 3 prefilter for K = 256, was removed in round 6: GQ_ERR_INVALID_ARG.)
@@ -221,7 +223,8 @@ int gq_hsq_levels_decode(const float *u, int64_t M, int n_bit, int random_mode, 
  *              gq_hsq_batched_path() says GQ_BATCH_EXACT
  *
  * gq_hsq_batched_path(b): which kernels serve (d, K, code_bytes, level_bytes, nseg) --
- *   GQ_BATCH_PREFILTER  K = 256, d in {8, 16, 32}, byte codes: f16 prefilter + exact rescoring + second pass (any number of tensors);
+ *   GQ_BATCH_PREFILTER  K <= 256 (a multiple of 4; round 5: K = 256 only), d in {8, 16, 32}, byte codes: f16 prefilter + exact rescoring +
+ *                       second pass (any number of tensors); K <= 32 / <= 64 score one / two row blocks of 32 codewords;
  *                       round 6: d = 12 / 24 too (the reference's repaired dimensions, nearest_neighbor_compressor.py:23-29) as
  *                       rows of 12 / 24 floats through the d = 16 / 32 kernels; their level / decode launches are the generic ones
  *   GQ_BATCH_PAGED      d in {8, 16, 32}, K = 512, 768, ... 65536, int32 codes, <= 384 tensors: the prefilter with the
@@ -315,7 +318,7 @@ int gq_hsq_decode_sum_batched_tail(const gq_hsq_batch *b, const uint8_t *gathere
  * residual when write_error), out = (+0 + codebook[code] * norm) / 1 (plain: the decompress as it is), the uncompressed
  * tensors copied into the wire AND averaged (t->rows points at the wire's dense region, rows_R = 1), and -- by the last
  * workgroup to finish, told by t->ticket -- the step of the draws' words and the accumulators' reset.  A step of the
- * ResNet-50 list is then two kernels.  Served in one launch for K = 256, d in {8, 16, 32}, byte codes, byte or 16-bit levels;
+ * ResNet-50 list is then two kernels.  Served in one launch for K <= 256, d in {8, 16, 32}, byte codes, byte or 16-bit levels;
  * every other descriptor runs the two calls (same results). */
 int gq_hsq_levels_decode_batched(const gq_hsq_batch *b, uint8_t *wire, int random_mode, uint64_t seed, const float *r_flat,
                                  int write_error, float *out, int plain, const gq_step_tail *t, void *stream);

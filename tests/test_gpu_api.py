@@ -50,7 +50,7 @@ def _args_for(g, name):
     kw = dict(n_bit=int(g["n_bit"]), random=int(g["random"]), gq_rng="reference")
     if name.startswith("hsq"):
         kw["k_bit"] = int(np.log2(K))
-        kw["c_dim"] = {"hsq_d24_k64_repair_det": 16, "hsq_d24_k256_repair_det": 16, "hsq_d12_k256_repair_det": 8}.get(name, d)
+        kw["c_dim"] = {"hsq_d24_k64_repair_det": 16, "hsq_d24_k256_repair_det": 16, "hsq_d12_k256_repair_det": 8, "hsq_d12_k32_repair_rand": 8}.get(name, d)
     return make_args(**kw)
 
 
@@ -66,7 +66,7 @@ def test_nearest_neighbor_compressor_signature_and_values(name):
         # reference-parity RNG: the same CPU draw the fixture recorded
         seeds = {"hsq_randn_s1_rand": 4321, "hsq_randn_s1_n2_rand": 99, "hsq_randn_s1e-3_rand": 777,
                  "hsq_small_48_rand": 5, "hsq_zeros_rand": 1, "hsq_constant_u_rand": 2, "hsq_d8_k256_rand": 11,
-                 "hsq_d12_k256_rand": 61, "hsq_d24_k256_rand": 62}
+                 "hsq_d12_k256_rand": 61, "hsq_d24_k256_rand": 62, "hsq_d16_k64_rand": 71, "hsq_d12_k32_repair_rand": 72}
         torch.manual_seed(seeds[name])
     sig = comp.compress(x)
     norms, codes = sig
@@ -649,8 +649,11 @@ def _write_unit_codebook(root, d, K, seed):
 
 
 ANY_CASES = [dict(c_dim=32, k_bit=8, n_bit=9),     # prefilter encode, 16-bit levels
+             dict(c_dim=16, k_bit=6, n_bit=6),     # round 6: K = 64 / 32 on the prefilter encode (two / one row blocks) and the K <= 256 level / decode kernels
+             dict(c_dim=32, k_bit=6, n_bit=9),
+             dict(c_dim=16, k_bit=5, n_bit=5),
              dict(c_dim=12, k_bit=9, n_bit=6),     # K = 512: int32 codes
-             dict(c_dim=24, k_bit=6, n_bit=4),
+             dict(c_dim=24, k_bit=6, n_bit=4),     # (the repaired dimension 24 on the padded d = 32 kernel, two row blocks; levels / decode generic)
              dict(c_dim=8, k_bit=5, n_bit=8),
              dict(c_dim=10, k_bit=5, n_bit=6),     # d % 4 != 0: scalar loads / stores
              dict(c_dim=48, k_bit=11, n_bit=17),   # 384 KiB codebook (chunked in LDS), int32 codes and levels
@@ -676,7 +679,7 @@ def test_batched_quantizer_any_shape_equals_per_tensor_path(case, tmp_path, monk
     grp = qb._groups[0][2]
     assert grp.codebook.shape == (K, d) and len(qb.batch_idx) == sum(int(np.prod(s)) > 1000 for s in shapes) >= 5
     from gq_amd import native
-    want = (native.BATCH_PREFILTER if (K == 256 and d in (8, 16, 32)) else
+    want = (native.BATCH_PREFILTER if (K <= 256 and K % 4 == 0 and d in (8, 12, 16, 24, 32)) else
             native.BATCH_PAGED if (K > 256 and K % 256 == 0 and d in (8, 16, 32)) else native.BATCH_EXACT)
     assert grp._batch.path == want      # the library's choice of kernels for this shape (gq_hsq_batched_path)
     for a, b, s in zip(gb, gp, shapes):

@@ -89,8 +89,8 @@ def test_hsq_matches_reference_golden(nat, name, impl):
         pytest.skip("valu cross-check kernel not built for this shape")
     if impl == "mfma_exact_d16k256" and (d, K) != (16, 256):
         pytest.skip("d16/K256 specialisation")
-    if impl == "prefilter_d16k256" and not (K == 256 and d in (8, 12, 16, 24, 32)):
-        pytest.skip("the prefilter kernels are built for K = 256 and d in {8, 16, 32} (12 / 24, the repaired dimensions, as padded 16 / 32)")
+    if impl == "prefilter_d16k256" and not (K <= 256 and K % 4 == 0 and d in (8, 12, 16, 24, 32)):
+        pytest.skip("the prefilter kernels are built for K <= 256 (a multiple of 4) and d in {8, 16, 32} (12 / 24, the repaired dimensions, as padded 16 / 32)")
     cb = _cb(d, K)
     r = g["r"] if random else None
     res = gpu_compress(nat, g["x"], cb, n_bit, random, r, impl=IMPLS[impl])
@@ -683,6 +683,49 @@ def test_prefilter_fuzz_against_exact_kernels():
     assert "120 rounds, 0 mismatching" in r.stdout
 
 
+
+
+def test_prefilter_fuzz_smaller_codebooks_against_exact_kernel():
+    """tools/fuzz_prefilter.py ... smallk: K = 4 ... 256 in multiples of 4 (round 6: --k-bit 5 / 6 and K == dim on the kernels
+    that score one / two row blocks, any other K on the eight-block kernel over zero rows), the same adversarial inputs plus
+    infinities and NaN: codes on every subvector and projections equal the exact f32 MFMA kernel's bit for bit; no code >= K."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_prefilter.py")
+    r = subprocess.run([sys.executable, tool, "200", "11", "smallk"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "200 rounds, 0 mismatching" in r.stdout
+
+
+@pytest.mark.parametrize("d,K", [(16, 64), (16, 32), (16, 16), (8, 8), (32, 32), (32, 64), (24, 64), (12, 32), (8, 64), (16, 4), (16, 132)])
+def test_prefilter_smaller_codebooks_match_oracle_at_full_size(nat, oracle, d, K):
+    """25 M elements through the prefilter kernels with fewer than 256 codewords (one / two / eight row blocks) against the CPU
+    oracle on a sample of tiles and against the exact kernel everywhere."""
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(100 + d + K)
+    cbn = rng.standard_normal((K, d)).astype(np.float32)
+    cbn /= np.linalg.norm(cbn, axis=1, keepdims=True)
+    M = 25_000_000 // d
+    torch.manual_seed(77 + K)
+    g = torch.randn(M * d, device=dev) * 1e-3
+    g[5 * d:6 * d] = 0.0
+    cb = torch.from_numpy(cbn).to(dev)
+    outs = {}
+    for impl in (4, 5):
+        codes = torch.empty(M, dtype=torch.uint8, device=dev)
+        u = torch.empty(M, dtype=torch.float32, device=dev)
+        ws = nat.new_workspace(dev, M)
+        nat.hsq_encode(g, cb, codes, u, ws, impl=impl)
+        torch.cuda.synchronize()
+        outs[impl] = (codes, u)
+    assert torch.equal(outs[4][0], outs[5][0]) and torch.equal(outs[4][1].view(torch.int32), outs[5][1].view(torch.int32))
+    assert int(outs[4][0].max()) < K
+    n = 4096 * d
+    for start in (0, (M // 2) * d, M * d - n):
+        ref_codes, ref_u = oracle.hsq_encode(g[start:start + n].cpu().numpy(), cbn)
+        m0 = start // d
+        assert np.array_equal(outs[4][0][m0:m0 + 4096].cpu().numpy().astype(np.int32), ref_codes)
+        assert np.array_equal(_bits(outs[4][1][m0:m0 + 4096].cpu().numpy()), _bits(ref_u))
 
 
 def test_compress_and_decode_replay_from_a_hip_graph(nat):

@@ -207,6 +207,8 @@ def _psq_args(name, users):
         kw.update(c_dim=64, n_bit=8)
     if "_k5" in name:
         kw.update(k_bit=5)
+    if "_k6" in name:
+        kw.update(k_bit=6)
     if "terngrad" in name:
         kw.update(c_dim=0, n_bit=1)
     if "_d32" in name:
@@ -654,7 +656,10 @@ def test_batch_descriptor_is_validated_before_anything_is_launched():
     path = lambda **kw: L.gq_hsq_batched_path(ctypes.byref(desc(**kw)))
     assert path() == native.BATCH_PREFILTER and path(d=8) == native.BATCH_PREFILTER and path(d=32, nseg=384) == native.BATCH_PREFILTER
     assert path(K=1024, code_bytes=4) == native.BATCH_PAGED and path(d=32, K=4096, code_bytes=4) == native.BATCH_PAGED
-    assert path(d=12, K=512, code_bytes=4) == native.BATCH_EXACT and path(d=24, K=64) == native.BATCH_EXACT
+    assert path(d=12, K=512, code_bytes=4) == native.BATCH_EXACT and path(d=20, K=64) == native.BATCH_EXACT
+    # (round 6: K <= 256 in multiples of 4 on the prefilter launch -- --k-bit 5 / 6, K == dim; other K on the exact kernels)
+    assert path(d=24, K=64) == native.BATCH_PREFILTER and path(K=32) == native.BATCH_PREFILTER and path(d=8, K=8) == native.BATCH_PREFILTER
+    assert path(K=30) == native.BATCH_EXACT and path(K=2) == native.BATCH_EXACT
     assert path(d=32, nseg=385) == native.BATCH_PREFILTER        # (round 5: beyond 384 tensors the records are read from global memory, d = 8 / 32 too)
     assert path(K=1024, code_bytes=4, nseg=500) == native.BATCH_EXACT
     assert path(d=600, K=256) == 0 and b"no multi-tensor kernel" in L.gq_last_error()

@@ -169,7 +169,7 @@ def _dim_for(size, c_dim):
 
 # an independent replay for the README configuration (HSQ d16 K256 n6); the other shapes and compressors run through the real
 # quantizer classes in tests/test_host_logic.py
-@pytest.mark.parametrize("name", [n for n in PSQ_CASES if not any(t in n for t in ("qsgd", "terngrad", "_d32", "_d8", "_d12", "_n32", "_k5", "_sgd"))])
+@pytest.mark.parametrize("name", [n for n in PSQ_CASES if not any(t in n for t in ("qsgd", "terngrad", "_d32", "_d8", "_d12", "_n32", "_k5", "_k6", "_sgd"))])
 def test_psquantizer_matches_reference(oracle, name):
     """Replays PSQuantizer.record/apply (quantizers/ps_quantizer.py:27-65) with the
     oracle primitives and compares with what the reference produced."""

@@ -11,6 +11,8 @@ from gq_amd.compressors import NearestNeighborCompressor
 from gq_amd.quantizers import Quantizer
 shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "resnet50_cifar_shapes.json")))["parameter_shapes"]
 dev = torch.device("cuda:0")
+D_, KB_ = int(os.environ.get("GQ_AB_D", "16")), int(os.environ.get("GQ_AB_KBIT", "8"))     # other shapes: GQ_AB_D=8 GQ_AB_KBIT=5 ...
+os.environ.setdefault("GQ_CODEBOOK_DIR", os.path.join(ROOT, "tests", "golden", "codebooks"))
 
 
 def ev(fn, reps=200, warm=50):
@@ -24,7 +26,7 @@ def ev(fn, reps=200, warm=50):
 
 
 def one_list(shapes, label):
-    args = Namespace(c_dim=16, k_bit=8, n_bit=6, no_cuda=False, random=0, ef=False, two_phase=False, scale="exp", num_users=1, mode="ps", cr=256, gq_graph=False)
+    args = Namespace(c_dim=D_, k_bit=KB_, n_bit=6, no_cuda=False, random=0, ef=False, two_phase=False, scale="exp", num_users=1, mode="ps", cr=256, gq_graph=False)
     params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
     with contextlib.redirect_stdout(sys.stderr):
         q = Quantizer(NearestNeighborCompressor, params, args)
@@ -45,7 +47,7 @@ one_list([(11796480,), (11796480,)], "two equal tensors")
 one_list([(310272,)] * 76, "76 equal tensors")
 one_list(sorted(big, key=lambda s: -torch.Size(s).numel()), "the ResNet-50 list, largest first")
 one_list([s for s in big if torch.Size(s).numel() >= 65536], "the ResNet-50 list without tensors < 64 K")
-args = Namespace(c_dim=16, k_bit=8, n_bit=6, no_cuda=False, random=0, ef=False, two_phase=False, scale="exp", num_users=1, mode="ps", cr=256, gq_graph=False)
+args = Namespace(c_dim=D_, k_bit=KB_, n_bit=6, no_cuda=False, random=0, ef=False, two_phase=False, scale="exp", num_users=1, mode="ps", cr=256, gq_graph=False)
 params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
 with contextlib.redirect_stdout(sys.stderr):
     q = Quantizer(NearestNeighborCompressor, params, args)
@@ -65,7 +67,7 @@ grp.encode(gl, q._wire[0], 0, 0)
 t_enc = ev(lambda: grp._batch.encode(q._wire[0], None, -1))
 t_lv = ev(lambda: grp._batch.levels(q._wire[0], native.RANDOM_OFF, 0, None))
 flat = torch.cat([g.reshape(-1) for g in gl])
-M = flat.numel() // 16
+M = flat.numel() // D_
 codes, u, ws = torch.empty(M, dtype=torch.uint8, device=dev), torch.empty(M, dtype=torch.float32, device=dev), native.new_workspace(dev, M)
 cb = grp.codebook
 t_flat = ev(lambda: native.hsq_encode(flat, cb, codes, u, ws))

@@ -60,7 +60,9 @@ run("HSQ c-dim 8 batched", NearestNeighborCompressor, c_dim=8)
 os.environ.setdefault("GQ_CODEBOOK_DIR", os.path.join(ROOT, "tests", "golden", "codebooks"))
 run("HSQ main.py defaults (d32 n8 random) batched", NearestNeighborCompressor, c_dim=32, n_bit=8)
 run("HSQ main.py defaults per-tensor launches", NearestNeighborCompressor, c_dim=32, n_bit=8, gq_no_batch=True)
-run("HSQ d8 K32 batched (exact kernels)", NearestNeighborCompressor, c_dim=8, k_bit=5)
+run("HSQ d8 K32 batched (one row block)", NearestNeighborCompressor, c_dim=8, k_bit=5)
+run("HSQ d16 K64 batched (two row blocks)", NearestNeighborCompressor, c_dim=16, k_bit=6)
+run("HSQ d16 K32 batched (one row block)", NearestNeighborCompressor, c_dim=16, k_bit=5)
 run("HSQ d8 K32 per-tensor launches", NearestNeighborCompressor, c_dim=8, k_bit=5, gq_no_batch=True)
 run("HSQ d8 K32 batched, EF + two-phase", NearestNeighborCompressor, c_dim=8, k_bit=5, ef=True, two_phase=True)
 run("TernGrad (qsgd c-dim 0 n-bit 1) batched", QSGDCompressor, c_dim=0, n_bit=1)

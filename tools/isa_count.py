@@ -91,7 +91,7 @@ def classify(op, line):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--file", default=os.path.join(PKG, "csrc", "hsq_encode_pf.hip"))
-    ap.add_argument("--kernel", default="hsq_encode_pf_kernelIhLi16ELb0ELb0ELb1ELi16EE")
+    ap.add_argument("--kernel", default="hsq_encode_pf_kernelIhLi16ELb0ELb0ELb1ELi16ELi8EE")
     ap.add_argument("--list", action="store_true", help="print the per-mnemonic table too")
     ap.add_argument("--extra", default="", help="extra compiler flags, e.g. -DPF_GROUP8=1")
     ap.add_argument("--asm", default=None, help="an existing .s instead of compiling")

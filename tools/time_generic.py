@@ -8,7 +8,7 @@ from gq_amd import native
 dev = torch.device("cuda:0")
 torch.manual_seed(1234)
 N = 25_000_000
-cases = [(8, 256), (16, 256), (32, 256), (12, 512), (16, 1024), (16, 4096), (32, 4096), (128, 256)]
+cases = [(8, 256), (16, 256), (32, 256), (16, 64), (16, 32), (16, 16), (8, 32), (32, 64), (32, 32), (24, 64), (12, 512), (16, 1024), (16, 4096), (32, 4096), (128, 256)]
 if len(sys.argv) > 1:
     cases = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
 for d, K in cases:
