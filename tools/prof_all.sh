@@ -22,6 +22,9 @@ python bench.py --workload resnet50 --ef --traffic off > $O/bench_resnet50_ef.js
 python bench.py --workload resnet50 --ef --two-phase --traffic off > $O/bench_resnet50_ef_twophase.json 2> /dev/null
 python bench.py --workload resnet50 --c-dim 32 --n-bit 8 --traffic off > $O/bench_resnet50_main_defaults.json 2> /dev/null
 python bench.py --workload resnet50 --c-dim 8 --traffic off > $O/bench_resnet50_d8.json 2> /dev/null
+python bench.py --workload resnet50 --k-bit 6 --traffic off > $O/bench_resnet50_k6.json 2> /dev/null
+python bench.py --workload resnet50 --k-bit 5 --traffic off > $O/bench_resnet50_k5.json 2> /dev/null
+python bench.py --workload resnet50 --c-dim 8 --k-bit 5 --traffic off > $O/bench_resnet50_d8_k5.json 2> /dev/null
 python bench.py --workload resnet50 --no-graph --traffic off > $O/bench_resnet50_eager.json 2> /dev/null
 python bench.py --workload qsgd --no-graph --traffic off > $O/bench_qsgd_eager.json 2> /dev/null
 python bench.py --wire-levels packed6 --no-cpu-baseline --traffic off > $O/bench_packed6.json 2> /dev/null
@@ -35,7 +38,7 @@ GQ_LIB_PATH=gradient-quantization_amd/libgq_hsq_clock.so python tools/stamp_read
 python tools/decode_r.py 1 2 4 8 16 > $O/decode_r.txt 2>&1
 python tools/hsq_batched_r.py > $O/hsq_batched_r.txt 2>&1
 python tools/time_generic.py > $O/time_generic.txt 2>&1
-python tools/time_pf_d.py 32 8 16 >> $O/time_generic.txt 2>&1
+python tools/time_pf_d.py 32 8 16 12 24 >> $O/time_generic.txt 2>&1
 python tools/pvq_time.py > $O/pvq_time.txt 2>&1
 python tools/qsgd_r.py > $O/qsgd_r.txt 2>&1
 python tools/bench_resnet50.py 2>&1 | grep -v 'alternate dimension' > $O/resnet50_steps.txt
@@ -45,6 +48,12 @@ python tools/config_sweep.py > $O/config_sweep.txt 2>/dev/null
 python tools/cpu_scaling.py > $O/cpu_scaling.txt 2>&1
 python tools/graph_pieces.py > $O/graph_pieces.txt 2>&1
 python tools/batched_vs_flat.py > $O/batched_vs_flat.txt 2>&1
+(for kb in 6 5; do echo "== k_bit $kb"; GQ_AB_KBIT=$kb python tools/batched_vs_flat.py 2>/dev/null | tail -1; done) >> $O/batched_vs_flat.txt
+python tools/step_host_vs_device.py 2>/dev/null > $O/step_host_vs_device.txt
+GQ_DIRECT_REPLAY=0 python tools/step_host_vs_device.py 2>/dev/null > $O/step_host_vs_device_graphlaunch.txt
+python tools/direct_vs_graph.py 2>/dev/null > $O/direct_vs_graph.txt
+python tools/cold_vs_warm.py 2>/dev/null > $O/cold_vs_warm.txt
+GQ_LIB_PATH=$PWD/gradient-quantization_amd/libgq_hsq_clock.so python tools/cold_vs_warm.py 2>/dev/null >> $O/cold_vs_warm.txt
 GQ_FUSE_STEP=0 python bench.py --workload resnet50 --no-workloads --traffic off > $O/bench_resnet50_two_graphs.json 2> /dev/null
 GQ_AGGREGATE=fma GQ_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_2ranks_gloo_fma.json 2> /dev/null
 ls $O
