@@ -72,6 +72,25 @@ static py::tuple scan_key(const py::list &parameters) {
     return py::make_tuple(py::bytes(key), ok, dev.is_cuda() ? (int)dev.index() : -1);
 }
 
+// `o.data = v` for one tensor.  at::Tensor::set_data re-derives everything a tensor carries from v (sizes, strides, key set, the
+// autograd meta's accumulator, ...): ~0.12 us, and a quantizer step does it 161 times in apply() (and the caller's backward, or
+// bench.py's feeder, as many times again) -- the largest single item of a replayed step's host time.  When v has the layout o
+// already has (same sizes, strides, dtype, device, offset 0 on both or not: what `.data =` would copy anyway), the ONLY thing
+// that changes is which storage the tensor looks at: swap that and leave the rest.  Anything else (another shape, a tensor whose
+// metadata may not change -- the result of .detach() --, a subclass, sparse / quantized layouts) takes set_data itself.
+static inline void rebind(const at::Tensor &o, const at::Tensor &v) {
+    c10::TensorImpl *oi = o.unsafeGetTensorImpl(), *vi = v.unsafeGetTensorImpl();
+    if (oi != vi && oi->allow_tensor_metadata_change() && oi->key_set() == vi->key_set() && oi->dtype() == vi->dtype() &&
+        oi->layout() == c10::kStrided && vi->layout() == c10::kStrided && oi->has_storage() && vi->has_storage() &&
+        oi->device() == vi->device() && oi->sizes().equals(vi->sizes()) && oi->strides().equals(vi->strides()) &&
+        !oi->is_python_dispatch() && !vi->is_python_dispatch() && !oi->has_named_tensor_meta() && !vi->has_named_tensor_meta()) {
+        oi->set_storage_keep_dtype(vi->storage());
+        oi->set_storage_offset(vi->storage_offset());
+        return;
+    }
+    o.set_data(v);
+}
+
 // set_data(objects, values): objects[i].data = values[i]  (ps_quantizer.py:63 for every parameter)
 static void set_data(const py::list &objects, const py::list &values) {
     const size_t n = objects.size();
@@ -81,7 +100,7 @@ static void set_data(const py::list &objects, const py::list &values) {
             throw py::type_error("set_data: the lists hold something that is not a tensor");
         const at::Tensor &o = THPVariable_Unpack(objects[i].ptr());
         const at::Tensor &v = THPVariable_Unpack(values[i].ptr());
-        o.set_data(v);
+        rebind(o, v);
     }
 }
 
@@ -98,7 +117,7 @@ static void set_grad_data(const py::list &parameters, const py::list &values) {
         const at::Tensor &p = THPVariable_Unpack(parameters[i].ptr());
         const at::Tensor &g = p.grad();
         if (!g.defined()) throw py::attribute_error("'NoneType' object has no attribute 'data' (parameter " + std::to_string(i) + " has no .grad)");
-        g.set_data(THPVariable_Unpack(values[i].ptr()));
+        rebind(g, THPVariable_Unpack(values[i].ptr()));
     }
 }
 

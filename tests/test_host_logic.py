@@ -758,6 +758,43 @@ def test_host_helper_walks_match_the_python_walks():
     assert not H.scan_grads(params)[2]
 
 
+def test_host_helper_rebinding_equals_the_data_setter():
+    """set_data / set_grad_data swap the storage under a tensor whose layout the value already has (round 6: at::Tensor::set_data
+    re-derives everything, ~0.12 us x 161 x 2 per step -- the largest item of a replayed step's host time) and take
+    at::Tensor::set_data for everything else: in both cases the tensor afterwards is what `o.data = v` (ps_quantizer.py:63) makes it."""
+    sys.path.insert(0, os.path.join(ROOT, "gradient-quantization_amd"))
+    from gq_amd import _gq_host as H
+
+    def both(make_o, make_v):
+        o1, o2, v = make_o(), make_o(), make_v()
+        H.set_data([o1], [v])
+        o2.data = v
+        assert o1.shape == o2.shape and o1.stride() == o2.stride() and o1.dtype == o2.dtype and o1.data_ptr() == o2.data_ptr() == v.data_ptr()
+        assert o1.storage_offset() == o2.storage_offset() and o1._version == o2._version and o1.requires_grad == o2.requires_grad
+        assert torch.equal(o1, o2) and o1.is_contiguous() == o2.is_contiguous()
+        return o1
+    base = torch.arange(24.0)
+    both(lambda: torch.zeros(3, 4), lambda: torch.randn(3, 4))                       # the fast path: same layout
+    both(lambda: torch.zeros(4), lambda: base[5:9])                                 # ... a view with an offset
+    both(lambda: torch.zeros(3, 4), lambda: torch.randn(6, 2))                       # another shape
+    both(lambda: torch.zeros(2, 3), lambda: torch.arange(6.0).reshape(3, 2).t())     # other strides
+    both(lambda: torch.zeros(4).detach(), lambda: torch.ones(4))                     # metadata may not change: the setter's own way
+    both(lambda: torch.zeros(4), lambda: torch.ones(4, dtype=torch.float64))         # another dtype
+    both(lambda: torch.zeros(0), lambda: torch.zeros(0))
+    o = torch.zeros(5)
+    H.set_data([o], [o])                                                             # the same tensor: nothing to do
+    assert o.tolist() == [0.0] * 5
+    # a gradient keeps being THE object the parameter holds, version counter and all
+    p = torch.nn.Parameter(torch.zeros(3, 4))
+    p.grad = torch.zeros(3, 4)
+    g, ver = p.grad, p.grad._version
+    v = torch.full((3, 4), 2.0)
+    H.set_grad_data([p], [v])
+    assert p.grad is g and g._version == ver and g.data_ptr() == v.data_ptr() and float(g.sum()) == 24.0
+    g.add_(1.0)                                                                      # (writes through to v's storage, as after `.data =`)
+    assert float(v.sum()) == 36.0
+
+
 def test_quantizer_results_do_not_depend_on_the_host_helper(oracle, monkeypatch):
     """GQ_HOST_EXT=0 (the Python walks of the parameter list) and the C++ helper: the same gradients after apply()."""
     sys.path.insert(0, HERE)
