@@ -1854,6 +1854,113 @@ def test_whole_step_replayed_as_one_graph_equals_the_eager_launches(kw, monkeypa
             assert torch.equal(pf.error[0], pe.error[0])
 
 
+def test_launch_plan_replays_a_chain_of_kernels_and_refuses_other_graphs():
+    """gq_launch_plan_*: the kernel nodes of a captured graph issued as plain launches give what the graph's own replay gives; a
+    graph that is not ONE chain of kernel launches (a copy node, two branches, no node) is refused with an error text and no plan."""
+    from gq_amd import native
+    dev = torch.device("cuda:0")
+    x = torch.zeros(4096, device=dev)
+    y, z = torch.empty_like(x), torch.empty_like(x)
+    torch.cuda.synchronize()
+
+    def chain():
+        torch.add(x, 1.0, out=y)
+        torch.mul(y, 2.0, out=z)
+    chain()                                     # (first calls outside a capture)
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g):
+        chain()
+    plan = native.LaunchPlan(g)
+    assert plan.nodes == 2
+    for v in (3.0, -1.5):
+        x.fill_(v)
+        z.zero_()
+        plan.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(z, (x + 1.0) * 2.0)
+    g.instantiate()
+    x.fill_(7.0)
+    g.replay()                                  # the graph itself still replays next to its plan
+    torch.cuda.synchronize()
+    assert float(z[0]) == 16.0
+    # a copy node in the chain
+    g2 = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g2):
+        torch.add(x, 1.0, out=y)
+        z.copy_(y)
+    with pytest.raises(native.GQNativeError) as e:
+        native.LaunchPlan(g2)
+    assert "gq_launch_plan_create" in str(e.value)
+    # two branches
+    side = torch.cuda.Stream()
+    g3 = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g3):
+        torch.add(x, 1.0, out=y)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            torch.mul(x, 2.0, out=z)
+        torch.add(y, 1.0, out=y)
+        torch.cuda.current_stream().wait_stream(side)
+    with pytest.raises(native.GQNativeError) as e:
+        native.LaunchPlan(g3)
+    assert "chain" in str(e.value) or "dependents" in str(e.value) or "root" in str(e.value)
+    L = native.lib()
+    import ctypes
+    pl = ctypes.c_void_p(0)
+    assert L.gq_launch_plan_create(None, ctypes.byref(pl), None) != 0 and b"null pointer" in L.gq_last_error()
+    assert L.gq_launch_plan_run(None, None) != 0 and b"null plan" in L.gq_last_error()
+    L.gq_launch_plan_destroy(None)              # (a no-op)
+
+
+@pytest.mark.parametrize("kw", [dict(random=1), dict(random=1, ef=True, two_phase=True, scale="0.5"), dict(qsgd=True, c_dim=128, n_bit=2, random=1)])
+def test_direct_replay_of_captured_steps_equals_the_graphs_own_replay(kw, monkeypatch):
+    """$GQ_DIRECT_REPLAY (default 1): a captured record / apply / whole step is replayed as plain launches of its kernel nodes
+    (native.LaunchPlan); 0 keeps the graph's own replay.  Twelve steps on two alternating sets of gradient addresses: the same
+    aggregates, wire and residuals bit for bit, and the replayed objects are what the switch says."""
+    from gq_amd import native
+    from gq_amd.compressors import NearestNeighborCompressor, QSGDCompressor
+    from gq_amd.quantizers import Quantizer
+    kw = dict(kw)
+    Comp = QSGDCompressor if kw.pop("qsgd", False) else NearestNeighborCompressor
+    shapes = RESNET50_COMPRESSED[:8] + RESNET50_SMALL[:3]
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    store = [[torch.randn(s, device=dev) * 1e-2 for s in shapes] for _ in range(2)]
+    order = [0, 1] * 6
+    fills = [[torch.randn(s, device=dev) * 1e-2 for s in shapes] for _ in order]
+
+    def run(direct):
+        from gq_amd import compressors
+        compressors._seed_counter[0] = 0
+        monkeypatch.setenv("GQ_DIRECT_REPLAY", direct)
+        params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
+        q = Quantizer(Comp, params, make_args(num_users=1, gq_graph=True, **kw))
+        outs = []
+        for step, k in enumerate(order):
+            for t, f in zip(store[k], fills[step]):
+                t.copy_(f)
+            for p, t in zip(params, store[k]):
+                p.grad = t.view(t.shape)
+            q.record(0, epoch=1)
+            q.apply()
+            outs.append([p.grad.data.clone() for p in params])
+        replayed = [e[1] for cache in (q._rec_graphs, q._apply_graphs, q._step_graphs) for e in cache.values() if e[1] is not None]
+        return q, outs, replayed
+
+    qd, od, rd = run("1")
+    qg, og, rg = run("0")
+    assert rd and all(isinstance(r, native.LaunchPlan) for r in rd), [type(r) for r in rd]
+    assert rg and not any(isinstance(r, native.LaunchPlan) for r in rg)
+    assert qd.graph_counts() == qg.graph_counts()
+    for a, b in zip(od, og):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    assert torch.equal(qd._wire, qg._wire)
+    if kw.get("ef"):
+        for pd, pg in zip(qd.parameters, qg.parameters):
+            assert torch.equal(pd.error[0], pg.error[0]) and torch.equal(pd.server_error, pg.server_error)
+
+
 @pytest.mark.parametrize("users", [2, 4, 3])
 def test_quantizer_fma_aggregate_is_opt_in_and_within_tolerance(users, monkeypatch):
     """$GQ_AGGREGATE=fma / args.gq_aggregate: the multi-tensor decode-mean accumulates with fused multiply-adds for R >= 2
