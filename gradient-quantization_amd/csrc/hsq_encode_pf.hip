@@ -991,6 +991,12 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         }
 
         GQ_STAMP(3)
+        // The draw of the tile after next, in two steps with work between them (round 6, block M): the look at the counter here, the
+        // add behind the conversion, the result read at the end of the tile.  As one call at the end (draw()) the wave waited out
+        // two dependent LDS round trips per tile there: -0.6 % (profiles/r06_encode_ab.txt).  The look may be ~1,000 cycles old
+        // when the add is decided: the PF_TAIL rule it serves is a heuristic.
+        int dk_seen = 0x3FFFFFFF;
+        if (lane == 0) dk_seen = __hip_atomic_load(&s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // Consume the prefetched tile (convert it to the next B fragments) BEFORE this tile's
         // stores are issued: the wait for the prefetch then sees only long-finished memory ops.
         // Done the other way round, the compiler's vmcnt wait at the first use of `nxt` sits right
@@ -1011,6 +1017,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         __builtin_amdgcn_sched_barrier(0);
 
         GQ_STAMP(4)
+        int dk_next = 0x3FFFFFFF;
+        if (lane == 0 && dk_seen < tail_from) dk_next = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // ---- the few subvectors the bound could not settle (header, 4): into this wave's ring, which goes through the
         // second pass when 32 are waiting and when the wave has run out of tiles.  A flagged lane writes its D floats and
         // where the answer goes.
@@ -1053,7 +1061,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void hsq_encode_pf_kernel(const PfAr
         }
         ti = tin;
         t = tn;
-        tn = draw();
+        tn = lo_tile + __builtin_amdgcn_readfirstlane(dk_next);
         sigma_t = sigma_n;
         GQ_STAMP(5)
         GQ_STAMPS_ONLY(++ntl;)

@@ -68,6 +68,37 @@ def _dist_world(process_group):
     return 1, 0
 
 
+class _capturing(object):
+    """`with _capturing(graph): ...` = torch.cuda.graph(graph, capture_error_mode="thread_local") with the cyclic garbage collector
+    held off for the duration.  torch.cuda.graph collects once BEFORE a capture begins because freeing device objects inside one is
+    not allowed; a collection that the interpreter starts by itself in the middle of the capture (an allocation count crossing its
+    threshold) can still finalize an older quantizer's graphs, plans and private memory pools there -- round 6 saw the process abort
+    in exactly that spot.  (thread_local: other threads -- RCCL's watchdog -- may call into HIP meanwhile.)"""
+
+    def __init__(self, graph):
+        self._ctx = torch.cuda.graph(graph, capture_error_mode="thread_local")
+        self._gc = False
+
+    def __enter__(self):
+        import gc
+        self._gc = gc.isenabled()
+        gc.disable()
+        try:
+            return self._ctx.__enter__()
+        except BaseException:
+            if self._gc:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self._ctx.__exit__(*exc)
+        finally:
+            if self._gc:
+                gc.enable()
+
+
 class PSQuantizer(object):
     def __init__(self, Compressor, parameters, args, process_group=None, codec_factory=None):
         self.parameters = list(parameters)
@@ -691,7 +722,7 @@ class PSQuantizer(object):
             # cost 15 us of every replayed step, tools/graph_pieces.py; the 5 KB header per captured graph is nothing)
             headers = None if generic else [g[2]._host[g[2]._last_slot].to(dev) for g in self._groups]
             graph = self._new_graph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (other threads -- RCCL's watchdog -- may call into HIP meanwhile)
+            with _capturing(graph):
                 self._record_launches(all_grads, wire, slot, user, salt, scale, None, dev, headers=headers, table_current=generic)
             graph = self._replayable(graph)
         except Exception as e:      # a capture that fails leaves the eager path as it was (this record has already run eagerly)
@@ -708,7 +739,7 @@ class PSQuantizer(object):
         after = ([g[2]._out_turn for g in self._groups], self._dense_turn)
         try:
             graph = self._new_graph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            with _capturing(graph):
                 resets = []      # the groups' accumulator resets ride in the step's last launch
                 fuse = self._can_fuse_levels()      # one rank, one user: level launch + decode of that payload as ONE launch
                 overlap = None
@@ -1034,7 +1065,7 @@ class PSQuantizer(object):
                         hdrs2 = [g[2]._host[g[2]._last_slot].to(gathered.device) for g in self._groups] if self.two_phase else None
                         calls = self._phase2_calls
                         graph = self._new_graph()
-                        with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (other threads -- RCCL's watchdog -- may call into HIP meanwhile)
+                        with _capturing(graph):
                             again = self._decode_all(gathered, self.two_phase, (), phase2_headers=hdrs2)
                         assert self._phase2_calls == calls, "a captured second phase must not take per-call seeds"
                         if len(again) == len(decoded) and all(a is b for a, b in zip(again, decoded)):

@@ -1961,6 +1961,65 @@ def test_direct_replay_of_captured_steps_equals_the_graphs_own_replay(kw, monkey
             assert torch.equal(pd.error[0], pg.error[0]) and torch.equal(pd.server_error, pg.server_error)
 
 
+def test_garbage_collection_is_held_off_during_a_capture():
+    """torch's CUDAGraph destructor raises inside a stream capture and the process aborts (at::cuda::CUDAGraph::~CUDAGraph ->
+    c10_hip_check; seen once in round 6 when the interpreter's own collection, started by an allocation count in the middle of
+    gq_hsq_levels_decode_batched's capture, finalized an older quantizer's graphs; torch.cuda.graph no longer collects before a
+    capture by itself).  The quantizer's captures run with the collector held off (quantizers._capturing).  In a child process: a
+    quantizer with captured graphs becomes cyclic garbage, and while a second one captures, a call inside the capture does what
+    an automatic collection would do there -- collect if the collector is enabled.  It is not: the process survives, the garbage
+    is collected afterwards, and the collector is back on after every capture."""
+    import subprocess
+    import sys
+    code = r"""
+import gc, os, sys, weakref
+sys.path.insert(0, os.path.join(%r, "gradient-quantization_amd"))
+import torch
+from argparse import Namespace
+from gq_amd import native
+from gq_amd.compressors import NearestNeighborCompressor
+from gq_amd.quantizers import Quantizer
+dev = torch.device("cuda:0")
+shapes = [(64, 64, 3, 3), (256, 64), (512, 128), (64,), (10,)]
+store = [[torch.randn(s, device=dev) * 1e-2 for s in shapes] for _ in range(2)]
+def run(steps):
+    params = [torch.nn.Parameter(torch.zeros(*s, device=dev)) for s in shapes]
+    q = Quantizer(NearestNeighborCompressor, params, Namespace(c_dim=16, k_bit=8, n_bit=6, no_cuda=False, random=1, ef=False, two_phase=False,
+                                                               scale="exp", num_users=1, mode="ps", cr=256, gq_graph=True))
+    for st in range(steps):
+        for p, t in zip(params, store[st %% 2]):
+            p.grad = t.view(t.shape)
+        q.record(0, epoch=1)
+        q.apply()
+    torch.cuda.synchronize()
+    return q
+gc.set_threshold(10 ** 9)        # no collection by itself: the hook below decides
+old = run(8)
+assert old.graph_counts()["whole_step"] >= 1
+alive = weakref.ref(old)
+old.myself = old                 # a cycle: only the collector frees it
+del old
+assert alive() is not None
+seen = []
+inner = native.HSQBatch.levels_decode
+def hooked(self, *a, **kw):
+    if torch.cuda.is_current_stream_capturing():
+        seen.append(gc.isenabled())
+        if gc.isenabled():       # what an automatic collection at this point would do
+            gc.collect()
+    return inner(self, *a, **kw)
+native.HSQBatch.levels_decode = hooked
+new = run(8)
+assert new.graph_counts()["whole_step"] >= 1 and seen and not any(seen), seen
+assert gc.isenabled() and alive() is not None
+gc.collect()
+assert alive() is None
+print("ok")
+""" % (os.path.dirname(HERE),)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("users", [2, 4, 3])
 def test_quantizer_fma_aggregate_is_opt_in_and_within_tolerance(users, monkeypatch):
     """$GQ_AGGREGATE=fma / args.gq_aggregate: the multi-tensor decode-mean accumulates with fused multiply-adds for R >= 2
