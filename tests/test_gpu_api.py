@@ -1,5 +1,6 @@
 """GPU tests of the reference-shaped Python API (Compressor / Quantizer classes) running on
 the HIP kernels: signatures and results against the golden vectors captured from the reference."""
+import contextlib
 import glob
 import os
 import sys
@@ -10,6 +11,22 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def _capture(graph):
+    """torch.cuda.graph(graph) with the garbage collector held off: a CUDAGraph of an earlier test that the collector finalizes
+    INSIDE a capture raises in its destructor and takes the process down (see gq_amd.quantizers._capturing)."""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden")
@@ -1868,7 +1885,7 @@ def test_launch_plan_replays_a_chain_of_kernels_and_refuses_other_graphs():
         torch.mul(y, 2.0, out=z)
     chain()                                     # (first calls outside a capture)
     g = torch.cuda.CUDAGraph(keep_graph=True)
-    with torch.cuda.graph(g):
+    with _capture(g):
         chain()
     plan = native.LaunchPlan(g)
     assert plan.nodes == 2
@@ -1885,7 +1902,7 @@ def test_launch_plan_replays_a_chain_of_kernels_and_refuses_other_graphs():
     assert float(z[0]) == 16.0
     # a copy node in the chain
     g2 = torch.cuda.CUDAGraph(keep_graph=True)
-    with torch.cuda.graph(g2):
+    with _capture(g2):
         torch.add(x, 1.0, out=y)
         z.copy_(y)
     with pytest.raises(native.GQNativeError) as e:
@@ -1894,7 +1911,7 @@ def test_launch_plan_replays_a_chain_of_kernels_and_refuses_other_graphs():
     # two branches
     side = torch.cuda.Stream()
     g3 = torch.cuda.CUDAGraph(keep_graph=True)
-    with torch.cuda.graph(g3):
+    with _capture(g3):
         torch.add(x, 1.0, out=y)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

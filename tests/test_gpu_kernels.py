@@ -2,6 +2,7 @@
 (1) the golden vectors captured from the reference and (2) the CPU oracle on seeded
 inputs.  Bit-exact for codes / levels / u / lb / ub and for the single-payload decode;
 the R-payload mean is bit-exact too (same summation order), asserted at 0 ulp."""
+import contextlib
 import glob
 import os
 
@@ -10,6 +11,22 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def _capture(graph):
+    """torch.cuda.graph(graph) with the garbage collector held off: a CUDAGraph of an earlier test that the collector finalizes
+    INSIDE a capture raises in its destructor and takes the process down (see gq_amd.quantizers._capturing)."""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden")
@@ -755,7 +772,7 @@ def test_compress_and_decode_replay_from_a_hip_graph(nat):
         run(captured)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with _capture(graph):
         run(captured)
     for trial in range(3):
         x.copy_(torch.randn(M * 16, device=dev) * (10.0 ** -trial))

@@ -6,6 +6,8 @@ from argparse import Namespace
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gradient-quantization_amd"))
 import torch
+import gc
+gc.disable()      # (a CUDAGraph finalized by the collector INSIDE a stream capture takes the process down: gq_amd.quantizers._capturing)
 from gq_amd import native
 from gq_amd.compressors import NearestNeighborCompressor
 from gq_amd.quantizers import Quantizer

@@ -3,6 +3,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gradient-quantization_amd"))
 import torch
+import gc
+gc.disable()      # (a CUDAGraph finalized by the collector INSIDE a stream capture takes the process down: gq_amd.quantizers._capturing)
 from gq_amd import native
 from gq_amd.codebook import load_codebook
 from gq_amd.wire import HSQWire
