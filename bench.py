@@ -1160,7 +1160,7 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
                % (n, dd, qargs.k_bit, qargs.n_bit, ", error feedback" if args.ef else "", ", two-phase" if args.two_phase else "",
                   "BASELINE configs[2]; the README's hsq command" if (dd == 16 and qargs.n_bit == 6 and qargs.k_bit == 8) else "main.py:90-92's own defaults" if (dd == 32 and qargs.n_bit == 8 and qargs.k_bit == 8) else "a variant"))
         note = ("kernel_ms: HIP start/stop events attached to the encode's dispatch on %d %s; compress_ms = encode + "
-                "levels launches back to back after the timed region; the step itself is host-bound (per-parameter torch work)"
+                "levels launches back to back after the timed region; a replayed step is bound by its kernels (the host issues one in ~40 us), an eager one by the host"
                 % (len(armed), "eager steps run after the timed region (a replayed graph has no armed dispatch)" if args.graph
                    else "of the timed steps"))
     else:
@@ -1170,8 +1170,8 @@ def run_list(args, torch, np, dist, native, exchange, dev, rank, world, backend,
         match, metric = "qsgd_compress_batched4_kernel", "gradient elements quantized/sec (QSGD c_dim=128 n_bit=2, ResNet-50 list)"
         cfg = ("ResNet-50/CIFAR parameter list (161 tensors, %d elements) per rank, QSGD c_dim=128 n_bit=2 "
                "random=1 (BASELINE configs[4]), packed 4-bit wire, multi-tensor kernels" % n)
-        note = ("HIP events around 50 back-to-back launches after the timed region (the step itself is host-bound: "
-                "~0.09 ms of kernels in a ~0.15 ms step)")
+        note = ("HIP events around 50 back-to-back launches after the timed region (a replayed step is bound by its two kernels, "
+                "compress + decode-mean; an eager one by the host)")
     achieved = algo / (k_ms * 1e-3) / 1e9
     achieved_compress = algo / (cmp_ms * 1e-3) / 1e9
     traffic, traffic_source = traffic_for(args, world, args.workload, match, None)
