@@ -1,4 +1,6 @@
-// HSQ encode, K = 256, sub-dimension D = 8, 16 or 32: f16 matrix-core prefilter (ONE MFMA per chain and 16 dimensions) +
+// HSQ encode, K <= 256 (256 in the text below; round 6: fewer codewords as zero rows, K <= 32 / <= 64 on one / two of the eight
+// row blocks -- template parameter NRB), sub-dimension D = 8, 16 or 32 (12 / 24 as padded 16 / 32 -- DR): f16 matrix-core prefilter
+// (ONE MFMA per chain and 16 dimensions) +
 // exact f32 rescoring + deferred exact scans.  Same bits as the exact f32 kernel (hsq_encode.hip) in about a quarter of
 // its time.  Written for D = 16 (BASELINE's shape; the text below describes that instantiation); round 5 made D a template
 // parameter (main.py:90's default is --c-dim 32): a chain is KS = ceil(D / 16) MFMAs, D = 8 feeds zeros for the upper half
